@@ -1,0 +1,236 @@
+"""oracle/xq_oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes wrapper over oracle/libxq_oracle.so (the plain-C restatement of the
+reference's rules + MCTS).  Mirrors the string-level API of the reference's
+``cchess_alphazero/environment/static_env.py`` so tests can compare it 1:1 with
+the golden vectors generated from the reference (tests/golden/make_golden.py).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libxq_oracle.so")
+
+NSQ, NLABELS, MAXMOVES, NOMOVE = 90, 2086, 128, 0xFFFF
+INIT_STATE = 'rkemsmekr/9/1c5c1/p1p1p1p1p/9/9/P1P1P1P1P/1C5C1/9/RKEMSMEKR'
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(('.c', '.h'))]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libxq_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.xqo_init()
+        _sig(_lib)
+    return _lib
+
+
+def _sig(L):
+    i8p, u16p, u8p, f32p = (C.POINTER(C.c_int8), C.POINTER(C.c_uint16),
+                            C.POINTER(C.c_uint8), C.POINTER(C.c_float))
+    ip = C.POINTER(C.c_int)
+    L.xqo_label_from.argtypes = [C.c_int]; L.xqo_label_from.restype = C.c_int
+    L.xqo_label_to.argtypes = [C.c_int]; L.xqo_label_to.restype = C.c_int
+    L.xqo_label_of.argtypes = [C.c_int, C.c_int]; L.xqo_label_of.restype = C.c_int
+    L.xqo_label_str.argtypes = [C.c_int, C.c_char_p]
+    L.xqo_label_parse.argtypes = [C.c_char_p]; L.xqo_label_parse.restype = C.c_int
+    L.xqo_flip_label.argtypes = [C.c_int]; L.xqo_flip_label.restype = C.c_int
+    L.xqo_state_to_board.argtypes = [C.c_char_p, i8p]; L.xqo_state_to_board.restype = C.c_int
+    L.xqo_board_to_state.argtypes = [i8p, C.c_char_p]; L.xqo_board_to_state.restype = C.c_int
+    L.xqo_flip_board.argtypes = [i8p, i8p]
+    L.xqo_legal_moves.argtypes = [i8p, u16p]; L.xqo_legal_moves.restype = C.c_int
+    L.xqo_done.argtypes = [i8p, C.c_int, ip, ip, ip, ip]
+    L.xqo_step.argtypes = [i8p, C.c_int, i8p, ip]; L.xqo_step.restype = C.c_int
+    L.xqo_planes.argtypes = [i8p, f32p]
+    L.xqo_planes_hist.argtypes = [i8p, i8p, f32p]
+    L.xqo_will_check_or_catch.argtypes = [i8p, C.c_int]; L.xqo_will_check_or_catch.restype = C.c_int
+    L.xqo_be_catched.argtypes = [i8p, C.c_int]; L.xqo_be_catched.restype = C.c_int
+    L.xqo_has_attack_chessman.argtypes = [i8p]; L.xqo_has_attack_chessman.restype = C.c_int
+    L.xqo_batch_rules.argtypes = [i8p, C.c_int, u16p, u8p, i8p, i8p, u16p, u8p, f32p]
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+# ---- tables -----------------------------------------------------------------
+def labels():
+    L = lib()
+    out = []
+    buf = C.create_string_buffer(5)
+    for i in range(NLABELS):
+        L.xqo_label_str(i, buf)
+        out.append(buf.value.decode())
+    return out
+
+
+def label_tables():
+    """(from[2086], to[2086], label_of[90][90]) as numpy arrays."""
+    L = lib()
+    fr = np.array([L.xqo_label_from(i) for i in range(NLABELS)], dtype=np.uint8)
+    to = np.array([L.xqo_label_to(i) for i in range(NLABELS)], dtype=np.uint8)
+    lo = np.full((NSQ, NSQ), NOMOVE, dtype=np.uint16)
+    lo[fr, to] = np.arange(NLABELS, dtype=np.uint16)
+    return fr, to, lo
+
+
+def label_of_str(mv):
+    r = lib().xqo_label_parse(mv.encode())
+    if r < 0:
+        raise ValueError(f"not a label: {mv}")
+    return r
+
+
+def label_str(label):
+    buf = C.create_string_buffer(5)
+    lib().xqo_label_str(int(label), buf)
+    return buf.value.decode()
+
+
+def flip_move(mv):
+    return label_str(lib().xqo_flip_label(label_of_str(mv)))
+
+
+# ---- board-level API ----------------------------------------------------------
+def state_to_board(state):
+    b = np.zeros(NSQ, dtype=np.int8)
+    if lib().xqo_state_to_board(state.encode(), _p(b, C.c_int8)) != 0:
+        raise ValueError(f"bad state {state}")
+    return b
+
+
+def board_to_state(board):
+    board = np.ascontiguousarray(board, dtype=np.int8)
+    buf = C.create_string_buffer(128)
+    lib().xqo_board_to_state(_p(board, C.c_int8), buf)
+    return buf.value.decode()
+
+
+def flip_board(board):
+    board = np.ascontiguousarray(board, dtype=np.int8)
+    out = np.zeros(NSQ, dtype=np.int8)
+    lib().xqo_flip_board(_p(board, C.c_int8), _p(out, C.c_int8))
+    return out
+
+
+def legal_moves_board(board):
+    board = np.ascontiguousarray(board, dtype=np.int8)
+    mv = np.zeros(MAXMOVES, dtype=np.uint16)
+    n = lib().xqo_legal_moves(_p(board, C.c_int8), _p(mv, C.c_uint16))
+    assert n <= MAXMOVES
+    return mv[:n].copy()
+
+
+def done_board(board, need_check=False):
+    board = np.ascontiguousarray(board, dtype=np.int8)
+    o, v, f, c = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    lib().xqo_done(_p(board, C.c_int8), int(need_check), C.byref(o), C.byref(v), C.byref(f), C.byref(c))
+    return bool(o.value), v.value, f.value, bool(c.value)
+
+
+def step_board(board, label):
+    board = np.ascontiguousarray(board, dtype=np.int8)
+    out = np.zeros(NSQ, dtype=np.int8)
+    ne = C.c_int()
+    if lib().xqo_step(_p(board, C.c_int8), int(label), _p(out, C.c_int8), C.byref(ne)) != 0:
+        raise ValueError("No chessman in source square")
+    return out, bool(ne.value)
+
+
+def planes_board(board):
+    board = np.ascontiguousarray(board, dtype=np.int8)
+    pl = np.zeros((14, 10, 9), dtype=np.float32)
+    lib().xqo_planes(_p(board, C.c_int8), _p(pl, C.c_float))
+    return pl
+
+
+def batch_rules(boards, want_planes=True):
+    boards = np.ascontiguousarray(boards, dtype=np.int8).reshape(-1, NSQ)
+    n = boards.shape[0]
+    moves = np.zeros((n, MAXMOVES), dtype=np.uint16)
+    counts = np.zeros(n, dtype=np.uint8)
+    over = np.zeros(n, dtype=np.int8)
+    v = np.zeros(n, dtype=np.int8)
+    fm = np.zeros(n, dtype=np.uint16)
+    ck = np.zeros(n, dtype=np.uint8)
+    planes = np.zeros((n, 14, 10, 9), dtype=np.float32) if want_planes else None
+    lib().xqo_batch_rules(_p(boards, C.c_int8), n, _p(moves, C.c_uint16), _p(counts, C.c_uint8),
+                          _p(over, C.c_int8), _p(v, C.c_int8), _p(fm, C.c_uint16), _p(ck, C.c_uint8),
+                          _p(planes, C.c_float) if want_planes else None)
+    return dict(moves=moves, counts=counts, over=over, v=v, final_move=fm, check=ck, planes=planes)
+
+
+# ---- string-level API (same names/semantics as the reference's static_env) -----
+def get_legal_moves(state):
+    return [label_str(m) for m in legal_moves_board(state_to_board(state))]
+
+
+def done(state, need_check=False):
+    b = state_to_board(state)
+    o, v, f, c = done_board(b, need_check)
+    fm = None if f == NOMOVE else label_str(f)
+    if not (b == 7).any() or not (b == -7).any():
+        return (o, v, fm)          # the reference's early returns are 3-tuples (static_env.py:15-18)
+    return (o, v, fm, c) if need_check else (o, v, fm)
+
+
+def step(state, action):
+    out, _ = step_board(state_to_board(state), label_of_str(action))
+    return board_to_state(out)
+
+
+def new_step(state, action):
+    out, ne = step_board(state_to_board(state), label_of_str(action))
+    return board_to_state(out), ne
+
+
+def fliped_state(state):
+    return board_to_state(flip_board(state_to_board(state)))
+
+
+def state_to_planes(state):
+    return planes_board(state_to_board(state))
+
+
+def state_history_to_planes(state, history):
+    b = state_to_board(state)
+    pl = np.zeros((28, 10, 9), dtype=np.float32)
+    prev = None
+    if history and len(history) >= 5:
+        prev = state_to_board(history[-5])
+    lib().xqo_planes_hist(_p(b, C.c_int8), _p(prev, C.c_int8) if prev is not None else None,
+                          _p(pl, C.c_float))
+    return pl
+
+
+def will_check_or_catch(state, action):
+    r = lib().xqo_will_check_or_catch(_p(state_to_board(state), C.c_int8), label_of_str(action))
+    if r < 0:
+        raise ValueError("No chessman in source square")
+    return bool(r)
+
+
+def be_catched(state, action):
+    return bool(lib().xqo_be_catched(_p(state_to_board(state), C.c_int8), label_of_str(action)))
+
+
+def has_attack_chessman(state):
+    return bool(lib().xqo_has_attack_chessman(_p(state_to_board(state), C.c_int8)))
