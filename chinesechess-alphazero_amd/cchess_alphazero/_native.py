@@ -1,0 +1,200 @@
+"""ctypes binding of libczero.so (C-ABI in include/czero.h).
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible, every compute
+entry point raises.  Device memory, streams and process groups come from PyTorch (plumbing).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libczero.so")
+
+NSQ, NLABELS, MAXMOVES, NOMOVE = 90, 2086, 128, 0xFFFF
+F32, F16, BF16, U8 = 0, 1, 2, 3
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libczero.so; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} not found: build the HIP engine first "
+                f"(python chinesechess-alphazero_amd/build.py); there is no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+        if _lib.cz_version() != 1:
+            raise NativeError("libczero.so version mismatch")
+    return _lib
+
+
+def _declare(L):
+    vp, i32 = C.c_void_p, C.c_int
+    L.cz_version.restype = i32
+    L.cz_last_error.restype = C.c_char_p
+    L.cz_device_count.restype = i32
+    L.cz_label_tables.argtypes = [vp, vp]
+    L.cz_movegen.argtypes = [vp, i32, vp, vp, vp]
+    L.cz_done.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    L.cz_step.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.cz_encode.argtypes = [vp, i32, vp, i32, vp]
+    L.cz_check_or_catch.argtypes = [vp, vp, i32, vp, vp]
+    L.cz_be_catched.argtypes = [vp, vp, i32, vp, vp]
+    L.cz_has_attack.argtypes = [vp, i32, vp, vp]
+    L.cz_rules_fused.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    for name in ("cz_label_tables", "cz_movegen", "cz_done", "cz_step", "cz_encode", "cz_check_or_catch",
+                 "cz_be_catched", "cz_has_attack", "cz_rules_fused"):
+        getattr(L, name).restype = i32
+    if hasattr(L, "cz_search_create"):
+        from . import _native_search
+        _native_search.declare(L)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise NativeError(f"{what} failed ({rc}): {lib().cz_last_error().decode()}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available() or lib().cz_device_count() < 1:
+        raise NativeError("no MI355X visible: the engine has no CPU path")
+
+
+_tables = None
+
+
+def label_tables():
+    """(label_of[90,90] uint16, from[2086] uint8, to[2086] uint8) -- host copies of the engine tables."""
+    global _tables
+    if _tables is None:
+        lo = np.zeros(NSQ * NSQ, dtype=np.uint16)
+        ft = np.zeros(NLABELS, dtype=np.uint16)
+        check(lib().cz_label_tables(lo.ctypes.data, ft.ctypes.data), "cz_label_tables")
+        _tables = (lo.reshape(NSQ, NSQ), (ft >> 8).astype(np.uint8), (ft & 0xFF).astype(np.uint8))
+    return _tables
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype):
+    import torch
+    assert isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous() and t.dtype == dtype, \
+        (t.dtype, dtype, t.device)
+    return C.c_void_p(t.data_ptr())
+
+
+_TORCH_DT = None
+
+
+def torch_dtype(code):
+    import torch
+    return {F32: torch.float32, F16: torch.float16, BF16: torch.bfloat16, U8: torch.uint8}[code]
+
+
+# ---- batched rules on device tensors (boards: int8 [n, 90] on cuda) -------------------------
+def movegen(boards):
+    import torch
+    require_gpu()
+    n = boards.shape[0]
+    moves = torch.empty((n, MAXMOVES), dtype=torch.uint16, device=boards.device)
+    counts = torch.empty((n,), dtype=torch.uint8, device=boards.device)
+    check(lib().cz_movegen(_dev(boards, torch.int8), n, _dev(moves, torch.uint16), _dev(counts, torch.uint8),
+                           _stream()), "cz_movegen")
+    return moves, counts
+
+
+def done(boards, need_check=False):
+    import torch
+    require_gpu()
+    n = boards.shape[0]
+    dev = boards.device
+    over = torch.empty((n,), dtype=torch.int8, device=dev)
+    v = torch.empty((n,), dtype=torch.int8, device=dev)
+    fm = torch.empty((n,), dtype=torch.uint16, device=dev)
+    ck = torch.zeros((n,), dtype=torch.uint8, device=dev)
+    check(lib().cz_done(_dev(boards, torch.int8), n, int(need_check), _dev(over, torch.int8), _dev(v, torch.int8),
+                        _dev(fm, torch.uint16), _dev(ck, torch.uint8), _stream()), "cz_done")
+    return over, v, fm, ck
+
+
+def step(boards, moves):
+    import torch
+    require_gpu()
+    n = boards.shape[0]
+    out = torch.empty_like(boards)
+    ne = torch.empty((n,), dtype=torch.uint8, device=boards.device)
+    check(lib().cz_step(_dev(boards, torch.int8), _dev(moves, torch.uint16), n, _dev(out, torch.int8),
+                        _dev(ne, torch.uint8), _stream()), "cz_step")
+    return out, ne
+
+
+def encode(boards, dtype=F32):
+    import torch
+    require_gpu()
+    n = boards.shape[0]
+    planes = torch.empty((n, 14, 10, 9), dtype=torch_dtype(dtype), device=boards.device)
+    check(lib().cz_encode(_dev(boards, torch.int8), n, C.c_void_p(planes.data_ptr()), dtype, _stream()), "cz_encode")
+    return planes
+
+
+def check_or_catch(boards, moves):
+    import torch
+    require_gpu()
+    n = boards.shape[0]
+    out = torch.empty((n,), dtype=torch.uint8, device=boards.device)
+    check(lib().cz_check_or_catch(_dev(boards, torch.int8), _dev(moves, torch.uint16), n, _dev(out, torch.uint8),
+                                  _stream()), "cz_check_or_catch")
+    return out
+
+
+def be_catched(boards, moves):
+    import torch
+    require_gpu()
+    n = boards.shape[0]
+    out = torch.empty((n,), dtype=torch.uint8, device=boards.device)
+    check(lib().cz_be_catched(_dev(boards, torch.int8), _dev(moves, torch.uint16), n, _dev(out, torch.uint8),
+                              _stream()), "cz_be_catched")
+    return out
+
+
+def has_attack(boards):
+    import torch
+    require_gpu()
+    n = boards.shape[0]
+    out = torch.empty((n,), dtype=torch.uint8, device=boards.device)
+    check(lib().cz_has_attack(_dev(boards, torch.int8), n, _dev(out, torch.uint8), _stream()), "cz_has_attack")
+    return out
+
+
+def rules_fused(boards, dtype=F32, out=None):
+    """move-gen + done(need_check) + planes for a batch; returns a dict of device tensors."""
+    import torch
+    require_gpu()
+    n = boards.shape[0]
+    dev = boards.device
+    if out is None:
+        out = dict(moves=torch.empty((n, MAXMOVES), dtype=torch.uint16, device=dev),
+                   counts=torch.empty((n,), dtype=torch.uint8, device=dev),
+                   over=torch.empty((n,), dtype=torch.int8, device=dev),
+                   v=torch.empty((n,), dtype=torch.int8, device=dev),
+                   final_move=torch.empty((n,), dtype=torch.uint16, device=dev),
+                   check=torch.empty((n,), dtype=torch.uint8, device=dev),
+                   planes=torch.empty((n, 14, 10, 9), dtype=torch_dtype(dtype), device=dev))
+    check(lib().cz_rules_fused(_dev(boards, torch.int8), n, _dev(out["moves"], torch.uint16),
+                               _dev(out["counts"], torch.uint8), _dev(out["over"], torch.int8),
+                               _dev(out["v"], torch.int8), _dev(out["final_move"], torch.uint16),
+                               _dev(out["check"], torch.uint8), C.c_void_p(out["planes"].data_ptr()), dtype,
+                               _stream()), "cz_rules_fused")
+    return out

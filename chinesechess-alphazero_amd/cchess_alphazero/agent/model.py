@@ -1,0 +1,213 @@
+"""Policy/value ResNet -- the reference's ``CChessModel`` (cchess_alphazero/agent/model.py:32-83)
+re-expressed as a ``torch.nn.Module`` for PyTorch-ROCm.
+
+Topology (channels-first, Keras names in brackets): Conv5x5(F) [input_conv] -> BN -> ReLU ->
+N x [Conv3x3 -> BN -> ReLU -> Conv3x3 -> BN -> +skip -> ReLU] -> policy: Conv1x1(4) -> BN -> ReLU ->
+Flatten(C,H,W) -> Dense(2086) softmax; value: Conv1x1(2) -> BN -> ReLU -> Flatten -> Dense(256) ReLU ->
+Dense(1) tanh.  Convs have no bias; BN eps = 1e-3 (Keras default, data/model/*.json).
+
+The MFMA work of the engine lives here (MIOpen / hipBLASLt kernels); the tree and rule kernels are
+hand-written HIP (csrc/).  ``InferenceNet`` is the eval-mode form used by self-play: BN folded into
+the convolutions, channels_last, optional fp16/bf16, captured into a HIP graph.
+"""
+import hashlib
+import json
+import os
+from logging import getLogger
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+logger = getLogger(__name__)
+
+N_LABELS = 2086
+BN_EPS = 1e-3
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, filters, ksize):
+        super().__init__()
+        self.conv1 = nn.Conv2d(filters, filters, ksize, padding=ksize // 2, bias=False)
+        self.bn1 = nn.BatchNorm2d(filters, eps=BN_EPS, momentum=0.01)
+        self.conv2 = nn.Conv2d(filters, filters, ksize, padding=ksize // 2, bias=False)
+        self.bn2 = nn.BatchNorm2d(filters, eps=BN_EPS, momentum=0.01)
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return F.relu(x + y)
+
+
+class CChessNet(nn.Module):
+    """Trainable form (BatchNorm layers kept); mirrors CChessModel.build(), model.py:32-66."""
+
+    def __init__(self, cnn_filter_num=256, cnn_first_filter_size=5, cnn_filter_size=3, res_layer_num=7,
+                 value_fc_size=256, input_depth=14, policy_filters=4, value_filters=2):
+        super().__init__()
+        self.cfg = dict(cnn_filter_num=cnn_filter_num, cnn_first_filter_size=cnn_first_filter_size,
+                        cnn_filter_size=cnn_filter_size, res_layer_num=res_layer_num,
+                        value_fc_size=value_fc_size, input_depth=input_depth,
+                        policy_filters=policy_filters, value_filters=value_filters)
+        f = cnn_filter_num
+        self.input_conv = nn.Conv2d(input_depth, f, cnn_first_filter_size, padding=cnn_first_filter_size // 2,
+                                    bias=False)
+        self.input_bn = nn.BatchNorm2d(f, eps=BN_EPS, momentum=0.01)
+        self.res = nn.ModuleList([ResidualBlock(f, cnn_filter_size) for _ in range(res_layer_num)])
+        self.policy_conv = nn.Conv2d(f, policy_filters, 1, bias=False)
+        self.policy_bn = nn.BatchNorm2d(policy_filters, eps=BN_EPS, momentum=0.01)
+        self.policy_out = nn.Linear(policy_filters * 90, N_LABELS)
+        self.value_conv = nn.Conv2d(f, value_filters, 1, bias=False)
+        self.value_bn = nn.BatchNorm2d(value_filters, eps=BN_EPS, momentum=0.01)
+        self.value_dense = nn.Linear(value_filters * 90, value_fc_size)
+        self.value_out = nn.Linear(value_fc_size, 1)
+
+    def trunk(self, x):
+        x = F.relu(self.input_bn(self.input_conv(x)))
+        for blk in self.res:
+            x = blk(x)
+        return x
+
+    def forward(self, x):
+        x = self.trunk(x)
+        p = F.relu(self.policy_bn(self.policy_conv(x)))
+        p = self.policy_out(p.flatten(1))                      # Flatten order C,H,W (channels_first)
+        v = F.relu(self.value_bn(self.value_conv(x)))
+        v = F.relu(self.value_dense(v.flatten(1)))
+        v = torch.tanh(self.value_out(v))
+        return F.softmax(p, dim=1), v.squeeze(1)
+
+    @classmethod
+    def from_model_config(cls, mc):
+        """mc: the reference's ModelConfig object (configs/*.py)."""
+        return cls(cnn_filter_num=mc.cnn_filter_num, cnn_first_filter_size=mc.cnn_first_filter_size,
+                   cnn_filter_size=mc.cnn_filter_size, res_layer_num=mc.res_layer_num,
+                   value_fc_size=mc.value_fc_size, input_depth=getattr(mc, "input_depth", 14))
+
+
+def _fold(conv, bn):
+    """Fold an eval-mode BatchNorm into the preceding bias-free convolution."""
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    w = conv.weight * scale.view(-1, 1, 1, 1)
+    b = bn.bias - bn.running_mean * scale
+    out = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, padding=conv.padding, bias=True)
+    out.weight.data.copy_(w)
+    out.bias.data.copy_(b)
+    return out
+
+
+class InferenceNet(nn.Module):
+    """Eval-mode network for self-play: BN folded, channels_last, optional reduced precision.
+    Outputs are always fp32: softmax policy [B, 2086] and value [B]."""
+
+    def __init__(self, net: CChessNet, dtype=torch.float32):
+        super().__init__()
+        net = net.eval()
+        self.dtype = dtype
+        self.input_depth = net.cfg["input_depth"]
+        with torch.no_grad():
+            self.input_conv = _fold(net.input_conv, net.input_bn)
+            self.res = nn.ModuleList()
+            for blk in net.res:
+                self.res.append(nn.ModuleList([_fold(blk.conv1, blk.bn1), _fold(blk.conv2, blk.bn2)]))
+            self.policy_conv = _fold(net.policy_conv, net.policy_bn)
+            self.value_conv = _fold(net.value_conv, net.value_bn)
+            self.policy_out = nn.Linear(net.policy_out.in_features, N_LABELS)
+            self.value_dense = nn.Linear(net.value_dense.in_features, net.value_dense.out_features)
+            self.value_out = nn.Linear(net.value_out.in_features, 1)
+            self.policy_out.load_state_dict(net.policy_out.state_dict())
+            self.value_dense.load_state_dict(net.value_dense.state_dict())
+            self.value_out.load_state_dict(net.value_out.state_dict())
+        self.to(dtype)
+        self.to(memory_format=torch.channels_last)
+        self.eval()
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    @torch.no_grad()
+    def forward(self, planes):
+        x = planes.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        x = F.relu(self.input_conv(x))
+        for c1, c2 in self.res:
+            y = F.relu(c1(x))
+            x = F.relu(x + c2(y))
+        p = F.relu(self.policy_conv(x))
+        p = self.policy_out(p.flatten(1))                # flatten of an NCHW-shaped tensor: C,H,W order
+        v = F.relu(self.value_conv(x))
+        v = F.relu(self.value_dense(v.flatten(1)))
+        v = torch.tanh(self.value_out(v).float())
+        return F.softmax(p.float(), dim=1), v.squeeze(1)
+
+
+def flops_per_position(cfg):
+    """Multiply-accumulate based FLOPs (2*MAC) of one forward pass."""
+    f, k1, k, n = cfg["cnn_filter_num"], cfg["cnn_first_filter_size"], cfg["cnn_filter_size"], cfg["res_layer_num"]
+    mac = cfg["input_depth"] * f * k1 * k1 * 90 + 2 * n * f * f * k * k * 90
+    mac += f * cfg["policy_filters"] * 90 + cfg["policy_filters"] * 90 * N_LABELS
+    mac += f * cfg["value_filters"] * 90 + cfg["value_filters"] * 90 * cfg["value_fc_size"] + cfg["value_fc_size"]
+    return 2 * mac
+
+
+class CChessModel:
+    """The reference's model holder (agent/model.py): build / load / save / digest, torch-backed.
+    Weight files are torch state-dicts (``.pt``); the Keras ``.h5`` blobs of the reference are not
+    shipped (``.MISSING_LARGE_BLOBS``) and h5py is not available here."""
+
+    def __init__(self, config):
+        self.config = config
+        self.model = None           # CChessNet
+        self.digest = None
+        self.n_labels = N_LABELS
+        self.api = None
+
+    def build(self, seed=None):
+        if seed is not None:
+            torch.manual_seed(seed)
+        self.model = CChessNet.from_model_config(self.config.model)
+        return self.model
+
+    @staticmethod
+    def fetch_digest(weight_path):
+        if os.path.exists(weight_path):
+            m = hashlib.sha256()
+            with open(weight_path, "rb") as f:
+                m.update(f.read())
+            return m.hexdigest()
+        return None
+
+    @staticmethod
+    def _pt(path):
+        return os.path.splitext(path)[0] + ".pt"
+
+    def load(self, config_path, weight_path):
+        wp = self._pt(weight_path)
+        if os.path.exists(config_path) and os.path.exists(wp):
+            with open(config_path, "rt") as f:
+                cfg = json.load(f)
+            self.model = CChessNet(**cfg)
+            self.model.load_state_dict(torch.load(wp, map_location="cpu"))
+            self.digest = self.fetch_digest(wp)
+            logger.debug(f"loaded model digest = {self.digest}")
+            return True
+        logger.debug(f"model files does not exist at {config_path} and {wp}")
+        return False
+
+    def save(self, config_path, weight_path):
+        wp = self._pt(weight_path)
+        os.makedirs(os.path.dirname(config_path), exist_ok=True)
+        with open(config_path, "wt") as f:
+            json.dump(self.model.cfg, f)
+        torch.save(self.model.state_dict(), wp)
+        self.digest = self.fetch_digest(wp)
+
+    def get_pipes(self, num=1, api=None, need_reload=True):
+        from cchess_alphazero.agent.api import CChessModelAPI
+        if self.api is None:
+            self.api = CChessModelAPI(self.config, self)
+            self.api.start(need_reload)
+        return self.api.get_pipe(need_reload)
+
+    def close_pipes(self):
+        if self.api is not None:
+            self.api.close()
+            self.api = None

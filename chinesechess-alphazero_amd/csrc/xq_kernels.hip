@@ -1,0 +1,306 @@
+// xq_kernels.hip -- batched Xiangqi rule kernels for gfx950 + their C-ABI entry points.
+//
+// One wavefront per board (workgroup = 64 threads), grid-stride over the batch.  These are
+// the device replacements of the reference's per-position Python functions
+// (cchess_alphazero/environment/static_env.py); the C-ABI is declared in include/czero.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "xq_rules.h"
+#include "../../include/czero.h"
+
+using namespace xq;
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int set_err(const char* what, hipError_t e)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return CZ_ERR_HIP;
+}
+int set_err_msg(int code, const char* what)
+{
+    snprintf(g_err, sizeof(g_err), "%s", what);
+    return code;
+}
+
+inline int grid_for(int n)
+{
+    // 256 CUs x up to 32 single-wave workgroups; the rest is grid-stride
+    const int cap = 256 * 32;
+    return n < cap ? (n > 0 ? n : 1) : cap;
+}
+
+#define CZ_LAUNCH_CHECK(name)                                        \
+    do {                                                             \
+        hipError_t e_ = hipGetLastError();                           \
+        if (e_ != hipSuccess) return set_err(name, e_);              \
+    } while (0)
+
+// ---- kernels ------------------------------------------------------------------------
+
+__global__ __launch_bounds__(64) void k_movegen(const int8_t* __restrict__ boards, int n,
+                                               uint16_t* __restrict__ moves, uint8_t* __restrict__ counts)
+{
+    __shared__ RulesLDS w;
+    const int lane = lane_id();
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        load_board(boards + (size_t)i * NSQ, w.bd[0]);
+        const int c = wave_movegen(w.bd[0], w.ml[0]);
+        uint16_t* mo = moves + (size_t)i * MAXMOVES;
+        mo[lane] = lane < c ? w.ml[0].lab[lane] : NOMOVE;
+        mo[lane + 64] = lane + 64 < c ? w.ml[0].lab[lane + 64] : NOMOVE;
+        if (lane == 0) counts[i] = (uint8_t)(c < 255 ? c : 255);
+        wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_done(const int8_t* __restrict__ boards, int n, int need_check,
+                                            int8_t* __restrict__ over, int8_t* __restrict__ v,
+                                            uint16_t* __restrict__ final_move, uint8_t* __restrict__ check)
+{
+    __shared__ RulesLDS w;
+    const int lane = lane_id();
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        load_board(boards + (size_t)i * NSQ, w.bd[0]);
+        const DoneResult r = wave_done(w.bd[0], w.bd[1], w.ml[0], w.ml[1], need_check != 0);
+        if (lane == 0) {
+            over[i] = (int8_t)r.over;
+            v[i] = (int8_t)r.v;
+            final_move[i] = (uint16_t)r.final_move;
+            if (check) check[i] = (uint8_t)r.check;
+        }
+        wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_step(const int8_t* __restrict__ boards, const uint16_t* __restrict__ mv, int n,
+                                            int8_t* __restrict__ out, uint8_t* __restrict__ no_eat)
+{
+    __shared__ RulesLDS w;
+    const int lane = lane_id();
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        load_board(boards + (size_t)i * NSQ, w.bd[0]);
+        const int label = mv[i];
+        int code = 0xFF;                               // 0xFF: invalid label or empty source (ValueError)
+        if (label < NLABELS) {
+            const int ft = label_ft(label);
+            const int f = ft >> 8, t = ft & 0xFF;
+            if (w.bd[0][f] != 0) {
+                code = w.bd[0][t] == 0 ? 1 : 0;
+                step_board(w.bd[0], f, t, w.bd[1]);
+                store_board(w.bd[1], out + (size_t)i * NSQ);
+            }
+        }
+        if (code == 0xFF) store_board(w.bd[0], out + (size_t)i * NSQ);
+        if (lane == 0 && no_eat) no_eat[i] = (uint8_t)code;
+        wave_sync();
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(64) void k_encode(const int8_t* __restrict__ boards, int n, void* __restrict__ planes)
+{
+    __shared__ int8_t b[BOARD_LDS];
+    constexpr size_t esz = DT == 0 ? 4 : (DT == 3 ? 1 : 2);
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        load_board(boards + (size_t)i * NSQ, b);
+        wave_encode<DT>(b, (char*)planes + (size_t)i * 1260 * esz);
+        wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_check_or_catch(const int8_t* __restrict__ boards, const uint16_t* __restrict__ mv,
+                                                      int n, uint8_t* __restrict__ out)
+{
+    __shared__ RulesLDS w;
+    const int lane = lane_id();
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        load_board(boards + (size_t)i * NSQ, w.bd[0]);
+        const int label = mv[i];
+        int r = -1;
+        if (label < NLABELS) r = wave_will_check_or_catch(w, w.bd[0], label);
+        if (lane == 0) out[i] = (uint8_t)(r < 0 ? 0xFF : r);
+        wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_be_catched(const int8_t* __restrict__ boards, const uint16_t* __restrict__ mv,
+                                                  int n, uint8_t* __restrict__ out)
+{
+    __shared__ RulesLDS w;
+    const int lane = lane_id();
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        load_board(boards + (size_t)i * NSQ, w.bd[0]);
+        const int label = mv[i];
+        int r = 0xFF;
+        if (label < NLABELS) r = wave_be_catched(w.bd[0], label_ft(label) >> 8, w.bd[1], w.ml[0]);
+        if (lane == 0) out[i] = (uint8_t)r;
+        wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_has_attack(const int8_t* __restrict__ boards, int n, uint8_t* __restrict__ out)
+{
+    __shared__ int8_t b[BOARD_LDS];
+    const int lane = lane_id();
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        load_board(boards + (size_t)i * NSQ, b);
+        const int r = wave_has_attack(b);
+        if (lane == 0) out[i] = (uint8_t)r;
+        wave_sync();
+    }
+}
+
+// The micro-suite kernel of SURVEY 8(d): move-gen + done(need_check) + plane encode per board,
+// 90 B in, 256 + 1 + 5 + planes out.
+template <int DT>
+__global__ __launch_bounds__(64) void k_rules_fused(const int8_t* __restrict__ boards, int n,
+                                                   uint16_t* __restrict__ moves, uint8_t* __restrict__ counts,
+                                                   int8_t* __restrict__ over, int8_t* __restrict__ v,
+                                                   uint16_t* __restrict__ final_move, uint8_t* __restrict__ check,
+                                                   void* __restrict__ planes)
+{
+    __shared__ RulesLDS w;
+    constexpr size_t esz = DT == 0 ? 4 : (DT == 3 ? 1 : 2);
+    const int lane = lane_id();
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        load_board(boards + (size_t)i * NSQ, w.bd[0]);
+        wave_encode<DT>(w.bd[0], (char*)planes + (size_t)i * 1260 * esz);
+        DoneResult r = wave_done(w.bd[0], w.bd[1], w.ml[0], w.ml[1], true);
+        int c = r.nmoves;
+        if (c < 0) c = wave_movegen(w.bd[0], w.ml[0]);       // early-decided positions still report their list
+        uint16_t* mo = moves + (size_t)i * MAXMOVES;
+        mo[lane] = lane < c ? w.ml[0].lab[lane] : NOMOVE;
+        mo[lane + 64] = lane + 64 < c ? w.ml[0].lab[lane + 64] : NOMOVE;
+        if (lane == 0) {
+            counts[i] = (uint8_t)(c < 255 ? c : 255);
+            over[i] = (int8_t)r.over;
+            v[i] = (int8_t)r.v;
+            final_move[i] = (uint16_t)r.final_move;
+            check[i] = (uint8_t)r.check;
+        }
+        wave_sync();
+    }
+}
+
+}  // namespace
+
+// ---- C-ABI ----------------------------------------------------------------------------
+extern "C" {
+
+int cz_version(void) { return CZ_VERSION; }
+
+const char* cz_last_error(void) { return g_err; }
+
+int cz_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int cz_label_tables(uint16_t* label_of, uint16_t* lab_ft)
+{
+    if (label_of) memcpy(label_of, h_tab.label_of, sizeof(uint16_t) * NSQ * NSQ);
+    if (lab_ft) memcpy(lab_ft, h_tab.lab_ft, sizeof(uint16_t) * NLABELS);
+    return CZ_OK;
+}
+
+int cz_movegen(const int8_t* boards, int n, uint16_t* moves, uint8_t* counts, void* stream)
+{
+    if (n < 0 || !boards || !moves || !counts) return set_err_msg(CZ_ERR_ARG, "cz_movegen: bad argument");
+    if (n == 0) return CZ_OK;
+    hipLaunchKernelGGL(k_movegen, dim3(grid_for(n)), dim3(64), 0, (hipStream_t)stream, boards, n, moves, counts);
+    CZ_LAUNCH_CHECK("cz_movegen");
+    return CZ_OK;
+}
+
+int cz_done(const int8_t* boards, int n, int need_check, int8_t* over, int8_t* v, uint16_t* final_move,
+            uint8_t* check, void* stream)
+{
+    if (n < 0 || !boards || !over || !v || !final_move || (need_check && !check))
+        return set_err_msg(CZ_ERR_ARG, "cz_done: bad argument");
+    if (n == 0) return CZ_OK;
+    hipLaunchKernelGGL(k_done, dim3(grid_for(n)), dim3(64), 0, (hipStream_t)stream, boards, n, need_check, over, v,
+                       final_move, check);
+    CZ_LAUNCH_CHECK("cz_done");
+    return CZ_OK;
+}
+
+int cz_step(const int8_t* boards, const uint16_t* moves, int n, int8_t* out, uint8_t* no_eat, void* stream)
+{
+    if (n < 0 || !boards || !moves || !out) return set_err_msg(CZ_ERR_ARG, "cz_step: bad argument");
+    if (n == 0) return CZ_OK;
+    hipLaunchKernelGGL(k_step, dim3(grid_for(n)), dim3(64), 0, (hipStream_t)stream, boards, moves, n, out, no_eat);
+    CZ_LAUNCH_CHECK("cz_step");
+    return CZ_OK;
+}
+
+int cz_encode(const int8_t* boards, int n, void* planes, int dtype, void* stream)
+{
+    if (n < 0 || !boards || !planes) return set_err_msg(CZ_ERR_ARG, "cz_encode: bad argument");
+    if (n == 0) return CZ_OK;
+    const dim3 g(grid_for(n)), b(64);
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+    case CZ_F32: hipLaunchKernelGGL(k_encode<0>, g, b, 0, s, boards, n, planes); break;
+    case CZ_F16: hipLaunchKernelGGL(k_encode<1>, g, b, 0, s, boards, n, planes); break;
+    case CZ_BF16: hipLaunchKernelGGL(k_encode<2>, g, b, 0, s, boards, n, planes); break;
+    case CZ_U8: hipLaunchKernelGGL(k_encode<3>, g, b, 0, s, boards, n, planes); break;
+    default: return set_err_msg(CZ_ERR_ARG, "cz_encode: unknown dtype");
+    }
+    CZ_LAUNCH_CHECK("cz_encode");
+    return CZ_OK;
+}
+
+int cz_check_or_catch(const int8_t* boards, const uint16_t* moves, int n, uint8_t* out, void* stream)
+{
+    if (n < 0 || !boards || !moves || !out) return set_err_msg(CZ_ERR_ARG, "cz_check_or_catch: bad argument");
+    if (n == 0) return CZ_OK;
+    hipLaunchKernelGGL(k_check_or_catch, dim3(grid_for(n)), dim3(64), 0, (hipStream_t)stream, boards, moves, n, out);
+    CZ_LAUNCH_CHECK("cz_check_or_catch");
+    return CZ_OK;
+}
+
+int cz_be_catched(const int8_t* boards, const uint16_t* moves, int n, uint8_t* out, void* stream)
+{
+    if (n < 0 || !boards || !moves || !out) return set_err_msg(CZ_ERR_ARG, "cz_be_catched: bad argument");
+    if (n == 0) return CZ_OK;
+    hipLaunchKernelGGL(k_be_catched, dim3(grid_for(n)), dim3(64), 0, (hipStream_t)stream, boards, moves, n, out);
+    CZ_LAUNCH_CHECK("cz_be_catched");
+    return CZ_OK;
+}
+
+int cz_has_attack(const int8_t* boards, int n, uint8_t* out, void* stream)
+{
+    if (n < 0 || !boards || !out) return set_err_msg(CZ_ERR_ARG, "cz_has_attack: bad argument");
+    if (n == 0) return CZ_OK;
+    hipLaunchKernelGGL(k_has_attack, dim3(grid_for(n)), dim3(64), 0, (hipStream_t)stream, boards, n, out);
+    CZ_LAUNCH_CHECK("cz_has_attack");
+    return CZ_OK;
+}
+
+int cz_rules_fused(const int8_t* boards, int n, uint16_t* moves, uint8_t* counts, int8_t* over, int8_t* v,
+                   uint16_t* final_move, uint8_t* check, void* planes, int dtype, void* stream)
+{
+    if (n < 0 || !boards || !moves || !counts || !over || !v || !final_move || !check || !planes)
+        return set_err_msg(CZ_ERR_ARG, "cz_rules_fused: bad argument");
+    if (n == 0) return CZ_OK;
+    const dim3 g(grid_for(n)), b(64);
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+    case CZ_F32: hipLaunchKernelGGL(k_rules_fused<0>, g, b, 0, s, boards, n, moves, counts, over, v, final_move, check, planes); break;
+    case CZ_F16: hipLaunchKernelGGL(k_rules_fused<1>, g, b, 0, s, boards, n, moves, counts, over, v, final_move, check, planes); break;
+    case CZ_BF16: hipLaunchKernelGGL(k_rules_fused<2>, g, b, 0, s, boards, n, moves, counts, over, v, final_move, check, planes); break;
+    case CZ_U8: hipLaunchKernelGGL(k_rules_fused<3>, g, b, 0, s, boards, n, moves, counts, over, v, final_move, check, planes); break;
+    default: return set_err_msg(CZ_ERR_ARG, "cz_rules_fused: unknown dtype");
+    }
+    CZ_LAUNCH_CHECK("cz_rules_fused");
+    return CZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,305 @@
+// xq_rules.h -- wave-cooperative Xiangqi rules for gfx950 (device only).
+//
+// Execution model: ONE 64-lane wavefront per board (workgroup = 64 threads), the board and
+// the ordered move lists staged in that wave's LDS.  Lane l owns squares l and l+64; the
+// reference's move ORDER (static_env.py:256-321: squares y-major/x-minor, per-piece direction
+// order) is kept by a two-pass ordered compaction: count per square -> wave prefix sum ->
+// emit at the square's offset.  Terminal detection, check detection and the perpetual
+// check/chase helpers are ballots over those lists.
+//
+// `__syncthreads()` below is a single-wave barrier (workgroup size 64): it orders LDS
+// traffic between lanes and costs no s_barrier round-trip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "xq_lane.h"
+
+namespace xq {
+
+constexpr int BOARD_LDS = 96;   // 90 squares padded to a multiple of 16 B
+
+struct MoveList {               // ordered move list in LDS
+    uint16_t lab[MAXMOVES];     // label index
+    uint16_t ft[MAXMOVES];      // from << 8 | to
+};
+
+// Per-wave LDS scratch for the rules (about 2.6 KB).
+struct RulesLDS {
+    int8_t bd[4][BOARD_LDS];    // 0: position, 1..3: derived boards (flip / step / nested step)
+    MoveList ml[3];
+    uint32_t cset[2][MAXMOVES]; // chase sets of will_check_or_catch
+};
+
+XQ_D int lane_id() { return (int)(threadIdx.x & 63u); }
+XQ_D void wave_sync() { __syncthreads(); }
+
+XQ_D int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+XQ_D int highest_bit(uint64_t lo, uint64_t hi)   // index over the 128-bit (lo: 0..63, hi: 64..127), -1 if none
+{
+    if (hi) return 64 + 63 - __clzll((long long)hi);
+    if (lo) return 63 - __clzll((long long)lo);
+    return -1;
+}
+XQ_D int lowest_bit(uint64_t lo, uint64_t hi)
+{
+    if (lo) return __ffsll((long long)lo) - 1;
+    if (hi) return 64 + __ffsll((long long)hi) - 1;
+    return -1;
+}
+
+// Load one int8[90] board from global memory into LDS (2-byte loads: 90*i is even).
+XQ_D void load_board(const int8_t* __restrict__ g, int8_t* b)
+{
+    const int lane = lane_id();
+    if (lane < 45) {
+        const uint16_t w = reinterpret_cast<const uint16_t*>(g)[lane];
+        reinterpret_cast<uint16_t*>(b)[lane] = w;
+    }
+    if (lane >= 45 && lane < 48) reinterpret_cast<uint16_t*>(b)[lane] = 0;
+    wave_sync();
+}
+
+XQ_D void store_board(const int8_t* b, int8_t* __restrict__ g)
+{
+    const int lane = lane_id();
+    if (lane < 45) reinterpret_cast<uint16_t*>(g)[lane] = reinterpret_cast<const uint16_t*>(b)[lane];
+}
+
+// fliped_state (static_env.py:245-254): out[89-s] = -in[s]
+XQ_D void flip_board(const int8_t* in, int8_t* out)
+{
+    const int lane = lane_id();
+    out[89 - lane] = (int8_t)(-in[lane]);
+    if (lane < 26) out[25 - lane] = (int8_t)(-in[lane + 64]);
+    wave_sync();
+}
+
+// step (static_env.py:79-86): move the piece, then flip.  Caller checked in[from] != 0.
+XQ_D void step_board(const int8_t* in, int from, int to, int8_t* out)
+{
+    const int lane = lane_id();
+    {
+        int p = in[lane];
+        if (lane == to) p = in[from];
+        if (lane == from) p = 0;
+        out[89 - lane] = (int8_t)(-p);
+    }
+    if (lane < 26) {
+        const int s = lane + 64;
+        int p = in[s];
+        if (s == to) p = in[from];
+        if (s == from) p = 0;
+        out[89 - s] = (int8_t)(-p);
+    }
+    wave_sync();
+}
+
+// The position after `from->to` WITHOUT the perspective flip (== fliped_state(step(.)))
+XQ_D void apply_move_noflip(const int8_t* in, int from, int to, int8_t* out)
+{
+    const int lane = lane_id();
+    {
+        int p = in[lane];
+        if (lane == to) p = in[from];
+        if (lane == from) p = 0;
+        out[lane] = (int8_t)p;
+    }
+    if (lane < 26) {
+        const int s = lane + 64;
+        int p = in[s];
+        if (s == to) p = in[from];
+        if (s == from) p = 0;
+        out[s] = (int8_t)p;
+    }
+    wave_sync();
+}
+
+// get_legal_moves (static_env.py:256-321).  Returns the move count (may exceed MAXMOVES only
+// for impossible boards; entries beyond MAXMOVES are dropped).  Board must be visible in LDS.
+XQ_D int wave_movegen(const int8_t* b, MoveList& ml)
+{
+    const int lane = lane_id();
+    const int c0 = gen_sq<false>(b, lane, nullptr, nullptr, 0);
+    const int c1 = (lane < 26) ? gen_sq<false>(b, lane + 64, nullptr, nullptr, 0) : 0;
+    const int i0 = wave_incl_scan(c0, lane);
+    const int i1 = wave_incl_scan(c1, lane);
+    const int t0 = __shfl(i0, 63, 64);
+    const int t1 = __shfl(i1, 63, 64);
+    wave_sync();                                  // earlier readers of `ml` are done
+    if (c0) gen_sq<true>(b, lane, ml.lab, ml.ft, i0 - c0);
+    if (c1) gen_sq<true>(b, lane + 64, ml.lab, ml.ft, t0 + i1 - c1);
+    wave_sync();
+    return t0 + t1;
+}
+
+// index of the first move in ml[0..n) whose destination is `sq`, or -1
+XQ_D int first_move_to(const MoveList& ml, int n, int sq)
+{
+    const int lane = lane_id();
+    n = n < MAXMOVES ? n : MAXMOVES;
+    const uint64_t m0 = __ballot(lane < n && (ml.ft[lane] & 0xFF) == sq);
+    const uint64_t m1 = __ballot(lane + 64 < n && (ml.ft[lane + 64] & 0xFF) == sq);
+    return lowest_bit(m0, m1);
+}
+
+struct DoneResult {
+    int over;        // 0/1
+    int v;           // value for the side to move
+    int final_move;  // label of the first king-capturing move, NOMOVE when None
+    int check;       // only with need_check
+    int nmoves;      // >= 0: ml0 holds the position's ordered move list; -1: not generated
+};
+
+// done (static_env.py:14-77).  b: position; tmpb: scratch board; ml0: receives the move list of b
+// (when the early tests did not decide); ml1: scratch list for the need_check pass.
+XQ_D DoneResult wave_done(const int8_t* b, int8_t* tmpb, MoveList& ml0, MoveList& ml1, bool need_check)
+{
+    const int lane = lane_id();
+    DoneResult r{0, 0, NOMOVE, 0, -1};
+    const int p0 = b[lane];
+    const int p1 = (lane < 26) ? b[lane + 64] : 0;
+    const uint64_t ok0 = __ballot(p0 == -KING), ok1 = __ballot(p1 == -KING);
+    const uint64_t mk0 = __ballot(p0 == KING), mk1 = __ballot(p1 == KING);
+    if (!(ok0 | ok1)) { r.over = 1; r.v = 1; return r; }       // 's' not in state
+    if (!(mk0 | mk1)) { r.over = 1; r.v = -1; return r; }      // 'S' not in state
+    const int rk = highest_bit(mk0, mk1), bk = highest_bit(ok0, ok1);   // scan order: last one wins
+    const int rx = rk % 9, ry = rk / 9, bx = bk % 9, by = bk / 9;
+    int winner = 0;
+    if (ry == 0 && rx == 0) { winner = 2; r.v = -1; }          // dead branches kept, :33-38
+    else if (by == 0 && bx == 0) { winner = 1; r.v = 1; }
+    else if (rx == bx) {                                       // kings on one file, :39-49
+        const int x0 = lane % 9, y0 = lane / 9;
+        const int s1 = lane + 64, x1 = s1 % 9, y1 = s1 / 9;
+        const bool blk0 = (x0 == rx && y0 > ry && y0 < by && p0 != 0);
+        const bool blk1 = (lane < 26 && x1 == rx && y1 > ry && y1 < by && p1 != 0);
+        if (!__ballot(blk0 || blk1)) { r.v = 1; winner = 1; }
+    }
+    if (!winner) {                                             // :52-60
+        const int n = wave_movegen(b, ml0);
+        r.nmoves = n;
+        const int k = first_move_to(ml0, n, bk);
+        if (k >= 0) { winner = 1; r.v = 1; r.final_move = ml0.lab[k]; }
+    }
+    if (!winner && need_check) {                               // :61-73
+        flip_board(b, tmpb);
+        const int n2 = wave_movegen(tmpb, ml1);
+        r.check = first_move_to(ml1, n2, 89 - rk) >= 0;
+    }
+    r.over = winner != 0;
+    return r;
+}
+
+// has_attack_chessman (static_env.py:471-479): any rook / knight / pawn / cannon of either side
+XQ_D int wave_has_attack(const int8_t* b)
+{
+    const int lane = lane_id();
+    int t0 = b[lane]; t0 = t0 < 0 ? -t0 : t0;
+    int t1 = (lane < 26) ? b[lane + 64] : 0; t1 = t1 < 0 ? -t1 : t1;
+    const bool a0 = (t0 == ROOK || t0 == KNIGHT || t0 == PAWN || t0 == CANNON);
+    const bool a1 = (t1 == ROOK || t1 == KNIGHT || t1 == PAWN || t1 == CANNON);
+    return __ballot(a0 || a1) != 0;
+}
+
+// be_catched (static_env.py:456-469): is the square the move starts from attacked right now
+XQ_D int wave_be_catched(const int8_t* b, int from, int8_t* tmpb, MoveList& ml)
+{
+    flip_board(b, tmpb);
+    const int n = wave_movegen(tmpb, ml);
+    return first_move_to(ml, n, 89 - from) >= 0;
+}
+
+// get_catch_list (static_env.py:423-454) over a given ordered move list.  Keys:
+// attacker type << 24 | from << 16 | victim type << 8 | to.  Returns the set size.
+XQ_D int wave_catch_list(const int8_t* b, const MoveList& moves, int nmoves,
+                         int8_t* nextb, MoveList& reply, uint32_t* set)
+{
+    const int lane = lane_id();
+    int cnt = 0;
+    nmoves = nmoves < MAXMOVES ? nmoves : MAXMOVES;
+    for (int k = 0; k < nmoves; ++k) {
+        const int ft = moves.ft[k];
+        const int f = ft >> 8, t = ft & 0xFF;
+        const int vict = b[t];
+        if (vict == 0) continue;                               // no capture
+        step_board(b, f, t, nextb);
+        const int nr = wave_movegen(nextb, reply);
+        if (first_move_to(reply, nr, 89 - t) >= 0) continue;   // could be recaptured
+        const int a = b[f];
+        if (a == PAWN && f / 9 <= 4) continue;                 // :443-444
+        if (vict == -PAWN && t / 9 > 4) continue;              // :447-448
+        if (-vict == a) continue;                              // exchange, :450-451
+        const uint32_t key = ((uint32_t)a << 24) | ((uint32_t)f << 16) | ((uint32_t)(-vict) << 8) | (uint32_t)t;
+        const bool dup0 = lane < cnt && set[lane] == key;
+        const bool dup1 = lane + 64 < cnt && set[lane + 64] == key;
+        if (!__ballot(dup0 || dup1)) {
+            if (lane == 0) set[cnt] = key;
+            ++cnt;
+        }
+        wave_sync();
+    }
+    return cnt;
+}
+
+// will_check_or_catch (static_env.py:390-421).  b is RulesLDS::bd[0]; returns -1 when the move's
+// source square is empty (the reference raises ValueError).
+XQ_D int wave_will_check_or_catch(RulesLDS& w, const int8_t* b, int label)
+{
+    const int lane = lane_id();
+    const int ft = label_ft(label);
+    const int f = ft >> 8, t = ft & 0xFF;
+    if (b[f] == 0) return -1;
+    int8_t* black = w.bd[1];
+    apply_move_noflip(b, f, t, black);            // == fliped_state(step(ori_state, action))
+    // the opponent's king as `state` sees it: last 'k' in scan order of `state` == lowest square here
+    const int q0 = black[lane], q1 = (lane < 26) ? black[lane + 64] : 0;
+    const int ksq = lowest_bit(__ballot(q0 == -KING), __ballot(q1 == -KING));
+    const int target = ksq >= 0 ? ksq : 89;       // red_k stays [0,0] -> (9,8) when the king is gone
+    const int nb = wave_movegen(black, w.ml[0]);
+    if (first_move_to(w.ml[0], nb, target) >= 0) return 1;                        // :406-411
+    const int n1 = wave_movegen(b, w.ml[1]);
+    const int c1 = wave_catch_list(b, w.ml[1], n1, w.bd[2], w.ml[2], w.cset[0]);  // first_set
+    const int c2 = wave_catch_list(black, w.ml[0], nb, w.bd[2], w.ml[2], w.cset[1]);
+    // second_set - first_set != {} and len(second_set) >= len(first_set), :415
+    bool fresh = false;
+    for (int i = 0; i < c2; ++i) {
+        const uint32_t key = w.cset[1][i];
+        const bool in0 = lane < c1 && w.cset[0][lane] == key;
+        const bool in1 = lane + 64 < c1 && w.cset[0][lane + 64] == key;
+        if (!__ballot(in0 || in1)) { fresh = true; break; }
+    }
+    return (fresh && c2 >= c1) ? 1 : 0;
+}
+
+// state_to_planes (static_env.py:137-156) for one board, written as 315 chunks of 4 elements.
+// DT: 0 = f32, 1 = f16, 2 = bf16, 3 = u8.  0/1 are exact in every format.
+template <int DT>
+XQ_D void wave_encode(const int8_t* b, void* __restrict__ out)
+{
+    const int lane = lane_id();
+    for (int q = lane; q < 315; q += 64) {
+        const int o = q * 4;
+        const int b0 = plane_bit(b, o), b1 = plane_bit(b, o + 1), b2 = plane_bit(b, o + 2), b3 = plane_bit(b, o + 3);
+        if (DT == 0) {
+            float4 v = make_float4((float)b0, (float)b1, (float)b2, (float)b3);
+            reinterpret_cast<float4*>(out)[q] = v;
+        } else if (DT == 1 || DT == 2) {
+            const uint32_t one = (DT == 1) ? 0x3C00u : 0x3F80u;    // 1.0 in f16 / bf16
+            uint2 v;
+            v.x = (b0 ? one : 0u) | ((b1 ? one : 0u) << 16);
+            v.y = (b2 ? one : 0u) | ((b3 ? one : 0u) << 16);
+            reinterpret_cast<uint2*>(out)[q] = v;
+        } else {
+            reinterpret_cast<uint32_t*>(out)[q] = (uint32_t)b0 | ((uint32_t)b1 << 8) | ((uint32_t)b2 << 16) | ((uint32_t)b3 << 24);
+        }
+    }
+}
+
+}  // namespace xq

@@ -1,0 +1,44 @@
+// tests/lane_harness.cpp -- CPU harness for the per-lane rule functions of the HIP engine
+// (chinesechess-alphazero_amd/csrc/xq_lane.h).  Built with g++ by tests/test_lane_cpu.py; it
+// emulates the wave-level ordered compaction with plain loops so the per-square logic and the
+// constexpr tables can be checked against the oracle without a GPU.
+#include <stdint.h>
+#include <string.h>
+#include "../chinesechess-alphazero_amd/csrc/xq_lane.h"
+
+using namespace xq;
+
+extern "C" {
+
+int lane_movegen(const int8_t* board, uint16_t* lab, uint16_t* ft)
+{
+    int counts[NSQ], total = 0;
+    for (int s = 0; s < NSQ; ++s) counts[s] = gen_sq<false>(board, s, nullptr, nullptr, 0);
+    int off = 0;
+    for (int s = 0; s < NSQ; ++s) {           // exclusive prefix sum in square order
+        if (counts[s]) gen_sq<true>(board, s, lab, ft, off);
+        off += counts[s];
+    }
+    total = off;
+    return total;
+}
+
+void lane_planes(const int8_t* board, float* planes)
+{
+    for (int o = 0; o < 1260; ++o) planes[o] = (float)plane_bit(board, o);
+}
+
+void lane_tables(uint16_t* label_of_out, uint16_t* lab_ft_out)
+{
+    memcpy(label_of_out, h_tab.label_of, sizeof(uint16_t) * NSQ * NSQ);
+    memcpy(lab_ft_out, h_tab.lab_ft, sizeof(uint16_t) * NLABELS);
+}
+
+int lane_nibble_roundtrip(void)
+{
+    for (int p = -7; p <= 7; ++p)
+        if (piece_of_nib(nib_of(p)) != p || nib_of(p) > 15) return 0;
+    return 1;
+}
+
+}

@@ -1,0 +1,194 @@
+"""-m gpu: the HIP rule kernels (through the C-ABI) against the oracle and the golden vectors.
+Bit-exact: move lists (order included), terminal/check flags, planes, step results."""
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import xq_oracle as xo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    import torch
+    from cchess_alphazero import _native
+    _native.require_gpu()
+    return _native, torch
+
+
+def _boards(states):
+    return np.stack([xo.state_to_board(s) for s in states])
+
+
+def _labels(moves_row, count):
+    return " ".join(xo.label_str(int(m)) for m in moves_row[:count])
+
+
+def test_golden_suite_fused(nat, positions_1k):
+    N, torch = nat
+    boards = _boards([r["state"] for r in positions_1k])
+    out = N.rules_fused(torch.from_numpy(boards).cuda(), N.F32)
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    for i, r in enumerate(positions_1k):
+        assert _labels(o["moves"][i], o["counts"][i]) == r["moves"], r["state"]
+        assert (o["moves"][i, o["counts"][i]:] == 0xFFFF).all()
+        d = r["done"]
+        assert bool(o["over"][i]) == d[0] and int(o["v"][i]) == d[1], r["state"]
+        fm = None if o["final_move"][i] == 0xFFFF else xo.label_str(int(o["final_move"][i]))
+        assert fm == d[2]
+        if len(d) > 3:
+            assert bool(o["check"][i]) == d[3]
+        assert zlib.crc32(o["planes"][i].tobytes()) & 0xFFFFFFFF == r["planes_crc"]
+
+
+def test_separate_kernels_match_fused(nat, positions_1k):
+    N, torch = nat
+    boards = torch.from_numpy(_boards([r["state"] for r in positions_1k])).cuda()
+    f = N.rules_fused(boards, N.F32)
+    mv, ct = N.movegen(boards)
+    assert torch.equal(mv.view(torch.int16), f["moves"].view(torch.int16)) and torch.equal(ct, f["counts"])
+    over, v, fm, ck = N.done(boards, need_check=True)
+    assert torch.equal(over, f["over"]) and torch.equal(v, f["v"]) and torch.equal(ck, f["check"])
+    assert torch.equal(fm.view(torch.int16), f["final_move"].view(torch.int16))
+    over2, v2, fm2, _ = N.done(boards, need_check=False)
+    assert torch.equal(over2, over) and torch.equal(v2, v)
+    ha = N.has_attack(boards).cpu().numpy()
+    for i, r in enumerate(positions_1k):
+        assert bool(ha[i]) == r["has_attack"]
+    p32 = N.encode(boards, N.F32)
+    assert torch.equal(p32, f["planes"])
+    for code in (N.F16, N.BF16, N.U8):
+        assert torch.equal(N.encode(boards, code).float(), p32)
+
+
+def test_step_all_moves(nat, positions_1k):
+    N, torch = nat
+    bl, ml, idx = [], [], []
+    for i, r in enumerate(positions_1k):
+        b = xo.state_to_board(r["state"])
+        for m in r["moves"].split():
+            bl.append(b)
+            ml.append(xo.label_of_str(m))
+            idx.append(i)
+    boards = torch.from_numpy(np.stack(bl)).cuda()
+    moves = torch.tensor(ml, dtype=torch.int32).to(torch.uint16).cuda()
+    out, ne = N.step(boards, moves)
+    out, ne = out.cpu().numpy(), ne.cpu().numpy()
+    k = 0
+    for i, r in enumerate(positions_1k):
+        mv = r["moves"].split()
+        steps = [xo.board_to_state(out[k + j]) for j in range(len(mv))]
+        bits = "".join("1" if ne[k + j] == 1 else "0" for j in range(len(mv)))
+        assert zlib.crc32("\n".join(steps).encode()) & 0xFFFFFFFF == r["step_crc"], r["state"]
+        assert bits == r["no_eat"]
+        k += len(mv)
+    # empty source square -> 0xFF (the reference raises ValueError), board unchanged
+    b0 = torch.from_numpy(xo.state_to_board(xo.INIT_STATE)[None]).cuda()
+    bad = torch.tensor([xo.label_of_str('4445')], dtype=torch.int32).to(torch.uint16).cuda()
+    o2, n2 = N.step(b0, bad)
+    assert int(n2.cpu()[0]) == 0xFF and torch.equal(o2, b0)
+
+
+def test_check_or_catch_golden(nat, catch_cases):
+    N, torch = nat
+    boards = torch.from_numpy(_boards([c["state"] for c in catch_cases])).cuda()
+    moves = torch.tensor([xo.label_of_str(c["move"]) for c in catch_cases], dtype=torch.int32).to(torch.uint16).cuda()
+    w = N.check_or_catch(boards, moves).cpu().numpy()
+    b = N.be_catched(boards, moves).cpu().numpy()
+    for i, c in enumerate(catch_cases):
+        assert bool(w[i]) == c["wcc"], c
+        assert bool(b[i]) == c["bc"], c
+
+
+def _random_boards(n_games, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_games):
+        b = xo.state_to_board(xo.INIT_STATE)
+        for _ply in range(160):
+            out.append(b)
+            if xo.done_board(b)[0]:
+                break
+            mv = xo.legal_moves_board(b)
+            b, _ = xo.step_board(b, int(mv[rng.integers(len(mv))]))
+    return np.stack(out)
+
+
+def test_random_playouts_vs_oracle(nat):
+    N, torch = nat
+    boards = _random_boards(150, 12345)
+    exp = xo.batch_rules(boards)
+    got = {k: v.cpu().numpy() for k, v in N.rules_fused(torch.from_numpy(boards).cuda(), N.F32).items()}
+    for k in ("moves", "counts", "over", "v", "final_move", "check", "planes"):
+        assert (got[k] == exp[k]).all(), k
+    # will_check_or_catch / be_catched on the first few moves of a subset
+    sub = boards[::17]
+    bl, ml, ew, eb = [], [], [], []
+    import ctypes as C
+    L = xo.lib()
+    for b in sub:
+        if xo.done_board(b)[0]:
+            continue
+        for m in xo.legal_moves_board(b)[:5]:
+            bl.append(b)
+            ml.append(int(m))
+            ew.append(L.xqo_will_check_or_catch(b.ctypes.data_as(C.POINTER(C.c_int8)), int(m)))
+            eb.append(L.xqo_be_catched(b.ctypes.data_as(C.POINTER(C.c_int8)), int(m)))
+    boards_d = torch.from_numpy(np.stack(bl)).cuda()
+    moves_d = torch.tensor(ml, dtype=torch.int32).to(torch.uint16).cuda()
+    assert (N.check_or_catch(boards_d, moves_d).cpu().numpy() == np.array(ew, dtype=np.uint8)).all()
+    assert (N.be_catched(boards_d, moves_d).cpu().numpy() == np.array(eb, dtype=np.uint8)).all()
+
+
+def test_full_size_replicated_suite(nat, positions_1k):
+    """1M boards (the micro-suite size of SURVEY 8(d)): every replica must reproduce its source row."""
+    N, torch = nat
+    base = torch.from_numpy(_boards([r["state"] for r in positions_1k])).cuda()
+    ref = N.rules_fused(base, N.U8)
+    n = 1 << 20
+    g = torch.Generator(device="cuda").manual_seed(1)
+    src = torch.randint(0, base.shape[0], (n,), device="cuda", generator=g)
+    big = base[src].contiguous()
+    out = N.rules_fused(big, N.U8)
+    for k in ("counts", "over", "v", "check"):
+        assert torch.equal(out[k], ref[k][src]), k
+    assert torch.equal(out["moves"].view(torch.int16), ref["moves"].view(torch.int16)[src])
+    assert torch.equal(out["final_move"].view(torch.int16), ref["final_move"].view(torch.int16)[src])
+    assert torch.equal(out["planes"], ref["planes"][src])
+    # planes are one-hot per piece: sum == piece count
+    assert torch.equal(out["planes"].sum(dim=(1, 2, 3), dtype=torch.int32), (big != 0).sum(dim=1, dtype=torch.int32))
+
+
+def test_edge_cases(nat):
+    N, torch = nat
+    empty = torch.zeros((0, 90), dtype=torch.int8, device="cuda")
+    mv, ct = N.movegen(empty)
+    assert mv.shape == (0, 128) and ct.shape == (0,)
+    # no pieces at all, a single board, and a ragged (non power of two) batch
+    boards = torch.zeros((3, 90), dtype=torch.int8, device="cuda")
+    boards[1] = torch.from_numpy(xo.state_to_board(xo.INIT_STATE)).cuda()
+    boards[2, 4] = 7                                        # lone mover king
+    out = N.rules_fused(boards, N.F32)
+    assert out["counts"].cpu().tolist() == [0, 44, 3]
+    assert out["over"].cpu().tolist() == [1, 0, 1] and out["v"].cpu().tolist() == [1, 0, 1]
+
+
+def test_string_facade(nat, known_answers):
+    import cchess_alphazero.environment.static_env as senv
+    ka = known_answers
+    assert senv.get_legal_moves(senv.INIT_STATE) == ka["init_moves"]
+    assert list(senv.done(senv.INIT_STATE, need_check=True)) == ka["init_done"]
+    assert senv.step(senv.INIT_STATE, '0001') == ka["step_init_0001"]
+    assert list(senv.done(ka["test_done"]["state"])) == ka["test_done"]["done"]
+    c = ka["test_check_and_catch"]
+    assert senv.will_check_or_catch(c["state"], c["move"]) == c["result"]
+    c = ka["test_be_catched"]
+    assert senv.be_catched(c["state"], c["move"]) == c["result"]
+    assert senv.get_legal_moves(ka["kings_facing"]["state"]) == ka["kings_facing"]["moves"]
+    assert list(senv.done(ka["kings_facing"]["state"])) == ka["kings_facing"]["done"]
+    assert senv.state_to_planes(senv.INIT_STATE).sum() == 32
+    assert senv.has_attack_chessman(senv.INIT_STATE)
+    with pytest.raises(ValueError):
+        senv.step(senv.INIT_STATE, '4445')
