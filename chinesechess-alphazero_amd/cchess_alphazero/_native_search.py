@@ -1,0 +1,209 @@
+"""ctypes binding of the batched search object of libczero.so (cz_search_* in include/czero.h)."""
+import ctypes as C
+
+import numpy as np
+
+from cchess_alphazero import _native
+
+COUNTER_NAMES = ["sims", "expansions", "terminal_sims", "repetition_sims", "parked", "sum_depth", "max_depth",
+                 "edges_visited", "leaf_moves", "plies", "games", "red_wins", "black_wins", "draws", "resigns",
+                 "tree_resets", "overflow_sims", "depth_overflow", "root_reused_sims", "ring_dropped"]
+
+
+class SearchCfg(C.Structure):
+    _fields_ = [("n_games", C.c_int32), ("sims_per_round", C.c_int32), ("simulation_num_per_move", C.c_int32),
+                ("virtual_loss", C.c_int32), ("node_capacity", C.c_int32), ("edge_capacity", C.c_int32),
+                ("max_depth", C.c_int32), ("max_game_length", C.c_int32), ("planes_dtype", C.c_int32),
+                ("min_resign_turn", C.c_int32), ("evaluate", C.c_int32), ("ring_capacity", C.c_int32),
+                ("c_puct", C.c_double), ("noise_eps", C.c_double), ("dirichlet_alpha", C.c_double),
+                ("tau_decay_rate", C.c_double), ("resign_threshold", C.c_double), ("enable_resign_rate", C.c_double),
+                ("seed", C.c_uint64)]
+
+
+def declare(L):
+    vp, i32 = C.c_void_p, C.c_int
+    L.cz_search_create.argtypes = [C.POINTER(SearchCfg), C.POINTER(vp)]
+    L.cz_search_destroy.argtypes = [vp]
+    L.cz_search_bytes.argtypes = [vp]
+    L.cz_search_bytes.restype = C.c_size_t
+    L.cz_search_info.argtypes = [vp, vp]
+    L.cz_search_start_selfplay.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp]
+    L.cz_search_set_roots.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.cz_search_round.argtypes = [vp, vp, vp, vp, vp]
+    L.cz_search_reset_trees.argtypes = [vp, vp]
+    L.cz_search_pending.argtypes = [vp, C.POINTER(C.c_int), vp]
+    L.cz_search_root_stats.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.cz_search_choose.argtypes = [vp, vp, vp, vp]
+    L.cz_search_counters.argtypes = [vp, vp, vp]
+    L.cz_search_drain_records.argtypes = [vp, C.POINTER(C.c_uint), vp, i32, C.POINTER(C.c_int), vp]
+    L.cz_debug_sqrt.argtypes = [vp, vp, i32, vp]
+    for n in ("cz_search_create", "cz_search_destroy", "cz_search_info", "cz_search_start_selfplay",
+              "cz_search_set_roots", "cz_search_round", "cz_search_reset_trees", "cz_search_pending",
+              "cz_search_root_stats", "cz_search_choose", "cz_search_counters", "cz_search_drain_records",
+              "cz_debug_sqrt"):
+        getattr(L, n).restype = i32
+
+
+class Search:
+    """Owns one cz_search (device memory for G game trees) plus the evaluation-queue tensors.
+
+    play_config: any object with the reference's ``config.play`` fields (simulation_num_per_move,
+    search_threads, c_puct, noise_eps, dirichlet_alpha, tau_decay_rate, virtual_loss, resign_threshold,
+    min_resign_turn, max_game_length, enable_resign_rate).
+    """
+
+    def __init__(self, play_config, n_games, planes_dtype=_native.F32, evaluate=False, seed=0,
+                 node_capacity=0, edge_capacity=0, max_depth=0, ring_capacity=0, sims_per_round=None,
+                 device=None):
+        import torch
+        _native.require_gpu()
+        self.L = _native.lib()
+        if not hasattr(self.L, "cz_search_create"):
+            raise _native.NativeError("libczero.so was built without the search kernels")
+        pc = play_config
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.G = int(n_games)
+        self.K = int(sims_per_round if sims_per_round is not None else pc.search_threads)
+        self.planes_dtype = planes_dtype
+        cfg = SearchCfg(self.G, self.K, int(pc.simulation_num_per_move), int(pc.virtual_loss), int(node_capacity),
+                        int(edge_capacity), int(max_depth), int(pc.max_game_length), int(planes_dtype),
+                        int(pc.min_resign_turn), int(bool(evaluate)), int(ring_capacity),
+                        float(pc.c_puct), float(pc.noise_eps), float(pc.dirichlet_alpha), float(pc.tau_decay_rate),
+                        float(pc.resign_threshold), float(pc.enable_resign_rate), int(seed))
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _native.check(self.L.cz_search_create(C.byref(cfg), C.byref(h)), "cz_search_create")
+        self.h = h
+        info = (C.c_int32 * 12)()
+        _native.check(self.L.cz_search_info(self.h, info), "cz_search_info")
+        (self.G, self.K, self.sims, self.node_cap, self.edge_cap, self.hash_cap, self.max_depth, self.max_plies,
+         self.record_stride, self.ring_cap, self.n_counters, _) = list(info)
+        self.slots = self.G * self.K
+        self.planes = torch.zeros((self.slots, 14, 10, 9), dtype=_native.torch_dtype(planes_dtype), device=self.device)
+        self.policy = torch.zeros((self.slots, _native.NLABELS), dtype=torch.float32, device=self.device)
+        self.value = torch.zeros((self.slots,), dtype=torch.float32, device=self.device)
+        self._cursor = C.c_uint(0)
+
+    # -- lifetime --
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cz_search_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_bytes(self):
+        return int(self.L.cz_search_bytes(self.h))
+
+    def _stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- modes --
+    def start_selfplay(self, seed=0, first_game_id=0, game_id_stride=0):
+        _native.check(self.L.cz_search_start_selfplay(self.h, int(seed), int(first_game_id), int(game_id_stride),
+                                                      self._stream()), "cz_search_start_selfplay")
+        self._cursor = C.c_uint(0)
+
+    def set_roots(self, boards, turns=None, no_act=None, n_no_act=None, increase_temp=None, enable_resign=None,
+                  select_mask=None):
+        """boards: int8 [G,90] cuda tensor; the optional arguments are cuda tensors of the documented dtypes."""
+        import torch
+
+        def ptr(t, dt):
+            if t is None:
+                return None
+            assert t.is_cuda and t.is_contiguous() and t.dtype == dt, (t.dtype, dt)
+            return C.c_void_p(t.data_ptr())
+        assert boards.shape == (self.G, 90)
+        self._keep = (boards, turns, no_act, n_no_act, increase_temp, enable_resign, select_mask)
+        _native.check(self.L.cz_search_set_roots(
+            self.h, ptr(boards, torch.int8), ptr(turns, torch.int32), ptr(no_act, torch.uint16),
+            ptr(n_no_act, torch.uint8), ptr(increase_temp, torch.uint8), ptr(enable_resign, torch.uint8),
+            ptr(select_mask, torch.uint8), self._stream()), "cz_search_set_roots")
+
+    def reset_trees(self):
+        _native.check(self.L.cz_search_reset_trees(self.h, self._stream()), "cz_search_reset_trees")
+
+    # -- one lock-step round: tree kernel only (the caller runs the network on self.planes) --
+    def round(self):
+        _native.check(self.L.cz_search_round(self.h, C.c_void_p(self.policy.data_ptr()),
+                                             C.c_void_p(self.value.data_ptr()), C.c_void_p(self.planes.data_ptr()),
+                                             self._stream()), "cz_search_round")
+
+    def pending(self):
+        out = C.c_int(0)
+        _native.check(self.L.cz_search_pending(self.h, C.byref(out), self._stream()), "cz_search_pending")
+        return out.value
+
+    def run_until_idle(self, evaluate, max_rounds=1000000):
+        """external mode: rounds until every search is complete.  evaluate(planes) -> (policy, value)."""
+        rounds = 0
+        while rounds < max_rounds:
+            self.round()
+            rounds += 1
+            if self.pending() == 0:
+                return rounds
+            p, v = evaluate(self.planes)
+            self.policy.copy_(p)
+            self.value.copy_(v)
+        raise RuntimeError("search did not finish")
+
+    def root_stats(self):
+        import torch
+        G, M = self.G, _native.MAXMOVES
+        moves = torch.empty((G, M), dtype=torch.uint16, device=self.device)
+        n = torch.empty((G, M), dtype=torch.int32, device=self.device)
+        w = torch.empty((G, M), dtype=torch.float64, device=self.device)
+        p = torch.empty((G, M), dtype=torch.float32, device=self.device)
+        sum_n = torch.empty((G,), dtype=torch.int32, device=self.device)
+        counts = torch.empty((G,), dtype=torch.uint8, device=self.device)
+        _native.check(self.L.cz_search_root_stats(self.h, C.c_void_p(moves.data_ptr()), C.c_void_p(n.data_ptr()),
+                                                  C.c_void_p(w.data_ptr()), C.c_void_p(p.data_ptr()),
+                                                  C.c_void_p(sum_n.data_ptr()), C.c_void_p(counts.data_ptr()),
+                                                  self._stream()), "cz_search_root_stats")
+        return dict(moves=moves.cpu().numpy(), n=n.cpu().numpy(), w=w.cpu().numpy(), p=p.cpu().numpy(),
+                    sum_n=sum_n.cpu().numpy(), counts=counts.cpu().numpy())
+
+    def choose(self, u=None):
+        import torch
+        action = torch.empty((self.G,), dtype=torch.int32, device=self.device)
+        ut = None
+        if u is not None:
+            ut = torch.as_tensor(np.asarray(u, dtype=np.float64)).to(self.device)
+        _native.check(self.L.cz_search_choose(self.h, C.c_void_p(ut.data_ptr()) if ut is not None else None,
+                                              C.c_void_p(action.data_ptr()), self._stream()), "cz_search_choose")
+        return action.cpu().numpy()
+
+    def counters(self):
+        out = (C.c_uint64 * self.n_counters)()
+        _native.check(self.L.cz_search_counters(self.h, out, self._stream()), "cz_search_counters")
+        return {k: int(out[i]) for i, k in enumerate(COUNTER_NAMES[:self.n_counters])}
+
+    def drain_records(self, max_records=4096):
+        """Finished games since the last call: list of dict(game_id, turns, value, store, resigned, moves[labels])."""
+        buf = np.zeros((max_records, self.record_stride), dtype=np.uint8)
+        n = C.c_int(0)
+        _native.check(self.L.cz_search_drain_records(self.h, C.byref(self._cursor), buf.ctypes.data, max_records,
+                                                     C.byref(n), self._stream()), "cz_search_drain_records")
+        out = []
+        for i in range(n.value):
+            hdr = buf[i, :16].view(np.int32)
+            turns = int(hdr[1])
+            mv = buf[i, 16:16 + 2 * min(turns, self.max_plies + 2)].view(np.uint16)
+            out.append(dict(game_id=int(buf[i, :4].view(np.uint32)[0]), turns=turns, value=int(hdr[2]),
+                            store=bool(hdr[3] & 1), resigned=bool(hdr[3] & 2), moves=mv.copy()))
+        return out
+
+
+def debug_sqrt(x):
+    """x: int32 cuda tensor -> float64 tensor of sqrt(x + 1) as computed by the PUCT kernel."""
+    import torch
+    y = torch.empty(x.shape, dtype=torch.float64, device=x.device)
+    _native.check(_native.lib().cz_debug_sqrt(C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), x.numel(),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), "cz_debug_sqrt")
+    return y

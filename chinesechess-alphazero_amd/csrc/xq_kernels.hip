@@ -192,6 +192,8 @@ __global__ __launch_bounds__(64) void k_rules_fused(const int8_t* __restrict__ b
 // ---- C-ABI ----------------------------------------------------------------------------
 extern "C" {
 
+void czi_set_error(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
+
 int cz_version(void) { return CZ_VERSION; }
 
 const char* cz_last_error(void) { return g_err; }
@@ -212,8 +214,8 @@ int cz_label_tables(uint16_t* label_of, uint16_t* lab_ft)
 
 int cz_movegen(const int8_t* boards, int n, uint16_t* moves, uint8_t* counts, void* stream)
 {
-    if (n < 0 || !boards || !moves || !counts) return set_err_msg(CZ_ERR_ARG, "cz_movegen: bad argument");
     if (n == 0) return CZ_OK;
+    if (n < 0 || !boards || !moves || !counts) return set_err_msg(CZ_ERR_ARG, "cz_movegen: bad argument");
     hipLaunchKernelGGL(k_movegen, dim3(grid_for(n)), dim3(64), 0, (hipStream_t)stream, boards, n, moves, counts);
     CZ_LAUNCH_CHECK("cz_movegen");
     return CZ_OK;
@@ -222,9 +224,9 @@ int cz_movegen(const int8_t* boards, int n, uint16_t* moves, uint8_t* counts, vo
 int cz_done(const int8_t* boards, int n, int need_check, int8_t* over, int8_t* v, uint16_t* final_move,
             uint8_t* check, void* stream)
 {
+    if (n == 0) return CZ_OK;
     if (n < 0 || !boards || !over || !v || !final_move || (need_check && !check))
         return set_err_msg(CZ_ERR_ARG, "cz_done: bad argument");
-    if (n == 0) return CZ_OK;
     hipLaunchKernelGGL(k_done, dim3(grid_for(n)), dim3(64), 0, (hipStream_t)stream, boards, n, need_check, over, v,
                        final_move, check);
     CZ_LAUNCH_CHECK("cz_done");
@@ -233,8 +235,8 @@ int cz_done(const int8_t* boards, int n, int need_check, int8_t* over, int8_t* v
 
 int cz_step(const int8_t* boards, const uint16_t* moves, int n, int8_t* out, uint8_t* no_eat, void* stream)
 {
-    if (n < 0 || !boards || !moves || !out) return set_err_msg(CZ_ERR_ARG, "cz_step: bad argument");
     if (n == 0) return CZ_OK;
+    if (n < 0 || !boards || !moves || !out) return set_err_msg(CZ_ERR_ARG, "cz_step: bad argument");
     hipLaunchKernelGGL(k_step, dim3(grid_for(n)), dim3(64), 0, (hipStream_t)stream, boards, moves, n, out, no_eat);
     CZ_LAUNCH_CHECK("cz_step");
     return CZ_OK;
@@ -242,8 +244,8 @@ int cz_step(const int8_t* boards, const uint16_t* moves, int n, int8_t* out, uin
 
 int cz_encode(const int8_t* boards, int n, void* planes, int dtype, void* stream)
 {
-    if (n < 0 || !boards || !planes) return set_err_msg(CZ_ERR_ARG, "cz_encode: bad argument");
     if (n == 0) return CZ_OK;
+    if (n < 0 || !boards || !planes) return set_err_msg(CZ_ERR_ARG, "cz_encode: bad argument");
     const dim3 g(grid_for(n)), b(64);
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
@@ -259,8 +261,8 @@ int cz_encode(const int8_t* boards, int n, void* planes, int dtype, void* stream
 
 int cz_check_or_catch(const int8_t* boards, const uint16_t* moves, int n, uint8_t* out, void* stream)
 {
-    if (n < 0 || !boards || !moves || !out) return set_err_msg(CZ_ERR_ARG, "cz_check_or_catch: bad argument");
     if (n == 0) return CZ_OK;
+    if (n < 0 || !boards || !moves || !out) return set_err_msg(CZ_ERR_ARG, "cz_check_or_catch: bad argument");
     hipLaunchKernelGGL(k_check_or_catch, dim3(grid_for(n)), dim3(64), 0, (hipStream_t)stream, boards, moves, n, out);
     CZ_LAUNCH_CHECK("cz_check_or_catch");
     return CZ_OK;
@@ -268,8 +270,8 @@ int cz_check_or_catch(const int8_t* boards, const uint16_t* moves, int n, uint8_
 
 int cz_be_catched(const int8_t* boards, const uint16_t* moves, int n, uint8_t* out, void* stream)
 {
-    if (n < 0 || !boards || !moves || !out) return set_err_msg(CZ_ERR_ARG, "cz_be_catched: bad argument");
     if (n == 0) return CZ_OK;
+    if (n < 0 || !boards || !moves || !out) return set_err_msg(CZ_ERR_ARG, "cz_be_catched: bad argument");
     hipLaunchKernelGGL(k_be_catched, dim3(grid_for(n)), dim3(64), 0, (hipStream_t)stream, boards, moves, n, out);
     CZ_LAUNCH_CHECK("cz_be_catched");
     return CZ_OK;
@@ -277,8 +279,8 @@ int cz_be_catched(const int8_t* boards, const uint16_t* moves, int n, uint8_t* o
 
 int cz_has_attack(const int8_t* boards, int n, uint8_t* out, void* stream)
 {
-    if (n < 0 || !boards || !out) return set_err_msg(CZ_ERR_ARG, "cz_has_attack: bad argument");
     if (n == 0) return CZ_OK;
+    if (n < 0 || !boards || !out) return set_err_msg(CZ_ERR_ARG, "cz_has_attack: bad argument");
     hipLaunchKernelGGL(k_has_attack, dim3(grid_for(n)), dim3(64), 0, (hipStream_t)stream, boards, n, out);
     CZ_LAUNCH_CHECK("cz_has_attack");
     return CZ_OK;
@@ -287,9 +289,9 @@ int cz_has_attack(const int8_t* boards, int n, uint8_t* out, void* stream)
 int cz_rules_fused(const int8_t* boards, int n, uint16_t* moves, uint8_t* counts, int8_t* over, int8_t* v,
                    uint16_t* final_move, uint8_t* check, void* planes, int dtype, void* stream)
 {
+    if (n == 0) return CZ_OK;
     if (n < 0 || !boards || !moves || !counts || !over || !v || !final_move || !check || !planes)
         return set_err_msg(CZ_ERR_ARG, "cz_rules_fused: bad argument");
-    if (n == 0) return CZ_OK;
     const dim3 g(grid_for(n)), b(64);
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {

@@ -1,0 +1,1305 @@
+// xq_search.hip -- batched PUCT-MCTS + self-play game loop for gfx950, one wavefront per game.
+//
+// Replaces, for thousands of concurrent games, the reference's per-game Python objects:
+//   CChessPlayer.action / MCTS_search / select_action_q_and_u / expand_and_evaluate / update_tree /
+//   calc_policy / apply_temperature      (cchess_alphazero/agent/player.py:145-470)
+//   SelfPlayWorker.start_game            (cchess_alphazero/worker/self_play.py:95-212)
+//
+// One launch of k_round is one lock-step ROUND for every game:
+//   1. attach the network results of the previous round to their leaves and back them up,
+//   2. resume simulations that were parked on those leaves,
+//   3. when a batch of K simulations is complete start the next one (or finish the ply: pick the
+//      move, apply the game rules, start the next search / the next game),
+//   4. every new leaf writes its input planes into its fixed slot (game * K + sim) of the
+//      evaluation queue; the host then runs ONE network forward over the whole queue.
+// There is no host decision inside a round and no device->host copy, so a round (kernel + network
+// forward) can be replayed from a HIP graph.
+//
+// Arithmetic follows the reference bit for bit: priors float32 (summed in move order),
+// sqrt / Q / U in float64 with the float32 product c_puct*p for non-root nodes, W float64.
+// Build with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include "xq_rules.h"
+#include "xq_search.h"
+#include "../../include/czero.h"
+
+using namespace xq;
+
+extern "C" void czi_set_error(const char* msg);   // xq_kernels.hip
+
+namespace {
+
+constexpr int MAXD_LDS = 128;          // LDS copy of the current path; SearchParams.max_depth <= this
+constexpr int INIT_NIB_WORDS = KEY_WORDS;
+
+struct SearchLDS {
+    RulesLDS r;
+    uint32_t key[KEY_WORDS + 4];
+    int32_t path_node[MAXD_LDS];
+    int32_t path_edge[MAXD_LDS];
+    double dsc[MAXMOVES];              // sampling scratch
+    float pr[MAXMOVES];                // prior gather scratch
+    uint16_t slab[MAXMOVES];           // labels sorted
+    int32_t sn[MAXMOVES];              // visit counts sorted by label
+};
+
+// pointers into one game's slices
+struct GameView {
+    uint32_t* node_key;
+    int32_t* node_sum_n;
+    uint32_t* node_eoff;
+    uint32_t* node_meta;
+    uint64_t* hash;
+    int32_t* e_n;
+    double* e_w;
+    float* e_p;
+    uint16_t* e_mv;
+    int32_t* e_child;
+    int32_t* path_node;     // [K][max_depth]
+    int32_t* path_edge;
+    uint8_t* s_state;
+    int32_t* s_depth;
+    int32_t* s_node;
+    unsigned long long* ctr;
+    int g;
+};
+
+XQ_D int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+XQ_D uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+XQ_D uint64_t uni64(uint64_t v)
+{
+    const uint32_t lo = uniu((uint32_t)v), hi = uniu((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+XQ_D double unid(double v) { return __longlong_as_double((long long)uni64((uint64_t)__double_as_longlong(v))); }
+
+XQ_D GameView make_view(const SearchBuffers& B, const SearchParams& P, int g)
+{
+    GameView v;
+    v.node_key = B.node_key + (size_t)g * P.node_cap * KEY_WORDS;
+    v.node_sum_n = B.node_sum_n + (size_t)g * P.node_cap;
+    v.node_eoff = B.node_eoff + (size_t)g * P.node_cap;
+    v.node_meta = B.node_meta + (size_t)g * P.node_cap;
+    v.hash = B.hash_tab + (size_t)g * P.hash_cap;
+    v.e_n = B.e_n + (size_t)g * P.edge_cap;
+    v.e_w = B.e_w + (size_t)g * P.edge_cap;
+    v.e_p = B.e_p + (size_t)g * P.edge_cap;
+    v.e_mv = B.e_mv + (size_t)g * P.edge_cap;
+    v.e_child = B.e_child + (size_t)g * P.edge_cap;
+    v.path_node = B.s_path_node + (size_t)g * P.K * P.max_depth;
+    v.path_edge = B.s_path_edge + (size_t)g * P.K * P.max_depth;
+    v.s_state = B.s_state + (size_t)g * P.K;
+    v.s_depth = B.s_depth + (size_t)g * P.K;
+    v.s_node = B.s_node + (size_t)g * P.K;
+    v.ctr = B.counters + (size_t)g * CT_COUNT;
+    v.g = g;
+    return v;
+}
+
+XQ_D void count(const GameView& gv, int which, unsigned long long by = 1)
+{
+    if (lane_id() == 0) gv.ctr[which] += by;
+}
+XQ_D void count_max(const GameView& gv, int which, unsigned long long val)
+{
+    if (lane_id() == 0 && gv.ctr[which] < val) gv.ctr[which] = val;
+}
+
+// ---- counter-based RNG (Philox4x32-10), same stream as oracle/xq_mcts.c ------------------------
+XQ_D double philox_uniform(uint64_t seed, uint32_t game_id, uint32_t stream, uint64_t idx)
+{
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = stream, c3 = game_id;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6)) / 9007199254740992.0;
+}
+
+// Gamma(a, 1) by Marsaglia-Tsang (with the a < 1 boost); per-lane, consumes idx.. upwards
+XQ_D double gamma_draw(double a, uint64_t seed, uint32_t gid, uint64_t& idx)
+{
+    double boost = 1.0;
+    if (a <= 0.0) return 0.0;
+    if (a < 1.0) {
+        double u = philox_uniform(seed, gid, 2, idx++);
+        if (u <= 0.0) u = 1e-300;
+        boost = pow(u, 1.0 / a);
+        a += 1.0;
+    }
+    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (int it = 0; it < 64; ++it) {
+        double u1 = philox_uniform(seed, gid, 2, idx++);
+        const double u2 = philox_uniform(seed, gid, 2, idx++);
+        if (u1 <= 0.0) u1 = 1e-300;
+        const double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        const double u = philox_uniform(seed, gid, 2, idx++);
+        if (u < 1.0 - 0.0331 * x * x * x * x) return boost * d * v;
+        if (u > 0.0 && log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return boost * d * v;
+    }
+    return boost * d;
+}
+
+// ---- packed keys and the transposition hash ----------------------------------------------------
+// board (LDS) -> key words in L.key (lanes 0..11), returns the 64-bit hash (wave-uniform)
+XQ_D uint64_t pack_key(const int8_t* b, uint32_t* key)
+{
+    const int lane = lane_id();
+    uint64_t h = 0;
+    if (lane < KEY_WORDS) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s = lane * 8 + j;
+            const int p = s < NSQ ? b[s] : 0;
+            w |= nib_of(p) << (4 * j);
+        }
+        key[lane] = w;
+        h = mix64((uint64_t)w + 0x9E3779B97F4A7C15ULL * (uint64_t)(lane + 1));
+    }
+    uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        lo ^= (uint32_t)__shfl_xor((int)lo, d, 64);
+        hi ^= (uint32_t)__shfl_xor((int)hi, d, 64);
+    }
+    wave_sync();
+    h = ((uint64_t)uniu(hi) << 32) | uniu(lo);
+    return mix64(h);
+}
+
+XQ_D void unpack_key(const uint32_t* __restrict__ gkey, int8_t* b)
+{
+    const int lane = lane_id();
+    {
+        const uint32_t w = gkey[lane >> 3];
+        b[lane] = (int8_t)piece_of_nib((w >> (4 * (lane & 7))) & 15u);
+    }
+    if (lane < 26) {
+        const int s = lane + 64;
+        const uint32_t w = gkey[s >> 3];
+        b[s] = (int8_t)piece_of_nib((w >> (4 * (s & 7))) & 15u);
+    }
+    if (lane >= 26 && lane < 32) b[lane + 64] = 0;
+    wave_sync();
+}
+
+// returns node index or -1; *slot_out = where to insert
+XQ_D int hash_lookup(const GameView& gv, const SearchParams& P, const uint32_t* key, uint64_t h, int* slot_out)
+{
+    const int lane = lane_id();
+    const uint32_t mask = (uint32_t)P.hash_cap - 1u;
+    uint32_t slot = (uint32_t)h & mask;
+    const uint32_t tag = (uint32_t)(h >> 32) | 1u;
+    for (int probe = 0; probe < P.hash_cap; ++probe) {
+        const uint64_t e = uni64(gv.hash[slot]);
+        if (e == 0) { *slot_out = (int)slot; return -1; }
+        if ((uint32_t)(e >> 32) == tag) {
+            const int idx = (int)((uint32_t)e) - 1;
+            const bool ne = lane < KEY_WORDS && gv.node_key[(size_t)idx * KEY_WORDS + lane] != key[lane];
+            if (!__ballot(ne)) { *slot_out = (int)slot; return idx; }
+        }
+        slot = (slot + 1) & mask;
+    }
+    *slot_out = -1;
+    return -1;
+}
+
+// ---- backup: update_tree, player.py:357-366 ------------------------------------------------------
+// levels are independent (a path never holds the same edge twice), so lane i updates level i
+XQ_D void backup(const SearchParams& P, const GameView& gv, const SearchLDS& L, int depth, double v)
+{
+    const int lane = lane_id();
+    for (int i = lane; i < depth; i += 64) {
+        const int e = L.path_edge[i];
+        const double vi = ((depth - i) & 1) ? -v : v;        // v = -v once per level walking up
+        gv.e_n[e] += 1 - P.vl;
+        gv.e_w[e] = gv.e_w[e] + (vi + (double)P.vl);
+    }
+    count(gv, CT_SIMS);
+    count(gv, CT_SUM_DEPTH, (unsigned long long)depth);
+    count_max(gv, CT_MAX_DEPTH, (unsigned long long)depth);
+    wave_sync();
+}
+
+// ---- prior spreading: select_action_q_and_u, player.py:272-284 ----------------------------------
+XQ_D void attach_policy(const GameView& gv, SearchLDS& L, int node, const float* __restrict__ prow)
+{
+    const int lane = lane_id();
+    const uint32_t meta = uniu(gv.node_meta[node]);
+    const int nm = (int)(meta & 0xFF);
+    const int eoff = (int)uniu(gv.node_eoff[node]);
+    if (lane < nm) L.pr[lane] = prow[gv.e_mv[eoff + lane]];
+    if (lane + 64 < nm) L.pr[lane + 64] = prow[gv.e_mv[eoff + lane + 64]];
+    wave_sync();
+    float all_p = 0.0f;
+    if (nm > 0) {
+        all_p = L.pr[0];                                   // int 0 + float32
+        for (int j = 1; j < nm; ++j) all_p = all_p + L.pr[j];   // float32 accumulation in move order
+    }
+    if (all_p == 0.0f) all_p = 1.0f;
+    if (lane < nm) gv.e_p[eoff + lane] = L.pr[lane] / all_p;
+    if (lane + 64 < nm) gv.e_p[eoff + lane + 64] = L.pr[lane + 64] / all_p;
+    if (lane == 0) gv.node_meta[node] = meta & ~(uint32_t)NODE_WAITING;
+    wave_sync();
+}
+
+// ---- select_action_q_and_u, player.py:286-320 --------------------------------------------------------
+struct RootCtx {
+    bool is_root;
+    int n_no_act;
+    const uint16_t* no_act;
+    uint64_t seed;
+    uint32_t game_id;
+    int turns;
+};
+
+XQ_D int select_edge(const SearchParams& P, const GameView& gv, int node, int nm, int eoff, const RootCtx& rc)
+{
+    const int lane = lane_id();
+    const int sum_n = uni(gv.node_sum_n[node]);
+    const double xx = __dsqrt_rn((double)(sum_n + 1));
+    double best_s = -1.0e300;
+    int best_j = -1;
+    bool win_any[2] = {false, false};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = lane + 64 * h;
+        bool valid = j < nm;
+        double score = -1.0e300;
+        bool win = false;
+        if (valid) {
+            const int n = gv.e_n[eoff + j];
+            const double w = gv.e_w[eoff + j];
+            const float p = gv.e_p[eoff + j];
+            const double q = n ? w / (double)n : 0.0;
+            double u;
+            if (rc.is_root) {
+                if (rc.n_no_act) {
+                    const uint16_t mv = gv.e_mv[eoff + j];
+                    for (int k = 0; k < rc.n_no_act; ++k) valid = valid && (rc.no_act[k] != mv);
+                }
+                const float a = P.one_minus_eps_f32 * p;
+                double p_ = (double)a;
+                if (P.noise_eps != 0.0) {
+                    uint64_t idx = ((uint64_t)(uint32_t)rc.turns << 48) | ((uint64_t)(uint32_t)sum_n << 24) | ((uint64_t)j << 16);
+                    const double x = gamma_draw(P.dirichlet_alpha, rc.seed, rc.game_id, idx);
+                    const double y = nm > 1 ? gamma_draw(P.dirichlet_alpha * (double)(nm - 1), rc.seed, rc.game_id, idx) : 0.0;
+                    const double dch = (x + y) > 0.0 ? x / (x + y) : 1.0 / (double)nm;
+                    p_ = p_ + P.noise_eps * dch;
+                }
+                u = P.c_puct * p_ * xx / (double)(1 + n);
+            } else {
+                const float a = P.c_puct_f32 * p;
+                u = (double)a * xx / (double)(1 + n);
+            }
+            if (valid) {
+                score = q + u;
+                win = q > (1.0 - 1e-7);
+                if (!(score >= -99999999.0)) valid = false;
+            }
+        }
+        win_any[h] = valid && win;
+        if (valid && score >= best_s) { best_s = score; best_j = j; }   // h = 1 has the larger index: wins ties
+    }
+    // proven-win shortcut: first edge in order with q > 1 - 1e-7 (player.py:309-311)
+    const int first_win = lowest_bit(__ballot(win_any[0]), __ballot(win_any[1]));
+    if (first_win >= 0) return first_win;
+    // arg max of (score, index): `>=` keeps the LAST maximal move (player.py:312-314)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double os = __shfl_xor(best_s, d, 64);
+        const int oj = __shfl_xor(best_j, d, 64);
+        if (os > best_s || (os == best_s && oj > best_j)) { best_s = os; best_j = oj; }
+    }
+    return uni(best_j);
+}
+
+// ---- simulation bookkeeping --------------------------------------------------------------------------
+XQ_D void sim_finish(const GameView& gv, int sim, int* active)
+{
+    if (lane_id() == 0) gv.s_state[sim] = SIM_IDLE;
+    *active -= 1;
+}
+
+XQ_D int find_in_path(const SearchLDS& L, int depth, int node)
+{
+    const int lane = lane_id();
+    for (int base = 0; base < depth; base += 64) {
+        const uint64_t m = __ballot(base + lane < depth && L.path_node[base + lane] == node);
+        if (m) return base + __ffsll((long long)m) - 1;
+    }
+    return -1;
+}
+
+struct RoundIO {
+    void* planes;
+    int planes_dtype;
+};
+
+XQ_D void write_planes(const RoundIO& io, const int8_t* b, size_t slot)
+{
+    switch (io.planes_dtype) {
+    case CZ_F32: wave_encode<0>(b, (char*)io.planes + slot * 1260 * 4); break;
+    case CZ_F16: wave_encode<1>(b, (char*)io.planes + slot * 1260 * 2); break;
+    case CZ_BF16: wave_encode<2>(b, (char*)io.planes + slot * 1260 * 2); break;
+    default: wave_encode<3>(b, (char*)io.planes + slot * 1260); break;
+    }
+}
+
+// create a node for the position in `b` whose ordered move list is in `ml` (nm moves);
+// returns the node index or -1 when the arena is full
+XQ_D int expand_node(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L,
+                     const MoveList& ml, int nm, int hash_slot, uint64_t h)
+{
+    const int lane = lane_id();
+    const int g = gv.g;
+    const int ncount = uni(B.g_node_count[g]), ecount = uni(B.g_edge_count[g]);
+    nm = nm < MAXMOVES ? nm : MAXMOVES;
+    if (ncount >= P.node_cap || ecount + nm > P.edge_cap || hash_slot < 0) return -1;
+    const int idx = ncount;
+    if (lane < KEY_WORDS) gv.node_key[(size_t)idx * KEY_WORDS + lane] = L.key[lane];
+    for (int j = lane; j < nm; j += 64) {
+        gv.e_n[ecount + j] = 0;
+        gv.e_w[ecount + j] = 0.0;
+        gv.e_p[ecount + j] = 0.0f;
+        gv.e_mv[ecount + j] = ml.lab[j];
+        gv.e_child[ecount + j] = CHILD_UNKNOWN;
+    }
+    if (lane == 0) {
+        gv.node_sum_n[idx] = 1;                                    // player.py:213
+        gv.node_eoff[idx] = (uint32_t)ecount;
+        gv.node_meta[idx] = (uint32_t)nm | NODE_WAITING;
+        gv.hash[hash_slot] = ((uint64_t)((uint32_t)(h >> 32) | 1u) << 32) | (uint32_t)(idx + 1);
+        B.g_node_count[g] = ncount + 1;
+        B.g_edge_count[g] = ecount + nm;
+    }
+    count(gv, CT_EXPANSIONS);
+    count(gv, CT_LEAF_MOVES, (unsigned long long)nm);
+    wave_sync();
+    return idx;
+}
+
+// One descent of simulation `sim` starting at `node` with `depth` path entries already in L.path_*
+// (MCTS_search, player.py:198-260).  `node` < 0 means the root position is not in the tree yet.
+XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L,
+                  const RoundIO& io, const RootCtx& rc0, int root, int sim, int node, int depth, int* active)
+{
+    const int lane = lane_id();
+    const int g = gv.g;
+    int32_t* hp_node = gv.path_node + (size_t)sim * P.max_depth;
+    int32_t* hp_edge = gv.path_edge + (size_t)sim * P.max_depth;
+    if (node < 0) {
+        // root expansion (player.py:211-221 with history == [state]); the position is in g_board
+        const int8_t* gb = B.g_board + (size_t)g * BOARD_LDS;
+        L.r.bd[1][lane] = gb[lane];
+        if (lane < 32) L.r.bd[1][lane + 64] = (lane < 26) ? gb[lane + 64] : (int8_t)0;
+        wave_sync();
+        const int nm = wave_movegen(L.r.bd[1], L.r.ml[0]);
+        const uint64_t h = pack_key(L.r.bd[1], L.key);
+        int slot;
+        int idx = hash_lookup(gv, P, L.key, h, &slot);
+        if (idx < 0) idx = expand_node(P, B, gv, L, L.r.ml[0], nm, slot, h);
+        if (idx < 0) { count(gv, CT_OVERFLOW_SIMS); backup(P, gv, L, 0, 0.0); sim_finish(gv, sim, active); return; }
+        if (lane == 0) {
+            B.g_root[g] = idx;
+            gv.s_state[sim] = SIM_LEAF; gv.s_node[sim] = idx; gv.s_depth[sim] = 0;
+        }
+        write_planes(io, L.r.bd[1], (size_t)g * P.K + sim);
+        wave_sync();
+        return;
+    }
+    for (;;) {
+        // state in history[:-1] (player.py:223-236)
+        const int rep = find_in_path(L, depth, node);
+        if (rep >= 0) {
+            unpack_key(gv.node_key + (size_t)node * KEY_WORDS, L.r.bd[0]);
+            const int mv = uni((int)gv.e_mv[L.path_edge[rep]]);
+            double v;
+            if (wave_will_check_or_catch(L.r, L.r.bd[0], mv) == 1) v = -1.0;
+            else if (wave_be_catched(L.r.bd[0], label_ft(mv) >> 8, L.r.bd[1], L.r.ml[0])) v = 1.0;
+            else v = 0.0;
+            count(gv, CT_REPETITION_SIMS);
+            backup(P, gv, L, depth, v);
+            sim_finish(gv, sim, active);
+            return;
+        }
+        const uint32_t meta = uniu(gv.node_meta[node]);
+        if (meta & NODE_WAITING) {                                  // player.py:238-242
+            if (lane == 0) { gv.s_state[sim] = SIM_PARKED; gv.s_node[sim] = node; gv.s_depth[sim] = depth; }
+            count(gv, CT_PARKED);
+            wave_sync();
+            return;
+        }
+        if (depth >= P.max_depth) {
+            count(gv, CT_DEPTH_OVERFLOW);
+            backup(P, gv, L, depth, 0.0);
+            sim_finish(gv, sim, active);
+            return;
+        }
+        const int nm = (int)(meta & 0xFF);
+        const int eoff = (int)uniu(gv.node_eoff[node]);
+        RootCtx rc = rc0;
+        rc.is_root = (node == root);                                // player.py:266
+        const int j = select_edge(P, gv, node, nm, eoff, rc);
+        if (j < 0) {                                                // "Best action is None": cannot happen
+            backup(P, gv, L, depth, 0.0);
+            sim_finish(gv, sim, active);
+            return;
+        }
+        const int e = eoff + j;
+        if (lane == 0) {                                            // player.py:245-252
+            gv.node_sum_n[node] += 1;
+            gv.e_n[e] += P.vl;
+            gv.e_w[e] = gv.e_w[e] - (double)P.vl;
+            L.path_node[depth] = node; L.path_edge[depth] = e;
+            hp_node[depth] = node; hp_edge[depth] = e;
+        }
+        count(gv, CT_EDGES_VISITED, (unsigned long long)nm);
+        depth += 1;
+        wave_sync();
+        int child = uni(gv.e_child[e]);
+        if (child == CHILD_UNKNOWN) {
+            unpack_key(gv.node_key + (size_t)node * KEY_WORDS, L.r.bd[0]);
+            const int ft = label_ft(uni((int)gv.e_mv[e]));
+            step_board(L.r.bd[0], ft >> 8, ft & 0xFF, L.r.bd[1]);
+            const DoneResult d = wave_done(L.r.bd[1], L.r.bd[2], L.r.ml[0], L.r.ml[1], false);   // player.py:204
+            if (d.over) {
+                child = d.v > 0 ? CHILD_TERM_WIN : CHILD_TERM_LOSS;
+                if (lane == 0) gv.e_child[e] = child;
+            } else {
+                const uint64_t h = pack_key(L.r.bd[1], L.key);
+                int slot;
+                int idx = hash_lookup(gv, P, L.key, h, &slot);
+                if (idx >= 0) {
+                    if (lane == 0) gv.e_child[e] = idx;
+                    child = idx;
+                } else {
+                    idx = expand_node(P, B, gv, L, L.r.ml[0], d.nmoves, slot, h);     // player.py:211-221
+                    if (idx < 0) {
+                        count(gv, CT_OVERFLOW_SIMS);
+                        backup(P, gv, L, depth, 0.0);
+                        sim_finish(gv, sim, active);
+                        return;
+                    }
+                    if (lane == 0) {
+                        gv.e_child[e] = idx;
+                        gv.s_state[sim] = SIM_LEAF; gv.s_node[sim] = idx; gv.s_depth[sim] = depth;
+                    }
+                    write_planes(io, L.r.bd[1], (size_t)g * P.K + sim);
+                    wave_sync();
+                    return;
+                }
+            }
+            wave_sync();
+        }
+        if (child == CHILD_TERM_WIN || child == CHILD_TERM_LOSS) {  // player.py:204-208: value doubled
+            count(gv, CT_TERMINAL_SIMS);
+            backup(P, gv, L, depth, child == CHILD_TERM_WIN ? 2.0 : -2.0);
+            sim_finish(gv, sim, active);
+            return;
+        }
+        node = child;
+    }
+}
+
+// reload a suspended simulation's path into LDS
+XQ_D void load_path(const SearchParams& P, const GameView& gv, SearchLDS& L, int sim, int depth)
+{
+    const int lane = lane_id();
+    const int32_t* hp_node = gv.path_node + (size_t)sim * P.max_depth;
+    const int32_t* hp_edge = gv.path_edge + (size_t)sim * P.max_depth;
+    wave_sync();
+    for (int i = lane; i < depth; i += 64) { L.path_node[i] = hp_node[i]; L.path_edge[i] = hp_edge[i]; }
+    wave_sync();
+}
+
+XQ_D void clear_tree(const SearchParams& P, const SearchBuffers& B, const GameView& gv)
+{
+    const int lane = lane_id();
+    for (int i = lane; i < P.hash_cap; i += 64) gv.hash[i] = 0;
+    if (lane == 0) { B.g_node_count[gv.g] = 0; B.g_edge_count[gv.g] = 0; B.g_root[gv.g] = -1; }
+    wave_sync();
+}
+
+// Start the search of the position in g_board (CChessPlayer.action, player.py:145-164): find the
+// root in the tree, apply the reuse rule, make room in the arena.
+XQ_D void begin_search(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L)
+{
+    const int lane = lane_id();
+    const int g = gv.g;
+    const int8_t* gb = B.g_board + (size_t)g * BOARD_LDS;
+    L.r.bd[1][lane] = gb[lane];
+    if (lane < 32) L.r.bd[1][lane + 64] = (lane < 26) ? gb[lane + 64] : (int8_t)0;
+    wave_sync();
+    const uint64_t h = pack_key(L.r.bd[1], L.key);
+    int slot;
+    int root = hash_lookup(gv, P, L.key, h, &slot);
+    int done_n = root >= 0 ? uni(gv.node_sum_n[root]) : 0;                       // :153-155
+    const int n_no_act = uni((int)B.g_n_no_act[g]), inc = uni((int)B.g_increase_temp[g]);
+    if (n_no_act > 0 || inc || done_n == P.sims) done_n = 0;                      // :156-158
+    int tasks = P.sims - done_n;
+    if (tasks < 0) tasks = 0;
+    // arena policy: the tree of a game is kept as long as it fits (reference: for the whole game);
+    // when the next ply might not fit, it is dropped and the search restarts from an empty tree
+    const int ncount = uni(B.g_node_count[g]), ecount = uni(B.g_edge_count[g]);
+    if (tasks > 0 && (ncount + tasks + 1 > P.node_cap || (long long)ecount + (long long)(tasks + 1) * 64 > P.edge_cap)) {
+        clear_tree(P, B, gv);
+        count(gv, CT_TREE_RESETS);
+        root = -1;
+        tasks = P.sims;
+        done_n = 0;
+    }
+    count(gv, CT_ROOT_REUSED_SIMS, (unsigned long long)done_n);
+    if (lane == 0) {
+        B.g_root[g] = root;
+        B.g_tasks_left[g] = tasks;
+        B.g_active[g] = 0;
+        B.g_phase[g] = PH_SEARCH;
+    }
+    wave_sync();
+}
+
+// ---- calc_policy + apply_temperature + choice (player.py:375-406, 453-470, :195) ---------------------
+// returns the chosen label, or -1 when the player resigns.  u is the uniform draw of np.random.choice.
+XQ_D int choose_action(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L, double u,
+                       bool enable_resign)
+{
+    const int lane = lane_id();
+    const int g = gv.g;
+    const int root = uni(B.g_root[g]);
+    if (root < 0) return -2;
+    const int nm = (int)(uniu(gv.node_meta[root]) & 0xFF);
+    const int eoff = (int)uniu(gv.node_eoff[root]);
+    const int n_no_act = uni((int)B.g_n_no_act[g]);
+    const uint16_t* no_act = B.g_no_act + (size_t)g * MAX_NO_ACT;
+    const int turns = uni(B.g_turns[g]);
+    // visit counts (banned -> 0), max q over the non-banned edges
+    int cnt[2];
+    double maxq = -100.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = lane + 64 * h;
+        cnt[h] = 0;
+        if (j < nm) {
+            const int n = gv.e_n[eoff + j];
+            const uint16_t mv = gv.e_mv[eoff + j];
+            bool banned = false;
+            for (int k = 0; k < n_no_act; ++k) banned = banned || (no_act[k] == mv);
+            if (!banned) {
+                cnt[h] = n;
+                const double q = n ? gv.e_w[eoff + j] / (double)n : 0.0;
+                maxq = q > maxq ? q : maxq;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_xor(maxq, d, 64);
+        maxq = o > maxq ? o : maxq;
+    }
+    maxq = unid(maxq);
+    if (maxq < P.resign_threshold && enable_resign && turns > P.min_resign_turn) return -1;   // :397-398
+    // order the edges by label (the policy vector is indexed by label)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = lane + 64 * h;
+        if (j < nm) {
+            const uint16_t mv = gv.e_mv[eoff + j];
+            int rank = 0;
+            for (int k = 0; k < nm; ++k) rank += gv.e_mv[eoff + k] < mv;
+            L.slab[rank] = mv;
+            L.sn[rank] = cnt[h];
+        }
+    }
+    wave_sync();
+    // temperature (player.py:453-461)
+    const int inc = uni((int)B.g_increase_temp[g]);
+    double tau = 0.0;
+    if (turns < 30 && P.tau_decay_rate != 0.0) tau = pow(P.tau_decay_rate, (double)(turns + 1));
+    if (tau < 0.1 || (turns >= 4 && P.evaluate)) tau = 0.0;
+    if (inc && !P.evaluate) tau = 0.5;
+    int chosen = 0;
+    if (lane == 0) {
+        long long total_n = 0;
+        for (int k = 0; k < nm; ++k) total_n += L.sn[k];
+        if (tau == 0.0) {
+            int best = -1, bestn = -1;                       // np.argmax: first maximum in label order
+            for (int k = 0; k < nm; ++k) if (L.sn[k] > bestn) { bestn = L.sn[k]; best = k; }
+            chosen = (best >= 0 && bestn > 0) ? (int)L.slab[best] : 0;
+        } else {
+            const double inv = 1.0 / tau;
+            double s = 0.0;
+            for (int k = 0; k < nm; ++k) {
+                const double pk = (double)L.sn[k] / (double)total_n;         // policy /= np.sum(policy)
+                const double rk = L.sn[k] > 0 ? pow(pk, inv) : 0.0;
+                L.dsc[k] = rk;
+                s += rk;
+            }
+            double total = 0.0;
+            for (int k = 0; k < nm; ++k) { L.dsc[k] = L.dsc[k] / s; total += L.dsc[k]; }
+            double c = 0.0;
+            int pick = -1;
+            for (int k = 0; k < nm; ++k) {                   // cdf.searchsorted(u, side='right')
+                c += L.dsc[k];
+                if (c / total > u) { pick = k; break; }
+            }
+            if (pick < 0) for (int k = nm - 1; k >= 0; --k) if (L.dsc[k] > 0.0) { pick = k; break; }
+            chosen = pick >= 0 ? (int)L.slab[pick] : 0;
+        }
+    }
+    wave_sync();
+    return uni(chosen);
+}
+
+XQ_D void store_key(uint32_t* dst, const uint32_t* key)
+{
+    const int lane = lane_id();
+    if (lane < KEY_WORDS) dst[lane] = key[lane];
+}
+
+XQ_D void set_init_board(int8_t* gb)
+{
+    // rkemsmekr/9/1c5c1/p1p1p1p1p/9/9/P1P1P1P1P/1C5C1/9/RKEMSMEKR (static_env.py:9)
+    const int lane = lane_id();
+    const int8_t back[9] = {ROOK, KNIGHT, ELEPHANT, ADVISOR, KING, ADVISOR, ELEPHANT, KNIGHT, ROOK};
+    for (int s = lane; s < BOARD_LDS; s += 64) {
+        int p = 0;
+        if (s < NSQ) {
+            const int x = s % 9, y = s / 9;
+            if (y == 0) p = back[x];
+            else if (y == 9) p = -back[x];
+            else if (y == 2 && (x == 1 || x == 7)) p = CANNON;
+            else if (y == 7 && (x == 1 || x == 7)) p = -CANNON;
+            else if (y == 3 && (x % 2 == 0)) p = PAWN;
+            else if (y == 6 && (x % 2 == 0)) p = -PAWN;
+        }
+        gb[s] = (int8_t)p;
+    }
+}
+
+// (re)start a self-play game in slot g (SelfPlayWorker.start_game, self_play.py:95-116)
+XQ_D void new_game(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L, uint32_t game_id)
+{
+    const int lane = lane_id();
+    const int g = gv.g;
+    clear_tree(P, B, gv);
+    set_init_board(B.g_board + (size_t)g * BOARD_LDS);
+    wave_sync();
+    const int8_t* gb = B.g_board + (size_t)g * BOARD_LDS;
+    L.r.bd[1][lane] = gb[lane];
+    if (lane < 32) L.r.bd[1][lane + 64] = gb[lane + 64];
+    wave_sync();
+    pack_key(L.r.bd[1], L.key);
+    store_key(B.g_hist_key + (size_t)g * (P.max_plies + 2) * KEY_WORDS, L.key);
+    if (lane == 0) {
+        B.g_game_id[g] = game_id;
+        B.g_turns[g] = 0;
+        B.g_no_eat[g] = 0;
+        B.g_n_no_act[g] = 0;
+        B.g_increase_temp[g] = 0;
+        // enable_resign = random() > enable_resign_rate (self_play.py:102-105): stream 0, draw 0
+        B.g_enable_resign[g] = philox_uniform(P.seed, game_id, 0, 0) > P.enable_resign_rate ? 1 : 0;
+    }
+    wave_sync();
+    begin_search(P, B, gv, L);
+}
+
+XQ_D void emit_record(const SearchParams& P, const SearchBuffers& B, const GameView& gv, int turns, int value,
+                      bool store, bool resigned)
+{
+    const int lane = lane_id();
+    const int g = gv.g;
+    unsigned int pos = 0;
+    if (lane == 0) pos = atomicAdd(B.ring_tail, 1u);
+    pos = uniu(pos);
+    uint8_t* rec = B.ring + (size_t)(pos % (unsigned)P.ring_cap) * P.record_stride;
+    if (lane == 0) {
+        GameRecord* hdr = reinterpret_cast<GameRecord*>(rec);
+        hdr->game_id = B.g_game_id[g];
+        hdr->turns = turns;
+        hdr->value = value;
+        hdr->flags = (store ? 1u : 0u) | (resigned ? 2u : 0u);
+    }
+    uint16_t* mv = reinterpret_cast<uint16_t*>(rec + sizeof(GameRecord));
+    const uint16_t* acts = B.g_hist_act + (size_t)g * (P.max_plies + 2);
+    for (int i = lane; i < turns && i < P.max_plies + 2; i += 64) mv[i] = acts[i];
+    count(gv, CT_GAMES);
+    count(gv, value > 0 ? CT_RED_WINS : (value < 0 ? CT_BLACK_WINS : CT_DRAWS));
+    if (resigned) count(gv, CT_RESIGNS);
+}
+
+// One ply of SelfPlayWorker.start_game after the search finished (self_play.py:124-212).
+XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L)
+{
+    const int lane = lane_id();
+    const int g = gv.g;
+    const uint32_t game_id = uniu(B.g_game_id[g]);
+    int turns = uni(B.g_turns[g]);
+    int8_t* gb = B.g_board + (size_t)g * BOARD_LDS;
+    uint32_t* hkeys = B.g_hist_key + (size_t)g * (P.max_plies + 2) * KEY_WORDS;
+    uint16_t* hacts = B.g_hist_act + (size_t)g * (P.max_plies + 2);
+    const double u = philox_uniform(P.seed, game_id, 1, (uint64_t)turns);
+    const int action = choose_action(P, B, gv, L, u, uni((int)B.g_enable_resign[g]) != 0);
+    count(gv, CT_PLIES);
+    bool game_over = false, resigned = false;
+    int value = 0;
+    int final_move = NOMOVE;
+    if (action < 0) {                                                  // resign, :126-129
+        value = -1; game_over = true; resigned = true;
+    } else {
+        // state, no_eat = senv.new_step(state, action)  (:133-141)
+        L.r.bd[0][lane] = gb[lane];
+        if (lane < 32) L.r.bd[0][lane + 64] = (lane < 26) ? gb[lane + 64] : (int8_t)0;
+        wave_sync();
+        const int ft = label_ft(action);
+        const int f = ft >> 8, t = ft & 0xFF;
+        const bool no_eat = L.r.bd[0][t] == 0;
+        step_board(L.r.bd[0], f, t, L.r.bd[3]);                         // bd[3] = new state, kept below
+        if (lane == 0) hacts[turns] = (uint16_t)action;
+        turns += 1;
+        int no_eat_count = uni(B.g_no_eat[g]);
+        no_eat_count = no_eat ? no_eat_count + 1 : 0;
+        const uint64_t h = pack_key(L.r.bd[3], L.key);
+        (void)h;
+        if (turns < P.max_plies + 2) store_key(hkeys + (size_t)turns * KEY_WORDS, L.key);
+        int n_no_act = 0, inc = 0;
+        if (no_eat_count >= 120 || turns >= 2 * P.max_game_length) {    // :149-151
+            game_over = true; value = 0;
+        } else {
+            const DoneResult d = wave_done(L.r.bd[3], L.r.bd[1], L.r.ml[0], L.r.ml[1], true);   // :153
+            game_over = d.over != 0; value = d.v; final_move = d.final_move;
+            if (!game_over && !wave_has_attack(L.r.bd[3])) { game_over = true; value = 0; }  // :154-158
+            if (!game_over && !d.check) {                               // :161-175
+                int free_move = 0;
+                // earlier states equal to this one, in order (both parities: the reference compares strings)
+                for (int i = 0; i < turns && !game_over; ++i) {
+                    const bool ne = lane < KEY_WORDS && hkeys[(size_t)i * KEY_WORDS + lane] != L.key[lane];
+                    if (__ballot(ne)) continue;
+                    const int mv = uni((int)hacts[i]);
+                    // the rule helpers need the position in bd[0]
+                    L.r.bd[0][lane] = L.r.bd[3][lane];
+                    if (lane < 32) L.r.bd[0][lane + 64] = L.r.bd[3][lane + 64];
+                    wave_sync();
+                    if (wave_will_check_or_catch(L.r, L.r.bd[0], mv) == 1) {
+                        if (n_no_act < MAX_NO_ACT) {
+                            if (lane == 0) B.g_no_act[(size_t)g * MAX_NO_ACT + n_no_act] = (uint16_t)mv;
+                            n_no_act += 1;
+                        }
+                    } else if (!wave_be_catched(L.r.bd[0], label_ft(mv) >> 8, L.r.bd[1], L.r.ml[0])) {
+                        inc = 1;
+                        free_move += 1;
+                        if (free_move >= 3) { game_over = true; value = 0; }
+                    }
+                }
+            }
+        }
+        // commit the new position
+        gb[lane] = L.r.bd[3][lane];
+        if (lane < 32) gb[lane + 64] = (lane < 26) ? L.r.bd[3][lane + 64] : (int8_t)0;
+        if (lane == 0) {
+            B.g_turns[g] = turns;
+            B.g_no_eat[g] = no_eat_count;
+            B.g_n_no_act[g] = (uint8_t)n_no_act;
+            B.g_increase_temp[g] = (uint8_t)inc;
+        }
+        wave_sync();
+    }
+    if (!game_over) {
+        begin_search(P, B, gv, L);
+        return;
+    }
+    if (final_move != NOMOVE) {                                         // :177-184
+        if (lane == 0 && turns < P.max_plies + 2) hacts[turns] = (uint16_t)final_move;
+        turns += 1;
+        value = -value;
+    }
+    if (turns % 2 == 1) value = -value;                                 // :190-191
+    bool store = true;
+    if (turns < 10) store = philox_uniform(P.seed, game_id, 0, 1) > 0.9;   // :194-200
+    wave_sync();
+    emit_record(P, B, gv, turns, value, store, resigned);
+    new_game(P, B, gv, L, game_id + P.game_id_stride);
+}
+
+// ---- the round kernel ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_round(SearchParams P, SearchBuffers B, const float* __restrict__ policy,
+                                             const float* __restrict__ value, void* planes)
+{
+    __shared__ SearchLDS L;
+    const int g = blockIdx.x;
+    if (g >= P.G) return;
+    const GameView gv = make_view(B, P, g);
+    const RoundIO io{planes, P.planes_dtype};
+    int phase = uni((int)B.g_phase[g]);
+    if (phase != PH_SEARCH && !(phase == PH_READY && P.mode == MODE_SELFPLAY)) return;
+    int active = uni(B.g_active[g]);
+    int root = uni(B.g_root[g]);
+    RootCtx rc{false, uni((int)B.g_n_no_act[g]), B.g_no_act + (size_t)g * MAX_NO_ACT, P.seed,
+               uniu(B.g_game_id[g]), uni(B.g_turns[g])};
+
+    if (phase == PH_SEARCH && active > 0) {
+        // 1. attach + backup evaluated leaves, in simulation order (update_tree, player.py:340-373)
+        for (int i = 0; i < P.K; ++i) {
+            if (uni((int)gv.s_state[i]) != SIM_LEAF) continue;
+            const int node = uni(gv.s_node[i]);
+            const int depth = uni(gv.s_depth[i]);
+            const size_t slot = (size_t)g * P.K + i;
+            attach_policy(gv, L, node, policy + slot * NLABELS);
+            load_path(P, gv, L, i, depth);
+            backup(P, gv, L, depth, (double)value[slot]);             // float(v) of a float32
+            sim_finish(gv, i, &active);
+        }
+        // 2. resume parked simulations, in simulation order (player.py:351-353)
+        for (int i = 0; i < P.K; ++i) {
+            if (uni((int)gv.s_state[i]) != SIM_PARKED) continue;
+            const int node = uni(gv.s_node[i]);
+            const int depth = uni(gv.s_depth[i]);
+            load_path(P, gv, L, i, depth);
+            run_sim(P, B, gv, L, io, rc, root, i, node, depth, &active);
+        }
+    }
+    // 3. next batch / next ply
+    for (int iter = 0; iter < 1024; ++iter) {
+        if (phase == PH_SEARCH && active == 0) {
+            int tasks = uni(B.g_tasks_left[g]);
+            if (tasks > 0) {
+                const int n = tasks < P.K ? tasks : P.K;                // player.py:169-178
+                tasks -= n;
+                active = n;
+                if (lane_id() == 0) B.g_tasks_left[g] = tasks;
+                for (int i = 0; i < n; ++i) {
+                    root = uni(B.g_root[g]);
+                    run_sim(P, B, gv, L, io, rc, root, i, root, 0, &active);
+                }
+                if (active > 0) break;
+                continue;
+            }
+            phase = PH_READY;
+        }
+        if (phase == PH_READY && P.mode == MODE_SELFPLAY) {
+            advance_game(P, B, gv, L);
+            phase = PH_SEARCH;
+            active = 0;
+            root = uni(B.g_root[g]);
+            rc.n_no_act = uni((int)B.g_n_no_act[g]);
+            rc.game_id = uniu(B.g_game_id[g]);
+            rc.turns = uni(B.g_turns[g]);
+            continue;
+        }
+        break;
+    }
+    if (lane_id() == 0) {
+        B.g_active[g] = active;
+        B.g_phase[g] = (uint8_t)phase;
+    }
+}
+
+// ---- auxiliary kernels ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_start_selfplay(SearchParams P, SearchBuffers B, uint32_t first_game_id)
+{
+    __shared__ SearchLDS L;
+    const int g = blockIdx.x;
+    if (g >= P.G) return;
+    const GameView gv = make_view(B, P, g);
+    const int lane = lane_id();
+    for (int i = lane; i < P.K; i += 64) gv.s_state[i] = SIM_IDLE;
+    for (int i = lane; i < CT_COUNT; i += 64) gv.ctr[i] = 0;
+    wave_sync();
+    new_game(P, B, gv, L, first_game_id + (uint32_t)g);
+}
+
+__global__ __launch_bounds__(64) void k_set_roots(SearchParams P, SearchBuffers B, const int8_t* __restrict__ boards,
+                                                 const int32_t* __restrict__ turns, const uint16_t* __restrict__ no_act,
+                                                 const uint8_t* __restrict__ n_no_act, const uint8_t* __restrict__ inc,
+                                                 const uint8_t* __restrict__ enable_resign,
+                                                 const uint8_t* __restrict__ select_mask)
+{
+    __shared__ SearchLDS L;
+    const int g = blockIdx.x;
+    if (g >= P.G) return;
+    if (select_mask && !select_mask[g]) return;
+    const GameView gv = make_view(B, P, g);
+    const int lane = lane_id();
+    load_board(boards + (size_t)g * NSQ, L.r.bd[0]);
+    int8_t* gb = B.g_board + (size_t)g * BOARD_LDS;
+    gb[lane] = L.r.bd[0][lane];
+    if (lane < 32) gb[lane + 64] = L.r.bd[0][lane + 64];
+    const int nna = n_no_act ? (int)n_no_act[g] : 0;
+    if (lane < MAX_NO_ACT) B.g_no_act[(size_t)g * MAX_NO_ACT + lane] = (no_act && lane < nna) ? no_act[(size_t)g * MAX_NO_ACT + lane] : (uint16_t)NOMOVE;
+    for (int i = lane; i < P.K; i += 64) gv.s_state[i] = SIM_IDLE;
+    if (lane == 0) {
+        B.g_turns[g] = turns ? turns[g] : 0;
+        B.g_n_no_act[g] = (uint8_t)(nna < MAX_NO_ACT ? nna : MAX_NO_ACT);
+        B.g_increase_temp[g] = inc ? inc[g] : 0;
+        B.g_enable_resign[g] = enable_resign ? enable_resign[g] : 0;
+    }
+    wave_sync();
+    // a terminal root has nothing to search (the reference's simulations would all return at once)
+    const DoneResult d = wave_done(L.r.bd[0], L.r.bd[1], L.r.ml[0], L.r.ml[1], false);
+    begin_search(P, B, gv, L);
+    if (d.over && lane == 0) { B.g_tasks_left[g] = 0; }
+}
+
+__global__ __launch_bounds__(64) void k_reset_trees(SearchParams P, SearchBuffers B)
+{
+    const int g = blockIdx.x;
+    if (g >= P.G) return;
+    const GameView gv = make_view(B, P, g);
+    clear_tree(P, B, gv);
+    const int lane = lane_id();
+    for (int i = lane; i < P.K; i += 64) gv.s_state[i] = SIM_IDLE;
+    if (lane == 0) { B.g_phase[g] = PH_IDLE; B.g_active[g] = 0; B.g_tasks_left[g] = 0; }
+}
+
+__global__ void k_pending(SearchParams P, SearchBuffers B)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < P.G && B.g_phase[g] == PH_SEARCH) atomicAdd(B.pending, 1);
+}
+
+__global__ __launch_bounds__(64) void k_root_stats(SearchParams P, SearchBuffers B, uint16_t* __restrict__ moves,
+                                                  int32_t* __restrict__ n, double* __restrict__ w,
+                                                  float* __restrict__ p, int32_t* __restrict__ sum_n,
+                                                  uint8_t* __restrict__ counts)
+{
+    const int g = blockIdx.x;
+    if (g >= P.G) return;
+    const GameView gv = make_view(B, P, g);
+    const int lane = lane_id();
+    const int root = B.g_root[g];
+    int nm = 0, eoff = 0;
+    if (root >= 0) { nm = (int)(gv.node_meta[root] & 0xFF); eoff = (int)gv.node_eoff[root]; }
+    for (int j = lane; j < MAXMOVES; j += 64) {
+        const bool ok = j < nm;
+        if (moves) moves[(size_t)g * MAXMOVES + j] = ok ? gv.e_mv[eoff + j] : (uint16_t)NOMOVE;
+        if (n) n[(size_t)g * MAXMOVES + j] = ok ? gv.e_n[eoff + j] : 0;
+        if (w) w[(size_t)g * MAXMOVES + j] = ok ? gv.e_w[eoff + j] : 0.0;
+        if (p) p[(size_t)g * MAXMOVES + j] = ok ? gv.e_p[eoff + j] : 0.0f;
+    }
+    if (lane == 0) {
+        if (sum_n) sum_n[g] = root >= 0 ? gv.node_sum_n[root] : 0;
+        if (counts) counts[g] = (uint8_t)nm;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_choose(SearchParams P, SearchBuffers B, const double* __restrict__ u,
+                                              int32_t* __restrict__ action)
+{
+    __shared__ SearchLDS L;
+    const int g = blockIdx.x;
+    if (g >= P.G) return;
+    const GameView gv = make_view(B, P, g);
+    const int a = choose_action(P, B, gv, L, u ? u[g] : 0.5, B.g_enable_resign[g] != 0);
+    if (lane_id() == 0) action[g] = a;
+}
+
+__global__ void k_debug_sqrt(const int32_t* __restrict__ x, double* __restrict__ y, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = __dsqrt_rn((double)(x[i] + 1));
+}
+
+}  // namespace
+
+// ---- host side: the opaque search object ----------------------------------------------------------------------
+struct cz_search {
+    SearchParams P;
+    SearchBuffers B;
+    void* slab;
+    size_t bytes;
+    int device;
+};
+
+namespace {
+
+int serr(int code, const char* what)
+{
+    czi_set_error(what);
+    return code;
+}
+int serr_hip(const char* what, hipError_t e)
+{
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    czi_set_error(buf);
+    return CZ_ERR_HIP;
+}
+
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <typename T>
+void carve(char*& cur, T*& ptr, size_t count, bool dry)
+{
+    if (!dry) ptr = reinterpret_cast<T*>(cur);
+    cur += align_up(sizeof(T) * count);
+}
+
+size_t layout(cz_search* s, char* base, bool dry)
+{
+    const SearchParams& P = s->P;
+    SearchBuffers& B = s->B;
+    char* cur = base;
+    const size_t G = (size_t)P.G, C = (size_t)P.node_cap, E = (size_t)P.edge_cap, H = (size_t)P.hash_cap;
+    const size_t K = (size_t)P.K, D = (size_t)P.max_depth, PL = (size_t)P.max_plies + 2;
+    carve(cur, B.node_key, G * C * KEY_WORDS, dry);
+    carve(cur, B.node_sum_n, G * C, dry);
+    carve(cur, B.node_eoff, G * C, dry);
+    carve(cur, B.node_meta, G * C, dry);
+    carve(cur, B.hash_tab, G * H, dry);
+    carve(cur, B.e_n, G * E, dry);
+    carve(cur, B.e_w, G * E, dry);
+    carve(cur, B.e_p, G * E, dry);
+    carve(cur, B.e_mv, G * E, dry);
+    carve(cur, B.e_child, G * E, dry);
+    carve(cur, B.g_node_count, G, dry);
+    carve(cur, B.g_edge_count, G, dry);
+    carve(cur, B.g_root, G, dry);
+    carve(cur, B.g_board, G * BOARD_LDS, dry);
+    carve(cur, B.g_tasks_left, G, dry);
+    carve(cur, B.g_active, G, dry);
+    carve(cur, B.g_phase, G, dry);
+    carve(cur, B.g_turns, G, dry);
+    carve(cur, B.g_no_act, G * MAX_NO_ACT, dry);
+    carve(cur, B.g_n_no_act, G, dry);
+    carve(cur, B.g_increase_temp, G, dry);
+    carve(cur, B.s_state, G * K, dry);
+    carve(cur, B.s_depth, G * K, dry);
+    carve(cur, B.s_node, G * K, dry);
+    carve(cur, B.s_path_node, G * K * D, dry);
+    carve(cur, B.s_path_edge, G * K * D, dry);
+    carve(cur, B.g_game_id, G, dry);
+    carve(cur, B.g_enable_resign, G, dry);
+    carve(cur, B.g_no_eat, G, dry);
+    carve(cur, B.g_hist_key, G * PL * KEY_WORDS, dry);
+    carve(cur, B.g_hist_act, G * PL, dry);
+    carve(cur, B.counters, G * CT_COUNT, dry);
+    carve(cur, B.ring, (size_t)P.ring_cap * P.record_stride, dry);
+    carve(cur, B.ring_tail, 1, dry);
+    carve(cur, B.g_last_action, G, dry);
+    carve(cur, B.pending, 1, dry);
+    return (size_t)(cur - base);
+}
+
+}  // namespace
+
+extern "C" {
+
+int cz_search_create(const cz_search_cfg* c, cz_search** out)
+{
+    if (!c || !out) return serr(CZ_ERR_ARG, "cz_search_create: null argument");
+    if (c->n_games < 1 || c->sims_per_round < 1 || c->simulation_num_per_move < 1)
+        return serr(CZ_ERR_ARG, "cz_search_create: n_games, sims_per_round, simulation_num_per_move must be >= 1");
+    cz_search* s = new (std::nothrow) cz_search();
+    if (!s) return serr(CZ_ERR_NOMEM, "cz_search_create: host allocation failed");
+    SearchParams& P = s->P;
+    P.G = c->n_games;
+    P.K = c->sims_per_round;
+    P.sims = c->simulation_num_per_move;
+    P.vl = c->virtual_loss;
+    P.node_cap = c->node_capacity > 0 ? c->node_capacity : 4 * P.sims + 64;
+    if (P.node_cap < P.sims + 2) P.node_cap = P.sims + 2;
+    P.edge_cap = c->edge_capacity > 0 ? c->edge_capacity : P.node_cap * 56;
+    if (P.edge_cap < (P.sims + 2) * 64) P.edge_cap = (P.sims + 2) * 64;
+    int h = 1;
+    while (h < 2 * P.node_cap) h <<= 1;
+    P.hash_cap = h;
+    P.max_depth = c->max_depth > 0 ? c->max_depth : 64;
+    if (P.max_depth > MAXD_LDS) P.max_depth = MAXD_LDS;
+    P.max_game_length = c->max_game_length > 0 ? c->max_game_length : 100;
+    P.max_plies = 2 * P.max_game_length + 2;
+    P.planes_dtype = c->planes_dtype;
+    P.mode = MODE_EXTERNAL;
+    P.c_puct = c->c_puct;
+    P.c_puct_f32 = (float)c->c_puct;
+    P.noise_eps = c->noise_eps;
+    P.one_minus_eps_f32 = (float)(1.0 - c->noise_eps);
+    P.dirichlet_alpha = c->dirichlet_alpha;
+    P.tau_decay_rate = c->tau_decay_rate;
+    P.resign_threshold = c->resign_threshold;
+    P.min_resign_turn = c->min_resign_turn;
+    P.evaluate = c->evaluate;
+    P.enable_resign_rate = c->enable_resign_rate;
+    P.seed = c->seed;
+    P.game_id_stride = (uint32_t)P.G;
+    P.ring_cap = c->ring_capacity > 0 ? c->ring_capacity : 2 * P.G + 64;
+    P.record_stride = (int)((sizeof(GameRecord) + sizeof(uint16_t) * (size_t)(P.max_plies + 2) + 15) & ~(size_t)15);
+    if (P.planes_dtype < CZ_F32 || P.planes_dtype > CZ_U8) { delete s; return serr(CZ_ERR_ARG, "cz_search_create: planes_dtype"); }
+    s->bytes = layout(s, nullptr, true);
+    hipError_t e = hipGetDevice(&s->device);
+    if (e != hipSuccess) { delete s; return serr_hip("cz_search_create: hipGetDevice", e); }
+    e = hipMalloc(&s->slab, s->bytes);
+    if (e != hipSuccess) { delete s; return serr_hip("cz_search_create: hipMalloc", e); }
+    e = hipMemset(s->slab, 0, s->bytes);
+    if (e != hipSuccess) { hipFree(s->slab); delete s; return serr_hip("cz_search_create: hipMemset", e); }
+    layout(s, (char*)s->slab, false);
+    *out = s;
+    return CZ_OK;
+}
+
+int cz_search_destroy(cz_search* s)
+{
+    if (!s) return CZ_OK;
+    hipFree(s->slab);
+    delete s;
+    return CZ_OK;
+}
+
+size_t cz_search_bytes(const cz_search* s) { return s ? s->bytes : 0; }
+
+int cz_search_info(const cz_search* s, int32_t* out)
+{
+    if (!s || !out) return serr(CZ_ERR_ARG, "cz_search_info: null argument");
+    out[0] = s->P.G; out[1] = s->P.K; out[2] = s->P.sims; out[3] = s->P.node_cap; out[4] = s->P.edge_cap;
+    out[5] = s->P.hash_cap; out[6] = s->P.max_depth; out[7] = s->P.max_plies; out[8] = s->P.record_stride;
+    out[9] = s->P.ring_cap; out[10] = CT_COUNT; out[11] = s->P.mode;
+    return CZ_OK;
+}
+
+#define S_LAUNCH_CHECK(name)                                         \
+    do {                                                             \
+        hipError_t e_ = hipGetLastError();                           \
+        if (e_ != hipSuccess) return serr_hip(name, e_);             \
+    } while (0)
+
+int cz_search_start_selfplay(cz_search* s, uint64_t seed, uint32_t first_game_id, uint32_t game_id_stride, void* stream)
+{
+    if (!s) return serr(CZ_ERR_ARG, "cz_search_start_selfplay: null handle");
+    s->P.mode = MODE_SELFPLAY;
+    s->P.seed = seed;
+    s->P.game_id_stride = game_id_stride ? game_id_stride : (uint32_t)s->P.G;
+    hipError_t e = hipMemsetAsync(s->B.ring_tail, 0, sizeof(unsigned int), (hipStream_t)stream);
+    if (e != hipSuccess) return serr_hip("cz_search_start_selfplay", e);
+    hipLaunchKernelGGL(k_start_selfplay, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, first_game_id);
+    S_LAUNCH_CHECK("cz_search_start_selfplay");
+    return CZ_OK;
+}
+
+int cz_search_set_roots(cz_search* s, const int8_t* boards, const int32_t* turns, const uint16_t* no_act,
+                        const uint8_t* n_no_act, const uint8_t* increase_temp, const uint8_t* enable_resign,
+                        const uint8_t* select_mask, void* stream)
+{
+    if (!s || !boards) return serr(CZ_ERR_ARG, "cz_search_set_roots: null argument");
+    s->P.mode = MODE_EXTERNAL;
+    hipLaunchKernelGGL(k_set_roots, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, boards, turns, no_act,
+                       n_no_act, increase_temp, enable_resign, select_mask);
+    S_LAUNCH_CHECK("cz_search_set_roots");
+    return CZ_OK;
+}
+
+int cz_search_round(cz_search* s, const float* policy, const float* value, void* planes, void* stream)
+{
+    if (!s || !planes || !policy || !value) return serr(CZ_ERR_ARG, "cz_search_round: null argument");
+    hipLaunchKernelGGL(k_round, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, policy, value, planes);
+    S_LAUNCH_CHECK("cz_search_round");
+    return CZ_OK;
+}
+
+int cz_search_reset_trees(cz_search* s, void* stream)
+{
+    if (!s) return serr(CZ_ERR_ARG, "cz_search_reset_trees: null handle");
+    hipLaunchKernelGGL(k_reset_trees, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B);
+    S_LAUNCH_CHECK("cz_search_reset_trees");
+    return CZ_OK;
+}
+
+int cz_search_pending(cz_search* s, int* host_out, void* stream)
+{
+    if (!s || !host_out) return serr(CZ_ERR_ARG, "cz_search_pending: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(s->B.pending, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return serr_hip("cz_search_pending", e);
+    hipLaunchKernelGGL(k_pending, dim3((s->P.G + 255) / 256), dim3(256), 0, st, s->P, s->B);
+    S_LAUNCH_CHECK("cz_search_pending");
+    int32_t v = 0;
+    e = hipMemcpyAsync(&v, s->B.pending, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return serr_hip("cz_search_pending", e);
+    *host_out = v;
+    return CZ_OK;
+}
+
+int cz_search_root_stats(cz_search* s, uint16_t* moves, int32_t* n, double* w, float* p, int32_t* sum_n,
+                         uint8_t* counts, void* stream)
+{
+    if (!s) return serr(CZ_ERR_ARG, "cz_search_root_stats: null handle");
+    hipLaunchKernelGGL(k_root_stats, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, moves, n, w, p, sum_n, counts);
+    S_LAUNCH_CHECK("cz_search_root_stats");
+    return CZ_OK;
+}
+
+int cz_search_choose(cz_search* s, const double* u, int32_t* action, void* stream)
+{
+    if (!s || !action) return serr(CZ_ERR_ARG, "cz_search_choose: null argument");
+    hipLaunchKernelGGL(k_choose, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, u, action);
+    S_LAUNCH_CHECK("cz_search_choose");
+    return CZ_OK;
+}
+
+int cz_search_counters(cz_search* s, uint64_t* host_out, void* stream)
+{
+    if (!s || !host_out) return serr(CZ_ERR_ARG, "cz_search_counters: null argument");
+    const size_t n = (size_t)s->P.G * CT_COUNT;
+    unsigned long long* tmp = new (std::nothrow) unsigned long long[n];
+    if (!tmp) return serr(CZ_ERR_NOMEM, "cz_search_counters: host allocation failed");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(tmp, s->B.counters, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { delete[] tmp; return serr_hip("cz_search_counters", e); }
+    for (int c = 0; c < CT_COUNT; ++c) host_out[c] = 0;
+    for (int g = 0; g < s->P.G; ++g)
+        for (int c = 0; c < CT_COUNT; ++c) {
+            const unsigned long long v = tmp[(size_t)g * CT_COUNT + c];
+            if (c == CT_MAX_DEPTH) { if (v > host_out[c]) host_out[c] = v; }
+            else host_out[c] += v;
+        }
+    delete[] tmp;
+    return CZ_OK;
+}
+
+int cz_search_drain_records(cz_search* s, unsigned int* cursor, void* host_buf, int max_records, int* n_out, void* stream)
+{
+    if (!s || !cursor || !host_buf || !n_out) return serr(CZ_ERR_ARG, "cz_search_drain_records: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned int tail = 0;
+    hipError_t e = hipMemcpyAsync(&tail, s->B.ring_tail, sizeof(tail), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return serr_hip("cz_search_drain_records", e);
+    unsigned int cur = *cursor;
+    if (tail - cur > (unsigned)s->P.ring_cap) cur = tail - (unsigned)s->P.ring_cap;   // overwritten records are lost
+    int n = 0;
+    while (cur != tail && n < max_records) {
+        const size_t off = (size_t)(cur % (unsigned)s->P.ring_cap) * s->P.record_stride;
+        e = hipMemcpyAsync((char*)host_buf + (size_t)n * s->P.record_stride, s->B.ring + off, s->P.record_stride,
+                           hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return serr_hip("cz_search_drain_records", e);
+        ++cur; ++n;
+    }
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return serr_hip("cz_search_drain_records", e);
+    *cursor = cur;
+    *n_out = n;
+    return CZ_OK;
+}
+
+int cz_debug_sqrt(const int32_t* x, double* y, int n, void* stream)
+{
+    if (n <= 0) return CZ_OK;
+    hipLaunchKernelGGL(k_debug_sqrt, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    S_LAUNCH_CHECK("cz_debug_sqrt");
+    return CZ_OK;
+}
+
+}  // extern "C"

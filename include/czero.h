@@ -21,6 +21,7 @@
 #ifndef CZERO_H
 #define CZERO_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -85,6 +86,79 @@ int cz_has_attack(const int8_t* boards, int n, uint8_t* out, void* stream);
 /* move-gen + done(need_check=True) + planes in one pass (the SURVEY 8(d) micro-suite kernel). */
 int cz_rules_fused(const int8_t* boards, int n, uint16_t* moves, uint8_t* counts, int8_t* over, int8_t* v,
                    uint16_t* final_move, uint8_t* check, void* planes, int dtype, void* stream);
+
+/* ---- batched PUCT-MCTS + self-play game loop: one wavefront per game ---------------------------
+ * Replaces agent/player.py::CChessPlayer (action :145-196, MCTS_search :198-260,
+ * select_action_q_and_u :262-320, expand_and_evaluate :322-338, update_tree :340-373, calc_policy
+ * :375-406, apply_temperature :453-470) and worker/self_play.py::SelfPlayWorker.start_game :95-212
+ * for n_games concurrent games.  The network stays with the caller: each cz_search_round() consumes the
+ * policy/value rows of the previous round and writes the input planes of the new leaves; the evaluation
+ * queue has one fixed slot per (game, simulation): slot = game * sims_per_round + sim.
+ */
+typedef struct cz_search cz_search;
+
+typedef struct cz_search_cfg {
+    int32_t n_games;                 /* G: concurrent games = wavefronts */
+    int32_t sims_per_round;          /* K: config.play.search_threads (lock-step batch per game) */
+    int32_t simulation_num_per_move; /* config.play.simulation_num_per_move */
+    int32_t virtual_loss;            /* config.play.virtual_loss */
+    int32_t node_capacity;           /* per game; 0 = 4 * sims + 64.  the tree is dropped when a ply may not fit */
+    int32_t edge_capacity;           /* per game; 0 = 56 * node_capacity */
+    int32_t max_depth;               /* longest path of one simulation; 0 = 64, at most 128 */
+    int32_t max_game_length;         /* config.play.max_game_length (full moves) */
+    int32_t planes_dtype;            /* CZ_F32 / CZ_F16 / CZ_BF16 / CZ_U8 */
+    int32_t min_resign_turn;         /* config.play.min_resign_turn */
+    int32_t evaluate;                /* config.opts.evaluate */
+    int32_t ring_capacity;           /* finished-game records kept on the device; 0 = 2 * n_games + 64 */
+    double c_puct, noise_eps, dirichlet_alpha, tau_decay_rate, resign_threshold, enable_resign_rate;
+    uint64_t seed;                   /* counter-based RNG key (Philox4x32-10): u(seed, game_id, stream, index) */
+} cz_search_cfg;
+
+/* finished-game record in the ring: this header, then uint16 moves[max_plies + 2] (labels, mover frame) */
+typedef struct cz_game_record {
+    uint32_t game_id;
+    int32_t turns;                   /* number of moves recorded */
+    int32_t value;                   /* +1 red won, -1 black won, 0 draw (self_play.py:190-191) */
+    uint32_t flags;                  /* bit 0: store (self_play.py:194-200), bit 1: ended by resignation */
+} cz_game_record;
+
+int cz_search_create(const cz_search_cfg* cfg, cz_search** out);   /* allocates device memory on the current device */
+int cz_search_destroy(cz_search* s);
+size_t cz_search_bytes(const cz_search* s);
+/* out[12]: G, K, sims, node_cap, edge_cap, hash_cap, max_depth, max_plies, record_stride, ring_cap, n_counters, mode */
+int cz_search_info(const cz_search* s, int32_t* out);
+
+/* self-play mode: every slot plays games from INIT_STATE forever; slot g starts with game id
+ * first_game_id + g and continues with + game_id_stride after each finished game (0 = n_games). */
+int cz_search_start_selfplay(cz_search* s, uint64_t seed, uint32_t first_game_id, uint32_t game_id_stride, void* stream);
+
+/* external mode (CChessPlayer.action): set the position to search for each game.  boards [G][90];
+ * turns [G] or NULL; no_act [G][16] + n_no_act [G] or NULL; increase_temp / enable_resign [G] or NULL;
+ * select_mask [G] or NULL (only games with a non-zero byte are touched).  Trees are kept (subtree reuse). */
+int cz_search_set_roots(cz_search* s, const int8_t* boards, const int32_t* turns, const uint16_t* no_act,
+                        const uint8_t* n_no_act, const uint8_t* increase_temp, const uint8_t* enable_resign,
+                        const uint8_t* select_mask, void* stream);
+
+/* one lock-step round for all games.  policy [G*K][2086] float32, value [G*K] float32 (results for the
+ * planes written by the previous round; ignored for slots that had no leaf), planes [G*K][14][10][9]. */
+int cz_search_round(cz_search* s, const float* policy, const float* value, void* planes, void* stream);
+
+int cz_search_reset_trees(cz_search* s, void* stream);
+/* synchronises the stream; *host_out = number of games whose current search is unfinished */
+int cz_search_pending(cz_search* s, int* host_out, void* stream);
+/* root edges after a search: moves/n/w/p [G][128], sum_n [G], counts [G] (any may be NULL) */
+int cz_search_root_stats(cz_search* s, uint16_t* moves, int32_t* n, double* w, float* p, int32_t* sum_n,
+                         uint8_t* counts, void* stream);
+/* calc_policy + apply_temperature + np.random.choice with the uniform draws u [G] (NULL = 0.5):
+ * action [G] = label, or -1 when the player resigns */
+int cz_search_choose(cz_search* s, const double* u, int32_t* action, void* stream);
+/* HOST out[n_counters] (order: enum Counter in csrc/xq_search.h); synchronises the stream */
+int cz_search_counters(cz_search* s, uint64_t* host_out, void* stream);
+/* copies finished-game records (record_stride bytes each) written since *cursor into HOST memory */
+int cz_search_drain_records(cz_search* s, unsigned int* cursor, void* host_buf, int max_records, int* n_out,
+                            void* stream);
+/* test hook: y[i] = sqrt((double)(x[i] + 1)) exactly as the PUCT kernel computes it */
+int cz_debug_sqrt(const int32_t* x, double* y, int n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -234,3 +234,178 @@ def be_catched(state, action):
 
 def has_attack_chessman(state):
     return bool(lib().xqo_has_attack_chessman(_p(state_to_board(state), C.c_int8)))
+
+
+# ---- MCTS / self-play restatement (oracle/xq_mcts.c) ---------------------------------------------
+class PlayCfg(C.Structure):
+    _fields_ = [("simulation_num_per_move", C.c_int), ("search_threads", C.c_int), ("c_puct", C.c_double),
+                ("noise_eps", C.c_double), ("dirichlet_alpha", C.c_double), ("tau_decay_rate", C.c_double),
+                ("virtual_loss", C.c_int), ("resign_threshold", C.c_double), ("min_resign_turn", C.c_int),
+                ("evaluate", C.c_int), ("max_game_length", C.c_int), ("enable_resign_rate", C.c_double)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("sims", "expansions", "terminal_sims", "repetition_sims", "parked",
+                                          "nn_batches", "nn_positions", "max_depth", "sum_depth",
+                                          "sum_edges_visited", "sum_leaf_moves")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float))
+RNG_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int, C.c_uint64)
+
+
+def play_cfg(simulation_num_per_move=100, search_threads=1, c_puct=1.5, noise_eps=0.0, dirichlet_alpha=0.2,
+             tau_decay_rate=0.0, virtual_loss=3, resign_threshold=-0.92, min_resign_turn=20, evaluate=0,
+             max_game_length=100, enable_resign_rate=1.0):
+    return PlayCfg(simulation_num_per_move, search_threads, c_puct, noise_eps, dirichlet_alpha, tau_decay_rate,
+                   virtual_loss, resign_threshold, min_resign_turn, evaluate, max_game_length, enable_resign_rate)
+
+
+_mcts_sig_done = False
+
+
+def _mcts_lib():
+    global _mcts_sig_done
+    L = lib()
+    if not _mcts_sig_done:
+        i8p, u16p = C.POINTER(C.c_int8), C.POINTER(C.c_uint16)
+        dp = C.POINTER(C.c_double)
+        L.xqo_player_create.argtypes = [C.POINTER(PlayCfg), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.xqo_player_create.restype = C.c_void_p
+        L.xqo_player_destroy.argtypes = [C.c_void_p]
+        L.xqo_player_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+        L.xqo_player_tree_size.argtypes = [C.c_void_p]; L.xqo_player_tree_size.restype = C.c_int
+        L.xqo_player_search.argtypes = [C.c_void_p, i8p, C.c_int, u16p, C.c_int, C.c_int, dp]
+        L.xqo_player_search.restype = C.c_int
+        L.xqo_sample_action.argtypes = [C.POINTER(PlayCfg), dp, C.c_int, C.c_int, C.c_double]
+        L.xqo_sample_action.restype = C.c_int
+        L.xqo_player_action.argtypes = [C.c_void_p, i8p, C.c_int, u16p, C.c_int, C.c_int, C.c_double, dp]
+        L.xqo_player_action.restype = C.c_int
+        L.xqo_player_node_stats.argtypes = [C.c_void_p, i8p, u16p, C.POINTER(C.c_int32), dp, C.POINTER(C.c_float),
+                                            C.POINTER(C.c_int)]
+        L.xqo_player_node_stats.restype = C.c_int
+        L.xqo_selfplay_game.argtypes = [C.POINTER(PlayCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u16p,
+                                        C.c_int, dp, C.POINTER(C.c_int), C.POINTER(Counters), C.POINTER(C.c_uint32)]
+        L.xqo_selfplay_game.restype = C.c_int
+        L.xqo_philox_uniform.argtypes = [C.c_void_p, C.c_int, C.c_uint64]; L.xqo_philox_uniform.restype = C.c_double
+        _mcts_sig_done = True
+    return L
+
+
+class _Stub:
+    """Resolves a stub spec to (function pointer, ctx pointer, keepalive)."""
+
+    def __init__(self, spec):
+        L = _mcts_lib()
+        if callable(spec):
+            def cb(ctx, planes, n, policy, value, _f=spec):
+                pl = np.ctypeslib.as_array(planes, shape=(n, 14, 10, 9))
+                p, v = _f(pl)
+                np.ctypeslib.as_array(policy, shape=(n, NLABELS))[:] = p
+                np.ctypeslib.as_array(value, shape=(n,))[:] = v
+            self.keep = EVAL_FN(cb)
+            self.fn = C.cast(self.keep, C.c_void_p)
+            self.ctx = None
+        elif spec["kind"] == "uniform":
+            self.keep = C.c_float(spec.get("value", 0.0))
+            self.fn = C.cast(L.xqo_stub_uniform, C.c_void_p)
+            self.ctx = C.cast(C.pointer(self.keep), C.c_void_p)
+        else:
+            self.keep = C.c_uint64(spec["salt"])
+            self.fn = C.cast(L.xqo_stub_hash, C.c_void_p)
+            self.ctx = C.cast(C.pointer(self.keep), C.c_void_p)
+
+
+class _Rng:
+    def __init__(self, seed, game_id):
+        L = _mcts_lib()
+        self.keep = (C.c_uint64 * 2)(seed, game_id)
+        self.fn = C.cast(L.xqo_philox_uniform, C.c_void_p)
+        self.ctx = C.cast(self.keep, C.c_void_p)
+
+
+def philox_uniform(seed, game_id, stream, idx):
+    r = _Rng(seed, game_id)
+    return _mcts_lib().xqo_philox_uniform(r.ctx, stream, idx)
+
+
+class Player:
+    """C restatement of CChessPlayer (agent/player.py); stub = {'kind': 'uniform'|'hash', ...} or a
+    python callable planes[n,14,10,9] -> (policy[n,2086], value[n])."""
+
+    def __init__(self, cfg, stub, enable_resign=False, seed=0, game_id=0):
+        self.L = _mcts_lib()
+        self.cfg = cfg
+        self.stub = _Stub(stub)
+        self.rng = _Rng(seed, game_id)
+        self.h = self.L.xqo_player_create(C.byref(cfg), int(enable_resign), self.stub.fn, self.stub.ctx,
+                                          self.rng.fn, self.rng.ctx)
+
+    def close(self):
+        if self.h:
+            self.L.xqo_player_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _na(self, no_act):
+        arr = np.array([label_of_str(m) for m in (no_act or [])], dtype=np.uint16)
+        return arr, (_p(arr, C.c_uint16) if len(arr) else None)
+
+    def search(self, state, turns=0, no_act=None, increase_temp=False):
+        b = state_to_board(state) if isinstance(state, str) else np.ascontiguousarray(state, dtype=np.int8)
+        arr, ptr = self._na(no_act)
+        pol = np.zeros(NLABELS, dtype=np.float64)
+        resign = self.L.xqo_player_search(self.h, _p(b, C.c_int8), turns, ptr, len(arr), int(increase_temp),
+                                          _p(pol, C.c_double))
+        return bool(resign), pol
+
+    def action(self, state, turns=0, no_act=None, increase_temp=False, u=0.5):
+        b = state_to_board(state) if isinstance(state, str) else np.ascontiguousarray(state, dtype=np.int8)
+        arr, ptr = self._na(no_act)
+        pol = np.zeros(NLABELS, dtype=np.float64)
+        a = self.L.xqo_player_action(self.h, _p(b, C.c_int8), turns, ptr, len(arr), int(increase_temp), u,
+                                     _p(pol, C.c_double))
+        return (None if a < 0 else label_str(a)), pol
+
+    def node_stats(self, state):
+        b = state_to_board(state) if isinstance(state, str) else np.ascontiguousarray(state, dtype=np.int8)
+        mv = np.zeros(MAXMOVES, dtype=np.uint16)
+        n = np.zeros(MAXMOVES, dtype=np.int32)
+        w = np.zeros(MAXMOVES, dtype=np.float64)
+        pr = np.zeros(MAXMOVES, dtype=np.float32)
+        sn = C.c_int()
+        c = self.L.xqo_player_node_stats(self.h, _p(b, C.c_int8), _p(mv, C.c_uint16), _p(n, C.c_int32),
+                                         _p(w, C.c_double), _p(pr, C.c_float), C.byref(sn))
+        if c < 0:
+            return None
+        return dict(moves=mv[:c].copy(), n=n[:c].copy(), w=w[:c].copy(), p=pr[:c].copy(), sum_n=sn.value)
+
+    def counters(self):
+        c = Counters()
+        self.L.xqo_player_counters(self.h, C.byref(c))
+        return c.as_dict()
+
+    def tree_size(self):
+        return self.L.xqo_player_tree_size(self.h)
+
+
+def sample_action(cfg, policy, turns, increase_temp, u):
+    pol = np.ascontiguousarray(policy, dtype=np.float64)
+    return _mcts_lib().xqo_sample_action(C.byref(cfg), _p(pol, C.c_double), turns, int(increase_temp), u)
+
+
+def selfplay_game(cfg, stub, seed, game_id, max_plies=512):
+    """SelfPlayWorker.start_game restated; returns dict(moves, value, store, turns, counters, visit_crc)."""
+    L = _mcts_lib()
+    st, rng = _Stub(stub), _Rng(seed, game_id)
+    moves = np.zeros(max_plies + 8, dtype=np.uint16)
+    crc = np.zeros(max_plies + 8, dtype=np.uint32)
+    value, store, ctr = C.c_double(), C.c_int(), Counters()
+    turns = L.xqo_selfplay_game(C.byref(cfg), st.fn, st.ctx, rng.fn, rng.ctx, _p(moves, C.c_uint16), max_plies,
+                                C.byref(value), C.byref(store), C.byref(ctr), _p(crc, C.c_uint32))
+    return dict(moves=[label_str(m) for m in moves[:turns]], value=value.value, store=bool(store.value),
+                turns=turns, counters=ctr.as_dict(), visit_crc=crc[:turns].copy())

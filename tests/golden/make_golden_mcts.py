@@ -1,0 +1,227 @@
+"""MCTS / self-play golden vectors, produced by running the REFERENCE's own CChessPlayer and
+SelfPlayWorker (imported read-only from /root/reference) against the deterministic stub networks
+of tests/stub_net.py.  search_threads = 1 (the only deterministic mode of the reference), noise 0.
+
+Environment control (no reference code is modified):
+  * tensorflow / keras are MagicMock modules (absent here; only needed to import worker/self_play.py)
+  * np.random.dirichlet -> constant (its value is multiplied by noise_eps = 0)
+  * np.random.choice / random.random are replaced by functions that consume the counter-based
+    uniform stream (Philox) the engine uses, via NumPy's documented choice algorithm
+    (cdf.searchsorted(u, side='right')), so sampled games are reproducible by the engine.
+"""
+import json
+import os
+import sys
+import zlib
+from unittest.mock import MagicMock
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+for p in (REF, os.path.join(REF, "cchess_alphazero"), os.path.dirname(HERE)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import stub_net  # noqa: E402  (tests/stub_net.py)
+
+import cchess_alphazero.environment.static_env as senv  # noqa: E402
+from cchess_alphazero.config import Config  # noqa: E402
+from cchess_alphazero.environment.lookup_tables import ActionLabelsRed  # noqa: E402
+import cchess_alphazero.agent.player as ref_player  # noqa: E402
+
+LABEL = {m: i for i, m in enumerate(ActionLabelsRed)}
+
+
+def meta():
+    return {"numpy": np.__version__, "python": sys.version.split()[0],
+            "generator": "tests/golden/make_golden_mcts.py",
+            "reference": "NeymarL/ChineseChess-AlphaZero @ /root/reference, search_threads=1"}
+
+
+def make_cfg(sims, c_puct=1.5, tau_decay_rate=0.0, vl=3, **kw):
+    cfg = Config('mini')
+    pc = cfg.play
+    pc.simulation_num_per_move = sims
+    pc.search_threads = 1
+    pc.c_puct = c_puct
+    pc.noise_eps = 0
+    pc.tau_decay_rate = tau_decay_rate
+    pc.virtual_loss = vl
+    for k, v in kw.items():
+        setattr(pc, k, v)
+    return cfg
+
+
+def stub_fn(spec):
+    if spec["kind"] == "uniform":
+        return lambda planes: stub_net.uniform_stub_numpy(planes, spec.get("value", 0.0))
+    return lambda planes: stub_net.hash_stub_numpy(planes, spec["salt"])
+
+
+def root_stats(player, state):
+    node = player.tree[state]
+    moves = node.legal_moves
+    n = [int(node.a[m].n) if m in node.a else 0 for m in moves]
+    w = [float(node.a[m].w) if m in node.a else 0.0 for m in moves]
+    p = [float(np.float32(node.a[m].p)) if m in node.a else 0.0 for m in moves]
+    return {"moves": " ".join(moves), "n": n, "w_hex": [float(x).hex() for x in w],
+            "p_hex": [float(x).hex() for x in p], "sum_n": int(node.sum_n)}
+
+
+def visit_crc(moves, n):
+    mv = np.array([LABEL[m] for m in moves], dtype=np.uint16)
+    nn = np.array(n, dtype=np.int32)
+    return zlib.crc32(nn.tobytes(), zlib.crc32(mv.tobytes())) & 0xFFFFFFFF
+
+
+def gen_mcts():
+    np.random.dirichlet = lambda alpha, size=None: np.full(len(alpha), 1.0 / len(alpha))
+    midgame = 'r1e1s1e1r/4m4/2k1c1k2/p1p1p1p1p/9/2P6/P3P1P1P/1CK1C1K2/9/R1EMSME1R'
+    endgame = '3s5/4m4/9/9/4p4/2R6/9/4C4/4M4/3MS4'
+    mate1 = '4s4/9/9/9/9/9/9/9/3R5/3S1R3'          # mover can take the king next ply lines nearby
+    cases = [
+        dict(name="uniform_100", state=senv.INIT_STATE, sims=100, stub=dict(kind="uniform", value=0.0)),
+        dict(name="uniform_800", state=senv.INIT_STATE, sims=800, stub=dict(kind="uniform", value=0.0)),
+        dict(name="uniform_v025_200", state=senv.INIT_STATE, sims=200, stub=dict(kind="uniform", value=0.25)),
+        dict(name="hash1_50", state=senv.INIT_STATE, sims=50, stub=dict(kind="hash", salt=1)),
+        dict(name="hash1_800", state=senv.INIT_STATE, sims=800, stub=dict(kind="hash", salt=1)),
+        dict(name="hash2_400_c5", state=senv.INIT_STATE, sims=400, c_puct=5.0, stub=dict(kind="hash", salt=2)),
+        dict(name="hash3_mid_400", state=midgame, sims=400, stub=dict(kind="hash", salt=3)),
+        dict(name="hash4_end_600", state=endgame, sims=600, stub=dict(kind="hash", salt=4)),
+        dict(name="hash5_mate_300", state=mate1, sims=300, stub=dict(kind="hash", salt=5)),
+        dict(name="hash6_noact_200", state=senv.INIT_STATE, sims=200, stub=dict(kind="hash", salt=6),
+             no_act=['1219', '7279', '1242']),
+        dict(name="hash7_vl1_300", state=midgame, sims=300, vl=1, stub=dict(kind="hash", salt=7)),
+    ]
+    out = []
+    for c in cases:
+        cfg = make_cfg(c["sims"], c_puct=c.get("c_puct", 1.5), vl=c.get("vl", 3))
+        pipe = stub_net.StubPipe(stub_fn(c["stub"]))
+        pl = ref_player.CChessPlayer(cfg, search_tree=None, pipes=pipe, enable_resign=False, debugging=False)
+        action, policy = pl.action(c["state"], 0, c.get("no_act"))
+        rec = dict(c)
+        rec.update(root_stats(pl, c["state"]))
+        rec["action"] = action
+        rec["policy_crc"] = zlib.crc32(np.asarray(policy, dtype=np.float64).tobytes()) & 0xFFFFFFFF
+        rec["tree_size"] = len(pl.tree)
+        rec["nn_positions"] = pipe.n_positions
+        out.append(rec)
+        pl.close()
+        print(c["name"], "action", action, "tree", rec["tree_size"], "evals", pipe.n_positions, flush=True)
+
+    # multi-ply lines with subtree reuse (tau = 0 -> argmax move, deterministic)
+    lines = []
+    for salt, sims, plies in ((11, 60, 14), (12, 150, 8)):
+        cfg = make_cfg(sims)
+        pipe = stub_net.StubPipe(stub_fn(dict(kind="hash", salt=salt)))
+        pl = ref_player.CChessPlayer(cfg, search_tree=None, pipes=pipe, enable_resign=False)
+        state, steps = senv.INIT_STATE, []
+        for turn in range(plies):
+            if senv.done(state)[0]:
+                break
+            before = pipe.n_positions
+            action, _ = pl.action(state, turn)
+            st = root_stats(pl, state)
+            steps.append({"state": state, "action": action, "sum_n": st["sum_n"], "n": st["n"],
+                          "moves": st["moves"], "evals": pipe.n_positions - before})
+            state = senv.step(state, action)
+        pl.close()
+        lines.append({"salt": salt, "sims": sims, "steps": steps})
+        print("line salt", salt, "plies", len(steps), "evals/ply", [s["evals"] for s in steps], flush=True)
+
+    with open(os.path.join(HERE, "mcts_k1.json"), "w") as f:
+        json.dump({"meta": meta(), "cases": out, "lines": lines}, f, separators=(",", ":"))
+
+
+def _shim_tf():
+    for name in ("tensorflow", "keras", "keras.engine", "keras.engine.topology", "keras.engine.training",
+                 "keras.layers", "keras.layers.convolutional", "keras.layers.core", "keras.layers.merge",
+                 "keras.layers.normalization", "keras.regularizers", "keras.backend", "keras.models",
+                 "keras.optimizers", "keras.callbacks", "keras.utils"):
+        sys.modules.setdefault(name, MagicMock())
+
+
+def gen_games():
+    _shim_tf()
+    import cchess_alphazero.worker.self_play as sp
+    from collections import defaultdict
+
+    specs = [
+        dict(name="argmax_a", salt=21, sims=40, tau=0.0, max_game_length=30, seed=1001),
+        dict(name="argmax_b", salt=22, sims=25, tau=0.0, max_game_length=40, seed=1002),
+        dict(name="sampled_a", salt=23, sims=40, tau=0.98, max_game_length=25, seed=1003),
+        dict(name="sampled_b", salt=24, sims=30, tau=0.9, max_game_length=30, seed=1004),
+        dict(name="resign", salt=25, sims=40, tau=0.0, max_game_length=40, seed=1005,
+             enable_resign_rate=0.0, resign_threshold=-0.35, min_resign_turn=6),
+        dict(name="short_c3", salt=26, sims=30, tau=0.98, max_game_length=12, seed=1006, c_puct=3.0),
+    ]
+    games = []
+    for s in specs:
+        cfg = make_cfg(s["sims"], c_puct=s.get("c_puct", 1.5), tau_decay_rate=s["tau"],
+                       max_game_length=s["max_game_length"],
+                       enable_resign_rate=s.get("enable_resign_rate", 1.0),
+                       resign_threshold=s.get("resign_threshold", -0.92),
+                       min_resign_turn=s.get("min_resign_turn", 20))
+        cfg.play_data.nb_game_in_file = 1
+        seed, game_id = s["seed"], 0
+        calls = {"choice": 0, "random": 0}
+        ply_log = []
+
+        def fake_choice(a, p=None, _c=calls):
+            u = stub_net.philox_uniform(seed, game_id, 1, _c["choice"])
+            _c["choice"] += 1
+            return stub_net.numpy_choice(p, u)
+
+        def fake_random(_c=calls):
+            u = stub_net.philox_uniform(seed, game_id, 0, _c["random"])
+            _c["random"] += 1
+            return u
+
+        np.random.choice = fake_choice
+        np.random.dirichlet = lambda alpha, size=None: np.full(len(alpha), 1.0 / len(alpha))
+        sp.random = fake_random
+
+        orig_action = ref_player.CChessPlayer.action
+
+        def logged_action(self, state, turns, no_act=None, depth=None, infinite=False, hist=None,
+                          increase_temp=False, _orig=orig_action, _log=ply_log):
+            r = _orig(self, state, turns, no_act, depth, infinite, hist, increase_temp)
+            node = self.tree[state]
+            n = [int(node.a[m].n) if m in node.a else 0 for m in node.legal_moves]
+            _log.append({"crc": visit_crc(node.legal_moves, n), "sum_n": int(node.sum_n),
+                         "no_act": list(no_act or []), "inc": bool(increase_temp)})
+            return r
+
+        ref_player.CChessPlayer.action = logged_action
+        sp.CChessPlayer.action = logged_action
+        saved = {}
+
+        def fake_save(self, idx, data, _s=saved):
+            _s["data"] = data
+
+        sp.SelfPlayWorker.save_play_data = fake_save
+        sp.SelfPlayWorker.remove_play_data = lambda self: None
+        pipe = stub_net.StubPipe(stub_fn(dict(kind="hash", salt=s["salt"])))
+        worker = sp.SelfPlayWorker(cfg, pipes=[pipe], pid=0, use_history=False)
+        v, turns, state, store = worker.start_game(1, defaultdict(ref_player.VisitState))
+        ref_player.CChessPlayer.action = orig_action
+        sp.CChessPlayer.action = orig_action
+        rec = dict(s)
+        rec.update({"value": v, "turns": turns, "final_state": state, "store": bool(store),
+                    "record": saved.get("data"), "plies": ply_log, "nn_positions": pipe.n_positions,
+                    "n_random_calls": calls["random"], "n_choice_calls": calls["choice"]})
+        games.append(rec)
+        print(s["name"], "turns", turns, "value", v, "store", store, "evals", pipe.n_positions,
+              "no_act plies", sum(1 for p in ply_log if p["no_act"]),
+              "inc_temp plies", sum(1 for p in ply_log if p["inc"]), flush=True)
+    with open(os.path.join(HERE, "games_k1.json"), "w") as f:
+        json.dump({"meta": meta(), "games": games}, f, separators=(",", ":"))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("mcts", "all"):
+        gen_mcts()
+    if what in ("games", "all"):
+        gen_games()

@@ -1,0 +1,271 @@
+"""-m gpu: the HIP MCTS / self-play kernels (through the C-ABI) against the oracle (oracle/xq_mcts.c)
+and against the golden vectors recorded from the reference's own CChessPlayer / SelfPlayWorker.
+The network is stubbed by the exact-arithmetic stub of tests/stub_net.py (torch version on the GPU),
+so visit counts, W sums (float64, compared bit for bit) and priors (float32) must be identical."""
+import json
+import os
+import types
+import zlib
+
+import numpy as np
+import pytest
+
+import stub_net
+from oracle import xq_oracle as xo
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+MID = 'r1e1s1e1r/4m4/2k1c1k2/p1p1p1p1p/9/2P6/P3P1P1P/1CK1C1K2/9/R1EMSME1R'
+END = '3s5/4m4/9/9/4p4/2R6/9/4C4/4M4/3MS4'
+MATE = '4s4/9/9/9/9/9/9/9/3R5/3S1R3'
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    from cchess_alphazero import _native, _native_search
+    _native.require_gpu()
+    return types.SimpleNamespace(torch=torch, N=_native, S=_native_search)
+
+
+def play_config(**kw):
+    d = dict(simulation_num_per_move=100, search_threads=1, c_puct=1.5, noise_eps=0.0, dirichlet_alpha=0.2,
+             tau_decay_rate=0.0, virtual_loss=3, resign_threshold=-0.92, min_resign_turn=20, max_game_length=100,
+             enable_resign_rate=1.0)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def oracle_cfg(pc, evaluate=0):
+    return xo.play_cfg(simulation_num_per_move=pc.simulation_num_per_move, search_threads=pc.search_threads,
+                       c_puct=pc.c_puct, noise_eps=pc.noise_eps, dirichlet_alpha=pc.dirichlet_alpha,
+                       tau_decay_rate=pc.tau_decay_rate, virtual_loss=pc.virtual_loss,
+                       resign_threshold=pc.resign_threshold, min_resign_turn=pc.min_resign_turn, evaluate=evaluate,
+                       max_game_length=pc.max_game_length, enable_resign_rate=pc.enable_resign_rate)
+
+
+def stub_eval(gpu, spec):
+    if spec["kind"] == "uniform":
+        val = float(spec.get("value", 0.0))
+
+        def f(planes):
+            n = planes.shape[0]
+            return (gpu.torch.full((n, 2086), np.float32(1.0 / 2086.0), dtype=gpu.torch.float32, device=planes.device),
+                    gpu.torch.full((n,), np.float32(val), dtype=gpu.torch.float32, device=planes.device))
+        return f
+    return lambda planes: stub_net.hash_stub_torch(planes, spec["salt"])
+
+
+def boards_tensor(gpu, states):
+    return gpu.torch.from_numpy(np.stack([xo.state_to_board(s) for s in states])).cuda()
+
+
+def no_act_tensors(gpu, lists):
+    G = len(lists)
+    na = np.full((G, 16), 0xFFFF, dtype=np.uint16)
+    nn = np.zeros(G, dtype=np.uint8)
+    for g, l in enumerate(lists):
+        for k, m in enumerate(l or []):
+            na[g, k] = xo.label_of_str(m)
+        nn[g] = len(l or [])
+    t = gpu.torch
+    return t.from_numpy(na.view(np.int16)).cuda().view(t.uint16), t.from_numpy(nn).cuda()
+
+
+def assert_root_equal(st, g, ref, what=""):
+    c = int(st["counts"][g])
+    assert c == len(ref["moves"]), what
+    assert (st["moves"][g, :c] == ref["moves"]).all(), what
+    assert int(st["sum_n"][g]) == ref["sum_n"], (what, int(st["sum_n"][g]), ref["sum_n"])
+    assert (st["n"][g, :c] == ref["n"]).all(), (what, st["n"][g, :c], ref["n"])
+    assert (st["w"][g, :c].view(np.uint64) == np.asarray(ref["w"], dtype=np.float64).view(np.uint64)).all(), what
+    assert (st["p"][g, :c].view(np.uint32) == np.asarray(ref["p"], dtype=np.float32).view(np.uint32)).all(), what
+
+
+def test_sqrt_is_correctly_rounded(gpu):
+    t = gpu.torch
+    x = t.arange(0, 1 << 21, dtype=t.int32, device="cuda")
+    y = gpu.S.debug_sqrt(x).cpu().numpy()
+    assert (y == np.sqrt(np.arange(1, (1 << 21) + 1, dtype=np.float64))).all()
+
+
+@pytest.mark.parametrize("K,sims,spec", [
+    (1, 200, dict(kind="hash", salt=1)),
+    (1, 120, dict(kind="uniform", value=0.25)),
+    (8, 400, dict(kind="hash", salt=2)),
+    (5, 203, dict(kind="hash", salt=3)),
+])
+def test_search_matches_oracle(gpu, K, sims, spec):
+    states = [xo.INIT_STATE, MID, END, MATE, xo.step(xo.INIT_STATE, '1242'), xo.fliped_state(MID)]
+    pc = play_config(simulation_num_per_move=sims, search_threads=K)
+    s = gpu.S.Search(pc, len(states), seed=7)
+    s.set_roots(boards_tensor(gpu, states))
+    s.run_until_idle(stub_eval(gpu, spec))
+    st = s.root_stats()
+    ctr = s.counters()
+    tot = dict(sims=0, expansions=0, terminal_sims=0, repetition_sims=0, parked=0)
+    for g, state in enumerate(states):
+        pl = xo.Player(oracle_cfg(pc), spec)
+        pl.search(state)
+        assert_root_equal(st, g, pl.node_stats(state), f"game {g} K={K}")
+        c = pl.counters()
+        for k in tot:
+            tot[k] += c[k]
+        pl.close()
+    for k, v in tot.items():
+        assert ctr[k] == v, (k, ctr[k], v)
+    assert ctr["overflow_sims"] == 0 and ctr["depth_overflow"] == 0 and ctr["tree_resets"] == 0
+    s.close()
+
+
+def test_no_act_and_choose(gpu):
+    pc = play_config(simulation_num_per_move=150, search_threads=1, tau_decay_rate=0.98)
+    spec = dict(kind="hash", salt=6)
+    bans = [['1219', '7279', '1242'], None, ['0001']]
+    states = [xo.INIT_STATE, xo.INIT_STATE, MID]
+    turns = [0, 5, 40]
+    s = gpu.S.Search(pc, 3, seed=3)
+    na, nn = no_act_tensors(gpu, bans)
+    t = gpu.torch
+    s.set_roots(boards_tensor(gpu, states), turns=t.tensor(turns, dtype=t.int32, device="cuda"), no_act=na, n_no_act=nn)
+    s.run_until_idle(stub_eval(gpu, spec))
+    st = s.root_stats()
+    us = [0.1234, 0.77, 0.5]
+    act = s.choose(us)
+    for g in range(3):
+        pl = xo.Player(oracle_cfg(pc), spec)
+        a, pol = pl.action(states[g], turns[g], bans[g], False, us[g])
+        assert_root_equal(st, g, pl.node_stats(states[g]), f"game {g}")
+        assert xo.label_str(int(act[g])) == a
+        pl.close()
+    s.close()
+
+
+def test_multi_ply_reuse_matches_oracle(gpu):
+    pc = play_config(simulation_num_per_move=80, search_threads=4)
+    spec = dict(kind="hash", salt=11)
+    G = 4
+    s = gpu.S.Search(pc, G, seed=1, node_capacity=4096)
+    players = [xo.Player(oracle_cfg(pc), spec) for _ in range(G)]
+    states = [xo.INIT_STATE, xo.step(xo.INIT_STATE, '7242'), MID, xo.INIT_STATE]
+    t = gpu.torch
+    for ply in range(10):
+        s.set_roots(boards_tensor(gpu, states), turns=t.full((G,), ply, dtype=t.int32, device="cuda"))
+        s.run_until_idle(stub_eval(gpu, spec))
+        st = s.root_stats()
+        act = s.choose(None)
+        for g in range(G):
+            a, _ = players[g].action(states[g], ply, None, False, 0.5)
+            assert_root_equal(st, g, players[g].node_stats(states[g]), f"ply {ply} game {g}")
+            assert xo.label_str(int(act[g])) == a
+            states[g] = xo.step(states[g], a)
+    assert s.counters()["tree_resets"] == 0
+    for p in players:
+        p.close()
+    s.close()
+
+
+def run_selfplay(gpu, pc, spec, G, seed, games_wanted, max_rounds=200000, **kw):
+    s = gpu.S.Search(pc, G, seed=seed, **kw)
+    ev = stub_eval(gpu, spec)
+    s.start_selfplay(seed=seed, first_game_id=0)
+    recs = {}
+    for r in range(max_rounds):
+        s.round()
+        p, v = ev(s.planes)
+        s.policy.copy_(p)
+        s.value.copy_(v)
+        if r % 64 == 63:
+            for rec in s.drain_records():
+                recs[rec["game_id"]] = rec
+            if all(g in recs for g in range(games_wanted)):
+                break
+    ctr = s.counters()
+    s.close()
+    return recs, ctr
+
+
+@pytest.mark.parametrize("K,tau", [(1, 0.0), (1, 0.98), (4, 0.9)])
+def test_selfplay_games_match_oracle(gpu, K, tau):
+    pc = play_config(simulation_num_per_move=24, search_threads=K, tau_decay_rate=tau, max_game_length=16,
+                     enable_resign_rate=0.5, resign_threshold=-0.4, min_resign_turn=4)
+    spec = dict(kind="hash", salt=31)
+    G, seed = 12, 4242
+    recs, ctr = run_selfplay(gpu, pc, spec, G, seed, G, node_capacity=24 * 40)
+    assert ctr["tree_resets"] == 0 and ctr["overflow_sims"] == 0
+    for gid in range(G):
+        ref = xo.selfplay_game(oracle_cfg(pc), spec, seed, gid)
+        got = recs[gid]
+        moves = [xo.label_str(int(m)) for m in got["moves"]]
+        assert moves == ref["moves"], (gid, moves, ref["moves"])
+        assert got["turns"] == ref["turns"] and got["value"] == int(ref["value"]) and got["store"] == ref["store"]
+
+
+# ---- golden vectors recorded from the reference itself -----------------------------------------------------
+def _golden(name):
+    path = os.path.join(GOLDEN, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not generated")
+    with open(path) as f:
+        return json.load(f)
+
+
+def test_golden_reference_searches(gpu):
+    data = _golden("mcts_k1.json")
+    for c in data["cases"]:
+        pc = play_config(simulation_num_per_move=c["sims"], search_threads=1, c_puct=c.get("c_puct", 1.5),
+                         virtual_loss=c.get("vl", 3))
+        s = gpu.S.Search(pc, 1, seed=0)
+        na, nn = no_act_tensors(gpu, [c.get("no_act")])
+        s.set_roots(boards_tensor(gpu, [c["state"]]), no_act=na, n_no_act=nn)
+        s.run_until_idle(stub_eval(gpu, c["stub"]))
+        st = s.root_stats()
+        ref = dict(moves=np.array([xo.label_of_str(m) for m in c["moves"].split()], dtype=np.uint16),
+                   n=np.array(c["n"], dtype=np.int32), sum_n=c["sum_n"],
+                   w=np.array([float.fromhex(x) for x in c["w_hex"]]),
+                   p=np.array([float.fromhex(x) for x in c["p_hex"]], dtype=np.float32))
+        assert_root_equal(st, 0, ref, c["name"])
+        assert xo.label_str(int(s.choose(None)[0])) == c["action"], c["name"]
+        assert s.counters()["expansions"] == c["nn_positions"], c["name"]
+        s.close()
+
+
+def test_golden_reference_lines(gpu):
+    data = _golden("mcts_k1.json")
+    t = gpu.torch
+    for line in data["lines"]:
+        pc = play_config(simulation_num_per_move=line["sims"], search_threads=1)
+        s = gpu.S.Search(pc, 1, seed=0, node_capacity=line["sims"] * (len(line["steps"]) + 2))
+        spec = dict(kind="hash", salt=line["salt"])
+        prev = 0
+        for turn, step in enumerate(line["steps"]):
+            s.set_roots(boards_tensor(gpu, [step["state"]]), turns=t.tensor([turn], dtype=t.int32, device="cuda"))
+            s.run_until_idle(stub_eval(gpu, spec))
+            st = s.root_stats()
+            c = int(st["counts"][0])
+            assert " ".join(xo.label_str(int(m)) for m in st["moves"][0, :c]) == step["moves"]
+            assert st["n"][0, :c].tolist() == step["n"] and int(st["sum_n"][0]) == step["sum_n"]
+            assert xo.label_str(int(s.choose(None)[0])) == step["action"]
+            ex = s.counters()["expansions"]
+            assert ex - prev == step["evals"]
+            prev = ex
+        s.close()
+
+
+def test_golden_reference_games(gpu):
+    data = _golden("games_k1.json")
+    for gm in data["games"]:
+        pc = play_config(simulation_num_per_move=gm["sims"], search_threads=1, c_puct=gm.get("c_puct", 1.5),
+                         tau_decay_rate=gm["tau"], max_game_length=gm["max_game_length"],
+                         enable_resign_rate=gm.get("enable_resign_rate", 1.0),
+                         resign_threshold=gm.get("resign_threshold", -0.92),
+                         min_resign_turn=gm.get("min_resign_turn", 20))
+        recs, ctr = run_selfplay(gpu, pc, dict(kind="hash", salt=gm["salt"]), 1, gm["seed"], 1,
+                                 node_capacity=gm["sims"] * (2 * gm["max_game_length"] + 4))
+        got = recs[0]
+        rec = gm["record"]
+        if rec is not None:
+            ref_moves = [m for m, _ in rec[1:]]
+            assert [xo.label_str(int(m)) for m in got["moves"]] == ref_moves, gm["name"]
+        assert got["turns"] == gm["turns"] and got["value"] == int(gm["value"]) and got["store"] == gm["store"]

@@ -1,0 +1,140 @@
+"""Pins oracle/xq_mcts.c (the C restatement of agent/player.py and worker/self_play.py) against the
+golden vectors recorded from the reference's own CChessPlayer / SelfPlayWorker (search_threads=1).  CPU only."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import stub_net
+from oracle import xq_oracle as xo
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _golden(name):
+    path = os.path.join(GOLDEN, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not generated")
+    with open(path) as f:
+        return json.load(f)
+
+
+def test_stub_nets_agree():
+    boards = [xo.state_to_board(xo.INIT_STATE), xo.state_to_board('3s5/4m4/9/9/4p4/2R6/9/4C4/4M4/3MS4')]
+    planes = np.stack([xo.planes_board(b) for b in boards])
+    p, v = stub_net.hash_stub_numpy(planes, 9)
+    import torch
+    pt, vt = stub_net.hash_stub_torch(torch.from_numpy(planes), 9)
+    assert np.array_equal(pt.numpy(), p) and np.array_equal(vt.numpy(), v)
+    # the C stub, through a 1-simulation search of each position: the root priors are p / sum(p) in float32
+    for i, b in enumerate(boards):
+        pl = xo.Player(xo.play_cfg(simulation_num_per_move=2), {"kind": "hash", "salt": 9})
+        pl.search(b)
+        st = pl.node_stats(b)
+        raw = p[i][st["moves"]]
+        s = np.float32(0)
+        for x in raw:
+            s = np.float32(s + x)
+        assert np.array_equal(st["p"], (raw / s).astype(np.float32))
+        pl.close()
+    assert xo.philox_uniform(1003, 5, 1, 7) == stub_net.philox_uniform(1003, 5, 1, 7)
+
+
+def test_reference_searches():
+    data = _golden("mcts_k1.json")
+    for c in data["cases"]:
+        cfg = xo.play_cfg(simulation_num_per_move=c["sims"], search_threads=1, c_puct=c.get("c_puct", 1.5),
+                          virtual_loss=c.get("vl", 3))
+        pl = xo.Player(cfg, c["stub"])
+        a, pol = pl.action(c["state"], 0, c.get("no_act"), False, 0.5)
+        st = pl.node_stats(c["state"])
+        assert " ".join(xo.label_str(int(m)) for m in st["moves"]) == c["moves"], c["name"]
+        assert st["n"].tolist() == c["n"], c["name"]
+        assert st["sum_n"] == c["sum_n"]
+        assert [float(x).hex() for x in st["w"]] == c["w_hex"], c["name"]
+        assert [float(x).hex() for x in st["p"]] == c["p_hex"], c["name"]
+        assert a == c["action"]
+        assert zlib.crc32(pol.tobytes()) & 0xFFFFFFFF == c["policy_crc"], c["name"]
+        assert pl.tree_size() == c["tree_size"] and pl.counters()["nn_positions"] == c["nn_positions"]
+        pl.close()
+
+
+def test_reference_lines_with_subtree_reuse():
+    data = _golden("mcts_k1.json")
+    for line in data["lines"]:
+        cfg = xo.play_cfg(simulation_num_per_move=line["sims"], search_threads=1)
+        pl = xo.Player(cfg, {"kind": "hash", "salt": line["salt"]})
+        prev = 0
+        for turn, step in enumerate(line["steps"]):
+            a, _ = pl.action(step["state"], turn, None, False, 0.5)
+            st = pl.node_stats(step["state"])
+            assert st["n"].tolist() == step["n"] and st["sum_n"] == step["sum_n"], (line["salt"], turn)
+            assert a == step["action"]
+            ev = pl.counters()["nn_positions"]
+            assert ev - prev == step["evals"]
+            prev = ev
+        pl.close()
+
+
+def test_reference_games():
+    data = _golden("games_k1.json")
+    for gm in data["games"]:
+        cfg = xo.play_cfg(simulation_num_per_move=gm["sims"], search_threads=1, c_puct=gm.get("c_puct", 1.5),
+                          tau_decay_rate=gm["tau"], max_game_length=gm["max_game_length"],
+                          enable_resign_rate=gm.get("enable_resign_rate", 1.0),
+                          resign_threshold=gm.get("resign_threshold", -0.92),
+                          min_resign_turn=gm.get("min_resign_turn", 20))
+        r = xo.selfplay_game(cfg, {"kind": "hash", "salt": gm["salt"]}, gm["seed"], 0)
+        assert r["turns"] == gm["turns"], gm["name"]
+        assert r["value"] == gm["value"] and r["store"] == gm["store"], gm["name"]
+        if gm["record"] is not None:
+            rec = gm["record"]
+            assert rec[0] == xo.INIT_STATE
+            assert r["moves"] == [m for m, _ in rec[1:]], gm["name"]
+            v = gm["value"]
+            assert [x for _, x in rec[1:]] == [v * (-1) ** i for i in range(gm["turns"])]
+        assert r["visit_crc"][:len(gm["plies"])].tolist() == [p["crc"] for p in gm["plies"]], gm["name"]
+        assert r["counters"]["nn_positions"] == gm["nn_positions"]
+
+
+def test_sampling_matches_numpy_choice():
+    rng = np.random.default_rng(5)
+    cfg = xo.play_cfg(tau_decay_rate=0.98)
+    for trial in range(300):
+        counts = np.zeros(2086)
+        idx = rng.choice(2086, size=rng.integers(2, 45), replace=False)
+        counts[idx] = rng.integers(0, 200, size=len(idx))
+        if counts.sum() == 0:
+            continue
+        policy = counts / counts.sum()
+        turns = int(rng.integers(0, 40))
+        inc = bool(rng.integers(0, 2))
+        u = float(rng.random())
+        tau = 0.98 ** (turns + 1) if turns < 30 else 0
+        if tau < 0.1:
+            tau = 0
+        if inc:
+            tau = 0.5
+        if tau == 0:
+            exp = int(np.argmax(policy))
+        else:
+            ret = np.power(policy, 1 / tau)
+            ret /= np.sum(ret)
+            exp = stub_net.numpy_choice(ret, u)
+        assert xo.sample_action(cfg, policy, turns, inc, u) == exp
+
+
+def test_k_gt_1_is_deterministic_and_complete():
+    cfg = xo.play_cfg(simulation_num_per_move=203, search_threads=8)
+    a = xo.Player(cfg, {"kind": "hash", "salt": 2})
+    b = xo.Player(cfg, {"kind": "hash", "salt": 2})
+    a.search(xo.INIT_STATE)
+    b.search(xo.INIT_STATE)
+    sa, sb = a.node_stats(xo.INIT_STATE), b.node_stats(xo.INIT_STATE)
+    assert np.array_equal(sa["n"], sb["n"]) and np.array_equal(sa["w"], sb["w"])
+    assert sa["sum_n"] == 203 and sa["n"].sum() == 202          # root expansion takes one simulation
+    c = a.counters()
+    assert c["sims"] == 203 and c["parked"] > 0
+    a.close(); b.close()
