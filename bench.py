@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play hot-path throughput on MI355X (metric of BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one lock-step ROUND of the hot path over every concurrent game of the rank:
+k_round (hand-written HIP: backup / PUCT select / expand / game rules, leaf planes into the queue) followed by
+one ResNet forward over the whole evaluation queue.  Workload at N=1 = BASELINE.json configs[1] ("normal"):
+4096 concurrent games per GPU, 800 sims/move, 7-block x 128-filter net, random-init weights, synthetic self-play
+from the opening position.  Games shard across ranks (disjoint game ids, no data-path collective); RCCL is used
+only to all-reduce the counters.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "chinesechess-alphazero_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--config", default="normal", choices=["mini", "normal", "deep", "eval"])
+    ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (default: config)")
+    ap.add_argument("--sims-per-round", type=int, default=None, help="K, lock-step batch per game")
+    ap.add_argument("--dtype", default=None, choices=["float32", "bfloat16", "float16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--graph", action="store_true", help="replay each round from a HIP graph")
+    return ap.parse_args()
+
+
+def build_config(args):
+    from cchess_alphazero.config import Config
+    from cchess_alphazero.configs._tables import benchmark_overrides
+    cfg = Config("normal")
+    m, p, e = benchmark_overrides(args.config)
+    for k, v in m.items():
+        setattr(cfg.model, k, v)
+    for k, v in p.items():
+        setattr(cfg.play, k, v)
+    for k, v in e.items():
+        setattr(cfg.engine, k, v)
+    if args.games:
+        cfg.engine.games_per_gpu = args.games
+    if args.sims_per_round:
+        cfg.play.search_threads = args.sims_per_round
+    if args.dtype:
+        cfg.engine.net_dtype = args.dtype
+    return cfg
+
+
+def cpu_baseline(cfg, seconds):
+    """The oracle (C port of the reference's player.py + static_env.py) on ONE host core, same search
+    parameters, network replaced by the hash stub (tree + rules only, like BASELINE.md section 2)."""
+    from oracle import xq_oracle as xo
+    pc = cfg.play
+    ocfg = xo.play_cfg(simulation_num_per_move=pc.simulation_num_per_move, search_threads=pc.search_threads,
+                       c_puct=pc.c_puct, noise_eps=0.0, dirichlet_alpha=pc.dirichlet_alpha, tau_decay_rate=0.0,
+                       virtual_loss=pc.virtual_loss, max_game_length=pc.max_game_length)
+    pl = xo.Player(ocfg, {"kind": "hash", "salt": 1})
+    state, turn = xo.INIT_STATE, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        a, _ = pl.action(state, turn, None, False, 0.5)
+        if a is None:
+            break
+        state = xo.step(state, a)
+        turn += 1
+        if xo.done(state)[0] or turn >= 2 * pc.max_game_length:
+            state, turn = xo.INIT_STATE, 0
+    dt = time.perf_counter() - t0
+    c = pl.counters()
+    pl.close()
+    return {"value": c["expansions"] / dt, "unit": "expansions/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/xq_mcts.c, {turn} plies of one game, {pc.simulation_num_per_move} sims/move, "
+                      f"K={pc.search_threads}, hash-stub net (tree+rules only), {dt:.1f} s on 1 core of "
+                      f"{os.cpu_count()} ({c['sims']} sims)",
+            "sims_per_s": c["sims"] / dt}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    from cchess_alphazero.agent.model import flops_per_position
+    from cchess_alphazero.engine import SelfPlayEngine, bytes_per_expansion
+
+    cfg = build_config(args)
+    dtype = getattr(torch, cfg.engine.net_dtype)
+    G = cfg.engine.games_per_gpu
+    eng = SelfPlayEngine(cfg, G, dtype=dtype, seed=20260923)
+    eng.start(first_game_id=rank * G, game_id_stride=world * G)
+    K = eng.search.K
+
+    for _ in range(args.warmup):
+        eng.step()
+    if args.graph:
+        eng.capture_graph(warmup=0)
+    torch.cuda.synchronize()
+    c0 = eng.counters()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if args.graph:
+            eng.step()
+        else:
+            ev[i][0].record()
+            eng.search.round()
+            ev[i][1].record()
+            eng._forward()
+            eng.rounds += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c1 = eng.counters()
+
+    keys = ["sims", "expansions", "terminal_sims", "repetition_sims", "parked", "sum_depth", "edges_visited",
+            "leaf_moves", "plies", "games", "tree_resets", "overflow_sims", "depth_overflow"]
+    delta = torch.tensor([c1[k] - c0[k] for k in keys], dtype=torch.int64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(delta, op=dist.ReduceOp.SUM)          # the only collective of the path
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    d = dict(zip(keys, delta.tolist()))
+    dt = float(tmax.item())
+
+    if rank == 0:
+        k_ms = None
+        if not args.graph:
+            k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        exp_per_launch = d["expansions"] / max(1, args.steps * world)
+        mean_d = d["sum_depth"] / max(1, d["sims"])
+        mean_c = d["edges_visited"] / max(1, d["sum_depth"])
+        mean_l = d["leaf_moves"] / max(1, d["expansions"])
+        bpe = bytes_per_expansion(mean_d, mean_c, mean_l)
+        slots = G * K
+        fl = flops_per_position(eng.model_cfg)
+        step_ms = dt / args.steps * 1e3
+        out = {
+            "metric": "mcts_node_expansions_per_sec", "value": d["expansions"] / dt, "unit": "expansions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[cfg.engine.net_dtype] + "+f64/i32 tree",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1] '{args.config}': {G} concurrent games/GPU, "
+                                   f"{cfg.play.simulation_num_per_move} sims/move, K={K} sims/round/game, "
+                                   f"{cfg.model.res_layer_num}x{cfg.model.cnn_filter_num} net "
+                                   f"({cfg.engine.net_dtype}), random-init weights, self-play from INIT_STATE",
+                       "games_per_gpu": G, "sims_per_round": K, "queue_slots_per_gpu": slots,
+                       "parallelism": f"games sharded over {world} rank(s), no data-path collective"},
+            "sims_per_s": d["sims"] / dt, "plies_per_s": d["plies"] / dt,
+            "queue_utilisation": d["expansions"] / max(1, args.steps * world * slots),
+            "games_finished": d["games"],
+            "tree_shape": {"mean_depth": mean_d, "mean_edges": mean_c, "mean_leaf_moves": mean_l,
+                           "terminal_sims": d["terminal_sims"], "repetition_sims": d["repetition_sims"],
+                           "parked": d["parked"], "tree_resets": d["tree_resets"],
+                           "overflow_sims": d["overflow_sims"] + d["depth_overflow"]},
+            "roofline": None, "roofline_nn": None, "cpu_baseline": None,
+        }
+        if k_ms is not None:
+            ach = bpe * exp_per_launch / (k_ms * 1e-3) / 1e9
+            out["roofline"] = {"kernel": "k_round", "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+                               "frac": ach / 8000.0, "traffic": None, "avg_launch_ms": k_ms,
+                               "bytes_per_expansion": bpe, "expansions_per_launch": exp_per_launch,
+                               "note": "latency/occupancy-bound pointer chasing (SURVEY 8d), not bandwidth-bound"}
+            nn_ms = step_ms - k_ms
+            peak = 157.3 if cfg.engine.net_dtype == "float32" else 2500.0
+            tf = fl * slots / (nn_ms * 1e-3) / 1e12
+            out["roofline_nn"] = {"kernel": "ResNet forward (MIOpen/hipBLASLt)", "bound": "mfma", "achieved": tf,
+                                  "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "ms": nn_ms,
+                                  "positions_per_forward": slots}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_seconds)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+"""Batched self-play engine: thousands of concurrent games on one MI355X.
+
+One engine = one GPU = one process.  Each ROUND is
+    k_round (hand-written HIP, one wavefront per game: backup / select / expand / game rules, leaf planes
+             written straight into the evaluation queue)
+ -> one ResNet forward over the whole queue (PyTorch-ROCm; MIOpen / hipBLASLt MFMA kernels)
+with no host decision and no device->host copy in between.  Finished games are appended to a device
+ring and drained by the host only when it wants to write play-record files.
+
+This replaces the reference's process/thread topology (worker/self_play.py:48-60 ProcessPoolExecutor,
+agent/player.py ThreadPoolExecutor + sender/receiver threads, agent/api.py prediction thread + pipes).
+"""
+import time
+from logging import getLogger
+
+import torch
+
+from cchess_alphazero import _native
+from cchess_alphazero._native_search import Search
+from cchess_alphazero.agent.model import CChessNet, InferenceNet
+from cchess_alphazero.environment.lookup_tables import ActionLabelsRed
+from cchess_alphazero.environment.static_env import INIT_STATE
+
+logger = getLogger(__name__)
+
+_PLANES_CODE = {torch.float32: _native.F32, torch.float16: _native.F16, torch.bfloat16: _native.BF16}
+
+
+def bytes_per_expansion(mean_depth, mean_edges, mean_leaf_moves):
+    """Algorithmic HBM bytes of one node expansion (canonical fp32 accounting):
+    13 478 + 14 L + sum_i (16 + 14 C_i) + 28 d."""
+    return 13478.0 + 14.0 * mean_leaf_moves + mean_depth * (16.0 + 14.0 * mean_edges) + 28.0 * mean_depth
+
+
+class SelfPlayEngine:
+    def __init__(self, config, n_games, net=None, dtype=torch.float32, device=None, seed=0,
+                 node_capacity=0, edge_capacity=0, max_depth=0, sims_per_round=None, evaluator=None):
+        """config: the reference's Config object (config.play.* / config.model.* are read).
+        net: a CChessNet (random-init if None).  evaluator: optional callable planes -> (policy, value)
+        replacing the network (tests)."""
+        _native.require_gpu()
+        self.config = config
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.dtype = dtype
+        self.search = Search(config.play, n_games, planes_dtype=_PLANES_CODE[dtype],
+                             evaluate=getattr(config.opts, "evaluate", False), seed=seed,
+                             node_capacity=node_capacity, edge_capacity=edge_capacity, max_depth=max_depth,
+                             sims_per_round=sims_per_round, device=self.device)
+        self.evaluator = evaluator
+        self.net = None
+        if evaluator is None:
+            if net is None:
+                torch.manual_seed(0)
+                net = CChessNet.from_model_config(config.model)
+            self.model_cfg = net.cfg
+            self.net = InferenceNet(net, dtype).to(self.device)
+        self.rounds = 0
+        self.seed = seed
+        self._graph = None
+
+    # ---- control ----
+    def start(self, first_game_id=0, game_id_stride=0):
+        self.search.start_selfplay(self.seed, first_game_id, game_id_stride)
+
+    def _forward(self):
+        s = self.search
+        if self.evaluator is not None:
+            p, v = self.evaluator(s.planes)
+        else:
+            p, v = self.net(s.planes)
+        s.policy.copy_(p)
+        s.value.copy_(v)
+
+    def step(self):
+        """One lock-step round for every game: tree kernel, then the network on the evaluation queue."""
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self.search.round()
+            self._forward()
+        self.rounds += 1
+
+    def capture_graph(self, warmup=2):
+        """Capture kernel + network forward of one round into a HIP graph (no host work per round)."""
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.search.round()
+                self._forward()
+                self.rounds += 1
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.search.round()
+            self._forward()
+        self.rounds += 1          # capture does not execute; the first replay does
+        self._graph = g
+
+    def counters(self):
+        return self.search.counters()
+
+    def drain(self, max_records=4096):
+        """Finished games since the last call, as the reference's play-record lists
+        ([init_state, [move, value], ...], self_play.py:202-208) plus metadata."""
+        out = []
+        for r in self.search.drain_records(max_records):
+            v = r["value"]
+            data = [INIT_STATE]
+            for i, m in enumerate(r["moves"]):
+                data.append([ActionLabelsRed[int(m)], v if i % 2 == 0 else -v])
+            out.append(dict(game_id=r["game_id"], turns=r["turns"], value=v, store=r["store"],
+                            resigned=r["resigned"], data=data))
+        return out
+
+    def close(self):
+        self.search.close()
