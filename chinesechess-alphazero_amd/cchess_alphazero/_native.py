@@ -25,6 +25,9 @@ def lib():
     """Load libczero.so; raise loudly when it has not been built."""
     global _lib
     if _lib is None:
+        # PyTorch ships its own HIP runtime: it must be loaded first so that libczero.so binds to the same
+        # one (loading /opt/rocm's runtime first leaves torch without a visible GPU).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise NativeError(
                 f"{LIB_PATH} not found: build the HIP engine first "

@@ -60,12 +60,14 @@ def array_to_state(b):
 
 def _to_device(states):
     import torch
+    _native.require_gpu()
     arr = np.stack([state_to_array(s) for s in states])
     return torch.from_numpy(arr).cuda()
 
 
 def _labels_to_device(actions):
     import torch
+    _native.require_gpu()
     return torch.tensor([label_index(a) for a in actions], dtype=torch.int32).to(torch.uint16).cuda()
 
 

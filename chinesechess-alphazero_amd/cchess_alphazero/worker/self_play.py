@@ -1,0 +1,154 @@
+"""``run.py self`` worker (reference: cchess_alphazero/worker/self_play.py).
+
+``start(config)`` never returns: it plays self-play games forever and writes play-record JSON files that
+the reference's ``opt`` trainer consumes.  Where the reference forks ``max_processes`` Python workers that
+each play one game at a time through a pipe to a prediction thread, this worker drives ONE batched engine
+per GPU (``config.engine.games_per_gpu`` concurrent games, one wavefront each).  With several GPUs
+(``--gpu 0,1,...`` or a torchrun launch) there is one process per GPU with disjoint game ids; the only
+collective is an all-reduce of the game counters (RCCL; gloo in the CPU tests).
+"""
+import os
+import time
+from logging import getLogger
+
+import numpy as np
+
+from cchess_alphazero.lib.data_helper import PlayDataWriter
+
+logger = getLogger(__name__)
+
+COUNTER_KEYS = ["games", "plies", "sims", "expansions", "red_wins", "black_wins", "draws", "resigns"]
+
+
+def load_model(config, config_file=None):
+    """Best model if its files exist, otherwise a freshly built random-init one (reference :29-46).
+    Always 14 input planes (the reference's use_history quirk is not reproduced, SURVEY C-7)."""
+    from cchess_alphazero.agent.model import CChessModel
+    model = CChessModel(config)
+    rc = config.resource
+    config_path = rc.model_best_config_path if not config_file else os.path.join(rc.model_dir, config_file)
+    if not model.load(config_path, rc.model_best_weight_path):
+        model.build(seed=0)
+        try:
+            model.save(rc.model_best_config_path, rc.model_best_weight_path)
+        except OSError as e:
+            logger.info(f"could not save the freshly built model: {e}")
+    return model, False
+
+
+def reduce_counters(counters, group=None):
+    """All-reduce (SUM) the game counters over the ranks.  counters: dict name -> int (local).
+    Returns the global dict.  One int64[len(COUNTER_KEYS)] message: latency-bound, SURVEY 8(e)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return {k: int(counters.get(k, 0)) for k in COUNTER_KEYS}
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([int(counters.get(k, 0)) for k in COUNTER_KEYS], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return dict(zip(COUNTER_KEYS, t.tolist()))
+
+
+def game_id_partition(rank, world, games_per_gpu):
+    """Disjoint game ids: slot g of rank r starts at r*G + g and advances by world*G."""
+    return rank * games_per_gpu, world * games_per_gpu
+
+
+class SelfPlayWorker:
+    """One GPU's worth of self-play.  ``start()`` loops forever like the reference's worker;
+    ``run(max_rounds=..., max_games=...)`` is the bounded form used by tests and benchmarks."""
+
+    def __init__(self, config, pipes=None, pid=None, use_history=False, rank=0, world=1, model=None):
+        self.config = config
+        self.id = pid
+        self.pid = os.getpid()
+        self.rank, self.world = rank, world
+        self.model = model
+        self.engine = None
+        self.writer = PlayDataWriter(config, rank, world)
+        self.stored_games = 0
+
+    def _make_engine(self):
+        import torch
+        from cchess_alphazero.engine import SelfPlayEngine
+        ec = self.config.engine
+        net = self.model.model if self.model is not None else None
+        self.engine = SelfPlayEngine(self.config, ec.games_per_gpu, net=net, dtype=getattr(torch, ec.net_dtype),
+                                     seed=ec.base_seed, node_capacity=ec.node_capacity,
+                                     edge_capacity=ec.edge_capacity, max_depth=ec.max_depth,
+                                     sims_per_round=ec.sims_per_round)
+        first, stride = game_id_partition(self.rank, self.world, ec.games_per_gpu)
+        self.engine.start(first, stride)
+        if ec.use_hip_graph:
+            self.engine.capture_graph()
+
+    def _harvest(self):
+        for g in self.engine.drain():
+            logger.debug(f"Process {self.pid}-{self.rank} game {g['game_id']} turn={g['turns'] / 2}, "
+                         f"winner = {g['value']:.2f} (1 = red, -1 = black, 0 draw)")
+            if g["store"]:
+                path = self.writer.add_game(g["data"])
+                self.stored_games += 1
+                if path:
+                    logger.info(f"Process {self.pid} save play data to {path}")
+
+    def run(self, max_rounds=None, max_games=None):
+        if self.engine is None:
+            self._make_engine()
+        every = max(1, self.config.engine.report_every_rounds)
+        t0, r = time.time(), 0
+        while True:
+            self.engine.step()
+            r += 1
+            if r % every == 0:
+                self._harvest()
+                c = reduce_counters(self.engine.counters())
+                if self.rank == 0:
+                    dt = time.time() - t0
+                    logger.info(f"rounds={r} games={c['games']} plies={c['plies']} "
+                                f"expansions/s={c['expansions'] / dt:.0f} games/h={c['games'] / dt * 3600:.0f}")
+                if max_games is not None and c["games"] >= max_games:
+                    break
+            if max_rounds is not None and r >= max_rounds:
+                break
+        self._harvest()
+        return reduce_counters(self.engine.counters())
+
+    def start(self):
+        self.run()
+
+    def close(self):
+        if self.engine is not None:
+            self.engine.close()
+            self.engine = None
+
+
+def _rank_main(rank, world, config, port):
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    devices = [int(x) for x in str(config.opts.device_list).split(",")]
+    torch.cuda.set_device(devices[rank] if rank < len(devices) else rank)
+    if world > 1:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    model, _ = load_model(config)
+    SelfPlayWorker(config, rank=rank, world=world, model=model).start()
+
+
+def start(config):
+    """Entry point of ``run.py self`` (reference :48-60)."""
+    import torch
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:      # launched by torchrun
+        import torch.distributed as dist
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        model, _ = load_model(config)
+        return SelfPlayWorker(config, rank=rank, world=world, model=model).start()
+    devices = str(config.opts.device_list).split(",")
+    if len(devices) > 1:
+        import torch.multiprocessing as mp
+        port = 29500 + (os.getpid() % 2000)
+        return mp.spawn(_rank_main, args=(len(devices), config, port), nprocs=len(devices), join=True)
+    return _rank_main(0, 1, config, 0)

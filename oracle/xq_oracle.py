@@ -408,4 +408,4 @@ def selfplay_game(cfg, stub, seed, game_id, max_plies=512):
     turns = L.xqo_selfplay_game(C.byref(cfg), st.fn, st.ctx, rng.fn, rng.ctx, _p(moves, C.c_uint16), max_plies,
                                 C.byref(value), C.byref(store), C.byref(ctr), _p(crc, C.c_uint32))
     return dict(moves=[label_str(m) for m in moves[:turns]], value=value.value, store=bool(store.value),
-                turns=turns, counters=ctr.as_dict(), visit_crc=crc[:turns].copy())
+                turns=turns, counters=ctr.as_dict(), visit_crc=crc.copy())   # one entry per action() call

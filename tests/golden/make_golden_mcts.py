@@ -32,6 +32,13 @@ import cchess_alphazero.agent.player as ref_player  # noqa: E402
 
 LABEL = {m: i for i, m in enumerate(ActionLabelsRed)}
 
+# The reference's sender thread sleeps 1 ms while HOLDING the queue lock (player.py:113-123), which
+# starves the search thread for seconds at a time when the network answers instantly (SURVEY C-12).
+# Shorten that sleep and make the interpreter switch threads eagerly: timing only, results unchanged.
+import time as _time  # noqa: E402
+sys.setswitchinterval(1e-5)
+ref_player.sleep = lambda s: _time.sleep(0)
+
 
 def meta():
     return {"numpy": np.__version__, "python": sys.version.split()[0],
@@ -155,6 +162,18 @@ def gen_games():
         dict(name="resign", salt=25, sims=40, tau=0.0, max_game_length=40, seed=1005,
              enable_resign_rate=0.0, resign_threshold=-0.35, min_resign_turn=6),
         dict(name="short_c3", salt=26, sims=30, tau=0.98, max_game_length=12, seed=1006, c_puct=3.0),
+        # near-random play (tiny searches): games that end by king capture (final_move) and early
+        dict(name="blunder_a", salt=27, sims=5, tau=0.98, max_game_length=60, seed=1007),
+        dict(name="blunder_b", salt=28, sims=6, tau=0.98, max_game_length=60, seed=1008),
+        dict(name="blunder_c", salt=29, sims=8, tau=0.9, max_game_length=60, seed=1009),
+        dict(name="blunder_d", salt=30, sims=4, tau=0.98, max_game_length=60, seed=1010),
+        # resignation: best root Q below a high threshold
+        dict(name="resign_hi", salt=31, sims=30, tau=0.98, max_game_length=40, seed=1011,
+             enable_resign_rate=0.0, resign_threshold=0.3, min_resign_turn=6),
+        # deterministic shallow play: position repetitions -> no_act / increase_temp / idle-loop draw
+        dict(name="repeat_a", salt=32, sims=8, tau=0.0, max_game_length=60, seed=1012),
+        dict(name="repeat_b", salt=33, sims=12, tau=0.0, max_game_length=60, seed=1013),
+        dict(name="repeat_c", salt=34, sims=10, tau=0.0, max_game_length=60, seed=1014, c_puct=0.5),
     ]
     games = []
     for s in specs:
