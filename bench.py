@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--sims-per-round", type=int, default=None, help="K, lock-step batch per game")
     ap.add_argument("--dtype", default=None, choices=["float32", "bfloat16", "float16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-micro", action="store_true", help="skip the 1M-board rule-kernel micro-suite")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--graph", action="store_true", help="replay each round from a HIP graph")
     return ap.parse_args()
@@ -89,6 +90,43 @@ def cpu_baseline(cfg, seconds):
             "sims_per_s": c["sims"] / dt}
 
 
+def micro_suite(n=1 << 20, iters=10):
+    """SURVEY 8(d) micro-suite: move-gen + done(need_check) + planes for 1 M boards (the fixed 1k-position suite
+    replicated), 90 B in, 256 + 6 + 5040 B out per board: the rule kernel where an HBM fraction is meaningful."""
+    from cchess_alphazero import _native
+    from cchess_alphazero.environment.static_env import state_to_array
+    import numpy as np
+    with open(os.path.join(ROOT, "tests", "golden", "positions_1k.json")) as f:
+        states = [r["state"] for r in json.load(f)["positions"]]
+    base = torch.from_numpy(np.stack([state_to_array(s) for s in states])).cuda()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    boards = base[torch.randint(0, base.shape[0], (n,), device="cuda", generator=g)].contiguous()
+    out = _native.rules_fused(boards, _native.F32)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        _native.rules_fused(boards, _native.F32, out=out)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    bytes_per_board = 90 + 256 + 6 + 5040
+    gbs = n * bytes_per_board / (ms * 1e-3) / 1e9
+    return {"kernel": "k_rules_fused<f32>", "boards": n, "bytes_per_board": bytes_per_board, "ms": ms,
+            "boards_per_s": n / (ms * 1e-3), "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}
+
+
+def pmc_traffic():
+    """HBM bytes per k_round launch from the committed PMC passes (profiles/, separate rocprofv3 --pmc runs)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_round.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return d.get("traffic_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,6 +149,7 @@ def main():
     eng.start(first_game_id=rank * G, game_id_stride=world * G)
     K = eng.search.K
 
+    eng.prewarm()                       # untimed initialisation: MIOpen solver selection / kernel compilation
     for _ in range(args.warmup):
         eng.step()
     if args.graph:
@@ -183,8 +222,10 @@ def main():
         }
         if k_ms is not None:
             ach = bpe * exp_per_launch / (k_ms * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic()
             out["roofline"] = {"kernel": "k_round", "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
-                               "frac": ach / 8000.0, "traffic": None, "avg_launch_ms": k_ms,
+                               "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                               "algorithmic_bytes_per_launch": bpe * exp_per_launch, "avg_launch_ms": k_ms,
                                "bytes_per_expansion": bpe, "expansions_per_launch": exp_per_launch,
                                "note": "latency/occupancy-bound pointer chasing (SURVEY 8d), not bandwidth-bound"}
             nn_ms = step_ms - k_ms
@@ -193,6 +234,8 @@ def main():
             out["roofline_nn"] = {"kernel": "ResNet forward (MIOpen/hipBLASLt)", "bound": "mfma", "achieved": tf,
                                   "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "ms": nn_ms,
                                   "positions_per_forward": slots}
+        if not args.no_micro:
+            out["micro_suite"] = micro_suite()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_seconds)
         print(json.dumps(out), flush=True)

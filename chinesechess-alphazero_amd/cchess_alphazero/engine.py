@@ -63,6 +63,23 @@ class SelfPlayEngine:
     def start(self, first_game_id=0, game_id_stride=0):
         self.search.start_selfplay(self.seed, first_game_id, game_id_stride)
 
+    def prewarm(self, max_iters=12):
+        """Run the network on the (idle) queue until its time settles: MIOpen picks / compiles its solvers on
+        the first calls of a new shape (seconds, with naive fallback kernels meanwhile).  Initialisation only."""
+        if self.net is None:
+            return
+        import time as _t
+        last = None
+        for _ in range(max_iters):
+            torch.cuda.synchronize(self.device)
+            t0 = _t.perf_counter()
+            self.net(self.search.planes)
+            torch.cuda.synchronize(self.device)
+            dt = _t.perf_counter() - t0
+            if last is not None and dt > 0.8 * last and dt < 1.25 * last:
+                break
+            last = dt
+
     def _forward(self):
         s = self.search
         if self.evaluator is not None:
