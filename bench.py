@@ -142,6 +142,7 @@ def main():
     from cchess_alphazero.agent.model import flops_per_position
     from cchess_alphazero.engine import SelfPlayEngine, bytes_per_expansion
 
+    t_start = time.perf_counter()
     cfg = build_config(args)
     dtype = getattr(torch, cfg.engine.net_dtype)
     G = cfg.engine.games_per_gpu
@@ -149,7 +150,13 @@ def main():
     eng.start(first_game_id=rank * G, game_id_stride=world * G)
     K = eng.search.K
 
-    eng.prewarm()                       # untimed initialisation: MIOpen solver selection / kernel compilation
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    # untimed initialisation: MIOpen solver selection / kernel compilation
+    log(f"engine ready ({eng.search.device_bytes() / 2**30:.1f} GiB of trees); prewarm forwards (s): "
+        + ", ".join(f"{x:.3f}" for x in eng.prewarm()))
     for _ in range(args.warmup):
         eng.step()
     if args.graph:
@@ -176,6 +183,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     c1 = eng.counters()
+    log(f"timed {args.steps} steps in {dt:.2f}s")
 
     keys = ["sims", "expansions", "terminal_sims", "repetition_sims", "parked", "sum_depth", "edges_visited",
             "leaf_moves", "plies", "games", "tree_resets", "overflow_sims", "depth_overflow"]
@@ -236,8 +244,10 @@ def main():
                                   "positions_per_forward": slots}
         if not args.no_micro:
             out["micro_suite"] = micro_suite()
+            log("micro-suite done")
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_seconds)
+            log("cpu baseline done")
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

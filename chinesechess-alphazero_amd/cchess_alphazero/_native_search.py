@@ -7,7 +7,7 @@ from cchess_alphazero import _native
 
 COUNTER_NAMES = ["sims", "expansions", "terminal_sims", "repetition_sims", "parked", "sum_depth", "max_depth",
                  "edges_visited", "leaf_moves", "plies", "games", "red_wins", "black_wins", "draws", "resigns",
-                 "tree_resets", "overflow_sims", "depth_overflow", "root_reused_sims", "ring_dropped"]
+                 "tree_resets", "overflow_sims", "depth_overflow", "root_reused_sims", "ring_dropped", "tree_compactions"]
 
 
 class SearchCfg(C.Structure):

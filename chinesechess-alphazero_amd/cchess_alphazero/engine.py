@@ -63,22 +63,26 @@ class SelfPlayEngine:
     def start(self, first_game_id=0, game_id_stride=0):
         self.search.start_selfplay(self.seed, first_game_id, game_id_stride)
 
-    def prewarm(self, max_iters=12):
+    def prewarm(self, max_iters=8, max_seconds=90.0):
         """Run the network on the (idle) queue until its time settles: MIOpen picks / compiles its solvers on
-        the first calls of a new shape (seconds, with naive fallback kernels meanwhile).  Initialisation only."""
+        the first calls of a new shape (seconds, with naive fallback kernels meanwhile).  Initialisation only.
+        Returns the list of forward times (s)."""
+        times = []
         if self.net is None:
-            return
+            return times
         import time as _t
-        last = None
+        t_begin = _t.perf_counter()
         for _ in range(max_iters):
             torch.cuda.synchronize(self.device)
             t0 = _t.perf_counter()
             self.net(self.search.planes)
             torch.cuda.synchronize(self.device)
-            dt = _t.perf_counter() - t0
-            if last is not None and dt > 0.8 * last and dt < 1.25 * last:
+            times.append(_t.perf_counter() - t0)
+            if len(times) >= 2 and 0.8 * times[-2] < times[-1] < 1.25 * times[-2]:
                 break
-            last = dt
+            if _t.perf_counter() - t_begin > max_seconds:
+                break
+        return times
 
     def _forward(self):
         s = self.search

@@ -63,7 +63,52 @@ struct MoveSink {
     }
 };
 
-// Moves of the piece standing on square s (0 if empty / opponent), reference order.
+// Step tables of the non-sliding pieces in the reference's direction order (mov_dir, common.py:66-76):
+// packed as (dx + 2) | (dy + 2) << 3.  Row = piece code (KNIGHT, ELEPHANT, ADVISOR, KING, PAWN).
+#define XQ_STEP(dx, dy) (uint8_t)(((dx) + 2) | (((dy) + 2) << 3))
+struct StepTable {
+    uint8_t n[8];
+    uint8_t d[8][8];
+};
+constexpr StepTable make_steps()
+{
+    StepTable t{};
+    const uint8_t king[4] = {XQ_STEP(0, -1), XQ_STEP(1, 0), XQ_STEP(0, 1), XQ_STEP(-1, 0)};
+    const uint8_t adv[4] = {XQ_STEP(-1, -1), XQ_STEP(1, -1), XQ_STEP(-1, 1), XQ_STEP(1, 1)};
+    const uint8_t ele[4] = {XQ_STEP(-2, -2), XQ_STEP(2, -2), XQ_STEP(2, 2), XQ_STEP(-2, 2)};
+    const uint8_t kn[8] = {XQ_STEP(-1, -2), XQ_STEP(1, -2), XQ_STEP(2, -1), XQ_STEP(2, 1),
+                           XQ_STEP(1, 2), XQ_STEP(-1, 2), XQ_STEP(-2, 1), XQ_STEP(-2, -1)};
+    const uint8_t pawn[3] = {XQ_STEP(0, 1), XQ_STEP(-1, 0), XQ_STEP(1, 0)};
+    for (int i = 0; i < 8; ++i) { t.n[i] = 0; for (int k = 0; k < 8; ++k) t.d[i][k] = 0; }
+    t.n[KING] = 4; t.n[ADVISOR] = 4; t.n[ELEPHANT] = 4; t.n[KNIGHT] = 8; t.n[PAWN] = 3;
+    for (int k = 0; k < 4; ++k) { t.d[KING][k] = king[k]; t.d[ADVISOR][k] = adv[k]; t.d[ELEPHANT][k] = ele[k]; }
+    for (int k = 0; k < 8; ++k) t.d[KNIGHT][k] = kn[k];
+    for (int k = 0; k < 3; ++k) t.d[PAWN][k] = pawn[k];
+    return t;
+}
+#if defined(__HIPCC__)
+static __device__ const StepTable d_steps = make_steps();
+#endif
+static constexpr StepTable h_steps = make_steps();
+
+XQ_HD int step_count(int p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return d_steps.n[p];
+#else
+    return h_steps.n[p];
+#endif
+}
+XQ_HD int step_code(int p, int k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return d_steps.d[p][k];
+#else
+    return h_steps.d[p][k];
+#endif
+}
+
+// Moves of the piece standing on square s (0 if empty / opponent), reference order (static_env.py:256-321).
 template <bool EMIT>
 XQ_HD int gen_sq(const int8_t* b, int s, uint16_t* lab, uint16_t* ft, int off)
 {
@@ -71,7 +116,8 @@ XQ_HD int gen_sq(const int8_t* b, int s, uint16_t* lab, uint16_t* ft, int off)
     if (p <= 0) return 0;
     MoveSink<EMIT> out{lab, ft, off, 0};
     const int x = s % 9, y = s / 9;
-    if (p == ROOK || p == CANNON) {                       // static_env.py:288-320
+    if (p == ROOK || p == CANNON) {                       // :288-320
+        // nearest blockers on the four rays (x_board_from / y_board_from, :332-348); sentinels -1 / 9 / 10
         int l = x - 1, r = x + 1, d = y - 1, u = y + 1;
         while (l > -1 && b[y * 9 + l] == 0) --l;
         while (r < 9 && b[y * 9 + r] == 0) ++r;
@@ -94,62 +140,36 @@ XQ_HD int gen_sq(const int8_t* b, int s, uint16_t* lab, uint16_t* ft, int off)
         if (u < 10 && b[u * 9 + x] < 0) out.put(s, u * 9 + x);
         return out.n;
     }
-    if (p == KING) {                                      // :277-286
-        const int dx[4] = {0, 1, 0, -1}, dy[4] = {-1, 0, 1, 0};
+    // stepping pieces: one table-driven loop (:264-286)
+    int fly = -1;                                         // flying-king capture target, -1 if none
+    if (p == KING) {
         int u = y + 1;
         while (u < 10 && b[u * 9 + x] == 0) ++u;
-        const bool flying = (u < 10 && b[u * 9 + x] == -KING);
-        for (int k = 0; k < 4; ++k) {
-            const int x_ = x + dx[k], y_ = y + dy[k];
-            if (x_ < 0 || x_ > 8 || y_ < 0 || y_ > 9 || b[y_ * 9 + x_] > 0) continue;
+        if (u < 10 && b[u * 9 + x] == -KING) fly = u * 9 + x;
+    }
+    const int nd = step_count(p);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+    for (int k = 0; k < nd; ++k) {
+        const int code = step_code(p, k);
+        const int dx = (code & 7) - 2, dy = (code >> 3) - 2;
+        const int x_ = x + dx, y_ = y + dy;
+        if (x_ < 0 || x_ > 8 || y_ < 0 || y_ > 9) continue;           // can_move, :323-330
+        const int t = y_ * 9 + x_;
+        if (b[t] > 0) continue;
+        if (p == PAWN) {
+            if (y < 5 && x_ != x) continue;                           // :270
+        } else if (p == KNIGHT || p == ELEPHANT) {
+            if (b[(y + dy / 2) * 9 + x + dx / 2] != 0) continue;      // leg / eye; int(d/2) truncates toward 0
+            if (p == ELEPHANT && y_ > 4) continue;                    // :275
+        } else {                                                      // king, advisor: palace (:277-281)
             if (x_ < 3 || x_ > 5 || y_ > 2) continue;
-            out.put(s, y_ * 9 + x_);
-            if (flying) out.put(s, u * 9 + x);            // emitted once per accepted king step
         }
-        return out.n;
+        out.put(s, t);
+        if (fly >= 0) out.put(s, fly);                                // once per accepted king step (:283-286)
     }
-    if (p == ADVISOR) {
-        const int dx[4] = {-1, 1, -1, 1}, dy[4] = {-1, -1, 1, 1};
-        for (int k = 0; k < 4; ++k) {
-            const int x_ = x + dx[k], y_ = y + dy[k];
-            if (x_ < 0 || x_ > 8 || y_ < 0 || y_ > 9 || b[y_ * 9 + x_] > 0) continue;
-            if (x_ < 3 || x_ > 5 || y_ > 2) continue;
-            out.put(s, y_ * 9 + x_);
-        }
-        return out.n;
-    }
-    if (p == ELEPHANT) {                                  // :272-276
-        const int dx[4] = {-2, 2, 2, -2}, dy[4] = {-2, -2, 2, 2};
-        for (int k = 0; k < 4; ++k) {
-            const int x_ = x + dx[k], y_ = y + dy[k];
-            if (x_ < 0 || x_ > 8 || y_ < 0 || y_ > 9 || b[y_ * 9 + x_] > 0) continue;
-            if (b[(y + dy[k] / 2) * 9 + x + dx[k] / 2] != 0) continue;
-            if (y_ > 4) continue;
-            out.put(s, y_ * 9 + x_);
-        }
-        return out.n;
-    }
-    if (p == KNIGHT) {
-        const int dx[8] = {-1, 1, 2, 2, 1, -1, -2, -2}, dy[8] = {-2, -2, -1, 1, 2, 2, 1, -1};
-        for (int k = 0; k < 8; ++k) {
-            const int x_ = x + dx[k], y_ = y + dy[k];
-            if (x_ < 0 || x_ > 8 || y_ < 0 || y_ > 9 || b[y_ * 9 + x_] > 0) continue;
-            if (b[(y + dy[k] / 2) * 9 + x + dx[k] / 2] != 0) continue;   // int(d/2) truncates toward 0
-            out.put(s, y_ * 9 + x_);
-        }
-        return out.n;
-    }
-    if (p == PAWN) {                                      // :270
-        const int dx[3] = {0, -1, 1}, dy[3] = {1, 0, 0};
-        for (int k = 0; k < 3; ++k) {
-            const int x_ = x + dx[k], y_ = y + dy[k];
-            if (x_ < 0 || x_ > 8 || y_ < 0 || y_ > 9 || b[y_ * 9 + x_] > 0) continue;
-            if (y < 5 && x_ != x) continue;
-            out.put(s, y_ * 9 + x_);
-        }
-        return out.n;
-    }
-    return 0;
+    return out.n;
 }
 
 // Value (0/1) of input-plane element o = c*90 + i*9 + j for a board (static_env.py:137-156):

@@ -180,6 +180,22 @@ XQ_D uint64_t pack_key(const int8_t* b, uint32_t* key)
     return mix64(h);
 }
 
+// hash of an already packed key (same value pack_key returns for that position)
+XQ_D uint64_t hash_of_key(const uint32_t* key)
+{
+    const int lane = lane_id();
+    uint64_t h = 0;
+    if (lane < KEY_WORDS) h = mix64((uint64_t)key[lane] + 0x9E3779B97F4A7C15ULL * (uint64_t)(lane + 1));
+    uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        lo ^= (uint32_t)__shfl_xor((int)lo, d, 64);
+        hi ^= (uint32_t)__shfl_xor((int)hi, d, 64);
+    }
+    h = ((uint64_t)uniu(hi) << 32) | uniu(lo);
+    return mix64(h);
+}
+
 XQ_D void unpack_key(const uint32_t* __restrict__ gkey, int8_t* b)
 {
     const int lane = lane_id();
@@ -534,6 +550,119 @@ XQ_D void clear_tree(const SearchParams& P, const SearchBuffers& B, const GameVi
     wave_sync();
 }
 
+// Keep only the sub-DAG reachable from `root` (through the child links of traversed edges) and slide it to
+// the front of the arena; rebuild the hash table.  Runs between plies (no simulation in flight).  The hash
+// table's memory doubles as scratch: remap[node_cap] (int32) + stack[node_cap] (int32) <= hash_cap * 8 bytes.
+// Returns the new root index.  Nodes keep their relative order, so every move is towards lower addresses.
+XQ_D int compact_tree(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L, int root)
+{
+    const int lane = lane_id();
+    const int g = gv.g;
+    const int ncount = uni(B.g_node_count[g]);
+    int32_t* remap = reinterpret_cast<int32_t*>(gv.hash);
+    int32_t* stack = remap + P.node_cap;
+    for (int i = lane; i < ncount; i += 64) remap[i] = -1;
+    wave_sync();
+    // mark
+    int top = 1;
+    if (lane == 0) { stack[0] = root; remap[root] = 0; }
+    wave_sync();
+    while (top > 0) {
+        const int node = uni(stack[top - 1]);
+        top -= 1;
+        const int nm = (int)(uniu(gv.node_meta[node]) & 0xFF);
+        const int eoff = (int)uniu(gv.node_eoff[node]);
+        for (int base = 0; base < nm; base += 64) {
+            const int j = base + lane;
+            int child = -1;
+            if (j < nm) child = gv.e_child[eoff + j];
+            const bool fresh = child >= 0 && remap[child] < 0;       // children of one node are distinct
+            const uint64_t m = __ballot(fresh);
+            if (fresh) {
+                const int pos = top + __popcll(m & ((1ull << lane) - 1ull));
+                stack[pos] = child;
+                remap[child] = 0;
+            }
+            top += __popcll(m);
+            wave_sync();
+        }
+    }
+    // new indices in old order
+    int live = 0;
+    for (int base = 0; base < ncount; base += 64) {
+        const int i = base + lane;
+        const bool keep = i < ncount && remap[i] == 0;
+        const uint64_t m = __ballot(keep);
+        if (keep) remap[i] = live + __popcll(m & ((1ull << lane) - 1ull));
+        live += __popcll(m);
+    }
+    wave_sync();
+    // slide nodes and their edges down, remapping the child links
+    int ecount = 0;
+    for (int i = 0; i < ncount; ++i) {
+        const int ni = uni(remap[i]);
+        if (ni < 0) continue;
+        const uint32_t meta = uniu(gv.node_meta[i]);
+        const int nm = (int)(meta & 0xFF);
+        const int eoff = (int)uniu(gv.node_eoff[i]);
+        const int sum_n = uni(gv.node_sum_n[i]);
+        uint32_t kw = 0;
+        if (lane < KEY_WORDS) kw = gv.node_key[(size_t)i * KEY_WORDS + lane];
+        int en[2], ec[2]; double ew[2]; float ep[2]; uint16_t em[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = lane + 64 * h;
+            en[h] = 0; ec[h] = CHILD_UNKNOWN; ew[h] = 0.0; ep[h] = 0.0f; em[h] = 0;
+            if (j < nm) {
+                en[h] = gv.e_n[eoff + j]; ew[h] = gv.e_w[eoff + j]; ep[h] = gv.e_p[eoff + j];
+                em[h] = gv.e_mv[eoff + j]; ec[h] = gv.e_child[eoff + j];
+                if (ec[h] >= 0) ec[h] = remap[ec[h]];
+            }
+        }
+        wave_sync();
+        if (lane < KEY_WORDS) gv.node_key[(size_t)ni * KEY_WORDS + lane] = kw;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = lane + 64 * h;
+            if (j < nm) {
+                gv.e_n[ecount + j] = en[h]; gv.e_w[ecount + j] = ew[h]; gv.e_p[ecount + j] = ep[h];
+                gv.e_mv[ecount + j] = em[h]; gv.e_child[ecount + j] = ec[h];
+            }
+        }
+        if (lane == 0) {
+            gv.node_sum_n[ni] = sum_n;
+            gv.node_eoff[ni] = (uint32_t)ecount;
+            gv.node_meta[ni] = meta;
+        }
+        ecount += nm;
+        wave_sync();
+    }
+    const int new_root = uni(remap[root]);
+    wave_sync();
+    // rebuild the hash table: one node per lane, linear probing with a compare-and-swap on the slot
+    for (int i = lane; i < P.hash_cap; i += 64) gv.hash[i] = 0;
+    wave_sync();
+    const uint32_t mask = (uint32_t)P.hash_cap - 1u;
+    for (int base = 0; base < live; base += 64) {
+        const int i = base + lane;
+        if (i < live) {
+            uint64_t x = 0;
+            for (int w = 0; w < KEY_WORDS; ++w)
+                x ^= mix64((uint64_t)gv.node_key[(size_t)i * KEY_WORDS + w] + 0x9E3779B97F4A7C15ULL * (uint64_t)(w + 1));
+            const uint64_t h = mix64(x);
+            const unsigned long long entry = ((unsigned long long)((uint32_t)(h >> 32) | 1u) << 32) | (uint32_t)(i + 1);
+            uint32_t slot = (uint32_t)h & mask;
+            unsigned long long* tab = reinterpret_cast<unsigned long long*>(gv.hash);
+            while (atomicCAS(&tab[slot], 0ull, entry) != 0ull) slot = (slot + 1) & mask;
+        }
+    }
+    wave_sync();
+    if (lane == 0) { B.g_node_count[g] = live; B.g_edge_count[g] = ecount; B.g_root[g] = new_root; }
+    wave_sync();
+    (void)L;
+    return new_root;
+}
+
 // Start the search of the position in g_board (CChessPlayer.action, player.py:145-164): find the
 // root in the tree, apply the reuse rule, make room in the arena.
 XQ_D void begin_search(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L)
@@ -552,15 +681,26 @@ XQ_D void begin_search(const SearchParams& P, const SearchBuffers& B, const Game
     if (n_no_act > 0 || inc || done_n == P.sims) done_n = 0;                      // :156-158
     int tasks = P.sims - done_n;
     if (tasks < 0) tasks = 0;
-    // arena policy: the tree of a game is kept as long as it fits (reference: for the whole game);
-    // when the next ply might not fit, it is dropped and the search restarts from an empty tree
-    const int ncount = uni(B.g_node_count[g]), ecount = uni(B.g_edge_count[g]);
-    if (tasks > 0 && (ncount + tasks + 1 > P.node_cap || (long long)ecount + (long long)(tasks + 1) * 64 > P.edge_cap)) {
-        clear_tree(P, B, gv);
-        count(gv, CT_TREE_RESETS);
-        root = -1;
-        tasks = P.sims;
-        done_n = 0;
+    // arena policy: the tree of a game is kept as long as it fits (reference: for the whole game).  When the
+    // next ply might not fit, it is first compacted to the sub-DAG reachable from the new root (what subtree
+    // reuse can still see); only if that is not enough (or the root is new) it is dropped.
+    int ncount = uni(B.g_node_count[g]), ecount = uni(B.g_edge_count[g]);
+    const auto no_room = [&](int nc, int ec) {
+        return nc + tasks + 1 > P.node_cap || (long long)ec + (long long)(tasks + 1) * 64 > P.edge_cap;
+    };
+    if (tasks > 0 && no_room(ncount, ecount)) {
+        if (root >= 0) {
+            root = compact_tree(P, B, gv, L, root);
+            count(gv, CT_TREE_COMPACTIONS);
+            ncount = uni(B.g_node_count[g]); ecount = uni(B.g_edge_count[g]);
+        }
+        if (root < 0 || no_room(ncount, ecount)) {
+            clear_tree(P, B, gv);
+            count(gv, CT_TREE_RESETS);
+            root = -1;
+            tasks = P.sims;
+            done_n = 0;
+        }
     }
     count(gv, CT_ROOT_REUSED_SIMS, (unsigned long long)done_n);
     if (lane == 0) {
@@ -1143,7 +1283,7 @@ int cz_search_create(const cz_search_cfg* c, cz_search** out)
     e = hipMalloc(&s->slab, s->bytes);
     if (e != hipSuccess) { delete s; return serr_hip("cz_search_create: hipMalloc", e); }
     e = hipMemset(s->slab, 0, s->bytes);
-    if (e != hipSuccess) { hipFree(s->slab); delete s; return serr_hip("cz_search_create: hipMemset", e); }
+    if (e != hipSuccess) { (void)hipFree(s->slab); delete s; return serr_hip("cz_search_create: hipMemset", e); }
     layout(s, (char*)s->slab, false);
     *out = s;
     return CZ_OK;
@@ -1152,7 +1292,7 @@ int cz_search_create(const cz_search_cfg* c, cz_search** out)
 int cz_search_destroy(cz_search* s)
 {
     if (!s) return CZ_OK;
-    hipFree(s->slab);
+    (void)hipFree(s->slab);
     delete s;
     return CZ_OK;
 }

@@ -166,6 +166,33 @@ def test_multi_ply_reuse_matches_oracle(gpu):
     s.close()
 
 
+def test_compaction_keeps_the_reachable_subtree(gpu):
+    """A small arena forces compaction between plies; as long as no dropped position recurs the search must be
+    indistinguishable from the oracle's unbounded tree (visit counts, W, subtree reuse)."""
+    pc = play_config(simulation_num_per_move=100, search_threads=4)
+    spec = dict(kind="hash", salt=17)
+    G = 3
+    s = gpu.S.Search(pc, G, seed=1, node_capacity=260)
+    players = [xo.Player(oracle_cfg(pc), spec) for _ in range(G)]
+    states = [xo.INIT_STATE, MID, xo.step(xo.INIT_STATE, '7242')]
+    t = gpu.torch
+    for ply in range(12):
+        s.set_roots(boards_tensor(gpu, states), turns=t.full((G,), ply, dtype=t.int32, device="cuda"))
+        s.run_until_idle(stub_eval(gpu, spec))
+        st = s.root_stats()
+        act = s.choose(None)
+        for g in range(G):
+            a, _ = players[g].action(states[g], ply, None, False, 0.5)
+            assert_root_equal(st, g, players[g].node_stats(states[g]), f"ply {ply} game {g}")
+            assert xo.label_str(int(act[g])) == a
+            states[g] = xo.step(states[g], a)
+    c = s.counters()
+    assert c["tree_compactions"] > 0 and c["tree_resets"] == 0 and c["overflow_sims"] == 0, c
+    for p in players:
+        p.close()
+    s.close()
+
+
 def run_selfplay(gpu, pc, spec, G, seed, games_wanted, max_rounds=200000, **kw):
     s = gpu.S.Search(pc, G, seed=seed, **kw)
     ev = stub_eval(gpu, spec)
