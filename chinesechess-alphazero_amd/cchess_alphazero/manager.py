@@ -1,6 +1,6 @@
-"""Command line of ``run.py`` (reference: cchess_alphazero/manager.py).  Only the self-play hot path is
-served by this package; the other sub-commands of the reference (opt, eval, play, sl, ob) are outside the
-scope table and report that."""
+"""Command line of ``run.py`` (reference: cchess_alphazero/manager.py).  ``self`` (the hot path) and ``eval``
+(the arena) are served by this package; the other sub-commands of the reference (opt, play, sl, ob)
+are outside the scope table and report that."""
 import argparse
 import os
 from logging import getLogger
@@ -72,6 +72,13 @@ def start():
             raise SystemExit("self-play against an external UCCI engine is outside the MI355X hot path")
         from cchess_alphazero.worker import self_play
         return self_play.start(config)
+    if args.cmd == 'eval':                                   # reference manager.py:94-103
+        if args.elo:
+            raise SystemExit("the server-driven Elo evaluator needs cczero.org (no network): outside the hot path")
+        config.eval.update_play_config(config.play)
+        config.opts.evaluate = True
+        from cchess_alphazero.worker import evaluator
+        return evaluator.start(config)
     raise SystemExit(f"`run.py {args.cmd}` is not part of the MI355X self-play hot path (SURVEY 8): "
                      f"use the reference implementation for it; the play records written by `run.py self` "
                      f"are in the reference's format")

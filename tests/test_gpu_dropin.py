@@ -79,3 +79,111 @@ def test_selfplay_worker_writes_reference_records(tmp_path, monkeypatch):
         assert all(v in (-1, 0, 1) for v in vals)
         assert all(vals[i] == -vals[i - 1] for i in range(1, len(vals)))   # alternating sign (self_play.py:202-208)
         assert len(vals) <= 2 * cfg.play.max_game_length + 1
+
+
+def test_record_decoder_matches_oracle_replay(tmp_path, monkeypatch):
+    """GPU form of the trainer's expanding_data (optimize.py:234-281) vs an oracle replay."""
+    import torch
+    from cchess_alphazero.lib.record_decoder import expand_records, split_games
+    rng = np.random.default_rng(3)
+    games = []
+    for g in range(7):
+        state, data = xo.INIT_STATE, [xo.INIT_STATE]
+        for ply in range(int(rng.integers(1, 40))):
+            if xo.done(state)[0]:
+                break
+            mv = xo.get_legal_moves(state)
+            m = mv[int(rng.integers(len(mv)))]
+            data.append([m, 1 if ply % 2 == 0 else -1])
+            state = xo.step(state, m)
+        games.append(data)
+    flat = [x for g in games for x in g]
+    assert split_games(flat) == games
+    planes, pol, vals, off = expand_records(games)
+    planes, pol, vals = planes.cpu().numpy(), pol.cpu().numpy(), vals.cpu().numpy()
+    k = 0
+    for g in games:
+        state = g[0]
+        for mv, v in g[1:]:
+            assert (planes[k] == xo.state_to_planes(state)).all()
+            assert pol[k] == xo.label_of_str(mv) and vals[k] == v
+            state = xo.step(state, mv)
+            k += 1
+    assert k == len(planes) == off[-1]
+    with pytest.raises(ValueError):
+        expand_records([[xo.INIT_STATE, ['4445', 1]]])
+
+
+def _oracle_arena_game(idx, pc, specs, u_fn):
+    """EvaluateWorker.start_game (reference worker/evaluator.py:147-250) with two oracle players."""
+    def ocfg():
+        return xo.play_cfg(simulation_num_per_move=pc.simulation_num_per_move, search_threads=pc.search_threads,
+                           c_puct=pc.c_puct, noise_eps=0.0, dirichlet_alpha=pc.dirichlet_alpha,
+                           tau_decay_rate=pc.tau_decay_rate, virtual_loss=pc.virtual_loss, evaluate=1,
+                           max_game_length=pc.max_game_length)
+    p1, p2 = xo.Player(ocfg(), specs[0]), xo.Player(ocfg(), specs[1])
+    red, black = (p1, p2) if idx % 2 == 0 else (p2, p1)
+    state, history = xo.INIT_STATE, [xo.INIT_STATE]
+    value = turns = no_eat_count = 0
+    game_over = check = False
+    final_move = None
+    while not game_over:
+        no_act, increase_temp = None, False
+        if not check and state in history[:-1]:
+            no_act, increase_temp, free = [], True, 0
+            for i in range(len(history) - 1):
+                if history[i] == state:
+                    if xo.will_check_or_catch(state, history[i + 1]):
+                        no_act.append(history[i + 1])
+                    else:
+                        free += 1
+                        if free >= 3:
+                            game_over, value = True, 0
+                            break
+        if game_over:
+            break
+        pl = red if turns % 2 == 0 else black
+        action, _ = pl.action(state, turns, no_act, increase_temp, u_fn(idx, turns))
+        if action is None:
+            value = -1
+            break
+        history.append(action)
+        state, no_eat = xo.new_step(state, action)
+        turns += 1
+        no_eat_count = no_eat_count + 1 if no_eat else 0
+        history.append(state)
+        if no_eat_count >= 120 or turns / 2 >= pc.max_game_length:
+            game_over, value = True, 0
+        else:
+            game_over, value, final_move, check = xo.done(state, need_check=True)
+            if not game_over and not xo.has_attack_chessman(state):
+                game_over, value = True, 0
+    if final_move:
+        turns += 1
+        value = -value
+    if turns % 2 == 1:
+        value = -value
+    p1.close()
+    p2.close()
+    return value, turns
+
+
+@pytest.mark.parametrize("K,sims,tau", [(1, 10, 0.0), (4, 24, 0.9)])
+def test_evaluator_arena_matches_oracle(tmp_path, monkeypatch, K, sims, tau):
+    """Two models, two trees per game, colours alternating by game index (BASELINE config 4)."""
+    from cchess_alphazero.worker.evaluator import EvaluateWorker, score_table
+    cfg = _cfg(tmp_path, monkeypatch, simulation_num_per_move=sims, search_threads=K, noise_eps=0.0,
+               tau_decay_rate=tau, c_puct=1.0, max_game_length=14)
+    cfg.opts.evaluate = True
+    specs = (dict(kind="hash", salt=41), dict(kind="hash", salt=42))
+    evs = tuple((lambda planes, s=s: stub_net.hash_stub_torch(planes, s["salt"])) for s in specs)
+
+    def u_fn(g, turns):
+        return stub_net.philox_uniform(99, g, 1, turns)
+    n = 10
+    w = EvaluateWorker(cfg, evaluators=evs, seed=5)
+    got = w.play_games(n, u_fn=u_fn)
+    exp = [_oracle_arena_game(i, cfg.play, specs, u_fn) for i in range(n)]
+    assert got == exp
+    table = score_table(got)
+    assert sum(table[1:]) == n and 0 <= table[0] <= n

@@ -37,8 +37,8 @@ def play_config(**kw):
     return types.SimpleNamespace(**d)
 
 
-def oracle_cfg(pc, evaluate=0):
-    return xo.play_cfg(simulation_num_per_move=pc.simulation_num_per_move, search_threads=pc.search_threads,
+def oracle_cfg(pc, evaluate=0, node_capacity=0):
+    return xo.play_cfg(node_capacity=node_capacity, simulation_num_per_move=pc.simulation_num_per_move, search_threads=pc.search_threads,
                        c_puct=pc.c_puct, noise_eps=pc.noise_eps, dirichlet_alpha=pc.dirichlet_alpha,
                        tau_decay_rate=pc.tau_decay_rate, virtual_loss=pc.virtual_loss,
                        resign_threshold=pc.resign_threshold, min_resign_turn=pc.min_resign_turn, evaluate=evaluate,
@@ -167,13 +167,13 @@ def test_multi_ply_reuse_matches_oracle(gpu):
 
 
 def test_compaction_keeps_the_reachable_subtree(gpu):
-    """A small arena forces compaction between plies; as long as no dropped position recurs the search must be
-    indistinguishable from the oracle's unbounded tree (visit counts, W, subtree reuse)."""
+    """A small arena forces compaction between plies (keep the sub-DAG reachable from the new root); the
+    oracle models the same arena, so visit counts, W and subtree reuse must stay identical."""
     pc = play_config(simulation_num_per_move=100, search_threads=4)
     spec = dict(kind="hash", salt=17)
     G = 3
     s = gpu.S.Search(pc, G, seed=1, node_capacity=260)
-    players = [xo.Player(oracle_cfg(pc), spec) for _ in range(G)]
+    players = [xo.Player(oracle_cfg(pc, node_capacity=260), spec) for _ in range(G)]   # same arena model
     states = [xo.INIT_STATE, MID, xo.step(xo.INIT_STATE, '7242')]
     t = gpu.torch
     for ply in range(12):
@@ -187,7 +187,10 @@ def test_compaction_keeps_the_reachable_subtree(gpu):
             assert xo.label_str(int(act[g])) == a
             states[g] = xo.step(states[g], a)
     c = s.counters()
-    assert c["tree_compactions"] > 0 and c["tree_resets"] == 0 and c["overflow_sims"] == 0, c
+    oc = [p.counters() for p in players]
+    assert c["tree_compactions"] > 0 and c["overflow_sims"] == 0, c
+    assert c["tree_compactions"] == sum(o["tree_compactions"] for o in oc)
+    assert c["tree_resets"] == sum(o["tree_resets"] for o in oc)
     for p in players:
         p.close()
     s.close()
