@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void k_movegen(const int8_t* __restrict__ board
     const int lane = lane_id();
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         load_board(boards + (size_t)i * NSQ, w.bd[0]);
-        const int c = wave_movegen(w.bd[0], w.ml[0]);
+        const int c = wave_movegen(w.bd[0], w.ml[0], w.plist);
         uint16_t* mo = moves + (size_t)i * MAXMOVES;
         mo[lane] = lane < c ? w.ml[0].lab[lane] : NOMOVE;
         mo[lane + 64] = lane + 64 < c ? w.ml[0].lab[lane + 64] : NOMOVE;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void k_done(const int8_t* __restrict__ boards, 
     const int lane = lane_id();
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         load_board(boards + (size_t)i * NSQ, w.bd[0]);
-        const DoneResult r = wave_done(w.bd[0], w.bd[1], w.ml[0], w.ml[1], need_check != 0);
+        const DoneResult r = wave_done(w.bd[0], w.bd[1], w.ml[0], w.ml[1], w.plist, need_check != 0);
         if (lane == 0) {
             over[i] = (int8_t)r.over;
             v[i] = (int8_t)r.v;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void k_be_catched(const int8_t* __restrict__ bo
         load_board(boards + (size_t)i * NSQ, w.bd[0]);
         const int label = mv[i];
         int r = 0xFF;
-        if (label < NLABELS) r = wave_be_catched(w.bd[0], label_ft(label) >> 8, w.bd[1], w.ml[0]);
+        if (label < NLABELS) r = wave_be_catched(w.bd[0], label_ft(label) >> 8, w.bd[1], w.ml[0], w.plist);
         if (lane == 0) out[i] = (uint8_t)r;
         wave_sync();
     }
@@ -170,9 +170,9 @@ __global__ __launch_bounds__(64) void k_rules_fused(const int8_t* __restrict__ b
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         load_board(boards + (size_t)i * NSQ, w.bd[0]);
         wave_encode<DT>(w.bd[0], (char*)planes + (size_t)i * 1260 * esz);
-        DoneResult r = wave_done(w.bd[0], w.bd[1], w.ml[0], w.ml[1], true);
+        DoneResult r = wave_done(w.bd[0], w.bd[1], w.ml[0], w.ml[1], w.plist, true);
         int c = r.nmoves;
-        if (c < 0) c = wave_movegen(w.bd[0], w.ml[0]);       // early-decided positions still report their list
+        if (c < 0) c = wave_movegen(w.bd[0], w.ml[0], w.plist);       // early-decided positions still report their list
         uint16_t* mo = moves + (size_t)i * MAXMOVES;
         mo[lane] = lane < c ? w.ml[0].lab[lane] : NOMOVE;
         mo[lane + 64] = lane + 64 < c ? w.ml[0].lab[lane + 64] : NOMOVE;

@@ -108,44 +108,72 @@ XQ_HD int step_code(int p, int k)
 #endif
 }
 
-// Moves of the piece standing on square s (0 if empty / opponent), reference order (static_env.py:256-321).
-template <bool EMIT>
-XQ_HD int gen_sq(const int8_t* b, int s, uint16_t* lab, uint16_t* ft, int off)
+// 90-bit square sets (bit s = square s): occupancy, the mover's pieces, the opponent's king(s).
+struct Set90 {
+    uint64_t lo, hi;
+};
+XQ_HD bool has(const Set90& m, int s) { return s < 64 ? (m.lo >> s) & 1ull : (m.hi >> (s - 64)) & 1ull; }
+// the 9 squares of rank y as bits 0..8
+XQ_HD uint32_t rank_bits(const Set90& m, int y)
 {
-    const int p = b[s];
-    if (p <= 0) return 0;
+    const int pos = 9 * y;
+    uint64_t v;
+    if (pos >= 64) v = m.hi >> (pos - 64);
+    else if (pos + 9 <= 64) v = m.lo >> pos;
+    else v = (m.lo >> pos) | (m.hi << (64 - pos));
+    return (uint32_t)v & 0x1FFu;
+}
+// the 10 squares of file x as bits 0..9
+XQ_HD uint32_t file_bits(const Set90& m, int x)
+{
+    uint32_t v = 0;
+    for (int y = 0; y < 10; ++y) v |= (uint32_t)has(m, 9 * y + x) << y;
+    return v;
+}
+XQ_HD int top_bit(uint32_t v) { return 31 - __builtin_clz(v); }       // v != 0
+XQ_HD int low_bit(uint32_t v) { return __builtin_ctz(v); }            // v != 0
+
+// Moves of the mover's piece `p` (> 0) standing on square s, reference order (static_env.py:256-321).
+// The board enters only through three square sets, so no lane touches LDS while generating:
+//   occ = all pieces, own = the mover's pieces, oking = the opponent's king(s).
+template <bool EMIT>
+XQ_HD int gen_piece(int p, int s, const Set90& occ, const Set90& own, const Set90& oking,
+                    uint16_t* lab, uint16_t* ft, int off)
+{
     MoveSink<EMIT> out{lab, ft, off, 0};
     const int x = s % 9, y = s / 9;
     if (p == ROOK || p == CANNON) {                       // :288-320
+        const uint32_t row = rank_bits(occ, y), col = file_bits(occ, x);
         // nearest blockers on the four rays (x_board_from / y_board_from, :332-348); sentinels -1 / 9 / 10
-        int l = x - 1, r = x + 1, d = y - 1, u = y + 1;
-        while (l > -1 && b[y * 9 + l] == 0) --l;
-        while (r < 9 && b[y * 9 + r] == 0) ++r;
-        while (d > -1 && b[d * 9 + x] == 0) --d;
-        while (u < 10 && b[u * 9 + x] == 0) ++u;
+        uint32_t lm = row & ((1u << x) - 1u), rm = row >> (x + 1);
+        uint32_t dm = col & ((1u << y) - 1u), um = col >> (y + 1);
+        int l = lm ? top_bit(lm) : -1, r = rm ? x + 1 + low_bit(rm) : 9;
+        int d = dm ? top_bit(dm) : -1, u = um ? y + 1 + low_bit(um) : 10;
         for (int t = l + 1; t < x; ++t) out.put(s, y * 9 + t);
         for (int t = x + 1; t < r; ++t) out.put(s, y * 9 + t);
         for (int t = d + 1; t < y; ++t) out.put(s, t * 9 + x);
         for (int t = y + 1; t < u; ++t) out.put(s, t * 9 + x);
-        if (p == CANNON) {                                // jump to the next blocker beyond each screen
-            if (l > -1) { --l; while (l > -1 && b[y * 9 + l] == 0) --l; }
-            if (r < 9) { ++r; while (r < 9 && b[y * 9 + r] == 0) ++r; }
-            if (d > -1) { --d; while (d > -1 && b[d * 9 + x] == 0) --d; }
-            if (u < 10) { ++u; while (u < 10 && b[u * 9 + x] == 0) ++u; }
+        if (p == CANNON) {                                // the next blocker beyond each screen
+            if (l > -1) { lm &= ~(1u << l); l = lm ? top_bit(lm) : -1; }
+            if (r < 9) { rm &= rm - 1u; r = rm ? x + 1 + low_bit(rm) : 9; }
+            if (d > -1) { dm &= ~(1u << d); d = dm ? top_bit(dm) : -1; }
+            if (u < 10) { um &= um - 1u; u = um ? y + 1 + low_bit(um) : 10; }
         }
         // a blocker is never empty, so can_move() == "on board and not the mover's own piece"
-        if (l > -1 && b[y * 9 + l] < 0) out.put(s, y * 9 + l);
-        if (r < 9 && b[y * 9 + r] < 0) out.put(s, y * 9 + r);
-        if (d > -1 && b[d * 9 + x] < 0) out.put(s, d * 9 + x);
-        if (u < 10 && b[u * 9 + x] < 0) out.put(s, u * 9 + x);
+        if (l > -1 && !has(own, y * 9 + l)) out.put(s, y * 9 + l);
+        if (r < 9 && !has(own, y * 9 + r)) out.put(s, y * 9 + r);
+        if (d > -1 && !has(own, d * 9 + x)) out.put(s, d * 9 + x);
+        if (u < 10 && !has(own, u * 9 + x)) out.put(s, u * 9 + x);
         return out.n;
     }
     // stepping pieces: one table-driven loop (:264-286)
     int fly = -1;                                         // flying-king capture target, -1 if none
     if (p == KING) {
-        int u = y + 1;
-        while (u < 10 && b[u * 9 + x] == 0) ++u;
-        if (u < 10 && b[u * 9 + x] == -KING) fly = u * 9 + x;
+        const uint32_t um = file_bits(occ, x) >> (y + 1);
+        if (um) {
+            const int u = y + 1 + low_bit(um);
+            if (has(oking, u * 9 + x)) fly = u * 9 + x;
+        }
     }
     const int nd = step_count(p);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -157,11 +185,11 @@ XQ_HD int gen_sq(const int8_t* b, int s, uint16_t* lab, uint16_t* ft, int off)
         const int x_ = x + dx, y_ = y + dy;
         if (x_ < 0 || x_ > 8 || y_ < 0 || y_ > 9) continue;           // can_move, :323-330
         const int t = y_ * 9 + x_;
-        if (b[t] > 0) continue;
+        if (has(own, t)) continue;
         if (p == PAWN) {
             if (y < 5 && x_ != x) continue;                           // :270
         } else if (p == KNIGHT || p == ELEPHANT) {
-            if (b[(y + dy / 2) * 9 + x + dx / 2] != 0) continue;      // leg / eye; int(d/2) truncates toward 0
+            if (has(occ, (y + dy / 2) * 9 + x + dx / 2)) continue;    // leg / eye; int(d/2) truncates toward 0
             if (p == ELEPHANT && y_ > 4) continue;                    // :275
         } else {                                                      // king, advisor: palace (:277-281)
             if (x_ < 3 || x_ > 5 || y_ > 2) continue;

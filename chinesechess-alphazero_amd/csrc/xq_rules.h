@@ -27,6 +27,7 @@ struct RulesLDS {
     int8_t bd[4][BOARD_LDS];    // 0: position, 1..3: derived boards (flip / step / nested step)
     MoveList ml[3];
     uint32_t cset[2][MAXMOVES]; // chase sets of will_check_or_catch
+    uint16_t plist[BOARD_LDS];  // the mover's pieces in square order: square | type << 8
 };
 
 XQ_D int lane_id() { return (int)(threadIdx.x & 63u); }
@@ -122,22 +123,37 @@ XQ_D void apply_move_noflip(const int8_t* in, int from, int to, int8_t* out)
     wave_sync();
 }
 
-// get_legal_moves (static_env.py:256-321).  Returns the move count (may exceed MAXMOVES only
-// for impossible boards; entries beyond MAXMOVES are dropped).  Board must be visible in LDS.
-XQ_D int wave_movegen(const int8_t* b, MoveList& ml)
+// get_legal_moves (static_env.py:256-321).  Returns the move count (may exceed MAXMOVES only for impossible
+// boards; entries beyond MAXMOVES are dropped).  Board must be visible in LDS.
+// The board is reduced to three wave-uniform square sets by ballots; the mover's pieces are compacted (in
+// square order) so that lane r generates the moves of the r-th piece from those sets alone, and the ordered
+// move list is assembled by a prefix sum over the per-piece counts.
+XQ_D int wave_movegen(const int8_t* b, MoveList& ml, uint16_t* plist)
 {
     const int lane = lane_id();
-    const int c0 = gen_sq<false>(b, lane, nullptr, nullptr, 0);
-    const int c1 = (lane < 26) ? gen_sq<false>(b, lane + 64, nullptr, nullptr, 0) : 0;
-    const int i0 = wave_incl_scan(c0, lane);
-    const int i1 = wave_incl_scan(c1, lane);
-    const int t0 = __shfl(i0, 63, 64);
-    const int t1 = __shfl(i1, 63, 64);
-    wave_sync();                                  // earlier readers of `ml` are done
-    if (c0) gen_sq<true>(b, lane, ml.lab, ml.ft, i0 - c0);
-    if (c1) gen_sq<true>(b, lane + 64, ml.lab, ml.ft, t0 + i1 - c1);
+    const int p0 = b[lane];
+    const int p1 = (lane < 26) ? b[lane + 64] : 0;
+    const Set90 occ{__ballot(p0 != 0), __ballot(p1 != 0)};
+    const Set90 own{__ballot(p0 > 0), __ballot(p1 > 0)};
+    const Set90 oking{__ballot(p0 == -KING), __ballot(p1 == -KING)};
+    const uint64_t below = (1ull << lane) - 1ull;
+    const int n_lo = __popcll(own.lo), np = n_lo + __popcll(own.hi);
+    wave_sync();                                  // earlier readers of `ml` / `plist` are done
+    if (p0 > 0) plist[__popcll(own.lo & below)] = (uint16_t)(lane | (p0 << 8));
+    if (p1 > 0) plist[n_lo + __popcll(own.hi & below)] = (uint16_t)((lane + 64) | (p1 << 8));
     wave_sync();
-    return t0 + t1;
+    int total = 0;
+    for (int base = 0; base < np; base += 64) {   // one pass for every legal position (<= 16 pieces)
+        const bool act = base + lane < np;
+        const int e = act ? plist[base + lane] : 0;
+        const int s = e & 0xFF, p = e >> 8;
+        const int c = act ? gen_piece<false>(p, s, occ, own, oking, nullptr, nullptr, 0) : 0;
+        const int inc = wave_incl_scan(c, lane);
+        if (c) gen_piece<true>(p, s, occ, own, oking, ml.lab, ml.ft, total + inc - c);
+        total += __shfl(inc, 63, 64);
+    }
+    wave_sync();
+    return total;
 }
 
 // index of the first move in ml[0..n) whose destination is `sq`, or -1
@@ -160,7 +176,7 @@ struct DoneResult {
 
 // done (static_env.py:14-77).  b: position; tmpb: scratch board; ml0: receives the move list of b
 // (when the early tests did not decide); ml1: scratch list for the need_check pass.
-XQ_D DoneResult wave_done(const int8_t* b, int8_t* tmpb, MoveList& ml0, MoveList& ml1, bool need_check)
+XQ_D DoneResult wave_done(const int8_t* b, int8_t* tmpb, MoveList& ml0, MoveList& ml1, uint16_t* plist, bool need_check)
 {
     const int lane = lane_id();
     DoneResult r{0, 0, NOMOVE, 0, -1};
@@ -183,14 +199,14 @@ XQ_D DoneResult wave_done(const int8_t* b, int8_t* tmpb, MoveList& ml0, MoveList
         if (!__ballot(blk0 || blk1)) { r.v = 1; winner = 1; }
     }
     if (!winner) {                                             // :52-60
-        const int n = wave_movegen(b, ml0);
+        const int n = wave_movegen(b, ml0, plist);
         r.nmoves = n;
         const int k = first_move_to(ml0, n, bk);
         if (k >= 0) { winner = 1; r.v = 1; r.final_move = ml0.lab[k]; }
     }
     if (!winner && need_check) {                               // :61-73
         flip_board(b, tmpb);
-        const int n2 = wave_movegen(tmpb, ml1);
+        const int n2 = wave_movegen(tmpb, ml1, plist);
         r.check = first_move_to(ml1, n2, 89 - rk) >= 0;
     }
     r.over = winner != 0;
@@ -209,17 +225,17 @@ XQ_D int wave_has_attack(const int8_t* b)
 }
 
 // be_catched (static_env.py:456-469): is the square the move starts from attacked right now
-XQ_D int wave_be_catched(const int8_t* b, int from, int8_t* tmpb, MoveList& ml)
+XQ_D int wave_be_catched(const int8_t* b, int from, int8_t* tmpb, MoveList& ml, uint16_t* plist)
 {
     flip_board(b, tmpb);
-    const int n = wave_movegen(tmpb, ml);
+    const int n = wave_movegen(tmpb, ml, plist);
     return first_move_to(ml, n, 89 - from) >= 0;
 }
 
 // get_catch_list (static_env.py:423-454) over a given ordered move list.  Keys:
 // attacker type << 24 | from << 16 | victim type << 8 | to.  Returns the set size.
 XQ_D int wave_catch_list(const int8_t* b, const MoveList& moves, int nmoves,
-                         int8_t* nextb, MoveList& reply, uint32_t* set)
+                         int8_t* nextb, MoveList& reply, uint32_t* set, uint16_t* plist)
 {
     const int lane = lane_id();
     int cnt = 0;
@@ -230,7 +246,7 @@ XQ_D int wave_catch_list(const int8_t* b, const MoveList& moves, int nmoves,
         const int vict = b[t];
         if (vict == 0) continue;                               // no capture
         step_board(b, f, t, nextb);
-        const int nr = wave_movegen(nextb, reply);
+        const int nr = wave_movegen(nextb, reply, plist);
         if (first_move_to(reply, nr, 89 - t) >= 0) continue;   // could be recaptured
         const int a = b[f];
         if (a == PAWN && f / 9 <= 4) continue;                 // :443-444
@@ -262,11 +278,11 @@ XQ_D int wave_will_check_or_catch(RulesLDS& w, const int8_t* b, int label)
     const int q0 = black[lane], q1 = (lane < 26) ? black[lane + 64] : 0;
     const int ksq = lowest_bit(__ballot(q0 == -KING), __ballot(q1 == -KING));
     const int target = ksq >= 0 ? ksq : 89;       // red_k stays [0,0] -> (9,8) when the king is gone
-    const int nb = wave_movegen(black, w.ml[0]);
+    const int nb = wave_movegen(black, w.ml[0], w.plist);
     if (first_move_to(w.ml[0], nb, target) >= 0) return 1;                        // :406-411
-    const int n1 = wave_movegen(b, w.ml[1]);
-    const int c1 = wave_catch_list(b, w.ml[1], n1, w.bd[2], w.ml[2], w.cset[0]);  // first_set
-    const int c2 = wave_catch_list(black, w.ml[0], nb, w.bd[2], w.ml[2], w.cset[1]);
+    const int n1 = wave_movegen(b, w.ml[1], w.plist);
+    const int c1 = wave_catch_list(b, w.ml[1], n1, w.bd[2], w.ml[2], w.cset[0], w.plist);  // first_set
+    const int c2 = wave_catch_list(black, w.ml[0], nb, w.bd[2], w.ml[2], w.cset[1], w.plist);
     // second_set - first_set != {} and len(second_set) >= len(first_set), :415
     bool fresh = false;
     for (int i = 0; i < c2; ++i) {

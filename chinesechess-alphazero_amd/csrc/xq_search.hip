@@ -423,7 +423,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
         L.r.bd[1][lane] = gb[lane];
         if (lane < 32) L.r.bd[1][lane + 64] = (lane < 26) ? gb[lane + 64] : (int8_t)0;
         wave_sync();
-        const int nm = wave_movegen(L.r.bd[1], L.r.ml[0]);
+        const int nm = wave_movegen(L.r.bd[1], L.r.ml[0], L.r.plist);
         const uint64_t h = pack_key(L.r.bd[1], L.key);
         int slot;
         int idx = hash_lookup(gv, P, L.key, h, &slot);
@@ -445,7 +445,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
             const int mv = uni((int)gv.e_mv[L.path_edge[rep]]);
             double v;
             if (wave_will_check_or_catch(L.r, L.r.bd[0], mv) == 1) v = -1.0;
-            else if (wave_be_catched(L.r.bd[0], label_ft(mv) >> 8, L.r.bd[1], L.r.ml[0])) v = 1.0;
+            else if (wave_be_catched(L.r.bd[0], label_ft(mv) >> 8, L.r.bd[1], L.r.ml[0], L.r.plist)) v = 1.0;
             else v = 0.0;
             count(gv, CT_REPETITION_SIMS);
             backup(P, gv, L, depth, v);
@@ -491,7 +491,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
             unpack_key(gv.node_key + (size_t)node * KEY_WORDS, L.r.bd[0]);
             const int ft = label_ft(uni((int)gv.e_mv[e]));
             step_board(L.r.bd[0], ft >> 8, ft & 0xFF, L.r.bd[1]);
-            const DoneResult d = wave_done(L.r.bd[1], L.r.bd[2], L.r.ml[0], L.r.ml[1], false);   // player.py:204
+            const DoneResult d = wave_done(L.r.bd[1], L.r.bd[2], L.r.ml[0], L.r.ml[1], L.r.plist, false);   // player.py:204
             if (d.over) {
                 child = d.v > 0 ? CHILD_TERM_WIN : CHILD_TERM_LOSS;
                 if (lane == 0) gv.e_child[e] = child;
@@ -919,7 +919,7 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
         if (no_eat_count >= 120 || turns >= 2 * P.max_game_length) {    // :149-151
             game_over = true; value = 0;
         } else {
-            const DoneResult d = wave_done(L.r.bd[3], L.r.bd[1], L.r.ml[0], L.r.ml[1], true);   // :153
+            const DoneResult d = wave_done(L.r.bd[3], L.r.bd[1], L.r.ml[0], L.r.ml[1], L.r.plist, true);   // :153
             game_over = d.over != 0; value = d.v; final_move = d.final_move;
             if (!game_over && !wave_has_attack(L.r.bd[3])) { game_over = true; value = 0; }  // :154-158
             if (!game_over && !d.check) {                               // :161-175
@@ -938,7 +938,7 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
                             if (lane == 0) B.g_no_act[(size_t)g * MAX_NO_ACT + n_no_act] = (uint16_t)mv;
                             n_no_act += 1;
                         }
-                    } else if (!wave_be_catched(L.r.bd[0], label_ft(mv) >> 8, L.r.bd[1], L.r.ml[0])) {
+                    } else if (!wave_be_catched(L.r.bd[0], label_ft(mv) >> 8, L.r.bd[1], L.r.ml[0], L.r.plist)) {
                         inc = 1;
                         free_move += 1;
                         if (free_move >= 3) { game_over = true; value = 0; }
@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(64) void k_set_roots(SearchParams P, SearchBuffers 
     }
     wave_sync();
     // a terminal root has nothing to search (the reference's simulations would all return at once)
-    const DoneResult d = wave_done(L.r.bd[0], L.r.bd[1], L.r.ml[0], L.r.ml[1], false);
+    const DoneResult d = wave_done(L.r.bd[0], L.r.bd[1], L.r.ml[0], L.r.ml[1], L.r.plist, false);
     begin_search(P, B, gv, L);
     if (d.over && lane == 0) { B.g_tasks_left[g] = 0; }
 }

@@ -12,15 +12,22 @@ extern "C" {
 
 int lane_movegen(const int8_t* board, uint16_t* lab, uint16_t* ft)
 {
-    int counts[NSQ], total = 0;
-    for (int s = 0; s < NSQ; ++s) counts[s] = gen_sq<false>(board, s, nullptr, nullptr, 0);
-    int off = 0;
-    for (int s = 0; s < NSQ; ++s) {           // exclusive prefix sum in square order
-        if (counts[s]) gen_sq<true>(board, s, lab, ft, off);
-        off += counts[s];
+    // what the wave does with ballots: three 90-bit square sets + the mover's pieces in square order
+    Set90 occ{0, 0}, own{0, 0}, oking{0, 0};
+    auto set = [](Set90& m, int s) { if (s < 64) m.lo |= 1ull << s; else m.hi |= 1ull << (s - 64); };
+    for (int s = 0; s < NSQ; ++s) {
+        if (board[s] != 0) set(occ, s);
+        if (board[s] > 0) set(own, s);
+        if (board[s] == -KING) set(oking, s);
     }
-    total = off;
-    return total;
+    int off = 0;
+    for (int s = 0; s < NSQ; ++s) {           // exclusive prefix sum over the pieces in square order
+        if (board[s] <= 0) continue;
+        const int c = gen_piece<false>(board[s], s, occ, own, oking, nullptr, nullptr, 0);
+        if (c) gen_piece<true>(board[s], s, occ, own, oking, lab, ft, off);
+        off += c;
+    }
+    return off;
 }
 
 void lane_planes(const int8_t* board, float* planes)

@@ -34,9 +34,10 @@ def test_engine_records_replay_with_oracle():
             assert v == (g["value"] if i % 2 == 0 else -g["value"])
             state = xo.step(state, mv)
         over = xo.done(state)[0]
-        # a decided game ends with the king capture appended (self_play.py:177-184) unless it ended by resignation
+        # a decided game ends in a terminal position: the king capture appended (self_play.py:177-184) or the
+        # two kings facing each other (static_env.py:39-49) -- unless it ended by resignation
         if g["value"] != 0 and not g["resigned"]:
-            assert over and 's' not in state
+            assert over
 
 
 def test_reference_trainer_parses_engine_records():
