@@ -42,6 +42,32 @@ XQ_HD uint16_t label_ft(int label)
 #endif
 }
 
+// Label of a rook / cannon / king / pawn / knight move without the 16 KB (from, to) table: the label set
+// lists, per source square, the 8 same-rank and 9 same-file destinations and then the on-board knight jumps
+// (lookup_tables.py:66-77), so the index is base[from] + a position computed from the coordinates.
+// Advisor and elephant moves live in the literal tail of the set and keep using the table.
+XQ_HD uint16_t label_of_line_or_knight(int from, int to)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const Tables& T = d_tab;
+#else
+    const Tables& T = h_tab;
+#endif
+    const int x = from % 9, y = from / 9, tx = to % 9, ty = to / 9;
+    const int base = T.base[from];
+    if (ty == y) return (uint16_t)(base + (tx < x ? tx : tx - 1));
+    if (tx == x) return (uint16_t)(base + 8 + (ty < y ? ty : ty - 1));
+    // knight: offsets (dy, dx) in label order {-2,-1},{-1,-2},{-2,1},{1,-2},{2,-1},{-1,2},{2,1},{1,2}
+    const int dy = ty - y, dx = tx - x;
+    int k;
+    if (dy == -2) k = dx < 0 ? 0 : 2;
+    else if (dy == 2) k = dx < 0 ? 4 : 6;
+    else if (dy == -1) k = dx < 0 ? 1 : 5;
+    else k = dx < 0 ? 3 : 7;
+    const uint32_t valid = T.kvalid[from];
+    return (uint16_t)(base + 17 + __builtin_popcount(valid & ((1u << k) - 1u)));
+}
+
 // Sink for generated moves: an ordered list of (label, from<<8|to) starting at `off`.
 // EMIT=false only counts (first pass of the two-pass ordered compaction).
 template <bool EMIT>
@@ -50,12 +76,13 @@ struct MoveSink {
     uint16_t* ft;
     int off;
     int n;
+    bool tail;                  // advisor / elephant: label from the table
     XQ_HD void put(int from, int to)
     {
         if (EMIT) {
             const int i = off + n;
             if (i < MAXMOVES) {
-                lab[i] = label_of(from, to);
+                lab[i] = tail ? label_of(from, to) : label_of_line_or_knight(from, to);
                 ft[i] = (uint16_t)((from << 8) | to);
             }
         }
@@ -140,7 +167,7 @@ template <bool EMIT>
 XQ_HD int gen_piece(int p, int s, const Set90& occ, const Set90& own, const Set90& oking,
                     uint16_t* lab, uint16_t* ft, int off)
 {
-    MoveSink<EMIT> out{lab, ft, off, 0};
+    MoveSink<EMIT> out{lab, ft, off, 0, p == ADVISOR || p == ELEPHANT};
     const int x = s % 9, y = s / 9;
     if (p == ROOK || p == CANNON) {                       // :288-320
         const uint32_t row = rank_bits(occ, y), col = file_bits(occ, x);

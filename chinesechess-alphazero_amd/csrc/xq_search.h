@@ -105,6 +105,8 @@ struct SearchBuffers {
     unsigned int* ring_tail;       // [1] total records ever written
     int32_t* g_last_action; // [G] external mode: result of choose
     int32_t* pending;       // [1] scratch for cz_search_pending
+    double* noise;          // [G][K][128] Dirichlet(alpha)[0] draws for the root edges, refreshed by k_noise
+    uint32_t* g_noise_epoch;   // [G]
 };
 
 // finished-game record header (followed by uint16 moves[max_plies + 2])

@@ -5,13 +5,14 @@
 //   calc_policy / apply_temperature      (cchess_alphazero/agent/player.py:145-470)
 //   SelfPlayWorker.start_game            (cchess_alphazero/worker/self_play.py:95-212)
 //
-// One launch of k_round is one lock-step ROUND for every game:
-//   1. attach the network results of the previous round to their leaves and back them up,
-//   2. resume simulations that were parked on those leaves,
-//   3. when a batch of K simulations is complete start the next one (or finish the ply: pick the
-//      move, apply the game rules, start the next search / the next game),
-//   4. every new leaf writes its input planes into its fixed slot (game * K + sim) of the
-//      evaluation queue; the host then runs ONE network forward over the whole queue.
+// cz_search_round() is one lock-step ROUND for every game, three launches on one stream:
+//   k_sim(BACKUP)  1. attach the network results of the previous round to their leaves and back them up,
+//                  2. resume simulations that were parked on those leaves;
+//   k_advance      3. where a search is complete: pick the move, apply the game rules, start the next
+//                     search / the next game (self-play) or mark the game READY (external mode);
+//   k_sim(SELECT)  4. where a batch of K simulations is complete start the next one; every new leaf writes
+//                     its input planes into its fixed slot (game * K + sim) of the evaluation queue.
+// The host then runs ONE network forward over the whole queue.
 // There is no host decision inside a round and no device->host copy, so a round (kernel + network
 // forward) can be replayed from a HIP graph.
 //
@@ -277,9 +278,8 @@ struct RootCtx {
     bool is_root;
     int n_no_act;
     const uint16_t* no_act;
-    uint64_t seed;
-    uint32_t game_id;
-    int turns;
+    const double* noise;        // this game's Dirichlet rows [K][MAXMOVES] written by k_noise (NULL when eps == 0)
+    int sim;
 };
 
 XQ_D int select_edge(const SearchParams& P, const GameView& gv, int node, int nm, int eoff, const RootCtx& rc)
@@ -309,13 +309,7 @@ XQ_D int select_edge(const SearchParams& P, const GameView& gv, int node, int nm
                 }
                 const float a = P.one_minus_eps_f32 * p;
                 double p_ = (double)a;
-                if (P.noise_eps != 0.0) {
-                    uint64_t idx = ((uint64_t)(uint32_t)rc.turns << 48) | ((uint64_t)(uint32_t)sum_n << 24) | ((uint64_t)j << 16);
-                    const double x = gamma_draw(P.dirichlet_alpha, rc.seed, rc.game_id, idx);
-                    const double y = nm > 1 ? gamma_draw(P.dirichlet_alpha * (double)(nm - 1), rc.seed, rc.game_id, idx) : 0.0;
-                    const double dch = (x + y) > 0.0 ? x / (x + y) : 1.0 / (double)nm;
-                    p_ = p_ + P.noise_eps * dch;
-                }
+                if (rc.noise) p_ = p_ + P.noise_eps * rc.noise[(size_t)rc.sim * MAXMOVES + j];   // player.py:304
                 u = P.c_puct * p_ * xx / (double)(1 + n);
             } else {
                 const float a = P.c_puct_f32 * p;
@@ -469,6 +463,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
         const int eoff = (int)uniu(gv.node_eoff[node]);
         RootCtx rc = rc0;
         rc.is_root = (node == root);                                // player.py:266
+        rc.sim = sim;
         const int j = select_edge(P, gv, node, nm, eoff, rc);
         if (j < 0) {                                                // "Best action is None": cannot happen
             backup(P, gv, L, depth, 0.0);
@@ -974,23 +969,26 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
     new_game(P, B, gv, L, game_id + P.game_id_stride);
 }
 
-// ---- the round kernel ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_round(SearchParams P, SearchBuffers B, const float* __restrict__ policy,
-                                             const float* __restrict__ value, void* planes)
+// ---- the round kernels --------------------------------------------------------------------------------------
+// One lock-step round = k_sim(BACKUP) -> k_advance -> k_sim(SELECT)   (+ k_noise before each k_sim when the
+// root noise is on).  Splitting the round keeps the hot simulation kernel free of the cold, register-hungry code
+// (move sampling with pow(), game rules, tree compaction, Gamma sampling).
+constexpr int SIM_BACKUP = 1, SIM_SELECT = 2;
+
+__global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, const float* __restrict__ policy,
+                                           const float* __restrict__ value, void* planes, int mask)
 {
     __shared__ SearchLDS L;
     const int g = blockIdx.x;
     if (g >= P.G) return;
+    if (uni((int)B.g_phase[g]) != PH_SEARCH) return;
     const GameView gv = make_view(B, P, g);
     const RoundIO io{planes, P.planes_dtype};
-    int phase = uni((int)B.g_phase[g]);
-    if (phase != PH_SEARCH && !(phase == PH_READY && P.mode == MODE_SELFPLAY)) return;
     int active = uni(B.g_active[g]);
-    int root = uni(B.g_root[g]);
-    RootCtx rc{false, uni((int)B.g_n_no_act[g]), B.g_no_act + (size_t)g * MAX_NO_ACT, P.seed,
-               uniu(B.g_game_id[g]), uni(B.g_turns[g])};
-
-    if (phase == PH_SEARCH && active > 0) {
+    const RootCtx rc{false, uni((int)B.g_n_no_act[g]), B.g_no_act + (size_t)g * MAX_NO_ACT,
+                     P.noise_eps != 0.0 ? B.noise + (size_t)g * P.K * MAXMOVES : nullptr, 0};
+    int resume_i = P.K;
+    if ((mask & SIM_BACKUP) && active > 0) {
         // 1. attach + backup evaluated leaves, in simulation order (update_tree, player.py:340-373)
         for (int i = 0; i < P.K; ++i) {
             if (uni((int)gv.s_state[i]) != SIM_LEAF) continue;
@@ -1002,49 +1000,74 @@ __global__ __launch_bounds__(64) void k_round(SearchParams P, SearchBuffers B, c
             backup(P, gv, L, depth, (double)value[slot]);             // float(v) of a float32
             sim_finish(gv, i, &active);
         }
-        // 2. resume parked simulations, in simulation order (player.py:351-353)
-        for (int i = 0; i < P.K; ++i) {
+        resume_i = 0;                                                 // 2. then resume the parked simulations
+    }
+    int new_i = 0, new_n = 0;
+    for (int guard = 0; guard < (1 << 20); ++guard) {
+        int sim, node, depth;
+        if (resume_i < P.K) {                                         // parked simulations, in index order
+            const int i = resume_i++;
             if (uni((int)gv.s_state[i]) != SIM_PARKED) continue;
-            const int node = uni(gv.s_node[i]);
-            const int depth = uni(gv.s_depth[i]);
+            sim = i; node = uni(gv.s_node[i]); depth = uni(gv.s_depth[i]);
             load_path(P, gv, L, i, depth);
-            run_sim(P, B, gv, L, io, rc, root, i, node, depth, &active);
-        }
-    }
-    // 3. next batch / next ply
-    for (int iter = 0; iter < 1024; ++iter) {
-        if (phase == PH_SEARCH && active == 0) {
-            int tasks = uni(B.g_tasks_left[g]);
-            if (tasks > 0) {
-                const int n = tasks < P.K ? tasks : P.K;                // player.py:169-178
-                tasks -= n;
-                active = n;
-                if (lane_id() == 0) B.g_tasks_left[g] = tasks;
-                for (int i = 0; i < n; ++i) {
-                    root = uni(B.g_root[g]);
-                    run_sim(P, B, gv, L, io, rc, root, i, root, 0, &active);
-                }
-                if (active > 0) break;
-                continue;
-            }
-            phase = PH_READY;
-        }
-        if (phase == PH_READY && P.mode == MODE_SELFPLAY) {
-            advance_game(P, B, gv, L);
-            phase = PH_SEARCH;
-            active = 0;
-            root = uni(B.g_root[g]);
-            rc.n_no_act = uni((int)B.g_n_no_act[g]);
-            rc.game_id = uniu(B.g_game_id[g]);
-            rc.turns = uni(B.g_turns[g]);
+        } else if (new_i < new_n) {                                   // the simulations of a fresh batch
+            sim = new_i++; node = uni(B.g_root[g]); depth = 0;
+        } else if ((mask & SIM_SELECT) && active == 0) {              // 3. next lock-step batch (player.py:169-178)
+            const int tasks = uni(B.g_tasks_left[g]);
+            if (tasks <= 0) break;                                    // search complete: k_advance takes over
+            new_n = tasks < P.K ? tasks : P.K;
+            new_i = 0;
+            active = new_n;
+            if (lane_id() == 0) B.g_tasks_left[g] = tasks - new_n;
             continue;
+        } else break;
+        run_sim(P, B, gv, L, io, rc, uni(B.g_root[g]), sim, node, depth, &active);
+    }
+    if (lane_id() == 0) B.g_active[g] = active;
+}
+
+// End of a search: external mode marks the game READY; self-play mode plays the move, applies the game rules
+// and sets up the next search (or the next game).
+__global__ __launch_bounds__(64) void k_advance(SearchParams P, SearchBuffers B)
+{
+    __shared__ SearchLDS L;
+    const int g = blockIdx.x;
+    if (g >= P.G) return;
+    if (uni((int)B.g_phase[g]) != PH_SEARCH || uni(B.g_active[g]) != 0 || uni(B.g_tasks_left[g]) != 0) return;
+    const GameView gv = make_view(B, P, g);
+    if (P.mode == MODE_SELFPLAY) {
+        for (int it = 0; it < 8; ++it) {          // a search with nothing to do (fully reused root) ends at once
+            advance_game(P, B, gv, L);
+            if (uni(B.g_tasks_left[g]) != 0) break;
         }
-        break;
+    } else if (lane_id() == 0) {
+        B.g_phase[g] = PH_READY;
     }
-    if (lane_id() == 0) {
-        B.g_active[g] = active;
-        B.g_phase[g] = (uint8_t)phase;
-    }
+}
+
+// Dirichlet(alpha 1_n)[0] for every (simulation slot, root edge) of every searching game: X / (X + Y),
+// X ~ Gamma(alpha), Y ~ Gamma(alpha (n - 1)).  The reference redraws it per move per root visit (player.py:304);
+// each simulation selects at the root at most once per k_sim launch, so one row per slot per launch is enough.
+__global__ __launch_bounds__(64) void k_noise(SearchParams P, SearchBuffers B)
+{
+    const int g = blockIdx.x;
+    if (g >= P.G || B.g_phase[g] != PH_SEARCH) return;
+    const int root = B.g_root[g];
+    if (root < 0) return;
+    const int lane = lane_id();
+    const int nm = (int)(B.node_meta[(size_t)g * P.node_cap + root] & 0xFF);
+    const uint32_t epoch = B.g_noise_epoch[g];
+    const uint32_t game_id = B.g_game_id[g] + (uint32_t)g * 2654435761u;   // distinct streams in external mode too
+    double* rows = B.noise + (size_t)g * P.K * MAXMOVES;
+    for (int sim = 0; sim < P.K; ++sim)
+        for (int j = lane; j < nm; j += 64) {
+            uint64_t idx = ((uint64_t)epoch << 32) | ((uint64_t)sim << 20) | ((uint64_t)j << 12);
+            const double x = gamma_draw(P.dirichlet_alpha, P.seed, game_id, idx);
+            const double y = nm > 1 ? gamma_draw(P.dirichlet_alpha * (double)(nm - 1), P.seed, game_id, idx) : 0.0;
+            rows[(size_t)sim * MAXMOVES + j] = (x + y) > 0.0 ? x / (x + y) : 1.0 / (double)nm;
+        }
+    __syncthreads();
+    if (lane == 0) B.g_noise_epoch[g] = epoch + 1;
 }
 
 // ---- auxiliary kernels ---------------------------------------------------------------------------------------
@@ -1230,6 +1253,8 @@ size_t layout(cz_search* s, char* base, bool dry)
     carve(cur, B.ring_tail, 1, dry);
     carve(cur, B.g_last_action, G, dry);
     carve(cur, B.pending, 1, dry);
+    carve(cur, B.noise, G * K * MAXMOVES, dry);
+    carve(cur, B.g_noise_epoch, G, dry);
     return (size_t)(cur - base);
 }
 
@@ -1342,7 +1367,14 @@ int cz_search_set_roots(cz_search* s, const int8_t* boards, const int32_t* turns
 int cz_search_round(cz_search* s, const float* policy, const float* value, void* planes, void* stream)
 {
     if (!s || !planes || !policy || !value) return serr(CZ_ERR_ARG, "cz_search_round: null argument");
-    hipLaunchKernelGGL(k_round, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, policy, value, planes);
+    const dim3 grid(s->P.G), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    const bool noise = s->P.noise_eps != 0.0;
+    if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B);
+    hipLaunchKernelGGL(k_sim, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP);
+    hipLaunchKernelGGL(k_advance, grid, block, 0, st, s->P, s->B);
+    if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B);
+    hipLaunchKernelGGL(k_sim, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT);
     S_LAUNCH_CHECK("cz_search_round");
     return CZ_OK;
 }

@@ -21,6 +21,8 @@ enum : int { EMPTY = 0, PAWN = 1, CANNON = 2, ROOK = 3, KNIGHT = 4, ELEPHANT = 5
 struct Tables {
     uint16_t label_of[NSQ * NSQ];
     uint16_t lab_ft[NLABELS + 2];
+    uint16_t base[NSQ];         // first label of each source square's block (8 row + 9 file + knight moves)
+    uint8_t kvalid[NSQ];        // which of the 8 knight offsets (label order) stay on the board
 };
 
 constexpr Tables make_tables()
@@ -39,6 +41,12 @@ constexpr Tables make_tables()
     const int kn[8][2] = {{-2, -1}, {-1, -2}, {-2, 1}, {1, -2}, {2, -1}, {-1, 2}, {2, 1}, {1, 2}};
     for (int n1 = 0; n1 < 10; ++n1)
         for (int l1 = 0; l1 < 9; ++l1) {
+            t.base[n1 * 9 + l1] = (uint16_t)n;
+            t.kvalid[n1 * 9 + l1] = 0;
+            for (int k = 0; k < 8; ++k) {
+                const int n2 = n1 + kn[k][0], l2 = l1 + kn[k][1];
+                if (n2 >= 0 && n2 < 10 && l2 >= 0 && l2 < 9) t.kvalid[n1 * 9 + l1] |= (uint8_t)(1u << k);
+            }
             for (int c = 0; c < 9; ++c)
                 if (c != l1) add(l1, n1, c, n1);
             for (int r = 0; r < 10; ++r)

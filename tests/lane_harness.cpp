@@ -41,6 +41,20 @@ void lane_tables(uint16_t* label_of_out, uint16_t* lab_ft_out)
     memcpy(lab_ft_out, h_tab.lab_ft, sizeof(uint16_t) * NLABELS);
 }
 
+// every row / file / knight label must be reproduced by the table-free formula
+int lane_label_formula_mismatches(void)
+{
+    int bad = 0;
+    for (int l = 0; l < NLABELS; ++l) {
+        const int f = h_tab.lab_ft[l] >> 8, t = h_tab.lab_ft[l] & 0xFF;
+        const int dx = t % 9 - f % 9, dy = t / 9 - f / 9;
+        const bool line = dx == 0 || dy == 0;
+        const bool knight = (dx * dx + dy * dy) == 5;
+        if ((line || knight) && label_of_line_or_knight(f, t) != l) ++bad;
+    }
+    return bad;
+}
+
 int lane_nibble_roundtrip(void)
 {
     for (int p = -7; p <= 7; ++p)

@@ -299,3 +299,22 @@ def test_golden_reference_games(gpu):
             ref_moves = [m for m, _ in rec[1:]]
             assert [xo.label_str(int(m)) for m in got["moves"]] == ref_moves, gm["name"]
         assert got["turns"] == gm["turns"] and got["value"] == int(gm["value"]) and got["store"] == gm["store"]
+
+
+def test_root_noise_changes_visits_but_not_totals(gpu):
+    """Dirichlet root noise (player.py:304) is reproduced in distribution only: with noise the visit counts move,
+    the bookkeeping (root.sum_n == sims, sum of child visits == sims - 1) does not."""
+    states = [xo.INIT_STATE] * 8
+    outs = []
+    for eps in (0.0, 0.25):
+        pc = play_config(simulation_num_per_move=160, search_threads=8, noise_eps=eps, dirichlet_alpha=0.2)
+        s = gpu.S.Search(pc, len(states), seed=9)
+        s.set_roots(boards_tensor(gpu, states))
+        s.run_until_idle(stub_eval(gpu, dict(kind="hash", salt=1)))
+        st = s.root_stats()
+        assert (st["sum_n"] == 160).all() and (st["n"].sum(axis=1) == 159).all()
+        outs.append(st["n"].copy())
+        s.close()
+    assert (outs[0] == outs[0][0]).all()                    # without noise all 8 games are identical
+    assert len({tuple(r) for r in outs[1]}) > 1             # with noise they differ from game to game
+    assert (outs[1] != outs[0]).any()

@@ -29,6 +29,7 @@ def test_tables_match_oracle(harness):
     assert (lo.reshape(90, 90) == lab).all()
     assert ((ft >> 8) == fr).all() and ((ft & 0xFF) == to).all()
     assert harness.lane_nibble_roundtrip() == 1
+    assert harness.lane_label_formula_mismatches() == 0
 
 
 def test_movegen_and_planes(harness, positions_1k):
