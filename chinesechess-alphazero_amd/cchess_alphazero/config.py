@@ -68,7 +68,8 @@ class EngineConfig(_Section):
                          sims_per_round=None,     # lock-step batch per game; None = play.search_threads
                          net_dtype="float32",     # float32 (reference precision) | bfloat16 | float16
                          node_capacity=0, edge_capacity=0, max_depth=0,
-                         use_hip_graph=False, base_seed=0, report_every_rounds=200)
+                         use_hip_graph=False, base_seed=0, report_every_rounds=200,
+                         max_rounds=None, max_games=None)   # None = run forever, like the reference
 
 
 class Options:

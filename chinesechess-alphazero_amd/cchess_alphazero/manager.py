@@ -36,6 +36,8 @@ def create_parser():
     # engine knobs (not in the reference)
     p.add_argument("--games-per-gpu", type=int, default=None, help="concurrent games per GPU")
     p.add_argument("--net-dtype", default=None, choices=["float32", "bfloat16", "float16"])
+    p.add_argument("--max-rounds", type=int, default=None, help="stop after this many lock-step rounds (default: never)")
+    p.add_argument("--max-games", type=int, default=None, help="stop after this many finished games (default: never)")
     return p
 
 
@@ -58,6 +60,8 @@ def start():
         config.engine.games_per_gpu = args.games_per_gpu
     if args.net_dtype:
         config.engine.net_dtype = args.net_dtype
+    config.engine.max_rounds = args.max_rounds
+    config.engine.max_games = args.max_games
     config.opts.piece_style = args.piece_style
     config.opts.bg_style = args.bg_style
     config.internet.distributed = args.distributed

@@ -115,7 +115,8 @@ class SelfPlayWorker:
         return reduce_counters(self.engine.counters())
 
     def start(self):
-        self.run()
+        ec = self.config.engine
+        return self.run(max_rounds=getattr(ec, "max_rounds", None), max_games=getattr(ec, "max_games", None))
 
     def close(self):
         if self.engine is not None:

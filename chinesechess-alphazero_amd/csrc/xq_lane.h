@@ -76,13 +76,12 @@ struct MoveSink {
     uint16_t* ft;
     int off;
     int n;
-    bool tail;                  // advisor / elephant: label from the table
     XQ_HD void put(int from, int to)
     {
         if (EMIT) {
             const int i = off + n;
             if (i < MAXMOVES) {
-                lab[i] = tail ? label_of(from, to) : label_of_line_or_knight(from, to);
+                lab[i] = label_of(from, to);      // 16 KB table, L1-resident; measured faster than label_of_line_or_knight
                 ft[i] = (uint16_t)((from << 8) | to);
             }
         }
@@ -167,7 +166,7 @@ template <bool EMIT>
 XQ_HD int gen_piece(int p, int s, const Set90& occ, const Set90& own, const Set90& oking,
                     uint16_t* lab, uint16_t* ft, int off)
 {
-    MoveSink<EMIT> out{lab, ft, off, 0, p == ADVISOR || p == ELEPHANT};
+    MoveSink<EMIT> out{lab, ft, off, 0};
     const int x = s % 9, y = s / 9;
     if (p == ROOK || p == CANNON) {                       // :288-320
         const uint32_t row = rank_bits(occ, y), col = file_bits(occ, x);

@@ -187,3 +187,18 @@ def test_evaluator_arena_matches_oracle(tmp_path, monkeypatch, K, sims, tau):
     assert got == exp
     table = score_table(got)
     assert sum(table[1:]) == n and 0 <= table[0] <= n
+
+
+def test_run_py_self_cli(tmp_path):
+    """`python cchess_alphazero/run.py self --type mini ...` (reference CLI) end to end: play records appear."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "chinesechess-alphazero_amd")
+    env = dict(os.environ, DATA_DIR=str(tmp_path / "data"), PROJECT_DIR=str(tmp_path), PYTHONPATH=pkg)
+    # a small bounded run: the mini type plays 100-sim searches with a 7x256 net; keep it short
+    r = subprocess.run([sys.executable, os.path.join(pkg, "cchess_alphazero", "run.py"), "self", "--type", "mini",
+                        "--games-per-gpu", "64", "--max-rounds", "60"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert os.path.isdir(tmp_path / "data" / "play_data") and os.path.exists(tmp_path / "logs" / "play.log")
