@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 #include "xq_rules.h"
+#include "xq_tpb.h"
 #include "../../include/czero.h"
 
 using namespace xq;
@@ -26,6 +27,9 @@ int set_err_msg(int code, const char* what)
     snprintf(g_err, sizeof(g_err), "%s", what);
     return code;
 }
+
+// batches at least this large run one board per LANE (k_rules_tpb); smaller ones one board per wavefront
+constexpr int CZ_TPB_MIN_BOARDS = 256;
 
 inline int grid_for(int n)
 {
@@ -187,6 +191,120 @@ __global__ __launch_bounds__(64) void k_rules_fused(const int8_t* __restrict__ b
     }
 }
 
+// ---- one board per lane (xq_tpb.h): the throughput form of move-gen + done + planes -------------------------
+// 64 boards per wavefront.  Global traffic stays coalesced by staging through LDS: the 64 boards are loaded as
+// one contiguous 5760-byte run, every lane then works on its own board and writes its ordered move list into its
+// own LDS row, and the move lists / planes leave through wave-wide stores, one board at a time.
+constexpr int TPB_BOARD_STRIDE = 100;    // bytes; 25 dwords: lanes reading the same square hit 64 different banks
+constexpr int TPB_ROW_STRIDE = 130;      // uint16 per move-list row; 65 dwords: row starts fall on different banks
+
+struct TpbLDS {
+    int8_t bd[64 * TPB_BOARD_STRIDE];
+    uint16_t rows[64 * TPB_ROW_STRIDE];
+    uint8_t cnt[64];
+};
+
+// turn a board row (int8[90], y = 0 first) into plane codes in the planes' row order (string row i = y 9 - i):
+// 0..13 = channel of the piece on that square, 0xFF = empty (static_env.py:137-156)
+XQ_D void board_to_plane_codes(int8_t* b)
+{
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 9; ++j) {
+            const int a = i * 9 + j, c = (9 - i) * 9 + j;
+            const int pa = b[a], pc = b[c];
+            b[a] = (int8_t)(pc == 0 ? -1 : (pc > 0 ? pc - 1 : 6 - pc));
+            b[c] = (int8_t)(pa == 0 ? -1 : (pa > 0 ? pa - 1 : 6 - pa));
+        }
+}
+
+template <int DT>
+XQ_D void tpb_write_planes(const int8_t* codes, void* __restrict__ out)
+{
+    const int lane = lane_id();
+    for (int q = lane; q < 315; q += 64) {
+        const int o = q * 4;
+        int c = o / 90, pos = o - c * 90;
+        int bit[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bit[e] = codes[pos] == c;
+            if (++pos == 90) { pos = 0; ++c; }
+        }
+        if (DT == 0) {
+            reinterpret_cast<float4*>(out)[q] = make_float4((float)bit[0], (float)bit[1], (float)bit[2], (float)bit[3]);
+        } else if (DT == 1 || DT == 2) {
+            const uint32_t one = (DT == 1) ? 0x3C00u : 0x3F80u;
+            uint2 v;
+            v.x = (bit[0] ? one : 0u) | ((bit[1] ? one : 0u) << 16);
+            v.y = (bit[2] ? one : 0u) | ((bit[3] ? one : 0u) << 16);
+            reinterpret_cast<uint2*>(out)[q] = v;
+        } else {
+            reinterpret_cast<uint32_t*>(out)[q] = (uint32_t)bit[0] | ((uint32_t)bit[1] << 8) | ((uint32_t)bit[2] << 16) |
+                                                   ((uint32_t)bit[3] << 24);
+        }
+    }
+}
+
+// outputs that are NULL are skipped (cz_movegen: moves + counts; cz_done: flags; cz_rules_fused: everything)
+template <int DT>
+__global__ __launch_bounds__(64) void k_rules_tpb(const int8_t* __restrict__ boards, int n, int need_check,
+                                                 uint16_t* __restrict__ moves, uint8_t* __restrict__ counts,
+                                                 int8_t* __restrict__ over, int8_t* __restrict__ v,
+                                                 uint16_t* __restrict__ final_move, uint8_t* __restrict__ check,
+                                                 void* __restrict__ planes)
+{
+    __shared__ TpbLDS L;
+    constexpr size_t esz = DT == 0 ? 4 : (DT == 3 ? 1 : 2);
+    const int lane = lane_id();
+    const int nblk = (n + 63) / 64;
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int base = blk * 64;
+        const int nb = n - base < 64 ? n - base : 64;
+        // 1. the boards of this block: one contiguous run of nb * 90 bytes, 2 bytes per lane per step
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(boards + (size_t)base * NSQ);
+        for (int u = lane; u < nb * 45; u += 64) {
+            const uint16_t w = src[u];
+            const int k = u / 45, sq = (u - k * 45) * 2;
+            L.bd[k * TPB_BOARD_STRIDE + sq] = (int8_t)(w & 0xFF);
+            L.bd[k * TPB_BOARD_STRIDE + sq + 1] = (int8_t)(w >> 8);
+        }
+        __syncthreads();
+        // 2. one board per lane
+        if (lane < nb) {
+            int8_t* b = L.bd + lane * TPB_BOARD_STRIDE;
+            const TpbResult r = tpb_rules(b, L.rows + lane * TPB_ROW_STRIDE, need_check != 0);
+            const int c = r.n < MAXMOVES ? r.n : MAXMOVES;
+            L.cnt[lane] = (uint8_t)c;
+            const int i = base + lane;
+            if (counts) counts[i] = (uint8_t)(r.n < 255 ? r.n : 255);
+            if (over) { over[i] = (int8_t)r.over; v[i] = (int8_t)r.v; final_move[i] = (uint16_t)r.final_move; }
+            if (check) check[i] = (uint8_t)r.check;
+            if (planes) board_to_plane_codes(b);
+        }
+        __syncthreads();
+        // 3. move lists and planes leave one board at a time, the whole wave storing contiguously
+        for (int k = 0; k < nb; ++k) {
+            if (moves) {
+                const int c = L.cnt[k];
+                const uint32_t pair = *reinterpret_cast<const uint32_t*>(&L.rows[k * TPB_ROW_STRIDE + 2 * lane]);
+                const uint32_t lo = (2 * lane < c) ? (pair & 0xFFFFu) : (uint32_t)NOMOVE;
+                const uint32_t hi = (2 * lane + 1 < c) ? (pair >> 16) : (uint32_t)NOMOVE;
+                reinterpret_cast<uint32_t*>(moves + (size_t)(base + k) * MAXMOVES)[lane] = lo | (hi << 16);
+            }
+            if (planes)
+                tpb_write_planes<DT>(L.bd + k * TPB_BOARD_STRIDE, (char*)planes + (size_t)(base + k) * 1260 * esz);
+        }
+        __syncthreads();
+    }
+}
+
+inline int grid_for_tpb(int n)
+{
+    const int nblk = (n + 63) / 64;
+    const int cap = 256 * 8;
+    return nblk < cap ? nblk : cap;
+}
+
 }  // namespace
 
 // ---- C-ABI ----------------------------------------------------------------------------
@@ -216,6 +334,13 @@ int cz_movegen(const int8_t* boards, int n, uint16_t* moves, uint8_t* counts, vo
 {
     if (n == 0) return CZ_OK;
     if (n < 0 || !boards || !moves || !counts) return set_err_msg(CZ_ERR_ARG, "cz_movegen: bad argument");
+    if (n >= CZ_TPB_MIN_BOARDS) {
+        hipLaunchKernelGGL(k_rules_tpb<0>, dim3(grid_for_tpb(n)), dim3(64), 0, (hipStream_t)stream, boards, n, 0, moves,
+                           counts, (int8_t*)nullptr, (int8_t*)nullptr, (uint16_t*)nullptr, (uint8_t*)nullptr,
+                           (void*)nullptr);
+        CZ_LAUNCH_CHECK("cz_movegen");
+        return CZ_OK;
+    }
     hipLaunchKernelGGL(k_movegen, dim3(grid_for(n)), dim3(64), 0, (hipStream_t)stream, boards, n, moves, counts);
     CZ_LAUNCH_CHECK("cz_movegen");
     return CZ_OK;
@@ -227,6 +352,13 @@ int cz_done(const int8_t* boards, int n, int need_check, int8_t* over, int8_t* v
     if (n == 0) return CZ_OK;
     if (n < 0 || !boards || !over || !v || !final_move || (need_check && !check))
         return set_err_msg(CZ_ERR_ARG, "cz_done: bad argument");
+    if (n >= CZ_TPB_MIN_BOARDS) {
+        hipLaunchKernelGGL(k_rules_tpb<0>, dim3(grid_for_tpb(n)), dim3(64), 0, (hipStream_t)stream, boards, n, need_check,
+                           (uint16_t*)nullptr, (uint8_t*)nullptr, over, v, final_move, need_check ? check : (uint8_t*)nullptr,
+                           (void*)nullptr);
+        CZ_LAUNCH_CHECK("cz_done");
+        return CZ_OK;
+    }
     hipLaunchKernelGGL(k_done, dim3(grid_for(n)), dim3(64), 0, (hipStream_t)stream, boards, n, need_check, over, v,
                        final_move, check);
     CZ_LAUNCH_CHECK("cz_done");
@@ -292,8 +424,20 @@ int cz_rules_fused(const int8_t* boards, int n, uint16_t* moves, uint8_t* counts
     if (n == 0) return CZ_OK;
     if (n < 0 || !boards || !moves || !counts || !over || !v || !final_move || !check || !planes)
         return set_err_msg(CZ_ERR_ARG, "cz_rules_fused: bad argument");
-    const dim3 g(grid_for(n)), b(64);
     hipStream_t s = (hipStream_t)stream;
+    if (n >= CZ_TPB_MIN_BOARDS) {
+        const dim3 g(grid_for_tpb(n)), b(64);
+        switch (dtype) {
+        case CZ_F32: hipLaunchKernelGGL(k_rules_tpb<0>, g, b, 0, s, boards, n, 1, moves, counts, over, v, final_move, check, planes); break;
+        case CZ_F16: hipLaunchKernelGGL(k_rules_tpb<1>, g, b, 0, s, boards, n, 1, moves, counts, over, v, final_move, check, planes); break;
+        case CZ_BF16: hipLaunchKernelGGL(k_rules_tpb<2>, g, b, 0, s, boards, n, 1, moves, counts, over, v, final_move, check, planes); break;
+        case CZ_U8: hipLaunchKernelGGL(k_rules_tpb<3>, g, b, 0, s, boards, n, 1, moves, counts, over, v, final_move, check, planes); break;
+        default: return set_err_msg(CZ_ERR_ARG, "cz_rules_fused: unknown dtype");
+        }
+        CZ_LAUNCH_CHECK("cz_rules_fused");
+        return CZ_OK;
+    }
+    const dim3 g(grid_for(n)), b(64);
     switch (dtype) {
     case CZ_F32: hipLaunchKernelGGL(k_rules_fused<0>, g, b, 0, s, boards, n, moves, counts, over, v, final_move, check, planes); break;
     case CZ_F16: hipLaunchKernelGGL(k_rules_fused<1>, g, b, 0, s, boards, n, moves, counts, over, v, final_move, check, planes); break;

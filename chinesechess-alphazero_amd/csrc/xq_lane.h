@@ -73,16 +73,19 @@ XQ_HD uint16_t label_of_line_or_knight(int from, int to)
 template <bool EMIT>
 struct MoveSink {
     uint16_t* lab;
-    uint16_t* ft;
+    uint16_t* ft;               // may be null
     int off;
     int n;
+    int watch;                  // destination square to look for (-1: none)
+    int hit;                    // list index of the first move landing on `watch`, -1 if none
     XQ_HD void put(int from, int to)
     {
+        if (to == watch && hit < 0) hit = off + n;
         if (EMIT) {
             const int i = off + n;
             if (i < MAXMOVES) {
                 lab[i] = label_of(from, to);      // 16 KB table, L1-resident; measured faster than label_of_line_or_knight
-                ft[i] = (uint16_t)((from << 8) | to);
+                if (ft) ft[i] = (uint16_t)((from << 8) | to);
             }
         }
         ++n;
@@ -164,9 +167,9 @@ XQ_HD int low_bit(uint32_t v) { return __builtin_ctz(v); }            // v != 0
 //   occ = all pieces, own = the mover's pieces, oking = the opponent's king(s).
 template <bool EMIT>
 XQ_HD int gen_piece(int p, int s, const Set90& occ, const Set90& own, const Set90& oking,
-                    uint16_t* lab, uint16_t* ft, int off)
+                    uint16_t* lab, uint16_t* ft, int off, int watch = -1, int* hit = nullptr)
 {
-    MoveSink<EMIT> out{lab, ft, off, 0};
+    MoveSink<EMIT> out{lab, ft, off, 0, watch, -1};
     const int x = s % 9, y = s / 9;
     if (p == ROOK || p == CANNON) {                       // :288-320
         const uint32_t row = rank_bits(occ, y), col = file_bits(occ, x);
@@ -190,6 +193,7 @@ XQ_HD int gen_piece(int p, int s, const Set90& occ, const Set90& own, const Set9
         if (r < 9 && !has(own, y * 9 + r)) out.put(s, y * 9 + r);
         if (d > -1 && !has(own, d * 9 + x)) out.put(s, d * 9 + x);
         if (u < 10 && !has(own, u * 9 + x)) out.put(s, u * 9 + x);
+        if (hit && out.hit >= 0 && *hit < 0) *hit = out.hit;
         return out.n;
     }
     // stepping pieces: one table-driven loop (:264-286)
@@ -223,6 +227,7 @@ XQ_HD int gen_piece(int p, int s, const Set90& occ, const Set90& own, const Set9
         out.put(s, t);
         if (fly >= 0) out.put(s, fly);                                // once per accepted king step (:283-286)
     }
+    if (hit && out.hit >= 0 && *hit < 0) *hit = out.hit;
     return out.n;
 }
 

@@ -126,29 +126,54 @@ XQ_D double philox_uniform(uint64_t seed, uint32_t game_id, uint32_t stream, uin
     return ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6)) / 9007199254740992.0;
 }
 
-// Gamma(a, 1) by Marsaglia-Tsang (with the a < 1 boost); per-lane, consumes idx.. upwards
-XQ_D double gamma_draw(double a, uint64_t seed, uint32_t gid, uint64_t& idx)
-{
-    double boost = 1.0;
-    if (a <= 0.0) return 0.0;
-    if (a < 1.0) {
-        double u = philox_uniform(seed, gid, 2, idx++);
-        if (u <= 0.0) u = 1e-300;
-        boost = pow(u, 1.0 / a);
-        a += 1.0;
+// per-lane uniform stream for the root noise: Philox4x32-10 blocks (stream 2), four 24-bit uniforms per block
+struct NoiseRng {
+    uint64_t seed, idx;
+    uint32_t gid, buf[4];
+    int left;
+    XQ_D float next()
+    {
+        if (left == 0) {
+            uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = 2u, c3 = gid;
+            uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+            for (int r = 0; r < 10; ++r) {
+                const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+                const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+                const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+                c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+                k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+            }
+            buf[0] = c0; buf[1] = c1; buf[2] = c2; buf[3] = c3;
+            left = 4;
+            ++idx;
+        }
+        return ((float)(buf[--left] >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
     }
-    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
-    for (int it = 0; it < 64; ++it) {
-        double u1 = philox_uniform(seed, gid, 2, idx++);
-        const double u2 = philox_uniform(seed, gid, 2, idx++);
-        if (u1 <= 0.0) u1 = 1e-300;
-        const double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
-        double v = 1.0 + c * x;
-        if (v <= 0.0) continue;
+};
+
+// Gamma(a, 1) by Marsaglia-Tsang (with the a < 1 boost).  The noise only has to follow the reference's
+// distribution (NumPy's global RNG cannot be matched), so it is sampled in float32 with the hardware
+// log / exp / cos approximations; the tree arithmetic it feeds stays float64.
+XQ_D float gamma_draw(float a, NoiseRng& rng)
+{
+    float boost = 1.0f;
+    if (a <= 0.0f) return 0.0f;
+    if (a < 1.0f) {
+        boost = __expf(__logf(rng.next()) / a);               // U^(1/a)
+        a += 1.0f;
+    }
+    const float d = a - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
+    for (int it = 0; it < 32; ++it) {
+        const float u1 = rng.next(), u2 = rng.next();
+        const float x = sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);   // Box-Muller
+        float v = 1.0f + c * x;
+        if (v <= 0.0f) continue;
         v = v * v * v;
-        const double u = philox_uniform(seed, gid, 2, idx++);
-        if (u < 1.0 - 0.0331 * x * x * x * x) return boost * d * v;
-        if (u > 0.0 && log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return boost * d * v;
+        const float u = rng.next();
+        const float x2 = x * x;
+        if (u < 1.0f - 0.0331f * x2 * x2) return boost * d * v;
+        if (__logf(u) < 0.5f * x2 + d * (1.0f - v + __logf(v))) return boost * d * v;
     }
     return boost * d;
 }
@@ -289,9 +314,10 @@ XQ_D int select_edge(const SearchParams& P, const GameView& gv, int node, int nm
     const double xx = __dsqrt_rn((double)(sum_n + 1));
     double best_s = -1.0e300;
     int best_j = -1;
-    bool win_any[2] = {false, false};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    bool win0 = false, win1 = false;
+    const int halves = nm > 64 ? 2 : 1;                     // almost every position has <= 64 moves
+#pragma nounroll
+    for (int h = 0; h < halves; ++h) {
         const int j = lane + 64 * h;
         bool valid = j < nm;
         double score = -1.0e300;
@@ -321,11 +347,11 @@ XQ_D int select_edge(const SearchParams& P, const GameView& gv, int node, int nm
                 if (!(score >= -99999999.0)) valid = false;
             }
         }
-        win_any[h] = valid && win;
+        if (h == 0) win0 = valid && win; else win1 = valid && win;
         if (valid && score >= best_s) { best_s = score; best_j = j; }   // h = 1 has the larger index: wins ties
     }
     // proven-win shortcut: first edge in order with q > 1 - 1e-7 (player.py:309-311)
-    const int first_win = lowest_bit(__ballot(win_any[0]), __ballot(win_any[1]));
+    const int first_win = lowest_bit(__ballot(win0), __ballot(win1));
     if (first_win >= 0) return first_win;
     // arg max of (score, index): `>=` keeps the LAST maximal move (player.py:312-314)
 #pragma unroll
@@ -1045,27 +1071,43 @@ __global__ __launch_bounds__(64) void k_advance(SearchParams P, SearchBuffers B)
     }
 }
 
-// Dirichlet(alpha 1_n)[0] for every (simulation slot, root edge) of every searching game: X / (X + Y),
+// Dirichlet(alpha 1_n)[0] for every (simulation slot, root edge) the next k_sim launch can consume: X / (X + Y),
 // X ~ Gamma(alpha), Y ~ Gamma(alpha (n - 1)).  The reference redraws it per move per root visit (player.py:304);
-// each simulation selects at the root at most once per k_sim launch, so one row per slot per launch is enough.
-__global__ __launch_bounds__(64) void k_noise(SearchParams P, SearchBuffers B)
+// a simulation selects at the root at most once per k_sim launch, so one row per slot per launch is enough:
+// before k_sim(BACKUP) only slots parked on the root need one, before k_sim(SELECT) the slots of the next batch.
+__global__ __launch_bounds__(64) void k_noise(SearchParams P, SearchBuffers B, int mask)
 {
     const int g = blockIdx.x;
     if (g >= P.G || B.g_phase[g] != PH_SEARCH) return;
     const int root = B.g_root[g];
     if (root < 0) return;
     const int lane = lane_id();
+    const int active = B.g_active[g];
+    int first = 0, last = 0;                                   // slot range [first, last)
+    if (mask == SIM_SELECT) {
+        // a new batch starts only when nothing is in flight (k_sim(BACKUP) may have finished the old one)
+        if (active != 0) return;
+        const int tasks = B.g_tasks_left[g];
+        last = tasks < P.K ? tasks : P.K;
+    } else {
+        if (active == 0) return;
+        last = P.K;
+    }
     const int nm = (int)(B.node_meta[(size_t)g * P.node_cap + root] & 0xFF);
     const uint32_t epoch = B.g_noise_epoch[g];
-    const uint32_t game_id = B.g_game_id[g] + (uint32_t)g * 2654435761u;   // distinct streams in external mode too
     double* rows = B.noise + (size_t)g * P.K * MAXMOVES;
-    for (int sim = 0; sim < P.K; ++sim)
+    const float alpha = (float)P.dirichlet_alpha;
+    for (int sim = first; sim < last; ++sim) {
+        if (mask != SIM_SELECT &&
+            !(B.s_state[(size_t)g * P.K + sim] == SIM_PARKED && B.s_node[(size_t)g * P.K + sim] == root)) continue;
         for (int j = lane; j < nm; j += 64) {
-            uint64_t idx = ((uint64_t)epoch << 32) | ((uint64_t)sim << 20) | ((uint64_t)j << 12);
-            const double x = gamma_draw(P.dirichlet_alpha, P.seed, game_id, idx);
-            const double y = nm > 1 ? gamma_draw(P.dirichlet_alpha * (double)(nm - 1), P.seed, game_id, idx) : 0.0;
-            rows[(size_t)sim * MAXMOVES + j] = (x + y) > 0.0 ? x / (x + y) : 1.0 / (double)nm;
+            NoiseRng rng{P.seed, ((uint64_t)epoch << 32) | ((uint64_t)sim << 20) | ((uint64_t)j << 8),
+                         B.g_game_id[g] + (uint32_t)g * 2654435761u, {0, 0, 0, 0}, 0};
+            const float x = gamma_draw(alpha, rng);
+            const float y = nm > 1 ? gamma_draw(alpha * (float)(nm - 1), rng) : 0.0f;
+            rows[(size_t)sim * MAXMOVES + j] = (x + y) > 0.0f ? (double)(x / (x + y)) : 1.0 / (double)nm;
         }
+    }
     __syncthreads();
     if (lane == 0) B.g_noise_epoch[g] = epoch + 1;
 }
@@ -1370,10 +1412,10 @@ int cz_search_round(cz_search* s, const float* policy, const float* value, void*
     const dim3 grid(s->P.G), block(64);
     hipStream_t st = (hipStream_t)stream;
     const bool noise = s->P.noise_eps != 0.0;
-    if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B);
+    if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B, SIM_BACKUP);
     hipLaunchKernelGGL(k_sim, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP);
     hipLaunchKernelGGL(k_advance, grid, block, 0, st, s->P, s->B);
-    if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B);
+    if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B, SIM_SELECT);
     hipLaunchKernelGGL(k_sim, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT);
     S_LAUNCH_CHECK("cz_search_round");
     return CZ_OK;

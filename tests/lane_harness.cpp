@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <string.h>
 #include "../chinesechess-alphazero_amd/csrc/xq_lane.h"
+#include "../chinesechess-alphazero_amd/csrc/xq_tpb.h"
 
 using namespace xq;
 
@@ -53,6 +54,14 @@ int lane_label_formula_mismatches(void)
         if ((line || knight) && label_of_line_or_knight(f, t) != l) ++bad;
     }
     return bad;
+}
+
+// the thread-per-board rules (xq_tpb.h), exactly as a GPU lane runs them
+int tpb_board(const int8_t* board, int need_check, uint16_t* lab, int* out /* over, v, final_move, check */)
+{
+    const TpbResult r = tpb_rules(board, lab, need_check != 0);
+    out[0] = r.over; out[1] = r.v; out[2] = r.final_move; out[3] = r.check;
+    return r.n;
 }
 
 int lane_nibble_roundtrip(void)

@@ -43,3 +43,27 @@ def test_movegen_and_planes(harness, positions_1k):
         assert " ".join(xo.label_str(m) for m in lab[:n]) == r["moves"], r["state"]
         harness.lane_planes(b.ctypes.data_as(C.c_void_p), pl.ctypes.data_as(C.c_void_p))
         assert (pl.reshape(14, 10, 9) == xo.planes_board(b)).all()
+
+
+def test_thread_per_board_rules(harness, positions_1k):
+    """xq_tpb.h (one board per GPU lane) run on the CPU: move lists, done(need_check) for the golden suite and a
+    few thousand oracle playout positions."""
+    lab = np.zeros(160, dtype=np.uint16)
+    out = np.zeros(4, dtype=np.int32)
+    boards = [xo.state_to_board(r["state"]) for r in positions_1k]
+    rng = np.random.default_rng(7)
+    for _ in range(40):
+        b = xo.state_to_board(xo.INIT_STATE)
+        for _ply in range(120):
+            boards.append(b)
+            if xo.done_board(b)[0]:
+                break
+            mv = xo.legal_moves_board(b)
+            b, _ = xo.step_board(b, int(mv[rng.integers(len(mv))]))
+    for b in boards:
+        n = harness.tpb_board(b.ctypes.data_as(C.c_void_p), 1, lab.ctypes.data_as(C.c_void_p),
+                              out.ctypes.data_as(C.c_void_p))
+        exp_moves = xo.legal_moves_board(b)
+        assert n == len(exp_moves) and (lab[:n] == exp_moves).all()
+        over, v, fm, ck = xo.done_board(b, True)
+        assert (bool(out[0]), int(out[1]), int(out[2]), bool(out[3])) == (over, v, fm, ck), xo.board_to_state(b)
