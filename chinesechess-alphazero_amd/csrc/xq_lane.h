@@ -78,13 +78,15 @@ struct MoveSink {
     int n;
     int watch;                  // destination square to look for (-1: none)
     int hit;                    // list index of the first move landing on `watch`, -1 if none
+    bool formula;               // label by arithmetic instead of the 16 KB table (one board per lane: the table
+                                // gather is a dependent global load per move and there are few waves to hide it)
     XQ_HD void put(int from, int to)
     {
         if (to == watch && hit < 0) hit = off + n;
         if (EMIT) {
             const int i = off + n;
             if (i < MAXMOVES) {
-                lab[i] = label_of(from, to);      // 16 KB table, L1-resident; measured faster than label_of_line_or_knight
+                lab[i] = formula ? label_of_line_or_knight(from, to) : label_of(from, to);
                 if (ft) ft[i] = (uint16_t)((from << 8) | to);
             }
         }
@@ -167,9 +169,11 @@ XQ_HD int low_bit(uint32_t v) { return __builtin_ctz(v); }            // v != 0
 //   occ = all pieces, own = the mover's pieces, oking = the opponent's king(s).
 template <bool EMIT>
 XQ_HD int gen_piece(int p, int s, const Set90& occ, const Set90& own, const Set90& oking,
-                    uint16_t* lab, uint16_t* ft, int off, int watch = -1, int* hit = nullptr)
+                    uint16_t* lab, uint16_t* ft, int off, int watch = -1, int* hit = nullptr,
+                    bool formula_labels = false)
 {
-    MoveSink<EMIT> out{lab, ft, off, 0, watch, -1};
+    // advisor / elephant moves live in the literal tail of the label set: always from the table
+    MoveSink<EMIT> out{lab, ft, off, 0, watch, -1, formula_labels && p != ADVISOR && p != ELEPHANT};
     const int x = s % 9, y = s / 9;
     if (p == ROOK || p == CANNON) {                       // :288-320
         const uint32_t row = rank_bits(occ, y), col = file_bits(occ, x);

@@ -74,7 +74,7 @@ XQ_HD int tpb_movegen(const int8_t* b, const BoardSets& t, uint16_t* lab, int wa
         const int s = first_sq(rest);
         if (s < 0) break;
         if (s < 64) rest.lo &= rest.lo - 1; else rest.hi &= rest.hi - 1;
-        n += gen_piece<true>(b[s], s, t.occ, t.own, t.oking, lab, nullptr, n, watch, hit);
+        n += gen_piece<true>(b[s], s, t.occ, t.own, t.oking, lab, nullptr, n, watch, hit);   // table labels: measured faster
     }
     return n;
 }
