@@ -53,6 +53,9 @@ def _declare(L):
     L.cz_be_catched.argtypes = [vp, vp, i32, vp, vp]
     L.cz_has_attack.argtypes = [vp, i32, vp, vp]
     L.cz_rules_fused.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    if hasattr(L, "cz_bias_act"):
+        L.cz_bias_act.argtypes = [vp, vp, vp, C.c_size_t, i32, i32, i32, vp]
+        L.cz_bias_act.restype = i32
     for name in ("cz_label_tables", "cz_movegen", "cz_done", "cz_step", "cz_encode", "cz_check_or_catch",
                  "cz_be_catched", "cz_has_attack", "cz_rules_fused"):
         getattr(L, name).restype = i32
@@ -179,6 +182,23 @@ def has_attack(boards):
     out = torch.empty((n,), dtype=torch.uint8, device=boards.device)
     check(lib().cz_has_attack(_dev(boards, torch.int8), n, _dev(out, torch.uint8), _stream()), "cz_has_attack")
     return out
+
+
+_DT_CODE = None
+
+
+def bias_act_(x, bias, residual=None, relu=True):
+    """In place: x = relu(x + bias[c] (+ residual)) for a channels-last activation (logical NCHW tensor whose
+    memory is NHWC, or any [..., C] contiguous tensor).  One HBM pass (csrc/xq_nn_epilogue.hip)."""
+    import torch
+    global _DT_CODE
+    if _DT_CODE is None:
+        _DT_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+    c = bias.numel()
+    check(lib().cz_bias_act(C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()),
+                            C.c_void_p(residual.data_ptr()) if residual is not None else None,
+                            x.numel(), c, _DT_CODE[x.dtype], int(relu), _stream()), "cz_bias_act")
+    return x
 
 
 def rules_fused(boards, dtype=F32, out=None):

@@ -104,6 +104,7 @@ class InferenceNet(nn.Module):
         super().__init__()
         net = net.eval()
         self.dtype = dtype
+        self.fused_epilogue = True          # on the GPU: hand-written bias + skip + ReLU pass after each conv
         self.input_depth = net.cfg["input_depth"]
         with torch.no_grad():
             self.input_conv = _fold(net.input_conv, net.input_bn)
@@ -124,13 +125,30 @@ class InferenceNet(nn.Module):
         for p in self.parameters():
             p.requires_grad_(False)
 
+    def _trunk_fused(self, x):
+        """Trunk with the hand-written epilogue (csrc/xq_nn_epilogue.hip): every convolution is followed by ONE
+        in-place pass  y = relu(y + bias (+ skip))  instead of PyTorch's separate bias / add / ReLU passes."""
+        from cchess_alphazero import _native
+
+        def conv(m, t):
+            return F.conv2d(t, m.weight, None, m.stride, m.padding)
+        cl = torch.channels_last
+        x = _native.bias_act_(conv(self.input_conv, x).contiguous(memory_format=cl), self.input_conv.bias)
+        for c1, c2 in self.res:
+            y = _native.bias_act_(conv(c1, x).contiguous(memory_format=cl), c1.bias)
+            x = _native.bias_act_(conv(c2, y).contiguous(memory_format=cl), c2.bias, residual=x)
+        return x
+
     @torch.no_grad()
     def forward(self, planes):
         x = planes.to(self.dtype).contiguous(memory_format=torch.channels_last)
-        x = F.relu(self.input_conv(x))
-        for c1, c2 in self.res:
-            y = F.relu(c1(x))
-            x = F.relu(x + c2(y))
+        if x.is_cuda and self.fused_epilogue and self.input_conv.out_channels % 8 == 0:
+            x = self._trunk_fused(x)
+        else:
+            x = F.relu(self.input_conv(x))
+            for c1, c2 in self.res:
+                y = F.relu(c1(x))
+                x = F.relu(x + c2(y))
         p = F.relu(self.policy_conv(x))
         p = self.policy_out(p.flatten(1))                # flatten of an NCHW-shaped tensor: C,H,W order
         v = F.relu(self.value_conv(x))

@@ -157,6 +157,13 @@ int cz_search_counters(cz_search* s, uint64_t* host_out, void* stream);
 /* copies finished-game records (record_stride bytes each) written since *cursor into HOST memory */
 int cz_search_drain_records(cz_search* s, unsigned int* cursor, void* host_buf, int max_records, int* n_out,
                             void* stream);
+/* ---- network epilogue -----------------------------------------------------------------------------
+ * x = relu?(x + bias[c] (+ residual)) in place over a channels-last activation x[rows][channels]
+ * (n_elems = rows * channels, channels % 8 == 0, dtype CZ_F32 / CZ_F16 / CZ_BF16).  Replaces the separate
+ * bias / add / ReLU passes that follow each trunk convolution of agent/model.py:68-83 (BatchNorm folded). */
+int cz_bias_act(void* x, const void* bias, const void* residual, size_t n_elems, int channels, int dtype,
+                int relu, void* stream);
+
 /* test hook: y[i] = sqrt((double)(x[i] + 1)) exactly as the PUCT kernel computes it */
 int cz_debug_sqrt(const int32_t* x, double* y, int n, void* stream);
 

@@ -202,3 +202,37 @@ def test_run_py_self_cli(tmp_path):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert os.path.isdir(tmp_path / "data" / "play_data") and os.path.exists(tmp_path / "logs" / "play.log")
+
+
+def test_inference_net_gpu_matches_fp32_reference():
+    """The GPU inference network (BN folded, channels-last, hand-written bias+skip+ReLU epilogue) against the plain
+    PyTorch fp32 module on the CPU: policy / value within 1e-4 (north_star tolerance); the fused epilogue against
+    PyTorch's own separate passes: identical."""
+    import torch
+    from cchess_alphazero.agent.model import CChessNet, InferenceNet
+    torch.manual_seed(3)
+    net = CChessNet(cnn_filter_num=128, res_layer_num=7)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.normal_(1, 0.2)
+            m.bias.data.normal_(0, 0.2)
+    net.eval()
+    boards = np.stack([xo.state_to_board(xo.INIT_STATE)] * 3 + [xo.state_to_board('3s5/4m4/9/9/4p4/2R6/9/4C4/4M4/3MS4')] * 2)
+    x = torch.from_numpy(np.stack([xo.planes_board(b) for b in boards]))
+    with torch.no_grad():
+        p_ref, v_ref = net(x)
+    inf = InferenceNet(net, torch.float32).cuda()
+    p1, v1 = inf(x.cuda())
+    inf.fused_epilogue = False
+    p2, v2 = inf(x.cuda())
+    assert torch.equal(p1, p2) and torch.equal(v1, v2)
+    assert (p1.cpu() - p_ref).abs().max() < 1e-4 and (v1.cpu() - v_ref).abs().max() < 1e-4
+    for dt, tol in ((torch.bfloat16, 3e-2), (torch.float16, 5e-3)):
+        lo = InferenceNet(net, dt).cuda()
+        p3, v3 = lo(x.cuda())
+        lo.fused_epilogue = False
+        p4, v4 = lo(x.cuda())
+        assert (p3 - p4).abs().max() < tol and (v3 - v4).abs().max() < tol * 10
+        assert (v3.cpu() - v_ref).abs().max() < tol * 10
