@@ -207,7 +207,7 @@ def test_run_py_self_cli(tmp_path):
 def test_inference_net_gpu_matches_fp32_reference():
     """The GPU inference network (BN folded, channels-last, hand-written bias+skip+ReLU epilogue) against the plain
     PyTorch fp32 module on the CPU: policy / value within 1e-4 (north_star tolerance); the fused epilogue against
-    PyTorch's own separate passes: identical."""
+    PyTorch's own separate passes: equal to rounding."""
     import torch
     from cchess_alphazero.agent.model import CChessNet, InferenceNet
     torch.manual_seed(3)
@@ -227,7 +227,7 @@ def test_inference_net_gpu_matches_fp32_reference():
     p1, v1 = inf(x.cuda())
     inf.fused_epilogue = False
     p2, v2 = inf(x.cuda())
-    assert torch.equal(p1, p2) and torch.equal(v1, v2)
+    assert (p1 - p2).abs().max() < 1e-6 and (v1 - v2).abs().max() < 1e-5      # same math, different kernels
     assert (p1.cpu() - p_ref).abs().max() < 1e-4 and (v1.cpu() - v_ref).abs().max() < 1e-4
     for dt, tol in ((torch.bfloat16, 3e-2), (torch.float16, 5e-3)):
         lo = InferenceNet(net, dt).cuda()
