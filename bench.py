@@ -116,6 +116,21 @@ def micro_suite(n=1 << 20, iters=10):
             "boards_per_s": n / (ms * 1e-3), "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}
 
 
+def games_per_hour_estimate(expansions_per_s, config):
+    """games/hour = expansions/s / (mean expansions per finished game) * 3600.  No game finishes inside a
+    short benchmark window (a game is ~10^4 rounds), so the per-game cost comes from a complete-games run of the
+    same search configuration (tools/measure_games.py -> profiles/r*_games_<config>.json)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_games_{config}.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return {"value": expansions_per_s / d["expansions_per_game"] * 3600.0, "unit": "games/hour",
+            "expansions_per_game": d["expansions_per_game"], "mean_plies_per_game": d["mean_plies_per_game"],
+            "source": os.path.relpath(files[-1], ROOT)}
+
+
 def pmc_traffic():
     """HBM bytes per k_round launch from the committed PMC passes (profiles/, separate rocprofv3 --pmc runs)."""
     import glob
@@ -213,13 +228,15 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[cfg.engine.net_dtype] + "+f64/i32 tree",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1] '{args.config}': {G} concurrent games/GPU, "
+            "config": {"workload": f"BASELINE configs[{dict(mini=0, normal=1, eval=3, deep=4)[args.config]}] "
+                                   f"'{args.config}': {G} concurrent games/GPU, "
                                    f"{cfg.play.simulation_num_per_move} sims/move, K={K} sims/round/game, "
                                    f"{cfg.model.res_layer_num}x{cfg.model.cnn_filter_num} net "
                                    f"({cfg.engine.net_dtype}), random-init weights, self-play from INIT_STATE",
                        "games_per_gpu": G, "sims_per_round": K, "queue_slots_per_gpu": slots,
                        "parallelism": f"games sharded over {world} rank(s), no data-path collective"},
             "sims_per_s": d["sims"] / dt, "plies_per_s": d["plies"] / dt,
+            "games_per_hour_est": games_per_hour_estimate(d["expansions"] / dt, args.config),
             "queue_utilisation": d["expansions"] / max(1, args.steps * world * slots),
             "games_finished": d["games"],
             "tree_shape": {"mean_depth": mean_d, "mean_edges": mean_c, "mean_leaf_moves": mean_l,

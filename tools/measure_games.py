@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""GPU: play complete self-play games with a BASELINE search configuration (fewer concurrent games than the
+benchmark, same sims / net / noise / temperature) to measure what a GAME costs: plies per game, expansions per
+game, simulations saved by subtree reuse, endings.  Output: gpurun_out/games_<config>.json
+(committed as profiles/r01_games_<config>.json; bench.py turns expansions/s into games/hour with it).
+
+    python tools/measure_games.py --config normal --games 256
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "chinesechess-alphazero_amd"), ROOT]
+import torch  # noqa: E402
+
+sys.argv_backup = list(sys.argv)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="normal")
+    ap.add_argument("--games", type=int, default=256)
+    ap.add_argument("--dtype", default=None)
+    ap.add_argument("--max-seconds", type=float, default=600.0)
+    a = ap.parse_args()
+    import bench
+    ns = argparse.Namespace(config=a.config, games=a.games, sims_per_round=None, dtype=a.dtype)
+    cfg = bench.build_config(ns)
+    from cchess_alphazero.engine import SelfPlayEngine
+    eng = SelfPlayEngine(cfg, a.games, dtype=getattr(torch, cfg.engine.net_dtype), seed=7)
+    eng.start()
+    eng.prewarm()
+    t0 = time.perf_counter()
+    first = {}
+    rounds = 0
+    while len(first) < a.games and time.perf_counter() - t0 < a.max_seconds:
+        for _ in range(200):
+            eng.step()
+        rounds += 200
+        for g in eng.drain(16384):
+            if g["game_id"] < a.games:
+                first[g["game_id"]] = g
+    dt = time.perf_counter() - t0
+    c = eng.counters()
+    done = list(first.values())
+    plies = [g["turns"] for g in done]
+    out = {"config": a.config, "games_requested": a.games, "first_games_finished": len(done), "seconds": dt,
+           "rounds": rounds, "net_dtype": cfg.engine.net_dtype,
+           "sims_per_move": cfg.play.simulation_num_per_move, "K": eng.search.K,
+           "counters": c,
+           "mean_plies_per_game": c["plies"] / max(1, c["games"]),
+           "expansions_per_game": c["expansions"] / max(1, c["games"]),
+           "expansions_per_ply": c["expansions"] / max(1, c["plies"]),
+           "sims_reused_per_ply": c["root_reused_sims"] / max(1, c["plies"]),
+           "first_games": {"mean_turns": sum(plies) / max(1, len(plies)), "min_turns": min(plies or [0]),
+                           "max_turns": max(plies or [0]),
+                           "red_wins": sum(g["value"] > 0 for g in done), "black_wins": sum(g["value"] < 0 for g in done),
+                           "draws": sum(g["value"] == 0 for g in done), "resigned": sum(g["resigned"] for g in done)},
+           "note": "expansions_per_game uses ALL plies and ALL finished games of the run (slots restart games)"}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"games_{a.config}.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k != "counters"}))
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
