@@ -318,4 +318,41 @@ XQ_D void wave_encode(const int8_t* b, void* __restrict__ out)
     }
 }
 
+// Same planes through a per-board code row: codes[pos] = channel (0..13) of the piece on the square that plane
+// position pos = i*9 + j shows (row i of the planes is y = 9 - i), 0xFF for an empty square.  One LDS byte write
+// per square, then each output element is a byte compare instead of two divisions and a board lookup.
+template <int DT>
+XQ_D void wave_encode_codes(const int8_t* b, uint8_t* codes, void* __restrict__ out)
+{
+    const int lane = lane_id();
+    wave_sync();
+    for (int s = lane; s < NSQ; s += 64) {
+        const int p = b[s];
+        const int y = s / 9, x = s - y * 9;
+        codes[(9 - y) * 9 + x] = (uint8_t)(p == 0 ? 0xFF : (p > 0 ? p - 1 : 6 - p));
+    }
+    wave_sync();
+    for (int q = lane; q < 315; q += 64) {
+        const int o = q * 4;
+        int c = o / 90, pos = o - c * 90;
+        uint32_t bit[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bit[e] = codes[pos] == c;
+            if (++pos == 90) { pos = 0; ++c; }
+        }
+        if (DT == 0) {
+            reinterpret_cast<float4*>(out)[q] = make_float4((float)bit[0], (float)bit[1], (float)bit[2], (float)bit[3]);
+        } else if (DT == 1 || DT == 2) {
+            const uint32_t one = (DT == 1) ? 0x3C00u : 0x3F80u;
+            uint2 v;
+            v.x = (bit[0] ? one : 0u) | ((bit[1] ? one : 0u) << 16);
+            v.y = (bit[2] ? one : 0u) | ((bit[3] ? one : 0u) << 16);
+            reinterpret_cast<uint2*>(out)[q] = v;
+        } else {
+            reinterpret_cast<uint32_t*>(out)[q] = bit[0] | (bit[1] << 8) | (bit[2] << 16) | (bit[3] << 24);
+        }
+    }
+}
+
 }  // namespace xq

@@ -42,6 +42,8 @@ struct SearchLDS {
     uint32_t key[KEY_WORDS + 4];
     int32_t path_node[MAXD_LDS];
     int32_t path_edge[MAXD_LDS];
+    unsigned long long ctr[CT_COUNT];  // counter accumulators of the running kernel
+    uint8_t codes[BOARD_LDS];          // plane codes of the leaf being encoded
     double dsc[MAXMOVES];              // sampling scratch
     float pr[MAXMOVES];                // prior gather scratch
     uint16_t slab[MAXMOVES];           // labels sorted
@@ -65,7 +67,8 @@ struct GameView {
     uint8_t* s_state;
     int32_t* s_depth;
     int32_t* s_node;
-    unsigned long long* ctr;
+    unsigned long long* ctr;     // global per-game counters
+    unsigned long long* lctr;    // this kernel's LDS accumulators
     int g;
 };
 
@@ -78,9 +81,10 @@ XQ_D uint64_t uni64(uint64_t v)
 }
 XQ_D double unid(double v) { return __longlong_as_double((long long)uni64((uint64_t)__double_as_longlong(v))); }
 
-XQ_D GameView make_view(const SearchBuffers& B, const SearchParams& P, int g)
+XQ_D GameView make_view(const SearchBuffers& B, const SearchParams& P, int g, unsigned long long* lctr)
 {
     GameView v;
+    v.lctr = lctr;
     v.node_key = B.node_key + (size_t)g * P.node_cap * KEY_WORDS;
     v.node_sum_n = B.node_sum_n + (size_t)g * P.node_cap;
     v.node_eoff = B.node_eoff + (size_t)g * P.node_cap;
@@ -101,13 +105,29 @@ XQ_D GameView make_view(const SearchBuffers& B, const SearchParams& P, int g)
     return v;
 }
 
+// Counters accumulate in LDS while a kernel runs (no global round trip per event) and are flushed once.
 XQ_D void count(const GameView& gv, int which, unsigned long long by = 1)
 {
-    if (lane_id() == 0) gv.ctr[which] += by;
+    if (lane_id() == 0) gv.lctr[which] += by;
 }
 XQ_D void count_max(const GameView& gv, int which, unsigned long long val)
 {
-    if (lane_id() == 0 && gv.ctr[which] < val) gv.ctr[which] = val;
+    if (lane_id() == 0 && gv.lctr[which] < val) gv.lctr[which] = val;
+}
+XQ_D void counters_begin(const GameView& gv)
+{
+    for (int i = lane_id(); i < CT_COUNT; i += 64) gv.lctr[i] = 0;
+    wave_sync();
+}
+XQ_D void counters_flush(const GameView& gv)
+{
+    wave_sync();
+    for (int i = lane_id(); i < CT_COUNT; i += 64) {
+        const unsigned long long v = gv.lctr[i];
+        if (v == 0) continue;
+        if (i == CT_MAX_DEPTH) { if (gv.ctr[i] < v) gv.ctr[i] = v; }
+        else gv.ctr[i] += v;
+    }
 }
 
 // ---- counter-based RNG (Philox4x32-10), same stream as oracle/xq_mcts.c ------------------------
@@ -385,13 +405,13 @@ struct RoundIO {
     int planes_dtype;
 };
 
-XQ_D void write_planes(const RoundIO& io, const int8_t* b, size_t slot)
+XQ_D void write_planes(const RoundIO& io, const int8_t* b, uint8_t* codes, size_t slot)
 {
     switch (io.planes_dtype) {
-    case CZ_F32: wave_encode<0>(b, (char*)io.planes + slot * 1260 * 4); break;
-    case CZ_F16: wave_encode<1>(b, (char*)io.planes + slot * 1260 * 2); break;
-    case CZ_BF16: wave_encode<2>(b, (char*)io.planes + slot * 1260 * 2); break;
-    default: wave_encode<3>(b, (char*)io.planes + slot * 1260); break;
+    case CZ_F32: wave_encode_codes<0>(b, codes, (char*)io.planes + slot * 1260 * 4); break;
+    case CZ_F16: wave_encode_codes<1>(b, codes, (char*)io.planes + slot * 1260 * 2); break;
+    case CZ_BF16: wave_encode_codes<2>(b, codes, (char*)io.planes + slot * 1260 * 2); break;
+    default: wave_encode_codes<3>(b, codes, (char*)io.planes + slot * 1260); break;
     }
 }
 
@@ -453,7 +473,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
             B.g_root[g] = idx;
             gv.s_state[sim] = SIM_LEAF; gv.s_node[sim] = idx; gv.s_depth[sim] = 0;
         }
-        write_planes(io, L.r.bd[1], (size_t)g * P.K + sim);
+        write_planes(io, L.r.bd[1], L.codes, (size_t)g * P.K + sim);
         wave_sync();
         return;
     }
@@ -535,7 +555,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
                         gv.e_child[e] = idx;
                         gv.s_state[sim] = SIM_LEAF; gv.s_node[sim] = idx; gv.s_depth[sim] = depth;
                     }
-                    write_planes(io, L.r.bd[1], (size_t)g * P.K + sim);
+                    write_planes(io, L.r.bd[1], L.codes, (size_t)g * P.K + sim);
                     wave_sync();
                     return;
                 }
@@ -1008,7 +1028,8 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
     const int g = blockIdx.x;
     if (g >= P.G) return;
     if (uni((int)B.g_phase[g]) != PH_SEARCH) return;
-    const GameView gv = make_view(B, P, g);
+    const GameView gv = make_view(B, P, g, L.ctr);
+    counters_begin(gv);
     const RoundIO io{planes, P.planes_dtype};
     int active = uni(B.g_active[g]);
     const RootCtx rc{false, uni((int)B.g_n_no_act[g]), B.g_no_act + (size_t)g * MAX_NO_ACT,
@@ -1050,6 +1071,7 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
         run_sim(P, B, gv, L, io, rc, uni(B.g_root[g]), sim, node, depth, &active);
     }
     if (lane_id() == 0) B.g_active[g] = active;
+    counters_flush(gv);
 }
 
 // End of a search: external mode marks the game READY; self-play mode plays the move, applies the game rules
@@ -1060,7 +1082,8 @@ __global__ __launch_bounds__(64) void k_advance(SearchParams P, SearchBuffers B)
     const int g = blockIdx.x;
     if (g >= P.G) return;
     if (uni((int)B.g_phase[g]) != PH_SEARCH || uni(B.g_active[g]) != 0 || uni(B.g_tasks_left[g]) != 0) return;
-    const GameView gv = make_view(B, P, g);
+    const GameView gv = make_view(B, P, g, L.ctr);
+    counters_begin(gv);
     if (P.mode == MODE_SELFPLAY) {
         for (int it = 0; it < 8; ++it) {          // a search with nothing to do (fully reused root) ends at once
             advance_game(P, B, gv, L);
@@ -1069,6 +1092,7 @@ __global__ __launch_bounds__(64) void k_advance(SearchParams P, SearchBuffers B)
     } else if (lane_id() == 0) {
         B.g_phase[g] = PH_READY;
     }
+    counters_flush(gv);
 }
 
 // Dirichlet(alpha 1_n)[0] for every (simulation slot, root edge) the next k_sim launch can consume: X / (X + Y),
@@ -1118,7 +1142,7 @@ __global__ __launch_bounds__(64) void k_start_selfplay(SearchParams P, SearchBuf
     __shared__ SearchLDS L;
     const int g = blockIdx.x;
     if (g >= P.G) return;
-    const GameView gv = make_view(B, P, g);
+    const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT);   // counts go straight to the global block
     const int lane = lane_id();
     for (int i = lane; i < P.K; i += 64) gv.s_state[i] = SIM_IDLE;
     for (int i = lane; i < CT_COUNT; i += 64) gv.ctr[i] = 0;
@@ -1136,7 +1160,7 @@ __global__ __launch_bounds__(64) void k_set_roots(SearchParams P, SearchBuffers 
     const int g = blockIdx.x;
     if (g >= P.G) return;
     if (select_mask && !select_mask[g]) return;
-    const GameView gv = make_view(B, P, g);
+    const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT);   // counts go straight to the global block
     const int lane = lane_id();
     load_board(boards + (size_t)g * NSQ, L.r.bd[0]);
     int8_t* gb = B.g_board + (size_t)g * BOARD_LDS;
@@ -1162,7 +1186,7 @@ __global__ __launch_bounds__(64) void k_reset_trees(SearchParams P, SearchBuffer
 {
     const int g = blockIdx.x;
     if (g >= P.G) return;
-    const GameView gv = make_view(B, P, g);
+    const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT);   // counts go straight to the global block
     clear_tree(P, B, gv);
     const int lane = lane_id();
     for (int i = lane; i < P.K; i += 64) gv.s_state[i] = SIM_IDLE;
@@ -1182,7 +1206,7 @@ __global__ __launch_bounds__(64) void k_root_stats(SearchParams P, SearchBuffers
 {
     const int g = blockIdx.x;
     if (g >= P.G) return;
-    const GameView gv = make_view(B, P, g);
+    const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT);   // counts go straight to the global block
     const int lane = lane_id();
     const int root = B.g_root[g];
     int nm = 0, eoff = 0;
@@ -1206,7 +1230,7 @@ __global__ __launch_bounds__(64) void k_choose(SearchParams P, SearchBuffers B, 
     __shared__ SearchLDS L;
     const int g = blockIdx.x;
     if (g >= P.G) return;
-    const GameView gv = make_view(B, P, g);
+    const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT);   // counts go straight to the global block
     const int a = choose_action(P, B, gv, L, u ? u[g] : 0.5, B.g_enable_resign[g] != 0);
     if (lane_id() == 0) action[g] = a;
 }

@@ -51,15 +51,15 @@ def main():
            "rounds": rounds, "net_dtype": cfg.engine.net_dtype,
            "sims_per_move": cfg.play.simulation_num_per_move, "K": eng.search.K,
            "counters": c,
-           "mean_plies_per_game": c["plies"] / max(1, c["games"]),
-           "expansions_per_game": c["expansions"] / max(1, c["games"]),
+           "mean_plies_per_game": sum(plies) / max(1, len(plies)),
+           "expansions_per_game": c["expansions"] / max(1, c["plies"]) * sum(plies) / max(1, len(plies)),
            "expansions_per_ply": c["expansions"] / max(1, c["plies"]),
            "sims_reused_per_ply": c["root_reused_sims"] / max(1, c["plies"]),
            "first_games": {"mean_turns": sum(plies) / max(1, len(plies)), "min_turns": min(plies or [0]),
                            "max_turns": max(plies or [0]),
                            "red_wins": sum(g["value"] > 0 for g in done), "black_wins": sum(g["value"] < 0 for g in done),
                            "draws": sum(g["value"] == 0 for g in done), "resigned": sum(g["resigned"] for g in done)},
-           "note": "expansions_per_game uses ALL plies and ALL finished games of the run (slots restart games)"}
+           "note": "expansions_per_game = expansions_per_ply (all plies of the run) x mean length of the first games"}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"games_{a.config}.json"), "w") as f:
         json.dump(out, f, indent=1)
