@@ -128,6 +128,8 @@ XQ_D void apply_move_noflip(const int8_t* in, int from, int to, int8_t* out)
 // The board is reduced to three wave-uniform square sets by ballots; the mover's pieces are compacted (in
 // square order) so that lane r generates the moves of the r-th piece from those sets alone, and the ordered
 // move list is assembled by a prefix sum over the per-piece counts.
+// FORMULA: labels by arithmetic (label_of_line_or_knight) instead of the table gather -- for latency-bound callers.
+template <bool FORMULA = false>
 XQ_D int wave_movegen(const int8_t* b, MoveList& ml, uint16_t* plist)
 {
     const int lane = lane_id();
@@ -149,7 +151,7 @@ XQ_D int wave_movegen(const int8_t* b, MoveList& ml, uint16_t* plist)
         const int s = e & 0xFF, p = e >> 8;
         const int c = act ? gen_piece<false>(p, s, occ, own, oking, nullptr, nullptr, 0) : 0;
         const int inc = wave_incl_scan(c, lane);
-        if (c) gen_piece<true>(p, s, occ, own, oking, ml.lab, ml.ft, total + inc - c);
+        if (c) gen_piece<true>(p, s, occ, own, oking, ml.lab, ml.ft, total + inc - c, -1, nullptr, FORMULA);
         total += __shfl(inc, 63, 64);
     }
     wave_sync();
@@ -176,6 +178,7 @@ struct DoneResult {
 
 // done (static_env.py:14-77).  b: position; tmpb: scratch board; ml0: receives the move list of b
 // (when the early tests did not decide); ml1: scratch list for the need_check pass.
+template <bool FORMULA = false>
 XQ_D DoneResult wave_done(const int8_t* b, int8_t* tmpb, MoveList& ml0, MoveList& ml1, uint16_t* plist, bool need_check)
 {
     const int lane = lane_id();
@@ -199,7 +202,7 @@ XQ_D DoneResult wave_done(const int8_t* b, int8_t* tmpb, MoveList& ml0, MoveList
         if (!__ballot(blk0 || blk1)) { r.v = 1; winner = 1; }
     }
     if (!winner) {                                             // :52-60
-        const int n = wave_movegen(b, ml0, plist);
+        const int n = wave_movegen<FORMULA>(b, ml0, plist);
         r.nmoves = n;
         const int k = first_move_to(ml0, n, bk);
         if (k >= 0) { winner = 1; r.v = 1; r.final_move = ml0.lab[k]; }

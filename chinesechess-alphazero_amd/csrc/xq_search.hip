@@ -296,13 +296,33 @@ XQ_D void backup(const SearchParams& P, const GameView& gv, const SearchLDS& L, 
     wave_sync();
 }
 
+// sum_n / first edge / (move count | flags) of a node: lanes 0..2 each fetch one word, one wait for all three
+struct NodeHdr {
+    int sum_n, eoff;
+    uint32_t meta;
+};
+XQ_D NodeHdr load_hdr(const GameView& gv, int node)
+{
+    const int lane = lane_id();
+    uint32_t v = 0;
+    if (lane == 0) v = (uint32_t)gv.node_sum_n[node];
+    else if (lane == 1) v = gv.node_eoff[node];
+    else if (lane == 2) v = gv.node_meta[node];
+    NodeHdr h;
+    h.sum_n = __builtin_amdgcn_readlane((int)v, 0);
+    h.eoff = __builtin_amdgcn_readlane((int)v, 1);
+    h.meta = (uint32_t)__builtin_amdgcn_readlane((int)v, 2);
+    return h;
+}
+
 // ---- prior spreading: select_action_q_and_u, player.py:272-284 ----------------------------------
 XQ_D void attach_policy(const GameView& gv, SearchLDS& L, int node, const float* __restrict__ prow)
 {
     const int lane = lane_id();
-    const uint32_t meta = uniu(gv.node_meta[node]);
+    const NodeHdr hdr = load_hdr(gv, node);
+    const uint32_t meta = hdr.meta;
     const int nm = (int)(meta & 0xFF);
-    const int eoff = (int)uniu(gv.node_eoff[node]);
+    const int eoff = hdr.eoff;
     if (lane < nm) L.pr[lane] = prow[gv.e_mv[eoff + lane]];
     if (lane + 64 < nm) L.pr[lane + 64] = prow[gv.e_mv[eoff + lane + 64]];
     wave_sync();
@@ -327,11 +347,19 @@ struct RootCtx {
     int sim;
 };
 
-XQ_D int select_edge(const SearchParams& P, const GameView& gv, int node, int nm, int eoff, const RootCtx& rc)
+struct Picked {
+    int j;              // edge index inside the node, -1 = none
+    bool have;          // n / w / child / mv below are valid (winner among the first 64 edges)
+    int n, child, mv;
+    double w;
+};
+
+XQ_D Picked select_edge(const SearchParams& P, const GameView& gv, int sum_n, int nm, int eoff, const RootCtx& rc)
 {
     const int lane = lane_id();
-    const int sum_n = uni(gv.node_sum_n[node]);
     const double xx = __dsqrt_rn((double)(sum_n + 1));
+    int n0 = 0, child0 = CHILD_UNKNOWN, mv0 = 0;           // this lane's edge of the first half
+    double w0 = 0.0;
     double best_s = -1.0e300;
     int best_j = -1;
     bool win0 = false, win1 = false;
@@ -346,11 +374,13 @@ XQ_D int select_edge(const SearchParams& P, const GameView& gv, int node, int nm
             const int n = gv.e_n[eoff + j];
             const double w = gv.e_w[eoff + j];
             const float p = gv.e_p[eoff + j];
+            const int child = gv.e_child[eoff + j];          // fetched with the rest: no extra round trip later
+            const uint16_t mv = gv.e_mv[eoff + j];
+            if (h == 0) { n0 = n; w0 = w; child0 = child; mv0 = mv; }
             const double q = n ? w / (double)n : 0.0;
             double u;
             if (rc.is_root) {
                 if (rc.n_no_act) {
-                    const uint16_t mv = gv.e_mv[eoff + j];
                     for (int k = 0; k < rc.n_no_act; ++k) valid = valid && (rc.no_act[k] != mv);
                 }
                 const float a = P.one_minus_eps_f32 * p;
@@ -372,15 +402,29 @@ XQ_D int select_edge(const SearchParams& P, const GameView& gv, int node, int nm
     }
     // proven-win shortcut: first edge in order with q > 1 - 1e-7 (player.py:309-311)
     const int first_win = lowest_bit(__ballot(win0), __ballot(win1));
-    if (first_win >= 0) return first_win;
-    // arg max of (score, index): `>=` keeps the LAST maximal move (player.py:312-314)
+    int pick;
+    if (first_win >= 0) pick = first_win;
+    else {
+        // arg max of (score, index): `>=` keeps the LAST maximal move (player.py:312-314)
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double os = __shfl_xor(best_s, d, 64);
-        const int oj = __shfl_xor(best_j, d, 64);
-        if (os > best_s || (os == best_s && oj > best_j)) { best_s = os; best_j = oj; }
+        for (int d = 1; d < 64; d <<= 1) {
+            const double os = __shfl_xor(best_s, d, 64);
+            const int oj = __shfl_xor(best_j, d, 64);
+            if (os > best_s || (os == best_s && oj > best_j)) { best_s = os; best_j = oj; }
+        }
+        pick = uni(best_j);
     }
-    return uni(best_j);
+    Picked r;
+    r.j = pick;
+    r.have = pick >= 0 && pick < 64;
+    r.n = 0; r.child = CHILD_UNKNOWN; r.mv = 0; r.w = 0.0;
+    if (r.have) {
+        r.n = __shfl(n0, pick, 64);
+        r.child = __shfl(child0, pick, 64);
+        r.mv = __shfl(mv0, pick, 64);
+        r.w = __shfl(w0, pick, 64);
+    }
+    return r;
 }
 
 // ---- simulation bookkeeping --------------------------------------------------------------------------
@@ -417,12 +461,15 @@ XQ_D void write_planes(const RoundIO& io, const int8_t* b, uint8_t* codes, size_
 
 // create a node for the position in `b` whose ordered move list is in `ml` (nm moves);
 // returns the node index or -1 when the arena is full
+struct Arena {              // node / edge fill of the game's arena, held in registers while k_sim runs
+    int ncount, ecount;
+};
+
 XQ_D int expand_node(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L,
-                     const MoveList& ml, int nm, int hash_slot, uint64_t h)
+                     const MoveList& ml, int nm, int hash_slot, uint64_t h, Arena& ar)
 {
     const int lane = lane_id();
-    const int g = gv.g;
-    const int ncount = uni(B.g_node_count[g]), ecount = uni(B.g_edge_count[g]);
+    const int ncount = ar.ncount, ecount = ar.ecount;
     nm = nm < MAXMOVES ? nm : MAXMOVES;
     if (ncount >= P.node_cap || ecount + nm > P.edge_cap || hash_slot < 0) return -1;
     const int idx = ncount;
@@ -439,9 +486,9 @@ XQ_D int expand_node(const SearchParams& P, const SearchBuffers& B, const GameVi
         gv.node_eoff[idx] = (uint32_t)ecount;
         gv.node_meta[idx] = (uint32_t)nm | NODE_WAITING;
         gv.hash[hash_slot] = ((uint64_t)((uint32_t)(h >> 32) | 1u) << 32) | (uint32_t)(idx + 1);
-        B.g_node_count[g] = ncount + 1;
-        B.g_edge_count[g] = ecount + nm;
     }
+    ar.ncount = ncount + 1;
+    ar.ecount = ecount + nm;
     count(gv, CT_EXPANSIONS);
     count(gv, CT_LEAF_MOVES, (unsigned long long)nm);
     wave_sync();
@@ -451,7 +498,8 @@ XQ_D int expand_node(const SearchParams& P, const SearchBuffers& B, const GameVi
 // One descent of simulation `sim` starting at `node` with `depth` path entries already in L.path_*
 // (MCTS_search, player.py:198-260).  `node` < 0 means the root position is not in the tree yet.
 XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L,
-                  const RoundIO& io, const RootCtx& rc0, int root, int sim, int node, int depth, int* active)
+                  const RoundIO& io, const RootCtx& rc0, int root, int sim, int node, int depth, int* active,
+                  Arena& ar)
 {
     const int lane = lane_id();
     const int g = gv.g;
@@ -463,11 +511,11 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
         L.r.bd[1][lane] = gb[lane];
         if (lane < 32) L.r.bd[1][lane + 64] = (lane < 26) ? gb[lane + 64] : (int8_t)0;
         wave_sync();
-        const int nm = wave_movegen(L.r.bd[1], L.r.ml[0], L.r.plist);
+        const int nm = wave_movegen<true>(L.r.bd[1], L.r.ml[0], L.r.plist);
         const uint64_t h = pack_key(L.r.bd[1], L.key);
         int slot;
         int idx = hash_lookup(gv, P, L.key, h, &slot);
-        if (idx < 0) idx = expand_node(P, B, gv, L, L.r.ml[0], nm, slot, h);
+        if (idx < 0) idx = expand_node(P, B, gv, L, L.r.ml[0], nm, slot, h, ar);
         if (idx < 0) { count(gv, CT_OVERFLOW_SIMS); backup(P, gv, L, 0, 0.0); sim_finish(gv, sim, active); return; }
         if (lane == 0) {
             B.g_root[g] = idx;
@@ -492,7 +540,8 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
             sim_finish(gv, sim, active);
             return;
         }
-        const uint32_t meta = uniu(gv.node_meta[node]);
+        const NodeHdr hdr = load_hdr(gv, node);
+        const uint32_t meta = hdr.meta;
         if (meta & NODE_WAITING) {                                  // player.py:238-242
             if (lane == 0) { gv.s_state[sim] = SIM_PARKED; gv.s_node[sim] = node; gv.s_depth[sim] = depth; }
             count(gv, CT_PARKED);
@@ -506,33 +555,38 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
             return;
         }
         const int nm = (int)(meta & 0xFF);
-        const int eoff = (int)uniu(gv.node_eoff[node]);
+        const int eoff = hdr.eoff;
         RootCtx rc = rc0;
         rc.is_root = (node == root);                                // player.py:266
         rc.sim = sim;
-        const int j = select_edge(P, gv, node, nm, eoff, rc);
-        if (j < 0) {                                                // "Best action is None": cannot happen
+        const Picked pk = select_edge(P, gv, hdr.sum_n, nm, eoff, rc);
+        if (pk.j < 0) {                                             // "Best action is None": cannot happen
             backup(P, gv, L, depth, 0.0);
             sim_finish(gv, sim, active);
             return;
         }
-        const int e = eoff + j;
+        const int e = eoff + pk.j;
         if (lane == 0) {                                            // player.py:245-252
-            gv.node_sum_n[node] += 1;
-            gv.e_n[e] += P.vl;
-            gv.e_w[e] = gv.e_w[e] - (double)P.vl;
+            gv.node_sum_n[node] = hdr.sum_n + 1;
+            if (pk.have) {                                          // the values select just read: no reload
+                gv.e_n[e] = pk.n + P.vl;
+                gv.e_w[e] = pk.w - (double)P.vl;
+            } else {
+                gv.e_n[e] += P.vl;
+                gv.e_w[e] = gv.e_w[e] - (double)P.vl;
+            }
             L.path_node[depth] = node; L.path_edge[depth] = e;
             hp_node[depth] = node; hp_edge[depth] = e;
         }
         count(gv, CT_EDGES_VISITED, (unsigned long long)nm);
         depth += 1;
         wave_sync();
-        int child = uni(gv.e_child[e]);
+        int child = pk.have ? pk.child : uni(gv.e_child[e]);
         if (child == CHILD_UNKNOWN) {
             unpack_key(gv.node_key + (size_t)node * KEY_WORDS, L.r.bd[0]);
-            const int ft = label_ft(uni((int)gv.e_mv[e]));
+            const int ft = label_ft(pk.have ? pk.mv : uni((int)gv.e_mv[e]));
             step_board(L.r.bd[0], ft >> 8, ft & 0xFF, L.r.bd[1]);
-            const DoneResult d = wave_done(L.r.bd[1], L.r.bd[2], L.r.ml[0], L.r.ml[1], L.r.plist, false);   // player.py:204
+            const DoneResult d = wave_done<true>(L.r.bd[1], L.r.bd[2], L.r.ml[0], L.r.ml[1], L.r.plist, false);   // player.py:204
             if (d.over) {
                 child = d.v > 0 ? CHILD_TERM_WIN : CHILD_TERM_LOSS;
                 if (lane == 0) gv.e_child[e] = child;
@@ -544,7 +598,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
                     if (lane == 0) gv.e_child[e] = idx;
                     child = idx;
                 } else {
-                    idx = expand_node(P, B, gv, L, L.r.ml[0], d.nmoves, slot, h);     // player.py:211-221
+                    idx = expand_node(P, B, gv, L, L.r.ml[0], d.nmoves, slot, h, ar);     // player.py:211-221
                     if (idx < 0) {
                         count(gv, CT_OVERFLOW_SIMS);
                         backup(P, gv, L, depth, 0.0);
@@ -1032,6 +1086,7 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
     counters_begin(gv);
     const RoundIO io{planes, P.planes_dtype};
     int active = uni(B.g_active[g]);
+    Arena ar{uni(B.g_node_count[g]), uni(B.g_edge_count[g])};
     const RootCtx rc{false, uni((int)B.g_n_no_act[g]), B.g_no_act + (size_t)g * MAX_NO_ACT,
                      P.noise_eps != 0.0 ? B.noise + (size_t)g * P.K * MAXMOVES : nullptr, 0};
     int resume_i = P.K;
@@ -1068,9 +1123,9 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             if (lane_id() == 0) B.g_tasks_left[g] = tasks - new_n;
             continue;
         } else break;
-        run_sim(P, B, gv, L, io, rc, uni(B.g_root[g]), sim, node, depth, &active);
+        run_sim(P, B, gv, L, io, rc, uni(B.g_root[g]), sim, node, depth, &active, ar);
     }
-    if (lane_id() == 0) B.g_active[g] = active;
+    if (lane_id() == 0) { B.g_active[g] = active; B.g_node_count[g] = ar.ncount; B.g_edge_count[g] = ar.ecount; }
     counters_flush(gv);
 }
 
