@@ -7,8 +7,7 @@
 // emit at the square's offset.  Terminal detection, check detection and the perpetual
 // check/chase helpers are ballots over those lists.
 //
-// `__syncthreads()` below is a single-wave barrier (workgroup size 64): it orders LDS
-// traffic between lanes and costs no s_barrier round-trip.
+// Synchronisation inside the single-wave workgroup: see wave_sync() / wave_sync_global() below.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "xq_lane.h"
@@ -31,7 +30,19 @@ struct RulesLDS {
 };
 
 XQ_D int lane_id() { return (int)(threadIdx.x & 63u); }
-XQ_D void wave_sync() { __syncthreads(); }
+// Two kinds of intra-wave synchronisation (a workgroup is ONE wavefront):
+//  * wave_sync(): LDS traffic only.  The LDS unit executes a wave's DS instructions in order, so lanes see each
+//    other's LDS writes as soon as the compiler keeps the program order: a compiler barrier + lgkmcnt(0).
+//    Outstanding GLOBAL loads / stores are NOT waited for (a full __syncthreads() emits `s_waitcnt vmcnt(0)`,
+//    a complete HBM round trip, at every call).
+//  * wave_sync_global(): also orders global memory between lanes (workgroup-scope fence = vmcnt(0)).
+//    Needed only where a lane reads global data another lane of the wave wrote in the same launch.
+XQ_D void wave_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+XQ_D void wave_sync_global() { __syncthreads(); }
 
 XQ_D int wave_incl_scan(int v, int lane)
 {

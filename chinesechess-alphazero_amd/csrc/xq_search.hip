@@ -121,7 +121,7 @@ XQ_D void counters_begin(const GameView& gv)
 }
 XQ_D void counters_flush(const GameView& gv)
 {
-    wave_sync();
+    wave_sync_global();
     for (int i = lane_id(); i < CT_COUNT; i += 64) {
         const unsigned long long v = gv.lctr[i];
         if (v == 0) continue;
@@ -293,10 +293,10 @@ XQ_D void backup(const SearchParams& P, const GameView& gv, const SearchLDS& L, 
     count(gv, CT_SIMS);
     count(gv, CT_SUM_DEPTH, (unsigned long long)depth);
     count_max(gv, CT_MAX_DEPTH, (unsigned long long)depth);
-    wave_sync();
+    wave_sync_global();
 }
 
-// sum_n / first edge / (move count | flags) of a node: lanes 0..2 each fetch one word, one wait for all three
+// sum_n / first edge / (move count | flags) of a node in one memory round trip
 struct NodeHdr {
     int sum_n, eoff;
     uint32_t meta;
@@ -304,14 +304,14 @@ struct NodeHdr {
 XQ_D NodeHdr load_hdr(const GameView& gv, int node)
 {
     const int lane = lane_id();
-    uint32_t v = 0;
-    if (lane == 0) v = (uint32_t)gv.node_sum_n[node];
-    else if (lane == 1) v = gv.node_eoff[node];
-    else if (lane == 2) v = gv.node_meta[node];
+    // lane 0 is also the only lane that ever writes these words, so its loads see its own earlier stores
+    // without a fence; the three loads are issued back to back and waited for once
+    uint32_t a = 0, b = 0, c = 0;
+    if (lane == 0) { a = (uint32_t)gv.node_sum_n[node]; b = gv.node_eoff[node]; c = gv.node_meta[node]; }
     NodeHdr h;
-    h.sum_n = __builtin_amdgcn_readlane((int)v, 0);
-    h.eoff = __builtin_amdgcn_readlane((int)v, 1);
-    h.meta = (uint32_t)__builtin_amdgcn_readlane((int)v, 2);
+    h.sum_n = __builtin_amdgcn_readfirstlane((int)a);
+    h.eoff = __builtin_amdgcn_readfirstlane((int)b);
+    h.meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
     return h;
 }
 
@@ -334,6 +334,7 @@ XQ_D void attach_policy(const GameView& gv, SearchLDS& L, int node, const float*
     if (all_p == 0.0f) all_p = 1.0f;
     if (lane < nm) gv.e_p[eoff + lane] = L.pr[lane] / all_p;
     if (lane + 64 < nm) gv.e_p[eoff + lane + 64] = L.pr[lane + 64] / all_p;
+    // e_p[j] is written and later read (select_edge) by the same lane, the node word by lane 0: no global fence
     if (lane == 0) gv.node_meta[node] = meta & ~(uint32_t)NODE_WAITING;
     wave_sync();
 }
@@ -491,6 +492,8 @@ XQ_D int expand_node(const SearchParams& P, const SearchBuffers& B, const GameVi
     ar.ecount = ecount + nm;
     count(gv, CT_EXPANSIONS);
     count(gv, CT_LEAF_MOVES, (unsigned long long)nm);
+    // edges are written by the lane that reads them in select_edge, the node words and the hash slot by lane 0,
+    // the key words by the lanes that compare them in hash_lookup: no global fence
     wave_sync();
     return idx;
 }
@@ -566,8 +569,9 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
             return;
         }
         const int e = eoff + pk.j;
-        if (lane == 0) {                                            // player.py:245-252
-            gv.node_sum_n[node] = hdr.sum_n + 1;
+        const int owner = pk.j & 63;        // the lane that loads this edge in select_edge: its own stores are
+                                            // visible to it in program order, no global fence per level
+        if (lane == owner) {                                        // player.py:245-252
             if (pk.have) {                                          // the values select just read: no reload
                 gv.e_n[e] = pk.n + P.vl;
                 gv.e_w[e] = pk.w - (double)P.vl;
@@ -575,6 +579,9 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
                 gv.e_n[e] += P.vl;
                 gv.e_w[e] = gv.e_w[e] - (double)P.vl;
             }
+        }
+        if (lane == 0) {
+            gv.node_sum_n[node] = hdr.sum_n + 1;
             L.path_node[depth] = node; L.path_edge[depth] = e;
             hp_node[depth] = node; hp_edge[depth] = e;
         }
@@ -589,13 +596,13 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
             const DoneResult d = wave_done<true>(L.r.bd[1], L.r.bd[2], L.r.ml[0], L.r.ml[1], L.r.plist, false);   // player.py:204
             if (d.over) {
                 child = d.v > 0 ? CHILD_TERM_WIN : CHILD_TERM_LOSS;
-                if (lane == 0) gv.e_child[e] = child;
+                if (lane == owner) gv.e_child[e] = child;
             } else {
                 const uint64_t h = pack_key(L.r.bd[1], L.key);
                 int slot;
                 int idx = hash_lookup(gv, P, L.key, h, &slot);
                 if (idx >= 0) {
-                    if (lane == 0) gv.e_child[e] = idx;
+                    if (lane == owner) gv.e_child[e] = idx;
                     child = idx;
                 } else {
                     idx = expand_node(P, B, gv, L, L.r.ml[0], d.nmoves, slot, h, ar);     // player.py:211-221
@@ -605,10 +612,8 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
                         sim_finish(gv, sim, active);
                         return;
                     }
-                    if (lane == 0) {
-                        gv.e_child[e] = idx;
-                        gv.s_state[sim] = SIM_LEAF; gv.s_node[sim] = idx; gv.s_depth[sim] = depth;
-                    }
+                    if (lane == owner) gv.e_child[e] = idx;
+                    if (lane == 0) { gv.s_state[sim] = SIM_LEAF; gv.s_node[sim] = idx; gv.s_depth[sim] = depth; }
                     write_planes(io, L.r.bd[1], L.codes, (size_t)g * P.K + sim);
                     wave_sync();
                     return;
@@ -642,7 +647,7 @@ XQ_D void clear_tree(const SearchParams& P, const SearchBuffers& B, const GameVi
     const int lane = lane_id();
     for (int i = lane; i < P.hash_cap; i += 64) gv.hash[i] = 0;
     if (lane == 0) { B.g_node_count[gv.g] = 0; B.g_edge_count[gv.g] = 0; B.g_root[gv.g] = -1; }
-    wave_sync();
+    wave_sync_global();
 }
 
 // Keep only the sub-DAG reachable from `root` (through the child links of traversed edges) and slide it to
@@ -657,11 +662,11 @@ XQ_D int compact_tree(const SearchParams& P, const SearchBuffers& B, const GameV
     int32_t* remap = reinterpret_cast<int32_t*>(gv.hash);
     int32_t* stack = remap + P.node_cap;
     for (int i = lane; i < ncount; i += 64) remap[i] = -1;
-    wave_sync();
+    wave_sync_global();
     // mark
     int top = 1;
     if (lane == 0) { stack[0] = root; remap[root] = 0; }
-    wave_sync();
+    wave_sync_global();
     while (top > 0) {
         const int node = uni(stack[top - 1]);
         top -= 1;
@@ -679,7 +684,7 @@ XQ_D int compact_tree(const SearchParams& P, const SearchBuffers& B, const GameV
                 remap[child] = 0;
             }
             top += __popcll(m);
-            wave_sync();
+            wave_sync_global();
         }
     }
     // new indices in old order
@@ -691,7 +696,7 @@ XQ_D int compact_tree(const SearchParams& P, const SearchBuffers& B, const GameV
         if (keep) remap[i] = live + __popcll(m & ((1ull << lane) - 1ull));
         live += __popcll(m);
     }
-    wave_sync();
+    wave_sync_global();
     // slide nodes and their edges down, remapping the child links
     int ecount = 0;
     for (int i = 0; i < ncount; ++i) {
@@ -714,7 +719,7 @@ XQ_D int compact_tree(const SearchParams& P, const SearchBuffers& B, const GameV
                 if (ec[h] >= 0) ec[h] = remap[ec[h]];
             }
         }
-        wave_sync();
+        wave_sync_global();
         if (lane < KEY_WORDS) gv.node_key[(size_t)ni * KEY_WORDS + lane] = kw;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -730,13 +735,13 @@ XQ_D int compact_tree(const SearchParams& P, const SearchBuffers& B, const GameV
             gv.node_meta[ni] = meta;
         }
         ecount += nm;
-        wave_sync();
+        wave_sync_global();
     }
     const int new_root = uni(remap[root]);
-    wave_sync();
+    wave_sync_global();
     // rebuild the hash table: one node per lane, linear probing with a compare-and-swap on the slot
     for (int i = lane; i < P.hash_cap; i += 64) gv.hash[i] = 0;
-    wave_sync();
+    wave_sync_global();
     const uint32_t mask = (uint32_t)P.hash_cap - 1u;
     for (int base = 0; base < live; base += 64) {
         const int i = base + lane;
@@ -751,9 +756,9 @@ XQ_D int compact_tree(const SearchParams& P, const SearchBuffers& B, const GameV
             while (atomicCAS(&tab[slot], 0ull, entry) != 0ull) slot = (slot + 1) & mask;
         }
     }
-    wave_sync();
+    wave_sync_global();
     if (lane == 0) { B.g_node_count[g] = live; B.g_edge_count[g] = ecount; B.g_root[g] = new_root; }
-    wave_sync();
+    wave_sync_global();
     (void)L;
     return new_root;
 }
@@ -767,7 +772,7 @@ XQ_D void begin_search(const SearchParams& P, const SearchBuffers& B, const Game
     const int8_t* gb = B.g_board + (size_t)g * BOARD_LDS;
     L.r.bd[1][lane] = gb[lane];
     if (lane < 32) L.r.bd[1][lane + 64] = (lane < 26) ? gb[lane + 64] : (int8_t)0;
-    wave_sync();
+    wave_sync_global();
     const uint64_t h = pack_key(L.r.bd[1], L.key);
     int slot;
     int root = hash_lookup(gv, P, L.key, h, &slot);
@@ -804,7 +809,7 @@ XQ_D void begin_search(const SearchParams& P, const SearchBuffers& B, const Game
         B.g_active[g] = 0;
         B.g_phase[g] = PH_SEARCH;
     }
-    wave_sync();
+    wave_sync_global();
 }
 
 // ---- calc_policy + apply_temperature + choice (player.py:375-406, 453-470, :195) ---------------------
@@ -859,7 +864,7 @@ XQ_D int choose_action(const SearchParams& P, const SearchBuffers& B, const Game
             L.sn[rank] = cnt[h];
         }
     }
-    wave_sync();
+    wave_sync_global();
     // temperature (player.py:453-461)
     const int inc = uni((int)B.g_increase_temp[g]);
     double tau = 0.0;
@@ -895,7 +900,7 @@ XQ_D int choose_action(const SearchParams& P, const SearchBuffers& B, const Game
             chosen = pick >= 0 ? (int)L.slab[pick] : 0;
         }
     }
-    wave_sync();
+    wave_sync_global();
     return uni(chosen);
 }
 
@@ -932,11 +937,11 @@ XQ_D void new_game(const SearchParams& P, const SearchBuffers& B, const GameView
     const int g = gv.g;
     clear_tree(P, B, gv);
     set_init_board(B.g_board + (size_t)g * BOARD_LDS);
-    wave_sync();
+    wave_sync_global();
     const int8_t* gb = B.g_board + (size_t)g * BOARD_LDS;
     L.r.bd[1][lane] = gb[lane];
     if (lane < 32) L.r.bd[1][lane + 64] = gb[lane + 64];
-    wave_sync();
+    wave_sync_global();
     pack_key(L.r.bd[1], L.key);
     store_key(B.g_hist_key + (size_t)g * (P.max_plies + 2) * KEY_WORDS, L.key);
     if (lane == 0) {
@@ -948,7 +953,7 @@ XQ_D void new_game(const SearchParams& P, const SearchBuffers& B, const GameView
         // enable_resign = random() > enable_resign_rate (self_play.py:102-105): stream 0, draw 0
         B.g_enable_resign[g] = philox_uniform(P.seed, game_id, 0, 0) > P.enable_resign_rate ? 1 : 0;
     }
-    wave_sync();
+    wave_sync_global();
     begin_search(P, B, gv, L);
 }
 
@@ -998,7 +1003,7 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
         // state, no_eat = senv.new_step(state, action)  (:133-141)
         L.r.bd[0][lane] = gb[lane];
         if (lane < 32) L.r.bd[0][lane + 64] = (lane < 26) ? gb[lane + 64] : (int8_t)0;
-        wave_sync();
+        wave_sync_global();
         const int ft = label_ft(action);
         const int f = ft >> 8, t = ft & 0xFF;
         const bool no_eat = L.r.bd[0][t] == 0;
@@ -1027,7 +1032,7 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
                     // the rule helpers need the position in bd[0]
                     L.r.bd[0][lane] = L.r.bd[3][lane];
                     if (lane < 32) L.r.bd[0][lane + 64] = L.r.bd[3][lane + 64];
-                    wave_sync();
+                    wave_sync_global();
                     if (wave_will_check_or_catch(L.r, L.r.bd[0], mv) == 1) {
                         if (n_no_act < MAX_NO_ACT) {
                             if (lane == 0) B.g_no_act[(size_t)g * MAX_NO_ACT + n_no_act] = (uint16_t)mv;
@@ -1050,7 +1055,7 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
             B.g_n_no_act[g] = (uint8_t)n_no_act;
             B.g_increase_temp[g] = (uint8_t)inc;
         }
-        wave_sync();
+        wave_sync_global();
     }
     if (!game_over) {
         begin_search(P, B, gv, L);
@@ -1064,7 +1069,7 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
     if (turns % 2 == 1) value = -value;                                 // :190-191
     bool store = true;
     if (turns < 10) store = philox_uniform(P.seed, game_id, 0, 1) > 0.9;   // :194-200
-    wave_sync();
+    wave_sync_global();
     emit_record(P, B, gv, turns, value, store, resigned);
     new_game(P, B, gv, L, game_id + P.game_id_stride);
 }
@@ -1201,7 +1206,7 @@ __global__ __launch_bounds__(64) void k_start_selfplay(SearchParams P, SearchBuf
     const int lane = lane_id();
     for (int i = lane; i < P.K; i += 64) gv.s_state[i] = SIM_IDLE;
     for (int i = lane; i < CT_COUNT; i += 64) gv.ctr[i] = 0;
-    wave_sync();
+    wave_sync_global();
     new_game(P, B, gv, L, first_game_id + (uint32_t)g);
 }
 
@@ -1230,7 +1235,7 @@ __global__ __launch_bounds__(64) void k_set_roots(SearchParams P, SearchBuffers 
         B.g_increase_temp[g] = inc ? inc[g] : 0;
         B.g_enable_resign[g] = enable_resign ? enable_resign[g] : 0;
     }
-    wave_sync();
+    wave_sync_global();
     // a terminal root has nothing to search (the reference's simulations would all return at once)
     const DoneResult d = wave_done(L.r.bd[0], L.r.bd[1], L.r.ml[0], L.r.ml[1], L.r.plist, false);
     begin_search(P, B, gv, L);
