@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one lock-step ROUND of the hot path over every concurrent game of the rank:
-k_round (hand-written HIP: backup / PUCT select / expand / game rules, leaf planes into the queue) followed by
+the tree kernels (hand-written HIP: backup / PUCT select / expand / game rules, leaf planes into the queue) followed by
 one ResNet forward over the whole evaluation queue.  Workload at N=1 = BASELINE.json configs[1] ("normal"):
 4096 concurrent games per GPU, 800 sims/move, 7-block x 128-filter net, random-init weights, synthetic self-play
 from the opening position.  Games shard across ranks (disjoint game ids, no data-path collective); RCCL is used
@@ -132,7 +132,7 @@ def games_per_hour_estimate(expansions_per_s, config):
 
 
 def pmc_traffic():
-    """HBM bytes per k_round launch from the committed PMC passes (profiles/, separate rocprofv3 --pmc runs)."""
+    """HBM bytes per round of the tree kernels from the committed PMC passes (profiles/, separate rocprofv3 --pmc runs)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_round.json")))
     if not files:
@@ -248,7 +248,7 @@ def main():
         if k_ms is not None:
             ach = bpe * exp_per_launch / (k_ms * 1e-3) / 1e9
             traffic, traffic_src = pmc_traffic()
-            out["roofline"] = {"kernel": "k_round", "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+            out["roofline"] = {"kernel": "cz_search_round = k_sim(BACKUP) + k_advance + k_sim(SELECT) (+ k_noise x2)", "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                                "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": bpe * exp_per_launch, "avg_launch_ms": k_ms,
                                "bytes_per_expansion": bpe, "expansions_per_launch": exp_per_launch,
