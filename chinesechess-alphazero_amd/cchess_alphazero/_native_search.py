@@ -17,7 +17,7 @@ class SearchCfg(C.Structure):
                 ("min_resign_turn", C.c_int32), ("evaluate", C.c_int32), ("ring_capacity", C.c_int32),
                 ("c_puct", C.c_double), ("noise_eps", C.c_double), ("dirichlet_alpha", C.c_double),
                 ("tau_decay_rate", C.c_double), ("resign_threshold", C.c_double), ("enable_resign_rate", C.c_double),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("use_history", C.c_int32), ("reserved", C.c_int32)]
 
 
 def declare(L):
@@ -28,7 +28,7 @@ def declare(L):
     L.cz_search_bytes.restype = C.c_size_t
     L.cz_search_info.argtypes = [vp, vp]
     L.cz_search_start_selfplay.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp]
-    L.cz_search_set_roots.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.cz_search_set_roots.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.cz_search_round.argtypes = [vp, vp, vp, vp, vp]
     L.cz_search_reset_trees.argtypes = [vp, vp]
     L.cz_search_pending.argtypes = [vp, C.POINTER(C.c_int), vp]
@@ -54,7 +54,7 @@ class Search:
 
     def __init__(self, play_config, n_games, planes_dtype=_native.F32, evaluate=False, seed=0,
                  node_capacity=0, edge_capacity=0, max_depth=0, ring_capacity=0, sims_per_round=None,
-                 device=None):
+                 device=None, use_history=False):
         import torch
         _native.require_gpu()
         self.L = _native.lib()
@@ -69,7 +69,8 @@ class Search:
                         int(edge_capacity), int(max_depth), int(pc.max_game_length), int(planes_dtype),
                         int(pc.min_resign_turn), int(bool(evaluate)), int(ring_capacity),
                         float(pc.c_puct), float(pc.noise_eps), float(pc.dirichlet_alpha), float(pc.tau_decay_rate),
-                        float(pc.resign_threshold), float(pc.enable_resign_rate), int(seed))
+                        float(pc.resign_threshold), float(pc.enable_resign_rate), int(seed),
+                        int(bool(use_history)), 0)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _native.check(self.L.cz_search_create(C.byref(cfg), C.byref(h)), "cz_search_create")
@@ -77,9 +78,9 @@ class Search:
         info = (C.c_int32 * 12)()
         _native.check(self.L.cz_search_info(self.h, info), "cz_search_info")
         (self.G, self.K, self.sims, self.node_cap, self.edge_cap, self.hash_cap, self.max_depth, self.max_plies,
-         self.record_stride, self.ring_cap, self.n_counters, _) = list(info)
+         self.record_stride, self.ring_cap, self.n_counters, self.in_planes) = list(info)
         self.slots = self.G * self.K
-        self.planes = torch.zeros((self.slots, 14, 10, 9), dtype=_native.torch_dtype(planes_dtype), device=self.device)
+        self.planes = torch.zeros((self.slots, self.in_planes, 10, 9), dtype=_native.torch_dtype(planes_dtype), device=self.device)
         self.policy = torch.zeros((self.slots, _native.NLABELS), dtype=torch.float32, device=self.device)
         self.value = torch.zeros((self.slots,), dtype=torch.float32, device=self.device)
         self._cursor = C.c_uint(0)
@@ -110,7 +111,7 @@ class Search:
         self._cursor = C.c_uint(0)
 
     def set_roots(self, boards, turns=None, no_act=None, n_no_act=None, increase_temp=None, enable_resign=None,
-                  select_mask=None):
+                  select_mask=None, prev_boards=None, hist_kind=None):
         """boards: int8 [G,90] cuda tensor; the optional arguments are cuda tensors of the documented dtypes."""
         import torch
 
@@ -120,11 +121,13 @@ class Search:
             assert t.is_cuda and t.is_contiguous() and t.dtype == dt, (t.dtype, dt)
             return C.c_void_p(t.data_ptr())
         assert boards.shape == (self.G, 90)
-        self._keep = (boards, turns, no_act, n_no_act, increase_temp, enable_resign, select_mask)
+        self._keep = (boards, turns, no_act, n_no_act, increase_temp, enable_resign, select_mask, prev_boards,
+                      hist_kind)
         _native.check(self.L.cz_search_set_roots(
             self.h, ptr(boards, torch.int8), ptr(turns, torch.int32), ptr(no_act, torch.uint16),
             ptr(n_no_act, torch.uint8), ptr(increase_temp, torch.uint8), ptr(enable_resign, torch.uint8),
-            ptr(select_mask, torch.uint8), self._stream()), "cz_search_set_roots")
+            ptr(select_mask, torch.uint8), ptr(prev_boards, torch.int8), ptr(hist_kind, torch.uint8),
+            self._stream()), "cz_search_set_roots")
 
     def reset_trees(self):
         _native.check(self.L.cz_search_reset_trees(self.h, self._stream()), "cz_search_reset_trees")

@@ -57,8 +57,7 @@ class CChessPlayer:
         self.root_state = None
         self.no_act = None
         self.increase_temp = False
-        if use_history:
-            raise NotImplementedError("28-plane history input is not built yet (SURVEY 8 f-3)")
+        self.use_history = use_history
         if pipes is None:
             raise ValueError("CChessPlayer needs a pipe to the network (model.get_pipes())")
         pc = self.play_config
@@ -68,7 +67,8 @@ class CChessPlayer:
         dt = _native.F32
         self._search = Search(merged, 1, planes_dtype=dt, evaluate=getattr(config.opts, "evaluate", False),
                               seed=int(np.random.randint(0, 2 ** 31 - 1)),
-                              node_capacity=getattr(getattr(config, "engine", None), "node_capacity", 0) or 0)
+                              node_capacity=getattr(getattr(config, "engine", None), "node_capacity", 0) or 0,
+                              use_history=use_history)
         self._torch = torch
 
     # -- network access: device fast path, or the reference's pipe protocol --
@@ -100,7 +100,14 @@ class CChessPlayer:
         bans = list(no_act or [])[:16]
         for k, m in enumerate(bans):
             na[0, k] = label_index(m)
-        s.set_roots(board,
+        prev, kind = None, None
+        if self.use_history and hist:                      # action(hist=...): player.py:150-151, :217-218
+            if len(hist) >= 5:
+                prev = t.from_numpy(senv.state_to_array(hist[-5])[None]).cuda()
+                kind = t.tensor([1], dtype=t.uint8, device="cuda")
+            else:
+                kind = t.tensor([2], dtype=t.uint8, device="cuda")
+        s.set_roots(board, prev_boards=prev, hist_kind=kind,
                     turns=t.tensor([turns], dtype=t.int32, device="cuda"),
                     no_act=t.from_numpy(na.view(np.int16)).cuda().view(t.uint16),
                     n_no_act=t.tensor([len(bans)], dtype=t.uint8, device="cuda"),

@@ -34,7 +34,8 @@ def bytes_per_expansion(mean_depth, mean_edges, mean_leaf_moves):
 
 class SelfPlayEngine:
     def __init__(self, config, n_games, net=None, dtype=torch.float32, device=None, seed=0,
-                 node_capacity=0, edge_capacity=0, max_depth=0, sims_per_round=None, evaluator=None):
+                 node_capacity=0, edge_capacity=0, max_depth=0, sims_per_round=None, evaluator=None,
+                 use_history=False):
         """config: the reference's Config object (config.play.* / config.model.* are read).
         net: a CChessNet (random-init if None).  evaluator: optional callable planes -> (policy, value)
         replacing the network (tests)."""
@@ -46,7 +47,7 @@ class SelfPlayEngine:
         self.search = Search(config.play, n_games, planes_dtype=_PLANES_CODE[dtype],
                              evaluate=getattr(config.opts, "evaluate", False), seed=seed,
                              node_capacity=node_capacity, edge_capacity=edge_capacity, max_depth=max_depth,
-                             sims_per_round=sims_per_round, device=self.device)
+                             sims_per_round=sims_per_round, device=self.device, use_history=use_history)
         self.evaluator = evaluator
         self.net = None
         if evaluator is None:

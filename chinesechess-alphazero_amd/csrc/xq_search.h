@@ -44,6 +44,7 @@ struct SearchParams {
     int G, K, sims, vl;
     int node_cap, edge_cap, hash_cap, max_depth, max_plies;
     int planes_dtype;
+    int in_planes;          // 14, or 28 with use_history
     int mode;
     // PUCT / game parameters (reference config.play.*)
     double c_puct;
@@ -107,6 +108,8 @@ struct SearchBuffers {
     int32_t* pending;       // [1] scratch for cz_search_pending
     double* noise;          // [G][K][128] Dirichlet(alpha)[0] draws for the root edges, refreshed by k_noise
     uint32_t* g_noise_epoch;   // [G]
+    int8_t* g_prev_board;   // [G][96] game position two plies before the root (action(hist=...), 28-plane input)
+    uint8_t* g_hist_kind;   // [G] 0 no game history, 1 g_prev_board valid, 2 history too short
 };
 
 // finished-game record header (followed by uint16 moves[max_plies + 2])

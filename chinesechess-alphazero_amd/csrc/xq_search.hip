@@ -448,16 +448,53 @@ XQ_D int find_in_path(const SearchLDS& L, int depth, int node)
 struct RoundIO {
     void* planes;
     int planes_dtype;
+    int in_planes;
 };
 
-XQ_D void write_planes(const RoundIO& io, const int8_t* b, uint8_t* codes, size_t slot)
+XQ_D void encode_block(int dtype, const int8_t* b, uint8_t* codes, char* out)
 {
-    switch (io.planes_dtype) {
-    case CZ_F32: wave_encode_codes<0>(b, codes, (char*)io.planes + slot * 1260 * 4); break;
-    case CZ_F16: wave_encode_codes<1>(b, codes, (char*)io.planes + slot * 1260 * 2); break;
-    case CZ_BF16: wave_encode_codes<2>(b, codes, (char*)io.planes + slot * 1260 * 2); break;
-    default: wave_encode_codes<3>(b, codes, (char*)io.planes + slot * 1260); break;
+    switch (dtype) {
+    case CZ_F32: wave_encode_codes<0>(b, codes, out); break;
+    case CZ_F16: wave_encode_codes<1>(b, codes, out); break;
+    case CZ_BF16: wave_encode_codes<2>(b, codes, out); break;
+    default: wave_encode_codes<3>(b, codes, out); break;
     }
+}
+
+// the leaf's input planes into its queue slot: 14 planes (state_to_planes), or 28 with the position two plies
+// earlier (`prev`, NULL = none: zeros) as the second block (state_history_to_planes, static_env.py:158-194)
+XQ_D void write_planes(const RoundIO& io, const int8_t* b, uint8_t* codes, size_t slot, const int8_t* prev)
+{
+    const size_t esz = io.planes_dtype == CZ_F32 ? 4 : (io.planes_dtype == CZ_U8 ? 1 : 2);
+    char* out = (char*)io.planes + slot * (size_t)io.in_planes * 90 * esz;
+    encode_block(io.planes_dtype, b, codes, out);
+    if (io.in_planes == 28) {
+        char* out2 = out + 1260 * esz;
+        if (prev) encode_block(io.planes_dtype, prev, codes, out2);
+        else for (int q = lane_id(); q < 315 * (int)esz; q += 64) reinterpret_cast<uint32_t*>(out2)[q] = 0u;
+    }
+}
+
+// second plane block of a new leaf (expand_and_evaluate, player.py:322-338): simulations started by action() with a
+// real game history use the game position two plies before the ROOT whatever their depth (the reference never
+// clears `is_root_node` while descending, :217); every other simulation uses its own search path.
+XQ_D const int8_t* history_board(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L,
+                                 bool fresh, int depth)
+{
+    if (P.in_planes != 28) return nullptr;
+    const int lane = lane_id();
+    const int kind = uni((int)B.g_hist_kind[gv.g]);
+    if (fresh && kind != 0) {
+        if (kind != 1) return nullptr;                                // a history shorter than 5 entries
+        const int8_t* pb = B.g_prev_board + (size_t)gv.g * BOARD_LDS;
+        L.r.bd[2][lane] = pb[lane];
+        if (lane < 32) L.r.bd[2][lane + 64] = (lane < 26) ? pb[lane + 64] : (int8_t)0;
+        wave_sync();
+        return L.r.bd[2];
+    }
+    if (depth < 2) return nullptr;
+    unpack_key(gv.node_key + (size_t)L.path_node[depth - 2] * KEY_WORDS, L.r.bd[2]);
+    return L.r.bd[2];
 }
 
 // create a node for the position in `b` whose ordered move list is in `ml` (nm moves);
@@ -502,7 +539,7 @@ XQ_D int expand_node(const SearchParams& P, const SearchBuffers& B, const GameVi
 // (MCTS_search, player.py:198-260).  `node` < 0 means the root position is not in the tree yet.
 XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L,
                   const RoundIO& io, const RootCtx& rc0, int root, int sim, int node, int depth, int* active,
-                  Arena& ar)
+                  Arena& ar, bool fresh)
 {
     const int lane = lane_id();
     const int g = gv.g;
@@ -524,7 +561,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
             B.g_root[g] = idx;
             gv.s_state[sim] = SIM_LEAF; gv.s_node[sim] = idx; gv.s_depth[sim] = 0;
         }
-        write_planes(io, L.r.bd[1], L.codes, (size_t)g * P.K + sim);
+        write_planes(io, L.r.bd[1], L.codes, (size_t)g * P.K + sim, history_board(P, B, gv, L, fresh, 0));
         wave_sync();
         return;
     }
@@ -614,7 +651,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
                     }
                     if (lane == owner) gv.e_child[e] = idx;
                     if (lane == 0) { gv.s_state[sim] = SIM_LEAF; gv.s_node[sim] = idx; gv.s_depth[sim] = depth; }
-                    write_planes(io, L.r.bd[1], L.codes, (size_t)g * P.K + sim);
+                    write_planes(io, L.r.bd[1], L.codes, (size_t)g * P.K + sim, history_board(P, B, gv, L, fresh, depth));
                     wave_sync();
                     return;
                 }
@@ -1089,7 +1126,7 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
     if (uni((int)B.g_phase[g]) != PH_SEARCH) return;
     const GameView gv = make_view(B, P, g, L.ctr);
     counters_begin(gv);
-    const RoundIO io{planes, P.planes_dtype};
+    const RoundIO io{planes, P.planes_dtype, P.in_planes};
     int active = uni(B.g_active[g]);
     Arena ar{uni(B.g_node_count[g]), uni(B.g_edge_count[g])};
     const RootCtx rc{false, uni((int)B.g_n_no_act[g]), B.g_no_act + (size_t)g * MAX_NO_ACT,
@@ -1112,13 +1149,14 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
     int new_i = 0, new_n = 0;
     for (int guard = 0; guard < (1 << 20); ++guard) {
         int sim, node, depth;
+        bool fresh;
         if (resume_i < P.K) {                                         // parked simulations, in index order
             const int i = resume_i++;
             if (uni((int)gv.s_state[i]) != SIM_PARKED) continue;
-            sim = i; node = uni(gv.s_node[i]); depth = uni(gv.s_depth[i]);
+            sim = i; node = uni(gv.s_node[i]); depth = uni(gv.s_depth[i]); fresh = false;
             load_path(P, gv, L, i, depth);
         } else if (new_i < new_n) {                                   // the simulations of a fresh batch
-            sim = new_i++; node = uni(B.g_root[g]); depth = 0;
+            sim = new_i++; node = uni(B.g_root[g]); depth = 0; fresh = true;
         } else if ((mask & SIM_SELECT) && active == 0) {              // 3. next lock-step batch (player.py:169-178)
             const int tasks = uni(B.g_tasks_left[g]);
             if (tasks <= 0) break;                                    // search complete: k_advance takes over
@@ -1128,7 +1166,7 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             if (lane_id() == 0) B.g_tasks_left[g] = tasks - new_n;
             continue;
         } else break;
-        run_sim(P, B, gv, L, io, rc, uni(B.g_root[g]), sim, node, depth, &active, ar);
+        run_sim(P, B, gv, L, io, rc, uni(B.g_root[g]), sim, node, depth, &active, ar, fresh);
     }
     if (lane_id() == 0) { B.g_active[g] = active; B.g_node_count[g] = ar.ncount; B.g_edge_count[g] = ar.ecount; }
     counters_flush(gv);
@@ -1214,7 +1252,9 @@ __global__ __launch_bounds__(64) void k_set_roots(SearchParams P, SearchBuffers 
                                                  const int32_t* __restrict__ turns, const uint16_t* __restrict__ no_act,
                                                  const uint8_t* __restrict__ n_no_act, const uint8_t* __restrict__ inc,
                                                  const uint8_t* __restrict__ enable_resign,
-                                                 const uint8_t* __restrict__ select_mask)
+                                                 const uint8_t* __restrict__ select_mask,
+                                                 const int8_t* __restrict__ prev_boards,
+                                                 const uint8_t* __restrict__ hist_kind)
 {
     __shared__ SearchLDS L;
     const int g = blockIdx.x;
@@ -1229,6 +1269,14 @@ __global__ __launch_bounds__(64) void k_set_roots(SearchParams P, SearchBuffers 
     const int nna = n_no_act ? (int)n_no_act[g] : 0;
     if (lane < MAX_NO_ACT) B.g_no_act[(size_t)g * MAX_NO_ACT + lane] = (no_act && lane < nna) ? no_act[(size_t)g * MAX_NO_ACT + lane] : (uint16_t)NOMOVE;
     for (int i = lane; i < P.K; i += 64) gv.s_state[i] = SIM_IDLE;
+    {
+        const int hk = hist_kind ? (int)hist_kind[g] : 0;
+        int8_t* pb = B.g_prev_board + (size_t)g * BOARD_LDS;
+        if (hk == 1 && prev_boards) {
+            for (int i = lane; i < NSQ; i += 64) pb[i] = prev_boards[(size_t)g * NSQ + i];
+        }
+        if (lane == 0) B.g_hist_kind[g] = (uint8_t)((hk == 1 && !prev_boards) ? 2 : hk);
+    }
     if (lane == 0) {
         B.g_turns[g] = turns ? turns[g] : 0;
         B.g_n_no_act[g] = (uint8_t)(nna < MAX_NO_ACT ? nna : MAX_NO_ACT);
@@ -1381,6 +1429,8 @@ size_t layout(cz_search* s, char* base, bool dry)
     carve(cur, B.pending, 1, dry);
     carve(cur, B.noise, G * K * MAXMOVES, dry);
     carve(cur, B.g_noise_epoch, G, dry);
+    carve(cur, B.g_prev_board, G * BOARD_LDS, dry);
+    carve(cur, B.g_hist_kind, G, dry);
     return (size_t)(cur - base);
 }
 
@@ -1412,6 +1462,7 @@ int cz_search_create(const cz_search_cfg* c, cz_search** out)
     P.max_game_length = c->max_game_length > 0 ? c->max_game_length : 100;
     P.max_plies = 2 * P.max_game_length + 2;
     P.planes_dtype = c->planes_dtype;
+    P.in_planes = c->use_history ? 28 : 14;
     P.mode = MODE_EXTERNAL;
     P.c_puct = c->c_puct;
     P.c_puct_f32 = (float)c->c_puct;
@@ -1455,7 +1506,7 @@ int cz_search_info(const cz_search* s, int32_t* out)
     if (!s || !out) return serr(CZ_ERR_ARG, "cz_search_info: null argument");
     out[0] = s->P.G; out[1] = s->P.K; out[2] = s->P.sims; out[3] = s->P.node_cap; out[4] = s->P.edge_cap;
     out[5] = s->P.hash_cap; out[6] = s->P.max_depth; out[7] = s->P.max_plies; out[8] = s->P.record_stride;
-    out[9] = s->P.ring_cap; out[10] = CT_COUNT; out[11] = s->P.mode;
+    out[9] = s->P.ring_cap; out[10] = CT_COUNT; out[11] = s->P.in_planes;
     return CZ_OK;
 }
 
@@ -1480,12 +1531,12 @@ int cz_search_start_selfplay(cz_search* s, uint64_t seed, uint32_t first_game_id
 
 int cz_search_set_roots(cz_search* s, const int8_t* boards, const int32_t* turns, const uint16_t* no_act,
                         const uint8_t* n_no_act, const uint8_t* increase_temp, const uint8_t* enable_resign,
-                        const uint8_t* select_mask, void* stream)
+                        const uint8_t* select_mask, const int8_t* prev_boards, const uint8_t* hist_kind, void* stream)
 {
     if (!s || !boards) return serr(CZ_ERR_ARG, "cz_search_set_roots: null argument");
     s->P.mode = MODE_EXTERNAL;
     hipLaunchKernelGGL(k_set_roots, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, boards, turns, no_act,
-                       n_no_act, increase_temp, enable_resign, select_mask);
+                       n_no_act, increase_temp, enable_resign, select_mask, prev_boards, hist_kind);
     S_LAUNCH_CHECK("cz_search_set_roots");
     return CZ_OK;
 }

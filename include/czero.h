@@ -112,6 +112,8 @@ typedef struct cz_search_cfg {
     int32_t ring_capacity;           /* finished-game records kept on the device; 0 = 2 * n_games + 64 */
     double c_puct, noise_eps, dirichlet_alpha, tau_decay_rate, resign_threshold, enable_resign_rate;
     uint64_t seed;                   /* counter-based RNG key (Philox4x32-10): u(seed, game_id, stream, index) */
+    int32_t use_history;             /* 28 input planes (CChessPlayer(use_history=True), static_env.py:158-194) */
+    int32_t reserved;
 } cz_search_cfg;
 
 /* finished-game record in the ring: this header, then uint16 moves[max_plies + 2] (labels, mover frame) */
@@ -125,7 +127,8 @@ typedef struct cz_game_record {
 int cz_search_create(const cz_search_cfg* cfg, cz_search** out);   /* allocates device memory on the current device */
 int cz_search_destroy(cz_search* s);
 size_t cz_search_bytes(const cz_search* s);
-/* out[12]: G, K, sims, node_cap, edge_cap, hash_cap, max_depth, max_plies, record_stride, ring_cap, n_counters, mode */
+/* out[12]: G, K, sims, node_cap, edge_cap, hash_cap, max_depth, max_plies, record_stride, ring_cap, n_counters,
+ * input planes (14 / 28) */
 int cz_search_info(const cz_search* s, int32_t* out);
 
 /* self-play mode: every slot plays games from INIT_STATE forever; slot g starts with game id
@@ -134,13 +137,15 @@ int cz_search_start_selfplay(cz_search* s, uint64_t seed, uint32_t first_game_id
 
 /* external mode (CChessPlayer.action): set the position to search for each game.  boards [G][90];
  * turns [G] or NULL; no_act [G][16] + n_no_act [G] or NULL; increase_temp / enable_resign [G] or NULL;
- * select_mask [G] or NULL (only games with a non-zero byte are touched).  Trees are kept (subtree reuse). */
+ * select_mask [G] or NULL (only games with a non-zero byte are touched).  Trees are kept (subtree reuse).
+ * use_history only: hist_kind [G] or NULL = the `hist` argument of action(): 0 none, 1 prev_boards[g] ([G][90]) is
+ * the game position two plies before the root, 2 a history shorter than 5 entries was passed. */
 int cz_search_set_roots(cz_search* s, const int8_t* boards, const int32_t* turns, const uint16_t* no_act,
                         const uint8_t* n_no_act, const uint8_t* increase_temp, const uint8_t* enable_resign,
-                        const uint8_t* select_mask, void* stream);
+                        const uint8_t* select_mask, const int8_t* prev_boards, const uint8_t* hist_kind, void* stream);
 
 /* one lock-step round for all games.  policy [G*K][2086] float32, value [G*K] float32 (results for the
- * planes written by the previous round; ignored for slots that had no leaf), planes [G*K][14][10][9]. */
+ * planes written by the previous round; ignored for slots that had no leaf), planes [G*K][14 or 28][10][9]. */
 int cz_search_round(cz_search* s, const float* policy, const float* value, void* planes, void* stream);
 
 int cz_search_reset_trees(cz_search* s, void* stream);

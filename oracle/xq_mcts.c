@@ -41,6 +41,7 @@ typedef struct {
     int path_edge[MAXDEPTH];
     int8_t board[90];      /* current state */
     Node *leaf;            /* expanded this round, waiting for NN */
+    int fresh;             /* started by action() (not resumed from a parked state): player.py:217 */
 } Sim;
 
 struct xqo_player {
@@ -54,6 +55,7 @@ struct xqo_player {
     const uint16_t *no_act; int n_no_act;
     Sim *sims; int n_sims_cap;
     xqo_counters ctr;
+    int hist_kind; int8_t hist_prev[90];
 };
 
 /* ---- tree ---------------------------------------------------------------- */
@@ -125,6 +127,11 @@ void xqo_player_destroy(xqo_player *p)
 }
 
 void xqo_player_counters(const xqo_player *p, xqo_counters *out) { *out = p->ctr; }
+void xqo_player_set_history(xqo_player *p, int kind, const int8_t prev[90])
+{
+    p->hist_kind = kind;
+    if (kind == 1 && prev) memcpy(p->hist_prev, prev, 90);
+}
 int xqo_player_tree_size(const xqo_player *p) { return p->n_nodes; }
 
 /* ---- Dirichlet(alpha * 1_n)[0] ~ Beta(alpha, alpha (n-1)) (player.py:304).  The reference draws
@@ -275,6 +282,7 @@ static void descend(xqo_player *p, int idx)
             return;
         }
         if (node->waiting) {                                          /* :238-242 */
+            s->fresh = 0;                                             /* resumed by MCTS_search(state, hist) */
             park(node, idx);
             p->ctr.parked++;
             return;
@@ -300,13 +308,15 @@ static void descend(xqo_player *p, int idx)
 static void run_batch(xqo_player *p, int n)
 {
     int i, pending;
-    float *planes = (float *)malloc(sizeof(float) * 14 * 90 * (size_t)n);
+    const int plane_len = p->cfg.use_history ? 28 * 90 : 14 * 90;
+    float *planes = (float *)malloc(sizeof(float) * plane_len * (size_t)n);
+    const int8_t **prevs = (const int8_t **)calloc((size_t)n, sizeof(*prevs));
     float *policy = (float *)malloc(sizeof(float) * XQO_NLABELS * (size_t)n);
     float *value = (float *)malloc(sizeof(float) * (size_t)n);
     int *leaf_sim = (int *)malloc(sizeof(int) * (size_t)n);
     for (i = 0; i < n; i++) {
         Sim *s = &p->sims[i];
-        s->active = 1; s->depth = 0; s->leaf = 0;
+        s->active = 1; s->depth = 0; s->leaf = 0; s->fresh = 1;
         memcpy(s->board, p->root, 90);
     }
     for (i = 0; i < n; i++) descend(p, i);
@@ -314,8 +324,18 @@ static void run_batch(xqo_player *p, int n)
         int nl = 0, k;
         for (i = 0; i < n; i++) if (p->sims[i].leaf) leaf_sim[nl++] = i;
         if (!nl) break;
-        for (k = 0; k < nl; k++) xqo_planes(p->sims[leaf_sim[k]].leaf->board, planes + (size_t)k * 14 * 90);
-        p->fn(p->fn_ctx, planes, nl, policy, value);
+        for (k = 0; k < nl; k++) {
+            Sim *s = &p->sims[leaf_sim[k]];
+            if (!p->cfg.use_history) { xqo_planes(s->leaf->board, planes + (size_t)k * plane_len); continue; }
+            /* expand_and_evaluate, player.py:322-338 */
+            {
+                const int8_t *prev = 0;
+                if (s->fresh && p->hist_kind) prev = p->hist_kind == 1 ? p->hist_prev : 0;   /* real_hist[-5] */
+                else if (s->depth >= 2) prev = s->path_node[s->depth - 2]->board;            /* history[-5] */
+                xqo_planes_hist(s->leaf->board, prev, planes + (size_t)k * plane_len);
+            }
+        }
+        p->fn(p->fn_ctx, planes, nl, plane_len, policy, value);
         p->ctr.nn_batches++;
         p->ctr.nn_positions += (uint64_t)nl;
         /* attach + backup in index order; collect parked sims */
@@ -352,7 +372,7 @@ static void run_batch(xqo_player *p, int n)
     pending = 0;
     for (i = 0; i < n; i++) pending += p->sims[i].active;
     if (pending) { fprintf(stderr, "xq_mcts: %d sims never completed\n", pending); abort(); }
-    free(planes); free(policy); free(value); free(leaf_sim);
+    free(planes); free(policy); free(value); free(leaf_sim); free(prevs);
 }
 
 /* ---- arena model (engine behaviour, not in the reference): keep what is reachable from the root ---- */
@@ -618,8 +638,9 @@ static uint64_t mix64(uint64_t z)
     return z;
 }
 
-void xqo_stub_uniform(void *ctx, const float *planes, int n, float *policy, float *value)
+void xqo_stub_uniform(void *ctx, const float *planes, int n, int plane_len, float *policy, float *value)
 {
+    (void)plane_len;
     const float v = ctx ? *(const float *)ctx : 0.0f;
     const float pu = (float)(1.0 / 2086.0);
     int i, a;
@@ -630,15 +651,15 @@ void xqo_stub_uniform(void *ctx, const float *planes, int n, float *policy, floa
     }
 }
 
-void xqo_stub_hash(void *ctx, const float *planes, int n, float *policy, float *value)
+void xqo_stub_hash(void *ctx, const float *planes, int n, int plane_len, float *policy, float *value)
 {
     const uint64_t salt = ctx ? *(const uint64_t *)ctx : 0;
     int i, o, a;
     for (i = 0; i < n; i++) {
-        const float *pl = planes + (size_t)i * 1260;
+        const float *pl = planes + (size_t)i * plane_len;
         uint64_t h = salt;
         uint64_t uv;
-        for (o = 0; o < 1260; o++) if (pl[o] != 0.0f) h += mix64((uint64_t)o + 1);
+        for (o = 0; o < plane_len; o++) if (pl[o] != 0.0f) h += mix64((uint64_t)o + 1);
         h = mix64(h);
         for (a = 0; a < XQO_NLABELS; a++) {
             uint64_t u = (mix64(h + (uint64_t)(a + 1) * 0x9E3779B97F4A7C15ULL) >> 40) & 0xFFFF;

@@ -242,7 +242,7 @@ class PlayCfg(C.Structure):
                 ("noise_eps", C.c_double), ("dirichlet_alpha", C.c_double), ("tau_decay_rate", C.c_double),
                 ("virtual_loss", C.c_int), ("resign_threshold", C.c_double), ("min_resign_turn", C.c_int),
                 ("evaluate", C.c_int), ("max_game_length", C.c_int), ("enable_resign_rate", C.c_double),
-                ("node_capacity", C.c_int), ("edge_capacity", C.c_int)]
+                ("node_capacity", C.c_int), ("edge_capacity", C.c_int), ("use_history", C.c_int)]
 
 
 class Counters(C.Structure):
@@ -255,16 +255,17 @@ class Counters(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
-EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float))
+EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_float),
+                      C.POINTER(C.c_float))
 RNG_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int, C.c_uint64)
 
 
 def play_cfg(simulation_num_per_move=100, search_threads=1, c_puct=1.5, noise_eps=0.0, dirichlet_alpha=0.2,
              tau_decay_rate=0.0, virtual_loss=3, resign_threshold=-0.92, min_resign_turn=20, evaluate=0,
-             max_game_length=100, enable_resign_rate=1.0, node_capacity=0, edge_capacity=0):
+             max_game_length=100, enable_resign_rate=1.0, node_capacity=0, edge_capacity=0, use_history=0):
     return PlayCfg(simulation_num_per_move, search_threads, c_puct, noise_eps, dirichlet_alpha, tau_decay_rate,
                    virtual_loss, resign_threshold, min_resign_turn, evaluate, max_game_length, enable_resign_rate,
-                   node_capacity, edge_capacity)
+                   node_capacity, edge_capacity, use_history)
 
 
 _mcts_sig_done = False
@@ -283,6 +284,7 @@ def _mcts_lib():
         L.xqo_player_tree_size.argtypes = [C.c_void_p]; L.xqo_player_tree_size.restype = C.c_int
         L.xqo_player_search.argtypes = [C.c_void_p, i8p, C.c_int, u16p, C.c_int, C.c_int, dp]
         L.xqo_player_search.restype = C.c_int
+        L.xqo_player_set_history.argtypes = [C.c_void_p, C.c_int, i8p]
         L.xqo_sample_action.argtypes = [C.POINTER(PlayCfg), dp, C.c_int, C.c_int, C.c_double]
         L.xqo_sample_action.restype = C.c_int
         L.xqo_player_action.argtypes = [C.c_void_p, i8p, C.c_int, u16p, C.c_int, C.c_int, C.c_double, dp]
@@ -304,8 +306,8 @@ class _Stub:
     def __init__(self, spec):
         L = _mcts_lib()
         if callable(spec):
-            def cb(ctx, planes, n, policy, value, _f=spec):
-                pl = np.ctypeslib.as_array(planes, shape=(n, 14, 10, 9))
+            def cb(ctx, planes, n, plane_len, policy, value, _f=spec):
+                pl = np.ctypeslib.as_array(planes, shape=(n, plane_len // 90, 10, 9))
                 p, v = _f(pl)
                 np.ctypeslib.as_array(policy, shape=(n, NLABELS))[:] = p
                 np.ctypeslib.as_array(value, shape=(n,))[:] = v
@@ -373,6 +375,16 @@ class Player:
         a = self.L.xqo_player_action(self.h, _p(b, C.c_int8), turns, ptr, len(arr), int(increase_temp), u,
                                      _p(pol, C.c_double))
         return (None if a < 0 else label_str(a)), pol
+
+    def set_history(self, hist):
+        """hist: the `hist` argument of CChessPlayer.action (list alternating state, action, ...), or None."""
+        if not hist:
+            self.L.xqo_player_set_history(self.h, 0, None)
+        elif len(hist) >= 5:
+            prev = state_to_board(hist[-5])
+            self.L.xqo_player_set_history(self.h, 1, _p(prev, C.c_int8))
+        else:
+            self.L.xqo_player_set_history(self.h, 2, None)
 
     def node_stats(self, state):
         b = state_to_board(state) if isinstance(state, str) else np.ascontiguousarray(state, dtype=np.int8)

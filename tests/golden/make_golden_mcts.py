@@ -137,8 +137,29 @@ def gen_mcts():
         lines.append({"salt": salt, "sims": sims, "steps": steps})
         print("line salt", salt, "plies", len(steps), "evals/ply", [s["evals"] for s in steps], flush=True)
 
+    # 28-plane input (use_history=True, state_history_to_planes): without a game history (self-play), with the
+    # `hist` argument of action() (UCI front-end) long enough / too short to reach two plies back
+    game = [senv.INIT_STATE]
+    for mv in ('7242', '7062', '1219', '0001'):
+        game += [mv, senv.step(game[-1], mv)]
+    hist_cases = []
+    for name, state, hist, salt, sims in (("hist_none", game[-1], None, 51, 200),
+                                          ("hist_full", game[-1], list(game), 52, 200),
+                                          ("hist_short", game[2], list(game[:3]), 53, 120)):
+        cfg = make_cfg(sims)
+        pipe = stub_net.StubPipe(stub_fn(dict(kind="hash", salt=salt)))
+        pl = ref_player.CChessPlayer(cfg, search_tree=None, pipes=pipe, enable_resign=False, use_history=True)
+        action, policy = pl.action(state, 4, None, hist=hist)
+        rec = dict(name=name, state=state, hist=hist, sims=sims, stub=dict(kind="hash", salt=salt))
+        rec.update(root_stats(pl, state))
+        rec["action"] = action
+        rec["nn_positions"] = pipe.n_positions
+        hist_cases.append(rec)
+        pl.close()
+        print(name, "action", action, "evals", pipe.n_positions, flush=True)
+
     with open(os.path.join(HERE, "mcts_k1.json"), "w") as f:
-        json.dump({"meta": meta(), "cases": out, "lines": lines}, f, separators=(",", ":"))
+        json.dump({"meta": meta(), "cases": out, "lines": lines, "hist_cases": hist_cases}, f, separators=(",", ":"))
 
 
 def _shim_tf():

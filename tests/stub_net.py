@@ -4,7 +4,7 @@
   * here in torch  -- replaces the ResNet on the GPU in the -m gpu parity tests
 so that "identical visit counts with the net stubbed to constants" can be checked exactly.
 
-hash stub:  h = mix64(salt + sum_{o: planes[o] != 0} mix64(o + 1))
+hash stub:  h = mix64(salt + sum_{o: planes[o] != 0} mix64(o + 1))      (o over 14*90 or 28*90 elements)
             policy[a] = x^8 (three float32 squarings), x = ((mix64(h + (a+1)*GOLD) >> 40 & 0xFFFF) + 1) / 65536
             value     = ((mix64(h ^ C2) >> 40 & 0xFFFF) - 32768) / 32768
 Also: the counter-based uniform stream (Philox4x32-10) shared by the oracle and the engine.
@@ -38,15 +38,15 @@ def _mix64_np(z):
     return z
 
 
-_C1 = _mix64_np(np.arange(1, 1261, dtype=np.uint64))
+_C1 = _mix64_np(np.arange(1, 2521, dtype=np.uint64))      # 14 or 28 planes of 90 squares
 _A = (np.arange(1, N_LABELS + 1, dtype=np.uint64) * np.uint64(GOLD))
 
 
 def hash_stub_numpy(planes, salt=0):
     """planes [n,14,10,9] (any dtype, 0/1) -> (policy float32 [n,2086], value float32 [n])"""
-    pl = np.asarray(planes).reshape(len(planes), 1260) != 0
+    pl = np.asarray(planes).reshape(len(planes), -1) != 0
     with np.errstate(over="ignore"):
-        h0 = (pl.astype(np.uint64) * _C1[None, :]).sum(axis=1, dtype=np.uint64) + np.uint64(salt)
+        h0 = (pl.astype(np.uint64) * _C1[None, :pl.shape[1]]).sum(axis=1, dtype=np.uint64) + np.uint64(salt)
         h = _mix64_np(h0)
         u = (_mix64_np(h[:, None] + _A[None, :]) >> np.uint64(40)) & np.uint64(0xFFFF)
     x = (u + np.uint64(1)).astype(np.float32) / np.float32(65536.0)
@@ -96,8 +96,8 @@ def hash_stub_torch(planes, salt=0):
         _torch_consts[key] = (c1, a)
     c1, a = _torch_consts[key]
     n = planes.shape[0]
-    pl = (planes.reshape(n, 1260) != 0).to(torch.int64)
-    h0 = (pl * c1[None, :]).sum(dim=1) + _s64(salt)
+    pl = (planes.reshape(n, -1) != 0).to(torch.int64)
+    h0 = (pl * c1[None, :pl.shape[1]]).sum(dim=1) + _s64(salt)
     h = _mix64_torch(h0)
     u = (_mix64_torch(h[:, None] + a[None, :]) >> 40) & 0xFFFF
     x = (u + 1).to(torch.float32) / 65536.0

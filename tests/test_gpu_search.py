@@ -37,8 +37,8 @@ def play_config(**kw):
     return types.SimpleNamespace(**d)
 
 
-def oracle_cfg(pc, evaluate=0, node_capacity=0):
-    return xo.play_cfg(node_capacity=node_capacity, simulation_num_per_move=pc.simulation_num_per_move, search_threads=pc.search_threads,
+def oracle_cfg(pc, evaluate=0, node_capacity=0, use_history=0):
+    return xo.play_cfg(node_capacity=node_capacity, use_history=use_history, simulation_num_per_move=pc.simulation_num_per_move, search_threads=pc.search_threads,
                        c_puct=pc.c_puct, noise_eps=pc.noise_eps, dirichlet_alpha=pc.dirichlet_alpha,
                        tau_decay_rate=pc.tau_decay_rate, virtual_loss=pc.virtual_loss,
                        resign_threshold=pc.resign_threshold, min_resign_turn=pc.min_resign_turn, evaluate=evaluate,
@@ -318,3 +318,48 @@ def test_root_noise_changes_visits_but_not_totals(gpu):
     assert (outs[0] == outs[0][0]).all()                    # without noise all 8 games are identical
     assert len({tuple(r) for r in outs[1]}) > 1             # with noise they differ from game to game
     assert (outs[1] != outs[0]).any()
+
+
+def test_history_planes_match_reference_and_oracle(gpu):
+    """28 input planes (use_history): golden searches of the reference player (no history / action(hist=...) long /
+    short), then K = 4 with parked simulations against the oracle."""
+    data = _golden("mcts_k1.json")
+    t = gpu.torch
+    for c in data["hist_cases"]:
+        pc = play_config(simulation_num_per_move=c["sims"], search_threads=1)
+        s = gpu.S.Search(pc, 1, seed=0, use_history=True)
+        assert s.planes.shape[1] == 28
+        prev = kind = None
+        if c["hist"]:
+            if len(c["hist"]) >= 5:
+                prev = boards_tensor(gpu, [c["hist"][-5]])
+                kind = t.tensor([1], dtype=t.uint8, device="cuda")
+            else:
+                kind = t.tensor([2], dtype=t.uint8, device="cuda")
+        s.set_roots(boards_tensor(gpu, [c["state"]]), turns=t.tensor([4], dtype=t.int32, device="cuda"),
+                    prev_boards=prev, hist_kind=kind)
+        s.run_until_idle(stub_eval(gpu, c["stub"]))
+        st = s.root_stats()
+        ref = dict(moves=np.array([xo.label_of_str(m) for m in c["moves"].split()], dtype=np.uint16),
+                   n=np.array(c["n"], dtype=np.int32), sum_n=c["sum_n"],
+                   w=np.array([float.fromhex(x) for x in c["w_hex"]]),
+                   p=np.array([float.fromhex(x) for x in c["p_hex"]], dtype=np.float32))
+        assert_root_equal(st, 0, ref, c["name"])
+        s.close()
+    # K > 1: parked simulations fall back to the path history
+    hist = data["hist_cases"][1]["hist"]
+    state = data["hist_cases"][1]["state"]
+    pc = play_config(simulation_num_per_move=150, search_threads=4)
+    spec = dict(kind="hash", salt=77)
+    s = gpu.S.Search(pc, 2, seed=0, use_history=True)
+    kinds = t.tensor([1, 0], dtype=t.uint8, device="cuda")
+    s.set_roots(boards_tensor(gpu, [state, state]), prev_boards=boards_tensor(gpu, [hist[-5], hist[-5]]), hist_kind=kinds)
+    s.run_until_idle(stub_eval(gpu, spec))
+    st = s.root_stats()
+    for g, h in enumerate((hist, None)):
+        pl = xo.Player(oracle_cfg(pc, use_history=1), spec)
+        pl.set_history(h)
+        pl.search(state)
+        assert_root_equal(st, g, pl.node_stats(state), f"hist game {g}")
+        pl.close()
+    s.close()

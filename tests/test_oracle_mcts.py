@@ -61,6 +61,22 @@ def test_reference_searches():
         pl.close()
 
 
+def test_reference_history_planes():
+    """use_history=True (28 input planes) incl. the action(hist=...) quirk of player.py:217-218."""
+    data = _golden("mcts_k1.json")
+    assert len(data.get("hist_cases", [])) >= 3
+    for c in data["hist_cases"]:
+        cfg = xo.play_cfg(simulation_num_per_move=c["sims"], search_threads=1, use_history=1)
+        pl = xo.Player(cfg, c["stub"])
+        pl.set_history(c["hist"])
+        a, _ = pl.action(c["state"], 4, None, False, 0.5)
+        st = pl.node_stats(c["state"])
+        assert st["n"].tolist() == c["n"] and st["sum_n"] == c["sum_n"], c["name"]
+        assert [float(x).hex() for x in st["w"]] == c["w_hex"], c["name"]
+        assert a == c["action"] and pl.counters()["nn_positions"] == c["nn_positions"]
+        pl.close()
+
+
 def test_reference_lines_with_subtree_reuse():
     data = _golden("mcts_k1.json")
     for line in data["lines"]:
