@@ -31,6 +31,7 @@ def declare(L):
     L.cz_search_set_roots.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.cz_search_round.argtypes = [vp, vp, vp, vp, vp]
     L.cz_search_reset_trees.argtypes = [vp, vp]
+    L.cz_search_set_sims.argtypes = [vp, i32]
     L.cz_search_pending.argtypes = [vp, C.POINTER(C.c_int), vp]
     L.cz_search_root_stats.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.cz_search_choose.argtypes = [vp, vp, vp, vp]
@@ -40,7 +41,7 @@ def declare(L):
     for n in ("cz_search_create", "cz_search_destroy", "cz_search_info", "cz_search_start_selfplay",
               "cz_search_set_roots", "cz_search_round", "cz_search_reset_trees", "cz_search_pending",
               "cz_search_root_stats", "cz_search_choose", "cz_search_counters", "cz_search_drain_records",
-              "cz_debug_sqrt"):
+              "cz_debug_sqrt", "cz_search_set_sims"):
         getattr(L, n).restype = i32
 
 
@@ -128,6 +129,10 @@ class Search:
             ptr(n_no_act, torch.uint8), ptr(increase_temp, torch.uint8), ptr(enable_resign, torch.uint8),
             ptr(select_mask, torch.uint8), ptr(prev_boards, torch.int8), ptr(hist_kind, torch.uint8),
             self._stream()), "cz_search_set_roots")
+
+    def set_sims(self, sims):
+        _native.check(self.L.cz_search_set_sims(self.h, int(sims)), "cz_search_set_sims")
+        self.sims = int(sims)
 
     def reset_trees(self):
         _native.check(self.L.cz_search_reset_trees(self.h, self._stream()), "cz_search_reset_trees")

@@ -90,10 +90,12 @@ class CChessPlayer:
             self._search = None
 
     def action(self, state, turns, no_act=None, depth=None, infinite=False, hist=None, increase_temp=False):
-        if depth or infinite:
-            raise NotImplementedError("depth / infinite search (UCI front-end) is not built yet (SURVEY 8 f-3)")
+        if infinite:
+            raise NotImplementedError("infinite search (UCI `go infinite` + stop) is not built yet (SURVEY 8 f-3)")
         t = self._torch
         s = self._search
+        base_sims = int(self.play_config.simulation_num_per_move)
+        s.set_sims(int(depth) if depth else base_sims)     # action(depth=...): that many simulations (player.py:160)
         self.root_state, self.no_act, self.increase_temp = state, no_act, increase_temp
         board = t.from_numpy(senv.state_to_array(state)[None]).cuda()
         na = np.full((1, 16), 0xFFFF, dtype=np.uint16)

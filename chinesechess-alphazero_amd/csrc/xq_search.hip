@@ -463,12 +463,13 @@ XQ_D void encode_block(int dtype, const int8_t* b, uint8_t* codes, char* out)
 
 // the leaf's input planes into its queue slot: 14 planes (state_to_planes), or 28 with the position two plies
 // earlier (`prev`, NULL = none: zeros) as the second block (state_history_to_planes, static_env.py:158-194)
+template <bool HIST>
 XQ_D void write_planes(const RoundIO& io, const int8_t* b, uint8_t* codes, size_t slot, const int8_t* prev)
 {
     const size_t esz = io.planes_dtype == CZ_F32 ? 4 : (io.planes_dtype == CZ_U8 ? 1 : 2);
     char* out = (char*)io.planes + slot * (size_t)io.in_planes * 90 * esz;
     encode_block(io.planes_dtype, b, codes, out);
-    if (io.in_planes == 28) {
+    if (HIST) {
         char* out2 = out + 1260 * esz;
         if (prev) encode_block(io.planes_dtype, prev, codes, out2);
         else for (int q = lane_id(); q < 315 * (int)esz; q += 64) reinterpret_cast<uint32_t*>(out2)[q] = 0u;
@@ -537,6 +538,7 @@ XQ_D int expand_node(const SearchParams& P, const SearchBuffers& B, const GameVi
 
 // One descent of simulation `sim` starting at `node` with `depth` path entries already in L.path_*
 // (MCTS_search, player.py:198-260).  `node` < 0 means the root position is not in the tree yet.
+template <bool HIST>
 XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L,
                   const RoundIO& io, const RootCtx& rc0, int root, int sim, int node, int depth, int* active,
                   Arena& ar, bool fresh)
@@ -561,7 +563,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
             B.g_root[g] = idx;
             gv.s_state[sim] = SIM_LEAF; gv.s_node[sim] = idx; gv.s_depth[sim] = 0;
         }
-        write_planes(io, L.r.bd[1], L.codes, (size_t)g * P.K + sim, history_board(P, B, gv, L, fresh, 0));
+        write_planes<HIST>(io, L.r.bd[1], L.codes, (size_t)g * P.K + sim, HIST ? history_board(P, B, gv, L, fresh, 0) : nullptr);
         wave_sync();
         return;
     }
@@ -651,7 +653,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
                     }
                     if (lane == owner) gv.e_child[e] = idx;
                     if (lane == 0) { gv.s_state[sim] = SIM_LEAF; gv.s_node[sim] = idx; gv.s_depth[sim] = depth; }
-                    write_planes(io, L.r.bd[1], L.codes, (size_t)g * P.K + sim, history_board(P, B, gv, L, fresh, depth));
+                    write_planes<HIST>(io, L.r.bd[1], L.codes, (size_t)g * P.K + sim, HIST ? history_board(P, B, gv, L, fresh, depth) : nullptr);
                     wave_sync();
                     return;
                 }
@@ -1117,6 +1119,7 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
 // (move sampling with pow(), game rules, tree compaction, Gamma sampling).
 constexpr int SIM_BACKUP = 1, SIM_SELECT = 2;
 
+template <bool HIST>        // HIST: 28 input planes (use_history); kept out of the common 14-plane instantiation
 __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, const float* __restrict__ policy,
                                            const float* __restrict__ value, void* planes, int mask)
 {
@@ -1166,7 +1169,7 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             if (lane_id() == 0) B.g_tasks_left[g] = tasks - new_n;
             continue;
         } else break;
-        run_sim(P, B, gv, L, io, rc, uni(B.g_root[g]), sim, node, depth, &active, ar, fresh);
+        run_sim<HIST>(P, B, gv, L, io, rc, uni(B.g_root[g]), sim, node, depth, &active, ar, fresh);
     }
     if (lane_id() == 0) { B.g_active[g] = active; B.g_node_count[g] = ar.ncount; B.g_edge_count[g] = ar.ecount; }
     counters_flush(gv);
@@ -1548,11 +1551,23 @@ int cz_search_round(cz_search* s, const float* policy, const float* value, void*
     hipStream_t st = (hipStream_t)stream;
     const bool noise = s->P.noise_eps != 0.0;
     if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B, SIM_BACKUP);
-    hipLaunchKernelGGL(k_sim, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP);
+    const bool hist = s->P.in_planes == 28;
+    if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP);
+    else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP);
     hipLaunchKernelGGL(k_advance, grid, block, 0, st, s->P, s->B);
     if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B, SIM_SELECT);
-    hipLaunchKernelGGL(k_sim, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT);
+    if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT);
+    else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT);
     S_LAUNCH_CHECK("cz_search_round");
+    return CZ_OK;
+}
+
+int cz_search_set_sims(cz_search* s, int simulation_num_per_move)
+{
+    if (!s || simulation_num_per_move < 1) return serr(CZ_ERR_ARG, "cz_search_set_sims: bad argument");
+    if (simulation_num_per_move + 2 > s->P.node_cap)
+        return serr(CZ_ERR_ARG, "cz_search_set_sims: more simulations than the arena holds (node_capacity)");
+    s->P.sims = simulation_num_per_move;
     return CZ_OK;
 }
 

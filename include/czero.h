@@ -148,6 +148,8 @@ int cz_search_set_roots(cz_search* s, const int8_t* boards, const int32_t* turns
  * planes written by the previous round; ignored for slots that had no leaf), planes [G*K][14 or 28][10][9]. */
 int cz_search_round(cz_search* s, const float* policy, const float* value, void* planes, void* stream);
 
+/* simulations per search for the following cz_search_set_roots calls (CChessPlayer.action(depth=...), player.py:160) */
+int cz_search_set_sims(cz_search* s, int simulation_num_per_move);
 int cz_search_reset_trees(cz_search* s, void* stream);
 /* synchronises the stream; *host_out = number of games whose current search is unfinished */
 int cz_search_pending(cz_search* s, int* host_out, void* stream);
