@@ -134,7 +134,7 @@ def games_per_hour_estimate(expansions_per_s, config):
 def pmc_traffic():
     """HBM bytes per round of the tree kernels from the committed PMC passes (profiles/, separate rocprofv3 --pmc runs)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_round.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_search_round.json")))
     if not files:
         return None, None
     with open(files[-1]) as f:

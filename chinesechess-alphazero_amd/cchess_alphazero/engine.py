@@ -1,8 +1,8 @@
 """Batched self-play engine: thousands of concurrent games on one MI355X.
 
 One engine = one GPU = one process.  Each ROUND is
-    k_round (hand-written HIP, one wavefront per game: backup / select / expand / game rules, leaf planes
-             written straight into the evaluation queue)
+    cz_search_round (hand-written HIP, one wavefront per game: k_sim(BACKUP) -> k_advance -> k_sim(SELECT);
+             backup / select / expand / game rules, leaf planes written straight into the evaluation queue)
  -> one ResNet forward over the whole queue (PyTorch-ROCm; MIOpen / hipBLASLt MFMA kernels)
 with no host decision and no device->host copy in between.  Finished games are appended to a device
 ring and drained by the host only when it wants to write play-record files.

@@ -1,11 +1,11 @@
 // xq_rules.h -- wave-cooperative Xiangqi rules for gfx950 (device only).
 //
-// Execution model: ONE 64-lane wavefront per board (workgroup = 64 threads), the board and
-// the ordered move lists staged in that wave's LDS.  Lane l owns squares l and l+64; the
-// reference's move ORDER (static_env.py:256-321: squares y-major/x-minor, per-piece direction
-// order) is kept by a two-pass ordered compaction: count per square -> wave prefix sum ->
-// emit at the square's offset.  Terminal detection, check detection and the perpetual
-// check/chase helpers are ballots over those lists.
+// Execution model: ONE 64-lane wavefront per board (workgroup = 64 threads), the board and the ordered move
+// lists staged in that wave's LDS.  The board is reduced to three 90-bit square sets by ballots and lane r
+// generates the moves of the mover's r-th piece (xq_lane.h::gen_piece); the reference's move ORDER
+// (static_env.py:256-321: squares y-major/x-minor, per-piece direction order) is kept by a two-pass ordered
+// compaction: count per piece -> wave prefix sum -> emit at the piece's offset.  Terminal detection, check
+// detection and the perpetual check/chase helpers are ballots over those lists.
 //
 // Synchronisation inside the single-wave workgroup: see wave_sync() / wave_sync_global() below.
 #pragma once
