@@ -363,3 +363,22 @@ def test_history_planes_match_reference_and_oracle(gpu):
         assert_root_equal(st, g, pl.node_stats(state), f"hist game {g}")
         pl.close()
     s.close()
+
+
+def test_many_concurrent_games_match_oracle(gpu):
+    """Stress form of the self-play parity: 384 concurrent game-waves (several per SIMD, like the benchmark) with
+    the root noise off, every first game compared move for move with the oracle."""
+    pc = play_config(simulation_num_per_move=20, search_threads=4, tau_decay_rate=0.95, max_game_length=12,
+                     enable_resign_rate=0.5, resign_threshold=-0.3, min_resign_turn=6)
+    spec = dict(kind="hash", salt=61)
+    G, seed = 384, 2024
+    recs, ctr = run_selfplay(gpu, pc, spec, G, seed, G, node_capacity=20 * 30)
+    assert ctr["overflow_sims"] == 0 and ctr["depth_overflow"] == 0
+    bad = []
+    for gid in range(G):
+        ref = xo.selfplay_game(oracle_cfg(pc), spec, seed, gid)
+        got = recs[gid]
+        if ([xo.label_str(int(m)) for m in got["moves"]] != ref["moves"] or got["value"] != int(ref["value"])
+                or got["store"] != ref["store"]):
+            bad.append(gid)
+    assert not bad, bad[:10]
