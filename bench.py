@@ -268,6 +268,7 @@ def main():
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
+        dist.barrier()                  # rank 0 may still be timing the CPU baseline: leave together
         dist.destroy_process_group()
 
 

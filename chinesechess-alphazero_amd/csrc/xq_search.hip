@@ -861,6 +861,7 @@ XQ_D int choose_action(const SearchParams& P, const SearchBuffers& B, const Game
     const int root = uni(B.g_root[g]);
     if (root < 0) return -2;
     const int nm = (int)(uniu(gv.node_meta[root]) & 0xFF);
+    if (nm == 0) return -1;             // no move at all (the reference player dead-locks here): give the game up
     const int eoff = (int)uniu(gv.node_eoff[root]);
     const int n_no_act = uni((int)B.g_n_no_act[g]);
     const uint16_t* no_act = B.g_no_act + (size_t)g * MAX_NO_ACT;

@@ -162,6 +162,39 @@ def gen_mcts():
         json.dump({"meta": meta(), "cases": out, "lines": lines, "hist_cases": hist_cases}, f, separators=(",", ":"))
 
 
+def gen_mcts_1k():
+    """north_star: "visit-count outputs bit-identical to the reference on a fixed 1k-position suite": one K = 1
+    search of 48 simulations from every non-terminal position of positions_1k.json (hash stub, salt 101)."""
+    np.random.dirichlet = lambda alpha, size=None: np.full(len(alpha), 1.0 / len(alpha))
+    with open(os.path.join(HERE, "positions_1k.json")) as f:
+        suite = json.load(f)
+    # the 960 positions taken from real (random) play; the hand-made special positions are left out: some of them
+    # lead to a node whose mover has no move at all, where the reference's search thread dies and action() hangs
+    positions = suite["positions"][:suite["n_random"]]
+    sims, salt = 48, 101
+    cfg = make_cfg(sims)
+    out = []
+    for i, r in enumerate(positions):
+        if r["done"][0] or not r["moves"]:           # terminal, or no move at all (the reference player dead-locks)
+            out.append(None)
+            continue
+        pipe = stub_net.StubPipe(stub_fn(dict(kind="hash", salt=salt)))
+        pl = ref_player.CChessPlayer(cfg, search_tree=None, pipes=pipe, enable_resign=False)
+        action, _ = pl.action(r["state"], 0)
+        node = pl.tree[r["state"]]
+        n = [int(node.a[m].n) if m in node.a else 0 for m in node.legal_moves]
+        w = np.array([float(node.a[m].w) if m in node.a else 0.0 for m in node.legal_moves], dtype=np.float64)
+        out.append({"crc": visit_crc(node.legal_moves, n), "w_crc": zlib.crc32(w.tobytes()) & 0xFFFFFFFF,
+                    "sum_n": int(node.sum_n), "action": action, "evals": pipe.n_positions})
+        pl.close()
+        if i % 100 == 0:
+            print("mcts_1k", i, flush=True)
+    with open(os.path.join(HERE, "mcts_1k.json"), "w") as f:
+        json.dump({"meta": meta(), "sims": sims, "stub": dict(kind="hash", salt=salt), "results": out}, f,
+                  separators=(",", ":"))
+    print("mcts_1k.json:", sum(1 for x in out if x), "searches")
+
+
 def _shim_tf():
     for name in ("tensorflow", "keras", "keras.engine", "keras.engine.topology", "keras.engine.training",
                  "keras.layers", "keras.layers.convolutional", "keras.layers.core", "keras.layers.merge",
@@ -265,3 +298,5 @@ if __name__ == "__main__":
         gen_mcts()
     if what in ("games", "all"):
         gen_games()
+    if what in ("mcts1k", "all"):
+        gen_mcts_1k()

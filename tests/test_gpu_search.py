@@ -382,3 +382,28 @@ def test_many_concurrent_games_match_oracle(gpu):
                 or got["store"] != ref["store"]):
             bad.append(gid)
     assert not bad, bad[:10]
+
+
+def test_golden_visit_counts_on_the_1k_suite(gpu, positions_1k):
+    """north_star: "move-gen and visit-count outputs bit-identical to the reference on a fixed 1k-position suite".
+    All non-terminal positions of the suite are searched at once (one game tree = one wavefront each) and compared
+    with the visit counts / W sums recorded from the reference's own player."""
+    data = _golden("mcts_1k.json")
+    idx = [i for i, r in enumerate(data["results"]) if r]
+    states = [positions_1k[i]["state"] for i in idx]
+    pc = play_config(simulation_num_per_move=data["sims"], search_threads=1)
+    s = gpu.S.Search(pc, len(states), seed=0)
+    s.set_roots(boards_tensor(gpu, states))
+    s.run_until_idle(stub_eval(gpu, data["stub"]))
+    st = s.root_stats()
+    act = s.choose(None)
+    for g, i in enumerate(idx):
+        r = data["results"][i]
+        c = int(st["counts"][g])
+        crc = zlib.crc32(st["n"][g, :c].astype(np.int32).tobytes(),
+                         zlib.crc32(st["moves"][g, :c].astype(np.uint16).tobytes())) & 0xFFFFFFFF
+        assert crc == r["crc"], states[g]
+        assert zlib.crc32(st["w"][g, :c].tobytes()) & 0xFFFFFFFF == r["w_crc"], states[g]
+        assert int(st["sum_n"][g]) == r["sum_n"] and xo.label_str(int(act[g])) == r["action"]
+    assert s.counters()["expansions"] == sum(data["results"][i]["evals"] for i in idx)
+    s.close()

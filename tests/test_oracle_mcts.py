@@ -77,6 +77,31 @@ def test_reference_history_planes():
         pl.close()
 
 
+def _visit_crc(moves, n):
+    return zlib.crc32(np.asarray(n, dtype=np.int32).tobytes(),
+                      zlib.crc32(np.asarray(moves, dtype=np.uint16).tobytes())) & 0xFFFFFFFF
+
+
+def test_reference_visit_counts_on_the_1k_suite(positions_1k):
+    """north_star: visit counts identical to the reference on the fixed 1k-position suite (one 48-simulation K = 1
+    search from every non-terminal position, recorded from the reference player)."""
+    data = _golden("mcts_1k.json")
+    res = data["results"]
+    assert len(res) == 960 and sum(1 for r in res if r) > 900      # the real-play part of the suite
+    cfg = xo.play_cfg(simulation_num_per_move=data["sims"], search_threads=1)
+    for r, pos in zip(res, positions_1k):
+        if r is None:
+            assert pos["done"][0] or not pos["moves"]
+            continue
+        pl = xo.Player(cfg, data["stub"])
+        a, _ = pl.action(pos["state"], 0, None, False, 0.5)
+        st = pl.node_stats(pos["state"])
+        assert _visit_crc(st["moves"], st["n"]) == r["crc"], pos["state"]
+        assert zlib.crc32(st["w"].tobytes()) & 0xFFFFFFFF == r["w_crc"], pos["state"]
+        assert st["sum_n"] == r["sum_n"] and a == r["action"] and pl.counters()["nn_positions"] == r["evals"]
+        pl.close()
+
+
 def test_reference_lines_with_subtree_reuse():
     data = _golden("mcts_k1.json")
     for line in data["lines"]:
