@@ -64,9 +64,94 @@ XQ_HD BoardSets board_sets(const int8_t* b)
     return t;
 }
 
-// get_legal_moves (static_env.py:256-321) into lab[0..); returns the count.  *hit = index of the first move
-// landing on `watch` (-1: none).
-XQ_HD int tpb_movegen(const int8_t* b, const BoardSets& t, uint16_t* lab, int watch, int* hit)
+// ---- divergence-free ordering of the per-lane work ---------------------------------------------------------
+// 64 lanes work on 64 different boards.  Walking each board's pieces in square order makes every lane meet a
+// different piece type in the same loop iteration, so the wave executes the union of all per-type code paths every
+// time.  Instead each lane first sorts its pieces by TYPE (packed square lists), and the move generator runs one
+// loop per type with the type a compile-time constant: all lanes execute the same specialised code.  The
+// reference's list order (by square) is restored with per-piece offsets: pass 1 counts, a prefix over the pieces in
+// square order gives each piece its offset, pass 2 emits there.
+struct TypeLists {
+    uint64_t sq[8];     // per type: up to 9 squares, 7 bits each (a side has at most 5 pieces of one type)
+    uint8_t n[8];
+    bool ok;            // false: more pieces of one type than the lists hold -> caller uses the generic path
+};
+
+XQ_HD TypeLists type_lists(const int8_t* b, Set90 side, bool negate)
+{
+    TypeLists t;
+    for (int k = 0; k < 8; ++k) { t.sq[k] = 0; t.n[k] = 0; }
+    t.ok = true;
+    for (;;) {
+        const int s = first_sq(side);
+        if (s < 0) break;
+        if (s < 64) side.lo &= side.lo - 1; else side.hi &= side.hi - 1;
+        const int p = negate ? -b[s] : b[s];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int k = 1; k < 8; ++k) {                       // predicated: no divergent indexing
+            const bool hit = p == k;
+            if (hit && t.n[k] >= 9) t.ok = false;
+            if (hit && t.n[k] < 9) { t.sq[k] |= (uint64_t)s << (7 * t.n[k]); t.n[k] += 1; }
+        }
+    }
+    return t;
+}
+
+struct PieceCounts {        // per piece (indexed by its rank in square order): move count, then list offset
+    uint64_t c[3];          // 8 bits x 24 pieces
+    XQ_HD void set(int r, uint32_t v)
+    {
+        const uint64_t m = (uint64_t)v << (8 * (r & 7));
+        if (r < 8) c[0] |= m; else if (r < 16) c[1] |= m; else c[2] |= m;
+    }
+    XQ_HD uint32_t get(int r) const
+    {
+        const uint64_t w = r < 8 ? c[0] : (r < 16 ? c[1] : c[2]);
+        return (uint32_t)(w >> (8 * (r & 7))) & 0xFFu;
+    }
+};
+
+XQ_HD int rank_of(const Set90& own, int s)
+{
+    if (s < 64) return __builtin_popcountll(own.lo & ((1ull << s) - 1ull));
+    return __builtin_popcountll(own.lo) + __builtin_popcountll(own.hi & ((1ull << (s - 64)) - 1ull));
+}
+
+// one type, all of this lane's pieces of that type.  COUNT: fill pc with the move counts; otherwise emit at pc's offsets
+template <int TYPE, bool COUNT>
+XQ_HD void tpb_type_pass(const TypeLists& tl, const BoardSets& t, PieceCounts& pc, uint16_t* lab, int watch, int* hit)
+{
+    uint64_t list = tl.sq[TYPE];
+    for (int i = 0; i < tl.n[TYPE]; ++i) {
+        const int s = (int)(list & 0x7F);
+        list >>= 7;
+        const int r = rank_of(t.own, s);
+        if (COUNT) {
+            pc.set(r, (uint32_t)gen_piece<false>(TYPE, s, t.occ, t.own, t.oking, nullptr, nullptr, 0));
+        } else {
+            int h = -1;
+            gen_piece<true>(TYPE, s, t.occ, t.own, t.oking, lab, nullptr, (int)pc.get(r), watch, &h);
+            if (h >= 0 && (*hit < 0 || h < *hit)) *hit = h;           // first in LIST order, not in type order
+        }
+    }
+}
+
+template <bool COUNT>
+XQ_HD void tpb_all_types(const TypeLists& tl, const BoardSets& t, PieceCounts& pc, uint16_t* lab, int watch, int* hit)
+{
+    tpb_type_pass<ROOK, COUNT>(tl, t, pc, lab, watch, hit);
+    tpb_type_pass<CANNON, COUNT>(tl, t, pc, lab, watch, hit);
+    tpb_type_pass<KNIGHT, COUNT>(tl, t, pc, lab, watch, hit);
+    tpb_type_pass<PAWN, COUNT>(tl, t, pc, lab, watch, hit);
+    tpb_type_pass<ELEPHANT, COUNT>(tl, t, pc, lab, watch, hit);
+    tpb_type_pass<ADVISOR, COUNT>(tl, t, pc, lab, watch, hit);
+    tpb_type_pass<KING, COUNT>(tl, t, pc, lab, watch, hit);
+}
+
+// generic (square-ordered) generator: any board, any number of pieces
+XQ_HD int tpb_movegen_generic(const int8_t* b, const BoardSets& t, uint16_t* lab, int watch, int* hit)
 {
     int n = 0;
     Set90 rest = t.own;
@@ -74,24 +159,62 @@ XQ_HD int tpb_movegen(const int8_t* b, const BoardSets& t, uint16_t* lab, int wa
         const int s = first_sq(rest);
         if (s < 0) break;
         if (s < 64) rest.lo &= rest.lo - 1; else rest.hi &= rest.hi - 1;
-        n += gen_piece<true>(b[s], s, t.occ, t.own, t.oking, lab, nullptr, n, watch, hit);   // table labels: measured faster
+        n += gen_piece<true>(b[s], s, t.occ, t.own, t.oking, lab, nullptr, n, watch, hit);
     }
     return n;
+}
+
+// get_legal_moves (static_env.py:256-321) into lab[0..); returns the count.  *hit = index of the first move
+// landing on `watch` (-1: none).
+XQ_HD int tpb_movegen(const int8_t* b, const BoardSets& t, uint16_t* lab, int watch, int* hit)
+{
+    const int np = __builtin_popcountll(t.own.lo) + __builtin_popcountll(t.own.hi);
+    const TypeLists tl = type_lists(b, t.own, false);
+    if (np > 24 || !tl.ok) return tpb_movegen_generic(b, t, lab, watch, hit);
+    PieceCounts pc{{0, 0, 0}};
+    tpb_all_types<true>(tl, t, pc, nullptr, -1, nullptr);
+    int total = 0;
+    PieceCounts off{{0, 0, 0}};
+    for (int r = 0; r < np; ++r) {                          // offsets in square order
+        const uint32_t c = pc.get(r);
+        off.set(r, (uint32_t)(total < 255 ? total : 255));
+        total += (int)c;
+    }
+    if (total > 255) return tpb_movegen_generic(b, t, lab, watch, hit);     // impossible boards only
+    tpb_all_types<false>(tl, t, off, lab, watch, hit);
+    return total;
 }
 
 // is square `target` (opponent's frame) attacked by the opponent, i.e. does get_legal_moves(fliped_state)
 // contain a move landing on it (static_env.py:61-70)
 XQ_HD bool tpb_opponent_reaches(const int8_t* b, const BoardSets& t, int target)
 {
-    Set90 opp{t.occ.lo & ~t.own.lo, t.occ.hi & ~t.own.hi};
-    const Set90 occ_r = flip_set(t.occ), own_r = flip_set(opp), oking_r = flip_set(t.mking);
-    Set90 rest = own_r;
+    const Set90 opp{t.occ.lo & ~t.own.lo, t.occ.hi & ~t.own.hi};
+    BoardSets f;                                            // the position seen by the opponent
+    f.occ = flip_set(t.occ); f.own = flip_set(opp); f.oking = flip_set(t.mking); f.mking = flip_set(t.oking);
+    const TypeLists tl = type_lists(b, opp, true);          // squares still in OUR frame
     int hit = -1;
+    if (tl.ok) {
+        // only "does any move land on target" matters: no ordering, no offsets
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int type = 1; type < 8; ++type) {
+            uint64_t list = tl.sq[type];
+            for (int i = 0; i < tl.n[type]; ++i) {
+                const int s = 89 - (int)(list & 0x7F);      // into the opponent's frame
+                list >>= 7;
+                gen_piece<false>(type, s, f.occ, f.own, f.oking, nullptr, nullptr, 0, target, &hit);
+            }
+        }
+        return hit >= 0;
+    }
+    Set90 rest = f.own;
     for (;;) {
         const int s = first_sq(rest);
         if (s < 0) break;
         if (s < 64) rest.lo &= rest.lo - 1; else rest.hi &= rest.hi - 1;
-        gen_piece<false>(-b[89 - s], s, occ_r, own_r, oking_r, nullptr, nullptr, 0, target, &hit);
+        gen_piece<false>(-b[89 - s], s, f.occ, f.own, f.oking, nullptr, nullptr, 0, target, &hit);
         if (hit >= 0) return true;
     }
     return false;
