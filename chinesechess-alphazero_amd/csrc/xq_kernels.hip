@@ -217,13 +217,31 @@ XQ_D void board_to_plane_codes(int8_t* b)
         }
 }
 
+// which (channel, position) each of this lane's five 4-element chunks starts at: the same for every board
+struct ChunkMap {
+    uint16_t cpos[5];       // channel << 8 | position
+};
+XQ_D ChunkMap make_chunk_map()
+{
+    ChunkMap m;
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        const int o = (lane_id() + 64 * it) * 4;
+        const int c = o / 90;
+        m.cpos[it] = (uint16_t)((c << 8) | (o - c * 90));
+    }
+    return m;
+}
+
 template <int DT>
-XQ_D void tpb_write_planes(const int8_t* codes, void* __restrict__ out)
+XQ_D void tpb_write_planes(const int8_t* codes, void* __restrict__ out, const ChunkMap& cm)
 {
     const int lane = lane_id();
-    for (int q = lane; q < 315; q += 64) {
-        const int o = q * 4;
-        int c = o / 90, pos = o - c * 90;
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        const int q = lane + 64 * it;
+        if (q >= 315) break;
+        int c = cm.cpos[it] >> 8, pos = cm.cpos[it] & 0xFF;
         int bit[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -257,6 +275,7 @@ __global__ __launch_bounds__(64) void k_rules_tpb(const int8_t* __restrict__ boa
     constexpr size_t esz = DT == 0 ? 4 : (DT == 3 ? 1 : 2);
     const int lane = lane_id();
     const int nblk = (n + 63) / 64;
+    const ChunkMap cm = make_chunk_map();
     for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int base = blk * 64;
         const int nb = n - base < 64 ? n - base : 64;
@@ -292,7 +311,7 @@ __global__ __launch_bounds__(64) void k_rules_tpb(const int8_t* __restrict__ boa
                 reinterpret_cast<uint32_t*>(moves + (size_t)(base + k) * MAXMOVES)[lane] = lo | (hi << 16);
             }
             if (planes)
-                tpb_write_planes<DT>(L.bd + k * TPB_BOARD_STRIDE, (char*)planes + (size_t)(base + k) * 1260 * esz);
+                tpb_write_planes<DT>(L.bd + k * TPB_BOARD_STRIDE, (char*)planes + (size_t)(base + k) * 1260 * esz, cm);
         }
         __syncthreads();
     }
