@@ -196,7 +196,9 @@ __global__ __launch_bounds__(64) void k_rules_fused(const int8_t* __restrict__ b
 // one contiguous 5760-byte run, every lane then works on its own board and writes its ordered move list into its
 // own LDS row, and the move lists / planes leave through wave-wide stores, one board at a time.
 constexpr int TPB_BOARD_STRIDE = 100;    // bytes; 25 dwords: lanes reading the same square hit 64 different banks
-constexpr int TPB_ROW_STRIDE = 130;      // uint16 per move-list row; 65 dwords: row starts fall on different banks
+constexpr int TPB_ROW_CAP = 64;          // moves a lane's LDS row holds; longer lists (rare: the mean is 40) are
+                                         // redone by k_movegen_fix, one wavefront per board
+constexpr int TPB_ROW_STRIDE = 66;       // uint16 per move-list row; 33 dwords: row starts fall on different banks
 
 struct TpbLDS {
     int8_t bd[64 * TPB_BOARD_STRIDE];
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(64) void k_rules_tpb(const int8_t* __restrict__ boa
         // 2. one board per lane
         if (lane < nb) {
             int8_t* b = L.bd + lane * TPB_BOARD_STRIDE;
-            const TpbResult r = tpb_rules(b, L.rows + lane * TPB_ROW_STRIDE, need_check != 0);
+            const TpbResult r = tpb_rules(b, L.rows + lane * TPB_ROW_STRIDE, need_check != 0, TPB_ROW_CAP);
             const int c = r.n < MAXMOVES ? r.n : MAXMOVES;
             L.cnt[lane] = (uint8_t)c;
             const int i = base + lane;
@@ -303,9 +305,10 @@ __global__ __launch_bounds__(64) void k_rules_tpb(const int8_t* __restrict__ boa
         __syncthreads();
         // 3. move lists and planes leave one board at a time, the whole wave storing contiguously
         for (int k = 0; k < nb; ++k) {
-            if (moves) {
+            if (moves && L.cnt[k] <= TPB_ROW_CAP) {          // longer lists: k_movegen_fix
                 const int c = L.cnt[k];
-                const uint32_t pair = *reinterpret_cast<const uint32_t*>(&L.rows[k * TPB_ROW_STRIDE + 2 * lane]);
+                const uint32_t pair = lane < TPB_ROW_CAP / 2
+                    ? *reinterpret_cast<const uint32_t*>(&L.rows[k * TPB_ROW_STRIDE + 2 * lane]) : 0u;
                 const uint32_t lo = (2 * lane < c) ? (pair & 0xFFFFu) : (uint32_t)NOMOVE;
                 const uint32_t hi = (2 * lane + 1 < c) ? (pair >> 16) : (uint32_t)NOMOVE;
                 reinterpret_cast<uint32_t*>(moves + (size_t)(base + k) * MAXMOVES)[lane] = lo | (hi << 16);
@@ -314,6 +317,23 @@ __global__ __launch_bounds__(64) void k_rules_tpb(const int8_t* __restrict__ boa
                 tpb_write_planes<DT>(L.bd + k * TPB_BOARD_STRIDE, (char*)planes + (size_t)(base + k) * 1260 * esz, cm);
         }
         __syncthreads();
+    }
+}
+
+// move lists longer than a row of k_rules_tpb: recomputed here, one wavefront per such board
+__global__ __launch_bounds__(64) void k_movegen_fix(const int8_t* __restrict__ boards, int n,
+                                                   uint16_t* __restrict__ moves, const uint8_t* __restrict__ counts)
+{
+    __shared__ RulesLDS w;
+    const int lane = lane_id();
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        if (counts[i] <= TPB_ROW_CAP) continue;
+        load_board(boards + (size_t)i * NSQ, w.bd[0]);
+        const int c = wave_movegen(w.bd[0], w.ml[0], w.plist);
+        uint16_t* mo = moves + (size_t)i * MAXMOVES;
+        mo[lane] = lane < c ? w.ml[0].lab[lane] : NOMOVE;
+        mo[lane + 64] = lane + 64 < c ? w.ml[0].lab[lane + 64] : NOMOVE;
+        wave_sync();
     }
 }
 
@@ -357,6 +377,7 @@ int cz_movegen(const int8_t* boards, int n, uint16_t* moves, uint8_t* counts, vo
         hipLaunchKernelGGL(k_rules_tpb<0>, dim3(grid_for_tpb(n)), dim3(64), 0, (hipStream_t)stream, boards, n, 0, moves,
                            counts, (int8_t*)nullptr, (int8_t*)nullptr, (uint16_t*)nullptr, (uint8_t*)nullptr,
                            (void*)nullptr);
+        hipLaunchKernelGGL(k_movegen_fix, dim3(grid_for(n)), dim3(64), 0, (hipStream_t)stream, boards, n, moves, counts);
         CZ_LAUNCH_CHECK("cz_movegen");
         return CZ_OK;
     }
@@ -453,6 +474,7 @@ int cz_rules_fused(const int8_t* boards, int n, uint16_t* moves, uint8_t* counts
         case CZ_U8: hipLaunchKernelGGL(k_rules_tpb<3>, g, b, 0, s, boards, n, 1, moves, counts, over, v, final_move, check, planes); break;
         default: return set_err_msg(CZ_ERR_ARG, "cz_rules_fused: unknown dtype");
         }
+        hipLaunchKernelGGL(k_movegen_fix, dim3(grid_for(n)), dim3(64), 0, s, boards, n, moves, counts);
         CZ_LAUNCH_CHECK("cz_rules_fused");
         return CZ_OK;
     }

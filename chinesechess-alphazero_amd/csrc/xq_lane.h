@@ -76,16 +76,18 @@ struct MoveSink {
     uint16_t* ft;               // may be null
     int off;
     int n;
+    int cap;                    // entries the list can hold (moves beyond it are counted but not stored)
     int watch;                  // destination square to look for (-1: none)
     int hit;                    // list index of the first move landing on `watch`, -1 if none
+    int hit_from;               // its source square
     bool formula;               // label by arithmetic instead of the 16 KB table (one board per lane: the table
                                 // gather is a dependent global load per move and there are few waves to hide it)
     XQ_HD void put(int from, int to)
     {
-        if (to == watch && hit < 0) hit = off + n;
+        if (to == watch && hit < 0) { hit = off + n; hit_from = from; }
         if (EMIT) {
             const int i = off + n;
-            if (i < MAXMOVES) {
+            if (i < cap) {
                 lab[i] = formula ? label_of_line_or_knight(from, to) : label_of(from, to);
                 if (ft) ft[i] = (uint16_t)((from << 8) | to);
             }
@@ -170,10 +172,10 @@ XQ_HD int low_bit(uint32_t v) { return __builtin_ctz(v); }            // v != 0
 template <bool EMIT>
 XQ_HD int gen_piece(int p, int s, const Set90& occ, const Set90& own, const Set90& oking,
                     uint16_t* lab, uint16_t* ft, int off, int watch = -1, int* hit = nullptr,
-                    bool formula_labels = false)
+                    bool formula_labels = false, int cap = MAXMOVES, int* hit_from = nullptr)
 {
     // advisor / elephant moves live in the literal tail of the label set: always from the table
-    MoveSink<EMIT> out{lab, ft, off, 0, watch, -1, formula_labels && p != ADVISOR && p != ELEPHANT};
+    MoveSink<EMIT> out{lab, ft, off, 0, cap, watch, -1, -1, formula_labels && p != ADVISOR && p != ELEPHANT};
     const int x = s % 9, y = s / 9;
     if (p == ROOK || p == CANNON) {                       // :288-320
         const uint32_t row = rank_bits(occ, y), col = file_bits(occ, x);
@@ -197,7 +199,7 @@ XQ_HD int gen_piece(int p, int s, const Set90& occ, const Set90& own, const Set9
         if (r < 9 && !has(own, y * 9 + r)) out.put(s, y * 9 + r);
         if (d > -1 && !has(own, d * 9 + x)) out.put(s, d * 9 + x);
         if (u < 10 && !has(own, u * 9 + x)) out.put(s, u * 9 + x);
-        if (hit && out.hit >= 0 && *hit < 0) *hit = out.hit;
+        if (hit && out.hit >= 0 && *hit < 0) { *hit = out.hit; if (hit_from) *hit_from = out.hit_from; }
         return out.n;
     }
     // stepping pieces: one table-driven loop (:264-286)
@@ -231,7 +233,7 @@ XQ_HD int gen_piece(int p, int s, const Set90& occ, const Set90& own, const Set9
         out.put(s, t);
         if (fly >= 0) out.put(s, fly);                                // once per accepted king step (:283-286)
     }
-    if (hit && out.hit >= 0 && *hit < 0) *hit = out.hit;
+    if (hit && out.hit >= 0 && *hit < 0) { *hit = out.hit; if (hit_from) *hit_from = out.hit_from; }
     return out.n;
 }
 

@@ -87,14 +87,15 @@ XQ_HD TypeLists type_lists(const int8_t* b, Set90 side, bool negate)
         if (s < 0) break;
         if (s < 64) side.lo &= side.lo - 1; else side.hi &= side.hi - 1;
         const int p = negate ? -b[s] : b[s];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int k = 1; k < 8; ++k) {                       // predicated: no divergent indexing
-            const bool hit = p == k;
-            if (hit && t.n[k] >= 9) t.ok = false;
-            if (hit && t.n[k] < 9) { t.sq[k] |= (uint64_t)s << (7 * t.n[k]); t.n[k] += 1; }
+        // predicated appends, written out per type: no divergent control flow and no dynamic register indexing
+#define XQ_TL(k)                                                                           \
+        {                                                                                      \
+            const bool hit_ = p == (k);                                                        \
+            if (hit_ && t.n[k] >= 9) t.ok = false;                                             \
+            if (hit_ && t.n[k] < 9) { t.sq[k] |= (uint64_t)s << (7 * t.n[k]); t.n[k] += 1; }  \
         }
+        XQ_TL(1) XQ_TL(2) XQ_TL(3) XQ_TL(4) XQ_TL(5) XQ_TL(6) XQ_TL(7)
+#undef XQ_TL
     }
     return t;
 }
@@ -121,7 +122,8 @@ XQ_HD int rank_of(const Set90& own, int s)
 
 // one type, all of this lane's pieces of that type.  COUNT: fill pc with the move counts; otherwise emit at pc's offsets
 template <int TYPE, bool COUNT>
-XQ_HD void tpb_type_pass(const TypeLists& tl, const BoardSets& t, PieceCounts& pc, uint16_t* lab, int watch, int* hit)
+XQ_HD void tpb_type_pass(const TypeLists& tl, const BoardSets& t, PieceCounts& pc, uint16_t* lab, int watch, int* hit,
+                         int cap, int* hit_from)
 {
     uint64_t list = tl.sq[TYPE];
     for (int i = 0; i < tl.n[TYPE]; ++i) {
@@ -131,27 +133,29 @@ XQ_HD void tpb_type_pass(const TypeLists& tl, const BoardSets& t, PieceCounts& p
         if (COUNT) {
             pc.set(r, (uint32_t)gen_piece<false>(TYPE, s, t.occ, t.own, t.oking, nullptr, nullptr, 0));
         } else {
-            int h = -1;
-            gen_piece<true>(TYPE, s, t.occ, t.own, t.oking, lab, nullptr, (int)pc.get(r), watch, &h);
-            if (h >= 0 && (*hit < 0 || h < *hit)) *hit = h;           // first in LIST order, not in type order
+            int h = -1, hf = -1;
+            gen_piece<true>(TYPE, s, t.occ, t.own, t.oking, lab, nullptr, (int)pc.get(r), watch, &h, false, cap, &hf);
+            if (h >= 0 && (*hit < 0 || h < *hit)) { *hit = h; *hit_from = hf; }   // first in LIST order, not in type order
         }
     }
 }
 
 template <bool COUNT>
-XQ_HD void tpb_all_types(const TypeLists& tl, const BoardSets& t, PieceCounts& pc, uint16_t* lab, int watch, int* hit)
+XQ_HD void tpb_all_types(const TypeLists& tl, const BoardSets& t, PieceCounts& pc, uint16_t* lab, int watch, int* hit,
+                         int cap, int* hit_from)
 {
-    tpb_type_pass<ROOK, COUNT>(tl, t, pc, lab, watch, hit);
-    tpb_type_pass<CANNON, COUNT>(tl, t, pc, lab, watch, hit);
-    tpb_type_pass<KNIGHT, COUNT>(tl, t, pc, lab, watch, hit);
-    tpb_type_pass<PAWN, COUNT>(tl, t, pc, lab, watch, hit);
-    tpb_type_pass<ELEPHANT, COUNT>(tl, t, pc, lab, watch, hit);
-    tpb_type_pass<ADVISOR, COUNT>(tl, t, pc, lab, watch, hit);
-    tpb_type_pass<KING, COUNT>(tl, t, pc, lab, watch, hit);
+    tpb_type_pass<ROOK, COUNT>(tl, t, pc, lab, watch, hit, cap, hit_from);
+    tpb_type_pass<CANNON, COUNT>(tl, t, pc, lab, watch, hit, cap, hit_from);
+    tpb_type_pass<KNIGHT, COUNT>(tl, t, pc, lab, watch, hit, cap, hit_from);
+    tpb_type_pass<PAWN, COUNT>(tl, t, pc, lab, watch, hit, cap, hit_from);
+    tpb_type_pass<ELEPHANT, COUNT>(tl, t, pc, lab, watch, hit, cap, hit_from);
+    tpb_type_pass<ADVISOR, COUNT>(tl, t, pc, lab, watch, hit, cap, hit_from);
+    tpb_type_pass<KING, COUNT>(tl, t, pc, lab, watch, hit, cap, hit_from);
 }
 
 // generic (square-ordered) generator: any board, any number of pieces
-XQ_HD int tpb_movegen_generic(const int8_t* b, const BoardSets& t, uint16_t* lab, int watch, int* hit)
+XQ_HD int tpb_movegen_generic(const int8_t* b, const BoardSets& t, uint16_t* lab, int watch, int* hit, int cap,
+                              int* hit_from)
 {
     int n = 0;
     Set90 rest = t.own;
@@ -159,20 +163,20 @@ XQ_HD int tpb_movegen_generic(const int8_t* b, const BoardSets& t, uint16_t* lab
         const int s = first_sq(rest);
         if (s < 0) break;
         if (s < 64) rest.lo &= rest.lo - 1; else rest.hi &= rest.hi - 1;
-        n += gen_piece<true>(b[s], s, t.occ, t.own, t.oking, lab, nullptr, n, watch, hit);
+        n += gen_piece<true>(b[s], s, t.occ, t.own, t.oking, lab, nullptr, n, watch, hit, false, cap, hit_from);
     }
     return n;
 }
 
-// get_legal_moves (static_env.py:256-321) into lab[0..); returns the count.  *hit = index of the first move
-// landing on `watch` (-1: none).
-XQ_HD int tpb_movegen(const int8_t* b, const BoardSets& t, uint16_t* lab, int watch, int* hit)
+// get_legal_moves (static_env.py:256-321) into lab[0..cap); returns the count (moves beyond cap are counted, not
+// stored).  *hit = index of the first move landing on `watch` (-1: none), *hit_from its source square.
+XQ_HD int tpb_movegen(const int8_t* b, const BoardSets& t, uint16_t* lab, int watch, int* hit, int cap, int* hit_from)
 {
     const int np = __builtin_popcountll(t.own.lo) + __builtin_popcountll(t.own.hi);
     const TypeLists tl = type_lists(b, t.own, false);
-    if (np > 24 || !tl.ok) return tpb_movegen_generic(b, t, lab, watch, hit);
+    if (np > 24 || !tl.ok) return tpb_movegen_generic(b, t, lab, watch, hit, cap, hit_from);
     PieceCounts pc{{0, 0, 0}};
-    tpb_all_types<true>(tl, t, pc, nullptr, -1, nullptr);
+    tpb_all_types<true>(tl, t, pc, nullptr, -1, nullptr, cap, nullptr);
     int total = 0;
     PieceCounts off{{0, 0, 0}};
     for (int r = 0; r < np; ++r) {                          // offsets in square order
@@ -180,9 +184,20 @@ XQ_HD int tpb_movegen(const int8_t* b, const BoardSets& t, uint16_t* lab, int wa
         off.set(r, (uint32_t)(total < 255 ? total : 255));
         total += (int)c;
     }
-    if (total > 255) return tpb_movegen_generic(b, t, lab, watch, hit);     // impossible boards only
-    tpb_all_types<false>(tl, t, off, lab, watch, hit);
+    if (total > 255) return tpb_movegen_generic(b, t, lab, watch, hit, cap, hit_from);     // impossible boards only
+    tpb_all_types<false>(tl, t, off, lab, watch, hit, cap, hit_from);
     return total;
+}
+
+template <int TYPE>
+XQ_HD void reach_type(const TypeLists& tl, const BoardSets& f, int target, int* hit)
+{
+    uint64_t list = tl.sq[TYPE];
+    for (int i = 0; i < tl.n[TYPE]; ++i) {
+        const int s = 89 - (int)(list & 0x7F);              // the lists hold squares of OUR frame
+        list >>= 7;
+        gen_piece<false>(TYPE, s, f.occ, f.own, f.oking, nullptr, nullptr, 0, target, hit);
+    }
 }
 
 // is square `target` (opponent's frame) attacked by the opponent, i.e. does get_legal_moves(fliped_state)
@@ -195,18 +210,14 @@ XQ_HD bool tpb_opponent_reaches(const int8_t* b, const BoardSets& t, int target)
     const TypeLists tl = type_lists(b, opp, true);          // squares still in OUR frame
     int hit = -1;
     if (tl.ok) {
-        // only "does any move land on target" matters: no ordering, no offsets
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int type = 1; type < 8; ++type) {
-            uint64_t list = tl.sq[type];
-            for (int i = 0; i < tl.n[type]; ++i) {
-                const int s = 89 - (int)(list & 0x7F);      // into the opponent's frame
-                list >>= 7;
-                gen_piece<false>(type, s, f.occ, f.own, f.oking, nullptr, nullptr, 0, target, &hit);
-            }
-        }
+        // only "does any move land on target" matters: no ordering, no offsets; one specialised loop per type
+        reach_type<ROOK>(tl, f, target, &hit);
+        reach_type<CANNON>(tl, f, target, &hit);
+        reach_type<KNIGHT>(tl, f, target, &hit);
+        reach_type<PAWN>(tl, f, target, &hit);
+        reach_type<ELEPHANT>(tl, f, target, &hit);
+        reach_type<ADVISOR>(tl, f, target, &hit);
+        reach_type<KING>(tl, f, target, &hit);
         return hit >= 0;
     }
     Set90 rest = f.own;
@@ -226,13 +237,13 @@ struct TpbResult {
 };
 
 // done(state, need_check) + the position's move list (static_env.py:14-77)
-XQ_HD TpbResult tpb_rules(const int8_t* b, uint16_t* lab, bool need_check)
+XQ_HD TpbResult tpb_rules(const int8_t* b, uint16_t* lab, bool need_check, int cap = MAXMOVES)
 {
     TpbResult r{0, 0, 0, NOMOVE, 0};
     const BoardSets t = board_sets(b);
     const int rk = last_sq(t.mking), bk = last_sq(t.oking);      // scan order: the last king found wins
-    int hit = -1;
-    r.n = tpb_movegen(b, t, lab, bk, &hit);
+    int hit = -1, hit_from = -1;
+    r.n = tpb_movegen(b, t, lab, bk, &hit, cap, &hit_from);
     if (bk < 0) { r.over = 1; r.v = 1; return r; }               // 's' not in state
     if (rk < 0) { r.over = 1; r.v = -1; return r; }              // 'S' not in state
     const int rx = rk % 9, ry = rk / 9, bx = bk % 9, by = bk / 9;
@@ -244,7 +255,7 @@ XQ_HD TpbResult tpb_rules(const int8_t* b, uint16_t* lab, bool need_check)
         for (int y = ry + 1; y < by; ++y) blocked = blocked || has(t.occ, y * 9 + rx);
         if (!blocked) { r.v = 1; winner = 1; }
     }
-    if (!winner && hit >= 0) { winner = 1; r.v = 1; r.final_move = lab[hit < MAXMOVES ? hit : 0]; }   // :52-60
+    if (!winner && hit >= 0) { winner = 1; r.v = 1; r.final_move = label_of(hit_from, bk); }         // :52-60
     if (!winner && need_check) r.check = tpb_opponent_reaches(b, t, 89 - rk) ? 1 : 0;              // :61-73
     r.over = winner != 0;
     return r;

@@ -192,3 +192,19 @@ def test_string_facade(nat, known_answers):
     assert senv.has_attack_chessman(senv.INIT_STATE)
     with pytest.raises(ValueError):
         senv.step(senv.INIT_STATE, '4445')
+
+
+def test_long_move_lists_in_large_batches(nat):
+    """Boards with more than 64 moves (longer than an LDS row of the lane-per-board kernel) inside a large batch:
+    the fix-up pass must deliver the complete ordered list."""
+    N, torch = nat
+    long_states = ['3s5/9/9/2K3K2/R7R/1C5C1/P1P1P1P1P/9/9/4S4', '4s4/9/4P4/R7R/1C2K2C1/2K6/P1P3P1P/9/9/4S4']
+    states = ([xo.INIT_STATE] * 5 + long_states) * 60            # 420 boards: the lane-per-board path
+    boards = np.stack([xo.state_to_board(s) for s in states])
+    exp = xo.batch_rules(boards)
+    assert exp["counts"].max() > 64
+    got = {k: v.cpu().numpy() for k, v in N.rules_fused(torch.from_numpy(boards).cuda(), N.F32).items()}
+    for k in ("moves", "counts", "over", "v", "final_move", "check", "planes"):
+        assert (got[k] == exp[k]).all(), k
+    mv, ct = N.movegen(torch.from_numpy(boards).cuda())
+    assert (mv.cpu().numpy() == exp["moves"]).all() and (ct.cpu().numpy() == exp["counts"]).all()
