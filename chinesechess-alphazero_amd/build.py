@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libczero.so")
-SOURCES = ["xq_kernels.hip", "xq_search.hip", "xq_nn_epilogue.hip"]
+SOURCES = ["xq_kernels.hip", "xq_search.hip", "xq_nn_epilogue.hip", "xq_conv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off",          # PUCT / backup arithmetic must not be fused (bit-parity with the reference)
          "-fno-fast-math"]

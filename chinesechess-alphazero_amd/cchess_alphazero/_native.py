@@ -56,6 +56,15 @@ def _declare(L):
     if hasattr(L, "cz_bias_act"):
         L.cz_bias_act.argtypes = [vp, vp, vp, C.c_size_t, i32, i32, i32, vp]
         L.cz_bias_act.restype = i32
+    if hasattr(L, "cz_conv3x3"):
+        L.cz_conv3x3.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+        L.cz_conv3x3.restype = i32
+        L.cz_conv3x3_packed_elems.argtypes = [i32, i32]
+        L.cz_conv3x3_packed_elems.restype = C.c_size_t
+        L.cz_conv3x3_pack_weights.argtypes = [vp, i32, i32, i32, vp]
+        L.cz_conv3x3_pack_weights.restype = i32
+        L.cz_split_bias_act.argtypes = [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, vp]
+        L.cz_split_bias_act.restype = i32
     for name in ("cz_label_tables", "cz_movegen", "cz_done", "cz_step", "cz_encode", "cz_check_or_catch",
                  "cz_be_catched", "cz_has_attack", "cz_rules_fused"):
         getattr(L, name).restype = i32
@@ -199,6 +208,62 @@ def bias_act_(x, bias, residual=None, relu=True):
                             C.c_void_p(residual.data_ptr()) if residual is not None else None,
                             x.numel(), c, _DT_CODE[x.dtype], int(relu), _stream()), "cz_bias_act")
     return x
+
+
+def _dt_code(dtype):
+    import torch
+    global _DT_CODE
+    if _DT_CODE is None:
+        _DT_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+    return _DT_CODE[dtype]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def pack_conv3x3_weights(w_oihw, dtype, parts):
+    """fp32 [C, C, 3, 3] filter (any device) -> packed 2-byte tensor in MFMA fragment order, on the CPU
+    (cz_conv3x3_pack_weights runs on the host); move it to the GPU with .cuda()."""
+    import torch
+    w = w_oihw.detach().to("cpu", torch.float32).contiguous()
+    c = w.shape[0]
+    assert tuple(w.shape) == (c, c, 3, 3)
+    n = lib().cz_conv3x3_packed_elems(c, parts)
+    if n == 0:
+        raise NativeError(f"cz_conv3x3: unsupported channels={c} parts={parts}")
+    out = torch.empty((n,), dtype=dtype)
+    check(lib().cz_conv3x3_pack_weights(_ptr(w), c, _dt_code(dtype), parts, _ptr(out)), "cz_conv3x3_pack_weights")
+    return out
+
+
+def conv3x3(x, w_packed, bias, skip=None, out=None, out_f32=None, relu=True):
+    """Trunk convolution on the hand-written MFMA kernel (csrc/xq_conv.hip).
+    x, skip, out: tuples (hi,) or (hi, lo) of [N, 90, C] bf16/fp16 tensors; bias fp32 [C];
+    out_f32: fp32 [N, 90, C] tensor to receive the result instead of `out`."""
+    require_gpu()
+    parts = len(x)
+    xh = x[0]
+    n, c = xh.shape[0], xh.shape[-1]
+    xl = x[1] if parts == 2 else None
+    sh = skip[0] if skip is not None else None
+    sl = skip[1] if skip is not None and parts == 2 else None
+    yh = out[0] if out is not None else None
+    yl = out[1] if out is not None and parts == 2 else None
+    check(lib().cz_conv3x3(_ptr(xh), _ptr(xl), _ptr(w_packed), _ptr(bias), _ptr(sh), _ptr(sl), _ptr(yh), _ptr(yl),
+                           _ptr(out_f32), n, c, _dt_code(xh.dtype), parts, int(relu), _stream()), "cz_conv3x3")
+    return out_f32 if out_f32 is not None else out
+
+
+def split_bias_act(x, bias, out, relu=True):
+    """fp32 [..., C] activation -> relu(x + bias) as a (hi,) or (hi, lo) operand pair (tensors in `out`)."""
+    require_gpu()
+    parts = len(out)
+    c = x.shape[-1] if bias is None else bias.numel()
+    check(lib().cz_split_bias_act(_ptr(x), _ptr(bias), _ptr(out[0]), _ptr(out[1]) if parts == 2 else None,
+                                  x.numel(), c, _dt_code(out[0].dtype), parts, int(relu), _stream()),
+          "cz_split_bias_act")
+    return out
 
 
 def rules_fused(boards, dtype=F32, out=None):

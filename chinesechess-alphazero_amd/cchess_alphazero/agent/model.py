@@ -98,14 +98,23 @@ def _fold(conv, bn):
 
 class InferenceNet(nn.Module):
     """Eval-mode network for self-play: BN folded, channels_last, optional reduced precision.
-    Outputs are always fp32: softmax policy [B, 2086] and value [B]."""
+    Outputs are always fp32: softmax policy [B, 2086] and value [B].
 
-    def __init__(self, net: CChessNet, dtype=torch.float32):
+    trunk="library": the residual tower runs in MIOpen (+ the hand-written bias/skip/ReLU pass).
+    trunk="mfma":    the tower's 3x3 convolutions run on the hand-written MFMA kernel (csrc/xq_conv.hip) with the
+                     epilogue fused.  With dtype=float32 the operands are (hi, lo) bf16 pairs -- three bf16 MFMAs per
+                     product, fp32 accumulate, fp32-class results (policy / value within 1e-4 of the fp32 network) --
+                     with bf16 / fp16 they are plain 2-byte operands."""
+
+    def __init__(self, net: CChessNet, dtype=torch.float32, trunk="library"):
         super().__init__()
         net = net.eval()
+        assert trunk in ("library", "mfma")
         self.dtype = dtype
+        self.trunk = trunk
         self.fused_epilogue = True          # on the GPU: hand-written bias + skip + ReLU pass after each conv
         self.input_depth = net.cfg["input_depth"]
+        self.filters = net.cfg["cnn_filter_num"]
         with torch.no_grad():
             self.input_conv = _fold(net.input_conv, net.input_bn)
             self.res = nn.ModuleList()
@@ -119,11 +128,77 @@ class InferenceNet(nn.Module):
             self.policy_out.load_state_dict(net.policy_out.state_dict())
             self.value_dense.load_state_dict(net.value_dense.state_dict())
             self.value_out.load_state_dict(net.value_out.state_dict())
+            packed = self._pack_trunk() if trunk == "mfma" else None
         self.to(dtype)
         self.to(memory_format=torch.channels_last)
+        if packed is not None:
+            # registered after the dtype conversion: packed filters are raw 2-byte MFMA operands (kept as int16 so
+            # that no later .to(dtype) can reinterpret them), biases stay fp32
+            for i, (w1, b1, w2, b2) in enumerate(packed):
+                self.register_buffer(f"tw{i}a", w1.view(torch.int16))
+                self.register_buffer(f"tb{i}a", b1)
+                self.register_buffer(f"tw{i}b", w2.view(torch.int16))
+                self.register_buffer(f"tb{i}b", b2)
+            self.register_buffer("in_bias32", self.input_conv.bias.detach().float().clone())
+        self._bufs = {}
         self.eval()
         for p in self.parameters():
             p.requires_grad_(False)
+
+    # ---- hand-written trunk ----
+    @property
+    def parts(self):
+        return 2 if self.dtype == torch.float32 else 1
+
+    @property
+    def operand_dtype(self):
+        return torch.bfloat16 if self.dtype == torch.float32 else self.dtype
+
+    def _pack_trunk(self):
+        """fp32 folded filters -> MFMA fragment order (cz_conv3x3_pack_weights); called before the dtype conversion."""
+        from cchess_alphazero import _native
+        out = []
+        for c1, c2 in self.res:
+            out.append((_native.pack_conv3x3_weights(c1.weight, self.operand_dtype, self.parts),
+                        c1.bias.detach().float().clone(),
+                        _native.pack_conv3x3_weights(c2.weight, self.operand_dtype, self.parts),
+                        c2.bias.detach().float().clone()))
+        return out
+
+    def _operands(self, n, device):
+        """Three rotating activation buffers ([n, 90, C] per part) + the fp32 output of the last layer."""
+        key = (n, str(device))
+        if key not in self._bufs:
+            od, c = self.operand_dtype, self.filters
+            bufs = [tuple(torch.empty((n, 90, c), dtype=od, device=device) for _ in range(self.parts))
+                    for _ in range(3)]
+            last = torch.empty((n, 90, c), dtype=torch.float32 if self.parts == 2 else od, device=device)
+            self._bufs = {key: (bufs, last)}              # one batch size at a time (the evaluation queue)
+        return self._bufs[key]
+
+    def _trunk_mfma(self, x):
+        from cchess_alphazero import _native
+        n, c = x.shape[0], self.filters
+        y = F.conv2d(x, self.input_conv.weight, None, self.input_conv.stride, self.input_conv.padding)
+        y = y.contiguous(memory_format=torch.channels_last)          # memory [n, 10, 9, c]
+        (cur, tmp, nxt), last = self._operands(n, x.device)
+        if self.parts == 2:
+            _native.split_bias_act(y, self.in_bias32, cur)
+        else:
+            cur = (_native.bias_act_(y, self.input_conv.bias).permute(0, 2, 3, 1).reshape(n, 90, c),)
+        nblk = len(self.res)
+        for i in range(nblk):
+            w1 = getattr(self, f"tw{i}a").view(self.operand_dtype)
+            w2 = getattr(self, f"tw{i}b").view(self.operand_dtype)
+            _native.conv3x3(cur, w1, getattr(self, f"tb{i}a"), out=tmp)
+            if i + 1 < nblk:
+                _native.conv3x3(tmp, w2, getattr(self, f"tb{i}b"), skip=cur, out=nxt)
+                cur, nxt = nxt, cur
+            elif self.parts == 2:
+                _native.conv3x3(tmp, w2, getattr(self, f"tb{i}b"), skip=cur, out_f32=last)
+            else:
+                _native.conv3x3(tmp, w2, getattr(self, f"tb{i}b"), skip=cur, out=(last,))
+        return last.view(n, 10, 9, c).permute(0, 3, 1, 2)                # logical NCHW over channels-last memory
 
     def _trunk_fused(self, x):
         """Trunk with the hand-written epilogue (csrc/xq_nn_epilogue.hip): every convolution is followed by ONE
@@ -142,7 +217,11 @@ class InferenceNet(nn.Module):
     @torch.no_grad()
     def forward(self, planes):
         x = planes.to(self.dtype).contiguous(memory_format=torch.channels_last)
-        if x.is_cuda and self.fused_epilogue and self.input_conv.out_channels % 8 == 0:
+        if self.trunk == "mfma":
+            if not x.is_cuda:
+                raise RuntimeError("trunk='mfma' is the hand-written HIP path: it has no CPU implementation")
+            x = self._trunk_mfma(x)
+        elif x.is_cuda and self.fused_epilogue and self.input_conv.out_channels % 8 == 0:
             x = self._trunk_fused(x)
         else:
             x = F.relu(self.input_conv(x))

@@ -67,6 +67,7 @@ class EngineConfig(_Section):
         super().__init__(games_per_gpu=4096,      # concurrent games = wavefronts per GPU
                          sims_per_round=None,     # lock-step batch per game; None = play.search_threads
                          net_dtype="float32",     # float32 (reference precision) | bfloat16 | float16
+                         net_trunk="mfma",        # mfma (hand-written convolution kernel) | library (MIOpen)
                          node_capacity=0, edge_capacity=0, max_depth=0,
                          use_hip_graph=False, base_seed=0, report_every_rounds=200,
                          max_rounds=None, max_games=None)   # None = run forever, like the reference

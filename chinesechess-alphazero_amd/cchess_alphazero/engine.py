@@ -35,10 +35,11 @@ def bytes_per_expansion(mean_depth, mean_edges, mean_leaf_moves):
 class SelfPlayEngine:
     def __init__(self, config, n_games, net=None, dtype=torch.float32, device=None, seed=0,
                  node_capacity=0, edge_capacity=0, max_depth=0, sims_per_round=None, evaluator=None,
-                 use_history=False):
+                 use_history=False, trunk=None):
         """config: the reference's Config object (config.play.* / config.model.* are read).
         net: a CChessNet (random-init if None).  evaluator: optional callable planes -> (policy, value)
-        replacing the network (tests)."""
+        replacing the network (tests).  trunk: "mfma" (hand-written convolution kernel, the default where the
+        filter count allows) or "library" (MIOpen), see agent/model.py InferenceNet."""
         _native.require_gpu()
         self.config = config
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -55,7 +56,12 @@ class SelfPlayEngine:
                 torch.manual_seed(0)
                 net = CChessNet.from_model_config(config.model)
             self.model_cfg = net.cfg
-            self.net = InferenceNet(net, dtype).to(self.device)
+            if trunk is None:
+                trunk = getattr(getattr(config, "engine", None), "net_trunk", "mfma")
+            if net.cfg["cnn_filter_num"] not in (32, 128, 256):
+                trunk = "library"
+            self.trunk = trunk
+            self.net = InferenceNet(net, dtype, trunk=trunk).to(self.device)
         self.rounds = 0
         self.seed = seed
         self._graph = None

@@ -171,6 +171,31 @@ int cz_search_drain_records(cz_search* s, unsigned int* cursor, void* host_buf, 
 int cz_bias_act(void* x, const void* bias, const void* residual, size_t n_elems, int channels, int dtype,
                 int relu, void* stream);
 
+/* ---- trunk convolution (hand-written MFMA kernel, csrc/xq_conv.hip) -------------------------------------------
+ * Replaces Conv2D(F, 3, padding="same") -> BatchNorm -> (+ skip) -> ReLU of the residual tower
+ * (agent/model.py:40-83, BatchNorm folded into w / bias) on channels-last 10x9 boards:
+ *   y[n][pix][o] = act( sum_{ky,kx,c} w[o][c][ky][kx] * x[n][pix + (ky-1, kx-1)][c] + bias[o] (+ skip[n][pix][o]) )
+ * Activations are [n_boards][90][channels] arrays of 2-byte elements (dtype CZ_BF16 or CZ_F16); fp32 accumulate.
+ *   parts = 1: plain bf16 / fp16 operands (x_lo, skip_lo, y_lo unused).
+ *   parts = 2: "split" operands -- every value is a pair hi + lo (lo = value - hi rounded again) and the kernel
+ *              accumulates hi*hi + hi*lo + lo*hi: fp32-class results (product error ~2^-17) from three
+ *              bf16 MFMAs.  Outputs are re-split into (y_hi, y_lo).
+ * y_f32 != NULL: write the fp32 result there instead of y_hi / y_lo (last trunk layer, feeds the heads).
+ * w_packed: device copy of what cz_conv3x3_pack_weights produced for the same channels / dtype / parts.
+ * channels in {32, 128, 256}.  skip_hi may be NULL (no residual). */
+int cz_conv3x3(const void* x_hi, const void* x_lo, const void* w_packed, const float* bias, const void* skip_hi,
+               const void* skip_lo, void* y_hi, void* y_lo, float* y_f32, int n_boards, int channels, int dtype,
+               int parts, int relu, void* stream);
+/* number of 2-byte elements of the packed filter (all parts, including the prefetch padding); 0 = bad argument */
+size_t cz_conv3x3_packed_elems(int channels, int parts);
+/* HOST: w_oihw[channels][channels][3][3] fp32 -> MFMA fragment order, split into parts; out_host holds
+ * cz_conv3x3_packed_elems() elements */
+int cz_conv3x3_pack_weights(const float* w_oihw, int channels, int dtype, int parts, void* out_host);
+/* fp32 activation x[rows][channels] (+ bias[c], may be NULL) -> ReLU? -> (y_hi, y_lo) operand pair (parts = 2) or
+ * a plain bf16 / fp16 copy (parts = 1).  Used after the 5x5 input convolution. */
+int cz_split_bias_act(const float* x, const float* bias, void* y_hi, void* y_lo, size_t n_elems, int channels,
+                      int dtype, int parts, int relu, void* stream);
+
 /* test hook: y[i] = sqrt((double)(x[i] + 1)) exactly as the PUCT kernel computes it */
 int cz_debug_sqrt(const int32_t* x, double* y, int n, void* stream);
 

@@ -1,0 +1,153 @@
+"""-m gpu: the hand-written MFMA trunk convolution (csrc/xq_conv.hip) through the C-ABI (cz_conv3x3,
+cz_conv3x3_pack_weights, cz_split_bias_act) against a plain PyTorch float64 reference of the same op, and the whole
+policy/value network with trunk="mfma" against the plain fp32 PyTorch module.
+
+Tolerances (floating point, stated here as the contract asks):
+  * split mode (parts = 2, the fp32 network): the kernel sees operands hi + lo with |x - hi - lo| <= 2^-17 |x| and
+    drops the lo*lo product, so each product carries <= ~3 * 2^-17 relative error; accumulation is fp32.
+    Against the float64 convolution OF THE SAME (hi + lo) OPERANDS: max |err| <= 2e-5 * max|y|.
+  * plain bf16 / fp16: the only difference to the float64 reference on the same rounded operands is fp32
+    accumulation and the final rounding of the result to 2 bytes: <= 2^-8 (bf16) / 2^-10 (fp16) relative.
+  * whole network, split mode: policy and value within 1e-4 of the fp32 module (north_star tolerance).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _split(t, dtype, parts):
+    hi = t.to(dtype)
+    return (hi,) if parts == 1 else (hi, (t - hi.float()).to(dtype))
+
+
+def _reference(x, w, b, skip, relu):
+    import torch
+    import torch.nn.functional as F
+    n, _, c = x.shape
+    y = F.conv2d(x.double().view(n, 10, 9, c).permute(0, 3, 1, 2), w.double(), b.double(), padding=1)
+    y = y.permute(0, 2, 3, 1).reshape(n, 90, c)
+    if skip is not None:
+        y = y + skip.double()
+    return torch.relu(y) if relu else y
+
+
+CASES = [(128, "bfloat16", 2), (128, "bfloat16", 1), (128, "float16", 1), (32, "bfloat16", 2), (32, "float16", 1),
+         (256, "float16", 1), (256, "bfloat16", 2)]
+
+
+@pytest.mark.parametrize("c,dt,parts", CASES)
+@pytest.mark.parametrize("n", [1, 2, 7, 64])
+def test_conv3x3_against_float64(c, dt, parts, n):
+    import torch
+    from cchess_alphazero import _native
+    dtype = getattr(torch, dt)
+    g = torch.Generator(device="cuda").manual_seed(1000 * c + n)
+    x = torch.randn((n, 90, c), device="cuda", generator=g).relu()
+    sk = torch.randn((n, 90, c), device="cuda", generator=g)
+    w = torch.randn((c, c, 3, 3), device="cuda", generator=g) / (3.0 * c ** 0.5)
+    b = torch.randn((c,), device="cuda", generator=g)
+    wp = _native.pack_conv3x3_weights(w, dtype, parts).cuda()
+    xs, ss = _split(x, dtype, parts), _split(sk, dtype, parts)
+    x_eff, s_eff = sum(t.double() for t in xs), sum(t.double() for t in ss)
+    w_eff = w if parts == 2 else w.to(dtype).float()
+    rel = 2e-5 if parts == 2 else (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10)
+    for skip, relu, f32out in ((None, True, False), (ss, True, False), (ss, False, True), (None, False, False)):
+        out = tuple(torch.full((n, 90, c), 7.0, device="cuda", dtype=dtype) for _ in range(parts))
+        of = torch.full((n, 90, c), 7.0, device="cuda") if f32out else None
+        _native.conv3x3(xs, wp, b, skip=skip, out=None if f32out else out, out_f32=of, relu=relu)
+        got = of.double() if f32out else sum(o.double() for o in out)
+        ref = _reference(x_eff, w_eff, b, s_eff if skip is not None else None, relu)
+        tol = (2e-5 if f32out else rel) * ref.abs().max().item()
+        assert (got - ref).abs().max().item() <= tol, (c, dt, parts, n, skip is not None, relu, f32out)
+
+
+def test_conv3x3_identity_filter_is_a_shift():
+    """Asymmetric known answer: a filter that copies input channel (o + 1) % C of the pixel one step up-left
+    (ky = 0, kx = 0) must reproduce the shifted board exactly, with zeros where the tap leaves the board."""
+    import torch
+    from cchess_alphazero import _native
+    c, n = 128, 3
+    x = torch.arange(n * 90 * c, device="cuda", dtype=torch.float32).reshape(n, 90, c) % 251 - 125.0   # exact in bf16
+    w = torch.zeros((c, c, 3, 3), device="cuda")
+    for o in range(c):
+        w[o, (o + 1) % c, 0, 0] = 1.0
+    wp = _native.pack_conv3x3_weights(w, torch.bfloat16, 1).cuda()
+    out = (torch.empty((n, 90, c), device="cuda", dtype=torch.bfloat16),)
+    _native.conv3x3((x.to(torch.bfloat16),), wp, torch.zeros(c, device="cuda"), out=out, relu=False)
+    want = torch.zeros((n, 10, 9, c), device="cuda")
+    want[:, 1:, 1:, :] = x.view(n, 10, 9, c)[:, :-1, :-1, :].roll(-1, dims=3)
+    assert torch.equal(out[0].float().view(n, 10, 9, c), want)
+
+
+def test_split_bias_act():
+    import torch
+    from cchess_alphazero import _native
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((11, 90, 128), device="cuda", generator=g) * 3
+    b = torch.randn((128,), device="cuda", generator=g)
+    out = tuple(torch.empty((11, 90, 128), device="cuda", dtype=torch.bfloat16) for _ in range(2))
+    _native.split_bias_act(x, b, out, relu=True)
+    want = torch.relu(x + b)
+    hi = want.to(torch.bfloat16)
+    assert torch.equal(out[0], hi) and torch.equal(out[1], (want - hi.float()).to(torch.bfloat16))
+    assert ((out[0].double() + out[1].double()) - want.double()).abs().max() <= 2.0 ** -16 * want.abs().max()
+
+
+def test_pack_weights_layout_and_errors():
+    import torch
+    from cchess_alphazero import _native
+    w = torch.randn(128, 128, 3, 3)
+    p = _native.pack_conv3x3_weights(w, torch.bfloat16, 2)
+    kk_n, ct_n = 8, 4
+    part = (9 * kk_n + 3) * ct_n * 64 * 8
+    assert p.numel() == 2 * part
+    hi = p[:part].view(9 * kk_n + 3, ct_n, 64, 8)
+    lo = p[part:].view(9 * kk_n + 3, ct_n, 64, 8)
+    for tap, kk, ct, lane, j in ((0, 0, 0, 0, 0), (5, 3, 2, 45, 6), (8, 7, 3, 63, 7)):
+        o, ci = ct * 32 + (lane & 31), kk * 16 + (lane >> 5) * 8 + j
+        v = w[o, ci, tap // 3, tap % 3]
+        assert hi[tap * kk_n + kk, ct, lane, j] == v.to(torch.bfloat16)
+        assert lo[tap * kk_n + kk, ct, lane, j] == (v - v.to(torch.bfloat16).float()).to(torch.bfloat16)
+    assert hi[72:].abs().sum() == 0                      # prefetch padding
+    with pytest.raises(_native.NativeError):
+        _native.pack_conv3x3_weights(torch.randn(48, 48, 3, 3), torch.bfloat16, 2)
+    with pytest.raises(_native.NativeError):
+        x = (torch.zeros((1, 90, 64), device="cuda", dtype=torch.bfloat16),)
+        _native.conv3x3(x, p.cuda(), torch.zeros(64, device="cuda"), out=x)
+
+
+@pytest.mark.parametrize("filters,blocks", [(128, 7), (32, 2)])
+def test_network_with_mfma_trunk_matches_fp32_module(filters, blocks):
+    """The whole policy/value network with the hand-written split-precision trunk against the plain PyTorch fp32
+    module (CPU): policy and value within 1e-4 (north_star tolerance)."""
+    import torch
+    from cchess_alphazero.agent.model import CChessNet, InferenceNet
+    import oracle.xq_oracle as xo
+    torch.manual_seed(11)
+    net = CChessNet(cnn_filter_num=filters, res_layer_num=blocks)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.normal_(1, 0.2)
+            m.bias.data.normal_(0, 0.2)
+    net.eval()
+    states = [xo.INIT_STATE, '3s5/4m4/9/9/4p4/2R6/9/4C4/4M4/3MS4', 'rkemsmek1/8r/1c5c1/p1p1p1p1p/9/9/P1P1P1P1P/1C2C4/9/RKEMSMEKR']
+    boards = np.stack([xo.state_to_board(s) for s in states] * 4 + [xo.state_to_board(states[0])])
+    x = torch.from_numpy(np.stack([xo.planes_board(b) for b in boards]))
+    with torch.no_grad():
+        p_ref, v_ref = net(x)
+    inf = InferenceNet(net, torch.float32, trunk="mfma").cuda()
+    p, v = inf(x.cuda())
+    assert (p.cpu() - p_ref).abs().max().item() < 1e-4
+    assert (v.cpu() - v_ref).abs().max().item() < 1e-4
+    lib = InferenceNet(net, torch.float32, trunk="library").cuda()
+    p2, v2 = lib(x.cuda())
+    assert (p - p2).abs().max().item() < 1e-4 and (v - v2).abs().max().item() < 1e-4
+    for dt, tol in ((torch.bfloat16, 3e-2), (torch.float16, 5e-3)):
+        lo = InferenceNet(net, dt, trunk="mfma").cuda()
+        p3, v3 = lo(x.cuda())
+        assert (p3.cpu() - p_ref).abs().max().item() < tol and (v3.cpu() - v_ref).abs().max().item() < tol * 10
+    with pytest.raises(RuntimeError):
+        InferenceNet(net, torch.float32, trunk="mfma")(x)          # no CPU implementation of the HIP trunk
