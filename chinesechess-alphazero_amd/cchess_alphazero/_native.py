@@ -63,6 +63,8 @@ def _declare(L):
         L.cz_conv3x3_packed_elems.restype = C.c_size_t
         L.cz_conv3x3_pack_weights.argtypes = [vp, i32, i32, i32, vp]
         L.cz_conv3x3_pack_weights.restype = i32
+        L.cz_resblock.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+        L.cz_resblock.restype = i32
         L.cz_split_bias_act.argtypes = [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, vp]
         L.cz_split_bias_act.restype = i32
     for name in ("cz_label_tables", "cz_movegen", "cz_done", "cz_step", "cz_encode", "cz_check_or_catch",
@@ -252,6 +254,19 @@ def conv3x3(x, w_packed, bias, skip=None, out=None, out_f32=None, relu=True):
     yl = out[1] if out is not None and parts == 2 else None
     check(lib().cz_conv3x3(_ptr(xh), _ptr(xl), _ptr(w_packed), _ptr(bias), _ptr(sh), _ptr(sl), _ptr(yh), _ptr(yl),
                            _ptr(out_f32), n, c, _dt_code(xh.dtype), parts, int(relu), _stream()), "cz_conv3x3")
+    return out_f32 if out_f32 is not None else out
+
+
+def resblock(x, w1_packed, bias1, w2_packed, bias2, out=None, out_f32=None):
+    """One residual block relu(conv(relu(conv(x, w1) + b1), w2) + b2 + x) in a single launch (split operands only:
+    x and out are (hi, lo) tuples of [N, 90, 128] tensors; out_f32 receives fp32 instead of `out`)."""
+    require_gpu()
+    xh, xl = x
+    n, c = xh.shape[0], xh.shape[-1]
+    yh = out[0] if out is not None else None
+    yl = out[1] if out is not None else None
+    check(lib().cz_resblock(_ptr(xh), _ptr(xl), _ptr(w1_packed), _ptr(bias1), _ptr(w2_packed), _ptr(bias2),
+                            _ptr(yh), _ptr(yl), _ptr(out_f32), n, c, _dt_code(xh.dtype), _stream()), "cz_resblock")
     return out_f32 if out_f32 is not None else out
 
 

@@ -113,6 +113,7 @@ class InferenceNet(nn.Module):
         self.dtype = dtype
         self.trunk = trunk
         self.fused_epilogue = True          # on the GPU: hand-written bias + skip + ReLU pass after each conv
+        self.fused_blocks = True            # trunk="mfma", fp32, 128 filters: one launch per residual block
         self.input_depth = net.cfg["input_depth"]
         self.filters = net.cfg["cnn_filter_num"]
         with torch.no_grad():
@@ -187,9 +188,18 @@ class InferenceNet(nn.Module):
         else:
             cur = (_native.bias_act_(y, self.input_conv.bias).permute(0, 2, 3, 1).reshape(n, 90, c),)
         nblk = len(self.res)
+        fused = self.parts == 2 and c == 128 and self.fused_blocks     # whole residual block in one launch
         for i in range(nblk):
             w1 = getattr(self, f"tw{i}a").view(self.operand_dtype)
             w2 = getattr(self, f"tw{i}b").view(self.operand_dtype)
+            if fused:
+                b1, b2 = getattr(self, f"tb{i}a"), getattr(self, f"tb{i}b")
+                if i + 1 < nblk:
+                    _native.resblock(cur, w1, b1, w2, b2, out=nxt)
+                    cur, nxt = nxt, cur
+                else:
+                    _native.resblock(cur, w1, b1, w2, b2, out_f32=last)
+                continue
             _native.conv3x3(cur, w1, getattr(self, f"tb{i}a"), out=tmp)
             if i + 1 < nblk:
                 _native.conv3x3(tmp, w2, getattr(self, f"tb{i}b"), skip=cur, out=nxt)

@@ -123,7 +123,7 @@ __device__ __forceinline__ void tile_write(unsigned char* region, int gtid,
 // The K loop: 9 taps x C input channels for the 32 output channels of this wave and all NT pixel tiles of the
 // LDS image.  acc[p][r] <-> pixel (p % 3) * 32 + (lane & 31) of board p / 3,
 //                          channel 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-template <typename E, int C, int P, int PARTS, bool NO_W = false>
+template <typename E, int C, int P, int PARTS, bool NO_W = false, bool NO_LDS = false>
 __device__ __forceinline__ void conv_kloop(const unsigned char* region, const uint4* wq, int lane,
                                            f32x16* acc)
 {
@@ -135,17 +135,18 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
     // chunk = 2*kk + kb, swizzled chunk = chunk ^ (row & SWZ) = (2*kk) ^ (kb ^ (row & SWZ)): the lane part is folded
     // into pre[], the K-step part is one XOR with the constant kk << 5.
     int pre[NT], pre_n[NT];
-    auto tap_rows = [&](int tap, int* out) {
-        const int ky = tap / 3;
-        const int dy = ky - 1, dx = tap - ky * 3 - 1;
+    int qy[3], qx[3];                                  // board row / column of this lane's pixel in each of the 3 tiles
 #pragma unroll
-        for (int p = 0; p < NT; ++p) {
-            const int q = (p % 3) * 32 + ln;
-            const int y = q / 9, x = q - y * 9;
-            const bool ok = q < 90 && (unsigned)(y + dy) < 10u && (unsigned)(x + dx) < 9u;
-            const int row = ok ? (p / 3) * 90 + q + dy * 9 + dx : G::ZROW;
-            out[p] = row * G::RB + (((kb ^ row) & G::SWZ) << 4);
-        }
+    for (int t = 0; t < 3; ++t) {
+        const int q = t * 32 + ln;
+        qy[t] = q < 90 ? q / 9 : 100;                  // 100: never on the board, whatever the tap
+        qx[t] = q - (q / 9) * 9;
+    }
+    auto tap_row = [&](int dy, int dx, int p) {
+        const int t = p % 3;
+        const bool ok = (unsigned)(qy[t] + dy) < 10u && (unsigned)(qx[t] + dx) < 9u;
+        const int row = ok ? (p / 3) * 90 + t * 32 + ln + dy * 9 + dx : G::ZROW;
+        return row * G::RB + (((kb ^ row) & G::SWZ) << 4);
     };
     V8 wf[W_RING][PARTS];
     V8 px[2][NT][PARTS];
@@ -161,7 +162,8 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
         return __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(region + part * G::PART_BYTES + off));
     };
 
-    tap_rows(0, pre);
+#pragma unroll
+    for (int p = 0; p < NT; ++p) pre[p] = tap_row(-1, -1, p);
 #pragma unroll
     for (int s = 0; s < W_RING - 1; ++s)
 #pragma unroll
@@ -169,7 +171,10 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
 #pragma unroll
     for (int part = 0; part < PARTS; ++part)
 #pragma unroll
-        for (int p = 0; p < NT; ++p) px[0][p][part] = load_px(pre[p], part);
+        for (int p = 0; p < NT; ++p) {
+            px[0][p][part] = load_px(pre[p], part);
+            if (NO_LDS) px[1][p][part] = px[0][p][part];
+        }
 
     // One K-step = NT (x3 in split mode) MFMAs.  The LDS reads of the NEXT K-step and the weight loads three K-steps
     // ahead are issued one per MFMA, in the shadow of the matrix pipe; sched_barrier pins that order (left alone, the
@@ -178,7 +183,11 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
     constexpr int NL = NT * PARTS;
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
-        tap_rows(tap < 8 ? tap + 1 : 8, pre_n);
+        // rows of the NEXT tap: computed a few at a time in the shadow of this tap's MFMAs (done in one block at the
+        // tap boundary they leave the matrix pipe idle for ~400 cycles per tap)
+        const int tn = tap < 8 ? tap + 1 : 8;
+        const int ndy = tn / 3 - 1, ndx = tn - (tn / 3) * 3 - 1;
+        constexpr int PER = (NT + KK - 2) / (KK - 1);    // rows to prepare per K-step: all done before the last step
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const int step = tap * KK + kk;
@@ -191,7 +200,9 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
             for (int i = 0; i < NM; ++i) {
                 const int pass = i / NT, p = i % NT;      // pass 0: w_hi*x_hi, 1: w_lo*x_hi, 2: w_hi*x_lo
                 acc[p] = Mfma<E>::mma(w[pass == 1 ? PARTS - 1 : 0], b[p][pass == 2 ? PARTS - 1 : 0], acc[p]);
-                if (i < NL) bn[i % NT][i / NT] = load_px(rows[i % NT] ^ kx, i / NT);
+                if (i < NL && !NO_LDS) bn[i % NT][i / NT] = load_px(rows[i % NT] ^ kx, i / NT);
+                if (i >= NM - PER && kk * PER + (i - (NM - PER)) < NT)
+                    pre_n[kk * PER + (i - (NM - PER))] = tap_row(ndy, ndx, kk * PER + (i - (NM - PER)));
                 if (i >= NM - PARTS && !NO_W)
                     wf[(kk + W_RING - 1) % W_RING][i - (NM - PARTS)] = load_w(step + W_RING - 1, i - (NM - PARTS));
                 __builtin_amdgcn_sched_barrier(0);
@@ -457,6 +468,189 @@ __global__ __launch_bounds__(NG * C / 32 * 64, NG) void k_conv3x3_pp(
 #undef CZ_STAMP
 }
 
+// ---- kernel 3: a whole residual block per launch, wave-specialised (split precision) -------------------------------
+// y = relu(conv2(relu(conv1(x) + b1)) + b2 + x) for one board at a time per workgroup, persistent over boards.
+// The intermediate activation never leaves LDS (it is written straight into a second operand image), the skip
+// operand is read back from the first image, and HBM sees one read of x and one write of y per block instead of
+// 2 reads + 1 skip read + 2 writes.  Waves 0..CT-1 ("matrix waves", one per SIMD) only run K loops and the two
+// register-level epilogues; waves CT..2CT-1 ("copy waves") own all global traffic: they fetch the NEXT board into
+// registers while the matrix waves work (their vmcnt is their own, so nothing in the K loop waits for it), drop it
+// into the X image the moment the matrix waves are done with it, and stream the PREVIOUS board's staged fp32
+// result out (ReLU'd, re-split into hi/lo, 16 bytes per lane) under the next K loop.
+//   LDS: X image (hi, lo) 46.6 KB | Y image (hi, lo) 46.6 KB | fp32 staging 46.1 KB  = 139 KB, one workgroup per CU.
+//   barriers per board: A (X ready) .. K1 .. epi1 -> Y .. B (Y ready) .. K2 .. epi2 -> staging .. C (staged, X free)
+template <typename E, int C, int DBG = 0>
+__global__ __launch_bounds__(2 * (C / 32) * 64, 2) void k_resblock(
+    const E* __restrict__ xh, const E* __restrict__ xl, const E* __restrict__ w1p, const float* __restrict__ b1,
+    const E* __restrict__ w2p, const float* __restrict__ b2, E* __restrict__ yh, E* __restrict__ yl,
+    float* __restrict__ yf, int n_boards)
+{
+    constexpr int P = 1, PARTS = 2;
+    typedef Geom<C, P, PARTS> G;
+    constexpr int NT = G::NT, CT = G::CT, GT = G::GTHREADS;
+    constexpr int SROW = C * 4;                        // fp32 staging row (one pixel)
+    constexpr int PIECES = 90 * (C / 8);               // 8-channel output pieces per board
+    constexpr int EITER = (PIECES + GT - 1) / GT;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::REGION + 90 * SROW];
+    unsigned char* X = lds;
+    unsigned char* Y = lds + G::REGION;
+    unsigned char* S = lds + 2 * G::REGION;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool copy_role = wave >= CT;
+    const int wg = wave % CT, gtid = tid % GT;
+    int b = blockIdx.x;
+    if (b >= n_boards) return;
+    const int stride = gridDim.x;
+
+    if (copy_role) {
+        uint4 v[PARTS][G::ITER];
+        tile_load<E, C, P, PARTS, (DBG & 2) != 0>(xh, xl, b, n_boards, gtid, v);
+        tile_write<C, P, PARTS>(X, gtid, v);
+        int b_prev = -1;
+        for (;;) {
+            __syncthreads();                                   // A: X holds board b
+            const int bn = b + stride;
+            const bool has_next = bn < n_boards;
+            int gt2 = gtid;
+            asm volatile("" : "+v"(gt2));                      // keep address arithmetic inside the loop (registers)
+            if (has_next) tile_load<E, C, P, PARTS, (DBG & 2) != 0>(xh, xl, bn, n_boards, gt2, v);
+            // stream out the previous board (staged fp32, already ReLU'd) while the matrix waves run K1
+            auto store_board = [&](int bo) {
+                const size_t ebase = (size_t)bo * 90 * C;
+#pragma unroll
+                for (int it = 0; it < EITER; ++it) {
+                    const int i = it * GT + gt2;
+                    if (!((it + 1) * GT <= PIECES || i < PIECES)) continue;
+                    const int q = i / (C / 8), c8 = i % (C / 8);
+                    const unsigned char* row = S + q * SROW + ((c8 >> 2) << 7);
+                    const float4 f0 = *reinterpret_cast<const float4*>(row + (((2 * c8) ^ q) & 7) * 16);
+                    const float4 f1 = *reinterpret_cast<const float4*>(row + (((2 * c8 + 1) ^ q) & 7) * 16);
+                    const float r[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                    if (DBG & 1) continue;
+                    if (yf) {
+                        float4* o = reinterpret_cast<float4*>(yf + ebase) + 2 * i;
+                        o[0] = f0;
+                        o[1] = f1;
+                    } else {
+                        struct alignas(16) E8 { E e[8]; };
+                        E8 hi, lo;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            hi.e[k] = (E)r[k];
+                            lo.e[k] = (E)(r[k] - (float)hi.e[k]);
+                        }
+                        reinterpret_cast<uint4*>(yh + ebase)[i] = __builtin_bit_cast(uint4, hi);
+                        reinterpret_cast<uint4*>(yl + ebase)[i] = __builtin_bit_cast(uint4, lo);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (b_prev >= 0) store_board(b_prev);
+            __syncthreads();                                   // B
+            __syncthreads();                                   // C: board b is staged, X is free
+            if (has_next) tile_write<C, P, PARTS>(X, gt2, v);
+            b_prev = b;
+            if (!has_next) {
+                store_board(b);
+                break;
+            }
+            b = bn;
+        }
+        return;
+    }
+
+    // ---- matrix waves ----
+    const uint4* wq1 = reinterpret_cast<const uint4*>(w1p) + wg * 64 + lane;
+    const uint4* wq2 = reinterpret_cast<const uint4*>(w2p) + wg * 64 + lane;
+    const int kb = lane >> 5, ln = lane & 31;
+    int kiter = 0;
+    for (;;) {
+        __syncthreads();                                       // A
+        const bool has_next = b + stride < n_boards;
+        f32x16 acc[NT];
+#define CZ_STAMP2(ph, val) do { if ((DBG & 8) && blockIdx.x == 0 && tid == 0 && kiter < 64) g_trace[0][kiter][ph] = (val); } while (0)
+        CZ_STAMP2(0, wall_clock64());
+        long long cyc0 = (DBG & 8) ? clock64() : 0;
+        __builtin_amdgcn_s_setprio(3);
+        conv_kloop<E, C, P, PARTS>(X, wq1, lane, acc);
+        __builtin_amdgcn_s_setprio(0);
+        CZ_STAMP2(1, wall_clock64());
+        CZ_STAMP2(6, clock64() - cyc0);
+        int ln2 = ln, kb2 = kb, gt2 = gtid;
+        asm volatile("" : "+v"(ln2), "+v"(kb2), "+v"(gt2));
+        // epilogue 1: relu(acc + b1) -> (hi, lo) -> Y image (operand layout of the second convolution)
+#pragma unroll
+        for (int p = 0; p < NT; ++p) {
+            const int q = p * 32 + ln2;
+            if (q < 90) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = wg * 32 + g * 8 + kb2 * 4;
+                    const float4 bv = *reinterpret_cast<const float4*>(b1 + ch);
+                    const float vv[4] = {acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
+                                         acc[p][g * 4 + 3] + bv.w};
+                    Quad<E> hi, lo;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float r = vv[i] > 0.0f ? vv[i] : 0.0f;
+                        hi.e[i] = (E)r;
+                        lo.e[i] = (E)(r - (float)hi.e[i]);
+                    }
+                    const int off = q * G::RB + ((((ch >> 3) ^ q) & G::SWZ) << 4) + (ch & 7) * 2;
+                    *reinterpret_cast<Quad<E>*>(Y + off) = hi;
+                    *reinterpret_cast<Quad<E>*>(Y + G::PART_BYTES + off) = lo;
+                }
+            }
+        }
+        if (gt2 < G::CPR) {
+            *reinterpret_cast<uint4*>(Y + G::ZROW * G::RB + gt2 * 16) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(Y + G::PART_BYTES + G::ZROW * G::RB + gt2 * 16) = make_uint4(0, 0, 0, 0);
+        }
+        CZ_STAMP2(2, wall_clock64());
+        __syncthreads();                                       // B: Y complete
+        CZ_STAMP2(3, wall_clock64());
+        cyc0 = (DBG & 8) ? clock64() : 0;
+        __builtin_amdgcn_s_setprio(3);
+        conv_kloop<E, C, P, PARTS, (DBG & 32) != 0, (DBG & 64) != 0>(Y, wq2, lane, acc);
+        __builtin_amdgcn_s_setprio(0);
+        CZ_STAMP2(4, wall_clock64());
+        CZ_STAMP2(7, clock64() - cyc0);
+        asm volatile("" : "+v"(ln2), "+v"(kb2));
+        // epilogue 2: relu(acc + b2 + x) -> fp32 staging (chunks swizzled by pixel & 7)
+#pragma unroll
+        for (int p = 0; p < NT; ++p) {
+            const int q = p * 32 + ln2;
+            if (q < 90) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = wg * 32 + g * 8 + kb2 * 4;
+                    const float4 bv = *reinterpret_cast<const float4*>(b2 + ch);
+                    const int off = q * G::RB + ((((ch >> 3) ^ q) & G::SWZ) << 4) + (ch & 7) * 2;
+                    const Quad<E> sh = *reinterpret_cast<const Quad<E>*>(X + off);
+                    const Quad<E> sl = *reinterpret_cast<const Quad<E>*>(X + G::PART_BYTES + off);
+                    float vv[4] = {acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
+                                   acc[p][g * 4 + 3] + bv.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        vv[i] += (float)sh.e[i];
+                        vv[i] += (float)sl.e[i];
+                        vv[i] = vv[i] > 0.0f ? vv[i] : 0.0f;
+                    }
+                    *reinterpret_cast<float4*>(S + q * SROW + ((((ch >> 2) ^ q) & 7) << 4) + ((ch >> 5) << 7)) =
+                        make_float4(vv[0], vv[1], vv[2], vv[3]);
+                }
+            }
+        }
+        CZ_STAMP2(5, wall_clock64());
+        __syncthreads();                                       // C: staged; X may be replaced
+        if (!has_next) break;
+        b += stride;
+        ++kiter;
+    }
+#undef CZ_STAMP2
+}
+
 // ---- fp32 activation -> (hi, lo) operand pair, with bias and ReLU (after the 5x5 input convolution) ---------------
 template <typename E, int PARTS>
 __global__ __launch_bounds__(256) void k_split_bias_act(const float* __restrict__ x, const float* __restrict__ bias,
@@ -656,6 +850,69 @@ extern "C" int cz_conv3x3(const void* x_hi, const void* x_lo, const void* w_pack
     if (rc == CZ_ERR_ARG) czi_set_error("cz_conv3x3: unsupported channels / dtype (channels 32|128|256, bf16|f16)");
     else if (rc != CZ_OK) czi_set_error("cz_conv3x3: launch failed");
     return rc;
+}
+
+extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1,
+                           const void* w2_packed, const float* bias2, void* y_hi, void* y_lo, float* y_f32,
+                           int n_boards, int channels, int dtype, void* stream)
+{
+    if (n_boards < 0 || !x_hi || !x_lo || !w1_packed || !w2_packed || !bias1 || !bias2 ||
+        (!y_f32 && (!y_hi || !y_lo))) {
+        czi_set_error("cz_resblock: bad argument");
+        return CZ_ERR_ARG;
+    }
+    if (n_boards == 0) return CZ_OK;
+    if (channels != 128 || (dtype != CZ_BF16 && dtype != CZ_F16)) {
+        czi_set_error("cz_resblock: only channels = 128 with bf16 / f16 split operands (use cz_conv3x3 otherwise)");
+        return CZ_ERR_ARG;
+    }
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            czi_set_error("cz_resblock: cannot query the device");
+            return CZ_ERR_HIP;
+        }
+        n_cu = prop.multiProcessorCount;
+    }
+    static const int variant = getenv("CZ_CONV_VARIANT") ? atoi(getenv("CZ_CONV_VARIANT")) : 0;   // tuning probe
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
+#define CZ_RB(E, DBG)                                                                                              \
+    hipLaunchKernelGGL((k_resblock<E, 128, DBG>), dim3(blocks), dim3(512), 0, st, (const E*)x_hi, (const E*)x_lo,   \
+                       (const E*)w1_packed, bias1, (const E*)w2_packed, bias2, (E*)y_hi, (E*)y_lo, y_f32, n_boards)
+    if (dtype == CZ_BF16) {
+        if (variant == 301) CZ_RB(__bf16, 1);
+        else if (variant == 303) CZ_RB(__bf16, 3);
+        else if (variant == 308 || variant == 340 || variant == 372 || variant == 404) {
+            if (variant == 308) CZ_RB(__bf16, 8);
+            if (variant == 340) CZ_RB(__bf16, 40);
+            if (variant == 372) CZ_RB(__bf16, 72);
+            if (variant == 404) CZ_RB(__bf16, 104);
+            static int shots = 0;
+            if (++shots == 5) {
+                static long long h[2][64][8];
+                (void)hipDeviceSynchronize();
+                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h));
+                for (int k = 2; k < 10; ++k) {
+                    fprintf(stderr, "rb trace k%2d:", k);
+                    for (int ph = 0; ph < 8; ++ph)
+                        fprintf(stderr, " %8lld", ph >= 6 ? h[0][k][ph] : (h[0][k][ph] - h[0][2][0]));
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
+        else CZ_RB(__bf16, 0);
+    } else {
+        CZ_RB(_Float16, 0);
+    }
+#undef CZ_RB
+    if (hipGetLastError() != hipSuccess) {
+        czi_set_error("cz_resblock: launch failed");
+        return CZ_ERR_HIP;
+    }
+    return CZ_OK;
 }
 
 extern "C" int cz_split_bias_act(const float* x, const float* bias, void* y_hi, void* y_lo, size_t n_elems,

@@ -80,6 +80,40 @@ def test_conv3x3_identity_filter_is_a_shift():
     assert torch.equal(out[0].float().view(n, 10, 9, c), want)
 
 
+@pytest.mark.parametrize("n", [1, 3, 257, 700])
+def test_resblock_equals_two_convolutions(n):
+    """cz_resblock (one launch, intermediate in LDS) must be BIT-identical to two cz_conv3x3 launches: same
+    operands, same MFMA order, same epilogue arithmetic."""
+    import torch
+    from cchess_alphazero import _native
+    c, dtype = 128, torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.randn((n, 90, c), device="cuda", generator=g).relu()
+    ws = [torch.randn((c, c, 3, 3), device="cuda", generator=g) / (3.0 * c ** 0.5) for _ in range(2)]
+    bs = [torch.randn((c,), device="cuda", generator=g) for _ in range(2)]
+    ps = [_native.pack_conv3x3_weights(w, dtype, 2).cuda() for w in ws]
+    xs = _split(x, dtype, 2)
+    t = tuple(torch.empty_like(xs[0]) for _ in range(2))
+    want = tuple(torch.empty_like(xs[0]) for _ in range(2))
+    want_f = torch.empty((n, 90, c), device="cuda")
+    _native.conv3x3(xs, ps[0], bs[0], out=t)
+    _native.conv3x3(t, ps[1], bs[1], skip=xs, out=want)
+    _native.conv3x3(t, ps[1], bs[1], skip=xs, out_f32=want_f)
+    got = tuple(torch.full_like(xs[0], 7.0) for _ in range(2))
+    got_f = torch.full((n, 90, c), 7.0, device="cuda")
+    _native.resblock(xs, ps[0], bs[0], ps[1], bs[1], out=got)
+    _native.resblock(xs, ps[0], bs[0], ps[1], bs[1], out_f32=got_f)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert torch.equal(got_f, want_f)
+    # in place (y aliases x): every workgroup has its board in LDS before it writes it back
+    xi = tuple(a.clone() for a in xs)
+    _native.resblock(xi, ps[0], bs[0], ps[1], bs[1], out=xi)
+    assert torch.equal(xi[0], want[0]) and torch.equal(xi[1], want[1])
+    with pytest.raises(_native.NativeError):
+        x64 = tuple(torch.zeros((1, 90, 64), device="cuda", dtype=dtype) for _ in range(2))
+        _native.resblock(x64, ps[0], bs[0], ps[1], bs[1], out=x64)
+
+
 def test_split_bias_act():
     import torch
     from cchess_alphazero import _native
@@ -145,6 +179,9 @@ def test_network_with_mfma_trunk_matches_fp32_module(filters, blocks):
     lib = InferenceNet(net, torch.float32, trunk="library").cuda()
     p2, v2 = lib(x.cuda())
     assert (p - p2).abs().max().item() < 1e-4 and (v - v2).abs().max().item() < 1e-4
+    inf.fused_blocks = False                 # per-convolution launches: identical trunk arithmetic (the library
+    p5, v5 = inf(x.cuda())                   # kernels around it may change solver between calls, hence not torch.equal)
+    assert (p5 - p).abs().max().item() < 1e-6 and (v5 - v).abs().max().item() < 1e-5
     for dt, tol in ((torch.bfloat16, 3e-2), (torch.float16, 5e-3)):
         lo = InferenceNet(net, dt, trunk="mfma").cuda()
         p3, v3 = lo(x.cuda())

@@ -84,6 +84,54 @@ def bench(c, dtype, parts, n, iters=10):
     return dict(ms=ms, tflops_algorithmic=flop / ms / 1e9, mfma_tflops=flop * (3 if parts == 2 else 1) / ms / 1e9)
 
 
+def check_block(c=128, dtype=torch.bfloat16, n=300, seed=3):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn((n, 90, c), device="cuda", generator=g).relu()
+    w1 = torch.randn((c, c, 3, 3), device="cuda", generator=g) / (3.0 * c ** 0.5)
+    w2 = torch.randn((c, c, 3, 3), device="cuda", generator=g) / (3.0 * c ** 0.5)
+    b1 = torch.randn((c,), device="cuda", generator=g)
+    b2 = torch.randn((c,), device="cuda", generator=g)
+    p1 = _native.pack_conv3x3_weights(w1, dtype, 2).cuda()
+    p2 = _native.pack_conv3x3_weights(w2, dtype, 2).cuda()
+    xs = split(x, dtype, 2)
+    # two-launch path as the reference for the fused one (bit-identical arithmetic expected)
+    t = tuple(torch.empty_like(xs[0]) for _ in range(2))
+    o2 = tuple(torch.empty_like(xs[0]) for _ in range(2))
+    _native.conv3x3(xs, p1, b1, out=t)
+    _native.conv3x3(t, p2, b2, skip=xs, out=o2)
+    o1 = tuple(torch.full_like(xs[0], 7.0) for _ in range(2))
+    _native.resblock(xs, p1, b1, p2, b2, out=o1)
+    of = torch.full((n, 90, c), 7.0, device="cuda")
+    _native.resblock(xs, p1, b1, p2, b2, out_f32=of)
+    torch.cuda.synchronize()
+    d = (sum(a.double() for a in o1) - sum(a.double() for a in o2)).abs().max().item()
+    d2 = (of.double() - sum(a.double() for a in o2)).abs().max().item()
+    return dict(fused_vs_two_launches=d, bit_equal=bool(torch.equal(o1[0], o2[0]) and torch.equal(o1[1], o2[1])),
+                f32_vs_two_launches=d2)
+
+
+def bench_block(c, dtype, n, iters=10):
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn((n, 90, c), device="cuda", generator=g).relu()
+    w = torch.randn((c, c, 3, 3), device="cuda", generator=g) / (3.0 * c ** 0.5)
+    b = torch.randn((c,), device="cuda", generator=g)
+    wp = _native.pack_conv3x3_weights(w, dtype, 2).cuda()
+    xs = split(x, dtype, 2)
+    out = tuple(torch.empty((n, 90, c), device="cuda", dtype=dtype) for _ in range(2))
+    for _ in range(2):
+        _native.resblock(xs, wp, b, wp, b, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        _native.resblock(xs, wp, b, wp, b, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flop = 2 * 2.0 * n * 90 * c * c * 9
+    return dict(ms=ms, ms_per_conv=ms / 2, tflops_algorithmic=flop / ms / 1e9, mfma_tflops=3 * flop / ms / 1e9)
+
+
 def bench_miopen(c, dtype, n, iters=5):
     x = torch.randn((n, c, 10, 9), device="cuda", dtype=dtype).contiguous(memory_format=torch.channels_last)
     w = (torch.randn((c, c, 3, 3), device="cuda") / (3.0 * c ** 0.5)).to(dtype).contiguous(
@@ -120,6 +168,12 @@ def main():
         key = f"{str(dtype).split('.')[-1]}_x{parts}"
         res["bench"][key] = bench(a.channels, dtype, parts, a.n)
         print(key, res["bench"][key], flush=True)
+    if a.channels == 128:
+        if not a.no_check:
+            res["check"]["resblock"] = check_block()
+            print("resblock", res["check"]["resblock"], flush=True)
+        res["bench"]["resblock_bf16_x2"] = bench_block(128, torch.bfloat16, a.n)
+        print("resblock", res["bench"]["resblock_bf16_x2"], flush=True)
     if not a.no_miopen:
         for dtype in (torch.float32, torch.bfloat16):
             key = "miopen_" + str(dtype).split(".")[-1]
