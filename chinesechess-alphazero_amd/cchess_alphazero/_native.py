@@ -63,6 +63,12 @@ def _declare(L):
         L.cz_conv3x3_packed_elems.restype = C.c_size_t
         L.cz_conv3x3_pack_weights.argtypes = [vp, i32, i32, i32, vp]
         L.cz_conv3x3_pack_weights.restype = i32
+        L.cz_input_conv.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+        L.cz_input_conv.restype = i32
+        L.cz_input_conv_packed_elems.argtypes = [i32, i32, i32]
+        L.cz_input_conv_packed_elems.restype = C.c_size_t
+        L.cz_input_conv_pack_weights.argtypes = [vp, i32, i32, i32, i32, vp]
+        L.cz_input_conv_pack_weights.restype = i32
         L.cz_resblock.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
         L.cz_resblock.restype = i32
         L.cz_split_bias_act.argtypes = [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, vp]
@@ -255,6 +261,36 @@ def conv3x3(x, w_packed, bias, skip=None, out=None, out_f32=None, relu=True):
     check(lib().cz_conv3x3(_ptr(xh), _ptr(xl), _ptr(w_packed), _ptr(bias), _ptr(sh), _ptr(sl), _ptr(yh), _ptr(yl),
                            _ptr(out_f32), n, c, _dt_code(xh.dtype), parts, int(relu), _stream()), "cz_conv3x3")
     return out_f32 if out_f32 is not None else out
+
+
+def pack_input_conv_weights(w_oihw, dtype, parts):
+    """fp32 [C, in_planes, 5, 5] filter -> packed 2-byte tensor in MFMA fragment order (on the CPU)."""
+    import torch
+    w = w_oihw.detach().to("cpu", torch.float32).contiguous()
+    c, ip = w.shape[0], w.shape[1]
+    assert tuple(w.shape[2:]) == (5, 5)
+    n = lib().cz_input_conv_packed_elems(c, ip, parts)
+    if n == 0:
+        raise NativeError(f"cz_input_conv: unsupported channels={c} in_planes={ip} parts={parts}")
+    out = torch.empty((n,), dtype=dtype)
+    check(lib().cz_input_conv_pack_weights(_ptr(w), c, ip, _dt_code(dtype), parts, _ptr(out)),
+          "cz_input_conv_pack_weights")
+    return out
+
+
+def input_conv(planes, w_packed, bias, out, relu=True):
+    """planes [N, in_planes, 10, 9] (fp32 / fp16 / bf16 / uint8, contiguous, as the search kernel writes them) ->
+    relu(conv5x5 + bias) as the (hi,) / (hi, lo) operand tuple `out` of [N, 90, C] tensors."""
+    import torch
+    require_gpu()
+    code = U8 if planes.dtype == torch.uint8 else _dt_code(planes.dtype)
+    if not planes.is_contiguous():
+        raise NativeError("cz_input_conv: planes must be a contiguous [N, in_planes, 10, 9] tensor")
+    parts = len(out)
+    check(lib().cz_input_conv(_ptr(planes), code, planes.shape[1], _ptr(w_packed), _ptr(bias), _ptr(out[0]),
+                              _ptr(out[1]) if parts == 2 else None, planes.shape[0], out[0].shape[-1],
+                              _dt_code(out[0].dtype), parts, int(relu), _stream()), "cz_input_conv")
+    return out
 
 
 def resblock(x, w1_packed, bias1, w2_packed, bias2, out=None, out_f32=None):

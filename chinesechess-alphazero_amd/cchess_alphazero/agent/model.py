@@ -140,7 +140,9 @@ class InferenceNet(nn.Module):
                 self.register_buffer(f"tb{i}a", b1)
                 self.register_buffer(f"tw{i}b", w2.view(torch.int16))
                 self.register_buffer(f"tb{i}b", b2)
-            self.register_buffer("in_bias32", self.input_conv.bias.detach().float().clone())
+            self.register_buffer("in_bias32", self._in_bias32)
+            self.register_buffer("in_w", self._packed_in.view(torch.int16))
+            del self._packed_in, self._in_bias32
         self._bufs = {}
         self.eval()
         for p in self.parameters():
@@ -158,6 +160,8 @@ class InferenceNet(nn.Module):
     def _pack_trunk(self):
         """fp32 folded filters -> MFMA fragment order (cz_conv3x3_pack_weights); called before the dtype conversion."""
         from cchess_alphazero import _native
+        self._in_bias32 = self.input_conv.bias.detach().float().clone()
+        self._packed_in = _native.pack_input_conv_weights(self.input_conv.weight, self.operand_dtype, self.parts)
         out = []
         for c1, c2 in self.res:
             out.append((_native.pack_conv3x3_weights(c1.weight, self.operand_dtype, self.parts),
@@ -177,16 +181,12 @@ class InferenceNet(nn.Module):
             self._bufs = {key: (bufs, last)}              # one batch size at a time (the evaluation queue)
         return self._bufs[key]
 
-    def _trunk_mfma(self, x):
+    def _trunk_mfma(self, planes):
+        """planes: the evaluation queue as the search kernel wrote it ([n, in_planes, 10, 9], any supported dtype)."""
         from cchess_alphazero import _native
-        n, c = x.shape[0], self.filters
-        y = F.conv2d(x, self.input_conv.weight, None, self.input_conv.stride, self.input_conv.padding)
-        y = y.contiguous(memory_format=torch.channels_last)          # memory [n, 10, 9, c]
-        (cur, tmp, nxt), last = self._operands(n, x.device)
-        if self.parts == 2:
-            _native.split_bias_act(y, self.in_bias32, cur)
-        else:
-            cur = (_native.bias_act_(y, self.input_conv.bias).permute(0, 2, 3, 1).reshape(n, 90, c),)
+        n, c = planes.shape[0], self.filters
+        (cur, tmp, nxt), last = self._operands(n, planes.device)
+        _native.input_conv(planes.contiguous(), self.in_w.view(self.operand_dtype), self.in_bias32, cur)
         nblk = len(self.res)
         fused = self.parts == 2 and c == 128 and self.fused_blocks     # whole residual block in one launch
         for i in range(nblk):
@@ -226,18 +226,19 @@ class InferenceNet(nn.Module):
 
     @torch.no_grad()
     def forward(self, planes):
-        x = planes.to(self.dtype).contiguous(memory_format=torch.channels_last)
         if self.trunk == "mfma":
-            if not x.is_cuda:
+            if not planes.is_cuda:
                 raise RuntimeError("trunk='mfma' is the hand-written HIP path: it has no CPU implementation")
-            x = self._trunk_mfma(x)
-        elif x.is_cuda and self.fused_epilogue and self.input_conv.out_channels % 8 == 0:
-            x = self._trunk_fused(x)
+            x = self._trunk_mfma(planes)
         else:
-            x = F.relu(self.input_conv(x))
-            for c1, c2 in self.res:
-                y = F.relu(c1(x))
-                x = F.relu(x + c2(y))
+            x = planes.to(self.dtype).contiguous(memory_format=torch.channels_last)
+            if x.is_cuda and self.fused_epilogue and self.input_conv.out_channels % 8 == 0:
+                x = self._trunk_fused(x)
+            else:
+                x = F.relu(self.input_conv(x))
+                for c1, c2 in self.res:
+                    y = F.relu(c1(x))
+                    x = F.relu(x + c2(y))
         p = F.relu(self.policy_conv(x))
         p = self.policy_out(p.flatten(1))                # flatten of an NCHW-shaped tensor: C,H,W order
         v = F.relu(self.value_conv(x))

@@ -45,12 +45,10 @@ class SelfPlayEngine:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         torch.cuda.set_device(self.device)
         self.dtype = dtype
-        self.search = Search(config.play, n_games, planes_dtype=_PLANES_CODE[dtype],
-                             evaluate=getattr(config.opts, "evaluate", False), seed=seed,
-                             node_capacity=node_capacity, edge_capacity=edge_capacity, max_depth=max_depth,
-                             sims_per_round=sims_per_round, device=self.device, use_history=use_history)
         self.evaluator = evaluator
         self.net = None
+        self.trunk = None
+        planes_code = _PLANES_CODE[dtype]
         if evaluator is None:
             if net is None:
                 torch.manual_seed(0)
@@ -61,7 +59,14 @@ class SelfPlayEngine:
             if net.cfg["cnn_filter_num"] not in (32, 128, 256):
                 trunk = "library"
             self.trunk = trunk
-            self.net = InferenceNet(net, dtype, trunk=trunk).to(self.device)
+            if trunk == "mfma":
+                planes_code = _native.U8      # the hand-written input convolution reads the 0/1 planes as bytes
+        self.search = Search(config.play, n_games, planes_dtype=planes_code,
+                             evaluate=getattr(config.opts, "evaluate", False), seed=seed,
+                             node_capacity=node_capacity, edge_capacity=edge_capacity, max_depth=max_depth,
+                             sims_per_round=sims_per_round, device=self.device, use_history=use_history)
+        if evaluator is None:
+            self.net = InferenceNet(net, dtype, trunk=self.trunk).to(self.device)
         self.rounds = 0
         self.seed = seed
         self._graph = None

@@ -284,191 +284,9 @@ __global__ __launch_bounds__(C / 32 * 64, MINW) void k_conv3x3(
     }
 }
 
-// ---- kernel 2: persistent ping-pong (split precision) -------------------------------------------------------------
-// One workgroup per CU, NG groups of C/32 waves.  Each group walks its own boards: [LDS image ready] -> wait for the
-// matrix-pipe turn -> K loop -> pass the turn -> epilogue + next board's load.  While one group owns the MFMA pipe
-// (which the K loop saturates on its own), the other group(s) do their HBM traffic, so the loads / stores that cost
-// 45 % of kernel 1 are hidden.  Groups synchronise internally through an LDS counter (a __syncthreads would couple
-// the groups); the turn is a performance hint only -- correctness never depends on it.
-// The epilogue goes through LDS (fp32, the group's own image region, which is free after the K loop) so that the
-// skip loads and the result stores are 16 bytes per lane, fully coalesced.
-__device__ long long g_trace[2][64][8];     // tuning probe (DBG & 8): [group][board k][phase] timestamps of block 0
+__device__ long long g_trace[64][8];     // tuning probe (DBG & 8): [board k][phase] time stamps of block 0
 
-struct GroupSync {
-    int* ctr;          // LDS arrival counter of this group
-    int target;
-    int lanes_per_group_waves;
-    __device__ __forceinline__ void barrier(int lane)
-    {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        target += lanes_per_group_waves;
-        if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
-            __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-    }
-};
-
-template <typename E, int C, int NG, int DBG = 0>
-__global__ __launch_bounds__(NG * C / 32 * 64, NG) void k_conv3x3_pp(
-    const E* __restrict__ xh, const E* __restrict__ xl, const E* __restrict__ wp, const float* __restrict__ bias,
-    const E* __restrict__ sh, const E* __restrict__ sl, E* __restrict__ yh, E* __restrict__ yl,
-    float* __restrict__ yf, int n_boards, int relu)
-{
-    constexpr int P = 1, PARTS = 2;
-    typedef Geom<C, P, PARTS> G;
-    constexpr int NT = G::NT, CT = G::CT, GT = G::GTHREADS;
-    constexpr int SROW = C * 4;                        // fp32 staging row (one pixel)
-    constexpr int PIECES = 90 * (C / 8);               // 8-channel output pieces per board
-    constexpr int EITER = (PIECES + GT - 1) / GT;
-    static_assert(G::REGION >= 90 * SROW, "the fp32 staging image must fit the group's operand region");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NG * G::REGION + 64];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = wave / CT, wg = wave % CT, gtid = tid - grp * GT;
-    unsigned char* region = lds + grp * G::REGION;
-    int* sync = reinterpret_cast<int*>(lds + NG * G::REGION);     // [0, NG): counters  [NG]: turn  [NG+1, 2NG]: done
-    if (tid < 16) sync[tid] = 0;
-    __syncthreads();
-    GroupSync gs{sync + grp, 0, CT};
-    volatile int* turn = sync + NG;
-    volatile int* done = sync + NG + 1;
-
-    const int stride = gridDim.x * NG;
-    int n = blockIdx.x * NG + grp;                    // this group's current board
-    if (n >= n_boards) {
-        if (gtid == 0) done[grp] = 1;
-        return;
-    }
-    const uint4* wq = reinterpret_cast<const uint4*>(wp) + wg * 64 + lane;
-    const int kb = lane >> 5, ln = lane & 31;
-    {
-        uint4 v[PARTS][G::ITER];
-        tile_load<E, C, P, PARTS, (DBG & 2) != 0>(xh, xl, n, n_boards, gtid, v);
-        tile_write<C, P, PARTS>(region, gtid, v);
-    }
-    int kiter = 0;
-#define CZ_STAMP(ph) do { if ((DBG & 8) && blockIdx.x == 0 && gtid == 0 && kiter < 64) g_trace[grp][kiter][ph] = wall_clock64(); } while (0)
-    for (;;) {
-        CZ_STAMP(0);
-        gs.barrier(lane);                              // B1: the LDS image of board n is complete
-        // wait for the matrix-pipe turn (or for a turn holder that has already left)
-        for (;;) {
-            const int t = *turn;
-            if (t == grp || done[t]) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-        f32x16 acc[NT];
-        CZ_STAMP(1);
-        long long cyc0 = 0;
-        if (DBG & 8) cyc0 = clock64();
-        if (!(DBG & 16)) __builtin_amdgcn_s_setprio(3);     // the K loop outranks the other groups' load / store streams
-        conv_kloop<E, C, P, PARTS, (DBG & 32) != 0>(region, wq, lane, acc);
-        if (!(DBG & 16)) __builtin_amdgcn_s_setprio(0);
-        CZ_STAMP(2);
-        if ((DBG & 8) && blockIdx.x == 0 && gtid == 0 && kiter < 64) {
-            g_trace[grp][kiter][3] = 0;
-            g_trace[grp][kiter][4] = clock64() - cyc0;
-        }
-        const int n_next = n + stride;
-        const bool has_next = n_next < n_boards;
-        gs.barrier(lane);                              // B2: every wave of the group is done with the image
-        if (gtid == 0) {
-            if (!has_next) done[grp] = 1;
-            *turn = (grp + 1) % NG;
-        }
-        // (opaque copies: without them the compiler hoists every address of the epilogue / next-board copy out of
-        //  the persistent loop and keeps ~100 registers live across the K loop)
-        int gt2 = gtid, ln2 = ln, kb2 = kb;
-        asm volatile("" : "+v"(gt2), "+v"(ln2), "+v"(kb2));
-        // in flight while the accumulators are staged: the skip operand of this board
-        uint4 sk[PARTS][EITER];
-        uint4 v[PARTS][G::ITER];
-        const size_t ebase = (size_t)n * 90 * C;
-        if (sh && !(DBG & 1)) {
-#pragma unroll
-            for (int part = 0; part < PARTS; ++part)
-#pragma unroll
-                for (int it = 0; it < EITER; ++it) {
-                    const int i = it * GT + gt2;
-                    sk[part][it] = make_uint4(0, 0, 0, 0);
-                    if ((it + 1) * GT <= PIECES || i < PIECES)
-                        sk[part][it] = reinterpret_cast<const uint4*>((part ? sl : sh) + ebase)[i];
-                }
-        }
-        // accumulators (+ bias) -> fp32 staging image [pixel][channel], 16-byte chunks swizzled by (pixel & 7)
-#pragma unroll
-        for (int p = 0; p < NT; ++p) {
-            const int q = p * 32 + ln2;
-            if (q < 90) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ch = wg * 32 + g * 8 + kb2 * 4;
-                    const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
-                    *reinterpret_cast<float4*>(region + q * SROW + ((((ch >> 2) ^ q) & 7) << 4) + ((ch >> 5) << 7)) =
-                        make_float4(acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
-                                    acc[p][g * 4 + 3] + bv.w);
-                }
-            }
-        }
-        gs.barrier(lane);                              // B3: staging image complete
-        if (!(DBG & 1)) {
-#pragma unroll
-            for (int it = 0; it < EITER; ++it) {
-                const int i = it * GT + gt2;
-                if (!((it + 1) * GT <= PIECES || i < PIECES)) continue;
-                const int q = i / (C / 8), c8 = i % (C / 8);        // channels 8*c8 .. 8*c8+7 = chunks 2*c8, 2*c8+1
-                const unsigned char* row = region + q * SROW + ((c8 >> 2) << 7);
-                const float4 f0 = *reinterpret_cast<const float4*>(row + (((2 * c8) ^ q) & 7) * 16);
-                const float4 f1 = *reinterpret_cast<const float4*>(row + (((2 * c8 + 1) ^ q) & 7) * 16);
-                float r[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-                if (sh) {
-                    struct alignas(16) E8 { E e[8]; };
-#pragma unroll
-                    for (int part = 0; part < PARTS; ++part) {
-                        const E8 s8 = __builtin_bit_cast(E8, sk[part][it]);
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) r[k] += (float)s8.e[k];
-                    }
-                }
-                if (relu) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) r[k] = r[k] > 0.0f ? r[k] : 0.0f;
-                }
-                if (yf) {
-                    float4* o = reinterpret_cast<float4*>(yf + ebase) + 2 * i;
-                    o[0] = make_float4(r[0], r[1], r[2], r[3]);
-                    o[1] = make_float4(r[4], r[5], r[6], r[7]);
-                } else {
-                    struct alignas(16) E8 { E e[8]; };
-                    E8 hi, lo;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        hi.e[k] = (E)r[k];
-                        lo.e[k] = (E)(r[k] - (float)hi.e[k]);
-                    }
-                    reinterpret_cast<uint4*>(yh + ebase)[i] = __builtin_bit_cast(uint4, hi);
-                    reinterpret_cast<uint4*>(yl + ebase)[i] = __builtin_bit_cast(uint4, lo);
-                }
-                __builtin_amdgcn_sched_barrier(0);      // one piece at a time: keeps the register footprint small
-            }
-        } else if (acc[0][0] + acc[1][5] + acc[2][10] == 12345.678f) {
-            yh[0] = (E)1.0f;
-        }
-        CZ_STAMP(5);
-        if (!has_next) break;
-        tile_load<E, C, P, PARTS, (DBG & 2) != 0>(xh, xl, (DBG & 4) ? (int)(blockIdx.x * NG + grp) : n_next, n_boards, gt2, v);
-        gs.barrier(lane);                              // B4: staging reads done, the region may be overwritten
-        CZ_STAMP(6);
-        tile_write<C, P, PARTS>(region, gt2, v);
-        CZ_STAMP(7);
-        n = n_next;
-        ++kiter;
-    }
-#undef CZ_STAMP
-}
-
-// ---- kernel 3: a whole residual block per launch, wave-specialised (split precision) -------------------------------
+// ---- kernel 2: a whole residual block per launch, wave-specialised (split precision) -------------------------------
 // y = relu(conv2(relu(conv1(x) + b1)) + b2 + x) for one board at a time per workgroup, persistent over boards.
 // The intermediate activation never leaves LDS (it is written straight into a second operand image), the skip
 // operand is read back from the first image, and HBM sees one read of x and one write of y per block instead of
@@ -569,7 +387,7 @@ __global__ __launch_bounds__(2 * (C / 32) * 64, 2) void k_resblock(
         __syncthreads();                                       // A
         const bool has_next = b + stride < n_boards;
         f32x16 acc[NT];
-#define CZ_STAMP2(ph, val) do { if ((DBG & 8) && blockIdx.x == 0 && tid == 0 && kiter < 64) g_trace[0][kiter][ph] = (val); } while (0)
+#define CZ_STAMP2(ph, val) do { if ((DBG & 8) && blockIdx.x == 0 && tid == 0 && kiter < 64) g_trace[kiter][ph] = (val); } while (0)
         CZ_STAMP2(0, wall_clock64());
         long long cyc0 = (DBG & 8) ? clock64() : 0;
         __builtin_amdgcn_s_setprio(3);
@@ -651,6 +469,133 @@ __global__ __launch_bounds__(2 * (C / 32) * 64, 2) void k_resblock(
 #undef CZ_STAMP2
 }
 
+// ---- kernel 3: the input convolution (5x5, 14 or 28 feature planes -> C channels) ----------------------------------
+// Reference: Conv2D(F, 5, padding="same") -> BatchNorm -> ReLU on the state_to_planes input (agent/model.py:36-39).
+// The planes arrive exactly as the search kernel writes them ([in_planes][10][9] per board, values 0 / 1, any of
+// fp32 / fp16 / bf16 / u8) and are transposed into a channels-last LDS image ([pixel][16 or 32 channels], zero padded)
+// while being staged.  0 / 1 are exact in bf16, so only the WEIGHTS are split: two MFMAs per product in split mode.
+// One K-step per tap and 16 input channels; output written as the (hi, lo) operand pair of the residual tower.
+template <typename PT> __device__ __forceinline__ float plane_to_f(PT v) { return (float)v; }
+
+template <typename E, typename PT, int C, int IC16, int P, int PARTS>
+__global__ __launch_bounds__(C / 32 * 64, 1) void k_input_conv(
+    const PT* __restrict__ planes, const E* __restrict__ wp, const float* __restrict__ bias, E* __restrict__ yh,
+    E* __restrict__ yl, int n_boards, int in_planes, int relu)
+{
+    typedef typename Mfma<E>::V8 V8;
+    constexpr int RBI = IC16 * 32;                  // bytes per pixel row of the input image
+    constexpr int ZROW = P * 90;
+    constexpr int IMG = (P * 90 + 1) * RBI;
+    constexpr int NT = P * 3, CT = C / 32, NTHR = CT * 64;
+    constexpr int NX = NT * IC16;                   // operand reads per tap
+    constexpr int NM = NX * PARTS;                  // MFMAs per tap
+    constexpr int W_STEP = CT * 64;                 // uint4 per (tap, 16-channel group)
+    constexpr int W_PART = (25 + 3) * IC16 * W_STEP;
+    __shared__ __attribute__((aligned(16))) unsigned char img[IMG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * P;
+    for (int i = tid; i < IMG / 16; i += NTHR) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    {
+        const int per_board = in_planes * 90;
+        const int nb = n_boards - n0 < P ? n_boards - n0 : P;
+        const PT* src = planes + (size_t)n0 * per_board;
+        for (int i = tid; i < nb * per_board; i += NTHR) {
+            const int bb = i / per_board, r = i - bb * per_board;
+            const int c = r / 90, pix = r - c * 90;
+            *reinterpret_cast<E*>(img + (bb * 90 + pix) * RBI + c * 2) = (E)plane_to_f(src[i]);
+        }
+    }
+    __syncthreads();
+
+    const int kb = lane >> 5, ln = lane & 31;
+    int qy[3], qx[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int q = t * 32 + ln;
+        qy[t] = q < 90 ? q / 9 : 100;
+        qx[t] = q - (q / 9) * 9;
+    }
+    auto tap_off = [&](int tap, int p) {            // byte offset of this lane's 16 bytes for (tap, 16-channel group 0)
+        const int ky = tap / 5;
+        const int dy = ky - 2, dx = tap - ky * 5 - 2;
+        const int t = p % 3;
+        const bool ok = (unsigned)(qy[t] + dy) < 10u && (unsigned)(qx[t] + dx) < 9u;
+        const int row = ok ? (p / 3) * 90 + t * 32 + ln + dy * 9 + dx : ZROW;
+        return row * RBI + kb * 16;
+    };
+    const uint4* wq = reinterpret_cast<const uint4*>(wp) + wave * 64 + lane;
+    auto load_w = [&](int tap, int g, int part) {
+        return __builtin_bit_cast(V8, wq[(size_t)part * W_PART + (size_t)(tap * IC16 + g) * W_STEP]);
+    };
+    V8 wf[4][IC16][PARTS];
+    V8 px[2][NX];
+    f32x16 acc[NT];
+#pragma unroll
+    for (int p = 0; p < NT; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int g = 0; g < IC16; ++g)
+#pragma unroll
+            for (int part = 0; part < PARTS; ++part) wf[s][g][part] = load_w(s, g, part);
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+        px[0][i] = __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(img + tap_off(0, i % NT) + (i / NT) * 32));
+
+    auto tap_body = [&](int tap, const int ring, const int buf) {
+        const int tn = tap < 24 ? tap + 1 : 24;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const int xi = i % NX, part = i / NX;          // all operands with w_hi first, then with w_lo
+            acc[xi % NT] = Mfma<E>::mma(wf[ring][xi / NT][part], px[buf][xi], acc[xi % NT]);
+            if (i < NX)
+                px[buf ^ 1][i] = __builtin_bit_cast(
+                    V8, *reinterpret_cast<const uint4*>(img + tap_off(tn, i % NT) + (i / NT) * 32));
+            if (i >= NM - IC16 * PARTS) {
+                const int j = i - (NM - IC16 * PARTS);
+                wf[(ring + 3) & 3][j / PARTS][j % PARTS] = load_w(tap + 3, j / PARTS, j % PARTS);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+#pragma unroll 1
+    for (int t4 = 0; t4 < 24; t4 += 4) {
+        tap_body(t4 + 0, 0, 0);
+        tap_body(t4 + 1, 1, 1);
+        tap_body(t4 + 2, 2, 0);
+        tap_body(t4 + 3, 3, 1);
+    }
+    tap_body(24, 0, 0);
+
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+        const int q = (p % 3) * 32 + ln;
+        const int n = n0 + p / 3;
+        if (q >= 90 || n >= n_boards) continue;
+        const size_t pix = ((size_t)n * 90 + q) * C;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = wave * 32 + g * 8 + kb * 4;
+            const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
+            float v[4] = {acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
+                          acc[p][g * 4 + 3] + bv.w};
+            Quad<E> hi, lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (relu) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+                hi.e[i] = (E)v[i];
+                lo.e[i] = (E)(v[i] - (float)hi.e[i]);
+            }
+            *reinterpret_cast<Quad<E>*>(yh + pix + ch) = hi;
+            if (PARTS == 2) *reinterpret_cast<Quad<E>*>(yl + pix + ch) = lo;
+        }
+    }
+}
+
 // ---- fp32 activation -> (hi, lo) operand pair, with bias and ReLU (after the 5x5 input convolution) ---------------
 template <typename E, int PARTS>
 __global__ __launch_bounds__(256) void k_split_bias_act(const float* __restrict__ x, const float* __restrict__ bias,
@@ -688,67 +633,13 @@ int launch_conv(const void* xh, const void* xl, const void* wp, const float* bia
     return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
 }
 
-template <typename E, int C, int NG, int DBG = 0>
-int launch_conv_pp(const void* xh, const void* xl, const void* wp, const float* bias, const void* sh, const void* sl,
-                   void* yh, void* yl, float* yf, int n_boards, int relu, hipStream_t st)
-{
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return CZ_ERR_HIP;
-        n_cu = prop.multiProcessorCount;
-    }
-    unsigned blocks = (unsigned)((n_boards + NG - 1) / NG);
-    if (blocks > (unsigned)n_cu) blocks = (unsigned)n_cu;
-    hipLaunchKernelGGL((k_conv3x3_pp<E, C, NG, DBG>), dim3(blocks), dim3(NG * C / 32 * 64), 0, st, (const E*)xh,
-                       (const E*)xl, (const E*)wp, bias, (const E*)sh, (const E*)sl, (E*)yh, (E*)yl, yf, n_boards,
-                       relu);
-    if (DBG & 8) {
-        static int shots = 0;
-        if (++shots == 5) {
-            static long long h[2][64][8];
-            (void)hipDeviceSynchronize();
-            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h));
-            for (int k = 2; k < 12; ++k)
-                for (int g = 0; g < 2; ++g) {
-                    fprintf(stderr, "trace g%d k%2d:", g, k);
-                    for (int ph = 0; ph < 8; ++ph) fprintf(stderr, " %8lld", ph == 3 || ph == 4 ? h[g][k][ph] : (h[g][k][ph] - h[0][2][0]));
-                    fprintf(stderr, "\n");
-                }
-        }
-    }
-    return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
-}
-
 template <typename E>
 int dispatch_conv(int channels, int parts, const void* xh, const void* xl, const void* wp, const float* bias,
                   const void* sh, const void* sl, void* yh, void* yl, float* yf, int n, int relu, hipStream_t st)
 {
 #define CZ_CONV_ARGS xh, xl, wp, bias, sh, sl, yh, yl, yf, n, relu, st
-    static const int variant = getenv("CZ_CONV_VARIANT") ? atoi(getenv("CZ_CONV_VARIANT")) : 0;   // tuning probe
-    if (channels == 128 && parts == 2) {
-        if (variant == 12) return launch_conv<E, 128, 1, 2, 2>(CZ_CONV_ARGS);
-        if (variant == 13) return launch_conv<E, 128, 1, 2, 3>(CZ_CONV_ARGS);
-        if (variant == 2) return launch_conv_pp<E, 128, 2>(CZ_CONV_ARGS);
-        if (variant == 3) return launch_conv_pp<E, 128, 3>(CZ_CONV_ARGS);
-        if (variant == 201) return launch_conv_pp<E, 128, 2, 1>(CZ_CONV_ARGS);
-        if (variant == 203) return launch_conv_pp<E, 128, 2, 3>(CZ_CONV_ARGS);
-        if (variant == 205) return launch_conv_pp<E, 128, 2, 5>(CZ_CONV_ARGS);
-        if (variant == 208) return launch_conv_pp<E, 128, 2, 8>(CZ_CONV_ARGS);
-        if (variant == 240) return launch_conv_pp<E, 128, 2, 40>(CZ_CONV_ARGS);
-        if (variant == 101) return launch_conv<E, 128, 2, 2, 1, 1>(CZ_CONV_ARGS);
-        if (variant == 103) return launch_conv<E, 128, 2, 2, 1, 3>(CZ_CONV_ARGS);
-        if (variant == 113) return launch_conv<E, 128, 1, 2, 3, 3>(CZ_CONV_ARGS);
-        return launch_conv<E, 128, 2, 2, 1>(CZ_CONV_ARGS);
-    }
-    if (channels == 128 && parts == 1) {
-        if (variant == 12) return launch_conv<E, 128, 1, 1, 2>(CZ_CONV_ARGS);
-        if (variant == 13) return launch_conv<E, 128, 1, 1, 3>(CZ_CONV_ARGS);
-        if (variant == 22) return launch_conv<E, 128, 2, 1, 2>(CZ_CONV_ARGS);
-        if (variant == 23) return launch_conv<E, 128, 2, 1, 3>(CZ_CONV_ARGS);
-        return launch_conv<E, 128, 4, 1, 1>(CZ_CONV_ARGS);
-    }
+    if (channels == 128 && parts == 2) return launch_conv<E, 128, 2, 2, 1>(CZ_CONV_ARGS);
+    if (channels == 128 && parts == 1) return launch_conv<E, 128, 2, 1, 2>(CZ_CONV_ARGS);   // 2 workgroups / CU
     if (channels == 256 && parts == 2) return launch_conv<E, 256, 1, 2>(xh, xl, wp, bias, sh, sl, yh, yl, yf, n, relu, st);
     if (channels == 256 && parts == 1) return launch_conv<E, 256, 2, 1>(xh, xl, wp, bias, sh, sl, yh, yl, yf, n, relu, st);
     if (channels == 32 && parts == 2) return launch_conv<E, 32, 2, 2>(xh, xl, wp, bias, sh, sl, yh, yl, yf, n, relu, st);
@@ -852,6 +743,114 @@ extern "C" int cz_conv3x3(const void* x_hi, const void* x_lo, const void* w_pack
     return rc;
 }
 
+extern "C" size_t cz_input_conv_packed_elems(int channels, int in_planes, int parts)
+{
+    if (channels <= 0 || channels % 32 != 0 || parts < 1 || parts > 2 || in_planes < 1 || in_planes > 32) return 0;
+    const int ic16 = (in_planes + 15) / 16;
+    return (size_t)parts * (size_t)(25 + 3) * ic16 * (size_t)(channels / 32) * 64 * 8;
+}
+
+extern "C" int cz_input_conv_pack_weights(const float* w_oihw, int channels, int in_planes, int dtype, int parts,
+                                          void* out_host)
+{
+    if (!w_oihw || !out_host || cz_input_conv_packed_elems(channels, in_planes, parts) == 0 ||
+        (dtype != CZ_BF16 && dtype != CZ_F16)) {
+        czi_set_error("cz_input_conv_pack_weights: bad argument");
+        return CZ_ERR_ARG;
+    }
+    const int CT = channels / 32, ic16 = (in_planes + 15) / 16;
+    const size_t part_elems = (size_t)(25 + 3) * ic16 * CT * 64 * 8;
+    uint16_t* out = (uint16_t*)out_host;
+    memset(out, 0, part_elems * parts * sizeof(uint16_t));
+    for (int tap = 0; tap < 25; ++tap)
+        for (int g = 0; g < ic16; ++g)
+            for (int ct = 0; ct < CT; ++ct)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int o = ct * 32 + (lane & 31);
+                        const int c = g * 16 + (lane >> 5) * 8 + j;
+                        if (c >= in_planes) continue;
+                        const float w = w_oihw[((size_t)o * in_planes + c) * 25 + tap];
+                        const size_t idx = ((((size_t)tap * ic16 + g) * CT + ct) * 64 + lane) * 8 + j;
+                        if (dtype == CZ_BF16) {
+                            const uint16_t hi = f32_to_bf16_bits(w);
+                            out[idx] = hi;
+                            if (parts == 2) out[part_elems + idx] = f32_to_bf16_bits(w - bf16_bits_to_f32(hi));
+                        } else {
+                            const uint16_t hi = f32_to_f16_bits(w);
+                            out[idx] = hi;
+                            if (parts == 2) out[part_elems + idx] = f32_to_f16_bits(w - f16_bits_to_f32(hi));
+                        }
+                    }
+    return CZ_OK;
+}
+
+namespace {
+template <typename E, typename PT, int C>
+int launch_input_conv(const void* planes, int in_planes, const void* wp, const float* bias, void* yh, void* yl,
+                      int n, int parts, int relu, hipStream_t st)
+{
+    constexpr int P = 2;
+    const unsigned blocks = (unsigned)((n + P - 1) / P);
+#define CZ_IC(IC16, PARTS)                                                                                       \
+    hipLaunchKernelGGL((k_input_conv<E, PT, C, IC16, P, PARTS>), dim3(blocks), dim3(C / 32 * 64), 0, st,           \
+                       (const PT*)planes, (const E*)wp, bias, (E*)yh, (E*)yl, n, in_planes, relu)
+    if (in_planes <= 16) {
+        if (parts == 2) CZ_IC(1, 2); else CZ_IC(1, 1);
+    } else {
+        if (parts == 2) CZ_IC(2, 2); else CZ_IC(2, 1);
+    }
+#undef CZ_IC
+    return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
+}
+
+template <typename E, typename PT>
+int dispatch_input_conv(int channels, const void* planes, int in_planes, const void* wp, const float* bias, void* yh,
+                        void* yl, int n, int parts, int relu, hipStream_t st)
+{
+    if (channels == 128) return launch_input_conv<E, PT, 128>(planes, in_planes, wp, bias, yh, yl, n, parts, relu, st);
+    if (channels == 256) return launch_input_conv<E, PT, 256>(planes, in_planes, wp, bias, yh, yl, n, parts, relu, st);
+    if (channels == 32) return launch_input_conv<E, PT, 32>(planes, in_planes, wp, bias, yh, yl, n, parts, relu, st);
+    return CZ_ERR_ARG;
+}
+
+template <typename E>
+int dispatch_input_conv_pt(int planes_dtype, int channels, const void* planes, int in_planes, const void* wp,
+                           const float* bias, void* yh, void* yl, int n, int parts, int relu, hipStream_t st)
+{
+    switch (planes_dtype) {
+    case CZ_F32: return dispatch_input_conv<E, float>(channels, planes, in_planes, wp, bias, yh, yl, n, parts, relu, st);
+    case CZ_F16: return dispatch_input_conv<E, _Float16>(channels, planes, in_planes, wp, bias, yh, yl, n, parts, relu, st);
+    case CZ_BF16: return dispatch_input_conv<E, __bf16>(channels, planes, in_planes, wp, bias, yh, yl, n, parts, relu, st);
+    case CZ_U8: return dispatch_input_conv<E, unsigned char>(channels, planes, in_planes, wp, bias, yh, yl, n, parts, relu, st);
+    }
+    return CZ_ERR_ARG;
+}
+}  // namespace
+
+extern "C" int cz_input_conv(const void* planes, int planes_dtype, int in_planes, const void* w_packed,
+                             const float* bias, void* y_hi, void* y_lo, int n_boards, int channels, int dtype,
+                             int parts, int relu, void* stream)
+{
+    if (n_boards < 0 || !planes || !w_packed || !bias || !y_hi || (parts == 2 && !y_lo) || (parts != 1 && parts != 2) ||
+        in_planes < 1 || in_planes > 32) {
+        czi_set_error("cz_input_conv: bad argument");
+        return CZ_ERR_ARG;
+    }
+    if (n_boards == 0) return CZ_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = CZ_ERR_ARG;
+    if (dtype == CZ_BF16)
+        rc = dispatch_input_conv_pt<__bf16>(planes_dtype, channels, planes, in_planes, w_packed, bias, y_hi, y_lo,
+                                            n_boards, parts, relu, st);
+    else if (dtype == CZ_F16)
+        rc = dispatch_input_conv_pt<_Float16>(planes_dtype, channels, planes, in_planes, w_packed, bias, y_hi, y_lo,
+                                              n_boards, parts, relu, st);
+    if (rc == CZ_ERR_ARG) czi_set_error("cz_input_conv: unsupported channels / dtype");
+    else if (rc != CZ_OK) czi_set_error("cz_input_conv: launch failed");
+    return rc;
+}
+
 extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1,
                            const void* w2_packed, const float* bias2, void* y_hi, void* y_lo, float* y_f32,
                            int n_boards, int channels, int dtype, void* stream)
@@ -892,13 +891,13 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
             if (variant == 404) CZ_RB(__bf16, 104);
             static int shots = 0;
             if (++shots == 5) {
-                static long long h[2][64][8];
+                static long long h[64][8];
                 (void)hipDeviceSynchronize();
                 (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h));
                 for (int k = 2; k < 10; ++k) {
                     fprintf(stderr, "rb trace k%2d:", k);
                     for (int ph = 0; ph < 8; ++ph)
-                        fprintf(stderr, " %8lld", ph >= 6 ? h[0][k][ph] : (h[0][k][ph] - h[0][2][0]));
+                        fprintf(stderr, " %8lld", ph >= 6 ? h[k][ph] : (h[k][ph] - h[2][0]));
                     fprintf(stderr, "\n");
                 }
             }

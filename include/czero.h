@@ -199,6 +199,16 @@ size_t cz_conv3x3_packed_elems(int channels, int parts);
 /* HOST: w_oihw[channels][channels][3][3] fp32 -> MFMA fragment order, split into parts; out_host holds
  * cz_conv3x3_packed_elems() elements */
 int cz_conv3x3_pack_weights(const float* w_oihw, int channels, int dtype, int parts, void* out_host);
+/* The input convolution of the network (csrc/xq_conv.hip, k_input_conv): Conv2D(F, 5, padding="same") -> BatchNorm ->
+ * ReLU on the feature planes (agent/model.py:36-39), BatchNorm folded.  planes: [n_boards][in_planes][10][9] exactly as
+ * cz_encode / the search kernel write them (planes_dtype CZ_F32 / CZ_F16 / CZ_BF16 / CZ_U8, in_planes 14 or 28);
+ * output: the [n_boards][90][channels] operand (pair) the residual tower reads (dtype CZ_BF16 / CZ_F16, parts as in
+ * cz_conv3x3 -- the 0/1 planes are exact in 2 bytes, so parts = 2 splits only the weights). */
+int cz_input_conv(const void* planes, int planes_dtype, int in_planes, const void* w_packed, const float* bias,
+                  void* y_hi, void* y_lo, int n_boards, int channels, int dtype, int parts, int relu, void* stream);
+size_t cz_input_conv_packed_elems(int channels, int in_planes, int parts);
+/* HOST: w_oihw[channels][in_planes][5][5] fp32 -> MFMA fragment order (cz_input_conv_packed_elems() elements) */
+int cz_input_conv_pack_weights(const float* w_oihw, int channels, int in_planes, int dtype, int parts, void* out_host);
 /* fp32 activation x[rows][channels] (+ bias[c], may be NULL) -> ReLU? -> (y_hi, y_lo) operand pair (parts = 2) or
  * a plain bf16 / fp16 copy (parts = 1).  Used after the 5x5 input convolution. */
 int cz_split_bias_act(const float* x, const float* bias, void* y_hi, void* y_lo, size_t n_elems, int channels,

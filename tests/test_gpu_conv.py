@@ -114,6 +114,33 @@ def test_resblock_equals_two_convolutions(n):
         _native.resblock(x64, ps[0], bs[0], ps[1], bs[1], out=x64)
 
 
+@pytest.mark.parametrize("c,in_planes,dt,parts", [(128, 14, "bfloat16", 2), (128, 28, "bfloat16", 2),
+                                                  (128, 14, "float16", 1), (32, 14, "bfloat16", 2),
+                                                  (256, 14, "float16", 1), (256, 28, "bfloat16", 2)])
+@pytest.mark.parametrize("pdt", ["float32", "uint8"])
+def test_input_conv_against_float64(c, in_planes, dt, parts, pdt):
+    """cz_input_conv on real feature planes (0/1) in the search kernel's layout against a float64 conv2d of the same
+    weights: split mode <= 2e-5 relative (weights carry 2^-17), plain mode the 2-byte rounding of weights + result."""
+    import torch
+    import torch.nn.functional as F
+    from cchess_alphazero import _native
+    dtype = getattr(torch, dt)
+    n = 9
+    g = torch.Generator(device="cuda").manual_seed(c + in_planes)
+    planes = (torch.rand((n, in_planes, 10, 9), device="cuda", generator=g) < 0.15).float()
+    w = torch.randn((c, in_planes, 5, 5), device="cuda", generator=g) / (5.0 * in_planes ** 0.5)
+    b = torch.randn((c,), device="cuda", generator=g)
+    wp = _native.pack_input_conv_weights(w, dtype, parts).cuda()
+    out = tuple(torch.full((n, 90, c), 7.0, device="cuda", dtype=dtype) for _ in range(parts))
+    _native.input_conv(planes.to(getattr(torch, pdt)), wp, b, out)
+    got = sum(o.double() for o in out)
+    w_eff = w if parts == 2 else w.to(dtype).float()
+    ref = torch.relu(F.conv2d(planes.double(), w_eff.double(), b.double(), padding=2)).permute(0, 2, 3, 1)
+    ref = ref.reshape(n, 90, c)
+    rel = 2e-5 if parts == 2 else (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10)
+    assert (got - ref).abs().max().item() <= rel * ref.abs().max().item()
+
+
 def test_split_bias_act():
     import torch
     from cchess_alphazero import _native
