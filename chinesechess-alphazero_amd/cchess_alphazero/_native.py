@@ -63,6 +63,8 @@ def _declare(L):
         L.cz_conv3x3_packed_elems.restype = C.c_size_t
         L.cz_conv3x3_pack_weights.argtypes = [vp, i32, i32, i32, vp]
         L.cz_conv3x3_pack_weights.restype = i32
+        L.cz_head_convs.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        L.cz_head_convs.restype = i32
         L.cz_input_conv.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
         L.cz_input_conv.restype = i32
         L.cz_input_conv_packed_elems.argtypes = [i32, i32, i32]
@@ -261,6 +263,16 @@ def conv3x3(x, w_packed, bias, skip=None, out=None, out_f32=None, relu=True):
     check(lib().cz_conv3x3(_ptr(xh), _ptr(xl), _ptr(w_packed), _ptr(bias), _ptr(sh), _ptr(sl), _ptr(yh), _ptr(yl),
                            _ptr(out_f32), n, c, _dt_code(xh.dtype), parts, int(relu), _stream()), "cz_conv3x3")
     return out_f32 if out_f32 is not None else out
+
+
+def head_convs(x, w, bias, n_policy, policy_feat, value_feat):
+    """x [N, 90, C] trunk output -> relu(1x1 convs + bias): policy_feat [N, n_policy*90], value_feat [N, n_value*90]
+    (fp32, channels-first Flatten order).  w [n_policy + n_value, C] fp32."""
+    require_gpu()
+    n, c = x.shape[0], x.shape[-1]
+    check(lib().cz_head_convs(_ptr(x), _dt_code(x.dtype), _ptr(w), _ptr(bias), _ptr(policy_feat), _ptr(value_feat),
+                              n, c, n_policy, w.shape[0] - n_policy, _stream()), "cz_head_convs")
+    return policy_feat, value_feat
 
 
 def pack_input_conv_weights(w_oihw, dtype, parts):

@@ -142,7 +142,9 @@ class InferenceNet(nn.Module):
                 self.register_buffer(f"tb{i}b", b2)
             self.register_buffer("in_bias32", self._in_bias32)
             self.register_buffer("in_w", self._packed_in.view(torch.int16))
-            del self._packed_in, self._in_bias32
+            self.register_buffer("head_w32", self._head_w)
+            self.register_buffer("head_b32", self._head_b)
+            del self._packed_in, self._in_bias32, self._head_w, self._head_b
         self._bufs = {}
         self.eval()
         for p in self.parameters():
@@ -161,6 +163,9 @@ class InferenceNet(nn.Module):
         """fp32 folded filters -> MFMA fragment order (cz_conv3x3_pack_weights); called before the dtype conversion."""
         from cchess_alphazero import _native
         self._in_bias32 = self.input_conv.bias.detach().float().clone()
+        self._head_w = torch.cat([self.policy_conv.weight.detach().float().flatten(1),
+                                  self.value_conv.weight.detach().float().flatten(1)]).contiguous()
+        self._head_b = torch.cat([self.policy_conv.bias.detach().float(), self.value_conv.bias.detach().float()])
         self._packed_in = _native.pack_input_conv_weights(self.input_conv.weight, self.operand_dtype, self.parts)
         out = []
         for c1, c2 in self.res:
@@ -208,7 +213,7 @@ class InferenceNet(nn.Module):
                 _native.conv3x3(tmp, w2, getattr(self, f"tb{i}b"), skip=cur, out_f32=last)
             else:
                 _native.conv3x3(tmp, w2, getattr(self, f"tb{i}b"), skip=cur, out=(last,))
-        return last.view(n, 10, 9, c).permute(0, 3, 1, 2)                # logical NCHW over channels-last memory
+        return last                                                      # [n, 90, c] channels-last trunk output
 
     def _trunk_fused(self, x):
         """Trunk with the hand-written epilogue (csrc/xq_nn_epilogue.hip): every convolution is followed by ONE
@@ -229,7 +234,18 @@ class InferenceNet(nn.Module):
         if self.trunk == "mfma":
             if not planes.is_cuda:
                 raise RuntimeError("trunk='mfma' is the hand-written HIP path: it has no CPU implementation")
-            x = self._trunk_mfma(planes)
+            last = self._trunk_mfma(planes)
+            n, npol = last.shape[0], self.policy_conv.out_channels
+            if self.head_w32.shape[0] == 6:
+                from cchess_alphazero import _native
+                pf = torch.empty((n, npol * 90), dtype=torch.float32, device=last.device)
+                vf = torch.empty((n, (6 - npol) * 90), dtype=torch.float32, device=last.device)
+                _native.head_convs(last, self.head_w32, self.head_b32, npol, pf, vf)
+                p = self.policy_out(pf.to(self.dtype))
+                v = F.relu(self.value_dense(vf.to(self.dtype)))
+                v = torch.tanh(self.value_out(v).float())
+                return F.softmax(p.float(), dim=1), v.squeeze(1)
+            x = last.view(n, 10, 9, self.filters).permute(0, 3, 1, 2)    # logical NCHW over channels-last memory
         else:
             x = planes.to(self.dtype).contiguous(memory_format=torch.channels_last)
             if x.is_cuda and self.fused_epilogue and self.input_conv.out_channels % 8 == 0:

@@ -67,6 +67,74 @@ int launch(void* x, const void* bias, const void* res, size_t n_elems, int chann
     return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
 }
 
+// ---- the two 1x1 head convolutions in one pass ----------------------------------------------------------------------
+// Reference: policy head Conv2D(4, 1) -> BN -> ReLU -> Flatten and value head Conv2D(2, 1) -> BN -> ReLU -> Flatten
+// (agent/model.py:56-57, 62-63; BatchNorm folded).  Both read the same trunk output, so ONE streaming pass over
+// x[n][90][C] (channels-last) produces the NP + NV per-pixel outputs, written in the Flatten order of a
+// channels-first tensor ([n][c][pixel]) that the dense layers expect.  HBM-bound: reads x once.
+// 8 lanes per pixel; each lane takes every 8th float4 of the pixel's channel row (128 contiguous bytes per 8 lanes).
+template <typename T, int NO>
+__global__ __launch_bounds__(256) void k_head_convs(const T* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ pol,
+                                                   float* __restrict__ val, int n_pixels, int channels, int np)
+{
+    extern __shared__ float ws[];                       // [NO][channels]
+    for (int i = threadIdx.x; i < NO * channels; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int j = threadIdx.x & 7;
+    const int nv = NO - np;
+    for (long pix = (long)blockIdx.x * 32 + (threadIdx.x >> 3); pix < n_pixels; pix += (long)gridDim.x * 32) {
+        float acc[NO];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) acc[o] = 0.0f;
+        const T* row = x + pix * channels;
+        for (int c = j * 4; c < channels; c += 32) {
+            float v[4];
+            if (sizeof(T) == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(row + c);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                struct alignas(8) Q { T e[4]; };
+                const Q t = *reinterpret_cast<const Q*>(row + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = to_f(t.e[k]);
+            }
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                const float4 wv = *reinterpret_cast<const float4*>(ws + o * channels + c);
+                acc[o] += v[0] * wv.x + v[1] * wv.y + v[2] * wv.z + v[3] * wv.w;
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            acc[o] += __shfl_xor(acc[o], 1);
+            acc[o] += __shfl_xor(acc[o], 2);
+            acc[o] += __shfl_xor(acc[o], 4);
+        }
+        const long n = pix / 90;
+        const int q = (int)(pix - n * 90);
+#pragma unroll
+        for (int o = 0; o < NO; ++o)
+            if (j == o) {
+                float r = acc[o] + bias[o];
+                r = r > 0.0f ? r : 0.0f;
+                if (o < np) pol[n * (np * 90) + o * 90 + q] = r;
+                else val[n * (nv * 90) + (o - np) * 90 + q] = r;
+            }
+    }
+}
+
+template <typename T>
+int launch_heads(const void* x, const float* w, const float* bias, float* pol, float* val, long n_pixels,
+                 int channels, int np, hipStream_t st)
+{
+    long blocks = (n_pixels + 31) / 32;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL((k_head_convs<T, 6>), dim3((unsigned)blocks), dim3(256), 6 * channels * sizeof(float), st,
+                       (const T*)x, w, bias, pol, val, (int)n_pixels, channels, np);
+    return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
+}
+
 }  // namespace
 
 extern "C" int cz_bias_act(void* x, const void* bias, const void* residual, size_t n_elems, int channels, int dtype,
@@ -86,5 +154,31 @@ extern "C" int cz_bias_act(void* x, const void* bias, const void* residual, size
     default: czi_set_error("cz_bias_act: unknown dtype"); return CZ_ERR_ARG;
     }
     if (rc != CZ_OK) czi_set_error("cz_bias_act: launch failed");
+    return rc;
+}
+
+extern "C" int cz_head_convs(const void* x, int dtype, const float* w, const float* bias, float* policy_feat,
+                             float* value_feat, int n_boards, int channels, int n_policy, int n_value, void* stream)
+{
+    if (!x || !w || !bias || !policy_feat || !value_feat || n_boards < 0 || channels <= 0 || channels % 32 != 0 ||
+        n_policy + n_value != 6 || n_policy < 1 || n_value < 1 || channels > 1024) {
+        czi_set_error("cz_head_convs: bad argument (channels % 32 == 0, n_policy + n_value == 6)");
+        return CZ_ERR_ARG;
+    }
+    if (n_boards == 0) return CZ_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long n_pixels = (long)n_boards * 90;
+    if (n_pixels > 0x7fffffffL) {
+        czi_set_error("cz_head_convs: too many boards");
+        return CZ_ERR_ARG;
+    }
+    int rc;
+    switch (dtype) {
+    case CZ_F32: rc = launch_heads<float>(x, w, bias, policy_feat, value_feat, n_pixels, channels, n_policy, st); break;
+    case CZ_F16: rc = launch_heads<__half>(x, w, bias, policy_feat, value_feat, n_pixels, channels, n_policy, st); break;
+    case CZ_BF16: rc = launch_heads<__hip_bfloat16>(x, w, bias, policy_feat, value_feat, n_pixels, channels, n_policy, st); break;
+    default: czi_set_error("cz_head_convs: unknown dtype"); return CZ_ERR_ARG;
+    }
+    if (rc != CZ_OK) czi_set_error("cz_head_convs: launch failed");
     return rc;
 }

@@ -214,6 +214,14 @@ int cz_input_conv_pack_weights(const float* w_oihw, int channels, int in_planes,
 int cz_split_bias_act(const float* x, const float* bias, void* y_hi, void* y_lo, size_t n_elems, int channels,
                       int dtype, int parts, int relu, void* stream);
 
+/* The two 1x1 head convolutions (policy Conv2D(4,1), value Conv2D(2,1), BatchNorm folded, ReLU; agent/model.py:56-63)
+ * in one streaming pass over the trunk output x[n_boards][90][channels] (dtype CZ_F32 / CZ_F16 / CZ_BF16):
+ *   w[n_policy + n_value][channels] fp32 (policy filters first), bias[n_policy + n_value] fp32;
+ *   policy_feat[n_boards][n_policy * 90], value_feat[n_boards][n_value * 90] fp32 in channels-first Flatten order.
+ * n_policy + n_value must be 6 (the reference's 4 + 2). */
+int cz_head_convs(const void* x, int dtype, const float* w, const float* bias, float* policy_feat, float* value_feat,
+                  int n_boards, int channels, int n_policy, int n_value, void* stream);
+
 /* test hook: y[i] = sqrt((double)(x[i] + 1)) exactly as the PUCT kernel computes it */
 int cz_debug_sqrt(const int32_t* x, double* y, int n, void* stream);
 

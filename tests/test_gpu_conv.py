@@ -141,6 +141,23 @@ def test_input_conv_against_float64(c, in_planes, dt, parts, pdt):
     assert (got - ref).abs().max().item() <= rel * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("c,dt", [(128, "float32"), (256, "float16"), (32, "bfloat16")])
+def test_head_convs_against_float64(c, dt):
+    import torch
+    from cchess_alphazero import _native
+    n = 37
+    g = torch.Generator(device="cuda").manual_seed(c)
+    x = torch.randn((n, 90, c), device="cuda", generator=g).relu().to(getattr(torch, dt))
+    w = torch.randn((6, c), device="cuda", generator=g) / c ** 0.5
+    b = torch.randn((6,), device="cuda", generator=g)
+    pf = torch.full((n, 360), 7.0, device="cuda")
+    vf = torch.full((n, 180), 7.0, device="cuda")
+    _native.head_convs(x, w, b, 4, pf, vf)
+    ref = torch.relu(torch.einsum("npc,oc->nop", x.double(), w.double()) + b.double()[None, :, None])
+    assert (pf.double() - ref[:, :4].reshape(n, 360)).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    assert (vf.double() - ref[:, 4:].reshape(n, 180)).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
 def test_split_bias_act():
     import torch
     from cchess_alphazero import _native

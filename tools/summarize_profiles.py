@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof (written by tools/collect_profiles.sh on the GPU box) into the committed evidence:
+
+    profiles/rNN_bench_f32_kernel_stats.md   rocprofv3 --kernel-trace --stats summary of the default bench.py run
+    profiles/rNN_pmc_search_round.json       HBM bytes per cz_search_round launch (FETCH_SIZE / WRITE_SIZE passes)
+    profiles/rNN_pmc_nn.json                 MFMA utilisation + HBM bytes of the hand-written network kernels
+
+    python tools/summarize_profiles.py [--round 1] [--src gpurun_out/prof]
+Counter units and the gfx950 correction follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are
+reported in KiB; FETCH_SIZE counts a wide coalesced read at half its bytes (doubled here); separate --pmc passes.
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEARCH = ("k_noise", "k_sim", "k_advance")
+NN = ("k_resblock", "k_input_conv", "k_conv3x3", "k_split_bias_act", "k_bias_act")
+
+
+def short(name):
+    for k in SEARCH + NN + ("k_rules_tpb", "k_movegen_fix", "k_start_selfplay"):
+        if k in name:
+            return k
+    return name[:70]
+
+
+def read_counters(src, sub):
+    files = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
+    rows = []
+    for f in files:
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                rows.append((int(r["Dispatch_Id"]), short(r["Kernel_Name"]), r["Counter_Name"], float(r["Counter_Value"])))
+    rows.sort()
+    return rows
+
+
+def per_kernel(rows, skip_first=2):
+    """mean per launch of each counter for each kernel, excluding the first `skip_first` launches of that kernel"""
+    seen = collections.Counter()
+    first = {}
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for did, k, c, v in rows:
+        key = (k, c)
+        seen[key] += 1
+        if seen[key] > skip_first:
+            acc[k][c].append(v)
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} | {"launches": max(len(v) for v in d.values())}
+            for k, d in acc.items()}
+
+
+def search_rounds(rows, counter):
+    """sum of `counter` over the 5 launches of each cz_search_round (k_noise, k_sim, k_advance, k_noise, k_sim)"""
+    vals = [v for did, k, c, v in rows if c == counter and k in SEARCH]
+    return [sum(vals[i:i + 5]) for i in range(0, len(vals) - len(vals) % 5, 5)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--round", type=int, default=1)
+    ap.add_argument("--src", default=os.path.join(ROOT, "gpurun_out", "prof"))
+    a = ap.parse_args()
+    tag = f"r{a.round:02d}"
+    prof = os.path.join(ROOT, "profiles")
+
+    # ---- 1. kernel stats ----
+    sf = glob.glob(os.path.join(a.src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    if sf:
+        rows = list(csv.DictReader(open(sf[0])))
+        bench = {}
+        try:
+            bench = json.loads(open(os.path.join(a.src, "stats.json")).read().strip().splitlines()[-1])
+        except Exception:
+            pass
+        lines = [f"# rocprofv3 --kernel-trace --stats of `bench.py` (normal config, split-bf16 network), round {a.round}",
+                 "",
+                 "Command (GPU box): `cd /tmp && export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv "
+                 "-d gpurun_out/prof/stats -o s -- python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-micro`",
+                 ""]
+        if bench:
+            lines += [f"bench.py under the profiler: {bench.get('value', 0):.0f} expansions/s, "
+                      f"{bench.get('ms_per_step', 0):.2f} ms per round "
+                      f"(search-round kernels {bench.get('roofline', {}).get('avg_launch_ms', 0):.3f} ms).", ""]
+        lines += ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
+        for r in rows[:28]:
+            lines.append(f"| `{r['Name'][:100]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | "
+                         f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | "
+                         f"{float(r['MaxNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+        tf = glob.glob(os.path.join(a.src, "stats", "**", "*kernel_trace.csv"), recursive=True)
+        if tf:
+            tr = [r for r in csv.DictReader(open(tf[0])) if short(r["Kernel_Name"]) in SEARCH]
+            seq = [(short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+                    r.get("VGPR_Count", r.get("Arch_VGPR_Count", "")), r.get("Scratch_Size", ""),
+                    r.get("LDS_Block_Size", "")) for r in tr]
+            nr = len(seq) // 5
+            if nr >= 4:
+                lines += ["", f"## One lock-step round = 5 launches on one stream (mean of the last {nr - 3} rounds, us)", "",
+                          "| launch | mean us | VGPR | scratch B | LDS B |", "|---|---|---|---|---|"]
+                names = ["k_noise (before BACKUP)", "k_sim(BACKUP)", "k_advance", "k_noise (before SELECT)", "k_sim(SELECT)"]
+                tot = 0.0
+                for j in range(5):
+                    v = [seq[i * 5 + j][1] for i in range(3, nr)]
+                    m = sum(v) / len(v)
+                    tot += m
+                    lines.append(f"| {names[j]} | {m:.1f} | {seq[3 * 5 + j][2]} | {seq[3 * 5 + j][3]} | {seq[3 * 5 + j][4]} |")
+                lines.append(f"| **sum** | **{tot:.1f}** | | | |")
+        with open(os.path.join(prof, f"{tag}_bench_f32_kernel_stats.md"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+        print("wrote", f"{tag}_bench_f32_kernel_stats.md")
+
+    # ---- 2. HBM traffic of the search round ----
+    fetch = read_counters(a.src, "pmc_fetch")
+    write = read_counters(a.src, "pmc_write")
+    if fetch and write:
+        fr, wr = search_rounds(fetch, "FETCH_SIZE"), search_rounds(write, "WRITE_SIZE")
+        n = min(len(fr), len(wr))
+        fm = sum(fr[3:n]) / max(1, n - 3)
+        wm = sum(wr[3:n]) / max(1, n - 3)
+        out = {"kernels": "k_noise + k_sim(BACKUP) + k_advance + k_noise + k_sim(SELECT) = one cz_search_round",
+               "workload": "bench.py normal config (4096 games, K=8, 7x128 split-bf16 network, u8 planes queue), "
+                           f"steady-state rounds (first 3 of {n} excluded)",
+               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs (tools/collect_profiles.sh)",
+               "unit_note": "FETCH_SIZE / WRITE_SIZE are in KiB. Per MI355X_MICROARCH.md the gfx950 FETCH_SIZE reports a wide "
+                            "coalesced read at half its bytes (these reads are narrow gathers: uncalibrated); "
+                            "traffic_bytes uses 2*FETCH + WRITE as the conservative figure",
+               "FETCH_SIZE_KB_per_round": fr[:n], "FETCH_SIZE_KB_steady_mean": fm,
+               "WRITE_SIZE_KB_per_round": wr[:n], "WRITE_SIZE_KB_steady_mean": wm,
+               "traffic_bytes_per_launch": (2 * fm + wm) * 1024.0, "traffic_bytes_per_launch_raw": (fm + wm) * 1024.0}
+        with open(os.path.join(prof, f"{tag}_pmc_search_round.json"), "w") as f:
+            json.dump(out, f, indent=1)
+        print("wrote", f"{tag}_pmc_search_round.json", out["traffic_bytes_per_launch"] / 1e6, "MB per round")
+
+    # ---- 3. network kernels: MFMA utilisation and HBM bytes ----
+    sq = per_kernel(read_counters(a.src, "pmc_sq"))
+    grbm = per_kernel(read_counters(a.src, "pmc_grbm"))
+    fk, wk = per_kernel(fetch), per_kernel(write)
+    nn = {}
+    for k in NN:
+        if k not in sq:
+            continue
+        d = dict(sq[k])
+        gui = grbm.get(k, {}).get("GRBM_GUI_ACTIVE")
+        d["GRBM_GUI_ACTIVE"] = gui
+        if gui:
+            # MfmaUtil as rocprof defines it: matrix-pipe busy cycles / (kernel cycles x SIMDs on the chip).
+            # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (62.2 M per 4.0 ms launch = 8 x 1.94 GHz x 4.0 ms).
+            d["kernel_cycles"] = gui / 8.0
+            d["mfma_util"] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8.0 * 256 * 4)
+        wc = d.get("SQ_WAVE_CYCLES")
+        if wc:
+            for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+                d[c + "_frac_of_wave_cycles"] = d.get(c, 0.0) / wc
+        if d.get("SQ_LDS_IDX_ACTIVE"):
+            d["lds_bank_conflict_frac"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
+        if k in fk and k in wk:
+            d["FETCH_SIZE_KB"] = fk[k]["FETCH_SIZE"]
+            d["WRITE_SIZE_KB"] = wk[k]["WRITE_SIZE"]
+            d["hbm_bytes_per_launch"] = (2 * fk[k]["FETCH_SIZE"] + wk[k]["WRITE_SIZE"]) * 1024.0
+        nn[k] = d
+    if nn:
+        out = {"workload": "bench.py normal config: 32768 boards per launch, 7x128 network, split-bf16 operands",
+               "method": "rocprofv3 --pmc passes of tools/collect_profiles.sh (SQ set, GRBM_GUI_ACTIVE, FETCH_SIZE, "
+                         "WRITE_SIZE: one run each); means per launch, first 2 launches of each kernel excluded",
+               "mfma_util_definition": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs)",
+               "kernels": nn}
+        with open(os.path.join(prof, f"{tag}_pmc_nn.json"), "w") as f:
+            json.dump(out, f, indent=1)
+        print("wrote", f"{tag}_pmc_nn.json", {k: round(v.get("mfma_util", 0), 3) for k, v in nn.items()})
+
+
+if __name__ == "__main__":
+    main()
