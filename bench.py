@@ -146,6 +146,18 @@ def pmc_traffic():
     return d.get("traffic_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
 
 
+def pmc_nn(kernel):
+    """MFMA utilisation / HBM bytes per launch of a network kernel from the committed PMC passes (profiles/)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_nn.json")))
+    if not files:
+        return {}
+    with open(files[-1]) as f:
+        d = json.load(f).get("kernels", {}).get(kernel, {})
+    return {"hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "mfma_util": d.get("mfma_util"),
+            "source": os.path.relpath(files[-1], ROOT)}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -190,6 +202,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if eng.net is not None and not args.graph:
+        eng.net.block_events = []      # HIP events around every residual-block launch of the timed region (same stream)
     t0 = time.perf_counter()
     for i in range(args.steps):
         if args.graph:
@@ -252,12 +266,12 @@ def main():
                            "terminal_sims": d["terminal_sims"], "repetition_sims": d["repetition_sims"],
                            "parked": d["parked"], "tree_resets": d["tree_resets"],
                            "overflow_sims": d["overflow_sims"] + d["depth_overflow"]},
-            "roofline": None, "roofline_nn": None, "cpu_baseline": None,
+            "roofline": None, "roofline_search": None, "roofline_nn": None, "cpu_baseline": None,
         }
         if k_ms is not None:
             ach = bpe * exp_per_launch / (k_ms * 1e-3) / 1e9
             traffic, traffic_src = pmc_traffic()
-            out["roofline"] = {"kernel": "cz_search_round = k_sim(BACKUP) + k_advance + k_sim(SELECT) (+ k_noise x2)", "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+            out["roofline_search"] = {"kernel": "cz_search_round = k_sim(BACKUP) + k_advance + k_sim(SELECT) (+ k_noise x2)", "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                                "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": bpe * exp_per_launch, "avg_launch_ms": k_ms,
                                "bytes_per_expansion": bpe, "expansions_per_launch": exp_per_launch,
@@ -276,6 +290,30 @@ def main():
                                                                       else "") + "MIOpen/hipBLASLt)",
                                       "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
                                       "frac": tf / peak, "ms": nn_ms, "positions_per_forward": slots}
+        blk = getattr(eng.net, "block_events", None) if eng.net is not None else None
+        if blk:
+            # the dominant kernel: k_resblock (one residual block of the tower per launch), > 90 % of a round
+            b_ms = sum(a.elapsed_time(b) for a, b in blk) / len(blk)
+            f = cfg.model.cnn_filter_num
+            flops_launch = 2 * 2.0 * 90 * f * f * 9 * slots          # two 3x3 convolutions, 2 flop per MAC
+            tfl = flops_launch / (b_ms * 1e-3) / 1e12
+            pmc = pmc_nn("k_resblock")
+            out["roofline"] = {"kernel": "k_resblock (csrc/xq_conv.hip): one residual block (2 x conv3x3 + bias + skip "
+                                         "+ ReLU) of the tower per launch, split-bf16 operands",
+                               "bound": "mfma", "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s", "frac": tfl / 2500.0,
+                               "traffic": pmc.get("hbm_bytes_per_launch"), "traffic_source": pmc.get("source"),
+                               "avg_launch_ms": b_ms, "launches_timed": len(blk),
+                               "algorithmic_flops_per_launch": flops_launch,
+                               "issued_bf16_tflops": 3.0 * tfl * 96.0 / 90.0,
+                               "issued_frac_of_peak": 3.0 * tfl * 96.0 / 90.0 / 2500.0,
+                               "mfma_util_pmc": pmc.get("mfma_util"),
+                               "share_of_round": b_ms * len(blk) / args.steps / step_ms,
+                               "note": "achieved = fp32-class convolution FLOPs (2 per MAC); every product is three "
+                                       "bf16 MFMAs on (hi, lo) operand pairs over 96 pixel slots per 90-pixel board, "
+                                       "hence issued_bf16_tflops = 3.2 x achieved; against the fp32 matrix peak "
+                                       "(157.3 TFLOP/s) the same number is > 1"}
+        else:
+            out["roofline"] = out.get("roofline_search")
         if not args.no_micro:
             out["micro_suite"] = micro_suite()
             log("micro-suite done")

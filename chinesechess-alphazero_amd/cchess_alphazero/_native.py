@@ -71,7 +71,7 @@ def _declare(L):
         L.cz_input_conv_packed_elems.restype = C.c_size_t
         L.cz_input_conv_pack_weights.argtypes = [vp, i32, i32, i32, i32, vp]
         L.cz_input_conv_pack_weights.restype = i32
-        L.cz_resblock.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+        L.cz_resblock.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
         L.cz_resblock.restype = i32
         L.cz_split_bias_act.argtypes = [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, vp]
         L.cz_split_bias_act.restype = i32
@@ -306,15 +306,18 @@ def input_conv(planes, w_packed, bias, out, relu=True):
 
 
 def resblock(x, w1_packed, bias1, w2_packed, bias2, out=None, out_f32=None):
-    """One residual block relu(conv(relu(conv(x, w1) + b1), w2) + b2 + x) in a single launch (split operands only:
-    x and out are (hi, lo) tuples of [N, 90, 128] tensors; out_f32 receives fp32 instead of `out`)."""
+    """One residual block relu(conv(relu(conv(x, w1) + b1), w2) + b2 + x) in a single launch.  x and out are (hi,) or
+    (hi, lo) tuples of [N, 90, C] tensors; out_f32 (split operands only) receives fp32 instead of `out`."""
     require_gpu()
-    xh, xl = x
+    parts = len(x)
+    xh = x[0]
     n, c = xh.shape[0], xh.shape[-1]
+    xl = x[1] if parts == 2 else None
     yh = out[0] if out is not None else None
-    yl = out[1] if out is not None else None
+    yl = out[1] if out is not None and parts == 2 else None
     check(lib().cz_resblock(_ptr(xh), _ptr(xl), _ptr(w1_packed), _ptr(bias1), _ptr(w2_packed), _ptr(bias2),
-                            _ptr(yh), _ptr(yl), _ptr(out_f32), n, c, _dt_code(xh.dtype), _stream()), "cz_resblock")
+                            _ptr(yh), _ptr(yl), _ptr(out_f32), n, c, _dt_code(xh.dtype), parts, _stream()),
+          "cz_resblock")
     return out_f32 if out_f32 is not None else out
 
 

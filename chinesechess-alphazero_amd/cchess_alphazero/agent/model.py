@@ -114,6 +114,7 @@ class InferenceNet(nn.Module):
         self.trunk = trunk
         self.fused_epilogue = True          # on the GPU: hand-written bias + skip + ReLU pass after each conv
         self.fused_blocks = True            # trunk="mfma", fp32, 128 filters: one launch per residual block
+        self.block_events = None            # bench.py: list collecting (start, end) HIP events around tower launches
         self.input_depth = net.cfg["input_depth"]
         self.filters = net.cfg["cnn_filter_num"]
         with torch.no_grad():
@@ -193,17 +194,27 @@ class InferenceNet(nn.Module):
         (cur, tmp, nxt), last = self._operands(n, planes.device)
         _native.input_conv(planes.contiguous(), self.in_w.view(self.operand_dtype), self.in_bias32, cur)
         nblk = len(self.res)
-        fused = self.parts == 2 and c == 128 and self.fused_blocks     # whole residual block in one launch
+        # whole residual block in one launch where k_resblock exists for the shape
+        fused = self.fused_blocks and ((c == 128) or (c == 256 and self.parts == 1))
         for i in range(nblk):
             w1 = getattr(self, f"tw{i}a").view(self.operand_dtype)
             w2 = getattr(self, f"tw{i}b").view(self.operand_dtype)
             if fused:
                 b1, b2 = getattr(self, f"tb{i}a"), getattr(self, f"tb{i}b")
+                ev = None
+                if self.block_events is not None:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
                 if i + 1 < nblk:
                     _native.resblock(cur, w1, b1, w2, b2, out=nxt)
                     cur, nxt = nxt, cur
-                else:
+                elif self.parts == 2:
                     _native.resblock(cur, w1, b1, w2, b2, out_f32=last)
+                else:
+                    _native.resblock(cur, w1, b1, w2, b2, out=(last,))
+                if ev is not None:
+                    ev[1].record()
+                    self.block_events.append(ev)
                 continue
             _native.conv3x3(cur, w1, getattr(self, f"tb{i}a"), out=tmp)
             if i + 1 < nblk:

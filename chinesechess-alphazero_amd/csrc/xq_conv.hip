@@ -80,19 +80,20 @@ template <int C, int P, int PARTS> struct Geom {
 };
 
 // global -> registers: the P boards starting at board n0 (16 bytes per lane per iteration, fully coalesced)
-template <typename E, int C, int P, int PARTS, bool SKIP_LOADS = false>
+template <typename E, int C, int P, int PARTS, bool SKIP_LOADS = false, int NTHR = Geom<C, P, PARTS>::GTHREADS>
 __device__ __forceinline__ void tile_load(const E* xh, const E* xl, int n0, int n_boards, int gtid,
-                                          uint4 (*v)[Geom<C, P, PARTS>::ITER])
+                                          uint4 (*v)[(Geom<C, P, PARTS>::CHUNKS + NTHR - 1) / NTHR])
 {
     typedef Geom<C, P, PARTS> G;
+    constexpr int ITER = (G::CHUNKS + NTHR - 1) / NTHR;
     const bool full = n0 + P <= n_boards;
 #pragma unroll
     for (int part = 0; part < PARTS; ++part) {
         const uint4* src = reinterpret_cast<const uint4*>((part ? xl : xh) + (size_t)n0 * 90 * C);
 #pragma unroll
-        for (int it = 0; it < G::ITER; ++it) {
-            const int i = it * G::GTHREADS + gtid;
-            const bool ok = ((it + 1) * G::GTHREADS <= G::CHUNKS || i < G::CHUNKS) &&
+        for (int it = 0; it < ITER; ++it) {
+            const int i = it * NTHR + gtid;
+            const bool ok = ((it + 1) * NTHR <= G::CHUNKS || i < G::CHUNKS) &&
                             (full || n0 + i / (G::CPR * 90) < n_boards);
             v[part][it] = make_uint4(0, 0, 0, 0);
             if (ok && !SKIP_LOADS) v[part][it] = src[i];
@@ -101,19 +102,20 @@ __device__ __forceinline__ void tile_load(const E* xh, const E* xl, int n0, int 
 }
 
 // registers -> LDS image: [row][chunk ^ (row & SWZ)], plus the all-zero row
-template <int C, int P, int PARTS>
+template <int C, int P, int PARTS, int NTHR = Geom<C, P, PARTS>::GTHREADS>
 __device__ __forceinline__ void tile_write(unsigned char* region, int gtid,
-                                           const uint4 (*v)[Geom<C, P, PARTS>::ITER])
+                                           const uint4 (*v)[(Geom<C, P, PARTS>::CHUNKS + NTHR - 1) / NTHR])
 {
     typedef Geom<C, P, PARTS> G;
+    constexpr int ITER = (G::CHUNKS + NTHR - 1) / NTHR;
 #pragma unroll
     for (int part = 0; part < PARTS; ++part) {
         unsigned char* dst = region + part * G::PART_BYTES;
 #pragma unroll
-        for (int it = 0; it < G::ITER; ++it) {
-            const int i = it * G::GTHREADS + gtid;
+        for (int it = 0; it < ITER; ++it) {
+            const int i = it * NTHR + gtid;
             const int row = i / G::CPR, ch = i % G::CPR;
-            if ((it + 1) * G::GTHREADS <= G::CHUNKS || i < G::CHUNKS)
+            if ((it + 1) * NTHR <= G::CHUNKS || i < G::CHUNKS)
                 *reinterpret_cast<uint4*>(dst + row * G::RB + ((ch ^ (row & G::SWZ)) << 4)) = v[part][it];
         }
         if (gtid < G::CPR) *reinterpret_cast<uint4*>(dst + G::ZROW * G::RB + gtid * 16) = make_uint4(0, 0, 0, 0);
@@ -286,106 +288,123 @@ __global__ __launch_bounds__(C / 32 * 64, MINW) void k_conv3x3(
 
 __device__ long long g_trace[64][8];     // tuning probe (DBG & 8): [board k][phase] time stamps of block 0
 
-// ---- kernel 2: a whole residual block per launch, wave-specialised (split precision) -------------------------------
-// y = relu(conv2(relu(conv1(x) + b1)) + b2 + x) for one board at a time per workgroup, persistent over boards.
+// ---- kernel 2: a whole residual block per launch, wave-specialised ---------------------------------------------------
+// y = relu(conv2(relu(conv1(x) + b1)) + b2 + x) for P boards at a time per workgroup, persistent over boards.
 // The intermediate activation never leaves LDS (it is written straight into a second operand image), the skip
 // operand is read back from the first image, and HBM sees one read of x and one write of y per block instead of
-// 2 reads + 1 skip read + 2 writes.  Waves 0..CT-1 ("matrix waves", one per SIMD) only run K loops and the two
-// register-level epilogues; waves CT..2CT-1 ("copy waves") own all global traffic: they fetch the NEXT board into
-// registers while the matrix waves work (their vmcnt is their own, so nothing in the K loop waits for it), drop it
-// into the X image the moment the matrix waves are done with it, and stream the PREVIOUS board's staged fp32
-// result out (ReLU'd, re-split into hi/lo, 16 bytes per lane) under the next K loop.
-//   LDS: X image (hi, lo) 46.6 KB | Y image (hi, lo) 46.6 KB | fp32 staging 46.1 KB  = 139 KB, one workgroup per CU.
-//   barriers per board: A (X ready) .. K1 .. epi1 -> Y .. B (Y ready) .. K2 .. epi2 -> staging .. C (staged, X free)
-template <typename E, int C, int DBG = 0>
-__global__ __launch_bounds__(2 * (C / 32) * 64, 2) void k_resblock(
+// 2 reads + 1 skip read + 2 writes.  Waves 0..CT-1 ("matrix waves", 32 output channels each) only run K loops and the
+// two register-level epilogues; 4 more waves ("copy waves") own all global traffic: they fetch the NEXT boards into
+// registers while the matrix waves work (their vmcnt is their own, so nothing in the K loop waits for it), drop them
+// into the X image the moment the matrix waves are done with it, and stream the PREVIOUS boards' staged result out
+// (16 bytes per lane, re-split into hi/lo in split mode) under the next K loop.
+//   LDS: X image | Y image | staging (fp32 in split mode, final 2-byte values otherwise); one workgroup per CU:
+//     128 filters split  (P = 1): 46.6 + 46.6 + 46.1 KB, 4 + 4 waves      128 filters plain (P = 2): the same bytes
+//     256 filters plain  (P = 1): 46.6 + 46.6 + 46.1 KB, 8 + 4 waves
+//   barriers per tile: A (X ready) .. K1 .. epi1 -> Y .. B (Y ready) .. K2 .. epi2 -> staging .. C (staged, X free)
+constexpr int RB_COPY_THREADS = 256;
+
+template <typename E, int C, int PARTS, int P, int DBG = 0>
+__global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_resblock(
     const E* __restrict__ xh, const E* __restrict__ xl, const E* __restrict__ w1p, const float* __restrict__ b1,
     const E* __restrict__ w2p, const float* __restrict__ b2, E* __restrict__ yh, E* __restrict__ yl,
     float* __restrict__ yf, int n_boards)
 {
-    constexpr int P = 1, PARTS = 2;
     typedef Geom<C, P, PARTS> G;
-    constexpr int NT = G::NT, CT = G::CT, GT = G::GTHREADS;
-    constexpr int SROW = C * 4;                        // fp32 staging row (one pixel)
-    constexpr int PIECES = 90 * (C / 8);               // 8-channel output pieces per board
-    constexpr int EITER = (PIECES + GT - 1) / GT;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::REGION + 90 * SROW];
+    constexpr int NT = G::NT, CT = G::CT, CTHR = RB_COPY_THREADS;
+    constexpr int SROW = PARTS == 2 ? C * 4 : C * 2;   // staging row (one pixel): fp32, or the final 2-byte values
+    constexpr int PIECES = P * 90 * (C / 8);           // 8-channel output pieces per tile
+    constexpr int EITER = (PIECES + CTHR - 1) / CTHR;
+    constexpr int LITER = (G::CHUNKS + CTHR - 1) / CTHR;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::REGION + P * 90 * SROW];
     unsigned char* X = lds;
     unsigned char* Y = lds + G::REGION;
     unsigned char* S = lds + 2 * G::REGION;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool copy_role = wave >= CT;
-    const int wg = wave % CT, gtid = tid % GT;
-    int b = blockIdx.x;
-    if (b >= n_boards) return;
+    const int n_tiles = (n_boards + P - 1) / P;
+    int t = blockIdx.x;                                 // tile = P consecutive boards
+    if (t >= n_tiles) return;
     const int stride = gridDim.x;
+    // staging offset of channels ch..ch+3 of tile pixel qq
+    auto stage_off = [&](int qq, int ch) {
+        if (PARTS == 2) return qq * SROW + ((((ch >> 2) & ~7) | (((ch >> 2) ^ qq) & 7)) << 4);
+        return qq * SROW + ((((ch >> 3) ^ (qq & G::SWZ))) << 4) + (ch & 7) * 2;
+    };
 
     if (copy_role) {
-        uint4 v[PARTS][G::ITER];
-        tile_load<E, C, P, PARTS, (DBG & 2) != 0>(xh, xl, b, n_boards, gtid, v);
-        tile_write<C, P, PARTS>(X, gtid, v);
-        int b_prev = -1;
+        const int ctid = tid - CT * 64;
+        uint4 v[PARTS][LITER];
+        tile_load<E, C, P, PARTS, (DBG & 2) != 0, CTHR>(xh, xl, t * P, n_boards, ctid, v);
+        tile_write<C, P, PARTS, CTHR>(X, ctid, v);
+        int t_prev = -1;
         for (;;) {
-            __syncthreads();                                   // A: X holds board b
-            const int bn = b + stride;
-            const bool has_next = bn < n_boards;
-            int gt2 = gtid;
-            asm volatile("" : "+v"(gt2));                      // keep address arithmetic inside the loop (registers)
-            if (has_next) tile_load<E, C, P, PARTS, (DBG & 2) != 0>(xh, xl, bn, n_boards, gt2, v);
-            // stream out the previous board (staged fp32, already ReLU'd) while the matrix waves run K1
-            auto store_board = [&](int bo) {
-                const size_t ebase = (size_t)bo * 90 * C;
+            __syncthreads();                                   // A: X holds tile t
+            const int tn = t + stride;
+            const bool has_next = tn < n_tiles;
+            int ct2 = ctid;
+            asm volatile("" : "+v"(ct2));                      // keep address arithmetic inside the loop (registers)
+            if (has_next) tile_load<E, C, P, PARTS, (DBG & 2) != 0, CTHR>(xh, xl, tn * P, n_boards, ct2, v);
+            // stream out the previous tile (staged, already ReLU'd) while the matrix waves run K1
+            auto store_tile = [&](int to) {
+                const size_t ebase = (size_t)to * P * 90 * C;
+                const int valid = (n_boards - to * P < P ? n_boards - to * P : P) * 90 * (C / 8);
 #pragma unroll
                 for (int it = 0; it < EITER; ++it) {
-                    const int i = it * GT + gt2;
-                    if (!((it + 1) * GT <= PIECES || i < PIECES)) continue;
-                    const int q = i / (C / 8), c8 = i % (C / 8);
-                    const unsigned char* row = S + q * SROW + ((c8 >> 2) << 7);
-                    const float4 f0 = *reinterpret_cast<const float4*>(row + (((2 * c8) ^ q) & 7) * 16);
-                    const float4 f1 = *reinterpret_cast<const float4*>(row + (((2 * c8 + 1) ^ q) & 7) * 16);
-                    const float r[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-                    if (DBG & 1) continue;
-                    if (yf) {
-                        float4* o = reinterpret_cast<float4*>(yf + ebase) + 2 * i;
-                        o[0] = f0;
-                        o[1] = f1;
-                    } else {
-                        struct alignas(16) E8 { E e[8]; };
-                        E8 hi, lo;
+                    const int i = it * CTHR + ct2;
+                    if (!((it + 1) * CTHR <= PIECES || i < PIECES) || i >= valid) continue;
+                    const int qq = i / (C / 8), c8 = i % (C / 8);
+                    if (PARTS == 2) {
+                        const float4 f0 = *reinterpret_cast<const float4*>(S + stage_off(qq, c8 * 8));
+                        const float4 f1 = *reinterpret_cast<const float4*>(S + stage_off(qq, c8 * 8 + 4));
+                        const float r[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                        if (DBG & 1) continue;
+                        if (yf) {
+                            float4* o = reinterpret_cast<float4*>(yf + ebase) + 2 * i;
+                            o[0] = f0;
+                            o[1] = f1;
+                        } else {
+                            struct alignas(16) E8 { E e[8]; };
+                            E8 hi, lo;
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            hi.e[k] = (E)r[k];
-                            lo.e[k] = (E)(r[k] - (float)hi.e[k]);
+                            for (int k = 0; k < 8; ++k) {
+                                hi.e[k] = (E)r[k];
+                                lo.e[k] = (E)(r[k] - (float)hi.e[k]);
+                            }
+                            reinterpret_cast<uint4*>(yh + ebase)[i] = __builtin_bit_cast(uint4, hi);
+                            reinterpret_cast<uint4*>(yl + ebase)[i] = __builtin_bit_cast(uint4, lo);
                         }
-                        reinterpret_cast<uint4*>(yh + ebase)[i] = __builtin_bit_cast(uint4, hi);
-                        reinterpret_cast<uint4*>(yl + ebase)[i] = __builtin_bit_cast(uint4, lo);
+                    } else {
+                        const uint4 f = *reinterpret_cast<const uint4*>(S + stage_off(qq, c8 * 8));
+                        if (DBG & 1) continue;
+                        reinterpret_cast<uint4*>(yh + ebase)[i] = f;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            if (b_prev >= 0) store_board(b_prev);
+            if (t_prev >= 0) store_tile(t_prev);
             __syncthreads();                                   // B
-            __syncthreads();                                   // C: board b is staged, X is free
-            if (has_next) tile_write<C, P, PARTS>(X, gt2, v);
-            b_prev = b;
+            __syncthreads();                                   // C: tile t is staged, X is free
+            if (has_next) tile_write<C, P, PARTS, CTHR>(X, ct2, v);
+            t_prev = t;
             if (!has_next) {
-                store_board(b);
+                store_tile(t);
                 break;
             }
-            b = bn;
+            t = tn;
         }
         return;
     }
 
     // ---- matrix waves ----
+    const int wg = wave;
     const uint4* wq1 = reinterpret_cast<const uint4*>(w1p) + wg * 64 + lane;
     const uint4* wq2 = reinterpret_cast<const uint4*>(w2p) + wg * 64 + lane;
     const int kb = lane >> 5, ln = lane & 31;
     int kiter = 0;
     for (;;) {
         __syncthreads();                                       // A
-        const bool has_next = b + stride < n_boards;
+        const bool has_next = t + stride < n_tiles;
         f32x16 acc[NT];
 #define CZ_STAMP2(ph, val) do { if ((DBG & 8) && blockIdx.x == 0 && tid == 0 && kiter < 64) g_trace[kiter][ph] = (val); } while (0)
         CZ_STAMP2(0, wall_clock64());
@@ -395,12 +414,13 @@ __global__ __launch_bounds__(2 * (C / 32) * 64, 2) void k_resblock(
         __builtin_amdgcn_s_setprio(0);
         CZ_STAMP2(1, wall_clock64());
         CZ_STAMP2(6, clock64() - cyc0);
-        int ln2 = ln, kb2 = kb, gt2 = gtid;
+        int ln2 = ln, kb2 = kb, gt2 = tid;
         asm volatile("" : "+v"(ln2), "+v"(kb2), "+v"(gt2));
         // epilogue 1: relu(acc + b1) -> (hi, lo) -> Y image (operand layout of the second convolution)
 #pragma unroll
         for (int p = 0; p < NT; ++p) {
-            const int q = p * 32 + ln2;
+            const int q = (p % 3) * 32 + ln2;
+            const int row = (p / 3) * 90 + q;
             if (q < 90) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -415,15 +435,16 @@ __global__ __launch_bounds__(2 * (C / 32) * 64, 2) void k_resblock(
                         hi.e[i] = (E)r;
                         lo.e[i] = (E)(r - (float)hi.e[i]);
                     }
-                    const int off = q * G::RB + ((((ch >> 3) ^ q) & G::SWZ) << 4) + (ch & 7) * 2;
+                    const int off = row * G::RB + (((ch >> 3) ^ (row & G::SWZ)) << 4) + (ch & 7) * 2;
                     *reinterpret_cast<Quad<E>*>(Y + off) = hi;
-                    *reinterpret_cast<Quad<E>*>(Y + G::PART_BYTES + off) = lo;
+                    if (PARTS == 2) *reinterpret_cast<Quad<E>*>(Y + G::PART_BYTES + off) = lo;
                 }
             }
         }
         if (gt2 < G::CPR) {
-            *reinterpret_cast<uint4*>(Y + G::ZROW * G::RB + gt2 * 16) = make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(Y + G::PART_BYTES + G::ZROW * G::RB + gt2 * 16) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int part = 0; part < PARTS; ++part)
+                *reinterpret_cast<uint4*>(Y + part * G::PART_BYTES + G::ZROW * G::RB + gt2 * 16) = make_uint4(0, 0, 0, 0);
         }
         CZ_STAMP2(2, wall_clock64());
         __syncthreads();                                       // B: Y complete
@@ -435,35 +456,44 @@ __global__ __launch_bounds__(2 * (C / 32) * 64, 2) void k_resblock(
         CZ_STAMP2(4, wall_clock64());
         CZ_STAMP2(7, clock64() - cyc0);
         asm volatile("" : "+v"(ln2), "+v"(kb2));
-        // epilogue 2: relu(acc + b2 + x) -> fp32 staging (chunks swizzled by pixel & 7)
+        // epilogue 2: relu(acc + b2 + x) -> staging
 #pragma unroll
         for (int p = 0; p < NT; ++p) {
-            const int q = p * 32 + ln2;
+            const int q = (p % 3) * 32 + ln2;
+            const int row = (p / 3) * 90 + q;
             if (q < 90) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int ch = wg * 32 + g * 8 + kb2 * 4;
                     const float4 bv = *reinterpret_cast<const float4*>(b2 + ch);
-                    const int off = q * G::RB + ((((ch >> 3) ^ q) & G::SWZ) << 4) + (ch & 7) * 2;
+                    const int off = row * G::RB + (((ch >> 3) ^ (row & G::SWZ)) << 4) + (ch & 7) * 2;
                     const Quad<E> sh = *reinterpret_cast<const Quad<E>*>(X + off);
-                    const Quad<E> sl = *reinterpret_cast<const Quad<E>*>(X + G::PART_BYTES + off);
                     float vv[4] = {acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
                                    acc[p][g * 4 + 3] + bv.w};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        vv[i] += (float)sh.e[i];
-                        vv[i] += (float)sl.e[i];
-                        vv[i] = vv[i] > 0.0f ? vv[i] : 0.0f;
+                    for (int i = 0; i < 4; ++i) vv[i] += (float)sh.e[i];
+                    if (PARTS == 2) {
+                        const Quad<E> sl = *reinterpret_cast<const Quad<E>*>(X + G::PART_BYTES + off);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) vv[i] += (float)sl.e[i];
                     }
-                    *reinterpret_cast<float4*>(S + q * SROW + ((((ch >> 2) ^ q) & 7) << 4) + ((ch >> 5) << 7)) =
-                        make_float4(vv[0], vv[1], vv[2], vv[3]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) vv[i] = vv[i] > 0.0f ? vv[i] : 0.0f;
+                    if (PARTS == 2) {
+                        *reinterpret_cast<float4*>(S + stage_off(row, ch)) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    } else {
+                        Quad<E> o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o.e[i] = (E)vv[i];
+                        *reinterpret_cast<Quad<E>*>(S + stage_off(row, ch)) = o;
+                    }
                 }
             }
         }
         CZ_STAMP2(5, wall_clock64());
         __syncthreads();                                       // C: staged; X may be replaced
         if (!has_next) break;
-        b += stride;
+        t += stride;
         ++kiter;
     }
 #undef CZ_STAMP2
@@ -851,20 +881,65 @@ extern "C" int cz_input_conv(const void* planes, int planes_dtype, int in_planes
     return rc;
 }
 
+namespace {
+template <typename E, int C, int PARTS, int P, int DBG = 0>
+int launch_resblock(const void* xh, const void* xl, const void* w1, const float* b1, const void* w2, const float* b2,
+                    void* yh, void* yl, float* yf, int n, int n_cu, hipStream_t st)
+{
+    const int tiles = (n + P - 1) / P;
+    const unsigned blocks = (unsigned)(tiles < n_cu ? tiles : n_cu);
+    hipLaunchKernelGGL((k_resblock<E, C, PARTS, P, DBG>), dim3(blocks), dim3((C / 32 + 4) * 64), 0, st, (const E*)xh,
+                       (const E*)xl, (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, yf, n);
+    return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
+}
+
+void print_trace()          // tuning probe (CZ_CONV_VARIANT=308): phase time stamps of workgroup 0, 5th launch
+{
+    static int shots = 0;
+    if (++shots != 5) return;
+    static long long h[64][8];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h));
+    for (int k = 2; k < 10; ++k) {
+        fprintf(stderr, "rb trace k%2d:", k);
+        for (int ph = 0; ph < 8; ++ph) fprintf(stderr, " %8lld", ph >= 6 ? h[k][ph] : (h[k][ph] - h[2][0]));
+        fprintf(stderr, "\n");
+    }
+}
+
+template <typename E>
+int dispatch_resblock(int channels, int parts, const void* xh, const void* xl, const void* w1, const float* b1,
+                      const void* w2, const float* b2, void* yh, void* yl, float* yf, int n, int n_cu, hipStream_t st)
+{
+    static const int variant = getenv("CZ_CONV_VARIANT") ? atoi(getenv("CZ_CONV_VARIANT")) : 0;   // tuning probe
+#define CZ_RB_ARGS xh, xl, w1, b1, w2, b2, yh, yl, yf, n, n_cu, st
+    if (channels == 128 && parts == 2) {
+        if (variant == 301) return launch_resblock<E, 128, 2, 1, 1>(CZ_RB_ARGS);
+        if (variant == 303) return launch_resblock<E, 128, 2, 1, 3>(CZ_RB_ARGS);
+        if (variant == 308) {
+            const int rc = launch_resblock<E, 128, 2, 1, 8>(CZ_RB_ARGS);
+            print_trace();
+            return rc;
+        }
+        return launch_resblock<E, 128, 2, 1>(CZ_RB_ARGS);
+    }
+    if (channels == 128 && parts == 1) return launch_resblock<E, 128, 1, 2>(CZ_RB_ARGS);
+    if (channels == 256 && parts == 1) return launch_resblock<E, 256, 1, 1>(CZ_RB_ARGS);
+#undef CZ_RB_ARGS
+    return CZ_ERR_ARG;
+}
+}  // namespace
+
 extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1,
                            const void* w2_packed, const float* bias2, void* y_hi, void* y_lo, float* y_f32,
-                           int n_boards, int channels, int dtype, void* stream)
+                           int n_boards, int channels, int dtype, int parts, void* stream)
 {
-    if (n_boards < 0 || !x_hi || !x_lo || !w1_packed || !w2_packed || !bias1 || !bias2 ||
-        (!y_f32 && (!y_hi || !y_lo))) {
-        czi_set_error("cz_resblock: bad argument");
+    if (n_boards < 0 || !x_hi || !w1_packed || !w2_packed || !bias1 || !bias2 || (parts != 1 && parts != 2) ||
+        (parts == 2 && (!x_lo || (!y_f32 && (!y_hi || !y_lo)))) || (parts == 1 && (!y_hi || y_f32))) {
+        czi_set_error("cz_resblock: bad argument (parts = 1 writes y_hi only; y_f32 needs parts = 2)");
         return CZ_ERR_ARG;
     }
     if (n_boards == 0) return CZ_OK;
-    if (channels != 128 || (dtype != CZ_BF16 && dtype != CZ_F16)) {
-        czi_set_error("cz_resblock: only channels = 128 with bf16 / f16 split operands (use cz_conv3x3 otherwise)");
-        return CZ_ERR_ARG;
-    }
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -875,43 +950,20 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
         }
         n_cu = prop.multiProcessorCount;
     }
-    static const int variant = getenv("CZ_CONV_VARIANT") ? atoi(getenv("CZ_CONV_VARIANT")) : 0;   // tuning probe
     hipStream_t st = (hipStream_t)stream;
-    const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
-#define CZ_RB(E, DBG)                                                                                              \
-    hipLaunchKernelGGL((k_resblock<E, 128, DBG>), dim3(blocks), dim3(512), 0, st, (const E*)x_hi, (const E*)x_lo,   \
-                       (const E*)w1_packed, bias1, (const E*)w2_packed, bias2, (E*)y_hi, (E*)y_lo, y_f32, n_boards)
-    if (dtype == CZ_BF16) {
-        if (variant == 301) CZ_RB(__bf16, 1);
-        else if (variant == 303) CZ_RB(__bf16, 3);
-        else if (variant == 308 || variant == 340 || variant == 372 || variant == 404) {
-            if (variant == 308) CZ_RB(__bf16, 8);
-            if (variant == 340) CZ_RB(__bf16, 40);
-            if (variant == 372) CZ_RB(__bf16, 72);
-            if (variant == 404) CZ_RB(__bf16, 104);
-            static int shots = 0;
-            if (++shots == 5) {
-                static long long h[64][8];
-                (void)hipDeviceSynchronize();
-                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h));
-                for (int k = 2; k < 10; ++k) {
-                    fprintf(stderr, "rb trace k%2d:", k);
-                    for (int ph = 0; ph < 8; ++ph)
-                        fprintf(stderr, " %8lld", ph >= 6 ? h[k][ph] : (h[k][ph] - h[2][0]));
-                    fprintf(stderr, "\n");
-                }
-            }
-        }
-        else CZ_RB(__bf16, 0);
-    } else {
-        CZ_RB(_Float16, 0);
-    }
-#undef CZ_RB
-    if (hipGetLastError() != hipSuccess) {
+    int rc = CZ_ERR_ARG;
+    if (dtype == CZ_BF16)
+        rc = dispatch_resblock<__bf16>(channels, parts, x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo,
+                                       y_f32, n_boards, n_cu, st);
+    else if (dtype == CZ_F16)
+        rc = dispatch_resblock<_Float16>(channels, parts, x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo,
+                                         y_f32, n_boards, n_cu, st);
+    if (rc == CZ_ERR_ARG)
+        czi_set_error("cz_resblock: supported: 128 filters (split or plain operands), 256 filters (plain), bf16 / f16; "
+                      "use cz_conv3x3 otherwise");
+    else if (rc != CZ_OK)
         czi_set_error("cz_resblock: launch failed");
-        return CZ_ERR_HIP;
-    }
-    return CZ_OK;
+    return rc;
 }
 
 extern "C" int cz_split_bias_act(const float* x, const float* bias, void* y_hi, void* y_lo, size_t n_elems,

@@ -186,14 +186,15 @@ int cz_bias_act(void* x, const void* bias, const void* residual, size_t n_elems,
 int cz_conv3x3(const void* x_hi, const void* x_lo, const void* w_packed, const float* bias, const void* skip_hi,
                const void* skip_lo, void* y_hi, void* y_lo, float* y_f32, int n_boards, int channels, int dtype,
                int parts, int relu, void* stream);
-/* A whole residual block in one launch (csrc/xq_conv.hip, k_resblock), split operands (parts = 2) only:
+/* A whole residual block in one launch (csrc/xq_conv.hip, k_resblock):
  *   y = relu( conv3x3(relu(conv3x3(x, w1) + bias1), w2) + bias2 + x )          (agent/model.py:68-83)
  * The intermediate activation and the skip operand stay in LDS; HBM sees one read of x and one write of y.
- * Same layouts as cz_conv3x3; y_f32 != NULL writes the fp32 result instead of (y_hi, y_lo); y may alias x.
- * channels = 128 (other sizes: CZ_ERR_ARG, use two cz_conv3x3 calls). */
+ * Same layouts and `parts` as cz_conv3x3; y_f32 != NULL (parts = 2 only) writes the fp32 result instead of
+ * (y_hi, y_lo); y may alias x.  Supported: 128 filters (parts 1 or 2), 256 filters (parts 1); anything else returns
+ * CZ_ERR_ARG (use two cz_conv3x3 calls).  Bit-identical to the two-call form. */
 int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1, const void* w2_packed,
                 const float* bias2, void* y_hi, void* y_lo, float* y_f32, int n_boards, int channels, int dtype,
-                void* stream);
+                int parts, void* stream);
 /* number of 2-byte elements of the packed filter (all parts, including the prefetch padding); 0 = bad argument */
 size_t cz_conv3x3_packed_elems(int channels, int parts);
 /* HOST: w_oihw[channels][channels][3][3] fp32 -> MFMA fragment order, split into parts; out_host holds

@@ -80,38 +80,48 @@ def test_conv3x3_identity_filter_is_a_shift():
     assert torch.equal(out[0].float().view(n, 10, 9, c), want)
 
 
+@pytest.mark.parametrize("c,dt,parts", [(128, "bfloat16", 2), (128, "bfloat16", 1), (128, "float16", 1),
+                                        (256, "float16", 1), (256, "bfloat16", 1)])
 @pytest.mark.parametrize("n", [1, 3, 257, 700])
-def test_resblock_equals_two_convolutions(n):
+def test_resblock_equals_two_convolutions(c, dt, parts, n):
     """cz_resblock (one launch, intermediate in LDS) must be BIT-identical to two cz_conv3x3 launches: same
     operands, same MFMA order, same epilogue arithmetic."""
     import torch
     from cchess_alphazero import _native
-    c, dtype = 128, torch.bfloat16
-    g = torch.Generator(device="cuda").manual_seed(n)
+    dtype = getattr(torch, dt)
+    g = torch.Generator(device="cuda").manual_seed(n + c)
     x = torch.randn((n, 90, c), device="cuda", generator=g).relu()
     ws = [torch.randn((c, c, 3, 3), device="cuda", generator=g) / (3.0 * c ** 0.5) for _ in range(2)]
     bs = [torch.randn((c,), device="cuda", generator=g) for _ in range(2)]
-    ps = [_native.pack_conv3x3_weights(w, dtype, 2).cuda() for w in ws]
-    xs = _split(x, dtype, 2)
-    t = tuple(torch.empty_like(xs[0]) for _ in range(2))
-    want = tuple(torch.empty_like(xs[0]) for _ in range(2))
-    want_f = torch.empty((n, 90, c), device="cuda")
+    ps = [_native.pack_conv3x3_weights(w, dtype, parts).cuda() for w in ws]
+    xs = _split(x, dtype, parts)
+    t = tuple(torch.empty_like(xs[0]) for _ in range(parts))
+    want = tuple(torch.empty_like(xs[0]) for _ in range(parts))
     _native.conv3x3(xs, ps[0], bs[0], out=t)
     _native.conv3x3(t, ps[1], bs[1], skip=xs, out=want)
-    _native.conv3x3(t, ps[1], bs[1], skip=xs, out_f32=want_f)
-    got = tuple(torch.full_like(xs[0], 7.0) for _ in range(2))
-    got_f = torch.full((n, 90, c), 7.0, device="cuda")
+    got = tuple(torch.full_like(xs[0], 7.0) for _ in range(parts))
     _native.resblock(xs, ps[0], bs[0], ps[1], bs[1], out=got)
-    _native.resblock(xs, ps[0], bs[0], ps[1], bs[1], out_f32=got_f)
-    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
-    assert torch.equal(got_f, want_f)
-    # in place (y aliases x): every workgroup has its board in LDS before it writes it back
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    if parts == 2:
+        want_f = torch.empty((n, 90, c), device="cuda")
+        _native.conv3x3(t, ps[1], bs[1], skip=xs, out_f32=want_f)
+        got_f = torch.full((n, 90, c), 7.0, device="cuda")
+        _native.resblock(xs, ps[0], bs[0], ps[1], bs[1], out_f32=got_f)
+        assert torch.equal(got_f, want_f)
+    # in place (y aliases x): every workgroup has its boards in LDS before it writes them back
     xi = tuple(a.clone() for a in xs)
     _native.resblock(xi, ps[0], bs[0], ps[1], bs[1], out=xi)
-    assert torch.equal(xi[0], want[0]) and torch.equal(xi[1], want[1])
+    assert all(torch.equal(a, b) for a, b in zip(xi, want))
+
+
+def test_resblock_rejects_unsupported_shapes():
+    import torch
+    from cchess_alphazero import _native
+    w = _native.pack_conv3x3_weights(torch.randn(32, 32, 3, 3), torch.bfloat16, 2).cuda()
+    b = torch.zeros(32, device="cuda")
+    x32 = tuple(torch.zeros((1, 90, 32), device="cuda", dtype=torch.bfloat16) for _ in range(2))
     with pytest.raises(_native.NativeError):
-        x64 = tuple(torch.zeros((1, 90, 64), device="cuda", dtype=dtype) for _ in range(2))
-        _native.resblock(x64, ps[0], bs[0], ps[1], bs[1], out=x64)
+        _native.resblock(x32, w, b, w, b, out=x32)
 
 
 @pytest.mark.parametrize("c,in_planes,dt,parts", [(128, 14, "bfloat16", 2), (128, 28, "bfloat16", 2),

@@ -110,14 +110,14 @@ def check_block(c=128, dtype=torch.bfloat16, n=300, seed=3):
                 f32_vs_two_launches=d2)
 
 
-def bench_block(c, dtype, n, iters=10):
+def bench_block(c, dtype, parts, n, iters=10):
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn((n, 90, c), device="cuda", generator=g).relu()
     w = torch.randn((c, c, 3, 3), device="cuda", generator=g) / (3.0 * c ** 0.5)
     b = torch.randn((c,), device="cuda", generator=g)
-    wp = _native.pack_conv3x3_weights(w, dtype, 2).cuda()
-    xs = split(x, dtype, 2)
-    out = tuple(torch.empty((n, 90, c), device="cuda", dtype=dtype) for _ in range(2))
+    wp = _native.pack_conv3x3_weights(w, dtype, parts).cuda()
+    xs = split(x, dtype, parts)
+    out = tuple(torch.empty((n, 90, c), device="cuda", dtype=dtype) for _ in range(parts))
     for _ in range(2):
         _native.resblock(xs, wp, b, wp, b, out=out)
     torch.cuda.synchronize()
@@ -129,7 +129,8 @@ def bench_block(c, dtype, n, iters=10):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flop = 2 * 2.0 * n * 90 * c * c * 9
-    return dict(ms=ms, ms_per_conv=ms / 2, tflops_algorithmic=flop / ms / 1e9, mfma_tflops=3 * flop / ms / 1e9)
+    return dict(ms=ms, ms_per_conv=ms / 2, tflops_algorithmic=flop / ms / 1e9,
+                mfma_tflops=(3 if parts == 2 else 1) * flop / ms / 1e9)
 
 
 def bench_miopen(c, dtype, n, iters=5):
@@ -172,8 +173,10 @@ def main():
         if not a.no_check:
             res["check"]["resblock"] = check_block()
             print("resblock", res["check"]["resblock"], flush=True)
-        res["bench"]["resblock_bf16_x2"] = bench_block(128, torch.bfloat16, a.n)
-        print("resblock", res["bench"]["resblock_bf16_x2"], flush=True)
+        for c, dtype, parts in ((128, torch.bfloat16, 2), (128, torch.bfloat16, 1), (256, torch.float16, 1)):
+            key = f"resblock_c{c}_{str(dtype).split('.')[-1]}_x{parts}"
+            res["bench"][key] = bench_block(c, dtype, parts, a.n if c == 128 else a.n // 2)
+            print(key, res["bench"][key], flush=True)
     if not a.no_miopen:
         for dtype in (torch.float32, torch.bfloat16):
             key = "miopen_" + str(dtype).split(".")[-1]

@@ -84,7 +84,7 @@ def main():
         if bench:
             lines += [f"bench.py under the profiler: {bench.get('value', 0):.0f} expansions/s, "
                       f"{bench.get('ms_per_step', 0):.2f} ms per round "
-                      f"(search-round kernels {bench.get('roofline', {}).get('avg_launch_ms', 0):.3f} ms).", ""]
+                      f"(search-round kernels {(bench.get('roofline_search') or {}).get('avg_launch_ms', 0):.3f} ms).", ""]
         lines += ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
         for r in rows[:28]:
             lines.append(f"| `{r['Name'][:100]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | "
