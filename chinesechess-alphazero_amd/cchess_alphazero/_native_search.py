@@ -34,6 +34,10 @@ def declare(L):
     L.cz_search_set_sims.argtypes = [vp, i32]
     L.cz_search_pending.argtypes = [vp, C.POINTER(C.c_int), vp]
     L.cz_search_root_stats.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.cz_search_node_stats.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.cz_search_node_stats.restype = i32
+    L.cz_search_stop.argtypes = [vp, vp]
+    L.cz_search_stop.restype = i32
     L.cz_search_choose.argtypes = [vp, vp, vp, vp]
     L.cz_search_counters.argtypes = [vp, vp, vp]
     L.cz_search_drain_records.argtypes = [vp, C.POINTER(C.c_uint), vp, i32, C.POINTER(C.c_int), vp]
@@ -160,6 +164,33 @@ class Search:
             self.policy.copy_(p)
             self.value.copy_(v)
         raise RuntimeError("search did not finish")
+
+    def stop(self):
+        """No further simulations are started; the next round() backs up the ones in flight."""
+        _native.check(self.L.cz_search_stop(self.h, self._stream()), "cz_search_stop")
+
+    def node_stats(self, path=None):
+        """Edges of the node reached from each root along path (label indices, [G, L] or [L] for G = 1);
+        path None / empty = the root (same as root_stats)."""
+        import torch
+        if path is None or len(path) == 0:
+            return self.root_stats()
+        G, M = self.G, _native.MAXMOVES
+        pa = np.asarray(path, dtype=np.uint16).reshape(G, -1)
+        pt = torch.from_numpy(pa.view(np.int16).copy()).to(self.device)
+        moves = torch.empty((G, M), dtype=torch.uint16, device=self.device)
+        n = torch.empty((G, M), dtype=torch.int32, device=self.device)
+        w = torch.empty((G, M), dtype=torch.float64, device=self.device)
+        p = torch.empty((G, M), dtype=torch.float32, device=self.device)
+        sum_n = torch.empty((G,), dtype=torch.int32, device=self.device)
+        counts = torch.empty((G,), dtype=torch.uint8, device=self.device)
+        _native.check(self.L.cz_search_node_stats(self.h, C.c_void_p(pt.data_ptr()), pa.shape[1],
+                                                  C.c_void_p(moves.data_ptr()), C.c_void_p(n.data_ptr()),
+                                                  C.c_void_p(w.data_ptr()), C.c_void_p(p.data_ptr()),
+                                                  C.c_void_p(sum_n.data_ptr()), C.c_void_p(counts.data_ptr()),
+                                                  self._stream()), "cz_search_node_stats")
+        return dict(moves=moves.cpu().numpy(), n=n.cpu().numpy(), w=w.cpu().numpy(), p=p.cpu().numpy(),
+                    sum_n=sum_n.cpu().numpy(), counts=counts.cpu().numpy())
 
     def root_stats(self):
         import torch

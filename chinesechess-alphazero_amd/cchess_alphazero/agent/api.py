@@ -46,7 +46,10 @@ class CChessModelAPI:
         self.pipes = []
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         dtype = dtype or getattr(torch, getattr(getattr(config, "engine", None), "net_dtype", "float32"))
-        self.net = InferenceNet(agent_model.model, dtype).to(self.device)
+        trunk = getattr(getattr(config, "engine", None), "net_trunk", "mfma")
+        if agent_model.model.cfg["cnn_filter_num"] not in (32, 128, 256):
+            trunk = "library"
+        self.net = InferenceNet(agent_model.model, dtype, trunk=trunk).to(self.device)
         self.done = False
 
     def start(self, need_reload=True):

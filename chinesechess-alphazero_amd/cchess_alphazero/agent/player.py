@@ -18,6 +18,8 @@ from cchess_alphazero.environment.lookup_tables import ActionLabelsRed, label_in
 
 logger = getLogger(__name__)
 
+INFINITE_SIMS = 100000        # `go infinite` (player.py:162-163)
+
 
 class ActionState:
     def __init__(self, n=0, w=0.0, p=0.0):
@@ -58,6 +60,12 @@ class CChessPlayer:
         self.no_act = None
         self.increase_temp = False
         self.use_history = use_history
+        self.job_done = False
+        self.out = None                      # where `info depth ...` lines go (None: sys.stdout)
+        self.last_action = None
+        import threading
+        self._idle = threading.Event()
+        self._idle.set()
         if pipes is None:
             raise ValueError("CChessPlayer needs a pipe to the network (model.get_pipes())")
         pc = self.play_config
@@ -67,7 +75,9 @@ class CChessPlayer:
         dt = _native.F32
         self._search = Search(merged, 1, planes_dtype=dt, evaluate=getattr(config.opts, "evaluate", False),
                               seed=int(np.random.randint(0, 2 ** 31 - 1)),
-                              node_capacity=getattr(getattr(config, "engine", None), "node_capacity", 0) or 0,
+                              node_capacity=(INFINITE_SIMS + 64) if uci else
+                              (getattr(getattr(config, "engine", None), "node_capacity", 0) or 0),
+                              edge_capacity=(INFINITE_SIMS + 66) * 64 if uci else 0,
                               use_history=use_history)
         self._torch = torch
 
@@ -85,57 +95,164 @@ class CChessPlayer:
         return p, v
 
     def close(self, wait=True):
+        self.job_done = True
         if getattr(self, "_search", None) is not None:
             self._search.close()
             self._search = None
 
+    # -- helpers ---------------------------------------------------------------------------------------------------
+    def _node(self, stats):
+        """VisitState of game 0 from a root_stats / node_stats dict (None when the position is not in the tree)."""
+        c = int(stats["counts"][0])
+        if c == 0:
+            return None
+        node = VisitState()
+        node.sum_n = int(stats["sum_n"][0])
+        node.legal_moves = [self.labels[int(m)] for m in stats["moves"][0, :c]]
+        for j, mov in enumerate(node.legal_moves):
+            node.a[mov] = ActionState(int(stats["n"][0, j]), float(stats["w"][0, j]), float(stats["p"][0, j]))
+        return node
+
+    def _root_value(self, state, hist):
+        """debugging=True: the network's (policy, value) of the root, what the reference keeps in self.debug[state]
+        (player.py:332-336) and its UCI front-end prints as the score (uci.py:291-292)."""
+        t = self._torch
+        if self.use_history and hist:
+            planes = senv.state_history_to_planes(state, hist)
+        else:
+            planes = senv.state_to_planes(state)
+        p, v = self._evaluate(t.from_numpy(np.asarray(planes, dtype=np.float32)[None]).cuda())
+        return p[0].float().cpu().numpy(), float(v[0])
+
+    def principal_variation(self, state, no_act=None, max_len=20):
+        """Most-visited line from the root (print_depth_info, player.py:408-433: `>=` keeps the LAST maximum; banned
+        moves are skipped at the root only).  Returns the moves in the mover's frame of each ply."""
+        path, pv = [], []
+        for ply in range(max_len):
+            node = self._node(self._search.node_stats(path))
+            if node is None or not node.a:
+                break
+            best, n = None, 0
+            for mov, a in node.a.items():
+                if a.n >= n:
+                    if ply == 0 and no_act and mov in no_act:
+                        continue
+                    n, best = a.n, mov
+            if best is None:
+                break
+            pv.append(best)
+            path.append(self.move_lookup[best])
+        return pv
+
+    def print_depth_info(self, state, turns, start_time, value, no_act):
+        """`info depth .. score .. time .. pv .. nps ..` (player.py:408-450)."""
+        import sys
+        from time import time
+        from cchess_alphazero.environment.lookup_tables import flip_move
+        depth = self.done_tasks // 100
+        pv = ""
+        t = turns
+        for mov in self.principal_variation(state, no_act):
+            pv += " " + senv.to_uci_move(flip_move(mov) if t % 2 == 1 else mov)
+            t += 1
+        if t % 2 != self.side:
+            value = -value
+        duration = max(time() - start_time, 1e-9)
+        nps = int(depth * 100 / duration) * 1000
+        out = f"info depth {depth} score {int(value * 1000)} time {int(duration * 1000)} pv" + pv + f" nps {nps}"
+        stream = self.out or sys.stdout
+        print(out, file=stream)
+        logger.debug(out)
+        stream.flush()
+
     def action(self, state, turns, no_act=None, depth=None, infinite=False, hist=None, increase_temp=False):
-        if infinite:
-            raise NotImplementedError("infinite search (UCI `go infinite` + stop) is not built yet (SURVEY 8 f-3)")
+        from time import time
         t = self._torch
         s = self._search
         base_sims = int(self.play_config.simulation_num_per_move)
-        s.set_sims(int(depth) if depth else base_sims)     # action(depth=...): that many simulations (player.py:160)
+        # action(depth=...): that many simulations; infinite: 100000 (player.py:160-163), ended by
+        # close_and_return_action from another thread
+        s.set_sims(INFINITE_SIMS if infinite else (int(depth) if depth else base_sims))
         self.root_state, self.no_act, self.increase_temp = state, no_act, increase_temp
-        board = t.from_numpy(senv.state_to_array(state)[None]).cuda()
-        na = np.full((1, 16), 0xFFFF, dtype=np.uint16)
-        bans = list(no_act or [])[:16]
-        for k, m in enumerate(bans):
-            na[0, k] = label_index(m)
-        prev, kind = None, None
-        if self.use_history and hist:                      # action(hist=...): player.py:150-151, :217-218
-            if len(hist) >= 5:
-                prev = t.from_numpy(senv.state_to_array(hist[-5])[None]).cuda()
-                kind = t.tensor([1], dtype=t.uint8, device="cuda")
-            else:
-                kind = t.tensor([2], dtype=t.uint8, device="cuda")
-        s.set_roots(board, prev_boards=prev, hist_kind=kind,
-                    turns=t.tensor([turns], dtype=t.int32, device="cuda"),
-                    no_act=t.from_numpy(na.view(np.int16)).cuda().view(t.uint16),
-                    n_no_act=t.tensor([len(bans)], dtype=t.uint8, device="cuda"),
-                    increase_temp=t.tensor([1 if increase_temp else 0], dtype=t.uint8, device="cuda"),
-                    enable_resign=t.tensor([1 if self.enable_resign else 0], dtype=t.uint8, device="cuda"))
-        before = s.counters()["sims"]
-        s.run_until_idle(self._evaluate)
-        self.done_tasks = s.counters()["sims"] - before
-        st = s.root_stats()
-        c = int(st["counts"][0])
-        policy = np.zeros(self.labels_n)
-        node = VisitState()
-        node.sum_n = int(st["sum_n"][0])
-        node.legal_moves = [self.labels[int(m)] for m in st["moves"][0, :c]]
-        for j, mov in enumerate(node.legal_moves):
-            n, w, p = int(st["n"][0, j]), float(st["w"][0, j]), float(st["p"][0, j])
-            node.a[mov] = ActionState(n, w, p)
-            policy[self.move_lookup[mov]] = 0 if (no_act and mov in no_act) else n
-        self.tree[state] = node
-        if self.debugging:
-            order = sorted(node.a.items(), key=lambda kv: -kv[1].n)[:5]
-            self.search_results = {m: (a.n, a.q, a.p) for m, a in order}
-        action = int(s.choose([float(np.random.random_sample())])[0])
-        if action < 0:
-            return None, list(policy)                      # resign: un-normalised counts (player.py:189-190)
-        total = policy.sum()
-        if total > 0:
-            policy /= total
-        return self.labels[action], list(policy)
+        self._idle.clear()
+        try:
+            board = t.from_numpy(senv.state_to_array(state)[None]).cuda()
+            na = np.full((1, 16), 0xFFFF, dtype=np.uint16)
+            bans = list(no_act or [])[:16]
+            for k, m in enumerate(bans):
+                na[0, k] = label_index(m)
+            prev, kind = None, None
+            if self.use_history and hist:                      # action(hist=...): player.py:150-151, :217-218
+                if len(hist) >= 5:
+                    prev = t.from_numpy(senv.state_to_array(hist[-5])[None]).cuda()
+                    kind = t.tensor([1], dtype=t.uint8, device="cuda")
+                else:
+                    kind = t.tensor([2], dtype=t.uint8, device="cuda")
+            s.set_roots(board, prev_boards=prev, hist_kind=kind,
+                        turns=t.tensor([turns], dtype=t.int32, device="cuda"),
+                        no_act=t.from_numpy(na.view(np.int16)).cuda().view(t.uint16),
+                        n_no_act=t.tensor([len(bans)], dtype=t.uint8, device="cuda"),
+                        increase_temp=t.tensor([1 if increase_temp else 0], dtype=t.uint8, device="cuda"),
+                        enable_resign=t.tensor([1 if self.enable_resign else 0], dtype=t.uint8, device="cuda"))
+            if self.debugging:
+                self.debug[state] = self._root_value(state, hist)
+            before = s.counters()["sims"]
+            start_time, shown, stopped = time(), 0, False
+            while True:
+                s.round()
+                if s.pending() == 0:
+                    break
+                p, v = self._evaluate(s.planes)
+                s.policy.copy_(p)
+                s.value.copy_(v)
+                if self.job_done and not stopped:
+                    s.stop()                                   # the next round backs up what is in flight
+                    stopped = True
+                if self.uci and not stopped:
+                    self.done_tasks = s.counters()["sims"] - before
+                    if self.done_tasks // 100 != shown:
+                        shown = self.done_tasks // 100
+                        self.print_depth_info(state, turns, start_time, self.debug.get(state, (None, 0.0))[1], no_act)
+            self.done_tasks = s.counters()["sims"] - before
+            st = s.root_stats()
+            c = int(st["counts"][0])
+            policy = np.zeros(self.labels_n)
+            node = self._node(st) or VisitState()
+            for mov, a in node.a.items():
+                policy[self.move_lookup[mov]] = 0 if (no_act and mov in no_act) else a.n
+            self.tree[state] = node
+            if self.debugging:
+                order = sorted(node.a.items(), key=lambda kv: -kv[1].n)[:5]
+                self.search_results = {m: (a.n, a.q, a.p) for m, a in order}
+            action = int(s.choose([float(np.random.random_sample())])[0])
+            self.last_action = self.labels[action] if action >= 0 else None
+            if action < 0:
+                return None, list(policy)                      # resign: un-normalised counts (player.py:189-190)
+            # the node behind the chosen move, for callers that read it from the tree they passed in
+            # (ponder move, uci.py:312-318)
+            child = self._node(s.node_stats([action]))
+            if child is not None:
+                self.tree[senv.step(state, self.labels[action])] = child
+            total = policy.sum()
+            if total > 0:
+                policy /= total
+            return self.labels[action], list(policy)
+        finally:
+            self._idle.set()
+
+    def close_and_return_action(self, state, turns, no_act=None):
+        """UCI `stop` (player.py:88-106): end the running search and answer from what has been searched so far.
+        Returns (action, value, depth) or None when the player resigns."""
+        self.job_done = True
+        self._idle.wait()                                      # the searching thread finishes its in-flight batch
+        node = self.tree.get(state)
+        if node is None or not node.a:
+            return None
+        if state in self.debug:
+            _, value = self.debug[state]
+        else:
+            value = 0
+        # the search thread's own choice (same calc_policy / temperature / sampling path) is in last_action
+        if self.last_action is None:
+            return None
+        return self.last_action, value, self.done_tasks // 100

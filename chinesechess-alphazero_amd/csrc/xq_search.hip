@@ -1311,7 +1311,10 @@ __global__ void k_pending(SearchParams P, SearchBuffers B)
     if (g < P.G && B.g_phase[g] == PH_SEARCH) atomicAdd(B.pending, 1);
 }
 
-__global__ __launch_bounds__(64) void k_root_stats(SearchParams P, SearchBuffers B, uint16_t* __restrict__ moves,
+// statistics of the root, or of the node reached from the root along path[g][0 .. path_len) (move labels, NOMOVE ends
+// the path early); a node that is not linked in the tree reports count 0
+__global__ __launch_bounds__(64) void k_root_stats(SearchParams P, SearchBuffers B, const uint16_t* __restrict__ path,
+                                                  int path_len, uint16_t* __restrict__ moves,
                                                   int32_t* __restrict__ n, double* __restrict__ w,
                                                   float* __restrict__ p, int32_t* __restrict__ sum_n,
                                                   uint8_t* __restrict__ counts)
@@ -1320,7 +1323,17 @@ __global__ __launch_bounds__(64) void k_root_stats(SearchParams P, SearchBuffers
     if (g >= P.G) return;
     const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT);   // counts go straight to the global block
     const int lane = lane_id();
-    const int root = B.g_root[g];
+    int root = B.g_root[g];
+    for (int d = 0; path && d < path_len && root >= 0; ++d) {
+        const uint16_t mv = path[(size_t)g * path_len + d];
+        if (mv == NOMOVE) break;
+        const int pn = (int)(gv.node_meta[root] & 0xFF), pe = (int)gv.node_eoff[root];
+        int child = -1;
+        for (int j = lane; j < pn; j += 64)
+            if (gv.e_mv[pe + j] == mv) child = gv.e_child[pe + j];
+        const unsigned long long hit = __ballot(child >= 0);
+        root = hit ? __shfl(child, __ffsll((long long)hit) - 1) : -1;
+    }
     int nm = 0, eoff = 0;
     if (root >= 0) { nm = (int)(gv.node_meta[root] & 0xFF); eoff = (int)gv.node_eoff[root]; }
     for (int j = lane; j < MAXMOVES; j += 64) {
@@ -1345,6 +1358,13 @@ __global__ __launch_bounds__(64) void k_choose(SearchParams P, SearchBuffers B, 
     const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT);   // counts go straight to the global block
     const int a = choose_action(P, B, gv, L, u ? u[g] : 0.5, B.g_enable_resign[g] != 0);
     if (lane_id() == 0) action[g] = a;
+}
+
+// cz_search_stop: no further simulations are STARTED; the ones in flight are backed up by the next round
+__global__ void k_stop(SearchParams P, SearchBuffers B)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < P.G && B.g_phase[g] == PH_SEARCH) B.g_tasks_left[g] = 0;
 }
 
 __global__ void k_debug_sqrt(const int32_t* __restrict__ x, double* __restrict__ y, int n)
@@ -1600,8 +1620,27 @@ int cz_search_root_stats(cz_search* s, uint16_t* moves, int32_t* n, double* w, f
                          uint8_t* counts, void* stream)
 {
     if (!s) return serr(CZ_ERR_ARG, "cz_search_root_stats: null handle");
-    hipLaunchKernelGGL(k_root_stats, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, moves, n, w, p, sum_n, counts);
+    hipLaunchKernelGGL(k_root_stats, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, (const uint16_t*)nullptr, 0,
+                       moves, n, w, p, sum_n, counts);
     S_LAUNCH_CHECK("cz_search_root_stats");
+    return CZ_OK;
+}
+
+int cz_search_stop(cz_search* s, void* stream)
+{
+    if (!s) return serr(CZ_ERR_ARG, "cz_search_stop: null handle");
+    hipLaunchKernelGGL(k_stop, dim3((s->P.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->P, s->B);
+    S_LAUNCH_CHECK("cz_search_stop");
+    return CZ_OK;
+}
+
+int cz_search_node_stats(cz_search* s, const uint16_t* path, int path_len, uint16_t* moves, int32_t* n, double* w,
+                         float* p, int32_t* sum_n, uint8_t* counts, void* stream)
+{
+    if (!s || path_len < 0 || (path_len > 0 && !path)) return serr(CZ_ERR_ARG, "cz_search_node_stats: bad argument");
+    hipLaunchKernelGGL(k_root_stats, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, path, path_len, moves, n, w,
+                       p, sum_n, counts);
+    S_LAUNCH_CHECK("cz_search_node_stats");
     return CZ_OK;
 }
 

@@ -156,6 +156,15 @@ int cz_search_pending(cz_search* s, int* host_out, void* stream);
 /* root edges after a search: moves/n/w/p [G][128], sum_n [G], counts [G] (any may be NULL) */
 int cz_search_root_stats(cz_search* s, uint16_t* moves, int32_t* n, double* w, float* p, int32_t* sum_n,
                          uint8_t* counts, void* stream);
+/* the same for the node reached from each root along path[g][0 .. path_len) (DEVICE move labels, 0xFFFF ends a path
+ * early; path_len = 0: the root).  A position that is not linked in the tree reports counts = 0.  This is what the
+ * reference's callers read out of the search_tree dict they handed to the player (ponder move uci.py:312-318,
+ * principal variation player.py:408-450). */
+int cz_search_node_stats(cz_search* s, const uint16_t* path, int path_len, uint16_t* moves, int32_t* n, double* w,
+                         float* p, int32_t* sum_n, uint8_t* counts, void* stream);
+/* stop starting simulations in every running search (UCI `stop`, CChessPlayer.close_and_return_action,
+ * player.py:88-106): the next cz_search_round backs up what is in flight and the searches become idle */
+int cz_search_stop(cz_search* s, void* stream);
 /* calc_policy + apply_temperature + np.random.choice with the uniform draws u [G] (NULL = 0.5):
  * action [G] = label, or -1 when the player resigns */
 int cz_search_choose(cz_search* s, const double* u, int32_t* action, void* stream);

@@ -236,3 +236,65 @@ def test_inference_net_gpu_matches_fp32_reference():
         p4, v4 = lo(x.cuda())
         assert (p3 - p4).abs().max() < tol and (v3 - v4).abs().max() < tol * 10
         assert (v3.cpu() - v_ref).abs().max() < tol * 10
+
+
+def test_uci_front_end_depth_infinite_stop():
+    """The UCI front-end on the engine (reference uci.py): `go depth`, `go infinite` + `stop`,
+    `position ... moves`, `bestmove .. ponder ..` in the GUI's frame, legal moves only."""
+    import io
+    import time
+    from cchess_alphazero.config import Config, PlayWithHumanConfig
+    from cchess_alphazero.uci import UCI
+    cfg = Config(config_type="mini")
+    PlayWithHumanConfig().update_play_config(cfg.play)
+    cfg.play.search_threads = 8
+    cfg.resource.model_best_config_path = "/nonexistent/config.json"      # random-init network
+    out = io.StringIO()
+    u = UCI(cfg, out=out)
+    for line in ("uci", "isready", "ucinewgame", "position startpos moves h2e2 h9g7"):
+        u.handle(line)
+    assert "uciok" in out.getvalue() and "readyok" in out.getvalue()
+    assert u.turns == 2 and u.is_red_turn and len(u.history) == 5
+
+    def wait_bestmove(n, timeout=120):
+        t0 = time.time()
+        while out.getvalue().count("bestmove") < n:
+            assert time.time() - t0 < timeout, out.getvalue()
+            time.sleep(0.05)
+        return [l for l in out.getvalue().splitlines() if l.startswith("bestmove")][-1]
+
+    u.handle("go depth 2")                                  # 200 simulations
+    best = wait_bestmove(1)
+    tok = best.split()
+    assert tok[0] == "bestmove" and len(tok[1]) == 4
+    red_moves = {senv_to_uci(m) for m in _legal(u.state)}
+    assert tok[1] in red_moves
+    info = [l for l in out.getvalue().splitlines() if l.startswith("info depth")]
+    assert len(info) >= 2 and " pv " in info[0] and "nps" in info[-1]      # per-depth lines carry the PV
+    if len(tok) == 4:
+        assert tok[2] == "ponder" and len(tok[3]) == 4
+
+    # black to move: moves come back flipped into the GUI's frame
+    u.handle("position startpos moves h2e2")
+    assert not u.is_red_turn and u.turns == 1
+    u.handle("go infinite")
+    time.sleep(1.0)
+    u.handle("stop")
+    best2 = wait_bestmove(2)
+    from cchess_alphazero.environment.lookup_tables import flip_move
+    black_moves = {senv_to_uci(flip_move(m)) for m in _legal(u.state)}
+    assert best2.split()[1] in black_moves
+    assert out.getvalue().count("bestmove") == 2           # one answer per go, also when stop races the search
+    u.handle("go movetime 300")
+    wait_bestmove(3)
+    assert u.handle("quit") is False
+
+
+def _legal(state):
+    from cchess_alphazero.environment import static_env as senv
+    return senv.get_legal_moves(state)
+
+
+def senv_to_uci(m):
+    from cchess_alphazero.environment import static_env as senv
+    return senv.to_uci_move(m)
