@@ -177,7 +177,10 @@ def main():
     cfg = build_config(args)
     dtype = getattr(torch, cfg.engine.net_dtype)
     G = cfg.engine.games_per_gpu
-    eng = SelfPlayEngine(cfg, G, dtype=dtype, seed=20260923)
+    from cchess_alphazero.agent.model import CChessNet
+    torch.manual_seed(0)
+    ref_net = CChessNet.from_model_config(cfg.model)          # random-init weights of the named architecture
+    eng = SelfPlayEngine(cfg, G, net=ref_net, dtype=dtype, seed=20260923)
     eng.start(first_game_id=rank * G, game_id_stride=world * G)
     K = eng.search.K
     split = eng.trunk == "mfma" and cfg.engine.net_dtype == "float32"
@@ -314,6 +317,16 @@ def main():
                                        "(157.3 TFLOP/s) the same number is > 1"}
         else:
             out["roofline"] = out.get("roofline_search")
+        # the network the engine ran vs the plain fp32 PyTorch module (CPU) on positions of the last round's queue
+        nq = min(64, slots)
+        qp = eng.search.planes[:nq].clone()
+        with torch.no_grad():
+            pg, vg = eng.net(qp)
+            pc_, vc_ = ref_net.eval()(qp.float().cpu())
+        out["numerics_check"] = {"positions": nq, "against": "plain PyTorch fp32 module on the CPU, same weights",
+                                 "policy_max_abs_diff": float((pg.float().cpu() - pc_).abs().max()),
+                                 "value_max_abs_diff": float((vg.float().cpu() - vc_).abs().max()),
+                                 "tolerance": 1e-4 if cfg.engine.net_dtype == "float32" else None}
         if not args.no_micro:
             out["micro_suite"] = micro_suite()
             log("micro-suite done")

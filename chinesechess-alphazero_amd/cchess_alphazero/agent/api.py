@@ -8,10 +8,16 @@ The reference runs a prediction thread that drains multiprocessing pipes and cal
   * ``send(list_of_planes)`` / ``poll()`` / ``recv()``  -- the reference's pipe protocol
     (player.py:108-143), for callers that still talk to it that way.
 """
+from logging import getLogger
+from time import time
+
 import numpy as np
 import torch
 
 from cchess_alphazero.agent.model import InferenceNet
+
+
+logger = getLogger(__name__)
 
 
 class DevicePipe:
@@ -50,10 +56,30 @@ class CChessModelAPI:
         if agent_model.model.cfg["cnn_filter_num"] not in (32, 128, 256):
             trunk = "library"
         self.net = InferenceNet(agent_model.model, dtype, trunk=trunk).to(self.device)
+        self._dtype, self._trunk = dtype, trunk
         self.done = False
+        self.need_reload = True
+        self.reload_interval = 600.0             # seconds between checks of the best-weight file (api.py:42-44)
+        self._last_check = time()
 
     def start(self, need_reload=True):
         self.need_reload = need_reload
+
+    def try_reload_model(self):
+        """Hot reload (api.py:76-87): when the best-weight file on disk has a different digest, load it and rebuild
+        the inference network.  Returns True when new weights were loaded."""
+        from cchess_alphazero.lib.model_helper import load_best_model_weight, need_to_reload_best_model_weight
+        try:
+            if self.need_reload and need_to_reload_best_model_weight(self.agent_model):
+                if load_best_model_weight(self.agent_model):
+                    trunk = self._trunk
+                    if self.agent_model.model.cfg["cnn_filter_num"] not in (32, 128, 256):
+                        trunk = "library"
+                    self.net = InferenceNet(self.agent_model.model, self._dtype, trunk=trunk).to(self.device)
+                    return True
+        except Exception as e:                    # a half-written file: keep serving the old weights
+            logger.error(e)
+        return False
 
     def get_pipe(self, need_reload=True):
         pipe = DevicePipe(self)
@@ -62,6 +88,9 @@ class CChessModelAPI:
 
     @torch.no_grad()
     def predict_device(self, planes):
+        if self.need_reload and time() - self._last_check > self.reload_interval:
+            self._last_check = time()
+            self.try_reload_model()
         return self.net(planes)
 
     def close(self):

@@ -43,12 +43,12 @@ class CChessNet(nn.Module):
     """Trainable form (BatchNorm layers kept); mirrors CChessModel.build(), model.py:32-66."""
 
     def __init__(self, cnn_filter_num=256, cnn_first_filter_size=5, cnn_filter_size=3, res_layer_num=7,
-                 value_fc_size=256, input_depth=14, policy_filters=4, value_filters=2):
+                 value_fc_size=256, input_depth=14, policy_filters=4, value_filters=2, n_labels=N_LABELS):
         super().__init__()
         self.cfg = dict(cnn_filter_num=cnn_filter_num, cnn_first_filter_size=cnn_first_filter_size,
                         cnn_filter_size=cnn_filter_size, res_layer_num=res_layer_num,
                         value_fc_size=value_fc_size, input_depth=input_depth,
-                        policy_filters=policy_filters, value_filters=value_filters)
+                        policy_filters=policy_filters, value_filters=value_filters, n_labels=n_labels)
         f = cnn_filter_num
         self.input_conv = nn.Conv2d(input_depth, f, cnn_first_filter_size, padding=cnn_first_filter_size // 2,
                                     bias=False)
@@ -56,7 +56,7 @@ class CChessNet(nn.Module):
         self.res = nn.ModuleList([ResidualBlock(f, cnn_filter_size) for _ in range(res_layer_num)])
         self.policy_conv = nn.Conv2d(f, policy_filters, 1, bias=False)
         self.policy_bn = nn.BatchNorm2d(policy_filters, eps=BN_EPS, momentum=0.01)
-        self.policy_out = nn.Linear(policy_filters * 90, N_LABELS)
+        self.policy_out = nn.Linear(policy_filters * 90, n_labels)
         self.value_conv = nn.Conv2d(f, value_filters, 1, bias=False)
         self.value_bn = nn.BatchNorm2d(value_filters, eps=BN_EPS, momentum=0.01)
         self.value_dense = nn.Linear(value_filters * 90, value_fc_size)
@@ -124,7 +124,7 @@ class InferenceNet(nn.Module):
                 self.res.append(nn.ModuleList([_fold(blk.conv1, blk.bn1), _fold(blk.conv2, blk.bn2)]))
             self.policy_conv = _fold(net.policy_conv, net.policy_bn)
             self.value_conv = _fold(net.value_conv, net.value_bn)
-            self.policy_out = nn.Linear(net.policy_out.in_features, N_LABELS)
+            self.policy_out = nn.Linear(net.policy_out.in_features, net.policy_out.out_features)
             self.value_dense = nn.Linear(net.value_dense.in_features, net.value_dense.out_features)
             self.value_out = nn.Linear(net.value_out.in_features, 1)
             self.policy_out.load_state_dict(net.policy_out.state_dict())
@@ -278,7 +278,7 @@ def flops_per_position(cfg):
     """Multiply-accumulate based FLOPs (2*MAC) of one forward pass."""
     f, k1, k, n = cfg["cnn_filter_num"], cfg["cnn_first_filter_size"], cfg["cnn_filter_size"], cfg["res_layer_num"]
     mac = cfg["input_depth"] * f * k1 * k1 * 90 + 2 * n * f * f * k * k * 90
-    mac += f * cfg["policy_filters"] * 90 + cfg["policy_filters"] * 90 * N_LABELS
+    mac += f * cfg["policy_filters"] * 90 + cfg["policy_filters"] * 90 * cfg.get("n_labels", N_LABELS)
     mac += f * cfg["value_filters"] * 90 + cfg["value_filters"] * 90 * cfg["value_fc_size"] + cfg["value_fc_size"]
     return 2 * mac
 
@@ -314,11 +314,39 @@ class CChessModel:
     def _pt(path):
         return os.path.splitext(path)[0] + ".pt"
 
-    def load(self, config_path, weight_path):
-        wp = self._pt(weight_path)
-        if os.path.exists(config_path) and os.path.exists(wp):
+    @classmethod
+    def weight_file(cls, config_path, weight_path):
+        """The file load() would read for this pair: the Keras HDF5 for a Keras topology JSON, else the torch .pt"""
+        try:
             with open(config_path, "rt") as f:
                 cfg = json.load(f)
+            if isinstance(cfg, dict) and ("layers" in cfg or "layers" in cfg.get("config", {})):
+                return weight_path
+        except (OSError, ValueError):
+            pass
+        return cls._pt(weight_path)
+
+    def load(self, config_path, weight_path):
+        """Two on-disk forms: this package's own (JSON of CChessNet keyword arguments + torch state dict ``.pt``) and
+        the reference's (Keras ``get_config()`` JSON + ``save_weights`` HDF5, agent/model.py:95-107), read without
+        Keras / h5py by lib/keras_io.py."""
+        if not os.path.exists(config_path):
+            logger.debug(f"model files does not exist at {config_path}")
+            return False
+        with open(config_path, "rt") as f:
+            cfg = json.load(f)
+        if isinstance(cfg, dict) and ("layers" in cfg or "layers" in cfg.get("config", {})):
+            if not os.path.exists(weight_path):
+                logger.debug(f"model files does not exist at {weight_path}")
+                return False
+            from cchess_alphazero.lib import keras_io
+            self.model = CChessNet(**keras_io.config_from_keras(cfg))
+            keras_io.load_keras_weights(self.model, weight_path, keras_io.names_from_keras(cfg))
+            self.digest = self.fetch_digest(weight_path)
+            logger.debug(f"loaded Keras model digest = {self.digest}")
+            return True
+        wp = self._pt(weight_path)
+        if os.path.exists(wp):
             self.model = CChessNet(**cfg)
             self.model.load_state_dict(torch.load(wp, map_location="cpu"))
             self.digest = self.fetch_digest(wp)

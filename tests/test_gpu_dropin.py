@@ -298,3 +298,31 @@ def _legal(state):
 def senv_to_uci(m):
     from cchess_alphazero.environment import static_env as senv
     return senv.to_uci_move(m)
+
+
+def test_model_api_hot_reload(tmp_path):
+    """CChessModelAPI.try_reload_model (reference agent/api.py:76-87): a new best-weight file on disk replaces the
+    network that serves the pipes; an unchanged file does not."""
+    import torch
+    from cchess_alphazero.agent.model import CChessModel
+    from cchess_alphazero.config import Config
+    from cchess_alphazero.lib import model_helper
+    cfg = Config(config_type="mini")
+    cfg.resource.model_best_config_path = str(tmp_path / "model_best_config.json")
+    cfg.resource.model_best_weight_path = str(tmp_path / "model_best_weight.h5")
+    m = CChessModel(cfg)
+    m.build(seed=1)
+    model_helper.save_as_best_model(m)
+    pipe = m.get_pipes(need_reload=True)
+    x = torch.from_numpy(np.stack([xo.planes_board(xo.state_to_board(xo.INIT_STATE))])).cuda()
+    p0, v0 = pipe.evaluate_device(x)
+    assert not m.api.try_reload_model()
+    other = CChessModel(cfg)
+    other.build(seed=2)
+    model_helper.save_as_best_model(other)
+    assert m.api.try_reload_model() and m.digest == other.digest
+    p1, v1 = pipe.evaluate_device(x)
+    assert (p1 - p0).abs().max() > 1e-6                    # the new weights are the ones being served
+    with torch.no_grad():
+        pr, vr = other.model.eval()(x.cpu())
+    assert (p1.cpu() - pr).abs().max() < 1e-4 and (v1.cpu() - vr).abs().max() < 1e-4
