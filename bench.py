@@ -327,10 +327,10 @@ def main():
                                  "policy_max_abs_diff": float((pg.float().cpu() - pc_).abs().max()),
                                  "value_max_abs_diff": float((vg.float().cpu() - vc_).abs().max()),
                                  "tolerance": 1e-4 if cfg.engine.net_dtype == "float32" else None}
-        if not args.no_micro:
+        if not args.no_micro and world == 1:
             out["micro_suite"] = micro_suite()
             log("micro-suite done")
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU leg is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_seconds)
             log("cpu baseline done")
         print(json.dumps(out), flush=True)
