@@ -27,11 +27,12 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, probe=False):
+    """probe=True adds -DCZ_CONV_PROBE: the tuning variants of tools/conv_probe.py (CZ_CONV_VARIANT) are compiled in."""
     if not force and not needs_build():
         return LIB
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = ["hipcc"] + FLAGS + srcs + ["-o", LIB]
+    cmd = ["hipcc"] + FLAGS + (["-DCZ_CONV_PROBE"] if probe else []) + srcs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -39,4 +40,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv or "--probe" in sys.argv, probe="--probe" in sys.argv)

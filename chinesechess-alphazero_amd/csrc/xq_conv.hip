@@ -893,6 +893,7 @@ int launch_resblock(const void* xh, const void* xl, const void* w1, const float*
     return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
 }
 
+#ifdef CZ_CONV_PROBE
 void print_trace()          // tuning probe (CZ_CONV_VARIANT=308): phase time stamps of workgroup 0, 5th launch
 {
     static int shots = 0;
@@ -907,13 +908,16 @@ void print_trace()          // tuning probe (CZ_CONV_VARIANT=308): phase time st
     }
 }
 
+#endif
+
 template <typename E>
 int dispatch_resblock(int channels, int parts, const void* xh, const void* xl, const void* w1, const float* b1,
                       const void* w2, const float* b2, void* yh, void* yl, float* yf, int n, int n_cu, hipStream_t st)
 {
-    static const int variant = getenv("CZ_CONV_VARIANT") ? atoi(getenv("CZ_CONV_VARIANT")) : 0;   // tuning probe
 #define CZ_RB_ARGS xh, xl, w1, b1, w2, b2, yh, yl, yf, n, n_cu, st
     if (channels == 128 && parts == 2) {
+#ifdef CZ_CONV_PROBE          // build.py --probe: ablations (1 = no stores, 2 = no loads) and in-kernel phase time stamps (8)
+        static const int variant = getenv("CZ_CONV_VARIANT") ? atoi(getenv("CZ_CONV_VARIANT")) : 0;
         if (variant == 301) return launch_resblock<E, 128, 2, 1, 1>(CZ_RB_ARGS);
         if (variant == 303) return launch_resblock<E, 128, 2, 1, 3>(CZ_RB_ARGS);
         if (variant == 308) {
@@ -921,6 +925,7 @@ int dispatch_resblock(int channels, int parts, const void* xh, const void* xl, c
             print_trace();
             return rc;
         }
+#endif
         return launch_resblock<E, 128, 2, 1>(CZ_RB_ARGS);
     }
     if (channels == 128 && parts == 1) return launch_resblock<E, 128, 1, 2>(CZ_RB_ARGS);
