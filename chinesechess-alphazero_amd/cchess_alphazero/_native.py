@@ -71,6 +71,8 @@ def _declare(L):
         L.cz_input_conv_packed_elems.restype = C.c_size_t
         L.cz_input_conv_pack_weights.argtypes = [vp, i32, i32, i32, i32, vp]
         L.cz_input_conv_pack_weights.restype = i32
+        L.cz_resblock_heads.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+        L.cz_resblock_heads.restype = i32
         L.cz_resblock.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
         L.cz_resblock.restype = i32
         L.cz_split_bias_act.argtypes = [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, vp]
@@ -319,6 +321,18 @@ def resblock(x, w1_packed, bias1, w2_packed, bias2, out=None, out_f32=None):
                             _ptr(yh), _ptr(yl), _ptr(out_f32), n, c, _dt_code(xh.dtype), parts, _stream()),
           "cz_resblock")
     return out_f32 if out_f32 is not None else out
+
+
+def resblock_heads(x, w1_packed, bias1, w2_packed, bias2, head_w, head_b, n_policy, policy_feat, value_feat):
+    """The last residual block with the 1x1 head convolutions folded in (split operands, 128 filters):
+    x = (hi, lo) -> policy_feat [N, n_policy*90], value_feat [N, (6-n_policy)*90] (fp32)."""
+    require_gpu()
+    xh, xl = x
+    check(lib().cz_resblock_heads(_ptr(xh), _ptr(xl), _ptr(w1_packed), _ptr(bias1), _ptr(w2_packed), _ptr(bias2),
+                                  _ptr(head_w), _ptr(head_b), _ptr(policy_feat), _ptr(value_feat), xh.shape[0],
+                                  xh.shape[-1], _dt_code(xh.dtype), n_policy, head_w.shape[0] - n_policy, _stream()),
+          "cz_resblock_heads")
+    return policy_feat, value_feat
 
 
 def split_bias_act(x, bias, out, relu=True):

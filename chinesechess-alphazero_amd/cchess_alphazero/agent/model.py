@@ -114,6 +114,7 @@ class InferenceNet(nn.Module):
         self.trunk = trunk
         self.fused_epilogue = True          # on the GPU: hand-written bias + skip + ReLU pass after each conv
         self.fused_blocks = True            # trunk="mfma", fp32, 128 filters: one launch per residual block
+        self.fused_heads = True             # ... and the 1x1 head convolutions folded into the last block's store pass
         self.block_events = None            # bench.py: list collecting (start, end) HIP events around tower launches
         self.input_depth = net.cfg["input_depth"]
         self.filters = net.cfg["cnn_filter_num"]
@@ -187,8 +188,10 @@ class InferenceNet(nn.Module):
             self._bufs = {key: (bufs, last)}              # one batch size at a time (the evaluation queue)
         return self._bufs[key]
 
-    def _trunk_mfma(self, planes):
-        """planes: the evaluation queue as the search kernel wrote it ([n, in_planes, 10, 9], any supported dtype)."""
+    def _trunk_mfma(self, planes, heads=None):
+        """planes: the evaluation queue as the search kernel wrote it ([n, in_planes, 10, 9], any supported dtype).
+        heads = (n_policy, policy_feat, value_feat): fold the 1x1 head convolutions into the last block where the
+        kernel exists for the shape (returns None then), else returns the [n, 90, c] trunk output."""
         from cchess_alphazero import _native
         n, c = planes.shape[0], self.filters
         (cur, tmp, nxt), last = self._operands(n, planes.device)
@@ -208,6 +211,9 @@ class InferenceNet(nn.Module):
                 if i + 1 < nblk:
                     _native.resblock(cur, w1, b1, w2, b2, out=nxt)
                     cur, nxt = nxt, cur
+                elif heads is not None and self.parts == 2 and c == 128:
+                    _native.resblock_heads(cur, w1, b1, w2, b2, self.head_w32, self.head_b32, heads[0], heads[1],
+                                           heads[2])
                 elif self.parts == 2:
                     _native.resblock(cur, w1, b1, w2, b2, out_f32=last)
                 else:
@@ -224,6 +230,8 @@ class InferenceNet(nn.Module):
                 _native.conv3x3(tmp, w2, getattr(self, f"tb{i}b"), skip=cur, out_f32=last)
             else:
                 _native.conv3x3(tmp, w2, getattr(self, f"tb{i}b"), skip=cur, out=(last,))
+        if heads is not None and fused and self.parts == 2 and c == 128:
+            return None                                                  # the head features are already written
         return last                                                      # [n, 90, c] channels-last trunk output
 
     def _trunk_fused(self, x):
@@ -245,17 +253,19 @@ class InferenceNet(nn.Module):
         if self.trunk == "mfma":
             if not planes.is_cuda:
                 raise RuntimeError("trunk='mfma' is the hand-written HIP path: it has no CPU implementation")
-            last = self._trunk_mfma(planes)
-            n, npol = last.shape[0], self.policy_conv.out_channels
+            n, npol = planes.shape[0], self.policy_conv.out_channels
             if self.head_w32.shape[0] == 6:
                 from cchess_alphazero import _native
-                pf = torch.empty((n, npol * 90), dtype=torch.float32, device=last.device)
-                vf = torch.empty((n, (6 - npol) * 90), dtype=torch.float32, device=last.device)
-                _native.head_convs(last, self.head_w32, self.head_b32, npol, pf, vf)
+                pf = torch.empty((n, npol * 90), dtype=torch.float32, device=planes.device)
+                vf = torch.empty((n, (6 - npol) * 90), dtype=torch.float32, device=planes.device)
+                last = self._trunk_mfma(planes, heads=(npol, pf, vf) if self.fused_heads else None)
+                if last is not None:
+                    _native.head_convs(last, self.head_w32, self.head_b32, npol, pf, vf)
                 p = self.policy_out(pf.to(self.dtype))
                 v = F.relu(self.value_dense(vf.to(self.dtype)))
                 v = torch.tanh(self.value_out(v).float())
                 return F.softmax(p.float(), dim=1), v.squeeze(1)
+            last = self._trunk_mfma(planes)
             x = last.view(n, 10, 9, self.filters).permute(0, 3, 1, 2)    # logical NCHW over channels-last memory
         else:
             x = planes.to(self.dtype).contiguous(memory_format=torch.channels_last)

@@ -303,12 +303,24 @@ __device__ long long g_trace[64][8];     // tuning probe (DBG & 8): [board k][ph
 //   barriers per tile: A (X ready) .. K1 .. epi1 -> Y .. B (Y ready) .. K2 .. epi2 -> staging .. C (staged, X free)
 constexpr int RB_COPY_THREADS = 256;
 
-template <typename E, int C, int PARTS, int P, int DBG = 0>
+// HEADS: the block is the last one of the tower and the copy waves, instead of storing its output, apply the two
+// 1x1 head convolutions (6 filters: n_pol policy + 6 - n_pol value, BatchNorm folded, ReLU) to the staged fp32
+// activation and write only the 6 x 90 head features per board (channels-first Flatten order).
+struct HeadArgs {
+    const float* w;        // [6][C]
+    const float* b;        // [6]
+    float* pol;            // [n][n_pol * 90]
+    float* val;            // [n][(6 - n_pol) * 90]
+    int n_pol;
+};
+
+template <typename E, int C, int PARTS, int P, int DBG = 0, bool HEADS = false>
 __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_resblock(
     const E* __restrict__ xh, const E* __restrict__ xl, const E* __restrict__ w1p, const float* __restrict__ b1,
     const E* __restrict__ w2p, const float* __restrict__ b2, E* __restrict__ yh, E* __restrict__ yl,
-    float* __restrict__ yf, int n_boards)
+    float* __restrict__ yf, int n_boards, HeadArgs hd)
 {
+    static_assert(!HEADS || (PARTS == 2 && C / 8 == 16), "fused heads: split operands, 128 filters");
     typedef Geom<C, P, PARTS> G;
     constexpr int NT = G::NT, CT = G::CT, CTHR = RB_COPY_THREADS;
     constexpr int SROW = PARTS == 2 ? C * 4 : C * 2;   // staging row (one pixel): fp32, or the final 2-byte values
@@ -338,6 +350,13 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
         tile_load<E, C, P, PARTS, (DBG & 2) != 0, CTHR>(xh, xl, t * P, n_boards, ctid, v);
         tile_write<C, P, PARTS, CTHR>(X, ctid, v);
         int t_prev = -1;
+        float hw[HEADS ? 6 : 1][8];                            // this thread's slice of the head filters (c8 is fixed)
+        if (HEADS) {
+#pragma unroll
+            for (int o = 0; o < 6; ++o)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) hw[o][k] = hd.w[o * C + (ctid % (C / 8)) * 8 + k];
+        }
         for (;;) {
             __syncthreads();                                   // A: X holds tile t
             const int tn = t + stride;
@@ -359,7 +378,29 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
                         const float4 f1 = *reinterpret_cast<const float4*>(S + stage_off(qq, c8 * 8 + 4));
                         const float r[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
                         if (DBG & 1) continue;
-                        if (yf) {
+                        if (HEADS) {
+                            // 16 consecutive lanes hold the 128 channels of one pixel: partial dot products, then a
+                            // 16-lane butterfly; lane o of the group writes head output o
+                            float hs[6];
+#pragma unroll
+                            for (int o = 0; o < 6; ++o) {
+                                float a = 0.0f;
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) a += r[k] * hw[o][k];
+#pragma unroll
+                                for (int d = 1; d < 16; d <<= 1) a += __shfl_xor(a, d, 64);
+                                hs[o] = a;
+                            }
+                            const int board = to * P + qq / 90, q = qq % 90;
+#pragma unroll
+                            for (int o = 0; o < 6; ++o)
+                                if (c8 == o) {
+                                    float v = hs[o] + hd.b[o];
+                                    v = v > 0.0f ? v : 0.0f;
+                                    if (o < hd.n_pol) hd.pol[(size_t)board * (hd.n_pol * 90) + o * 90 + q] = v;
+                                    else hd.val[(size_t)board * ((6 - hd.n_pol) * 90) + (o - hd.n_pol) * 90 + q] = v;
+                                }
+                        } else if (yf) {
                             float4* o = reinterpret_cast<float4*>(yf + ebase) + 2 * i;
                             o[0] = f0;
                             o[1] = f1;
@@ -882,14 +923,14 @@ extern "C" int cz_input_conv(const void* planes, int planes_dtype, int in_planes
 }
 
 namespace {
-template <typename E, int C, int PARTS, int P, int DBG = 0>
+template <typename E, int C, int PARTS, int P, int DBG = 0, bool HEADS = false>
 int launch_resblock(const void* xh, const void* xl, const void* w1, const float* b1, const void* w2, const float* b2,
-                    void* yh, void* yl, float* yf, int n, int n_cu, hipStream_t st)
+                    void* yh, void* yl, float* yf, int n, int n_cu, hipStream_t st, HeadArgs hd = HeadArgs{})
 {
     const int tiles = (n + P - 1) / P;
     const unsigned blocks = (unsigned)(tiles < n_cu ? tiles : n_cu);
-    hipLaunchKernelGGL((k_resblock<E, C, PARTS, P, DBG>), dim3(blocks), dim3((C / 32 + 4) * 64), 0, st, (const E*)xh,
-                       (const E*)xl, (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, yf, n);
+    hipLaunchKernelGGL((k_resblock<E, C, PARTS, P, DBG, HEADS>), dim3(blocks), dim3((C / 32 + 4) * 64), 0, st,
+                       (const E*)xh, (const E*)xl, (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, yf, n, hd);
     return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
 }
 
@@ -935,6 +976,51 @@ int dispatch_resblock(int channels, int parts, const void* xh, const void* xl, c
 }
 }  // namespace
 
+static int device_cu_count()
+{
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        n_cu = prop.multiProcessorCount;
+    }
+    return n_cu;
+}
+
+extern "C" int cz_resblock_heads(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1,
+                                 const void* w2_packed, const float* bias2, const float* head_w, const float* head_b,
+                                 float* policy_feat, float* value_feat, int n_boards, int channels, int dtype,
+                                 int n_policy, int n_value, void* stream)
+{
+    if (n_boards < 0 || !x_hi || !x_lo || !w1_packed || !w2_packed || !bias1 || !bias2 || !head_w || !head_b ||
+        !policy_feat || !value_feat || n_policy < 1 || n_value < 1 || n_policy + n_value != 6) {
+        czi_set_error("cz_resblock_heads: bad argument (split operands; n_policy + n_value == 6)");
+        return CZ_ERR_ARG;
+    }
+    if (n_boards == 0) return CZ_OK;
+    if (channels != 128 || (dtype != CZ_BF16 && dtype != CZ_F16)) {
+        czi_set_error("cz_resblock_heads: 128 filters, bf16 / f16 split operands only (use cz_resblock + cz_head_convs)");
+        return CZ_ERR_ARG;
+    }
+    const int n_cu = device_cu_count();
+    if (n_cu < 0) {
+        czi_set_error("cz_resblock_heads: cannot query the device");
+        return CZ_ERR_HIP;
+    }
+    const HeadArgs hd{head_w, head_b, policy_feat, value_feat, n_policy};
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (dtype == CZ_BF16)
+        rc = launch_resblock<__bf16, 128, 2, 1, 0, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, nullptr, nullptr,
+                                                       nullptr, n_boards, n_cu, st, hd);
+    else
+        rc = launch_resblock<_Float16, 128, 2, 1, 0, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, nullptr,
+                                                         nullptr, nullptr, n_boards, n_cu, st, hd);
+    if (rc != CZ_OK) czi_set_error("cz_resblock_heads: launch failed");
+    return rc;
+}
+
 extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1,
                            const void* w2_packed, const float* bias2, void* y_hi, void* y_lo, float* y_f32,
                            int n_boards, int channels, int dtype, int parts, void* stream)
@@ -945,15 +1031,10 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
         return CZ_ERR_ARG;
     }
     if (n_boards == 0) return CZ_OK;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-            czi_set_error("cz_resblock: cannot query the device");
-            return CZ_ERR_HIP;
-        }
-        n_cu = prop.multiProcessorCount;
+    const int n_cu = device_cu_count();
+    if (n_cu < 0) {
+        czi_set_error("cz_resblock: cannot query the device");
+        return CZ_ERR_HIP;
     }
     hipStream_t st = (hipStream_t)stream;
     int rc = CZ_ERR_ARG;

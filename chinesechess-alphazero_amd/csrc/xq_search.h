@@ -29,6 +29,7 @@ enum GamePhase : uint8_t {
     PH_IDLE = 0,        // nothing to do (external mode: waiting for set_roots / choose)
     PH_SEARCH = 1,      // simulations outstanding for the current root
     PH_READY = 2,       // search of the current root complete (external mode: results can be read)
+    PH_COMPACT = 3,     // self-play: the next search needs the arena compacted first (k_compact, off the round's critical path)
 };
 
 // per-game counters (uint64 each); summed on the host

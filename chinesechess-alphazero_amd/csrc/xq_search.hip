@@ -37,6 +37,8 @@ namespace {
 constexpr int MAXD_LDS = 128;          // LDS copy of the current path; SearchParams.max_depth <= this
 constexpr int INIT_NIB_WORDS = KEY_WORDS;
 
+constexpr int MAX_BATCHES_PER_LAUNCH = 3;   // lock-step batches one k_sim launch may START for a game
+
 struct SearchLDS {
     RulesLDS r;
     uint32_t key[KEY_WORDS + 4];
@@ -695,87 +697,156 @@ XQ_D void clear_tree(const SearchParams& P, const SearchBuffers& B, const GameVi
 // Returns the new root index.  Nodes keep their relative order, so every move is towards lower addresses.
 XQ_D int compact_tree(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L, int root)
 {
+    // Every phase works on batches of up to 64 nodes with one lane per node for the bookkeeping and one lane per EDGE
+    // for the bulk (flat walk over the edges of the whole batch, independent steps), so that a compaction costs a few
+    // dozen dependent memory round trips instead of several per node: it runs inside k_advance, where one game's
+    // compaction is every game's latency.
     const int lane = lane_id();
     const int g = gv.g;
     const int ncount = uni(B.g_node_count[g]);
     int32_t* remap = reinterpret_cast<int32_t*>(gv.hash);
     int32_t* stack = remap + P.node_cap;
+    int* pfx = L.sn;                                   // [64] exclusive prefix of the batch's edge counts
+    int* oe = L.sn + 64;                               // [64] old edge offset of each batch node
+    int* ne = reinterpret_cast<int*>(L.pr);            // [64] new edge offset
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const auto scan_edges = [&](int nm_l, int* total) {       // exclusive prefix over the lanes, sum in *total
+        int incl = nm_l;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        *total = __shfl(incl, 63, 64);
+        return incl - nm_l;
+    };
+    const auto slot_of = [&](int f) {                          // batch node that owns flat edge f: last s with pfx[s] <= f
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step; step >>= 1)
+            if (pfx[lo + step] <= f) lo += step;
+        return lo;
+    };
     for (int i = lane; i < ncount; i += 64) remap[i] = -1;
     wave_sync_global();
-    // mark
+    // ---- mark (DFS over batches; a child is claimed by the first edge that reaches it) ----
     int top = 1;
     if (lane == 0) { stack[0] = root; remap[root] = 0; }
     wave_sync_global();
     while (top > 0) {
-        const int node = uni(stack[top - 1]);
-        top -= 1;
-        const int nm = (int)(uniu(gv.node_meta[node]) & 0xFF);
-        const int eoff = (int)uniu(gv.node_eoff[node]);
-        for (int base = 0; base < nm; base += 64) {
-            const int j = base + lane;
-            int child = -1;
-            if (j < nm) child = gv.e_child[eoff + j];
-            const bool fresh = child >= 0 && remap[child] < 0;       // children of one node are distinct
-            const uint64_t m = __ballot(fresh);
-            if (fresh) {
-                const int pos = top + __popcll(m & ((1ull << lane) - 1ull));
-                stack[pos] = child;
-                remap[child] = 0;
-            }
-            top += __popcll(m);
-            wave_sync_global();
+        const int nb = top < 64 ? top : 64;
+        int nm_l = 0, eoff_l = 0;
+        if (lane < nb) {
+            const int node = stack[top - 1 - lane];
+            nm_l = (int)(gv.node_meta[node] & 0xFF);
+            eoff_l = (int)gv.node_eoff[node];
         }
+        top -= nb;
+        int total;
+        const int ex = scan_edges(nm_l, &total);
+        wave_sync();
+        pfx[lane] = lane < nb ? ex : 0x7fffffff;
+        oe[lane] = eoff_l;
+        wave_sync();
+        for (int f0 = 0; f0 < total; f0 += 256) {
+            int child[4];
+            bool fresh[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = f0 + u * 64 + lane;
+                child[u] = -1;
+                if (f < total) {
+                    const int sl = slot_of(f);
+                    child[u] = gv.e_child[oe[sl] + (f - pfx[sl])];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                fresh[u] = false;
+                if (child[u] >= 0) fresh[u] = atomicCAS(&remap[child[u]], -1, 0) == -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint64_t m = __ballot(fresh[u]);
+                if (fresh[u]) stack[top + __popcll(m & lt)] = child[u];
+                top += __popcll(m);
+            }
+        }
+        wave_sync_global();
     }
-    // new indices in old order
+    // ---- new indices in old order ----
     int live = 0;
     for (int base = 0; base < ncount; base += 64) {
         const int i = base + lane;
         const bool keep = i < ncount && remap[i] == 0;
         const uint64_t m = __ballot(keep);
-        if (keep) remap[i] = live + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep) remap[i] = live + __popcll(m & lt);
         live += __popcll(m);
     }
     wave_sync_global();
-    // slide nodes and their edges down, remapping the child links
+    // ---- slide nodes and their edges down, remapping the child links.  Nodes keep their order and edge offsets grow
+    //      with the node index, so every destination is at or below its source and below every later source ----
     int ecount = 0;
-    for (int i = 0; i < ncount; ++i) {
-        const int ni = uni(remap[i]);
-        if (ni < 0) continue;
-        const uint32_t meta = uniu(gv.node_meta[i]);
-        const int nm = (int)(meta & 0xFF);
-        const int eoff = (int)uniu(gv.node_eoff[i]);
-        const int sum_n = uni(gv.node_sum_n[i]);
-        uint32_t kw = 0;
-        if (lane < KEY_WORDS) kw = gv.node_key[(size_t)i * KEY_WORDS + lane];
-        int en[2], ec[2]; double ew[2]; float ep[2]; uint16_t em[2];
+    for (int base = 0; base < ncount; base += 64) {
+        const int i = base + lane;
+        const int ni = i < ncount ? remap[i] : -1;
+        const uint64_t lm = __ballot(ni >= 0);
+        if (lm == 0) continue;
+        uint32_t meta = 0, eoff_l = 0;
+        int sum_n = 0;
+        uint32_t kw[KEY_WORDS];
+        if (ni >= 0) {
+            meta = gv.node_meta[i];
+            eoff_l = gv.node_eoff[i];
+            sum_n = gv.node_sum_n[i];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int j = lane + 64 * h;
-            en[h] = 0; ec[h] = CHILD_UNKNOWN; ew[h] = 0.0; ep[h] = 0.0f; em[h] = 0;
-            if (j < nm) {
-                en[h] = gv.e_n[eoff + j]; ew[h] = gv.e_w[eoff + j]; ep[h] = gv.e_p[eoff + j];
-                em[h] = gv.e_mv[eoff + j]; ec[h] = gv.e_child[eoff + j];
-                if (ec[h] >= 0) ec[h] = remap[ec[h]];
-            }
+            for (int w = 0; w < KEY_WORDS; ++w) kw[w] = gv.node_key[(size_t)i * KEY_WORDS + w];
         }
-        wave_sync_global();
-        if (lane < KEY_WORDS) gv.node_key[(size_t)ni * KEY_WORDS + lane] = kw;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int j = lane + 64 * h;
-            if (j < nm) {
-                gv.e_n[ecount + j] = en[h]; gv.e_w[ecount + j] = ew[h]; gv.e_p[ecount + j] = ep[h];
-                gv.e_mv[ecount + j] = em[h]; gv.e_child[ecount + j] = ec[h];
-            }
-        }
-        if (lane == 0) {
-            gv.node_sum_n[ni] = sum_n;
-            gv.node_eoff[ni] = (uint32_t)ecount;
+        const int nm_l = ni >= 0 ? (int)(meta & 0xFF) : 0;
+        int total;
+        const int ex = scan_edges(nm_l, &total);
+        wave_sync();
+        pfx[lane] = ex;                                     // dead lanes: nm 0, never selected by slot_of
+        oe[lane] = (int)eoff_l;
+        ne[lane] = ecount + ex;
+        wave_sync();
+        if (ni >= 0) {                                      // headers: all of the batch's reads are done
             gv.node_meta[ni] = meta;
+            gv.node_eoff[ni] = (uint32_t)(ecount + ex);
+            gv.node_sum_n[ni] = sum_n;
+#pragma unroll
+            for (int w = 0; w < KEY_WORDS; ++w) gv.node_key[(size_t)ni * KEY_WORDS + w] = kw[w];
         }
-        ecount += nm;
-        wave_sync_global();
+        for (int f0 = 0; f0 < total; f0 += 128) {
+            int src[2], dst[2], en[2], ec[2];
+            double ew[2];
+            float ep[2];
+            uint16_t em[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int f = f0 + u * 64 + lane;
+                src[u] = -1;
+                if (f < total) {
+                    const int sl = slot_of(f);
+                    src[u] = oe[sl] + (f - pfx[sl]);
+                    dst[u] = ne[sl] + (f - pfx[sl]);
+                    en[u] = gv.e_n[src[u]]; ew[u] = gv.e_w[src[u]]; ep[u] = gv.e_p[src[u]];
+                    em[u] = gv.e_mv[src[u]]; ec[u] = gv.e_child[src[u]];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (src[u] >= 0 && ec[u] >= 0) ec[u] = remap[ec[u]];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (src[u] >= 0) {
+                    gv.e_n[dst[u]] = en[u]; gv.e_w[dst[u]] = ew[u]; gv.e_p[dst[u]] = ep[u];
+                    gv.e_mv[dst[u]] = em[u]; gv.e_child[dst[u]] = ec[u];
+                }
+        }
+        ecount += total;
     }
+    wave_sync_global();
     const int new_root = uni(remap[root]);
     wave_sync_global();
     // rebuild the hash table: one node per lane, linear probing with a compare-and-swap on the slot
@@ -804,7 +875,11 @@ XQ_D int compact_tree(const SearchParams& P, const SearchBuffers& B, const GameV
 
 // Start the search of the position in g_board (CChessPlayer.action, player.py:145-164): find the
 // root in the tree, apply the reuse rule, make room in the arena.
-XQ_D void begin_search(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L)
+// defer_compaction (self-play, k_advance): when the arena has to be compacted first, only mark the game PH_COMPACT;
+// k_compact finishes the job (this function again, not deferred) on a side stream while the round goes on without
+// this game -- one game's compaction (a few ms of dependent round trips) is otherwise every game's latency.
+XQ_D void begin_search(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L,
+                       bool defer_compaction = false)
 {
     const int lane = lane_id();
     const int g = gv.g;
@@ -828,6 +903,16 @@ XQ_D void begin_search(const SearchParams& P, const SearchBuffers& B, const Game
         return nc + tasks + 1 > P.node_cap || (long long)ec + (long long)(tasks + 1) * 64 > P.edge_cap;
     };
     if (tasks > 0 && no_room(ncount, ecount)) {
+        if (defer_compaction && root >= 0) {
+            if (lane == 0) {
+                B.g_root[g] = root;
+                B.g_tasks_left[g] = 0;
+                B.g_active[g] = 0;
+                B.g_phase[g] = PH_COMPACT;
+            }
+            wave_sync_global();
+            return;
+        }
         if (root >= 0) {
             root = compact_tree(P, B, gv, L, root);
             count(gv, CT_TREE_COMPACTIONS);
@@ -994,7 +1079,7 @@ XQ_D void new_game(const SearchParams& P, const SearchBuffers& B, const GameView
         B.g_enable_resign[g] = philox_uniform(P.seed, game_id, 0, 0) > P.enable_resign_rate ? 1 : 0;
     }
     wave_sync_global();
-    begin_search(P, B, gv, L);
+    begin_search(P, B, gv, L, true);                 // (a new game starts on an empty tree: never deferred in effect)
 }
 
 XQ_D void emit_record(const SearchParams& P, const SearchBuffers& B, const GameView& gv, int turns, int value,
@@ -1098,7 +1183,7 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
         wave_sync_global();
     }
     if (!game_over) {
-        begin_search(P, B, gv, L);
+        begin_search(P, B, gv, L, true);
         return;
     }
     if (final_move != NOMOVE) {                                         // :177-184
@@ -1150,7 +1235,7 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
         }
         resume_i = 0;                                                 // 2. then resume the parked simulations
     }
-    int new_i = 0, new_n = 0;
+    int new_i = 0, new_n = 0, batches = 0;
     for (int guard = 0; guard < (1 << 20); ++guard) {
         int sim, node, depth;
         bool fresh;
@@ -1164,6 +1249,10 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
         } else if ((mask & SIM_SELECT) && active == 0) {              // 3. next lock-step batch (player.py:169-178)
             const int tasks = uni(B.g_tasks_left[g]);
             if (tasks <= 0) break;                                    // search complete: k_advance takes over
+            // A batch whose simulations all end on terminal / repeated positions needs no evaluation and the next one
+            // could start at once -- in a won endgame that chains hundreds of batches inside one launch and the whole
+            // round waits for this wave.  The order of simulations does not depend on where the chain is cut.
+            if (++batches > MAX_BATCHES_PER_LAUNCH) break;
             new_n = tasks < P.K ? tasks : P.K;
             new_i = 0;
             active = new_n;
@@ -1189,11 +1278,24 @@ __global__ __launch_bounds__(64) void k_advance(SearchParams P, SearchBuffers B)
     if (P.mode == MODE_SELFPLAY) {
         for (int it = 0; it < 8; ++it) {          // a search with nothing to do (fully reused root) ends at once
             advance_game(P, B, gv, L);
-            if (uni(B.g_tasks_left[g]) != 0) break;
+            if (uni((int)B.g_phase[g]) != PH_SEARCH || uni(B.g_tasks_left[g]) != 0) break;
         }
     } else if (lane_id() == 0) {
         B.g_phase[g] = PH_READY;
     }
+    counters_flush(gv);
+}
+
+// The deferred half of begin_search for the games k_advance left in PH_COMPACT.
+__global__ __launch_bounds__(64) void k_compact(SearchParams P, SearchBuffers B)
+{
+    __shared__ SearchLDS L;
+    const int g = blockIdx.x;
+    if (g >= P.G) return;
+    if (uni((int)B.g_phase[g]) != PH_COMPACT) return;
+    const GameView gv = make_view(B, P, g, L.ctr);
+    counters_begin(gv);
+    begin_search(P, B, gv, L, false);
     counters_flush(gv);
 }
 
@@ -1382,6 +1484,9 @@ struct cz_search {
     void* slab;
     size_t bytes;
     int device;
+    hipStream_t side = nullptr;       // k_compact runs here, overlapping the rest of the round and the network
+    hipEvent_t ev_fork = nullptr, ev_done = nullptr;
+    bool side_pending = false;        // a k_compact launch the caller's stream has not waited for yet
 };
 
 namespace {
@@ -1400,6 +1505,16 @@ int serr_hip(const char* what, hipError_t e)
 }
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Every entry point that touches the search state first orders the caller's stream behind a k_compact still running
+// on the side stream.
+void join_side(cz_search* s, hipStream_t st)
+{
+    if (s->side_pending) {
+        (void)hipStreamWaitEvent(st, s->ev_done, 0);
+        s->side_pending = false;
+    }
+}
 
 template <typename T>
 void carve(char*& cur, T*& ptr, size_t count, bool dry)
@@ -1511,6 +1626,10 @@ int cz_search_create(const cz_search_cfg* c, cz_search** out)
     e = hipMemset(s->slab, 0, s->bytes);
     if (e != hipSuccess) { (void)hipFree(s->slab); delete s; return serr_hip("cz_search_create: hipMemset", e); }
     layout(s, (char*)s->slab, false);
+    e = hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming);
+    if (e != hipSuccess) { (void)cz_search_destroy(s); return serr_hip("cz_search_create: side stream", e); }
     *out = s;
     return CZ_OK;
 }
@@ -1518,6 +1637,9 @@ int cz_search_create(const cz_search_cfg* c, cz_search** out)
 int cz_search_destroy(cz_search* s)
 {
     if (!s) return CZ_OK;
+    if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_done) (void)hipEventDestroy(s->ev_done);
     (void)hipFree(s->slab);
     delete s;
     return CZ_OK;
@@ -1543,6 +1665,7 @@ int cz_search_info(const cz_search* s, int32_t* out)
 int cz_search_start_selfplay(cz_search* s, uint64_t seed, uint32_t first_game_id, uint32_t game_id_stride, void* stream)
 {
     if (!s) return serr(CZ_ERR_ARG, "cz_search_start_selfplay: null handle");
+    join_side(s, (hipStream_t)stream);
     s->P.mode = MODE_SELFPLAY;
     s->P.seed = seed;
     s->P.game_id_stride = game_id_stride ? game_id_stride : (uint32_t)s->P.G;
@@ -1558,6 +1681,7 @@ int cz_search_set_roots(cz_search* s, const int8_t* boards, const int32_t* turns
                         const uint8_t* select_mask, const int8_t* prev_boards, const uint8_t* hist_kind, void* stream)
 {
     if (!s || !boards) return serr(CZ_ERR_ARG, "cz_search_set_roots: null argument");
+    join_side(s, (hipStream_t)stream);
     s->P.mode = MODE_EXTERNAL;
     hipLaunchKernelGGL(k_set_roots, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, boards, turns, no_act,
                        n_no_act, increase_temp, enable_resign, select_mask, prev_boards, hist_kind);
@@ -1570,12 +1694,29 @@ int cz_search_round(cz_search* s, const float* policy, const float* value, void*
     if (!s || !planes || !policy || !value) return serr(CZ_ERR_ARG, "cz_search_round: null argument");
     const dim3 grid(s->P.G), block(64);
     hipStream_t st = (hipStream_t)stream;
+    join_side(s, st);
     const bool noise = s->P.noise_eps != 0.0;
     if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B, SIM_BACKUP);
     const bool hist = s->P.in_planes == 28;
     if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP);
     else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP);
     hipLaunchKernelGGL(k_advance, grid, block, 0, st, s->P, s->B);
+    if (s->P.mode == MODE_SELFPLAY) {
+        // games whose next search needs a compaction sit this round out; k_compact readies them on the side stream,
+        // under the rest of the round and the network forward.  (While the caller captures a HIP graph the fork could
+        // not be joined inside the capture: run it in line.)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (cap != hipStreamCaptureStatusNone) {
+            hipLaunchKernelGGL(k_compact, grid, block, 0, st, s->P, s->B);
+        } else {
+            (void)hipEventRecord(s->ev_fork, st);
+            (void)hipStreamWaitEvent(s->side, s->ev_fork, 0);
+            hipLaunchKernelGGL(k_compact, grid, block, 0, s->side, s->P, s->B);
+            (void)hipEventRecord(s->ev_done, s->side);
+            s->side_pending = true;
+        }
+    }
     if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B, SIM_SELECT);
     if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT);
     else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT);
@@ -1595,6 +1736,7 @@ int cz_search_set_sims(cz_search* s, int simulation_num_per_move)
 int cz_search_reset_trees(cz_search* s, void* stream)
 {
     if (!s) return serr(CZ_ERR_ARG, "cz_search_reset_trees: null handle");
+    join_side(s, (hipStream_t)stream);
     hipLaunchKernelGGL(k_reset_trees, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B);
     S_LAUNCH_CHECK("cz_search_reset_trees");
     return CZ_OK;
@@ -1603,6 +1745,7 @@ int cz_search_reset_trees(cz_search* s, void* stream)
 int cz_search_pending(cz_search* s, int* host_out, void* stream)
 {
     if (!s || !host_out) return serr(CZ_ERR_ARG, "cz_search_pending: null argument");
+    join_side(s, (hipStream_t)stream);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(s->B.pending, 0, sizeof(int32_t), st);
     if (e != hipSuccess) return serr_hip("cz_search_pending", e);
@@ -1620,6 +1763,7 @@ int cz_search_root_stats(cz_search* s, uint16_t* moves, int32_t* n, double* w, f
                          uint8_t* counts, void* stream)
 {
     if (!s) return serr(CZ_ERR_ARG, "cz_search_root_stats: null handle");
+    join_side(s, (hipStream_t)stream);
     hipLaunchKernelGGL(k_root_stats, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, (const uint16_t*)nullptr, 0,
                        moves, n, w, p, sum_n, counts);
     S_LAUNCH_CHECK("cz_search_root_stats");
@@ -1629,6 +1773,7 @@ int cz_search_root_stats(cz_search* s, uint16_t* moves, int32_t* n, double* w, f
 int cz_search_stop(cz_search* s, void* stream)
 {
     if (!s) return serr(CZ_ERR_ARG, "cz_search_stop: null handle");
+    join_side(s, (hipStream_t)stream);
     hipLaunchKernelGGL(k_stop, dim3((s->P.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->P, s->B);
     S_LAUNCH_CHECK("cz_search_stop");
     return CZ_OK;
@@ -1638,6 +1783,7 @@ int cz_search_node_stats(cz_search* s, const uint16_t* path, int path_len, uint1
                          float* p, int32_t* sum_n, uint8_t* counts, void* stream)
 {
     if (!s || path_len < 0 || (path_len > 0 && !path)) return serr(CZ_ERR_ARG, "cz_search_node_stats: bad argument");
+    join_side(s, (hipStream_t)stream);
     hipLaunchKernelGGL(k_root_stats, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, path, path_len, moves, n, w,
                        p, sum_n, counts);
     S_LAUNCH_CHECK("cz_search_node_stats");
@@ -1647,6 +1793,7 @@ int cz_search_node_stats(cz_search* s, const uint16_t* path, int path_len, uint1
 int cz_search_choose(cz_search* s, const double* u, int32_t* action, void* stream)
 {
     if (!s || !action) return serr(CZ_ERR_ARG, "cz_search_choose: null argument");
+    join_side(s, (hipStream_t)stream);
     hipLaunchKernelGGL(k_choose, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, u, action);
     S_LAUNCH_CHECK("cz_search_choose");
     return CZ_OK;
@@ -1655,6 +1802,7 @@ int cz_search_choose(cz_search* s, const double* u, int32_t* action, void* strea
 int cz_search_counters(cz_search* s, uint64_t* host_out, void* stream)
 {
     if (!s || !host_out) return serr(CZ_ERR_ARG, "cz_search_counters: null argument");
+    join_side(s, (hipStream_t)stream);
     const size_t n = (size_t)s->P.G * CT_COUNT;
     unsigned long long* tmp = new (std::nothrow) unsigned long long[n];
     if (!tmp) return serr(CZ_ERR_NOMEM, "cz_search_counters: host allocation failed");
@@ -1676,6 +1824,7 @@ int cz_search_counters(cz_search* s, uint64_t* host_out, void* stream)
 int cz_search_drain_records(cz_search* s, unsigned int* cursor, void* host_buf, int max_records, int* n_out, void* stream)
 {
     if (!s || !cursor || !host_buf || !n_out) return serr(CZ_ERR_ARG, "cz_search_drain_records: null argument");
+    join_side(s, (hipStream_t)stream);
     hipStream_t st = (hipStream_t)stream;
     unsigned int tail = 0;
     hipError_t e = hipMemcpyAsync(&tail, s->B.ring_tail, sizeof(tail), hipMemcpyDeviceToHost, st);

@@ -204,6 +204,13 @@ int cz_conv3x3(const void* x_hi, const void* x_lo, const void* w_packed, const f
 int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1, const void* w2_packed,
                 const float* bias2, void* y_hi, void* y_lo, float* y_f32, int n_boards, int channels, int dtype,
                 int parts, void* stream);
+/* The LAST residual block of the tower with the two 1x1 head convolutions folded into its store pass (cz_resblock +
+ * cz_head_convs in one launch; the block's activation never reaches HBM): split operands, 128 filters,
+ * n_policy + n_value == 6.  Outputs as cz_head_convs. */
+int cz_resblock_heads(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1,
+                      const void* w2_packed, const float* bias2, const float* head_w, const float* head_b,
+                      float* policy_feat, float* value_feat, int n_boards, int channels, int dtype, int n_policy,
+                      int n_value, void* stream);
 /* number of 2-byte elements of the packed filter (all parts, including the prefetch padding); 0 = bad argument */
 size_t cz_conv3x3_packed_elems(int channels, int parts);
 /* HOST: w_oihw[channels][channels][3][3] fp32 -> MFMA fragment order, split into parts; out_host holds

@@ -114,6 +114,33 @@ def test_resblock_equals_two_convolutions(c, dt, parts, n):
     assert all(torch.equal(a, b) for a, b in zip(xi, want))
 
 
+@pytest.mark.parametrize("n,npol", [(1, 4), (5, 2), (300, 4)])
+def test_resblock_heads_equals_resblock_then_head_convs(n, npol):
+    """cz_resblock_heads = cz_resblock (fp32 out) followed by cz_head_convs; only the summation order of the 128-term
+    dot products differs: <= 2e-6 relative."""
+    import torch
+    from cchess_alphazero import _native
+    c, dtype = 128, torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.randn((n, 90, c), device="cuda", generator=g).relu()
+    ws = [torch.randn((c, c, 3, 3), device="cuda", generator=g) / (3.0 * c ** 0.5) for _ in range(2)]
+    bs = [torch.randn((c,), device="cuda", generator=g) for _ in range(2)]
+    ps = [_native.pack_conv3x3_weights(w, dtype, 2).cuda() for w in ws]
+    hw = torch.randn((6, c), device="cuda", generator=g) / c ** 0.5
+    hb = torch.randn((6,), device="cuda", generator=g)
+    xs = _split(x, dtype, 2)
+    mid = torch.empty((n, 90, c), device="cuda")
+    _native.resblock(xs, ps[0], bs[0], ps[1], bs[1], out_f32=mid)
+    pf0 = torch.empty((n, npol * 90), device="cuda")
+    vf0 = torch.empty((n, (6 - npol) * 90), device="cuda")
+    _native.head_convs(mid, hw, hb, npol, pf0, vf0)
+    pf = torch.full_like(pf0, 7.0)
+    vf = torch.full_like(vf0, 7.0)
+    _native.resblock_heads(xs, ps[0], bs[0], ps[1], bs[1], hw, hb, npol, pf, vf)
+    scale = max(pf0.abs().max().item(), vf0.abs().max().item())
+    assert (pf - pf0).abs().max().item() <= 2e-6 * scale and (vf - vf0).abs().max().item() <= 2e-6 * scale
+
+
 def test_resblock_rejects_unsupported_shapes():
     import torch
     from cchess_alphazero import _native
@@ -233,6 +260,9 @@ def test_network_with_mfma_trunk_matches_fp32_module(filters, blocks):
     lib = InferenceNet(net, torch.float32, trunk="library").cuda()
     p2, v2 = lib(x.cuda())
     assert (p - p2).abs().max().item() < 1e-4 and (v - v2).abs().max().item() < 1e-4
+    inf.fused_heads = False                  # separate head-convolution launch
+    p6, v6 = inf(x.cuda())
+    assert (p6 - p).abs().max().item() < 1e-6 and (v6 - v).abs().max().item() < 1e-5
     inf.fused_blocks = False                 # per-convolution launches: identical trunk arithmetic (the library
     p5, v5 = inf(x.cuda())                   # kernels around it may change solver between calls, hence not torch.equal)
     assert (p5 - p).abs().max().item() < 1e-6 and (v5 - v).abs().max().item() < 1e-5
