@@ -77,7 +77,7 @@ class CChessPlayer:
                               seed=int(np.random.randint(0, 2 ** 31 - 1)),
                               node_capacity=(INFINITE_SIMS + 64) if uci else
                               (getattr(getattr(config, "engine", None), "node_capacity", 0) or 0),
-                              edge_capacity=(INFINITE_SIMS + 66) * 64 if uci else 0,
+                              edge_capacity=(INFINITE_SIMS + 66) * 80 if uci else 0,
                               use_history=use_history)
         self._torch = torch
 

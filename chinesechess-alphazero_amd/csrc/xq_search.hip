@@ -900,7 +900,8 @@ XQ_D void begin_search(const SearchParams& P, const SearchBuffers& B, const Game
     // reuse can still see); only if that is not enough (or the root is new) it is dropped.
     int ncount = uni(B.g_node_count[g]), ecount = uni(B.g_edge_count[g]);
     const auto no_room = [&](int nc, int ec) {
-        return nc + tasks + 1 > P.node_cap || (long long)ec + (long long)(tasks + 1) * 64 > P.edge_cap;
+        // 80 edges reserved per node the search may add: positions with 65-70 legal moves do come in runs
+        return nc + tasks + 1 > P.node_cap || (long long)ec + (long long)(tasks + 1) * 80 > P.edge_cap;
     };
     if (tasks > 0 && no_room(ncount, ecount)) {
         if (defer_compaction && root >= 0) {
@@ -1591,8 +1592,8 @@ int cz_search_create(const cz_search_cfg* c, cz_search** out)
     P.vl = c->virtual_loss;
     P.node_cap = c->node_capacity > 0 ? c->node_capacity : 4 * P.sims + 64;
     if (P.node_cap < P.sims + 2) P.node_cap = P.sims + 2;
-    P.edge_cap = c->edge_capacity > 0 ? c->edge_capacity : P.node_cap * 56;
-    if (P.edge_cap < (P.sims + 2) * 64) P.edge_cap = (P.sims + 2) * 64;
+    P.edge_cap = c->edge_capacity > 0 ? c->edge_capacity : P.node_cap * 64;
+    if (P.edge_cap < (P.sims + 2) * 80) P.edge_cap = (P.sims + 2) * 80;
     int h = 1;
     while (h < 2 * P.node_cap) h <<= 1;
     P.hash_cap = h;

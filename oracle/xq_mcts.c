@@ -456,8 +456,8 @@ int xqo_player_search(xqo_player *p, const int8_t board[90], int turns, const ui
     num_task = sims - done_n;
     if (num_task < 0) num_task = 0;
     if (p->cfg.node_capacity > 0 && num_task > 0) {
-        const long ecap = p->cfg.edge_capacity > 0 ? p->cfg.edge_capacity : 56L * p->cfg.node_capacity;
-#define NO_ROOM() (p->n_nodes + num_task + 1 > p->cfg.node_capacity || p->n_edges + (long)(num_task + 1) * 64 > ecap)
+        const long ecap = p->cfg.edge_capacity > 0 ? p->cfg.edge_capacity : 64L * p->cfg.node_capacity;
+#define NO_ROOM() (p->n_nodes + num_task + 1 > p->cfg.node_capacity || p->n_edges + (long)(num_task + 1) * 80 > ecap)
         if (NO_ROOM()) {
             if (root) { tree_compact(p, root); p->ctr.tree_compactions++; }
             if (!root || NO_ROOM()) { tree_clear(p); p->ctr.tree_resets++; num_task = sims; }
