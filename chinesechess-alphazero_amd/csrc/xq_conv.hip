@@ -1,4 +1,11 @@
-// xq_conv.hip -- the trunk convolution of the policy/value ResNet as a hand-written MFMA kernel (gfx950).
+// xq_conv.hip -- the convolutions of the policy/value ResNet as hand-written MFMA kernels (gfx950).
+//
+//   conv_kloop      the shared K loop (9 taps x C channels out of an LDS image, weights streamed from L2)
+//   k_conv3x3       kernel 1: one convolution per launch, P boards per workgroup (any supported filter count / mode)
+//   k_resblock      kernel 2: a whole residual block per launch, persistent, matrix waves + copy waves; optionally the
+//                   two 1x1 head convolutions folded into the last block's store pass
+//   k_input_conv    kernel 3: the 5x5 input convolution on the feature planes as the search kernel writes them
+//   k_split_bias_act  fp32 -> operand pair (used when the input layer comes from a library convolution)
 //
 // Reference: the residual tower of CChessModel.build / _build_residual_block (cchess_alphazero/agent/model.py:40-83):
 // Conv2D(F, 3, padding="same", use_bias=False) -> BatchNorm -> (+ skip) -> ReLU on 10x9 boards.  With BatchNorm folded

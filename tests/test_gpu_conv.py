@@ -272,3 +272,21 @@ def test_network_with_mfma_trunk_matches_fp32_module(filters, blocks):
         assert (p3.cpu() - p_ref).abs().max().item() < tol and (v3.cpu() - v_ref).abs().max().item() < tol * 10
     with pytest.raises(RuntimeError):
         InferenceNet(net, torch.float32, trunk="mfma")(x)          # no CPU implementation of the HIP trunk
+
+
+def test_network_with_history_planes_and_reference_head_shapes():
+    """28 input planes (use_history) and the 2-policy / 4-value head filters of the reference's published topologies
+    (data/model/model_128f.json) through the hand-written path, uint8 planes as the engine feeds them."""
+    import torch
+    from cchess_alphazero.agent.model import CChessNet, InferenceNet
+    torch.manual_seed(5)
+    net = CChessNet(cnn_filter_num=128, res_layer_num=3, input_depth=28, policy_filters=2, value_filters=4).eval()
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand((9, 28, 10, 9), generator=g) < 0.12).float()
+    with torch.no_grad():
+        p_ref, v_ref = net(x)
+    inf = InferenceNet(net, torch.float32, trunk="mfma").cuda()
+    p, v = inf(x.to(torch.uint8).cuda())
+    assert (p.cpu() - p_ref).abs().max().item() < 1e-4 and (v.cpu() - v_ref).abs().max().item() < 1e-4
+    p2, v2 = inf(x.cuda())                                   # fp32 planes give the same answer
+    assert torch.equal(p, p2) and torch.equal(v, v2)
