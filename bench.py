@@ -268,7 +268,7 @@ def main():
             "tree_shape": {"mean_depth": mean_d, "mean_edges": mean_c, "mean_leaf_moves": mean_l,
                            "terminal_sims": d["terminal_sims"], "repetition_sims": d["repetition_sims"],
                            "parked": d["parked"], "tree_resets": d["tree_resets"],
-                           "overflow_sims": d["overflow_sims"] + d["depth_overflow"]},
+                           "overflow_sims": d["overflow_sims"], "depth_overflow": d["depth_overflow"]},
             "roofline": None, "roofline_search": None, "roofline_nn": None, "cpu_baseline": None,
         }
         if k_ms is not None:

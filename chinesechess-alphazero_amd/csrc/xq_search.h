@@ -30,6 +30,7 @@ enum GamePhase : uint8_t {
     PH_SEARCH = 1,      // simulations outstanding for the current root
     PH_READY = 2,       // search of the current root complete (external mode: results can be read)
     PH_COMPACT = 3,     // self-play: the next search needs the arena compacted first (k_compact, off the round's critical path)
+    PH_COMPACTED = 4,   // k_compact is done; the NEXT round's first kernel turns this into PH_SEARCH (see k_compact)
 };
 
 // per-game counters (uint64 each); summed on the host

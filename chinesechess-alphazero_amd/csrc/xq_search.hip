@@ -879,7 +879,7 @@ XQ_D int compact_tree(const SearchParams& P, const SearchBuffers& B, const GameV
 // k_compact finishes the job (this function again, not deferred) on a side stream while the round goes on without
 // this game -- one game's compaction (a few ms of dependent round trips) is otherwise every game's latency.
 XQ_D void begin_search(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L,
-                       bool defer_compaction = false)
+                       bool defer_compaction = false, int ready_phase = PH_SEARCH)
 {
     const int lane = lane_id();
     const int g = gv.g;
@@ -932,7 +932,7 @@ XQ_D void begin_search(const SearchParams& P, const SearchBuffers& B, const Game
         B.g_root[g] = root;
         B.g_tasks_left[g] = tasks;
         B.g_active[g] = 0;
-        B.g_phase[g] = PH_SEARCH;
+        B.g_phase[g] = (uint8_t)ready_phase;
     }
     wave_sync_global();
 }
@@ -1213,7 +1213,12 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
     __shared__ SearchLDS L;
     const int g = blockIdx.x;
     if (g >= P.G) return;
-    if (uni((int)B.g_phase[g]) != PH_SEARCH) return;
+    int phase = uni((int)B.g_phase[g]);
+    if (phase == PH_COMPACTED && (mask & SIM_BACKUP)) {          // compacted during the previous round (k_compact)
+        phase = PH_SEARCH;
+        if (lane_id() == 0) B.g_phase[g] = PH_SEARCH;
+    }
+    if (phase != PH_SEARCH) return;
     const GameView gv = make_view(B, P, g, L.ctr);
     counters_begin(gv);
     const RoundIO io{planes, P.planes_dtype, P.in_planes};
@@ -1296,7 +1301,11 @@ __global__ __launch_bounds__(64) void k_compact(SearchParams P, SearchBuffers B)
     if (uni((int)B.g_phase[g]) != PH_COMPACT) return;
     const GameView gv = make_view(B, P, g, L.ctr);
     counters_begin(gv);
-    begin_search(P, B, gv, L, false);
+    // k_compact overlaps this round's k_noise / k_sim(SELECT) on another stream, possibly on another XCD whose L2 is
+    // not coherent with ours: those kernels must not pick this game up half-way.  It is left in PH_COMPACTED and the
+    // next round's k_sim(BACKUP) -- ordered behind this kernel by an event, i.e. a kernel boundary -- makes it
+    // PH_SEARCH.
+    begin_search(P, B, gv, L, false, PH_COMPACTED);
     counters_flush(gv);
 }
 
@@ -1597,7 +1606,7 @@ int cz_search_create(const cz_search_cfg* c, cz_search** out)
     int h = 1;
     while (h < 2 * P.node_cap) h <<= 1;
     P.hash_cap = h;
-    P.max_depth = c->max_depth > 0 ? c->max_depth : 64;
+    P.max_depth = c->max_depth > 0 ? c->max_depth : MAXD_LDS;      // simulations deeper than this are cut (counted)
     if (P.max_depth > MAXD_LDS) P.max_depth = MAXD_LDS;
     P.max_game_length = c->max_game_length > 0 ? c->max_game_length : 100;
     P.max_plies = 2 * P.max_game_length + 2;
