@@ -155,3 +155,47 @@ def test_multi_rank_counters_gloo(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
     mins = sorted(int(o.split()[2]) for o in outs if o.startswith("OK") or "OK" in o for o in [o[o.index("OK"):]])
     assert mins == [0, 4096]                               # disjoint game-id ranges per rank
+
+
+def test_weight_packers_on_the_host():
+    """cz_conv3x3_pack_weights / cz_input_conv_pack_weights run on the host: the MFMA fragment order
+    [K-step][channel tile][lane][8] (k = 16 * step' + 8 * (lane >> 5) + j, output channel = 32 * tile + (lane & 31)),
+    the (hi, lo) split with lo = bf16(w - hi), the zero K-steps the kernels prefetch past the end, and the argument
+    checks -- without a GPU."""
+    import torch
+    from cchess_alphazero import _native
+    g = torch.Generator().manual_seed(0)
+    for c in (32, 128):
+        w = torch.randn((c, c, 3, 3), generator=g)
+        for dt in (torch.bfloat16, torch.float16):
+            for parts in (1, 2):
+                p = _native.pack_conv3x3_weights(w, dt, parts)
+                kk, ct = c // 16, c // 32
+                steps = 9 * kk + 3
+                assert p.numel() == parts * steps * ct * 64 * 8 == _native.lib().cz_conv3x3_packed_elems(c, parts)
+                v = p.view(parts, steps, ct, 2, 32, 8)                    # [part][step][tile][lane >> 5][lane & 31][j]
+                want = w.permute(2, 3, 1, 0).reshape(9, kk, 2, 8, ct, 32)  # [tap][kk][half][j][tile][out]
+                want = want.permute(0, 1, 4, 2, 5, 3).reshape(9 * kk, ct, 2, 32, 8)
+                hi = want.to(dt)
+                assert torch.equal(v[0, :9 * kk], hi)
+                assert v[:, 9 * kk:].abs().sum() == 0
+                if parts == 2:
+                    assert torch.equal(v[1, :9 * kk], (want - hi.float()).to(dt))
+    wi = torch.randn((128, 14, 5, 5), generator=g)
+    p = _native.pack_input_conv_weights(wi, torch.bfloat16, 2)
+    assert p.numel() == 2 * 28 * 4 * 64 * 8 == _native.lib().cz_input_conv_packed_elems(128, 14, 2)
+    v = p.view(2, 28, 4, 2, 32, 8)
+    pad = torch.zeros((128, 16, 5, 5))
+    pad[:, :14] = wi
+    want = pad.permute(2, 3, 1, 0).reshape(25, 2, 8, 4, 32).permute(0, 3, 1, 4, 2)      # [tap][tile][half][out][j]
+    assert torch.equal(v[0, :25], want.to(torch.bfloat16))
+    assert torch.equal(v[1, :25], (want - want.to(torch.bfloat16).float()).to(torch.bfloat16))
+    assert v[:, 25:].abs().sum() == 0
+    w28 = torch.randn((32, 28, 5, 5), generator=g)
+    assert _native.pack_input_conv_weights(w28, torch.float16, 1).numel() == 28 * 2 * 1 * 64 * 8
+    for bad in ((48, 2), (128, 3), (0, 1)):
+        assert _native.lib().cz_conv3x3_packed_elems(*bad) == 0
+    with pytest.raises(_native.NativeError):
+        _native.pack_conv3x3_weights(torch.randn(48, 48, 3, 3), torch.bfloat16, 2)
+    with pytest.raises(_native.NativeError):
+        _native.pack_input_conv_weights(torch.randn(128, 40, 5, 5), torch.bfloat16, 2)
