@@ -2,6 +2,9 @@
 """Correctness + timing probe of the hand-written trunk convolution (csrc/xq_conv.hip) against MIOpen.
 
     python tools/conv_probe.py [--n 32768] [--channels 128] [--out gpurun_out/conv_probe.json]
+
+The ablation / in-kernel trace variants (CZ_CONV_VARIANT=301|303|308) exist only in a probe build of the library:
+    python chinesechess-alphazero_amd/build.py --probe
 """
 import argparse
 import json
