@@ -199,3 +199,30 @@ def test_weight_packers_on_the_host():
         _native.pack_conv3x3_weights(torch.randn(48, 48, 3, 3), torch.bfloat16, 2)
     with pytest.raises(_native.NativeError):
         _native.pack_input_conv_weights(torch.randn(128, 40, 5, 5), torch.bfloat16, 2)
+
+
+def test_uci_position_parsing_without_a_gpu():
+    """The command parser of cchess_alphazero/uci.py (reference uci.py:116-170): `position fen ... w|b`, move counters,
+    side to move, unknown commands ignored; nothing here needs the device."""
+    import io
+    from cchess_alphazero.config import Config
+    from cchess_alphazero.environment import static_env as senv
+    from cchess_alphazero.uci import UCI
+    out = io.StringIO()
+    u = UCI(Config(config_type="mini"), out=out)
+    u.is_ready = True                                       # skip `uci` (it loads the network)
+    u.handle("isready")
+    assert out.getvalue().strip() == "readyok"
+    fen = "rnbakabnr/9/1c5c1/p1p1p1p1p/9/9/P1P1P1P1P/1C5C1/9/RNBAKABNR"
+    u.handle(f"position fen {fen} w - - 0 1")
+    assert u.state == senv.INIT_STATE and u.is_red_turn and u.turns == 0 and u.history == [senv.INIT_STATE]
+    u.handle(f"fen {fen} b - - 0 7")
+    assert not u.is_red_turn and u.turns == 13 and u.state == senv.fliped_state(senv.INIT_STATE)
+    u.handle("position fen broken")                          # malformed: the position is kept
+    assert u.turns == 13
+    u.handle("position startpos")
+    assert u.is_red_turn and u.turns == 0 and u.state == senv.INIT_STATE
+    u.handle("setoption name Threads value 16")
+    assert u.config.play.search_threads == 16
+    assert u.handle("no_such_command 1 2") is True
+    assert u.handle("quit") is False
