@@ -53,7 +53,7 @@ class CChessModelAPI:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         dtype = dtype or getattr(torch, getattr(getattr(config, "engine", None), "net_dtype", "float32"))
         trunk = getattr(getattr(config, "engine", None), "net_trunk", "mfma")
-        if agent_model.model.cfg["cnn_filter_num"] not in (32, 128, 256):
+        if agent_model.model.cfg["cnn_filter_num"] not in (32, 128, 192, 256):
             trunk = "library"
         self.net = InferenceNet(agent_model.model, dtype, trunk=trunk).to(self.device)
         self._dtype, self._trunk = dtype, trunk
@@ -73,7 +73,7 @@ class CChessModelAPI:
             if self.need_reload and need_to_reload_best_model_weight(self.agent_model):
                 if load_best_model_weight(self.agent_model):
                     trunk = self._trunk
-                    if self.agent_model.model.cfg["cnn_filter_num"] not in (32, 128, 256):
+                    if self.agent_model.model.cfg["cnn_filter_num"] not in (32, 128, 192, 256):
                         trunk = "library"
                     self.net = InferenceNet(self.agent_model.model, self._dtype, trunk=trunk).to(self.device)
                     return True

@@ -57,7 +57,7 @@ class SelfPlayEngine:
             self.model_cfg = net.cfg
             if trunk is None:
                 trunk = getattr(getattr(config, "engine", None), "net_trunk", "mfma")
-            if net.cfg["cnn_filter_num"] not in (32, 128, 256):
+            if net.cfg["cnn_filter_num"] not in (32, 128, 192, 256):
                 trunk = "library"
             self.trunk = trunk
             if trunk == "mfma":

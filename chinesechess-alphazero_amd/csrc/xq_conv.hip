@@ -70,7 +70,18 @@ template <typename E> struct alignas(8) Quad { E e[4]; };
 template <int C, int P, int PARTS> struct Geom {
     static constexpr int RB = C * 2;                 // bytes per pixel row in LDS
     static constexpr int CPR = RB / 16;              // 16-byte chunks per row
-    static constexpr int SWZ = CPR - 1 < 15 ? CPR - 1 : 15;   // swizzle: chunk ^= row & SWZ
+    static constexpr bool POW2 = (RB & (RB - 1)) == 0;        // 192 filters: 384-byte rows, 24 chunks
+    // swizzle: chunk ^= row & SWZ.  It must stay inside the row: all chunks for power-of-two rows, an aligned group of 8
+    // otherwise (two of the 16 rows of a read group then share a slot: a 2-way conflict instead of none)
+    static constexpr int SWZ = POW2 ? (CPR - 1 < 15 ? CPR - 1 : 15) : 7;
+    static_assert(POW2 || CPR % 8 == 0, "rows must be a whole number of 8-chunk groups");
+    // byte offset of K-step kk relative to pre[] (= row * RB + ((kb ^ (row & SWZ)) << 4)): the chunk is 2 * kk + kb and
+    // the XOR only touches the bits SWZ covers, the rest of 2 * kk is a plain add
+    static __device__ __forceinline__ int kstep(int pre, int kk)
+    {
+        if (POW2) return pre ^ (kk << 5);
+        return (pre ^ ((kk & 3) << 5)) + ((kk >> 2) << 7);
+    }
     static constexpr int ZROW = P * 90;              // the all-zero row (out-of-board taps, padding pixels)
     static constexpr int PART_BYTES = (P * 90 + 1) * RB;
     static constexpr int REGION = PARTS * PART_BYTES;
@@ -204,12 +215,12 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
             V8 (*b)[PARTS] = px[kk & 1];
             V8 (*bn)[PARTS] = px[(kk + 1) & 1];
             const int* rows = kk + 1 < KK ? pre : pre_n;
-            const int kx = ((kk + 1) % KK) << 5;
+            const int kn = (kk + 1) % KK;
 #pragma unroll
             for (int i = 0; i < NM; ++i) {
                 const int pass = i / NT, p = i % NT;      // pass 0: w_hi*x_hi, 1: w_lo*x_hi, 2: w_hi*x_lo
                 acc[p] = Mfma<E>::mma(w[pass == 1 ? PARTS - 1 : 0], b[p][pass == 2 ? PARTS - 1 : 0], acc[p]);
-                if (i < NL && !NO_LDS) bn[i % NT][i / NT] = load_px(rows[i % NT] ^ kx, i / NT);
+                if (i < NL && !NO_LDS) bn[i % NT][i / NT] = load_px(G::kstep(rows[i % NT], kn), i / NT);
                 if (i >= NM - PER && kk * PER + (i - (NM - PER)) < NT)
                     pre_n[kk * PER + (i - (NM - PER))] = tap_row(ndy, ndx, kk * PER + (i - (NM - PER)));
                 if (i >= NM - PARTS && !NO_W)
@@ -718,6 +729,8 @@ int dispatch_conv(int channels, int parts, const void* xh, const void* xl, const
 #define CZ_CONV_ARGS xh, xl, wp, bias, sh, sl, yh, yl, yf, n, relu, st
     if (channels == 128 && parts == 2) return launch_conv<E, 128, 2, 2, 1>(CZ_CONV_ARGS);
     if (channels == 128 && parts == 1) return launch_conv<E, 128, 2, 1, 2>(CZ_CONV_ARGS);   // 2 workgroups / CU
+    if (channels == 192 && parts == 2) return launch_conv<E, 192, 1, 2, 1>(CZ_CONV_ARGS);
+    if (channels == 192 && parts == 1) return launch_conv<E, 192, 2, 1, 1>(CZ_CONV_ARGS);
     if (channels == 256 && parts == 2) return launch_conv<E, 256, 1, 2>(xh, xl, wp, bias, sh, sl, yh, yl, yf, n, relu, st);
     if (channels == 256 && parts == 1) return launch_conv<E, 256, 2, 1>(xh, xl, wp, bias, sh, sl, yh, yl, yf, n, relu, st);
     if (channels == 32 && parts == 2) return launch_conv<E, 32, 2, 2>(xh, xl, wp, bias, sh, sl, yh, yl, yf, n, relu, st);
@@ -816,7 +829,7 @@ extern "C" int cz_conv3x3(const void* x_hi, const void* x_lo, const void* w_pack
                                      n_boards, relu, st);
     else
         rc = CZ_ERR_ARG;
-    if (rc == CZ_ERR_ARG) czi_set_error("cz_conv3x3: unsupported channels / dtype (channels 32|128|256, bf16|f16)");
+    if (rc == CZ_ERR_ARG) czi_set_error("cz_conv3x3: unsupported channels / dtype (channels 32|128|192|256, bf16|f16)");
     else if (rc != CZ_OK) czi_set_error("cz_conv3x3: launch failed");
     return rc;
 }
@@ -887,6 +900,7 @@ int dispatch_input_conv(int channels, const void* planes, int in_planes, const v
                         void* yl, int n, int parts, int relu, hipStream_t st)
 {
     if (channels == 128) return launch_input_conv<E, PT, 128>(planes, in_planes, wp, bias, yh, yl, n, parts, relu, st);
+    if (channels == 192) return launch_input_conv<E, PT, 192>(planes, in_planes, wp, bias, yh, yl, n, parts, relu, st);
     if (channels == 256) return launch_input_conv<E, PT, 256>(planes, in_planes, wp, bias, yh, yl, n, parts, relu, st);
     if (channels == 32) return launch_input_conv<E, PT, 32>(planes, in_planes, wp, bias, yh, yl, n, parts, relu, st);
     return CZ_ERR_ARG;

@@ -191,7 +191,7 @@ int cz_bias_act(void* x, const void* bias, const void* residual, size_t n_elems,
  *              bf16 MFMAs.  Outputs are re-split into (y_hi, y_lo).
  * y_f32 != NULL: write the fp32 result there instead of y_hi / y_lo (last trunk layer, feeds the heads).
  * w_packed: device copy of what cz_conv3x3_pack_weights produced for the same channels / dtype / parts.
- * channels in {32, 128, 256}.  skip_hi may be NULL (no residual). */
+ * channels in {32, 128, 192, 256}.  skip_hi may be NULL (no residual). */
 int cz_conv3x3(const void* x_hi, const void* x_lo, const void* w_packed, const float* bias, const void* skip_hi,
                const void* skip_lo, void* y_hi, void* y_lo, float* y_f32, int n_boards, int channels, int dtype,
                int parts, int relu, void* stream);

@@ -33,7 +33,7 @@ def _reference(x, w, b, skip, relu):
 
 
 CASES = [(128, "bfloat16", 2), (128, "bfloat16", 1), (128, "float16", 1), (32, "bfloat16", 2), (32, "float16", 1),
-         (256, "float16", 1), (256, "bfloat16", 2)]
+         (256, "float16", 1), (256, "bfloat16", 2), (192, "bfloat16", 2), (192, "float16", 1)]
 
 
 @pytest.mark.parametrize("c,dt,parts", CASES)
@@ -153,7 +153,8 @@ def test_resblock_rejects_unsupported_shapes():
 
 @pytest.mark.parametrize("c,in_planes,dt,parts", [(128, 14, "bfloat16", 2), (128, 28, "bfloat16", 2),
                                                   (128, 14, "float16", 1), (32, 14, "bfloat16", 2),
-                                                  (256, 14, "float16", 1), (256, 28, "bfloat16", 2)])
+                                                  (256, 14, "float16", 1), (256, 28, "bfloat16", 2),
+                                                  (192, 14, "bfloat16", 2)])
 @pytest.mark.parametrize("pdt", ["float32", "uint8"])
 def test_input_conv_against_float64(c, in_planes, dt, parts, pdt):
     """cz_input_conv on real feature planes (0/1) in the search kernel's layout against a float64 conv2d of the same
@@ -178,7 +179,7 @@ def test_input_conv_against_float64(c, in_planes, dt, parts, pdt):
     assert (got - ref).abs().max().item() <= rel * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("c,dt", [(128, "float32"), (256, "float16"), (32, "bfloat16")])
+@pytest.mark.parametrize("c,dt", [(128, "float32"), (256, "float16"), (32, "bfloat16"), (192, "float32")])
 def test_head_convs_against_float64(c, dt):
     import torch
     from cchess_alphazero import _native
@@ -232,7 +233,7 @@ def test_pack_weights_layout_and_errors():
         _native.conv3x3(x, p.cuda(), torch.zeros(64, device="cuda"), out=x)
 
 
-@pytest.mark.parametrize("filters,blocks", [(128, 7), (32, 2)])
+@pytest.mark.parametrize("filters,blocks", [(128, 7), (32, 2), (192, 3)])
 def test_network_with_mfma_trunk_matches_fp32_module(filters, blocks):
     """The whole policy/value network with the hand-written split-precision trunk against the plain PyTorch fp32
     module (CPU): policy and value within 1e-4 (north_star tolerance)."""
