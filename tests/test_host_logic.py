@@ -226,3 +226,26 @@ def test_uci_position_parsing_without_a_gpu():
     assert u.config.play.search_threads == 16
     assert u.handle("no_such_command 1 2") is True
     assert u.handle("quit") is False
+
+
+def test_bench_configs_follow_baseline():
+    """bench.py's workloads are BASELINE.json's configs (network shape, simulations, concurrent games), and the engine
+    defaults put the hand-written network kernels on the path."""
+    import argparse
+    import json
+    import bench
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "800 sims/move" in base["configs"][1] and "4096 concurrent games" in base["configs"][1]
+    want = {"mini": (2, 32, 50, 1), "normal": (7, 128, 800, 4096), "eval": (7, 128, 400, 200), "deep": (20, 256, 1600, None)}
+    for name, (blocks, filters, sims, games) in want.items():
+        cfg = bench.build_config(argparse.Namespace(config=name, games=None, sims_per_round=None, dtype=None, trunk=None))
+        assert cfg.model.res_layer_num == blocks and cfg.model.cnn_filter_num == filters
+        assert cfg.play.simulation_num_per_move == sims
+        if games is not None:
+            assert cfg.engine.games_per_gpu == games
+        assert cfg.engine.net_trunk == "mfma"
+    deep = bench.build_config(argparse.Namespace(config="deep", games=None, sims_per_round=None, dtype=None, trunk=None))
+    assert deep.engine.net_dtype == "float16"
+    lib = bench.build_config(argparse.Namespace(config="normal", games=64, sims_per_round=4, dtype="bfloat16", trunk="library"))
+    assert (lib.engine.games_per_gpu, lib.play.search_threads, lib.engine.net_dtype, lib.engine.net_trunk) == \
+        (64, 4, "bfloat16", "library")
