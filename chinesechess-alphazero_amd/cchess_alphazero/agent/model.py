@@ -198,7 +198,7 @@ class InferenceNet(nn.Module):
         _native.input_conv(planes.contiguous(), self.in_w.view(self.operand_dtype), self.in_bias32, cur)
         nblk = len(self.res)
         # whole residual block in one launch where k_resblock exists for the shape
-        fused = self.fused_blocks and ((c == 128) or (c == 256 and self.parts == 1))
+        fused = self.fused_blocks and ((c == 128) or (c in (192, 256) and self.parts == 1))
         for i in range(nblk):
             w1 = getattr(self, f"tw{i}a").view(self.operand_dtype)
             w2 = getattr(self, f"tw{i}b").view(self.operand_dtype)

@@ -991,6 +991,7 @@ int dispatch_resblock(int channels, int parts, const void* xh, const void* xl, c
         return launch_resblock<E, 128, 2, 1>(CZ_RB_ARGS);
     }
     if (channels == 128 && parts == 1) return launch_resblock<E, 128, 1, 2>(CZ_RB_ARGS);
+    if (channels == 192 && parts == 1) return launch_resblock<E, 192, 1, 1>(CZ_RB_ARGS);
     if (channels == 256 && parts == 1) return launch_resblock<E, 256, 1, 1>(CZ_RB_ARGS);
 #undef CZ_RB_ARGS
     return CZ_ERR_ARG;
@@ -1066,7 +1067,7 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
         rc = dispatch_resblock<_Float16>(channels, parts, x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo,
                                          y_f32, n_boards, n_cu, st);
     if (rc == CZ_ERR_ARG)
-        czi_set_error("cz_resblock: supported: 128 filters (split or plain operands), 256 filters (plain), bf16 / f16; "
+        czi_set_error("cz_resblock: supported: 128 filters (split or plain operands), 192 / 256 filters (plain), bf16 / f16; "
                       "use cz_conv3x3 otherwise");
     else if (rc != CZ_OK)
         czi_set_error("cz_resblock: launch failed");

@@ -199,7 +199,7 @@ int cz_conv3x3(const void* x_hi, const void* x_lo, const void* w_packed, const f
  *   y = relu( conv3x3(relu(conv3x3(x, w1) + bias1), w2) + bias2 + x )          (agent/model.py:68-83)
  * The intermediate activation and the skip operand stay in LDS; HBM sees one read of x and one write of y.
  * Same layouts and `parts` as cz_conv3x3; y_f32 != NULL (parts = 2 only) writes the fp32 result instead of
- * (y_hi, y_lo); y may alias x.  Supported: 128 filters (parts 1 or 2), 256 filters (parts 1); anything else returns
+ * (y_hi, y_lo); y may alias x.  Supported: 128 filters (parts 1 or 2), 192 / 256 filters (parts 1); anything else returns
  * CZ_ERR_ARG (use two cz_conv3x3 calls).  Bit-identical to the two-call form. */
 int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1, const void* w2_packed,
                 const float* bias2, void* y_hi, void* y_lo, float* y_f32, int n_boards, int channels, int dtype,

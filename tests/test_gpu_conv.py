@@ -81,7 +81,7 @@ def test_conv3x3_identity_filter_is_a_shift():
 
 
 @pytest.mark.parametrize("c,dt,parts", [(128, "bfloat16", 2), (128, "bfloat16", 1), (128, "float16", 1),
-                                        (256, "float16", 1), (256, "bfloat16", 1)])
+                                        (256, "float16", 1), (256, "bfloat16", 1), (192, "float16", 1)])
 @pytest.mark.parametrize("n", [1, 3, 257, 700])
 def test_resblock_equals_two_convolutions(c, dt, parts, n):
     """cz_resblock (one launch, intermediate in LDS) must be BIT-identical to two cz_conv3x3 launches: same
