@@ -317,7 +317,8 @@ __device__ long long g_trace[64][8];     // tuning probe (DBG & 8): [board k][ph
 // (16 bytes per lane, re-split into hi/lo in split mode) under the next K loop.
 //   LDS: X image | Y image | staging (fp32 in split mode, final 2-byte values otherwise); one workgroup per CU:
 //     128 filters split  (P = 1): 46.6 + 46.6 + 46.1 KB, 4 + 4 waves      128 filters plain (P = 2): the same bytes
-//     256 filters plain  (P = 1): 46.6 + 46.6 + 46.1 KB, 8 + 4 waves
+//     256 filters plain  (P = 1): 46.6 + 46.6 + 46.1 KB, 8 + 4 waves      192 filters plain (P = 1): 34.9 + 34.9 + 34.6
+//     (192 / 256 filters with split operands do not fit: those run one k_conv3x3 per convolution)
 //   barriers per tile: A (X ready) .. K1 .. epi1 -> Y .. B (Y ready) .. K2 .. epi2 -> staging .. C (staged, X free)
 constexpr int RB_COPY_THREADS = 256;
 
