@@ -130,9 +130,19 @@ def games_per_hour_estimate(expansions_per_s, config):
         return None
     with open(files[-1]) as f:
         d = json.load(f)
-    return {"value": expansions_per_s / d["expansions_per_game"] * 3600.0, "unit": "games/hour",
-            "expansions_per_game": d["expansions_per_game"], "mean_plies_per_game": d["mean_plies_per_game"],
-            "source": os.path.relpath(files[-1], ROOT)}
+    out = {"value": expansions_per_s / d["expansions_per_game"] * 3600.0, "unit": "games/hour",
+           "expansions_per_game": d["expansions_per_game"], "mean_plies_per_game": d["mean_plies_per_game"],
+           "source": os.path.relpath(files[-1], ROOT)}
+    # the sustained figure of the committed long run of this configuration (games in every phase), if there is one
+    longs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_f32_*_rounds.json")),
+                   key=lambda f: int(f.split("_")[-2]))
+    if config == "normal" and longs:
+        with open(longs[-1]) as f:
+            ld = json.load(f)
+        out["sustained_measured"] = {"games_per_hour": ld["plies_per_s"] / d["mean_plies_per_game"] * 3600.0,
+                                     "expansions_per_s": ld["value"], "rounds": ld["steps"],
+                                     "games_finished": ld["games_finished"], "source": os.path.relpath(longs[-1], ROOT)}
+    return out
 
 
 def pmc_traffic():
