@@ -7,6 +7,7 @@ python3.9 -- the main interpreter of this image has no h5py), so that the pure-P
 
   hdf5_misc.h5        nested groups (enough members to split symbol nodes), datasets and attributes of every supported
                       kind, many attributes on one object (continuation blocks)
+  hdf5_chunked.h5 / hdf5_latest.h5   a chunked + gzip dataset and a libver="latest" file: must be refused, not mis-read
   keras_tiny.json     Model.get_config()-style topology of a 2-block x 32-filter network with the layer names, graph
                       and per-layer config keys of the reference's data/model/model_128f.json
   keras_tiny.h5       its weights, written exactly the way Keras 2.0.8 save_weights does (topology.py
@@ -132,8 +133,18 @@ def keras_tiny():
                 d[...] = val
 
 
+def unsupported():
+    """files the reader must refuse with a clear error instead of mis-reading"""
+    with h5py.File(os.path.join(HERE, "hdf5_chunked.h5"), "w") as f:
+        f.create_dataset("c", data=np.arange(100, dtype=np.float32).reshape(10, 10), chunks=(5, 5), compression="gzip")
+        f.create_dataset("plain", data=np.arange(4, dtype=np.float32))
+    with h5py.File(os.path.join(HERE, "hdf5_latest.h5"), "w", libver="latest") as f:
+        f.create_dataset("x", data=np.arange(4, dtype=np.float32))
+
+
 if __name__ == "__main__":
     misc()
     keras_tiny()
-    for n in ("hdf5_misc.h5", "keras_tiny.json", "keras_tiny.h5"):
+    unsupported()
+    for n in ("hdf5_misc.h5", "keras_tiny.json", "keras_tiny.h5", "hdf5_chunked.h5", "hdf5_latest.h5"):
         print(n, os.path.getsize(os.path.join(HERE, n)))

@@ -47,6 +47,13 @@ def test_hdf5_reader_rejects_other_files(tmp_path):
     p.write_bytes(b"not an hdf5 file at all")
     with pytest.raises(hdf5_min.Hdf5Error):
         hdf5_min.File(str(p))
+    # real HDF5 the reader does not implement: a clear error, never a wrong array
+    with hdf5_min.File(os.path.join(GOLD, "hdf5_chunked.h5")) as f:
+        assert f["plain"].read().tolist() == [0.0, 1.0, 2.0, 3.0]
+        with pytest.raises(hdf5_min.Hdf5Error, match="chunked"):
+            f["c"].read()
+    with pytest.raises(hdf5_min.Hdf5Error, match="superblock"):
+        hdf5_min.File(os.path.join(GOLD, "hdf5_latest.h5"))
 
 
 @pytest.mark.parametrize("name,want", [
