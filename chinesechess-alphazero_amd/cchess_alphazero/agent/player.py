@@ -130,7 +130,9 @@ class CChessPlayer:
         path, pv = [], []
         for ply in range(max_len):
             node = self._node(self._search.node_stats(path))
-            if node is None or not node.a:
+            # the reference creates a node's edges at the first selection from it (player.py:274-286): an expanded but
+            # never-selected node has an empty `a` there and ends the line
+            if node is None or not node.a or all(a.n == 0 for a in node.a.values()):
                 break
             best, n = None, 0
             for mov, a in node.a.items():
@@ -214,6 +216,8 @@ class CChessPlayer:
                         shown = self.done_tasks // 100
                         self.print_depth_info(state, turns, start_time, self.debug.get(state, (None, 0.0))[1], no_act)
             self.done_tasks = s.counters()["sims"] - before
+            if self.uci and not stopped and self.done_tasks // 100 != shown:      # the last batch reports too
+                self.print_depth_info(state, turns, start_time, self.debug.get(state, (None, 0.0))[1], no_act)
             st = s.root_stats()
             c = int(st["counts"][0])
             policy = np.zeros(self.labels_n)

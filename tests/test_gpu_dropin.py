@@ -326,3 +326,39 @@ def test_model_api_hot_reload(tmp_path):
     with torch.no_grad():
         pr, vr = other.model.eval()(x.cpu())
     assert (p1.cpu() - pr).abs().max() < 1e-4 and (v1.cpu() - vr).abs().max() < 1e-4
+
+
+def test_uci_searches_match_reference_player(tmp_path, monkeypatch):
+    """action(depth=...), the principal variation behind `info depth .. pv ..` and the ponder move against the
+    REFERENCE's own player run with uci=True (tests/golden/uci_k1.json, make_golden_uci.py)."""
+    import io
+    from cchess_alphazero.agent.player import CChessPlayer
+    from cchess_alphazero.environment import static_env as senv
+    from cchess_alphazero.environment.lookup_tables import flip_move
+    with open(os.path.join(GOLDEN, "uci_k1.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        cfg = _cfg(tmp_path, monkeypatch, simulation_num_per_move=800, search_threads=1, noise_eps=0,
+                   tau_decay_rate=0, c_puct=1.0)
+        pipe = stub_net.StubPipe(lambda p, s=c["salt"]: stub_net.hash_stub_numpy(p, s))
+        tree = {}
+        pl = CChessPlayer(cfg, search_tree=tree, pipes=pipe, enable_resign=False, debugging=True, uci=True,
+                          side=c["turns"] % 2)
+        pl.out = io.StringIO()
+        action, _ = pl.action(c["state"], c["turns"], depth=c["depth"])
+        assert action == c["action"]
+        assert pl.done_tasks == c["done_tasks"]
+        lines = [l for l in pl.out.getvalue().splitlines() if l.startswith("info depth")]
+        assert lines and int(lines[-1].split()[2]) <= c["final_depth"]
+        pv, t = [], c["turns"]
+        for mov in pl.principal_variation(c["state"]):
+            pv.append(senv.to_uci_move(flip_move(mov) if t % 2 == 1 else mov))
+            t += 1
+        assert pv == c["pv"], (pv, c["pv"])
+        node = tree.get(senv.step(c["state"], action))
+        ponder, cnt = None, 0
+        for mov, a in (node.a.items() if node else ()):
+            if a.n > cnt:
+                ponder, cnt = mov, a.n
+        assert ponder == c["ponder"]
+        pl.close()
