@@ -40,7 +40,53 @@ def parse():
     ap.add_argument("--no-micro", action="store_true", help="skip the 1M-board rule-kernel micro-suite")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--graph", action="store_true", help="replay each round from a HIP graph")
+    ap.add_argument("--sustained-rounds", type=int, default=None,
+                    help="rounds of the sustained leg that follows the timed steps (default 3000 at N=1 for the "
+                         "'normal' config, 0 otherwise)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: only the launch / barrier / counter all-reduce plumbing of the ranks (gloo), with "
+                         "synthetic counters; used by the CPU test of --gpus N")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-exec this script under torch.distributed.run with one rank per
+    GPU (the same command the driver uses; reference shape: worker/self_play.py:55-60, one worker per device).
+    Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    if not args.dry_run:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:                     # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world, rank):
+    """The multi-rank plumbing without an engine: every rank contributes a known counter vector; rank 0 prints the
+    line with n_gpus = the number of ranks that actually reported."""
+    dist.init_process_group("gloo", rank=rank, world_size=world) if world > 1 else None
+    delta = torch.tensor([1000 * (rank + 1), 1], dtype=torch.int64)      # expansions, ranks reporting
+    tmax = torch.tensor([0.5 + 0.1 * rank], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(delta, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "mcts_node_expansions_per_sec", "value": delta[0].item() / tmax.item(),
+                          "unit": "expansions/s", "n_gpus": int(delta[1].item()), "steps": args.steps,
+                          "warmup": args.warmup, "data": "dry-run (no GPU work: launch plumbing only)"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def build_config(args):
@@ -66,32 +112,51 @@ def build_config(args):
 
 
 def cpu_baseline(cfg, seconds):
-    """The oracle (C port of the reference's player.py + static_env.py) on ONE host core, same search
-    parameters, network replaced by the hash stub (tree + rules only, like BASELINE.md section 2)."""
-    from oracle import xq_oracle as xo
+    """CPU leg (kind "port"): the C restatement of the reference's player.py + static_env.py (oracle/) on EVERY host
+    core at once -- P = usable cores independent processes, one seed each, a new tree per game, same search
+    parameters, network replaced by the hash stub (tree + rules only, like BASELINE.md section 2).  The reference's
+    own Python path cannot run on the GPU box (/root/reference is not there); its timing on the build container is
+    in profiles/r*_reference_cpu.json.  Not like-for-like with the GPU line (which includes the 7x128 network)."""
+    import statistics
+    import subprocess
     pc = cfg.play
-    ocfg = xo.play_cfg(simulation_num_per_move=pc.simulation_num_per_move, search_threads=pc.search_threads,
-                       c_puct=pc.c_puct, noise_eps=0.0, dirichlet_alpha=pc.dirichlet_alpha, tau_decay_rate=0.0,
-                       virtual_loss=pc.virtual_loss, max_game_length=pc.max_game_length)
-    pl = xo.Player(ocfg, {"kind": "hash", "salt": 1})
-    state, turn = xo.INIT_STATE, 0
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        a, _ = pl.action(state, turn, None, False, 0.5)
-        if a is None:
-            break
-        state = xo.step(state, a)
-        turn += 1
-        if xo.done(state)[0] or turn >= 2 * pc.max_game_length:
-            state, turn = xo.INIT_STATE, 0
-    dt = time.perf_counter() - t0
-    c = pl.counters()
-    pl.close()
-    return {"value": c["expansions"] / dt, "unit": "expansions/s", "cores": 1, "kind": "port",
-            "sample": f"oracle/xq_mcts.c, {turn} plies of one game, {pc.simulation_num_per_move} sims/move, "
-                      f"K={pc.search_threads}, hash-stub net (tree+rules only), {dt:.1f} s on 1 core of "
-                      f"{os.cpu_count()} ({c['sims']} sims)",
-            "sims_per_s": c["sims"] / dt}
+    procs = len(os.sched_getaffinity(0))
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "baseline_worker.py"), "--procs", str(procs),
+           "--seconds", str(seconds), "--sims", str(pc.simulation_num_per_move), "--threads", str(pc.search_threads),
+           "--c-puct", str(pc.c_puct), "--vl", str(pc.virtual_loss), "--max-game-length", str(pc.max_game_length)]
+    d = json.loads(subprocess.check_output(cmd, timeout=seconds * 6 + 120))
+    per = [r["expansions_per_s"] for r in d["per_process"]]
+    sims = [r["sims_per_s"] for r in d["per_process"]]
+    cpu = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    return {"value": sum(per), "unit": "expansions/s", "cores": procs, "kind": "port",
+            "per_process": {"median": statistics.median(per), "min": min(per), "max": max(per), "seeds": len(per)},
+            "sims_per_s": sum(sims), "cpu_model": cpu,
+            "sample": f"oracle/xq_mcts.c + xq_rules.c (C port of player.py / static_env.py), {procs} processes x "
+                      f"{seconds:.0f} s of self-play from INIT_STATE, {pc.simulation_num_per_move} sims/move, "
+                      f"K={pc.search_threads}, hash-stub net (tree + rules only, no ResNet), one seed per process, "
+                      f"new tree per game; value = sum over processes",
+            "reference_python_timing": reference_cpu_timing()}
+
+
+def reference_cpu_timing():
+    """The unmodified reference (Python/NumPy) timed on the build container (it does not exist on the GPU box):
+    summary of the committed profiles/r*_reference_cpu.json, SURVEY 8(d)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reference_cpu.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    out = {"source": os.path.relpath(files[-1], ROOT)}
+    for k in ("host", "summary"):
+        if k in d:
+            out[k] = d[k]
+    return out
 
 
 def micro_suite(n=1 << 20, iters=10):
@@ -116,7 +181,7 @@ def micro_suite(n=1 << 20, iters=10):
     ms = a.elapsed_time(b) / iters
     bytes_per_board = 90 + 256 + 6 + 5040
     gbs = n * bytes_per_board / (ms * 1e-3) / 1e9
-    return {"kernel": "k_rules_fused<f32>", "boards": n, "bytes_per_board": bytes_per_board, "ms": ms,
+    return {"kernel": "k_rules_tpb<f32> (cz_rules_fused dispatches to the lane-per-board kernel at this size)", "boards": n, "bytes_per_board": bytes_per_board, "ms": ms,
             "boards_per_s": n / (ms * 1e-3), "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}
 
 
@@ -170,9 +235,15 @@ def pmc_nn(kernel):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -210,45 +281,67 @@ def main():
     if args.graph:
         eng.capture_graph(warmup=0)
     torch.cuda.synchronize()
-    c0 = eng.counters()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    if eng.net is not None and not args.graph:
-        eng.net.block_events = []      # HIP events around every residual-block launch of the timed region (same stream)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if args.graph:
-            eng.step()
-        else:
-            ev[i][0].record()
-            eng.search.round()
-            ev[i][1].record()
+    keys = ["sims", "expansions", "terminal_sims", "repetition_sims", "parked", "sum_depth", "edges_visited",
+            "leaf_moves", "plies", "games", "tree_resets", "overflow_sims", "depth_overflow", "chunks_taken", "stat_blocks"]
+
+    def run_leg(n_rounds, sample_every):
+        """n_rounds rounds bracketed by barrier + synchronize on both sides; HIP events (same stream) around the tree
+        kernels and around every residual-block launch of each sampled round.  Returns (seconds = max over ranks,
+        counter deltas summed over ranks + the number of ranks reporting, search-round ms, block ms list)."""
+        c0 = eng.counters()
+        ev, blk_all = [], []
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_rounds):
+            if args.graph:
+                eng.step()
+                continue
+            sampled = i % sample_every == 0
+            if eng.net is not None:
+                eng.net.block_events = [] if sampled else None
+            if sampled:
+                e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                e[0].record()
+                eng.search.round()
+                e[1].record()
+                ev.append(e)
+            else:
+                eng.search.round()
             eng._forward()
             eng.rounds += 1
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    c1 = eng.counters()
-    log(f"timed {args.steps} steps in {dt:.2f}s")
+            if sampled and eng.net is not None:
+                blk_all += eng.net.block_events
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        if eng.net is not None:
+            eng.net.block_events = None
+        c1 = eng.counters()
+        delta = torch.tensor([c1[k] - c0[k] for k in keys] + [1], dtype=torch.int64, device="cuda")
+        tmax = torch.tensor([dt_], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(delta, op=dist.ReduceOp.SUM)          # the only collective of the path (SURVEY 8e)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dd = dict(zip(keys + ["ranks"], delta.tolist()))
+        k_ms_ = sum(x.elapsed_time(y) for x, y in ev) / len(ev) if ev else None
+        b_ms_ = [x.elapsed_time(y) for x, y in blk_all]
+        return float(tmax.item()), dd, k_ms_, b_ms_
 
-    keys = ["sims", "expansions", "terminal_sims", "repetition_sims", "parked", "sum_depth", "edges_visited",
-            "leaf_moves", "plies", "games", "tree_resets", "overflow_sims", "depth_overflow"]
-    delta = torch.tensor([c1[k] - c0[k] for k in keys], dtype=torch.int64, device="cuda")
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(delta, op=dist.ReduceOp.SUM)          # the only collective of the path
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    d = dict(zip(keys, delta.tolist()))
-    dt = float(tmax.item())
+    dt, d, k_ms, blk_ms = run_leg(args.steps, 1)
+    log(f"timed {args.steps} steps in {dt:.2f}s")
+    n_sus = args.sustained_rounds
+    if n_sus is None:
+        n_sus = 3000 if (world == 1 and args.config == "normal" and not args.graph) else 0
+    sus = None
+    if n_sus > 0:
+        sus = run_leg(n_sus, 10)
+        log(f"sustained leg: {n_sus} rounds in {sus[0]:.1f}s")
 
     if rank == 0:
-        k_ms = None
-        if not args.graph:
-            k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
         exp_per_launch = d["expansions"] / max(1, args.steps * world)
         mean_d = d["sum_depth"] / max(1, d["sims"])
         mean_c = d["edges_visited"] / max(1, d["sum_depth"])
@@ -259,7 +352,7 @@ def main():
         step_ms = dt / args.steps * 1e3
         out = {
             "metric": "mcts_node_expansions_per_sec", "value": d["expansions"] / dt, "unit": "expansions/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
+            "n_gpus": d["ranks"], "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": net_label + "+f64/i32 tree",
             "data": "synthetic",
@@ -278,7 +371,9 @@ def main():
             "tree_shape": {"mean_depth": mean_d, "mean_edges": mean_c, "mean_leaf_moves": mean_l,
                            "terminal_sims": d["terminal_sims"], "repetition_sims": d["repetition_sims"],
                            "parked": d["parked"], "tree_resets": d["tree_resets"],
+                           "tree_compactions": d["chunks_taken", "stat_blocks"],
                            "overflow_sims": d["overflow_sims"], "depth_overflow": d["depth_overflow"]},
+            "tree_memory": eng.search.memory_info(),
             "roofline": None, "roofline_search": None, "roofline_nn": None, "cpu_baseline": None,
         }
         if k_ms is not None:
@@ -303,10 +398,10 @@ def main():
                                                                       else "") + "MIOpen/hipBLASLt)",
                                       "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
                                       "frac": tf / peak, "ms": nn_ms, "positions_per_forward": slots}
-        blk = getattr(eng.net, "block_events", None) if eng.net is not None else None
+        blk = blk_ms
         if blk:
             # the dominant kernel: k_resblock (one residual block of the tower per launch), > 90 % of a round
-            b_ms = sum(a.elapsed_time(b) for a, b in blk) / len(blk)
+            b_ms = sum(blk) / len(blk)
             f = cfg.model.cnn_filter_num
             flops_launch = 2 * 2.0 * 90 * f * f * 9 * slots          # two 3x3 convolutions, 2 flop per MAC
             tfl = flops_launch / (b_ms * 1e-3) / 1e12
@@ -327,16 +422,49 @@ def main():
                                        "(157.3 TFLOP/s) the same number is > 1"}
         else:
             out["roofline"] = out.get("roofline_search")
+        if sus is not None:
+            # the sustained leg: games in every phase (openings to endgames), finished games replaced by new ones
+            sdt, sd, sk_ms, sblk = sus
+            s_exp = sd["expansions"] / sdt
+            est = out["games_per_hour_est"] or {}
+            mean_plies = est.get("mean_plies_per_game")
+            srec = {"rounds": n_sus, "seconds": sdt, "value": s_exp, "unit": "expansions/s",
+                    "ms_per_step": sdt / n_sus * 1e3, "sims_per_s": sd["sims"] / sdt,
+                    "plies_per_s": sd["plies"] / sdt, "games_finished": sd["games"],
+                    "games_per_hour_measured": sd["games"] / sdt * 3600.0,
+                    "games_per_hour_steady_state": (sd["plies"] / sdt / mean_plies * 3600.0) if mean_plies else None,
+                    "queue_utilisation": sd["expansions"] / max(1, n_sus * world * slots),
+                    "tree_resets": sd["tree_resets"], "tree_compactions": sd["chunks_taken", "stat_blocks"],
+                    "overflow_sims": sd["overflow_sims"], "depth_overflow": sd["depth_overflow"],
+                    "mean_depth": sd["sum_depth"] / max(1, sd["sims"]),
+                    "search_round_ms": sk_ms, "tree_memory": eng.search.memory_info(),
+                    "note": "games_per_hour_measured counts the games that FINISHED inside this leg (started from the "
+                            "opening together, so early on only short games end); games_per_hour_steady_state = "
+                            "measured plies/s / mean plies per game of the committed complete-games run"}
+            if sblk:
+                sb_ms = sum(sblk) / len(sblk)
+                f = cfg.model.cnn_filter_num
+                stfl = 2 * 2.0 * 90 * f * f * 9 * slots / (sb_ms * 1e-3) / 1e12
+                srec["roofline"] = {"kernel": "k_resblock", "bound": "mfma", "achieved": stfl, "peak": 2500.0,
+                                    "unit": "TFLOP/s", "frac": stfl / 2500.0, "avg_launch_ms": sb_ms,
+                                    "launches_timed": len(sblk)}
+            out["sustained"] = srec
+            out["value_sustained"] = s_exp
         # the network the engine ran vs the plain fp32 PyTorch module (CPU) on positions of the last round's queue
         nq = min(64, slots)
         qp = eng.search.planes[:nq].clone()
         with torch.no_grad():
             pg, vg = eng.net(qp)
             pc_, vc_ = ref_net.eval()(qp.float().cpu())
+            lg_g, lg_c = torch.log(pg.float().cpu().clamp_min(1e-30)), torch.log(pc_.clamp_min(1e-30))
+        lg_g, lg_c = lg_g - lg_g.mean(1, keepdim=True), lg_c - lg_c.mean(1, keepdim=True)   # logits up to a shift
         out["numerics_check"] = {"positions": nq, "against": "plain PyTorch fp32 module on the CPU, same weights",
                                  "policy_max_abs_diff": float((pg.float().cpu() - pc_).abs().max()),
+                                 "policy_max_rel_diff": float(((pg.float().cpu() - pc_).abs() / pc_.clamp_min(1e-12)).max()),
+                                 "policy_logit_max_abs_diff": float((lg_g - lg_c).abs().max()),
                                  "value_max_abs_diff": float((vg.float().cpu() - vc_).abs().max()),
-                                 "tolerance": 1e-4 if cfg.engine.net_dtype == "float32" else None}
+                                 "tolerance": ({"policy_abs": 1e-4, "value_abs": 1e-4, "policy_logit_abs": 1e-3}
+                                               if cfg.engine.net_dtype == "float32" else None)}
         if not args.no_micro and world == 1:
             out["micro_suite"] = micro_suite()
             log("micro-suite done")

@@ -34,7 +34,7 @@ def lib():
                 f"(python chinesechess-alphazero_amd/build.py); there is no CPU fallback")
         _lib = C.CDLL(LIB_PATH)
         _declare(_lib)
-        if _lib.cz_version() != 1:
+        if _lib.cz_version() != 2:
             raise NativeError("libczero.so version mismatch")
     return _lib
 

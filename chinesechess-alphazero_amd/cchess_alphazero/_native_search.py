@@ -7,12 +7,14 @@ from cchess_alphazero import _native
 
 COUNTER_NAMES = ["sims", "expansions", "terminal_sims", "repetition_sims", "parked", "sum_depth", "max_depth",
                  "edges_visited", "leaf_moves", "plies", "games", "red_wins", "black_wins", "draws", "resigns",
-                 "tree_resets", "overflow_sims", "depth_overflow", "root_reused_sims", "ring_dropped", "tree_compactions"]
+                 "tree_resets", "overflow_sims", "depth_overflow", "root_reused_sims", "ring_dropped", "chunks_taken",
+                 "stat_blocks"]
+MAX_NO_ACT = 32          # csrc/xq_search.h: banned root moves per game and ply
 
 
 class SearchCfg(C.Structure):
     _fields_ = [("n_games", C.c_int32), ("sims_per_round", C.c_int32), ("simulation_num_per_move", C.c_int32),
-                ("virtual_loss", C.c_int32), ("node_capacity", C.c_int32), ("edge_capacity", C.c_int32),
+                ("virtual_loss", C.c_int32), ("max_nodes_per_game", C.c_int32), ("pool_chunks", C.c_int32),
                 ("max_depth", C.c_int32), ("max_game_length", C.c_int32), ("planes_dtype", C.c_int32),
                 ("min_resign_turn", C.c_int32), ("evaluate", C.c_int32), ("ring_capacity", C.c_int32),
                 ("c_puct", C.c_double), ("noise_eps", C.c_double), ("dirichlet_alpha", C.c_double),
@@ -27,6 +29,8 @@ def declare(L):
     L.cz_search_bytes.argtypes = [vp]
     L.cz_search_bytes.restype = C.c_size_t
     L.cz_search_info.argtypes = [vp, vp]
+    L.cz_search_memory_info.argtypes = [vp, vp, vp]
+    L.cz_search_memory_info.restype = i32
     L.cz_search_start_selfplay.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     L.cz_search_set_roots.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.cz_search_round.argtypes = [vp, vp, vp, vp, vp]
@@ -42,6 +46,8 @@ def declare(L):
     L.cz_search_counters.argtypes = [vp, vp, vp]
     L.cz_search_drain_records.argtypes = [vp, C.POINTER(C.c_uint), vp, i32, C.POINTER(C.c_int), vp]
     L.cz_debug_sqrt.argtypes = [vp, vp, i32, vp]
+    L.cz_debug_noise.argtypes = [C.c_uint64, C.c_uint32, C.c_double, i32, vp, i32, vp]
+    L.cz_debug_noise.restype = i32
     for n in ("cz_search_create", "cz_search_destroy", "cz_search_info", "cz_search_start_selfplay",
               "cz_search_set_roots", "cz_search_round", "cz_search_reset_trees", "cz_search_pending",
               "cz_search_root_stats", "cz_search_choose", "cz_search_counters", "cz_search_drain_records",
@@ -58,8 +64,11 @@ class Search:
     """
 
     def __init__(self, play_config, n_games, planes_dtype=_native.F32, evaluate=False, seed=0,
-                 node_capacity=0, edge_capacity=0, max_depth=0, ring_capacity=0, sims_per_round=None,
+                 max_nodes_per_game=0, pool_chunks=0, max_depth=0, ring_capacity=0, sims_per_round=None,
                  device=None, use_history=False):
+        """max_nodes_per_game: sizes a game's hash / chunk table (0 = the whole tree of the longest game);
+        pool_chunks: tree memory shared by all games in MiB (0 = what the games can use, at most 80 % of the free
+        device memory)."""
         import torch
         _native.require_gpu()
         self.L = _native.lib()
@@ -70,8 +79,8 @@ class Search:
         self.G = int(n_games)
         self.K = int(sims_per_round if sims_per_round is not None else pc.search_threads)
         self.planes_dtype = planes_dtype
-        cfg = SearchCfg(self.G, self.K, int(pc.simulation_num_per_move), int(pc.virtual_loss), int(node_capacity),
-                        int(edge_capacity), int(max_depth), int(pc.max_game_length), int(planes_dtype),
+        cfg = SearchCfg(self.G, self.K, int(pc.simulation_num_per_move), int(pc.virtual_loss), int(max_nodes_per_game),
+                        int(pool_chunks), int(max_depth), int(pc.max_game_length), int(planes_dtype),
                         int(pc.min_resign_turn), int(bool(evaluate)), int(ring_capacity),
                         float(pc.c_puct), float(pc.noise_eps), float(pc.dirichlet_alpha), float(pc.tau_decay_rate),
                         float(pc.resign_threshold), float(pc.enable_resign_rate), int(seed),
@@ -80,10 +89,11 @@ class Search:
         with torch.cuda.device(self.device):
             _native.check(self.L.cz_search_create(C.byref(cfg), C.byref(h)), "cz_search_create")
         self.h = h
-        info = (C.c_int32 * 12)()
+        info = (C.c_int32 * 16)()
         _native.check(self.L.cz_search_info(self.h, info), "cz_search_info")
-        (self.G, self.K, self.sims, self.node_cap, self.edge_cap, self.hash_cap, self.max_depth, self.max_plies,
-         self.record_stride, self.ring_cap, self.n_counters, self.in_planes) = list(info)
+        (self.G, self.K, self.sims, self.pool_chunks, self.max_chunks, self.hash_cap, self.max_depth, self.max_plies,
+         self.record_stride, self.ring_cap, self.n_counters, self.in_planes, self.keep_chunks,
+         self.max_no_act) = list(info)[:14]
         self.slots = self.G * self.K
         self.planes = torch.zeros((self.slots, self.in_planes, 10, 9), dtype=_native.torch_dtype(planes_dtype), device=self.device)
         self.policy = torch.zeros((self.slots, _native.NLABELS), dtype=torch.float32, device=self.device)
@@ -104,6 +114,14 @@ class Search:
 
     def device_bytes(self):
         return int(self.L.cz_search_bytes(self.h))
+
+    def memory_info(self):
+        """Tree memory: the shared chunk pool (1 MiB chunks) and what the games hold / use of it."""
+        out = (C.c_int64 * 8)()
+        _native.check(self.L.cz_search_memory_info(self.h, out, self._stream()), "cz_search_memory_info")
+        keys = ("pool_chunks", "free_chunks", "held_chunks", "held_chunks_max_game", "tree_bytes", "tree_bytes_max_game",
+                "nodes", "nodes_max_game")
+        return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def _stream(self):
         import torch
@@ -126,6 +144,7 @@ class Search:
             assert t.is_cuda and t.is_contiguous() and t.dtype == dt, (t.dtype, dt)
             return C.c_void_p(t.data_ptr())
         assert boards.shape == (self.G, 90)
+        assert no_act is None or tuple(no_act.shape) == (self.G, MAX_NO_ACT), "no_act: [G, 32] uint16"
         self._keep = (boards, turns, no_act, n_no_act, increase_temp, enable_resign, select_mask, prev_boards,
                       hist_kind)
         _native.check(self.L.cz_search_set_roots(
@@ -237,6 +256,17 @@ class Search:
             out.append(dict(game_id=int(buf[i, :4].view(np.uint32)[0]), turns=turns, value=int(hdr[2]),
                             store=bool(hdr[3] & 1), resigned=bool(hdr[3] & 2), moves=mv.copy()))
         return out
+
+
+def debug_noise(alpha, n_moves, n, seed=0, game_key=0):
+    """n draws of Dirichlet(alpha * 1_{n_moves})[0] from the search kernel's root-noise generator (float64 cuda tensor)."""
+    import torch
+    _native.require_gpu()
+    out = torch.empty((n,), dtype=torch.float64, device="cuda")
+    _native.check(_native.lib().cz_debug_noise(int(seed), int(game_key), float(alpha), int(n_moves),
+                                               C.c_void_p(out.data_ptr()), int(n),
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), "cz_debug_noise")
+    return out
 
 
 def debug_sqrt(x):

@@ -12,7 +12,7 @@ from logging import getLogger
 import numpy as np
 
 from cchess_alphazero import _native
-from cchess_alphazero._native_search import Search
+from cchess_alphazero._native_search import MAX_NO_ACT, Search
 from cchess_alphazero.environment import static_env as senv
 from cchess_alphazero.environment.lookup_tables import ActionLabelsRed, label_index
 
@@ -75,9 +75,10 @@ class CChessPlayer:
         dt = _native.F32
         self._search = Search(merged, 1, planes_dtype=dt, evaluate=getattr(config.opts, "evaluate", False),
                               seed=int(np.random.randint(0, 2 ** 31 - 1)),
-                              node_capacity=(INFINITE_SIMS + 64) if uci else
-                              (getattr(getattr(config, "engine", None), "node_capacity", 0) or 0),
-                              edge_capacity=(INFINITE_SIMS + 66) * 80 if uci else 0,
+                              # one game: a quarter of a GiB of tree at most (`go infinite` reserves 100000 nodes)
+                              max_nodes_per_game=600000 if uci else
+                              (getattr(getattr(config, "engine", None), "max_nodes_per_game", 0) or 0),
+                              pool_chunks=256 if uci else 0,
                               use_history=use_history)
         self._torch = torch
 
@@ -154,11 +155,18 @@ class CChessPlayer:
         depth = self.done_tasks // 100
         pv = ""
         t = turns
+        end_state = state
         for mov in self.principal_variation(state, no_act):
             pv += " " + senv.to_uci_move(flip_move(mov) if t % 2 == 1 else mov)
+            end_state = senv.step(end_state, mov)
             t += 1
-        if t % 2 != self.side:
-            value = -value
+        # the reference prints the network value of the position at the END of the line (self.debug holds every
+        # evaluated state when debugging, :442-445), seen from `side`; a line that ends on a position the network
+        # never saw (terminal, or debugging off) keeps the root's value as it was passed in, un-negated
+        if self.debugging and t != turns and not senv.done(end_state)[0]:
+            value = self._root_value(end_state, None)[1]
+            if t % 2 != self.side:
+                value = -value
         duration = max(time() - start_time, 1e-9)
         nps = int(depth * 100 / duration) * 1000
         out = f"info depth {depth} score {int(value * 1000)} time {int(duration * 1000)} pv" + pv + f" nps {nps}"
@@ -179,8 +187,10 @@ class CChessPlayer:
         self._idle.clear()
         try:
             board = t.from_numpy(senv.state_to_array(state)[None]).cuda()
-            na = np.full((1, 16), 0xFFFF, dtype=np.uint16)
-            bans = list(no_act or [])[:16]
+            na = np.full((1, MAX_NO_ACT), 0xFFFF, dtype=np.uint16)
+            bans = list(dict.fromkeys(no_act or []))           # (a move banned twice is banned once)
+            if len(bans) > MAX_NO_ACT:                         # the reference's list is unbounded; never truncate silently
+                raise ValueError(f"CChessPlayer.action: {len(bans)} banned moves, the engine holds {MAX_NO_ACT}")
             for k, m in enumerate(bans):
                 na[0, k] = label_index(m)
             prev, kind = None, None

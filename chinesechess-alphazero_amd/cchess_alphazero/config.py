@@ -68,7 +68,10 @@ class EngineConfig(_Section):
                          sims_per_round=None,     # lock-step batch per game; None = play.search_threads
                          net_dtype="float32",     # float32 (reference precision) | bfloat16 | float16
                          net_trunk="mfma",        # mfma (hand-written convolution kernel) | library (MIOpen)
-                         node_capacity=0, edge_capacity=0, max_depth=0,
+                         max_nodes_per_game=0,    # sizes a game's hash / chunk table; 0 = the longest game's whole tree
+                         pool_chunks=0,           # tree memory for all games in MiB; 0 = auto (<= 80 % of free HBM)
+                         max_depth=0,
+                         reload_seconds=600,      # self-play re-checks the best-model digest this often (api.py:37-44)
                          use_hip_graph=False, base_seed=0, report_every_rounds=200,
                          max_rounds=None, max_games=None)   # None = run forever, like the reference
 

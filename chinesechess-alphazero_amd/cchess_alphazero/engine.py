@@ -35,7 +35,7 @@ def bytes_per_expansion(mean_depth, mean_edges, mean_leaf_moves):
 
 class SelfPlayEngine:
     def __init__(self, config, n_games, net=None, dtype=torch.float32, device=None, seed=0,
-                 node_capacity=0, edge_capacity=0, max_depth=0, sims_per_round=None, evaluator=None,
+                 max_nodes_per_game=0, pool_chunks=0, max_depth=0, sims_per_round=None, evaluator=None,
                  use_history=False, trunk=None):
         """config: the reference's Config object (config.play.* / config.model.* are read).
         net: a CChessNet (random-init if None).  evaluator: optional callable planes -> (policy, value)
@@ -64,7 +64,7 @@ class SelfPlayEngine:
                 planes_code = _native.U8      # the hand-written input convolution reads the 0/1 planes as bytes
         self.search = Search(config.play, n_games, planes_dtype=planes_code,
                              evaluate=getattr(config.opts, "evaluate", False), seed=seed,
-                             node_capacity=node_capacity, edge_capacity=edge_capacity, max_depth=max_depth,
+                             max_nodes_per_game=max_nodes_per_game, pool_chunks=pool_chunks, max_depth=max_depth,
                              sims_per_round=sims_per_round, device=self.device, use_history=use_history)
         if evaluator is None:
             self.net = InferenceNet(net, dtype, trunk=self.trunk).to(self.device)
@@ -73,6 +73,20 @@ class SelfPlayEngine:
         self._graph = None
 
     # ---- control ----
+    def set_network(self, net):
+        """Swap the weights the games are played with (hot reload of the best model, reference agent/api.py:76-87):
+        rebuilds the inference network; a captured HIP graph holds the old weights' buffers and is captured again."""
+        if self.evaluator is not None:
+            raise RuntimeError("the engine was built on an evaluator callable, not on a network")
+        if net.cfg != self.model_cfg:
+            raise ValueError(f"hot reload: topology changed ({self.model_cfg} -> {net.cfg})")
+        had_graph = self._graph is not None
+        self._graph = None
+        torch.cuda.synchronize(self.device)
+        self.net = InferenceNet(net, self.dtype, trunk=self.trunk).to(self.device)
+        if had_graph:
+            self.capture_graph()
+
     def start(self, first_game_id=0, game_id_stride=0):
         self.search.start_selfplay(self.seed, first_game_id, game_id_stride)
 

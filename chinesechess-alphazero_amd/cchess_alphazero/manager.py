@@ -81,7 +81,8 @@ def start():
         if args.elo:
             raise SystemExit("the server-driven Elo evaluator needs cczero.org (no network): outside the hot path")
         config.eval.update_play_config(config.play)
-        config.opts.evaluate = True
+        # (config.opts.evaluate stays False here, as in the reference: only its Elo evaluator sets it,
+        #  compute_elo.py:88 -- so a repeated position is still played at tau = 0.5, player.py:460-461)
         from cchess_alphazero.worker import evaluator
         return evaluator.start(config)
     raise SystemExit(f"`run.py {args.cmd}` is not part of the MI355X self-play hot path (SURVEY 8): use the reference "

@@ -16,7 +16,7 @@ from logging import getLogger
 import numpy as np
 
 from cchess_alphazero import _native
-from cchess_alphazero._native_search import Search
+from cchess_alphazero._native_search import MAX_NO_ACT, Search
 from cchess_alphazero.environment.static_env import INIT_STATE, state_to_array
 
 logger = getLogger(__name__)
@@ -79,18 +79,31 @@ class EvaluateWorker:
         return score_table(results)
 
     # ------------------------------------------------------------------------------------------------
-    def play_games(self, n_games, u_fn=None):
-        """Plays games idx = 0..n_games-1 concurrently; returns [(value from red's view, turns)]."""
+    def play_games(self, n_games, u_fn=None, indices=None, init_state=None, trace=None, stats=None):
+        """Plays the games idx = 0..n_games-1 (or the given `indices`) concurrently; returns
+        [(value from red's view, turns)] in that order.
+
+        All games advance ply by ply together: at every ply the games whose mover is the best model are searched on
+        search object 0 and the others on search object 1 (one tree per game in each), both run lock-step rounds --
+        tree kernels, then that model's forward over the rows of ITS games only -- until every search is complete;
+        the moves are picked on the device and the game rules are applied to all boards with the batched rule
+        kernels.  Per-game bookkeeping is vectorised; the only per-game Python work is the (rare) repeated position.
+        u_fn(idx, ply) -> uniform draw of np.random.choice (default: NumPy's global RNG, like the reference);
+        init_state: start position (default INIT_STATE); trace: dict filled with idx -> [one dict per searched ply];
+        stats: dict that receives the search counters (rounds, expansions, ...)."""
         import torch
         _native.require_gpu()
         pc = self.config.play
-        G = n_games
-        searches = [Search(pc, G, planes_dtype=self.dtype, evaluate=getattr(self.config.opts, "evaluate", True),
+        idx = np.arange(n_games) if indices is None else np.asarray(list(indices), dtype=np.int64)
+        G = len(idx)
+        searches = [Search(pc, G, planes_dtype=self.dtype, evaluate=getattr(self.config.opts, "evaluate", False),
                            seed=self.seed + k) for k in range(2)]
         dev = searches[0].device
-        boards = torch.from_numpy(np.tile(state_to_array(INIT_STATE), (G, 1))).to(dev)
-        hist = [[boards[g].cpu().numpy().copy()] for g in range(G)]       # per game: boards (host)
-        acts = [[] for _ in range(G)]                                      # per game: labels
+        K = searches[0].K
+        max_plies = 2 * int(pc.max_game_length) + 2
+        boards = torch.from_numpy(np.tile(state_to_array(init_state or INIT_STATE), (G, 1))).to(dev)
+        hist = torch.zeros((max_plies + 1, G, 90), dtype=torch.int8, device=dev)      # position searched at each ply
+        acts = torch.zeros((max_plies + 1, G), dtype=torch.int32, device=dev)         # move played at each ply
         turns = 0
         live = np.ones(G, dtype=bool)
         value = np.zeros(G, dtype=np.int64)
@@ -98,38 +111,48 @@ class EvaluateWorker:
         final_move = np.full(G, _native.NOMOVE, dtype=np.int64)
         no_eat_count = np.zeros(G, dtype=np.int64)
         check = np.zeros(G, dtype=bool)
-        idx = np.arange(G)
+        rounds = 0
+        kslots = torch.arange(K, device=dev)
+        if trace is not None:
+            from cchess_alphazero.environment.lookup_tables import ActionLabelsRed
+            from cchess_alphazero.environment.static_env import array_to_state
+            for i in idx:
+                trace[int(i)] = []
         while live.any():
-            # -- repetition handling before the move (reference :172-189) --
-            no_act = np.full((G, 16), _native.NOMOVE, dtype=np.uint16)
+            hist[turns] = boards
+            # -- repetition handling BEFORE the move (reference :172-189; no be_catched branch here) --
+            no_act = np.full((G, MAX_NO_ACT), _native.NOMOVE, dtype=np.uint16)
             n_no_act = np.zeros(G, dtype=np.uint8)
             inc = np.zeros(G, dtype=np.uint8)
-            q_game, q_move = [], []
-            for g in np.nonzero(live & ~check)[0]:
-                cur = hist[g][-1]
-                for i in range(len(hist[g]) - 1):
-                    if (hist[g][i] == cur).all():
-                        q_game.append(g)
-                        q_move.append(acts[g][i])
-            if q_game:
-                qb = boards[torch.as_tensor(q_game, device=dev)].contiguous()
-                qm = torch.tensor(q_move, dtype=torch.int32, device=dev).to(torch.uint16)
-                wcc = _native.check_or_catch(qb, qm).cpu().numpy()
-                free = {}
-                for g, mv, r in zip(q_game, q_move, wcc):
-                    if not live[g]:
-                        continue
-                    inc[g] = 1
-                    if r == 1:
-                        if n_no_act[g] < 16:
-                            no_act[g, n_no_act[g]] = mv
-                            n_no_act[g] += 1
-                    else:
-                        free[g] = free.get(g, 0) + 1
-                        if free[g] >= 3:                                   # idle loop three times: draw
-                            live[g] = False
-                            value[g] = 0
-                            game_turns[g] = turns
+            bans = {}                                                   # game -> the reference's no_act list
+            if turns > 0:
+                cand = torch.from_numpy(live & ~check).to(dev)
+                eq = (hist[:turns] == boards[None]).all(dim=2) & cand[None]          # [turns, G]
+                pairs = eq.t().nonzero().cpu().numpy()                  # (game, earlier ply), ply ascending per game
+                if len(pairs):
+                    qg = torch.from_numpy(pairs[:, 0]).to(dev)
+                    qm = acts[torch.from_numpy(pairs[:, 1]).to(dev), qg]
+                    wcc = _native.check_or_catch(boards[qg].contiguous(), qm.to(torch.uint16)).cpu().numpy()
+                    qm = qm.cpu().numpy()
+                    free = {}
+                    for (g, _), mv, r in zip(pairs, qm, wcc):
+                        if not live[g]:
+                            continue                                    # (the reference's `break` after the draw)
+                        inc[g] = 1
+                        bans.setdefault(g, [])
+                        if r == 1:                                      # the earlier move checks / chases: banned
+                            bans[g].append(int(mv))
+                            if mv not in no_act[g, :n_no_act[g]]:
+                                if n_no_act[g] >= MAX_NO_ACT:
+                                    raise RuntimeError(f"game {idx[g]}: more than {MAX_NO_ACT} banned moves")
+                                no_act[g, n_no_act[g]] = mv
+                                n_no_act[g] += 1
+                        else:
+                            free[g] = free.get(g, 0) + 1
+                            if free[g] >= 3:                            # idle loop three times: draw
+                                live[g] = False
+                                value[g] = 0
+                                game_turns[g] = turns
             if not live.any():
                 break
             # -- search: the mover's model; even idx: best = red (reference :160-168) --
@@ -140,10 +163,13 @@ class EvaluateWorker:
             t_na = torch.from_numpy(no_act.view(np.int16)).to(dev).view(torch.uint16)
             t_nn = torch.from_numpy(n_no_act).to(dev)
             t_inc = torch.from_numpy(inc).to(dev)
+            rows = [None, None]
             for k in range(2):
                 if masks[k].any():
                     searches[k].set_roots(boards, turns=t_turns, no_act=t_na, n_no_act=t_nn, increase_temp=t_inc,
                                           select_mask=torch.from_numpy(masks[k].astype(np.uint8)).to(dev))
+                    gk = torch.from_numpy(np.nonzero(masks[k])[0]).to(dev)
+                    rows[k] = (gk[:, None] * K + kslots[None, :]).reshape(-1)     # queue rows of this model's games
             busy = [bool(m.any()) for m in masks]
             while any(busy):
                 for k in range(2):
@@ -151,18 +177,29 @@ class EvaluateWorker:
                         continue
                     s = searches[k]
                     s.round()
+                    rounds += 1
                     if s.pending() == 0:
                         busy[k] = False
                         continue
-                    p, v = self.evaluators[k](s.planes)
-                    s.policy.copy_(p)
-                    s.value.copy_(v)
-            u = np.array([u_fn(g, turns) if u_fn else np.random.random_sample() for g in range(G)])
+                    p, v = self.evaluators[k](s.planes.index_select(0, rows[k]))
+                    s.policy.index_copy_(0, rows[k], p.float())
+                    s.value.index_copy_(0, rows[k], v.float())
+            u = np.array([u_fn(int(idx[g]), turns) if u_fn else np.random.random_sample() for g in range(G)])
             action = np.full(G, -1, dtype=np.int64)
             for k in range(2):
                 if masks[k].any():
                     a = searches[k].choose(u)
                     action[masks[k]] = a[masks[k]]
+            if trace is not None:
+                st = [searches[k].root_stats() if masks[k].any() else None for k in range(2)]
+                cur = boards.cpu().numpy()
+                for g in np.nonzero(live)[0]:
+                    r = st[0 if masks[0][g] else 1]
+                    c = int(r["counts"][g])
+                    trace[int(idx[g])].append(dict(
+                        state=array_to_state(cur[g]), action=ActionLabelsRed[action[g]] if action[g] >= 0 else None,
+                        moves=r["moves"][g, :c].copy(), n=r["n"][g, :c].copy(), sum_n=int(r["sum_n"][g]),
+                        no_act=[ActionLabelsRed[m] for m in bans[g]] if g in bans else None, inc=bool(inc[g])))
             # -- apply the moves and the game rules to every live game (reference :196-226) --
             resigned = live & (action < 0)
             value[resigned] = -1
@@ -170,32 +207,27 @@ class EvaluateWorker:
             live &= ~resigned
             if not live.any():
                 break
-            mv = torch.from_numpy(np.where(live, action, 0).astype(np.int32)).to(dev).to(torch.uint16)
-            nxt, ne = _native.step(boards, mv)
-            ne = ne.cpu().numpy()
+            mv32 = torch.from_numpy(np.where(live, action, 0).astype(np.int32)).to(dev)
+            acts[turns] = mv32
+            nxt, ne = _native.step(boards, mv32.to(torch.uint16))
             lmask = torch.from_numpy(live).to(dev)
             boards = torch.where(lmask[:, None], nxt, boards).contiguous()
             turns += 1
+            over, v, fm, ck = _native.done(boards, need_check=True)
+            attack = _native.has_attack(boards)
+            ne, over, v, fm, ck, attack = (t.cpu().numpy() for t in (ne, over, v, fm, ck, attack))
             no_eat_count = np.where(live, np.where(ne == 1, no_eat_count + 1, 0), no_eat_count)
-            over, v, fm, ck = (t.cpu().numpy() for t in _native.done(boards, need_check=True))
-            attack = _native.has_attack(boards).cpu().numpy()
-            host_boards = boards.cpu().numpy()
-            for g in np.nonzero(live)[0]:
-                acts[g].append(int(action[g]))
-                hist[g].append(host_boards[g].copy())
-                game_turns[g] = turns
-                if no_eat_count[g] >= 120 or turns >= 2 * pc.max_game_length:
-                    live[g] = False
-                    value[g] = 0
-                    continue
-                check[g] = bool(ck[g])
-                if over[g]:
-                    live[g] = False
-                    value[g] = int(v[g])
-                    final_move[g] = int(fm[g])
-                elif not attack[g]:
-                    live[g] = False
-                    value[g] = 0
+            game_turns[live] = turns
+            capped = live & ((no_eat_count >= 120) | (turns >= 2 * pc.max_game_length))      # :212-214
+            value[capped] = 0
+            rest = live & ~capped
+            check = np.where(rest, ck != 0, check)
+            ended = rest & (over != 0)
+            value[ended] = v[ended].astype(np.int64)
+            final_move[ended] = fm[ended].astype(np.int64)
+            bare = rest & ~ended & (attack == 0)                       # neither side can attack: draw (:219-223)
+            value[bare] = 0
+            live &= ~(capped | ended | bare)
         # -- the king capture is appended, the value turned to red's view (reference :228-241) --
         results = []
         for g in range(G):
@@ -206,6 +238,10 @@ class EvaluateWorker:
             if t % 2 == 1:
                 val = -val
             results.append((val, t))
+        if stats is not None:
+            c = [s.counters() for s in searches]
+            stats.update(rounds=rounds, plies=turns, games=G, sims_per_round=K,
+                         **{k: c[0][k] + c[1][k] for k in ("sims", "expansions", "tree_resets", "overflow_sims")})
         for s in searches:
             s.close()
         return results

@@ -29,10 +29,15 @@ def load_model(config, config_file=None):
     config_path = rc.model_best_config_path if not config_file else os.path.join(rc.model_dir, config_file)
     if not model.load(config_path, rc.model_best_weight_path):
         model.build(seed=0)
-        try:
-            model.save(rc.model_best_config_path, rc.model_best_weight_path)
-        except OSError as e:
-            logger.info(f"could not save the freshly built model: {e}")
+        if os.path.exists(rc.model_best_config_path):
+            # a config whose weights are missing (e.g. the reference's Keras JSON without its .h5 blob): leave it alone
+            logger.info(f"{rc.model_best_config_path} exists but its weights could not be loaded: playing with a "
+                        f"random-init network, nothing is written")
+        else:
+            try:
+                model.save(rc.model_best_config_path, rc.model_best_weight_path)
+            except OSError as e:
+                logger.info(f"could not save the freshly built model: {e}")
     return model, False
 
 
@@ -74,8 +79,8 @@ class SelfPlayWorker:
         ec = self.config.engine
         net = self.model.model if self.model is not None else None
         self.engine = SelfPlayEngine(self.config, ec.games_per_gpu, net=net, dtype=getattr(torch, ec.net_dtype),
-                                     seed=ec.base_seed, node_capacity=ec.node_capacity,
-                                     edge_capacity=ec.edge_capacity, max_depth=ec.max_depth,
+                                     seed=ec.base_seed, max_nodes_per_game=ec.max_nodes_per_game,
+                                     pool_chunks=ec.pool_chunks, max_depth=ec.max_depth,
                                      sims_per_round=ec.sims_per_round)
         first, stride = game_id_partition(self.rank, self.world, ec.games_per_gpu)
         self.engine.start(first, stride)
@@ -92,21 +97,45 @@ class SelfPlayWorker:
                 if path:
                     logger.info(f"Process {self.pid} save play data to {path}")
 
+    def reload_best_model(self):
+        """The reference's self-play picks up a new best model while it runs: its prediction thread re-checks the
+        best-weight digest every 600 s (agent/api.py:37-44, get_pipes(need_reload=True) in self_play.py:62-64).
+        Same here: when the file on disk differs from the weights in memory, load it and hand it to the engine.
+        Games in flight continue with the new weights, as they do in the reference.  Returns True on a reload."""
+        from cchess_alphazero.lib.model_helper import load_best_model_weight, need_to_reload_best_model_weight
+        if self.model is None or self.engine is None:
+            return False
+        try:
+            if need_to_reload_best_model_weight(self.model) and load_best_model_weight(self.model):
+                self.engine.set_network(self.model.model)
+                logger.info(f"Process {self.pid}-{self.rank}: best model reloaded, digest {self.model.digest}")
+                return True
+        except Exception as e:                 # a half-written file: keep playing with the old weights
+            logger.error(f"best-model reload failed: {e}")
+        return False
+
     def run(self, max_rounds=None, max_games=None):
         if self.engine is None:
             self._make_engine()
         every = max(1, self.config.engine.report_every_rounds)
+        reload_s = getattr(self.config.engine, "reload_seconds", 600)
         t0, r = time.time(), 0
+        last_check = t0
         while True:
             self.engine.step()
             r += 1
             if r % every == 0:
                 self._harvest()
+                if reload_s is not None and time.time() - last_check >= reload_s:
+                    last_check = time.time()
+                    self.reload_best_model()
                 c = reduce_counters(self.engine.counters())
                 if self.rank == 0:
                     dt = time.time() - t0
+                    lc = self.engine.counters()
                     logger.info(f"rounds={r} games={c['games']} plies={c['plies']} "
-                                f"expansions/s={c['expansions'] / dt:.0f} games/h={c['games'] / dt * 3600:.0f}")
+                                f"expansions/s={c['expansions'] / dt:.0f} games/h={c['games'] / dt * 3600:.0f} "
+                                f"tree_resets={lc['tree_resets']} overflow_sims={lc['overflow_sims']}")
                 if max_games is not None and c["games"] >= max_games:
                     break
             if max_rounds is not None and r >= max_rounds:

@@ -1,11 +1,21 @@
 // xq_search.h -- device-side data layout of the batched PUCT-MCTS engine (gfx950).
 //
-// One wavefront per game tree.  Everything a tree owns lives in one per-game slice of a few
-// structure-of-arrays buffers in HBM (so that a wave's loads of N/W/P/move for one node are
-// contiguous), the hot scratch (boards, ordered move lists, the current path) lives in LDS.
+// One wavefront per game tree.  The reference keeps a game's whole tree for the whole game
+// (worker/self_play.py:84,98-100); 4096 games x 800 simulations x ~150 plies is ~130 GB of tree, which is what
+// the 288 GB of HBM are for.  Trees live in a POOL of 1 MiB chunks shared by all games of the search object:
+//   * a game owns a list of chunks (g_chunk_tab) and bump-allocates variable-size records in them; a record is
+//     addressed by a 32-bit id = local chunk number << 16 | 16-byte granule inside the chunk;
+//   * NODE record  = 48 B packed position | 16 B header {sum_n, move count | flags, stat id, -} | float p[nm] |
+//     uint16 move[nm]: everything a wave needs to price a node's edges is one contiguous run;
+//   * STAT block   = nm x 16 B {double W, int32 N, int32 child}: allocated only when a node is first selected
+//     FROM (two nodes in three are leaves that never are), edge j of a node = granule stat + j, so an edge id is a
+//     record id as well and a path entry is one word;
+//   * chunks are taken from / returned to a device-side free ring (pool_* below) between plies and between games,
+//     never inside the simulation kernel: begin_search reserves the worst case of the coming ply.
+// The hot scratch (boards, ordered move lists, the current path, the game's chunk table) lives in LDS.
 //
 // Reference objects replaced (cchess_alphazero/agent/player.py):
-//   VisitState (:17-25)  -> node_* arrays          ActionState (:28-33) -> e_* arrays
+//   VisitState (:17-25)  -> node record          ActionState (:28-33) -> p / move in the node record + stat block
 //   tree = defaultdict keyed by state string (:49) -> per-game open-addressing hash on the packed board
 //   history lists of MCTS_search (:198-260)        -> s_path_* per simulation slot
 #pragma once
@@ -14,7 +24,13 @@
 namespace xq {
 
 constexpr int KEY_WORDS = 12;          // 90 squares x 4 bit, padded to 48 B
-constexpr int MAX_NO_ACT = 16;         // banned root moves per ply (self_play.py:161-175)
+constexpr int MAX_NO_ACT = 32;         // banned root moves per ply (self_play.py:161-175); longer lists are refused by the host
+constexpr int CHUNK_SHIFT = 16;        // granules (16 B) per chunk = 65536 -> 1 MiB chunks
+constexpr int CHUNK_GRANULES = 1 << CHUNK_SHIFT;
+constexpr size_t CHUNK_BYTES = (size_t)CHUNK_GRANULES * 16;
+constexpr int MAX_CHUNKS = 256;        // per game (LDS copy of the chunk table): 256 MiB of tree per game at most
+constexpr int NODE_HDR_GRANULES = 4;   // key (3) + header (1)
+constexpr int RESERVE_MOVES = 80;      // moves per new node the per-ply reservation assumes (observed maximum 70)
 constexpr int CHILD_UNKNOWN = -1;
 constexpr int CHILD_TERM_WIN = -2;     // done() == (True, +1): value for the child's mover +1 -> x2
 constexpr int CHILD_TERM_LOSS = -3;    // done() == (True, -1)
@@ -29,22 +45,23 @@ enum GamePhase : uint8_t {
     PH_IDLE = 0,        // nothing to do (external mode: waiting for set_roots / choose)
     PH_SEARCH = 1,      // simulations outstanding for the current root
     PH_READY = 2,       // search of the current root complete (external mode: results can be read)
-    PH_COMPACT = 3,     // self-play: the next search needs the arena compacted first (k_compact, off the round's critical path)
-    PH_COMPACTED = 4,   // k_compact is done; the NEXT round's first kernel turns this into PH_SEARCH (see k_compact)
 };
 
 // per-game counters (uint64 each); summed on the host
 enum Counter : int {
     CT_SIMS = 0, CT_EXPANSIONS, CT_TERMINAL_SIMS, CT_REPETITION_SIMS, CT_PARKED, CT_SUM_DEPTH, CT_MAX_DEPTH,
     CT_EDGES_VISITED, CT_LEAF_MOVES, CT_PLIES, CT_GAMES, CT_RED_WINS, CT_BLACK_WINS, CT_DRAWS, CT_RESIGNS,
-    CT_TREE_RESETS, CT_OVERFLOW_SIMS, CT_DEPTH_OVERFLOW, CT_ROOT_REUSED_SIMS, CT_RING_DROPPED, CT_TREE_COMPACTIONS,
-    CT_COUNT
+    CT_TREE_RESETS, CT_OVERFLOW_SIMS, CT_DEPTH_OVERFLOW, CT_ROOT_REUSED_SIMS, CT_RING_DROPPED, CT_CHUNKS_TAKEN,
+    CT_STAT_BLOCKS, CT_COUNT
 };
 
 struct SearchParams {
     // sizes
     int G, K, sims, vl;
-    int node_cap, edge_cap, hash_cap, max_depth, max_plies;
+    int hash_cap, max_depth, max_plies;
+    int n_chunks;           // chunks in the pool
+    int max_chunks;         // chunk-table entries per game (<= MAX_CHUNKS)
+    int keep_chunks;        // chunks a game never gives back: enough for one full search on an empty tree
     int planes_dtype;
     int in_planes;          // 14, or 28 with use_history
     int mode;
@@ -67,19 +84,17 @@ struct SearchParams {
 };
 
 struct SearchBuffers {
-    // ---- tree, per game ----
-    uint32_t* node_key;     // [G][node_cap][12]
-    int32_t* node_sum_n;    // [G][node_cap]
-    uint32_t* node_eoff;    // [G][node_cap]  first edge (index inside the game's edge slice)
-    uint32_t* node_meta;    // [G][node_cap]  move count | flags
-    uint64_t* hash_tab;     // [G][hash_cap]  tag << 32 | node + 1, 0 = empty
-    int32_t* e_n;           // [G][edge_cap]
-    double* e_w;            // [G][edge_cap]
-    float* e_p;             // [G][edge_cap]
-    uint16_t* e_mv;         // [G][edge_cap]
-    int32_t* e_child;       // [G][edge_cap]
+    // ---- trees ----
+    char* pool;             // [n_chunks] x 1 MiB
+    uint32_t* pool_ring;    // [n_chunks] free chunk numbers; entries [head, tail) are free
+    unsigned int* pool_head;     // [1] chunks ever taken      (monotonic; ring index = value % n_chunks)
+    unsigned int* pool_tail;     // [1] chunks ever returned + the initial fill
+    unsigned int* pool_tail_vis; // [1] pool_tail as of the last kernel boundary: takers stay below it
+    uint32_t* g_chunk_tab;  // [G][max_chunks] pool chunk number of the game's local chunk i
+    int32_t* g_nchunks;     // [G]
+    uint32_t* g_heap_top;   // [G] next free granule (record id); 1 on an empty tree (id 0 = none)
+    uint64_t* hash_tab;     // [G][hash_cap]  tag << 32 | node id + 1, 0 = empty
     int32_t* g_node_count;  // [G]
-    int32_t* g_edge_count;  // [G]
     // ---- search state, per game ----
     int32_t* g_root;        // [G] node index of the root, -1 = not in the tree yet
     int8_t* g_board;        // [G][96] current root position (int8 board)

@@ -50,20 +50,25 @@ struct SearchLDS {
     float pr[MAXMOVES];                // prior gather scratch
     uint16_t slab[MAXMOVES];           // labels sorted
     int32_t sn[MAXMOVES];              // visit counts sorted by label
+    uint32_t chtab[MAX_CHUNKS];        // the game's chunk table (pool chunk number of local chunk i)
 };
 
-// pointers into one game's slices
+// one edge's visit statistics (ActionState n / w + the child link); edge j of a node = granule stat + j
+struct __attribute__((aligned(16))) EdgeStat {
+    double w;
+    int32_t n;
+    int32_t child;          // node id; CHILD_UNKNOWN / CHILD_TERM_*
+};
+static_assert(sizeof(EdgeStat) == 16, "one granule per edge");
+
+// node record: key[12] | {sum_n, meta, stat, -} | float p[nm] | uint16 mv[nm]
+constexpr int NODE_OFF_HDR = 48, NODE_OFF_P = 64;
+
+// pointers into one game's state
 struct GameView {
-    uint32_t* node_key;
-    int32_t* node_sum_n;
-    uint32_t* node_eoff;
-    uint32_t* node_meta;
+    char* pool;
+    const uint32_t* chtab;  // LDS copy of the chunk table
     uint64_t* hash;
-    int32_t* e_n;
-    double* e_w;
-    float* e_p;
-    uint16_t* e_mv;
-    int32_t* e_child;
     int32_t* path_node;     // [K][max_depth]
     int32_t* path_edge;
     uint8_t* s_state;
@@ -83,20 +88,16 @@ XQ_D uint64_t uni64(uint64_t v)
 }
 XQ_D double unid(double v) { return __longlong_as_double((long long)uni64((uint64_t)__double_as_longlong(v))); }
 
-XQ_D GameView make_view(const SearchBuffers& B, const SearchParams& P, int g, unsigned long long* lctr)
+// `chtab` = LDS array of MAX_CHUNKS words that receives the game's chunk table
+XQ_D GameView make_view(const SearchBuffers& B, const SearchParams& P, int g, unsigned long long* lctr, uint32_t* chtab)
 {
     GameView v;
     v.lctr = lctr;
-    v.node_key = B.node_key + (size_t)g * P.node_cap * KEY_WORDS;
-    v.node_sum_n = B.node_sum_n + (size_t)g * P.node_cap;
-    v.node_eoff = B.node_eoff + (size_t)g * P.node_cap;
-    v.node_meta = B.node_meta + (size_t)g * P.node_cap;
+    v.pool = B.pool;
+    const int nch = uni(B.g_nchunks[g]);
+    for (int i = lane_id(); i < nch; i += 64) chtab[i] = B.g_chunk_tab[(size_t)g * P.max_chunks + i];
+    v.chtab = chtab;
     v.hash = B.hash_tab + (size_t)g * P.hash_cap;
-    v.e_n = B.e_n + (size_t)g * P.edge_cap;
-    v.e_w = B.e_w + (size_t)g * P.edge_cap;
-    v.e_p = B.e_p + (size_t)g * P.edge_cap;
-    v.e_mv = B.e_mv + (size_t)g * P.edge_cap;
-    v.e_child = B.e_child + (size_t)g * P.edge_cap;
     v.path_node = B.s_path_node + (size_t)g * P.K * P.max_depth;
     v.path_edge = B.s_path_edge + (size_t)g * P.K * P.max_depth;
     v.s_state = B.s_state + (size_t)g * P.K;
@@ -104,8 +105,19 @@ XQ_D GameView make_view(const SearchBuffers& B, const SearchParams& P, int g, un
     v.s_node = B.s_node + (size_t)g * P.K;
     v.ctr = B.counters + (size_t)g * CT_COUNT;
     v.g = g;
+    wave_sync();
     return v;
 }
+
+// record id -> address (ids of one record never straddle a chunk)
+XQ_D char* rec_ptr(const GameView& gv, uint32_t id)
+{
+    return gv.pool + ((size_t)gv.chtab[id >> CHUNK_SHIFT] << 20) + ((size_t)(id & (uint32_t)(CHUNK_GRANULES - 1)) << 4);
+}
+XQ_D const uint32_t* node_key(const GameView& gv, int node) { return reinterpret_cast<const uint32_t*>(rec_ptr(gv, (uint32_t)node)); }
+XQ_D float* node_p(char* base) { return reinterpret_cast<float*>(base + NODE_OFF_P); }
+XQ_D uint16_t* node_mv(char* base, int nm) { return reinterpret_cast<uint16_t*>(base + NODE_OFF_P + 4 * nm); }
+XQ_D EdgeStat* edge_ptr(const GameView& gv, uint32_t edge) { return reinterpret_cast<EdgeStat*>(rec_ptr(gv, edge)); }
 
 // Counters accumulate in LDS while a kernel runs (no global round trip per event) and are flushed once.
 XQ_D void count(const GameView& gv, int which, unsigned long long by = 1)
@@ -200,6 +212,17 @@ XQ_D float gamma_draw(float a, NoiseRng& rng)
     return boost * d;
 }
 
+// np.random.dirichlet(alpha * ones(n))[0] (player.py:304) = X / (X + Y), X ~ Gamma(alpha), Y ~ Gamma(alpha (n - 1)),
+// i.e. Beta(alpha, alpha (n - 1)); tests/test_gpu_noise.py checks the distribution against NumPy's
+XQ_D double dirichlet0(float alpha, int nm, NoiseRng& rng)
+{
+    const double x = (double)gamma_draw(alpha, rng);
+    const double y = nm > 1 ? (double)gamma_draw(alpha * (float)(nm - 1), rng) : 0.0;
+    // the quotient in float64: in float32 every draw with y < 6e-8 x would collapse onto exactly 1.0 (1.8 % of the
+    // mass of Beta(0.2, 0.2), the two-move case) -- found by the KS test of tests/test_gpu_noise.py
+    return (x + y) > 0.0 ? x / (x + y) : 1.0 / (double)nm;
+}
+
 // ---- packed keys and the transposition hash ----------------------------------------------------
 // board (LDS) -> key words in L.key (lanes 0..11), returns the 64-bit hash (wave-uniform)
 XQ_D uint64_t pack_key(const int8_t* b, uint32_t* key)
@@ -272,7 +295,7 @@ XQ_D int hash_lookup(const GameView& gv, const SearchParams& P, const uint32_t* 
         if (e == 0) { *slot_out = (int)slot; return -1; }
         if ((uint32_t)(e >> 32) == tag) {
             const int idx = (int)((uint32_t)e) - 1;
-            const bool ne = lane < KEY_WORDS && gv.node_key[(size_t)idx * KEY_WORDS + lane] != key[lane];
+            const bool ne = lane < KEY_WORDS && node_key(gv, idx)[lane] != key[lane];
             if (!__ballot(ne)) { *slot_out = (int)slot; return idx; }
         }
         slot = (slot + 1) & mask;
@@ -287,10 +310,11 @@ XQ_D void backup(const SearchParams& P, const GameView& gv, const SearchLDS& L, 
 {
     const int lane = lane_id();
     for (int i = lane; i < depth; i += 64) {
-        const int e = L.path_edge[i];
+        EdgeStat* e = edge_ptr(gv, (uint32_t)L.path_edge[i]);
         const double vi = ((depth - i) & 1) ? -v : v;        // v = -v once per level walking up
-        gv.e_n[e] += 1 - P.vl;
-        gv.e_w[e] = gv.e_w[e] + (vi + (double)P.vl);
+        const EdgeStat cur = *e;                             // one 16-byte load
+        e->n = cur.n + (1 - P.vl);
+        e->w = cur.w + (vi + (double)P.vl);
     }
     count(gv, CT_SIMS);
     count(gv, CT_SUM_DEPTH, (unsigned long long)depth);
@@ -298,35 +322,39 @@ XQ_D void backup(const SearchParams& P, const GameView& gv, const SearchLDS& L, 
     wave_sync_global();
 }
 
-// sum_n / first edge / (move count | flags) of a node in one memory round trip
+// sum_n / (move count | flags) / stat block of a node: one 16-byte load
 struct NodeHdr {
-    int sum_n, eoff;
-    uint32_t meta;
+    int sum_n;
+    uint32_t meta, stat;
 };
-XQ_D NodeHdr load_hdr(const GameView& gv, int node)
+XQ_D NodeHdr load_hdr(char* base)
 {
-    const int lane = lane_id();
-    // lane 0 is also the only lane that ever writes these words, so its loads see its own earlier stores
-    // without a fence; the three loads are issued back to back and waited for once
-    uint32_t a = 0, b = 0, c = 0;
-    if (lane == 0) { a = (uint32_t)gv.node_sum_n[node]; b = gv.node_eoff[node]; c = gv.node_meta[node]; }
+    // lane 0 is also the only lane that ever writes these words, so its load sees its own earlier stores
+    // without a fence
+    int4 v = make_int4(0, 0, 0, 0);
+    if (lane_id() == 0) v = *reinterpret_cast<const int4*>(base + NODE_OFF_HDR);
     NodeHdr h;
-    h.sum_n = __builtin_amdgcn_readfirstlane((int)a);
-    h.eoff = __builtin_amdgcn_readfirstlane((int)b);
-    h.meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    h.sum_n = __builtin_amdgcn_readfirstlane(v.x);
+    h.meta = (uint32_t)__builtin_amdgcn_readfirstlane(v.y);
+    h.stat = (uint32_t)__builtin_amdgcn_readfirstlane(v.z);
     return h;
 }
+XQ_D void store_sum_n(char* base, int v) { *reinterpret_cast<int32_t*>(base + NODE_OFF_HDR) = v; }
+XQ_D void store_meta(char* base, uint32_t v) { *reinterpret_cast<uint32_t*>(base + NODE_OFF_HDR + 4) = v; }
+XQ_D void store_stat(char* base, uint32_t v) { *reinterpret_cast<uint32_t*>(base + NODE_OFF_HDR + 8) = v; }
 
 // ---- prior spreading: select_action_q_and_u, player.py:272-284 ----------------------------------
 XQ_D void attach_policy(const GameView& gv, SearchLDS& L, int node, const float* __restrict__ prow)
 {
     const int lane = lane_id();
-    const NodeHdr hdr = load_hdr(gv, node);
+    char* base = rec_ptr(gv, (uint32_t)node);
+    const NodeHdr hdr = load_hdr(base);
     const uint32_t meta = hdr.meta;
     const int nm = (int)(meta & 0xFF);
-    const int eoff = hdr.eoff;
-    if (lane < nm) L.pr[lane] = prow[gv.e_mv[eoff + lane]];
-    if (lane + 64 < nm) L.pr[lane + 64] = prow[gv.e_mv[eoff + lane + 64]];
+    float* pp = node_p(base);
+    const uint16_t* pm = node_mv(base, nm);
+    if (lane < nm) L.pr[lane] = prow[pm[lane]];
+    if (lane + 64 < nm) L.pr[lane + 64] = prow[pm[lane + 64]];
     wave_sync();
     float all_p = 0.0f;
     if (nm > 0) {
@@ -334,10 +362,10 @@ XQ_D void attach_policy(const GameView& gv, SearchLDS& L, int node, const float*
         for (int j = 1; j < nm; ++j) all_p = all_p + L.pr[j];   // float32 accumulation in move order
     }
     if (all_p == 0.0f) all_p = 1.0f;
-    if (lane < nm) gv.e_p[eoff + lane] = L.pr[lane] / all_p;
-    if (lane + 64 < nm) gv.e_p[eoff + lane + 64] = L.pr[lane + 64] / all_p;
-    // e_p[j] is written and later read (select_edge) by the same lane, the node word by lane 0: no global fence
-    if (lane == 0) gv.node_meta[node] = meta & ~(uint32_t)NODE_WAITING;
+    if (lane < nm) pp[lane] = L.pr[lane] / all_p;
+    if (lane + 64 < nm) pp[lane + 64] = L.pr[lane + 64] / all_p;
+    // p[j] is written and later read (select_edge) by the same lane, the header by lane 0: no global fence
+    if (lane == 0) store_meta(base, meta & ~(uint32_t)NODE_WAITING);
     wave_sync();
 }
 
@@ -357,10 +385,13 @@ struct Picked {
     double w;
 };
 
-XQ_D Picked select_edge(const SearchParams& P, const GameView& gv, int sum_n, int nm, int eoff, const RootCtx& rc)
+// base: the node's record; sb: its stat block (nullptr: allocated in this visit, every edge is {0, 0, unknown})
+XQ_D Picked select_edge(const SearchParams& P, char* base, const EdgeStat* sb, int sum_n, int nm, const RootCtx& rc)
 {
     const int lane = lane_id();
     const double xx = __dsqrt_rn((double)(sum_n + 1));
+    const float* pp = node_p(base);
+    const uint16_t* pm = node_mv(base, nm);
     int n0 = 0, child0 = CHILD_UNKNOWN, mv0 = 0;           // this lane's edge of the first half
     double w0 = 0.0;
     double best_s = -1.0e300;
@@ -374,12 +405,13 @@ XQ_D Picked select_edge(const SearchParams& P, const GameView& gv, int sum_n, in
         double score = -1.0e300;
         bool win = false;
         if (valid) {
-            const int n = gv.e_n[eoff + j];
-            const double w = gv.e_w[eoff + j];
-            const float p = gv.e_p[eoff + j];
-            const int child = gv.e_child[eoff + j];          // fetched with the rest: no extra round trip later
-            const uint16_t mv = gv.e_mv[eoff + j];
-            if (h == 0) { n0 = n; w0 = w; child0 = child; mv0 = mv; }
+            EdgeStat es{0.0, 0, CHILD_UNKNOWN};
+            if (sb) es = sb[j];                              // N, W and the child link in one 16-byte load
+            const float p = pp[j];
+            const uint16_t mv = pm[j];
+            const int n = es.n;
+            const double w = es.w;
+            if (h == 0) { n0 = n; w0 = w; child0 = es.child; mv0 = mv; }
             const double q = n ? w / (double)n : 0.0;
             double u;
             if (rc.is_root) {
@@ -496,46 +528,67 @@ XQ_D const int8_t* history_board(const SearchParams& P, const SearchBuffers& B, 
         return L.r.bd[2];
     }
     if (depth < 2) return nullptr;
-    unpack_key(gv.node_key + (size_t)L.path_node[depth - 2] * KEY_WORDS, L.r.bd[2]);
+    unpack_key(node_key(gv, L.path_node[depth - 2]), L.r.bd[2]);
     return L.r.bd[2];
 }
 
-// create a node for the position in `b` whose ordered move list is in `ml` (nm moves);
-// returns the node index or -1 when the arena is full
-struct Arena {              // node / edge fill of the game's arena, held in registers while k_sim runs
-    int ncount, ecount;
+// The game's heap while a kernel runs: bump pointer + owned chunks, held in registers (wave-uniform).
+struct Arena {
+    uint32_t top;           // next free granule (record id)
+    int nchunks;            // chunks the game owns (reserved by begin_search for the whole ply)
+    int ncount;             // nodes in the tree
 };
 
+// `granules` <= 128 contiguous granules inside one chunk; 0 = the game's chunks are used up
+XQ_D uint32_t heap_alloc(Arena& ar, int granules)
+{
+    uint32_t top = ar.top;
+    if ((int)(top & (uint32_t)(CHUNK_GRANULES - 1)) + granules > CHUNK_GRANULES)
+        top = ((top >> CHUNK_SHIFT) + 1u) << CHUNK_SHIFT;            // records never straddle chunks
+    if ((int)(top >> CHUNK_SHIFT) >= ar.nchunks) return 0u;
+    ar.top = top + (uint32_t)granules;
+    return top;
+}
+
+// create a node for the position whose packed key is in L.key and whose ordered move list is in `ml` (nm moves);
+// returns the node id or -1 when the game's chunks (or its hash table) are full
 XQ_D int expand_node(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L,
                      const MoveList& ml, int nm, int hash_slot, uint64_t h, Arena& ar)
 {
     const int lane = lane_id();
-    const int ncount = ar.ncount, ecount = ar.ecount;
     nm = nm < MAXMOVES ? nm : MAXMOVES;
-    if (ncount >= P.node_cap || ecount + nm > P.edge_cap || hash_slot < 0) return -1;
-    const int idx = ncount;
-    if (lane < KEY_WORDS) gv.node_key[(size_t)idx * KEY_WORDS + lane] = L.key[lane];
+    if (hash_slot < 0) return -1;
+    const uint32_t id = heap_alloc(ar, NODE_HDR_GRANULES + (6 * nm + 15) / 16);
+    if (id == 0u) return -1;
+    char* base = rec_ptr(gv, id);
+    if (lane < KEY_WORDS) reinterpret_cast<uint32_t*>(base)[lane] = L.key[lane];
+    float* pp = node_p(base);
+    uint16_t* pm = node_mv(base, nm);
     for (int j = lane; j < nm; j += 64) {
-        gv.e_n[ecount + j] = 0;
-        gv.e_w[ecount + j] = 0.0;
-        gv.e_p[ecount + j] = 0.0f;
-        gv.e_mv[ecount + j] = ml.lab[j];
-        gv.e_child[ecount + j] = CHILD_UNKNOWN;
+        pp[j] = 0.0f;
+        pm[j] = ml.lab[j];
     }
     if (lane == 0) {
-        gv.node_sum_n[idx] = 1;                                    // player.py:213
-        gv.node_eoff[idx] = (uint32_t)ecount;
-        gv.node_meta[idx] = (uint32_t)nm | NODE_WAITING;
-        gv.hash[hash_slot] = ((uint64_t)((uint32_t)(h >> 32) | 1u) << 32) | (uint32_t)(idx + 1);
+        // sum_n = 1 (player.py:213), no statistics yet: they are allocated when the node is first selected from
+        *reinterpret_cast<int4*>(base + NODE_OFF_HDR) = make_int4(1, (int)((uint32_t)nm | NODE_WAITING), 0, 0);
+        gv.hash[hash_slot] = ((uint64_t)((uint32_t)(h >> 32) | 1u) << 32) | (uint32_t)(id + 1u);
     }
-    ar.ncount = ncount + 1;
-    ar.ecount = ecount + nm;
+    ar.ncount += 1;
     count(gv, CT_EXPANSIONS);
     count(gv, CT_LEAF_MOVES, (unsigned long long)nm);
-    // edges are written by the lane that reads them in select_edge, the node words and the hash slot by lane 0,
+    // p / move are written by the lane that reads them in select_edge, the header and the hash slot by lane 0,
     // the key words by the lanes that compare them in hash_lookup: no global fence
     wave_sync();
-    return idx;
+    return (int)id;
+}
+
+// move label of path entry (node, edge): edge - stat block = index into the node's move list (rare: repetitions)
+XQ_D int edge_move(const GameView& gv, int node, int edge)
+{
+    char* base = rec_ptr(gv, (uint32_t)node);
+    const NodeHdr hdr = load_hdr(base);
+    const int nm = (int)(hdr.meta & 0xFF);
+    return uni((int)node_mv(base, nm)[(uint32_t)edge - hdr.stat]);
 }
 
 // One descent of simulation `sim` starting at `node` with `depth` path entries already in L.path_*
@@ -573,8 +626,8 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
         // state in history[:-1] (player.py:223-236)
         const int rep = find_in_path(L, depth, node);
         if (rep >= 0) {
-            unpack_key(gv.node_key + (size_t)node * KEY_WORDS, L.r.bd[0]);
-            const int mv = uni((int)gv.e_mv[L.path_edge[rep]]);
+            unpack_key(node_key(gv, node), L.r.bd[0]);
+            const int mv = edge_move(gv, L.path_node[rep], L.path_edge[rep]);
             double v;
             if (wave_will_check_or_catch(L.r, L.r.bd[0], mv) == 1) v = -1.0;
             else if (wave_be_catched(L.r.bd[0], label_ft(mv) >> 8, L.r.bd[1], L.r.ml[0], L.r.plist)) v = 1.0;
@@ -584,7 +637,8 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
             sim_finish(gv, sim, active);
             return;
         }
-        const NodeHdr hdr = load_hdr(gv, node);
+        char* base = rec_ptr(gv, (uint32_t)node);
+        const NodeHdr hdr = load_hdr(base);
         const uint32_t meta = hdr.meta;
         if (meta & NODE_WAITING) {                                  // player.py:238-242
             if (lane == 0) { gv.s_state[sim] = SIM_PARKED; gv.s_node[sim] = node; gv.s_depth[sim] = depth; }
@@ -599,51 +653,70 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
             return;
         }
         const int nm = (int)(meta & 0xFF);
-        const int eoff = hdr.eoff;
+        // the node's statistics block: allocated on the first selection FROM the node (most nodes stay leaves)
+        uint32_t stat = hdr.stat;
+        const bool fresh_stat = stat == 0u && nm > 0;
+        if (fresh_stat) {
+            stat = heap_alloc(ar, nm);
+            if (stat == 0u) {
+                count(gv, CT_OVERFLOW_SIMS);
+                backup(P, gv, L, depth, 0.0);
+                sim_finish(gv, sim, active);
+                return;
+            }
+            if (lane == 0) store_stat(base, stat);
+            count(gv, CT_STAT_BLOCKS);
+        }
+        EdgeStat* sb = nm > 0 ? edge_ptr(gv, stat) : nullptr;
+        if (fresh_stat) {
+            // edge j is initialised by the lane that owns it in select_edge (j & 63): no fence before its later loads
+            for (int j = lane; j < nm; j += 64) sb[j] = EdgeStat{0.0, 0, CHILD_UNKNOWN};
+        }
         RootCtx rc = rc0;
         rc.is_root = (node == root);                                // player.py:266
         rc.sim = sim;
-        const Picked pk = select_edge(P, gv, hdr.sum_n, nm, eoff, rc);
+        const Picked pk = select_edge(P, base, fresh_stat ? nullptr : sb, hdr.sum_n, nm, rc);
         if (pk.j < 0) {                                             // "Best action is None": cannot happen
             backup(P, gv, L, depth, 0.0);
             sim_finish(gv, sim, active);
             return;
         }
-        const int e = eoff + pk.j;
+        EdgeStat* ep = sb + pk.j;
+        const int e = (int)(stat + (uint32_t)pk.j);                 // edge id = granule of its statistics
         const int owner = pk.j & 63;        // the lane that loads this edge in select_edge: its own stores are
                                             // visible to it in program order, no global fence per level
         if (lane == owner) {                                        // player.py:245-252
             if (pk.have) {                                          // the values select just read: no reload
-                gv.e_n[e] = pk.n + P.vl;
-                gv.e_w[e] = pk.w - (double)P.vl;
+                ep->n = pk.n + P.vl;
+                ep->w = pk.w - (double)P.vl;
             } else {
-                gv.e_n[e] += P.vl;
-                gv.e_w[e] = gv.e_w[e] - (double)P.vl;
+                ep->n += P.vl;
+                ep->w = ep->w - (double)P.vl;
             }
         }
         if (lane == 0) {
-            gv.node_sum_n[node] = hdr.sum_n + 1;
+            store_sum_n(base, hdr.sum_n + 1);
             L.path_node[depth] = node; L.path_edge[depth] = e;
             hp_node[depth] = node; hp_edge[depth] = e;
         }
         count(gv, CT_EDGES_VISITED, (unsigned long long)nm);
         depth += 1;
         wave_sync();
-        int child = pk.have ? pk.child : uni(gv.e_child[e]);
+        int child = pk.have ? pk.child : uni(ep->child);
         if (child == CHILD_UNKNOWN) {
-            unpack_key(gv.node_key + (size_t)node * KEY_WORDS, L.r.bd[0]);
-            const int ft = label_ft(pk.have ? pk.mv : uni((int)gv.e_mv[e]));
+            unpack_key(reinterpret_cast<const uint32_t*>(base), L.r.bd[0]);
+            const int ft = label_ft(pk.have ? pk.mv : uni((int)node_mv(base, nm)[pk.j]));
             step_board(L.r.bd[0], ft >> 8, ft & 0xFF, L.r.bd[1]);
             const DoneResult d = wave_done<true>(L.r.bd[1], L.r.bd[2], L.r.ml[0], L.r.ml[1], L.r.plist, false);   // player.py:204
             if (d.over) {
                 child = d.v > 0 ? CHILD_TERM_WIN : CHILD_TERM_LOSS;
-                if (lane == owner) gv.e_child[e] = child;
+                if (lane == owner) ep->child = child;
             } else {
                 const uint64_t h = pack_key(L.r.bd[1], L.key);
                 int slot;
                 int idx = hash_lookup(gv, P, L.key, h, &slot);
                 if (idx >= 0) {
-                    if (lane == owner) gv.e_child[e] = idx;
+                    if (lane == owner) ep->child = idx;
                     child = idx;
                 } else {
                     idx = expand_node(P, B, gv, L, L.r.ml[0], d.nmoves, slot, h, ar);     // player.py:211-221
@@ -653,7 +726,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
                         sim_finish(gv, sim, active);
                         return;
                     }
-                    if (lane == owner) gv.e_child[e] = idx;
+                    if (lane == owner) ep->child = idx;
                     if (lane == 0) { gv.s_state[sim] = SIM_LEAF; gv.s_node[sim] = idx; gv.s_depth[sim] = depth; }
                     write_planes<HIST>(io, L.r.bd[1], L.codes, (size_t)g * P.K + sim, HIST ? history_board(P, B, gv, L, fresh, depth) : nullptr);
                     wave_sync();
@@ -683,203 +756,90 @@ XQ_D void load_path(const SearchParams& P, const GameView& gv, SearchLDS& L, int
     wave_sync();
 }
 
-XQ_D void clear_tree(const SearchParams& P, const SearchBuffers& B, const GameView& gv)
+// ---- the chunk pool ---------------------------------------------------------------------------------------------
+// Free chunks sit in a ring: entries [head, tail) are free.  Games take chunks (begin_search) and give them back
+// (clear_tree) inside the same kernels, so takers only go up to `tail_vis`, the tail as of an earlier kernel boundary
+// (committed by pool_commit): a ring entry is never read in the launch that wrote it.
+XQ_D void pool_commit(const SearchBuffers& B)
+{
+    *B.pool_tail_vis = __hip_atomic_load(B.pool_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one chunk for this game, or -1 when the pool is empty (wave-uniform result)
+XQ_D int pool_take(const SearchParams& P, const SearchBuffers& B)
+{
+    int id = -1;
+    if (lane_id() == 0) {
+        unsigned int old = __hip_atomic_load(B.pool_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int vis = *B.pool_tail_vis;
+        while ((int)(vis - old) > 0) {
+            const unsigned int seen = atomicCAS(B.pool_head, old, old + 1u);
+            if (seen == old) { id = (int)B.pool_ring[old % (unsigned int)P.n_chunks]; break; }
+            old = seen;
+        }
+    }
+    return uni(id);
+}
+
+// Drop the game's tree (new game, reset): empty hash table, bump pointer back to the start, every chunk beyond the
+// first `keep_chunks` back to the pool.
+XQ_D void clear_tree(const SearchParams& P, const SearchBuffers& B, const GameView& gv, uint32_t* chtab)
 {
     const int lane = lane_id();
-    for (int i = lane; i < P.hash_cap; i += 64) gv.hash[i] = 0;
-    if (lane == 0) { B.g_node_count[gv.g] = 0; B.g_edge_count[gv.g] = 0; B.g_root[gv.g] = -1; }
+    const int g = gv.g;
+    {
+        uint4* h4 = reinterpret_cast<uint4*>(gv.hash);                // hash_cap is a power of two >= 64
+        for (int i = lane; i < P.hash_cap / 2; i += 64) h4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int nch = uni(B.g_nchunks[g]);
+    for (int i = P.keep_chunks + lane; i < nch; i += 64) {
+        const unsigned int slot = atomicAdd(B.pool_tail, 1u);
+        B.pool_ring[slot % (unsigned int)P.n_chunks] = chtab[i];
+    }
+    if (lane == 0) {
+        B.g_nchunks[g] = nch < P.keep_chunks ? nch : P.keep_chunks;
+        B.g_heap_top[g] = 1u;                                         // id 0 = "none"
+        B.g_node_count[g] = 0;
+        B.g_root[g] = -1;
+    }
     wave_sync_global();
 }
 
-// Keep only the sub-DAG reachable from `root` (through the child links of traversed edges) and slide it to
-// the front of the arena; rebuild the hash table.  Runs between plies (no simulation in flight).  The hash
-// table's memory doubles as scratch: remap[node_cap] (int32) + stack[node_cap] (int32) <= hash_cap * 8 bytes.
-// Returns the new root index.  Nodes keep their relative order, so every move is towards lower addresses.
-XQ_D int compact_tree(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L, int root)
+// Make sure the game owns room for `tasks` more simulations (each may add one node record and one statistics block of
+// RESERVE_MOVES moves): takes chunks from the pool.  false = the pool, the game's chunk table or its hash table is
+// exhausted.
+XQ_D bool reserve_ply(const SearchParams& P, const SearchBuffers& B, const GameView& gv, uint32_t* chtab, int tasks)
 {
-    // Every phase works on batches of up to 64 nodes with one lane per node for the bookkeeping and one lane per EDGE
-    // for the bulk (flat walk over the edges of the whole batch, independent steps), so that a compaction costs a few
-    // dozen dependent memory round trips instead of several per node: it runs inside k_advance, where one game's
-    // compaction is every game's latency.
-    const int lane = lane_id();
     const int g = gv.g;
+    const uint32_t top = uniu(B.g_heap_top[g]);
+    int nch = uni(B.g_nchunks[g]);
     const int ncount = uni(B.g_node_count[g]);
-    int32_t* remap = reinterpret_cast<int32_t*>(gv.hash);
-    int32_t* stack = remap + P.node_cap;
-    int* pfx = L.sn;                                   // [64] exclusive prefix of the batch's edge counts
-    int* oe = L.sn + 64;                               // [64] old edge offset of each batch node
-    int* ne = reinterpret_cast<int*>(L.pr);            // [64] new edge offset
-    const uint64_t lt = (1ull << lane) - 1ull;
-    const auto scan_edges = [&](int nm_l, int* total) {       // exclusive prefix over the lanes, sum in *total
-        int incl = nm_l;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
+    if ((long long)ncount + tasks + 1 > (long long)P.hash_cap * 7 / 8) return false;      // open addressing: keep it sparse
+    constexpr int PER_TASK = NODE_HDR_GRANULES + (6 * RESERVE_MOVES + 15) / 16 + RESERVE_MOVES;
+    constexpr int USABLE = CHUNK_GRANULES - MAXMOVES;                 // a record that does not fit moves to the next chunk
+    const long long need = (long long)(tasks + 1) * PER_TASK;
+    long long have = (long long)(nch - (int)(top >> CHUNK_SHIFT)) * USABLE - (long long)(top & (uint32_t)(CHUNK_GRANULES - 1));
+    bool ok = true;
+    while (have < need) {
+        if (nch >= P.max_chunks) { ok = false; break; }
+        const int id = pool_take(P, B);
+        if (id < 0) { ok = false; break; }
+        if (lane_id() == 0) {
+            B.g_chunk_tab[(size_t)g * P.max_chunks + nch] = (uint32_t)id;
+            chtab[nch] = (uint32_t)id;
         }
-        *total = __shfl(incl, 63, 64);
-        return incl - nm_l;
-    };
-    const auto slot_of = [&](int f) {                          // batch node that owns flat edge f: last s with pfx[s] <= f
-        int lo = 0;
-#pragma unroll
-        for (int step = 32; step; step >>= 1)
-            if (pfx[lo + step] <= f) lo += step;
-        return lo;
-    };
-    for (int i = lane; i < ncount; i += 64) remap[i] = -1;
-    wave_sync_global();
-    // ---- mark (DFS over batches; a child is claimed by the first edge that reaches it) ----
-    int top = 1;
-    if (lane == 0) { stack[0] = root; remap[root] = 0; }
-    wave_sync_global();
-    while (top > 0) {
-        const int nb = top < 64 ? top : 64;
-        int nm_l = 0, eoff_l = 0;
-        if (lane < nb) {
-            const int node = stack[top - 1 - lane];
-            nm_l = (int)(gv.node_meta[node] & 0xFF);
-            eoff_l = (int)gv.node_eoff[node];
-        }
-        top -= nb;
-        int total;
-        const int ex = scan_edges(nm_l, &total);
-        wave_sync();
-        pfx[lane] = lane < nb ? ex : 0x7fffffff;
-        oe[lane] = eoff_l;
-        wave_sync();
-        for (int f0 = 0; f0 < total; f0 += 256) {
-            int child[4];
-            bool fresh[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int f = f0 + u * 64 + lane;
-                child[u] = -1;
-                if (f < total) {
-                    const int sl = slot_of(f);
-                    child[u] = gv.e_child[oe[sl] + (f - pfx[sl])];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                fresh[u] = false;
-                if (child[u] >= 0) fresh[u] = atomicCAS(&remap[child[u]], -1, 0) == -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint64_t m = __ballot(fresh[u]);
-                if (fresh[u]) stack[top + __popcll(m & lt)] = child[u];
-                top += __popcll(m);
-            }
-        }
-        wave_sync_global();
+        nch += 1;
+        have += USABLE;
+        count(gv, CT_CHUNKS_TAKEN);
     }
-    // ---- new indices in old order ----
-    int live = 0;
-    for (int base = 0; base < ncount; base += 64) {
-        const int i = base + lane;
-        const bool keep = i < ncount && remap[i] == 0;
-        const uint64_t m = __ballot(keep);
-        if (keep) remap[i] = live + __popcll(m & lt);
-        live += __popcll(m);
-    }
-    wave_sync_global();
-    // ---- slide nodes and their edges down, remapping the child links.  Nodes keep their order and edge offsets grow
-    //      with the node index, so every destination is at or below its source and below every later source ----
-    int ecount = 0;
-    for (int base = 0; base < ncount; base += 64) {
-        const int i = base + lane;
-        const int ni = i < ncount ? remap[i] : -1;
-        const uint64_t lm = __ballot(ni >= 0);
-        if (lm == 0) continue;
-        uint32_t meta = 0, eoff_l = 0;
-        int sum_n = 0;
-        uint32_t kw[KEY_WORDS];
-        if (ni >= 0) {
-            meta = gv.node_meta[i];
-            eoff_l = gv.node_eoff[i];
-            sum_n = gv.node_sum_n[i];
-#pragma unroll
-            for (int w = 0; w < KEY_WORDS; ++w) kw[w] = gv.node_key[(size_t)i * KEY_WORDS + w];
-        }
-        const int nm_l = ni >= 0 ? (int)(meta & 0xFF) : 0;
-        int total;
-        const int ex = scan_edges(nm_l, &total);
-        wave_sync();
-        pfx[lane] = ex;                                     // dead lanes: nm 0, never selected by slot_of
-        oe[lane] = (int)eoff_l;
-        ne[lane] = ecount + ex;
-        wave_sync();
-        if (ni >= 0) {                                      // headers: all of the batch's reads are done
-            gv.node_meta[ni] = meta;
-            gv.node_eoff[ni] = (uint32_t)(ecount + ex);
-            gv.node_sum_n[ni] = sum_n;
-#pragma unroll
-            for (int w = 0; w < KEY_WORDS; ++w) gv.node_key[(size_t)ni * KEY_WORDS + w] = kw[w];
-        }
-        for (int f0 = 0; f0 < total; f0 += 128) {
-            int src[2], dst[2], en[2], ec[2];
-            double ew[2];
-            float ep[2];
-            uint16_t em[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int f = f0 + u * 64 + lane;
-                src[u] = -1;
-                if (f < total) {
-                    const int sl = slot_of(f);
-                    src[u] = oe[sl] + (f - pfx[sl]);
-                    dst[u] = ne[sl] + (f - pfx[sl]);
-                    en[u] = gv.e_n[src[u]]; ew[u] = gv.e_w[src[u]]; ep[u] = gv.e_p[src[u]];
-                    em[u] = gv.e_mv[src[u]]; ec[u] = gv.e_child[src[u]];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (src[u] >= 0 && ec[u] >= 0) ec[u] = remap[ec[u]];
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (src[u] >= 0) {
-                    gv.e_n[dst[u]] = en[u]; gv.e_w[dst[u]] = ew[u]; gv.e_p[dst[u]] = ep[u];
-                    gv.e_mv[dst[u]] = em[u]; gv.e_child[dst[u]] = ec[u];
-                }
-        }
-        ecount += total;
-    }
-    wave_sync_global();
-    const int new_root = uni(remap[root]);
-    wave_sync_global();
-    // rebuild the hash table: one node per lane, linear probing with a compare-and-swap on the slot
-    for (int i = lane; i < P.hash_cap; i += 64) gv.hash[i] = 0;
-    wave_sync_global();
-    const uint32_t mask = (uint32_t)P.hash_cap - 1u;
-    for (int base = 0; base < live; base += 64) {
-        const int i = base + lane;
-        if (i < live) {
-            uint64_t x = 0;
-            for (int w = 0; w < KEY_WORDS; ++w)
-                x ^= mix64((uint64_t)gv.node_key[(size_t)i * KEY_WORDS + w] + 0x9E3779B97F4A7C15ULL * (uint64_t)(w + 1));
-            const uint64_t h = mix64(x);
-            const unsigned long long entry = ((unsigned long long)((uint32_t)(h >> 32) | 1u) << 32) | (uint32_t)(i + 1);
-            uint32_t slot = (uint32_t)h & mask;
-            unsigned long long* tab = reinterpret_cast<unsigned long long*>(gv.hash);
-            while (atomicCAS(&tab[slot], 0ull, entry) != 0ull) slot = (slot + 1) & mask;
-        }
-    }
-    wave_sync_global();
-    if (lane == 0) { B.g_node_count[g] = live; B.g_edge_count[g] = ecount; B.g_root[g] = new_root; }
-    wave_sync_global();
-    (void)L;
-    return new_root;
+    if (lane_id() == 0) B.g_nchunks[g] = nch;
+    wave_sync();
+    return ok;
 }
 
 // Start the search of the position in g_board (CChessPlayer.action, player.py:145-164): find the
-// root in the tree, apply the reuse rule, make room in the arena.
-// defer_compaction (self-play, k_advance): when the arena has to be compacted first, only mark the game PH_COMPACT;
-// k_compact finishes the job (this function again, not deferred) on a side stream while the round goes on without
-// this game -- one game's compaction (a few ms of dependent round trips) is otherwise every game's latency.
-XQ_D void begin_search(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L,
-                       bool defer_compaction = false, int ready_phase = PH_SEARCH)
+// root in the tree, apply the reuse rule, reserve the ply's memory.
+XQ_D void begin_search(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L)
 {
     const int lane = lane_id();
     const int g = gv.g;
@@ -890,49 +850,28 @@ XQ_D void begin_search(const SearchParams& P, const SearchBuffers& B, const Game
     const uint64_t h = pack_key(L.r.bd[1], L.key);
     int slot;
     int root = hash_lookup(gv, P, L.key, h, &slot);
-    int done_n = root >= 0 ? uni(gv.node_sum_n[root]) : 0;                       // :153-155
+    int done_n = root >= 0 ? uni(*reinterpret_cast<const int32_t*>(rec_ptr(gv, (uint32_t)root) + NODE_OFF_HDR)) : 0;   // :153-155
     const int n_no_act = uni((int)B.g_n_no_act[g]), inc = uni((int)B.g_increase_temp[g]);
     if (n_no_act > 0 || inc || done_n == P.sims) done_n = 0;                      // :156-158
     int tasks = P.sims - done_n;
     if (tasks < 0) tasks = 0;
-    // arena policy: the tree of a game is kept as long as it fits (reference: for the whole game).  When the
-    // next ply might not fit, it is first compacted to the sub-DAG reachable from the new root (what subtree
-    // reuse can still see); only if that is not enough (or the root is new) it is dropped.
-    int ncount = uni(B.g_node_count[g]), ecount = uni(B.g_edge_count[g]);
-    const auto no_room = [&](int nc, int ec) {
-        // 80 edges reserved per node the search may add: positions with 65-70 legal moves do come in runs
-        return nc + tasks + 1 > P.node_cap || (long long)ec + (long long)(tasks + 1) * 80 > P.edge_cap;
-    };
-    if (tasks > 0 && no_room(ncount, ecount)) {
-        if (defer_compaction && root >= 0) {
-            if (lane == 0) {
-                B.g_root[g] = root;
-                B.g_tasks_left[g] = 0;
-                B.g_active[g] = 0;
-                B.g_phase[g] = PH_COMPACT;
-            }
-            wave_sync_global();
-            return;
-        }
-        if (root >= 0) {
-            root = compact_tree(P, B, gv, L, root);
-            count(gv, CT_TREE_COMPACTIONS);
-            ncount = uni(B.g_node_count[g]); ecount = uni(B.g_edge_count[g]);
-        }
-        if (root < 0 || no_room(ncount, ecount)) {
-            clear_tree(P, B, gv);
-            count(gv, CT_TREE_RESETS);
-            root = -1;
-            tasks = P.sims;
-            done_n = 0;
-        }
+    // Memory policy: the reference keeps a game's tree for the whole game (self_play.py:84,98-100) and so does the
+    // engine as long as the pool has chunks.  Only when the coming ply cannot be reserved is the game's tree dropped
+    // (counted: tree_resets; the chunks it keeps hold one full search).
+    if (tasks > 0 && !reserve_ply(P, B, gv, L.chtab, tasks)) {
+        clear_tree(P, B, gv, L.chtab);
+        count(gv, CT_TREE_RESETS);
+        root = -1;
+        tasks = P.sims;
+        done_n = 0;
+        (void)reserve_ply(P, B, gv, L.chtab, tasks);     // within keep_chunks by construction; else overflow_sims counts
     }
     count(gv, CT_ROOT_REUSED_SIMS, (unsigned long long)done_n);
     if (lane == 0) {
         B.g_root[g] = root;
         B.g_tasks_left[g] = tasks;
         B.g_active[g] = 0;
-        B.g_phase[g] = (uint8_t)ready_phase;
+        B.g_phase[g] = PH_SEARCH;
     }
     wave_sync_global();
 }
@@ -946,9 +885,12 @@ XQ_D int choose_action(const SearchParams& P, const SearchBuffers& B, const Game
     const int g = gv.g;
     const int root = uni(B.g_root[g]);
     if (root < 0) return -2;
-    const int nm = (int)(uniu(gv.node_meta[root]) & 0xFF);
+    char* base = rec_ptr(gv, (uint32_t)root);
+    const NodeHdr hdr = load_hdr(base);
+    const int nm = (int)(hdr.meta & 0xFF);
     if (nm == 0) return -1;             // no move at all (the reference player dead-locks here): give the game up
-    const int eoff = (int)uniu(gv.node_eoff[root]);
+    const uint16_t* pm = node_mv(base, nm);
+    const EdgeStat* sb = hdr.stat ? edge_ptr(gv, hdr.stat) : nullptr;   // none: the root was never selected from
     const int n_no_act = uni((int)B.g_n_no_act[g]);
     const uint16_t* no_act = B.g_no_act + (size_t)g * MAX_NO_ACT;
     const int turns = uni(B.g_turns[g]);
@@ -960,13 +902,15 @@ XQ_D int choose_action(const SearchParams& P, const SearchBuffers& B, const Game
         const int j = lane + 64 * h;
         cnt[h] = 0;
         if (j < nm) {
-            const int n = gv.e_n[eoff + j];
-            const uint16_t mv = gv.e_mv[eoff + j];
+            EdgeStat es{0.0, 0, CHILD_UNKNOWN};
+            if (sb) es = sb[j];
+            const int n = es.n;
+            const uint16_t mv = pm[j];
             bool banned = false;
             for (int k = 0; k < n_no_act; ++k) banned = banned || (no_act[k] == mv);
             if (!banned) {
                 cnt[h] = n;
-                const double q = n ? gv.e_w[eoff + j] / (double)n : 0.0;
+                const double q = n ? es.w / (double)n : 0.0;
                 maxq = q > maxq ? q : maxq;
             }
         }
@@ -983,9 +927,9 @@ XQ_D int choose_action(const SearchParams& P, const SearchBuffers& B, const Game
     for (int h = 0; h < 2; ++h) {
         const int j = lane + 64 * h;
         if (j < nm) {
-            const uint16_t mv = gv.e_mv[eoff + j];
+            const uint16_t mv = pm[j];
             int rank = 0;
-            for (int k = 0; k < nm; ++k) rank += gv.e_mv[eoff + k] < mv;
+            for (int k = 0; k < nm; ++k) rank += pm[k] < mv;
             L.slab[rank] = mv;
             L.sn[rank] = cnt[h];
         }
@@ -1061,7 +1005,7 @@ XQ_D void new_game(const SearchParams& P, const SearchBuffers& B, const GameView
 {
     const int lane = lane_id();
     const int g = gv.g;
-    clear_tree(P, B, gv);
+    clear_tree(P, B, gv, L.chtab);
     set_init_board(B.g_board + (size_t)g * BOARD_LDS);
     wave_sync_global();
     const int8_t* gb = B.g_board + (size_t)g * BOARD_LDS;
@@ -1080,7 +1024,7 @@ XQ_D void new_game(const SearchParams& P, const SearchBuffers& B, const GameView
         B.g_enable_resign[g] = philox_uniform(P.seed, game_id, 0, 0) > P.enable_resign_rate ? 1 : 0;
     }
     wave_sync_global();
-    begin_search(P, B, gv, L, true);                 // (a new game starts on an empty tree: never deferred in effect)
+    begin_search(P, B, gv, L);
 }
 
 XQ_D void emit_record(const SearchParams& P, const SearchBuffers& B, const GameView& gv, int turns, int value,
@@ -1184,7 +1128,7 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
         wave_sync_global();
     }
     if (!game_over) {
-        begin_search(P, B, gv, L, true);
+        begin_search(P, B, gv, L);
         return;
     }
     if (final_move != NOMOVE) {                                         // :177-184
@@ -1203,7 +1147,7 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
 // ---- the round kernels --------------------------------------------------------------------------------------
 // One lock-step round = k_sim(BACKUP) -> k_advance -> k_sim(SELECT)   (+ k_noise before each k_sim when the
 // root noise is on).  Splitting the round keeps the hot simulation kernel free of the cold, register-hungry code
-// (move sampling with pow(), game rules, tree compaction, Gamma sampling).
+// (move sampling with pow(), game rules, chunk reservation, Gamma sampling).
 constexpr int SIM_BACKUP = 1, SIM_SELECT = 2;
 
 template <bool HIST>        // HIST: 28 input planes (use_history); kept out of the common 14-plane instantiation
@@ -1212,18 +1156,15 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
 {
     __shared__ SearchLDS L;
     const int g = blockIdx.x;
+    // first kernel of a round: chunks returned during the previous round become takeable (see pool_commit)
+    if (g == 0 && (mask & SIM_BACKUP) && lane_id() == 0) pool_commit(B);
     if (g >= P.G) return;
-    int phase = uni((int)B.g_phase[g]);
-    if (phase == PH_COMPACTED && (mask & SIM_BACKUP)) {          // compacted during the previous round (k_compact)
-        phase = PH_SEARCH;
-        if (lane_id() == 0) B.g_phase[g] = PH_SEARCH;
-    }
-    if (phase != PH_SEARCH) return;
-    const GameView gv = make_view(B, P, g, L.ctr);
+    if (uni((int)B.g_phase[g]) != PH_SEARCH) return;
+    const GameView gv = make_view(B, P, g, L.ctr, L.chtab);
     counters_begin(gv);
     const RoundIO io{planes, P.planes_dtype, P.in_planes};
     int active = uni(B.g_active[g]);
-    Arena ar{uni(B.g_node_count[g]), uni(B.g_edge_count[g])};
+    Arena ar{uniu(B.g_heap_top[g]), uni(B.g_nchunks[g]), uni(B.g_node_count[g])};
     const RootCtx rc{false, uni((int)B.g_n_no_act[g]), B.g_no_act + (size_t)g * MAX_NO_ACT,
                      P.noise_eps != 0.0 ? B.noise + (size_t)g * P.K * MAXMOVES : nullptr, 0};
     int resume_i = P.K;
@@ -1267,7 +1208,7 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
         } else break;
         run_sim<HIST>(P, B, gv, L, io, rc, uni(B.g_root[g]), sim, node, depth, &active, ar, fresh);
     }
-    if (lane_id() == 0) { B.g_active[g] = active; B.g_node_count[g] = ar.ncount; B.g_edge_count[g] = ar.ecount; }
+    if (lane_id() == 0) { B.g_active[g] = active; B.g_node_count[g] = ar.ncount; B.g_heap_top[g] = ar.top; }
     counters_flush(gv);
 }
 
@@ -1279,7 +1220,7 @@ __global__ __launch_bounds__(64) void k_advance(SearchParams P, SearchBuffers B)
     const int g = blockIdx.x;
     if (g >= P.G) return;
     if (uni((int)B.g_phase[g]) != PH_SEARCH || uni(B.g_active[g]) != 0 || uni(B.g_tasks_left[g]) != 0) return;
-    const GameView gv = make_view(B, P, g, L.ctr);
+    const GameView gv = make_view(B, P, g, L.ctr, L.chtab);
     counters_begin(gv);
     if (P.mode == MODE_SELFPLAY) {
         for (int it = 0; it < 8; ++it) {          // a search with nothing to do (fully reused root) ends at once
@@ -1289,23 +1230,6 @@ __global__ __launch_bounds__(64) void k_advance(SearchParams P, SearchBuffers B)
     } else if (lane_id() == 0) {
         B.g_phase[g] = PH_READY;
     }
-    counters_flush(gv);
-}
-
-// The deferred half of begin_search for the games k_advance left in PH_COMPACT.
-__global__ __launch_bounds__(64) void k_compact(SearchParams P, SearchBuffers B)
-{
-    __shared__ SearchLDS L;
-    const int g = blockIdx.x;
-    if (g >= P.G) return;
-    if (uni((int)B.g_phase[g]) != PH_COMPACT) return;
-    const GameView gv = make_view(B, P, g, L.ctr);
-    counters_begin(gv);
-    // k_compact overlaps this round's k_noise / k_sim(SELECT) on another stream, possibly on another XCD whose L2 is
-    // not coherent with ours: those kernels must not pick this game up half-way.  It is left in PH_COMPACTED and the
-    // next round's k_sim(BACKUP) -- ordered behind this kernel by an event, i.e. a kernel boundary -- makes it
-    // PH_SEARCH.
-    begin_search(P, B, gv, L, false, PH_COMPACTED);
     counters_flush(gv);
 }
 
@@ -1331,7 +1255,9 @@ __global__ __launch_bounds__(64) void k_noise(SearchParams P, SearchBuffers B, i
         if (active == 0) return;
         last = P.K;
     }
-    const int nm = (int)(B.node_meta[(size_t)g * P.node_cap + root] & 0xFF);
+    const char* rbase = B.pool + ((size_t)B.g_chunk_tab[(size_t)g * P.max_chunks + ((uint32_t)root >> CHUNK_SHIFT)] << 20)
+                        + ((size_t)((uint32_t)root & (uint32_t)(CHUNK_GRANULES - 1)) << 4);
+    const int nm = (int)(*reinterpret_cast<const uint32_t*>(rbase + NODE_OFF_HDR + 4) & 0xFF);
     const uint32_t epoch = B.g_noise_epoch[g];
     double* rows = B.noise + (size_t)g * P.K * MAXMOVES;
     const float alpha = (float)P.dirichlet_alpha;
@@ -1341,9 +1267,7 @@ __global__ __launch_bounds__(64) void k_noise(SearchParams P, SearchBuffers B, i
         for (int j = lane; j < nm; j += 64) {
             NoiseRng rng{P.seed, ((uint64_t)epoch << 32) | ((uint64_t)sim << 20) | ((uint64_t)j << 8),
                          B.g_game_id[g] + (uint32_t)g * 2654435761u, {0, 0, 0, 0}, 0};
-            const float x = gamma_draw(alpha, rng);
-            const float y = nm > 1 ? gamma_draw(alpha * (float)(nm - 1), rng) : 0.0f;
-            rows[(size_t)sim * MAXMOVES + j] = (x + y) > 0.0f ? (double)(x / (x + y)) : 1.0 / (double)nm;
+            rows[(size_t)sim * MAXMOVES + j] = dirichlet0(alpha, nm, rng);
         }
     }
     __syncthreads();
@@ -1356,7 +1280,7 @@ __global__ __launch_bounds__(64) void k_start_selfplay(SearchParams P, SearchBuf
     __shared__ SearchLDS L;
     const int g = blockIdx.x;
     if (g >= P.G) return;
-    const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT);   // counts go straight to the global block
+    const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT, L.chtab);   // counts go straight to the global block
     const int lane = lane_id();
     for (int i = lane; i < P.K; i += 64) gv.s_state[i] = SIM_IDLE;
     for (int i = lane; i < CT_COUNT; i += 64) gv.ctr[i] = 0;
@@ -1376,7 +1300,7 @@ __global__ __launch_bounds__(64) void k_set_roots(SearchParams P, SearchBuffers 
     const int g = blockIdx.x;
     if (g >= P.G) return;
     if (select_mask && !select_mask[g]) return;
-    const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT);   // counts go straight to the global block
+    const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT, L.chtab);   // counts go straight to the global block
     const int lane = lane_id();
     load_board(boards + (size_t)g * NSQ, L.r.bd[0]);
     int8_t* gb = B.g_board + (size_t)g * BOARD_LDS;
@@ -1408,14 +1332,18 @@ __global__ __launch_bounds__(64) void k_set_roots(SearchParams P, SearchBuffers 
 
 __global__ __launch_bounds__(64) void k_reset_trees(SearchParams P, SearchBuffers B)
 {
+    __shared__ uint32_t chtab[MAX_CHUNKS];
     const int g = blockIdx.x;
     if (g >= P.G) return;
-    const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT);   // counts go straight to the global block
-    clear_tree(P, B, gv);
+    const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT, chtab);   // counts go straight to the global block
+    clear_tree(P, B, gv, chtab);
     const int lane = lane_id();
     for (int i = lane; i < P.K; i += 64) gv.s_state[i] = SIM_IDLE;
     if (lane == 0) { B.g_phase[g] = PH_IDLE; B.g_active[g] = 0; B.g_tasks_left[g] = 0; }
 }
+
+// chunks returned by earlier launches become takeable (entry points outside the round call this first)
+__global__ void k_pool_commit(SearchBuffers B) { pool_commit(B); }
 
 __global__ void k_pending(SearchParams P, SearchBuffers B)
 {
@@ -1431,32 +1359,49 @@ __global__ __launch_bounds__(64) void k_root_stats(SearchParams P, SearchBuffers
                                                   float* __restrict__ p, int32_t* __restrict__ sum_n,
                                                   uint8_t* __restrict__ counts)
 {
+    __shared__ uint32_t chtab[MAX_CHUNKS];
     const int g = blockIdx.x;
     if (g >= P.G) return;
-    const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT);   // counts go straight to the global block
+    const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT, chtab);   // counts go straight to the global block
     const int lane = lane_id();
     int root = B.g_root[g];
     for (int d = 0; path && d < path_len && root >= 0; ++d) {
         const uint16_t mv = path[(size_t)g * path_len + d];
         if (mv == NOMOVE) break;
-        const int pn = (int)(gv.node_meta[root] & 0xFF), pe = (int)gv.node_eoff[root];
+        char* base = rec_ptr(gv, (uint32_t)root);
+        const NodeHdr hdr = load_hdr(base);
+        const int pn = (int)(hdr.meta & 0xFF);
+        const uint16_t* pm = node_mv(base, pn);
         int child = -1;
-        for (int j = lane; j < pn; j += 64)
-            if (gv.e_mv[pe + j] == mv) child = gv.e_child[pe + j];
+        if (hdr.stat) {
+            const EdgeStat* sb = edge_ptr(gv, hdr.stat);
+            for (int j = lane; j < pn; j += 64)
+                if (pm[j] == mv) child = sb[j].child;
+        }
         const unsigned long long hit = __ballot(child >= 0);
         root = hit ? __shfl(child, __ffsll((long long)hit) - 1) : -1;
     }
-    int nm = 0, eoff = 0;
-    if (root >= 0) { nm = (int)(gv.node_meta[root] & 0xFF); eoff = (int)gv.node_eoff[root]; }
+    int nm = 0, root_sum_n = 0;
+    char* base = nullptr;
+    const EdgeStat* sb = nullptr;
+    if (root >= 0) {
+        base = rec_ptr(gv, (uint32_t)root);
+        const NodeHdr hdr = load_hdr(base);
+        nm = (int)(hdr.meta & 0xFF);
+        root_sum_n = hdr.sum_n;
+        if (hdr.stat) sb = edge_ptr(gv, hdr.stat);
+    }
     for (int j = lane; j < MAXMOVES; j += 64) {
         const bool ok = j < nm;
-        if (moves) moves[(size_t)g * MAXMOVES + j] = ok ? gv.e_mv[eoff + j] : (uint16_t)NOMOVE;
-        if (n) n[(size_t)g * MAXMOVES + j] = ok ? gv.e_n[eoff + j] : 0;
-        if (w) w[(size_t)g * MAXMOVES + j] = ok ? gv.e_w[eoff + j] : 0.0;
-        if (p) p[(size_t)g * MAXMOVES + j] = ok ? gv.e_p[eoff + j] : 0.0f;
+        EdgeStat es{0.0, 0, CHILD_UNKNOWN};
+        if (ok && sb) es = sb[j];
+        if (moves) moves[(size_t)g * MAXMOVES + j] = ok ? node_mv(base, nm)[j] : (uint16_t)NOMOVE;
+        if (n) n[(size_t)g * MAXMOVES + j] = es.n;
+        if (w) w[(size_t)g * MAXMOVES + j] = es.w;
+        if (p) p[(size_t)g * MAXMOVES + j] = ok ? node_p(base)[j] : 0.0f;
     }
     if (lane == 0) {
-        if (sum_n) sum_n[g] = root >= 0 ? gv.node_sum_n[root] : 0;
+        if (sum_n) sum_n[g] = root_sum_n;
         if (counts) counts[g] = (uint8_t)nm;
     }
 }
@@ -1467,7 +1412,7 @@ __global__ __launch_bounds__(64) void k_choose(SearchParams P, SearchBuffers B, 
     __shared__ SearchLDS L;
     const int g = blockIdx.x;
     if (g >= P.G) return;
-    const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT);   // counts go straight to the global block
+    const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT, L.chtab);   // counts go straight to the global block
     const int a = choose_action(P, B, gv, L, u ? u[g] : 0.5, B.g_enable_resign[g] != 0);
     if (lane_id() == 0) action[g] = a;
 }
@@ -1477,6 +1422,17 @@ __global__ void k_stop(SearchParams P, SearchBuffers B)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < P.G && B.g_phase[g] == PH_SEARCH) B.g_tasks_left[g] = 0;
+}
+
+// test hook: `n` draws of the root noise exactly as k_noise produces them (same generator, same stream layout: one
+// Philox counter block sequence per (epoch, sim, move) triple)
+__global__ void k_debug_noise(uint64_t seed, uint32_t game_key, float alpha, int nm, double* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t epoch = (uint32_t)(i / (8 * 128)), sim = (uint32_t)(i / 128) % 8u, j = (uint32_t)i % 128u;
+    NoiseRng rng{seed, ((uint64_t)epoch << 32) | ((uint64_t)sim << 20) | ((uint64_t)j << 8), game_key, {0, 0, 0, 0}, 0};
+    out[i] = dirichlet0(alpha, nm, rng);
 }
 
 __global__ void k_debug_sqrt(const int32_t* __restrict__ x, double* __restrict__ y, int n)
@@ -1491,12 +1447,10 @@ __global__ void k_debug_sqrt(const int32_t* __restrict__ x, double* __restrict__
 struct cz_search {
     SearchParams P;
     SearchBuffers B;
-    void* slab;
-    size_t bytes;
-    int device;
-    hipStream_t side = nullptr;       // k_compact runs here, overlapping the rest of the round and the network
-    hipEvent_t ev_fork = nullptr, ev_done = nullptr;
-    bool side_pending = false;        // a k_compact launch the caller's stream has not waited for yet
+    void* slab = nullptr;             // everything but the chunk pool
+    void* pool = nullptr;             // n_chunks x 1 MiB
+    size_t bytes = 0;                 // slab + pool
+    int device = 0;
 };
 
 namespace {
@@ -1516,16 +1470,6 @@ int serr_hip(const char* what, hipError_t e)
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// Every entry point that touches the search state first orders the caller's stream behind a k_compact still running
-// on the side stream.
-void join_side(cz_search* s, hipStream_t st)
-{
-    if (s->side_pending) {
-        (void)hipStreamWaitEvent(st, s->ev_done, 0);
-        s->side_pending = false;
-    }
-}
-
 template <typename T>
 void carve(char*& cur, T*& ptr, size_t count, bool dry)
 {
@@ -1538,20 +1482,17 @@ size_t layout(cz_search* s, char* base, bool dry)
     const SearchParams& P = s->P;
     SearchBuffers& B = s->B;
     char* cur = base;
-    const size_t G = (size_t)P.G, C = (size_t)P.node_cap, E = (size_t)P.edge_cap, H = (size_t)P.hash_cap;
+    const size_t G = (size_t)P.G, H = (size_t)P.hash_cap;
     const size_t K = (size_t)P.K, D = (size_t)P.max_depth, PL = (size_t)P.max_plies + 2;
-    carve(cur, B.node_key, G * C * KEY_WORDS, dry);
-    carve(cur, B.node_sum_n, G * C, dry);
-    carve(cur, B.node_eoff, G * C, dry);
-    carve(cur, B.node_meta, G * C, dry);
-    carve(cur, B.hash_tab, G * H, dry);
-    carve(cur, B.e_n, G * E, dry);
-    carve(cur, B.e_w, G * E, dry);
-    carve(cur, B.e_p, G * E, dry);
-    carve(cur, B.e_mv, G * E, dry);
-    carve(cur, B.e_child, G * E, dry);
+    carve(cur, B.hash_tab, G * H, dry);                  // first: the only part that has to be zeroed per game
+    carve(cur, B.pool_ring, (size_t)P.n_chunks, dry);
+    carve(cur, B.pool_head, 1, dry);
+    carve(cur, B.pool_tail, 1, dry);
+    carve(cur, B.pool_tail_vis, 1, dry);
+    carve(cur, B.g_chunk_tab, G * (size_t)P.max_chunks, dry);
+    carve(cur, B.g_nchunks, G, dry);
+    carve(cur, B.g_heap_top, G, dry);
     carve(cur, B.g_node_count, G, dry);
-    carve(cur, B.g_edge_count, G, dry);
     carve(cur, B.g_root, G, dry);
     carve(cur, B.g_board, G * BOARD_LDS, dry);
     carve(cur, B.g_tasks_left, G, dry);
@@ -1583,6 +1524,47 @@ size_t layout(cz_search* s, char* base, bool dry)
     return (size_t)(cur - base);
 }
 
+// chunks a game needs for one full search on an empty tree (what it keeps through resets and between games)
+int keep_chunks_for(int sims)
+{
+    constexpr long long PER_TASK = NODE_HDR_GRANULES + (6 * RESERVE_MOVES + 15) / 16 + RESERVE_MOVES;
+    constexpr long long USABLE = CHUNK_GRANULES - MAXMOVES;
+    const long long need = (long long)(sims + 1) * PER_TASK + 1;
+    return (int)((need + USABLE - 1) / USABLE);
+}
+
+// initial state of the pool: game g owns chunks [g * keep, (g + 1) * keep), the rest is free
+int init_pool(cz_search* s)
+{
+    const SearchParams& P = s->P;
+    const size_t G = (size_t)P.G;
+    const int owned = P.G * P.keep_chunks;
+    uint32_t* tab = new (std::nothrow) uint32_t[G * P.max_chunks]();
+    uint32_t* ring = new (std::nothrow) uint32_t[(size_t)P.n_chunks]();
+    int32_t* nch = new (std::nothrow) int32_t[G];
+    uint32_t* top = new (std::nothrow) uint32_t[G];
+    hipError_t e = hipSuccess;
+    if (!tab || !ring || !nch || !top) e = hipErrorOutOfMemory;
+    else {
+        for (size_t g = 0; g < G; ++g) {
+            for (int i = 0; i < P.keep_chunks; ++i) tab[g * P.max_chunks + i] = (uint32_t)(g * P.keep_chunks + i);
+            nch[g] = P.keep_chunks;
+            top[g] = 1u;
+        }
+        for (int i = owned; i < P.n_chunks; ++i) ring[i - owned] = (uint32_t)i;
+        const unsigned int head = 0u, tail = (unsigned int)(P.n_chunks - owned);
+        e = hipMemcpy(s->B.g_chunk_tab, tab, sizeof(uint32_t) * G * P.max_chunks, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s->B.pool_ring, ring, sizeof(uint32_t) * (size_t)P.n_chunks, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s->B.g_nchunks, nch, sizeof(int32_t) * G, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s->B.g_heap_top, top, sizeof(uint32_t) * G, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s->B.pool_head, &head, sizeof(head), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s->B.pool_tail, &tail, sizeof(tail), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s->B.pool_tail_vis, &tail, sizeof(tail), hipMemcpyHostToDevice);
+    }
+    delete[] tab; delete[] ring; delete[] nch; delete[] top;
+    return e == hipSuccess ? CZ_OK : serr_hip("cz_search_create: pool initialisation", e);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1599,17 +1581,25 @@ int cz_search_create(const cz_search_cfg* c, cz_search** out)
     P.K = c->sims_per_round;
     P.sims = c->simulation_num_per_move;
     P.vl = c->virtual_loss;
-    P.node_cap = c->node_capacity > 0 ? c->node_capacity : 4 * P.sims + 64;
-    if (P.node_cap < P.sims + 2) P.node_cap = P.sims + 2;
-    P.edge_cap = c->edge_capacity > 0 ? c->edge_capacity : P.node_cap * 64;
-    if (P.edge_cap < (P.sims + 2) * 80) P.edge_cap = (P.sims + 2) * 80;
-    int h = 1;
-    while (h < 2 * P.node_cap) h <<= 1;
-    P.hash_cap = h;
     P.max_depth = c->max_depth > 0 ? c->max_depth : MAXD_LDS;      // simulations deeper than this are cut (counted)
     if (P.max_depth > MAXD_LDS) P.max_depth = MAXD_LDS;
     P.max_game_length = c->max_game_length > 0 ? c->max_game_length : 100;
     P.max_plies = 2 * P.max_game_length + 2;
+    // the most nodes one game's tree is sized for: every simulation of every ply of the longest game expands one
+    long long max_nodes = c->max_nodes_per_game > 0 ? c->max_nodes_per_game : (long long)(P.max_plies + 2) * P.sims;
+    if (max_nodes < P.sims + 2) max_nodes = P.sims + 2;
+    if (max_nodes > (1ll << 23)) max_nodes = 1ll << 23;
+    int h = 128;
+    while ((long long)h * 2 < max_nodes * 3) h <<= 1;              // load factor <= 2/3 at max_nodes
+    P.hash_cap = h;
+    P.keep_chunks = keep_chunks_for(P.sims);
+    // chunk table: the whole-game tree at ~420 B per node (node record + its share of statistics blocks)
+    const long long game_chunks = (max_nodes * 420 + (long long)CHUNK_BYTES - 1) / (long long)CHUNK_BYTES;
+    long long mc = game_chunks + P.keep_chunks;
+    if (mc < P.keep_chunks + 1) mc = P.keep_chunks + 1;
+    if (mc > MAX_CHUNKS) mc = MAX_CHUNKS;
+    if (P.keep_chunks > MAX_CHUNKS) { delete s; return serr(CZ_ERR_ARG, "cz_search_create: simulation_num_per_move too large for one game's chunk table"); }
+    P.max_chunks = (int)mc;
     P.planes_dtype = c->planes_dtype;
     P.in_planes = c->use_history ? 28 : 14;
     P.mode = MODE_EXTERNAL;
@@ -1628,18 +1618,36 @@ int cz_search_create(const cz_search_cfg* c, cz_search** out)
     P.ring_cap = c->ring_capacity > 0 ? c->ring_capacity : 2 * P.G + 64;
     P.record_stride = (int)((sizeof(GameRecord) + sizeof(uint16_t) * (size_t)(P.max_plies + 2) + 15) & ~(size_t)15);
     if (P.planes_dtype < CZ_F32 || P.planes_dtype > CZ_U8) { delete s; return serr(CZ_ERR_ARG, "cz_search_create: planes_dtype"); }
-    s->bytes = layout(s, nullptr, true);
     hipError_t e = hipGetDevice(&s->device);
     if (e != hipSuccess) { delete s; return serr_hip("cz_search_create: hipGetDevice", e); }
-    e = hipMalloc(&s->slab, s->bytes);
+    // pool size: what the games can use at most, bounded by the memory that is free now (the caller's network and
+    // queue buffers come later: leave a fifth of it), never less than what the games keep
+    const long long floor_chunks = (long long)P.G * P.keep_chunks + 1;
+    long long want = c->pool_chunks > 0 ? c->pool_chunks : (long long)P.G * P.max_chunks;
+    if (c->pool_chunks <= 0) {
+        size_t free_b = 0, total_b = 0;
+        e = hipMemGetInfo(&free_b, &total_b);
+        if (e != hipSuccess) { delete s; return serr_hip("cz_search_create: hipMemGetInfo", e); }
+        P.n_chunks = 0;
+        const size_t fixed = layout(s, nullptr, true);             // (n_chunks = 0: the ring is added below, 4 B per chunk)
+        const long long avail = ((long long)(free_b / 5 * 4) - (long long)fixed) / (long long)(CHUNK_BYTES + 4);
+        if (want > avail) want = avail;
+    }
+    if (want < floor_chunks) want = floor_chunks;
+    if (want > 0x7fffff00ll) want = 0x7fffff00ll;
+    P.n_chunks = (int)want;
+    const size_t slab_bytes = layout(s, nullptr, true);
+    e = hipMalloc(&s->slab, slab_bytes);
     if (e != hipSuccess) { delete s; return serr_hip("cz_search_create: hipMalloc", e); }
-    e = hipMemset(s->slab, 0, s->bytes);
-    if (e != hipSuccess) { (void)hipFree(s->slab); delete s; return serr_hip("cz_search_create: hipMemset", e); }
+    e = hipMalloc(&s->pool, (size_t)P.n_chunks * CHUNK_BYTES + 4096);   // (+ slack: speculative reads past a record)
+    if (e != hipSuccess) { (void)hipFree(s->slab); delete s; return serr_hip("cz_search_create: hipMalloc (chunk pool)", e); }
+    s->bytes = slab_bytes + (size_t)P.n_chunks * CHUNK_BYTES;
+    e = hipMemset(s->slab, 0, slab_bytes);
+    if (e != hipSuccess) { (void)cz_search_destroy(s); return serr_hip("cz_search_create: hipMemset", e); }
     layout(s, (char*)s->slab, false);
-    e = hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming);
-    if (e != hipSuccess) { (void)cz_search_destroy(s); return serr_hip("cz_search_create: side stream", e); }
+    s->B.pool = (char*)s->pool;
+    const int rc = init_pool(s);
+    if (rc != CZ_OK) { (void)cz_search_destroy(s); return rc; }
     *out = s;
     return CZ_OK;
 }
@@ -1647,9 +1655,7 @@ int cz_search_create(const cz_search_cfg* c, cz_search** out)
 int cz_search_destroy(cz_search* s)
 {
     if (!s) return CZ_OK;
-    if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
-    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-    if (s->ev_done) (void)hipEventDestroy(s->ev_done);
+    (void)hipFree(s->pool);
     (void)hipFree(s->slab);
     delete s;
     return CZ_OK;
@@ -1660,9 +1666,51 @@ size_t cz_search_bytes(const cz_search* s) { return s ? s->bytes : 0; }
 int cz_search_info(const cz_search* s, int32_t* out)
 {
     if (!s || !out) return serr(CZ_ERR_ARG, "cz_search_info: null argument");
-    out[0] = s->P.G; out[1] = s->P.K; out[2] = s->P.sims; out[3] = s->P.node_cap; out[4] = s->P.edge_cap;
+    out[0] = s->P.G; out[1] = s->P.K; out[2] = s->P.sims; out[3] = s->P.n_chunks; out[4] = s->P.max_chunks;
     out[5] = s->P.hash_cap; out[6] = s->P.max_depth; out[7] = s->P.max_plies; out[8] = s->P.record_stride;
-    out[9] = s->P.ring_cap; out[10] = CT_COUNT; out[11] = s->P.in_planes;
+    out[9] = s->P.ring_cap; out[10] = CT_COUNT; out[11] = s->P.in_planes; out[12] = s->P.keep_chunks;
+    out[13] = MAX_NO_ACT; out[14] = 0; out[15] = 0;
+    return CZ_OK;
+}
+
+int cz_search_memory_info(cz_search* s, int64_t* host_out, void* stream)
+{
+    if (!s || !host_out) return serr(CZ_ERR_ARG, "cz_search_memory_info: null argument");
+    const size_t G = (size_t)s->P.G;
+    int32_t* nch = new (std::nothrow) int32_t[G];
+    uint32_t* top = new (std::nothrow) uint32_t[G];
+    int32_t* cnt = new (std::nothrow) int32_t[G];
+    unsigned int ht[2] = {0u, 0u};
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = (nch && top && cnt) ? hipSuccess : hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipMemcpyAsync(nch, s->B.g_nchunks, sizeof(int32_t) * G, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(top, s->B.g_heap_top, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(cnt, s->B.g_node_count, sizeof(int32_t) * G, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&ht[0], s->B.pool_head, sizeof(unsigned int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&ht[1], s->B.pool_tail, sizeof(unsigned int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) {
+        int64_t held = 0, held_max = 0, used = 0, used_max = 0, nodes = 0, nodes_max = 0;
+        for (size_t g = 0; g < G; ++g) {
+            held += nch[g];
+            if (nch[g] > held_max) held_max = nch[g];
+            const int64_t u = (int64_t)(top[g] >> CHUNK_SHIFT) * (int64_t)CHUNK_BYTES + (int64_t)(top[g] & (CHUNK_GRANULES - 1)) * 16;
+            used += u;
+            if (u > used_max) used_max = u;
+            nodes += cnt[g];
+            if (cnt[g] > nodes_max) nodes_max = cnt[g];
+        }
+        host_out[0] = s->P.n_chunks;                  // pool size (chunks of 1 MiB)
+        host_out[1] = (int64_t)(unsigned int)(ht[1] - ht[0]);     // free chunks
+        host_out[2] = held;                           // chunks owned by games
+        host_out[3] = held_max;                       // ... by the largest game
+        host_out[4] = used;                           // tree bytes in use (all games)
+        host_out[5] = used_max;                       // ... of the largest game
+        host_out[6] = nodes;
+        host_out[7] = nodes_max;
+    }
+    delete[] nch; delete[] top; delete[] cnt;
+    if (e != hipSuccess) return serr_hip("cz_search_memory_info", e);
     return CZ_OK;
 }
 
@@ -1675,12 +1723,12 @@ int cz_search_info(const cz_search* s, int32_t* out)
 int cz_search_start_selfplay(cz_search* s, uint64_t seed, uint32_t first_game_id, uint32_t game_id_stride, void* stream)
 {
     if (!s) return serr(CZ_ERR_ARG, "cz_search_start_selfplay: null handle");
-    join_side(s, (hipStream_t)stream);
     s->P.mode = MODE_SELFPLAY;
     s->P.seed = seed;
     s->P.game_id_stride = game_id_stride ? game_id_stride : (uint32_t)s->P.G;
     hipError_t e = hipMemsetAsync(s->B.ring_tail, 0, sizeof(unsigned int), (hipStream_t)stream);
     if (e != hipSuccess) return serr_hip("cz_search_start_selfplay", e);
+    hipLaunchKernelGGL(k_pool_commit, dim3(1), dim3(1), 0, (hipStream_t)stream, s->B);
     hipLaunchKernelGGL(k_start_selfplay, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, first_game_id);
     S_LAUNCH_CHECK("cz_search_start_selfplay");
     return CZ_OK;
@@ -1691,8 +1739,8 @@ int cz_search_set_roots(cz_search* s, const int8_t* boards, const int32_t* turns
                         const uint8_t* select_mask, const int8_t* prev_boards, const uint8_t* hist_kind, void* stream)
 {
     if (!s || !boards) return serr(CZ_ERR_ARG, "cz_search_set_roots: null argument");
-    join_side(s, (hipStream_t)stream);
     s->P.mode = MODE_EXTERNAL;
+    hipLaunchKernelGGL(k_pool_commit, dim3(1), dim3(1), 0, (hipStream_t)stream, s->B);
     hipLaunchKernelGGL(k_set_roots, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, boards, turns, no_act,
                        n_no_act, increase_temp, enable_resign, select_mask, prev_boards, hist_kind);
     S_LAUNCH_CHECK("cz_search_set_roots");
@@ -1704,29 +1752,12 @@ int cz_search_round(cz_search* s, const float* policy, const float* value, void*
     if (!s || !planes || !policy || !value) return serr(CZ_ERR_ARG, "cz_search_round: null argument");
     const dim3 grid(s->P.G), block(64);
     hipStream_t st = (hipStream_t)stream;
-    join_side(s, st);
     const bool noise = s->P.noise_eps != 0.0;
     if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B, SIM_BACKUP);
     const bool hist = s->P.in_planes == 28;
     if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP);
     else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP);
     hipLaunchKernelGGL(k_advance, grid, block, 0, st, s->P, s->B);
-    if (s->P.mode == MODE_SELFPLAY) {
-        // games whose next search needs a compaction sit this round out; k_compact readies them on the side stream,
-        // under the rest of the round and the network forward.  (While the caller captures a HIP graph the fork could
-        // not be joined inside the capture: run it in line.)
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(st, &cap);
-        if (cap != hipStreamCaptureStatusNone) {
-            hipLaunchKernelGGL(k_compact, grid, block, 0, st, s->P, s->B);
-        } else {
-            (void)hipEventRecord(s->ev_fork, st);
-            (void)hipStreamWaitEvent(s->side, s->ev_fork, 0);
-            hipLaunchKernelGGL(k_compact, grid, block, 0, s->side, s->P, s->B);
-            (void)hipEventRecord(s->ev_done, s->side);
-            s->side_pending = true;
-        }
-    }
     if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B, SIM_SELECT);
     if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT);
     else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT);
@@ -1737,8 +1768,7 @@ int cz_search_round(cz_search* s, const float* policy, const float* value, void*
 int cz_search_set_sims(cz_search* s, int simulation_num_per_move)
 {
     if (!s || simulation_num_per_move < 1) return serr(CZ_ERR_ARG, "cz_search_set_sims: bad argument");
-    if (simulation_num_per_move + 2 > s->P.node_cap)
-        return serr(CZ_ERR_ARG, "cz_search_set_sims: more simulations than the arena holds (node_capacity)");
+    // (a search longer than the chunks a game can own ends in counted overflow_sims, it is not refused here)
     s->P.sims = simulation_num_per_move;
     return CZ_OK;
 }
@@ -1746,7 +1776,7 @@ int cz_search_set_sims(cz_search* s, int simulation_num_per_move)
 int cz_search_reset_trees(cz_search* s, void* stream)
 {
     if (!s) return serr(CZ_ERR_ARG, "cz_search_reset_trees: null handle");
-    join_side(s, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_pool_commit, dim3(1), dim3(1), 0, (hipStream_t)stream, s->B);
     hipLaunchKernelGGL(k_reset_trees, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B);
     S_LAUNCH_CHECK("cz_search_reset_trees");
     return CZ_OK;
@@ -1755,7 +1785,6 @@ int cz_search_reset_trees(cz_search* s, void* stream)
 int cz_search_pending(cz_search* s, int* host_out, void* stream)
 {
     if (!s || !host_out) return serr(CZ_ERR_ARG, "cz_search_pending: null argument");
-    join_side(s, (hipStream_t)stream);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(s->B.pending, 0, sizeof(int32_t), st);
     if (e != hipSuccess) return serr_hip("cz_search_pending", e);
@@ -1773,7 +1802,6 @@ int cz_search_root_stats(cz_search* s, uint16_t* moves, int32_t* n, double* w, f
                          uint8_t* counts, void* stream)
 {
     if (!s) return serr(CZ_ERR_ARG, "cz_search_root_stats: null handle");
-    join_side(s, (hipStream_t)stream);
     hipLaunchKernelGGL(k_root_stats, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, (const uint16_t*)nullptr, 0,
                        moves, n, w, p, sum_n, counts);
     S_LAUNCH_CHECK("cz_search_root_stats");
@@ -1783,7 +1811,6 @@ int cz_search_root_stats(cz_search* s, uint16_t* moves, int32_t* n, double* w, f
 int cz_search_stop(cz_search* s, void* stream)
 {
     if (!s) return serr(CZ_ERR_ARG, "cz_search_stop: null handle");
-    join_side(s, (hipStream_t)stream);
     hipLaunchKernelGGL(k_stop, dim3((s->P.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->P, s->B);
     S_LAUNCH_CHECK("cz_search_stop");
     return CZ_OK;
@@ -1793,7 +1820,6 @@ int cz_search_node_stats(cz_search* s, const uint16_t* path, int path_len, uint1
                          float* p, int32_t* sum_n, uint8_t* counts, void* stream)
 {
     if (!s || path_len < 0 || (path_len > 0 && !path)) return serr(CZ_ERR_ARG, "cz_search_node_stats: bad argument");
-    join_side(s, (hipStream_t)stream);
     hipLaunchKernelGGL(k_root_stats, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, path, path_len, moves, n, w,
                        p, sum_n, counts);
     S_LAUNCH_CHECK("cz_search_node_stats");
@@ -1803,7 +1829,6 @@ int cz_search_node_stats(cz_search* s, const uint16_t* path, int path_len, uint1
 int cz_search_choose(cz_search* s, const double* u, int32_t* action, void* stream)
 {
     if (!s || !action) return serr(CZ_ERR_ARG, "cz_search_choose: null argument");
-    join_side(s, (hipStream_t)stream);
     hipLaunchKernelGGL(k_choose, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, u, action);
     S_LAUNCH_CHECK("cz_search_choose");
     return CZ_OK;
@@ -1812,7 +1837,6 @@ int cz_search_choose(cz_search* s, const double* u, int32_t* action, void* strea
 int cz_search_counters(cz_search* s, uint64_t* host_out, void* stream)
 {
     if (!s || !host_out) return serr(CZ_ERR_ARG, "cz_search_counters: null argument");
-    join_side(s, (hipStream_t)stream);
     const size_t n = (size_t)s->P.G * CT_COUNT;
     unsigned long long* tmp = new (std::nothrow) unsigned long long[n];
     if (!tmp) return serr(CZ_ERR_NOMEM, "cz_search_counters: host allocation failed");
@@ -1834,7 +1858,6 @@ int cz_search_counters(cz_search* s, uint64_t* host_out, void* stream)
 int cz_search_drain_records(cz_search* s, unsigned int* cursor, void* host_buf, int max_records, int* n_out, void* stream)
 {
     if (!s || !cursor || !host_buf || !n_out) return serr(CZ_ERR_ARG, "cz_search_drain_records: null argument");
-    join_side(s, (hipStream_t)stream);
     hipStream_t st = (hipStream_t)stream;
     unsigned int tail = 0;
     hipError_t e = hipMemcpyAsync(&tail, s->B.ring_tail, sizeof(tail), hipMemcpyDeviceToHost, st);
@@ -1854,6 +1877,16 @@ int cz_search_drain_records(cz_search* s, unsigned int* cursor, void* host_buf, 
     if (e != hipSuccess) return serr_hip("cz_search_drain_records", e);
     *cursor = cur;
     *n_out = n;
+    return CZ_OK;
+}
+
+int cz_debug_noise(uint64_t seed, uint32_t game_key, double alpha, int n_moves, double* out, int n, void* stream)
+{
+    if (n <= 0) return CZ_OK;
+    if (!out || n_moves < 1 || n_moves > MAXMOVES || !(alpha > 0.0)) return serr(CZ_ERR_ARG, "cz_debug_noise: bad argument");
+    hipLaunchKernelGGL(k_debug_noise, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed, game_key, (float)alpha,
+                       n_moves, out, n);
+    S_LAUNCH_CHECK("cz_debug_noise");
     return CZ_OK;
 }
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CZ_VERSION 1
+#define CZ_VERSION 2
 
 #define CZ_OK 0
 #define CZ_ERR_ARG (-1)
@@ -102,8 +102,10 @@ typedef struct cz_search_cfg {
     int32_t sims_per_round;          /* K: config.play.search_threads (lock-step batch per game) */
     int32_t simulation_num_per_move; /* config.play.simulation_num_per_move */
     int32_t virtual_loss;            /* config.play.virtual_loss */
-    int32_t node_capacity;           /* per game; 0 = 4 * sims + 64.  the tree is dropped when a ply may not fit */
-    int32_t edge_capacity;           /* per game; 0 = 56 * node_capacity */
+    int32_t max_nodes_per_game;      /* sizes a game's hash table and chunk table; 0 = (2 * max_game_length + 4) * sims,
+                                        i.e. the tree of the longest game is kept whole (self_play.py:84,98-100) */
+    int32_t pool_chunks;             /* tree memory shared by all games, in chunks of 1 MiB; 0 = what the games can use,
+                                        at most 80 % of the device memory that is free at creation */
     int32_t max_depth;               /* longest path of one simulation; 0 = 64, at most 128 */
     int32_t max_game_length;         /* config.play.max_game_length (full moves) */
     int32_t planes_dtype;            /* CZ_F32 / CZ_F16 / CZ_BF16 / CZ_U8 */
@@ -127,16 +129,22 @@ typedef struct cz_game_record {
 int cz_search_create(const cz_search_cfg* cfg, cz_search** out);   /* allocates device memory on the current device */
 int cz_search_destroy(cz_search* s);
 size_t cz_search_bytes(const cz_search* s);
-/* out[12]: G, K, sims, node_cap, edge_cap, hash_cap, max_depth, max_plies, record_stride, ring_cap, n_counters,
- * input planes (14 / 28) */
+/* out[16]: G, K, sims, pool chunks, chunk-table entries per game, hash_cap, max_depth, max_plies, record_stride,
+ * ring_cap, n_counters, input planes (14 / 28), chunks a game always keeps, longest no_act list, 0, 0 */
 int cz_search_info(const cz_search* s, int32_t* out);
+/* HOST out[8]: pool chunks, free chunks, chunks owned by games, ... by the largest game, tree bytes in use, ... of the
+ * largest game, nodes in all trees, ... in the largest tree; synchronises the stream.
+ * Tree memory: a game's tree is kept for the whole game (the reference's behaviour) in 1 MiB chunks taken from a pool
+ * shared by all games; only when a ply cannot be reserved (pool empty) is that game's tree dropped -- counter
+ * tree_resets; simulations that still find no room end with value 0 -- counter overflow_sims. */
+int cz_search_memory_info(cz_search* s, int64_t* host_out, void* stream);
 
 /* self-play mode: every slot plays games from INIT_STATE forever; slot g starts with game id
  * first_game_id + g and continues with + game_id_stride after each finished game (0 = n_games). */
 int cz_search_start_selfplay(cz_search* s, uint64_t seed, uint32_t first_game_id, uint32_t game_id_stride, void* stream);
 
 /* external mode (CChessPlayer.action): set the position to search for each game.  boards [G][90];
- * turns [G] or NULL; no_act [G][16] + n_no_act [G] or NULL; increase_temp / enable_resign [G] or NULL;
+ * turns [G] or NULL; no_act [G][32] + n_no_act [G] or NULL (at most 32 banned moves per game); increase_temp / enable_resign [G] or NULL;
  * select_mask [G] or NULL (only games with a non-zero byte are touched).  Trees are kept (subtree reuse).
  * use_history only: hist_kind [G] or NULL = the `hist` argument of action(): 0 none, 1 prev_boards[g] ([G][90]) is
  * the game position two plies before the root, 2 a history shorter than 5 entries was passed. */
@@ -239,6 +247,10 @@ int cz_split_bias_act(const float* x, const float* bias, void* y_hi, void* y_lo,
 int cz_head_convs(const void* x, int dtype, const float* w, const float* bias, float* policy_feat, float* value_feat,
                   int n_boards, int channels, int n_policy, int n_value, void* stream);
 
+/* test hook: out[n] (DEVICE, float64) = n draws of the root noise np.random.dirichlet(alpha * ones(n_moves))[0]
+ * (agent/player.py:304) from the generator the search kernel uses (k_noise: Philox4x32-10 stream keyed by seed /
+ * game_key, float32 Marsaglia-Tsang Gamma draws) */
+int cz_debug_noise(uint64_t seed, uint32_t game_key, double alpha, int n_moves, double* out, int n, void* stream);
 /* test hook: y[i] = sqrt((double)(x[i] + 1)) exactly as the PUCT kernel computes it */
 int cz_debug_sqrt(const int32_t* x, double* y, int n, void* stream);
 

@@ -375,8 +375,10 @@ static void run_batch(xqo_player *p, int n)
     free(planes); free(policy); free(value); free(leaf_sim); free(prevs);
 }
 
-/* ---- arena model (engine behaviour, not in the reference): keep what is reachable from the root ---- */
-static void tree_clear(xqo_player *p)
+/* ---- the one engine behaviour that is not in the reference: a game whose tree no longer fits the engine's chunk
+ * pool starts over with an empty tree (counter tree_resets there).  Tests replay it by calling this at the plies
+ * where the engine reported a reset. ---- */
+void xqo_player_clear_tree(xqo_player *p)
 {
     size_t i;
     for (i = 0; i < p->nbuckets; i++) {
@@ -386,36 +388,6 @@ static void tree_clear(xqo_player *p)
     }
     p->n_nodes = 0;
     p->n_edges = 0;
-}
-
-static void mark_reachable(xqo_player *p, Node *node)
-{
-    int i;
-    node->spread |= 2;                                   /* bit 1 = reachable mark */
-    for (i = 0; i < node->n_moves; i++) {
-        int8_t nb[90];
-        Node *c;
-        if (node->n[i] <= 0) continue;                   /* edge never traversed: no child link */
-        xqo_step(node->board, node->moves[i], nb, 0);
-        c = tree_find(p, nb);                            /* terminal children are not nodes */
-        if (c && !(c->spread & 2)) mark_reachable(p, c);
-    }
-}
-
-static void tree_compact(xqo_player *p, Node *root)
-{
-    size_t i;
-    mark_reachable(p, root);
-    p->n_nodes = 0;
-    p->n_edges = 0;
-    for (i = 0; i < p->nbuckets; i++) {
-        Node **pp = &p->buckets[i];
-        while (*pp) {
-            Node *n = *pp;
-            if (n->spread & 2) { n->spread &= 1; p->n_nodes++; p->n_edges += n->n_moves; pp = &n->next; }
-            else { *pp = n->next; node_free(n); }
-        }
-    }
 }
 
 /* ---- calc_policy: player.py:375-406 ------------------------------------------ */
@@ -455,15 +427,6 @@ int xqo_player_search(xqo_player *p, const int8_t board[90], int turns, const ui
     if (n_no_act > 0 || increase_temp || done_n == sims) done_n = 0;      /* :156-158 */
     num_task = sims - done_n;
     if (num_task < 0) num_task = 0;
-    if (p->cfg.node_capacity > 0 && num_task > 0) {
-        const long ecap = p->cfg.edge_capacity > 0 ? p->cfg.edge_capacity : 64L * p->cfg.node_capacity;
-#define NO_ROOM() (p->n_nodes + num_task + 1 > p->cfg.node_capacity || p->n_edges + (long)(num_task + 1) * 80 > ecap)
-        if (NO_ROOM()) {
-            if (root) { tree_compact(p, root); p->ctr.tree_compactions++; }
-            if (!root || NO_ROOM()) { tree_clear(p); p->ctr.tree_resets++; num_task = sims; }
-        }
-#undef NO_ROOM
-    }
     if (num_task > 0) {
         int all = num_task, batch = all / K + (all % K != 0), it;
         for (it = 0; it < batch; it++) {

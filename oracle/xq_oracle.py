@@ -242,14 +242,13 @@ class PlayCfg(C.Structure):
                 ("noise_eps", C.c_double), ("dirichlet_alpha", C.c_double), ("tau_decay_rate", C.c_double),
                 ("virtual_loss", C.c_int), ("resign_threshold", C.c_double), ("min_resign_turn", C.c_int),
                 ("evaluate", C.c_int), ("max_game_length", C.c_int), ("enable_resign_rate", C.c_double),
-                ("node_capacity", C.c_int), ("edge_capacity", C.c_int), ("use_history", C.c_int)]
+                ("use_history", C.c_int)]
 
 
 class Counters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("sims", "expansions", "terminal_sims", "repetition_sims", "parked",
                                           "nn_batches", "nn_positions", "max_depth", "sum_depth",
-                                          "sum_edges_visited", "sum_leaf_moves", "tree_compactions",
-                                          "tree_resets")]
+                                          "sum_edges_visited", "sum_leaf_moves")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -262,10 +261,10 @@ RNG_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int, C.c_uint64)
 
 def play_cfg(simulation_num_per_move=100, search_threads=1, c_puct=1.5, noise_eps=0.0, dirichlet_alpha=0.2,
              tau_decay_rate=0.0, virtual_loss=3, resign_threshold=-0.92, min_resign_turn=20, evaluate=0,
-             max_game_length=100, enable_resign_rate=1.0, node_capacity=0, edge_capacity=0, use_history=0):
+             max_game_length=100, enable_resign_rate=1.0, use_history=0):
     return PlayCfg(simulation_num_per_move, search_threads, c_puct, noise_eps, dirichlet_alpha, tau_decay_rate,
                    virtual_loss, resign_threshold, min_resign_turn, evaluate, max_game_length, enable_resign_rate,
-                   node_capacity, edge_capacity, use_history)
+                   use_history)
 
 
 _mcts_sig_done = False
@@ -282,6 +281,7 @@ def _mcts_lib():
         L.xqo_player_destroy.argtypes = [C.c_void_p]
         L.xqo_player_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
         L.xqo_player_tree_size.argtypes = [C.c_void_p]; L.xqo_player_tree_size.restype = C.c_int
+        L.xqo_player_clear_tree.argtypes = [C.c_void_p]; L.xqo_player_clear_tree.restype = None
         L.xqo_player_search.argtypes = [C.c_void_p, i8p, C.c_int, u16p, C.c_int, C.c_int, dp]
         L.xqo_player_search.restype = C.c_int
         L.xqo_player_set_history.argtypes = [C.c_void_p, C.c_int, i8p]
@@ -406,6 +406,10 @@ class Player:
 
     def tree_size(self):
         return self.L.xqo_player_tree_size(self.h)
+
+    def clear_tree(self):
+        """Forget the tree: replays the engine's pool-exhausted fallback (counter tree_resets)."""
+        self.L.xqo_player_clear_tree(self.h)
 
 
 def sample_action(cfg, policy, turns, increase_temp, u):

@@ -162,37 +162,51 @@ def gen_mcts():
         json.dump({"meta": meta(), "cases": out, "lines": lines, "hist_cases": hist_cases}, f, separators=(",", ":"))
 
 
-def gen_mcts_1k():
-    """north_star: "visit-count outputs bit-identical to the reference on a fixed 1k-position suite": one K = 1
-    search of 48 simulations from every non-terminal position of positions_1k.json (hash stub, salt 101)."""
+def _mcts_1k_chunk(args):
+    """worker process: one K = 1 search per position of the chunk"""
+    idx, states, sims, salt = args
     np.random.dirichlet = lambda alpha, size=None: np.full(len(alpha), 1.0 / len(alpha))
+    cfg = make_cfg(sims)
+    out = []
+    for state in states:
+        pipe = stub_net.StubPipe(stub_fn(dict(kind="hash", salt=salt)))
+        pl = ref_player.CChessPlayer(cfg, search_tree=None, pipes=pipe, enable_resign=False)
+        action, _ = pl.action(state, 0)
+        node = pl.tree[state]
+        n = [int(node.a[m].n) if m in node.a else 0 for m in node.legal_moves]
+        w = np.array([float(node.a[m].w) if m in node.a else 0.0 for m in node.legal_moves], dtype=np.float64)
+        out.append({"crc": visit_crc(node.legal_moves, n), "w_crc": zlib.crc32(w.tobytes()) & 0xFFFFFFFF,
+                    "sum_n": int(node.sum_n), "action": action, "evals": pipe.n_positions,
+                    "tree_size": len(pl.tree)})
+        pl.close()
+    print("mcts_1k chunk", idx, "done", flush=True)
+    return idx, out
+
+
+def gen_mcts_1k(sims=800, procs=7):
+    """north_star: "visit-count outputs bit-identical to the reference on a fixed 1k-position suite" at "800
+    sims/move": one K = 1 search of 800 simulations from every non-terminal position of positions_1k.json that was
+    taken from real play (hash stub, salt 101), run by the reference's own CChessPlayer.  ~5 s per search: the
+    positions are spread over `procs` worker processes (the searches are independent)."""
+    import multiprocessing as mp
     with open(os.path.join(HERE, "positions_1k.json")) as f:
         suite = json.load(f)
     # the 960 positions taken from real (random) play; the hand-made special positions are left out: some of them
     # lead to a node whose mover has no move at all, where the reference's search thread dies and action() hangs
     positions = suite["positions"][:suite["n_random"]]
-    sims, salt = 48, 101
-    cfg = make_cfg(sims)
-    out = []
-    for i, r in enumerate(positions):
-        if r["done"][0] or not r["moves"]:           # terminal, or no move at all (the reference player dead-locks)
-            out.append(None)
-            continue
-        pipe = stub_net.StubPipe(stub_fn(dict(kind="hash", salt=salt)))
-        pl = ref_player.CChessPlayer(cfg, search_tree=None, pipes=pipe, enable_resign=False)
-        action, _ = pl.action(r["state"], 0)
-        node = pl.tree[r["state"]]
-        n = [int(node.a[m].n) if m in node.a else 0 for m in node.legal_moves]
-        w = np.array([float(node.a[m].w) if m in node.a else 0.0 for m in node.legal_moves], dtype=np.float64)
-        out.append({"crc": visit_crc(node.legal_moves, n), "w_crc": zlib.crc32(w.tobytes()) & 0xFFFFFFFF,
-                    "sum_n": int(node.sum_n), "action": action, "evals": pipe.n_positions})
-        pl.close()
-        if i % 100 == 0:
-            print("mcts_1k", i, flush=True)
+    salt = 101
+    todo = [i for i, r in enumerate(positions) if not (r["done"][0] or not r["moves"])]
+    chunks = [todo[i:i + 8] for i in range(0, len(todo), 8)]
+    jobs = [(k, [positions[i]["state"] for i in ch], sims, salt) for k, ch in enumerate(chunks)]
+    out = [None] * len(positions)          # terminal / no move at all (the reference player dead-locks): null
+    with mp.get_context("fork").Pool(procs) as pool:
+        for k, res in pool.imap_unordered(_mcts_1k_chunk, jobs):
+            for i, r in zip(chunks[k], res):
+                out[i] = r
     with open(os.path.join(HERE, "mcts_1k.json"), "w") as f:
         json.dump({"meta": meta(), "sims": sims, "stub": dict(kind="hash", salt=salt), "results": out}, f,
                   separators=(",", ":"))
-    print("mcts_1k.json:", sum(1 for x in out if x), "searches")
+    print("mcts_1k.json:", sum(1 for x in out if x), "searches of", sims, "simulations")
 
 
 def _shim_tf():
@@ -292,11 +306,109 @@ def gen_games():
         json.dump({"meta": meta(), "games": games}, f, separators=(",", ":"))
 
 
+def _arena_game(ev, s):
+    cfg = make_cfg(s["sims"], c_puct=s.get("c_puct", 1.0), tau_decay_rate=0.0,
+                   max_game_length=s["max_game_length"])
+    cfg.opts.evaluate = bool(s.get("evaluate", False))
+    seed, idx = s["seed"], s["idx"]
+    calls = {"choice": 0}
+    ply_log = []
+
+    def fake_choice(a, p=None, _c=calls):
+        u = stub_net.philox_uniform(seed, idx, 1, _c["choice"])
+        _c["choice"] += 1
+        return stub_net.numpy_choice(p, u)
+
+    class Playouts:                     # randint(8, 12) * 100 -> the simulations of this golden game
+        def __mul__(self, other, _n=s["sims"]):
+            return _n
+
+    np.random.choice = fake_choice
+    np.random.dirichlet = lambda alpha, size=None: np.full(len(alpha), 1.0 / len(alpha))
+    ev.randint = lambda a, b: Playouts()
+    orig_action = ref_player.CChessPlayer.action
+
+    def logged_action(self, state, turns, no_act=None, depth=None, infinite=False, hist=None,
+                      increase_temp=False, _orig=orig_action, _log=ply_log):
+        r = _orig(self, state, turns, no_act, depth, infinite, hist, increase_temp)
+        node = self.tree[state]
+        n = [int(node.a[m].n) if m in node.a else 0 for m in node.legal_moves]
+        _log.append({"state": state, "action": r[0], "crc": visit_crc(node.legal_moves, n),
+                     "sum_n": int(node.sum_n), "no_act": None if no_act is None else list(no_act),
+                     "inc": bool(increase_temp), "tree": len(self.tree)})
+        return r
+
+    ref_player.CChessPlayer.action = logged_action
+    ev.CChessPlayer.action = logged_action
+    pipes = [stub_net.StubPipe(stub_fn(dict(kind="hash", salt=x))) for x in s["salts"]]
+    worker = ev.EvaluateWorker(cfg, [pipes[0]], [pipes[1]], pid=0)
+    # start_game always begins at senv.INIT_STATE (:170); endgame starts (where positions repeat and perpetual
+    # checks / chases occur within a short game) are fed in through that module attribute
+    init_saved = ev.senv.INIT_STATE
+    ev.senv.INIT_STATE = s.get("init_state", init_saved)
+    try:
+        value, turns = worker.start_game(idx)
+    finally:
+        ev.senv.INIT_STATE = init_saved
+        ref_player.CChessPlayer.action = orig_action
+        ev.CChessPlayer.action = orig_action
+    rec = dict(s)
+    rec.update({"value": value, "turns": turns, "plies": ply_log,
+                "nn_positions": [pp.n_positions for pp in pipes], "n_choice_calls": calls["choice"]})
+    print(s["name"], "idx", idx, "turns", turns, "value", value, "evals", rec["nn_positions"],
+          "no_act plies", sum(1 for p in ply_log if p["no_act"]),
+          "inc plies", sum(1 for p in ply_log if p["inc"]), flush=True)
+    return rec
+
+
+def gen_arena():
+    """EvaluateWorker.start_game (worker/evaluator.py:147-250) recorded from the reference itself: two players with
+    their own trees and their own (stub) networks, colours by game index, the arena's own repetition handling
+    (before the move, no be_catched branch).  randint (the playout lottery, :153) is pinned per game; the move
+    sampling consumes the Philox stream (seed, idx, stream 1, ply) like the engine's arena."""
+    _shim_tf()
+    import cchess_alphazero.worker.evaluator as ev
+
+    specs = [
+        dict(name="even_a", idx=0, salts=(41, 42), sims=30, max_game_length=30, seed=2001),
+        dict(name="odd_a", idx=1, salts=(41, 42), sims=30, max_game_length=30, seed=2001),
+        dict(name="even_b", idx=2, salts=(43, 44), sims=50, max_game_length=20, seed=2002, c_puct=1.5),
+        dict(name="odd_b", idx=3, salts=(43, 44), sims=50, max_game_length=20, seed=2002, c_puct=1.5),
+        # shallow deterministic play: positions repeat -> no_act / increase_temp / idle-loop draw before the move
+        dict(name="repeat_a", idx=4, salts=(45, 46), sims=8, max_game_length=60, seed=2003),
+        dict(name="repeat_b", idx=5, salts=(47, 48), sims=10, max_game_length=60, seed=2004),
+        dict(name="repeat_c", idx=6, salts=(49, 50), sims=12, max_game_length=60, seed=2005, c_puct=0.5),
+        dict(name="repeat_d", idx=7, salts=(51, 52), sims=6, max_game_length=80, seed=2006),
+        # near-random play: king captures (final_move), early endings
+        dict(name="blunder_a", idx=8, salts=(53, 54), sims=4, max_game_length=80, seed=2007),
+        dict(name="blunder_b", idx=9, salts=(55, 56), sims=5, max_game_length=80, seed=2008),
+        # endgame starts: repeated positions before the move -> increase_temp (tau 0.5 sampling), the idle-loop draw
+        # after three free repetitions, and a banned move (no_act) from a perpetual check
+        dict(name="end_inc", idx=1, salts=(63, 163), sims=8, max_game_length=40, seed=3063,
+             init_state='3s5/4m4/9/9/4p4/2R6/9/4C4/4M4/3MS4'),
+        dict(name="end_idle_draw", idx=1, salts=(63, 163), sims=16, max_game_length=40, seed=3063,
+             init_state='3s5/4m4/9/9/4p4/2R6/9/4C4/4M4/3MS4'),
+        dict(name="end_no_act", idx=1, salts=(65, 165), sims=16, max_game_length=40, seed=3065,
+             init_state='4s4/9/9/9/9/9/9/9/3R5/3S1R3'),
+        dict(name="end_inc_even", idx=0, salts=(66, 166), sims=8, max_game_length=40, seed=3066,
+             init_state='3s5/4m4/9/9/4p4/2R6/9/4C4/4M4/3MS4'),
+        # config.opts.evaluate = True (compute_elo.py:88): argmax even on repeated positions
+        dict(name="elo_end_inc", idx=1, salts=(63, 163), sims=8, max_game_length=40, seed=3063, evaluate=True,
+             init_state='3s5/4m4/9/9/4p4/2R6/9/4C4/4M4/3MS4'),
+        dict(name="elo_odd", idx=11, salts=(57, 58), sims=20, max_game_length=40, seed=2010, evaluate=True),
+    ]
+    games = [_arena_game(ev, s) for s in specs]
+    with open(os.path.join(HERE, "arena_k1.json"), "w") as f:
+        json.dump({"meta": meta(), "games": games}, f, separators=(",", ":"))
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("mcts", "all"):
         gen_mcts()
     if what in ("games", "all"):
         gen_games()
+    if what in ("arena", "all"):
+        gen_arena()
     if what in ("mcts1k", "all"):
-        gen_mcts_1k()
+        gen_mcts_1k(sims=int(sys.argv[2]) if len(sys.argv) > 2 else 800)

@@ -114,67 +114,46 @@ def test_record_decoder_matches_oracle_replay(tmp_path, monkeypatch):
         expand_records([[xo.INIT_STATE, ['4445', 1]]])
 
 
-def _oracle_arena_game(idx, pc, specs, u_fn):
-    """EvaluateWorker.start_game (reference worker/evaluator.py:147-250) with two oracle players."""
-    def ocfg():
-        return xo.play_cfg(simulation_num_per_move=pc.simulation_num_per_move, search_threads=pc.search_threads,
-                           c_puct=pc.c_puct, noise_eps=0.0, dirichlet_alpha=pc.dirichlet_alpha,
-                           tau_decay_rate=pc.tau_decay_rate, virtual_loss=pc.virtual_loss, evaluate=1,
-                           max_game_length=pc.max_game_length)
-    p1, p2 = xo.Player(ocfg(), specs[0]), xo.Player(ocfg(), specs[1])
-    red, black = (p1, p2) if idx % 2 == 0 else (p2, p1)
-    state, history = xo.INIT_STATE, [xo.INIT_STATE]
-    value = turns = no_eat_count = 0
-    game_over = check = False
-    final_move = None
-    while not game_over:
-        no_act, increase_temp = None, False
-        if not check and state in history[:-1]:
-            no_act, increase_temp, free = [], True, 0
-            for i in range(len(history) - 1):
-                if history[i] == state:
-                    if xo.will_check_or_catch(state, history[i + 1]):
-                        no_act.append(history[i + 1])
-                    else:
-                        free += 1
-                        if free >= 3:
-                            game_over, value = True, 0
-                            break
-        if game_over:
-            break
-        pl = red if turns % 2 == 0 else black
-        action, _ = pl.action(state, turns, no_act, increase_temp, u_fn(idx, turns))
-        if action is None:
-            value = -1
-            break
-        history.append(action)
-        state, no_eat = xo.new_step(state, action)
-        turns += 1
-        no_eat_count = no_eat_count + 1 if no_eat else 0
-        history.append(state)
-        if no_eat_count >= 120 or turns / 2 >= pc.max_game_length:
-            game_over, value = True, 0
-        else:
-            game_over, value, final_move, check = xo.done(state, need_check=True)
-            if not game_over and not xo.has_attack_chessman(state):
-                game_over, value = True, 0
-    if final_move:
-        turns += 1
-        value = -value
-    if turns % 2 == 1:
-        value = -value
-    p1.close()
-    p2.close()
-    return value, turns
+def _arena_cfg(tmp_path, monkeypatch, gm, K=1):
+    cfg = _cfg(tmp_path, monkeypatch, simulation_num_per_move=gm["sims"], search_threads=K, noise_eps=0.0,
+               tau_decay_rate=0.0, c_puct=gm.get("c_puct", 1.0), max_game_length=gm["max_game_length"])
+    cfg.opts.evaluate = bool(gm.get("evaluate", False))
+    return cfg
 
 
-@pytest.mark.parametrize("K,sims,tau", [(1, 10, 0.0), (4, 24, 0.9)])
+def test_evaluator_arena_reproduces_reference_games(tmp_path, monkeypatch):
+    """EvaluateWorker.play_games against games recorded from the REFERENCE's own
+    EvaluateWorker.start_game (tests/golden/arena_k1.json; generator make_golden_mcts.py arena): result, length and,
+    ply by ply, the position searched, the move, the root visit counts, the banned moves and the temperature flag."""
+    from arena_oracle import visit_crc
+    from cchess_alphazero.worker.evaluator import EvaluateWorker
+    with open(os.path.join(GOLDEN, "arena_k1.json")) as f:
+        games = json.load(f)["games"]
+    for gm in games:
+        cfg = _arena_cfg(tmp_path, monkeypatch, gm)
+        evs = tuple((lambda planes, s=x: stub_net.hash_stub_torch(planes, s)) for x in gm["salts"])
+        w = EvaluateWorker(cfg, evaluators=evs, seed=5)
+        trace = {}
+        got = w.play_games(1, u_fn=lambda g, turns, _s=gm["seed"]: stub_net.philox_uniform(_s, g, 1, turns),
+                           indices=[gm["idx"]], init_state=gm.get("init_state"), trace=trace)
+        assert got == [(gm["value"], gm["turns"])], gm["name"]
+        tr = trace[gm["idx"]]
+        assert len(tr) == len(gm["plies"]), gm["name"]
+        for t, r in zip(tr, gm["plies"]):
+            assert t["state"] == r["state"] and t["action"] == r["action"], (gm["name"], t, r)
+            assert visit_crc(t["moves"], t["n"]) == r["crc"] and t["sum_n"] == r["sum_n"], gm["name"]
+            assert t["no_act"] == r["no_act"] and t["inc"] == r["inc"], gm["name"]
+
+
+@pytest.mark.parametrize("K,sims,tau", [(4, 24, 0.9), (8, 40, 0.0)])
 def test_evaluator_arena_matches_oracle(tmp_path, monkeypatch, K, sims, tau):
-    """Two models, two trees per game, colours alternating by game index (BASELINE config 4)."""
+    """Two models, two trees per game, colours alternating by game index, all games concurrent, K > 1: against the
+    arena loop over two oracle players (tests/arena_oracle.py, itself pinned to the reference's games at K = 1)."""
+    from arena_oracle import arena_game
     from cchess_alphazero.worker.evaluator import EvaluateWorker, score_table
     cfg = _cfg(tmp_path, monkeypatch, simulation_num_per_move=sims, search_threads=K, noise_eps=0.0,
                tau_decay_rate=tau, c_puct=1.0, max_game_length=14)
-    cfg.opts.evaluate = True
+    cfg.opts.evaluate = False
     specs = (dict(kind="hash", salt=41), dict(kind="hash", salt=42))
     evs = tuple((lambda planes, s=s: stub_net.hash_stub_torch(planes, s["salt"])) for s in specs)
 
@@ -183,7 +162,7 @@ def test_evaluator_arena_matches_oracle(tmp_path, monkeypatch, K, sims, tau):
     n = 10
     w = EvaluateWorker(cfg, evaluators=evs, seed=5)
     got = w.play_games(n, u_fn=u_fn)
-    exp = [_oracle_arena_game(i, cfg.play, specs, u_fn) for i in range(n)]
+    exp = [arena_game(i, cfg.play, specs, u_fn)[:2] for i in range(n)]
     assert got == exp
     table = score_table(got)
     assert sum(table[1:]) == n and 0 <= table[0] <= n

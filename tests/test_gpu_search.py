@@ -37,8 +37,8 @@ def play_config(**kw):
     return types.SimpleNamespace(**d)
 
 
-def oracle_cfg(pc, evaluate=0, node_capacity=0, use_history=0):
-    return xo.play_cfg(node_capacity=node_capacity, use_history=use_history, simulation_num_per_move=pc.simulation_num_per_move, search_threads=pc.search_threads,
+def oracle_cfg(pc, evaluate=0, use_history=0):
+    return xo.play_cfg(use_history=use_history, simulation_num_per_move=pc.simulation_num_per_move, search_threads=pc.search_threads,
                        c_puct=pc.c_puct, noise_eps=pc.noise_eps, dirichlet_alpha=pc.dirichlet_alpha,
                        tau_decay_rate=pc.tau_decay_rate, virtual_loss=pc.virtual_loss,
                        resign_threshold=pc.resign_threshold, min_resign_turn=pc.min_resign_turn, evaluate=evaluate,
@@ -63,7 +63,7 @@ def boards_tensor(gpu, states):
 
 def no_act_tensors(gpu, lists):
     G = len(lists)
-    na = np.full((G, 16), 0xFFFF, dtype=np.uint16)
+    na = np.full((G, 32), 0xFFFF, dtype=np.uint16)
     nn = np.zeros(G, dtype=np.uint8)
     for g, l in enumerate(lists):
         for k, m in enumerate(l or []):
@@ -146,7 +146,7 @@ def test_multi_ply_reuse_matches_oracle(gpu):
     pc = play_config(simulation_num_per_move=80, search_threads=4)
     spec = dict(kind="hash", salt=11)
     G = 4
-    s = gpu.S.Search(pc, G, seed=1, node_capacity=4096)
+    s = gpu.S.Search(pc, G, seed=1)
     players = [xo.Player(oracle_cfg(pc), spec) for _ in range(G)]
     states = [xo.INIT_STATE, xo.step(xo.INIT_STATE, '7242'), MID, xo.INIT_STATE]
     t = gpu.torch
@@ -166,33 +166,81 @@ def test_multi_ply_reuse_matches_oracle(gpu):
     s.close()
 
 
-def test_compaction_keeps_the_reachable_subtree(gpu):
-    """A small arena forces compaction between plies (keep the sub-DAG reachable from the new root); the
-    oracle models the same arena, so visit counts, W and subtree reuse must stay identical."""
-    pc = play_config(simulation_num_per_move=100, search_threads=4)
-    spec = dict(kind="hash", salt=17)
-    G = 3
-    s = gpu.S.Search(pc, G, seed=1, node_capacity=260)
-    players = [xo.Player(oracle_cfg(pc, node_capacity=260), spec) for _ in range(G)]   # same arena model
-    states = [xo.INIT_STATE, MID, xo.step(xo.INIT_STATE, '7242')]
+def _play_with_resets(gpu, s, pc, spec, states, plies):
+    """Drive G external-mode games ply by ply against one oracle player each.  A game whose GPU result differs from the
+    oracle's is accepted only if it equals the oracle's search on an EMPTY tree (= the engine dropped that game's tree
+    before the search); returns the number of such resets."""
+    G = len(states)
+    players = [xo.Player(oracle_cfg(pc), spec) for _ in range(G)]
     t = gpu.torch
-    for ply in range(12):
+    resets = 0
+    for ply in range(plies):
         s.set_roots(boards_tensor(gpu, states), turns=t.full((G,), ply, dtype=t.int32, device="cuda"))
         s.run_until_idle(stub_eval(gpu, spec))
         st = s.root_stats()
         act = s.choose(None)
         for g in range(G):
             a, _ = players[g].action(states[g], ply, None, False, 0.5)
+            ref = players[g].node_stats(states[g])
+            c = int(st["counts"][g])
+            if not (np.array_equal(st["n"][g, :c], ref["n"]) and np.array_equal(st["w"][g, :c], ref["w"])):
+                players[g].clear_tree()
+                a, _ = players[g].action(states[g], ply, None, False, 0.5)
+                resets += 1
             assert_root_equal(st, g, players[g].node_stats(states[g]), f"ply {ply} game {g}")
             assert xo.label_str(int(act[g])) == a
             states[g] = xo.step(states[g], a)
-    c = s.counters()
-    oc = [p.counters() for p in players]
-    assert c["tree_compactions"] > 0 and c["overflow_sims"] == 0, c
-    assert c["tree_compactions"] == sum(o["tree_compactions"] for o in oc)
-    assert c["tree_resets"] == sum(o["tree_resets"] for o in oc)
     for p in players:
         p.close()
+    return resets
+
+
+def test_full_hash_table_drops_the_tree(gpu):
+    """The reference keeps a game's whole tree; the engine does too until a ply can no longer be reserved.  A tiny
+    max_nodes_per_game (= a tiny hash table) forces that: the game's tree is dropped (tree_resets) and the search of
+    that ply is exactly a search on an empty tree; every other ply reuses the subtree like the reference."""
+    pc = play_config(simulation_num_per_move=100, search_threads=4)
+    spec = dict(kind="hash", salt=17)
+    s = gpu.S.Search(pc, 3, seed=1, max_nodes_per_game=300)
+    assert s.hash_cap == 512
+    resets = _play_with_resets(gpu, s, pc, spec, [xo.INIT_STATE, MID, xo.step(xo.INIT_STATE, '7242')], 12)
+    c = s.counters()
+    assert c["tree_resets"] == resets and resets > 0 and c["overflow_sims"] == 0, (c, resets)
+    s.close()
+
+
+def test_exhausted_pool_drops_one_tree_and_returns_its_chunks(gpu):
+    """Two games share a pool with ONE spare chunk: the first game that outgrows its own chunks takes it, the next
+    reservation that finds the pool empty drops that game's tree (exactly: the search equals a search on an empty
+    tree) and the chunks it held beyond its base allotment go back to the pool."""
+    pc = play_config(simulation_num_per_move=800, search_threads=8)
+    spec = dict(kind="hash", salt=19)
+    s = gpu.S.Search(pc, 2, seed=1, pool_chunks=1)              # (raised to the floor: games x keep_chunks + 1)
+    assert s.pool_chunks == 2 * s.keep_chunks + 1
+    m0 = s.memory_info()
+    assert m0["free_chunks"] == 1 and m0["held_chunks"] == 2 * s.keep_chunks
+    resets = _play_with_resets(gpu, s, pc, spec, [xo.INIT_STATE, MID], 16)
+    c, m = s.counters(), s.memory_info()
+    assert c["tree_resets"] == resets and resets > 0 and c["overflow_sims"] == 0, (c, resets, m)
+    assert c["chunks_taken"] >= 1
+    assert m["free_chunks"] + m["held_chunks"] == m["pool_chunks"]          # no chunk lost or duplicated
+    s.reset_trees()
+    m = s.memory_info()
+    assert m["free_chunks"] == 1 and m["held_chunks"] == 2 * s.keep_chunks and m["nodes"] == 0
+    s.close()
+
+
+def test_whole_game_tree_is_kept(gpu):
+    """Production memory policy (self_play.py:84,98-100): with the default pool nothing is ever dropped -- a 40-ply
+    line keeps every node it expanded and each ply's visit counts equal the oracle's unbounded tree."""
+    pc = play_config(simulation_num_per_move=200, search_threads=8)
+    spec = dict(kind="hash", salt=23)
+    s = gpu.S.Search(pc, 2, seed=1)
+    resets = _play_with_resets(gpu, s, pc, spec, [xo.INIT_STATE, MID], 40)
+    c, m = s.counters(), s.memory_info()
+    assert resets == 0 and c["tree_resets"] == 0 and c["overflow_sims"] == 0
+    assert m["nodes"] == c["expansions"]                      # every expanded node is still in a tree
+    assert c["stat_blocks"] < c["expansions"]                 # most nodes stay leaves: no statistics block
     s.close()
 
 
@@ -222,7 +270,7 @@ def test_selfplay_games_match_oracle(gpu, K, tau):
                      enable_resign_rate=0.5, resign_threshold=-0.4, min_resign_turn=4)
     spec = dict(kind="hash", salt=31)
     G, seed = 12, 4242
-    recs, ctr = run_selfplay(gpu, pc, spec, G, seed, G, node_capacity=24 * 40)
+    recs, ctr = run_selfplay(gpu, pc, spec, G, seed, G)
     assert ctr["tree_resets"] == 0 and ctr["overflow_sims"] == 0
     for gid in range(G):
         ref = xo.selfplay_game(oracle_cfg(pc), spec, seed, gid)
@@ -266,7 +314,7 @@ def test_golden_reference_lines(gpu):
     t = gpu.torch
     for line in data["lines"]:
         pc = play_config(simulation_num_per_move=line["sims"], search_threads=1)
-        s = gpu.S.Search(pc, 1, seed=0, node_capacity=line["sims"] * (len(line["steps"]) + 2))
+        s = gpu.S.Search(pc, 1, seed=0)
         spec = dict(kind="hash", salt=line["salt"])
         prev = 0
         for turn, step in enumerate(line["steps"]):
@@ -292,7 +340,7 @@ def test_golden_reference_games(gpu):
                          resign_threshold=gm.get("resign_threshold", -0.92),
                          min_resign_turn=gm.get("min_resign_turn", 20))
         recs, ctr = run_selfplay(gpu, pc, dict(kind="hash", salt=gm["salt"]), 1, gm["seed"], 1,
-                                 node_capacity=gm["sims"] * (2 * gm["max_game_length"] + 4))
+                                 )
         got = recs[0]
         rec = gm["record"]
         if rec is not None:
@@ -372,7 +420,7 @@ def test_many_concurrent_games_match_oracle(gpu):
                      enable_resign_rate=0.5, resign_threshold=-0.3, min_resign_turn=6)
     spec = dict(kind="hash", salt=61)
     G, seed = 384, 2024
-    recs, ctr = run_selfplay(gpu, pc, spec, G, seed, G, node_capacity=20 * 30)
+    recs, ctr = run_selfplay(gpu, pc, spec, G, seed, G)
     assert ctr["overflow_sims"] == 0 and ctr["depth_overflow"] == 0
     bad = []
     for gid in range(G):

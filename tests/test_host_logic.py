@@ -23,7 +23,7 @@ def test_cabi_exports_every_declared_symbol():
     L = ctypes.CDLL(_native.LIB_PATH)
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/czero.h but not exported"
-    assert L.cz_version() == 1
+    assert L.cz_version() == 2
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -249,3 +249,21 @@ def test_bench_configs_follow_baseline():
     lib = bench.build_config(argparse.Namespace(config="normal", games=64, sims_per_round=4, dtype="bfloat16", trunk="library"))
     assert (lib.engine.games_per_gpu, lib.play.search_threads, lib.engine.net_dtype, lib.engine.net_trunk) == \
         (64, 4, "bfloat16", "library")
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run with N ranks (the
+    driver's own command shape) and reports n_gpus = the number of ranks that took part in the counter all-reduce;
+    a launcher that started a different number of ranks is refused.  --dry-run: gloo, no GPU work."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] == (1000 + 2000) / 0.6
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"],
+                         env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "--gpus 2" in (bad.stderr + bad.stdout)

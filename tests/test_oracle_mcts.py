@@ -140,6 +140,34 @@ def test_reference_games():
         assert r["counters"]["nn_positions"] == gm["nn_positions"]
 
 
+def test_reference_arena_games():
+    """the arena loop over two oracle players (tests/arena_oracle.py) reproduces the games recorded
+    from the reference's own EvaluateWorker.start_game (two trees, colours by game index, repetition handling before
+    the move, tau = 0.5 on repeated positions unless config.opts.evaluate, king-capture endings, idle-loop draws)."""
+    import types
+    from arena_oracle import arena_game
+    data = _golden("arena_k1.json")
+    assert len(data["games"]) >= 8
+    assert any(any(p["no_act"] for p in g["plies"]) for g in data["games"])          # a banned move
+    assert any(g["turns"] > len(g["plies"]) for g in data["games"])                  # a king capture (final_move)
+    for gm in data["games"]:
+        pc = types.SimpleNamespace(simulation_num_per_move=gm["sims"], search_threads=1, c_puct=gm.get("c_puct", 1.0),
+                                   dirichlet_alpha=0.2, tau_decay_rate=0.0, virtual_loss=3,
+                                   max_game_length=gm["max_game_length"])
+        specs = tuple(dict(kind="hash", salt=x) for x in gm["salts"])
+        trace = []
+        value, turns, evals = arena_game(gm["idx"], pc, specs,
+                                         lambda idx, ply, _s=gm["seed"]: stub_net.philox_uniform(_s, idx, 1, ply),
+                                         init_state=gm.get("init_state"), evaluate=gm.get("evaluate", False),
+                                         trace=trace)
+        assert (value, turns) == (gm["value"], gm["turns"]), gm["name"]
+        assert len(trace) == len(gm["plies"]), gm["name"]
+        for t, r in zip(trace, gm["plies"]):
+            assert (t["state"], t["action"], t["crc"], t["sum_n"]) == (r["state"], r["action"], r["crc"], r["sum_n"]), gm["name"]
+            assert t["no_act"] == r["no_act"] and t["inc"] == r["inc"], gm["name"]
+        assert evals == gm["nn_positions"], gm["name"]
+
+
 def test_sampling_matches_numpy_choice():
     rng = np.random.default_rng(5)
     cfg = xo.play_cfg(tau_decay_rate=0.98)

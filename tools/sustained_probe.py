@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sustained.json"))
     a = ap.parse_args()
     cfg = B.build_config(argparse.Namespace(config="normal", games=None, sims_per_round=None, dtype=None, trunk=None))
-    eng = SelfPlayEngine(cfg, cfg.engine.games_per_gpu, seed=20260923, node_capacity=a.node_capacity)
+    eng = SelfPlayEngine(cfg, cfg.engine.games_per_gpu, seed=20260923, max_nodes_per_game=a.node_capacity)
     eng.start()
     eng.prewarm()
     rows = []
