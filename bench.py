@@ -121,6 +121,14 @@ def cpu_baseline(cfg, seconds):
     import subprocess
     pc = cfg.play
     procs = len(os.sched_getaffinity(0))
+    quota = None
+    try:                                                     # a container may be allowed fewer CPUs than it can see
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "baseline_worker.py"), "--procs", str(procs),
            "--seconds", str(seconds), "--sims", str(pc.simulation_num_per_move), "--threads", str(pc.search_threads),
            "--c-puct", str(pc.c_puct), "--vl", str(pc.virtual_loss), "--max-game-length", str(pc.max_game_length)]
@@ -135,7 +143,7 @@ def cpu_baseline(cfg, seconds):
         pass
     return {"value": sum(per), "unit": "expansions/s", "cores": procs, "kind": "port",
             "per_process": {"median": statistics.median(per), "min": min(per), "max": max(per), "seeds": len(per)},
-            "sims_per_s": sum(sims), "cpu_model": cpu,
+            "sims_per_s": sum(sims), "cpu_model": cpu, "cgroup_cpu_quota": quota,
             "sample": f"oracle/xq_mcts.c + xq_rules.c (C port of player.py / static_env.py), {procs} processes x "
                       f"{seconds:.0f} s of self-play from INIT_STATE, {pc.simulation_num_per_move} sims/move, "
                       f"K={pc.search_threads}, hash-stub net (tree + rules only, no ResNet), one seed per process, "
@@ -337,9 +345,12 @@ def main():
     if n_sus is None:
         n_sus = 3000 if (world == 1 and args.config == "normal" and not args.graph) else 0
     sus = None
+    mem_timed = eng.search.memory_info()
     if n_sus > 0:
+        eng.drain(1 << 16)                                   # (records of the games that ended so far)
         sus = run_leg(n_sus, 10)
         log(f"sustained leg: {n_sus} rounds in {sus[0]:.1f}s")
+        sus_games = eng.drain(1 << 16)                       # rank 0's finished games of the leg (ring: 2 G + 64 records)
 
     if rank == 0:
         exp_per_launch = d["expansions"] / max(1, args.steps * world)
@@ -371,9 +382,9 @@ def main():
             "tree_shape": {"mean_depth": mean_d, "mean_edges": mean_c, "mean_leaf_moves": mean_l,
                            "terminal_sims": d["terminal_sims"], "repetition_sims": d["repetition_sims"],
                            "parked": d["parked"], "tree_resets": d["tree_resets"],
-                           "tree_compactions": d["chunks_taken", "stat_blocks"],
+                           "chunks_taken": d["chunks_taken"], "stat_blocks": d["stat_blocks"],
                            "overflow_sims": d["overflow_sims"], "depth_overflow": d["depth_overflow"]},
-            "tree_memory": eng.search.memory_info(),
+            "tree_memory": dict(mem_timed, when="after the timed steps", chunk_bytes=1 << 20),
             "roofline": None, "roofline_search": None, "roofline_nn": None, "cpu_baseline": None,
         }
         if k_ms is not None:
@@ -434,10 +445,17 @@ def main():
                     "games_per_hour_measured": sd["games"] / sdt * 3600.0,
                     "games_per_hour_steady_state": (sd["plies"] / sdt / mean_plies * 3600.0) if mean_plies else None,
                     "queue_utilisation": sd["expansions"] / max(1, n_sus * world * slots),
-                    "tree_resets": sd["tree_resets"], "tree_compactions": sd["chunks_taken", "stat_blocks"],
+                    "tree_resets": sd["tree_resets"], "chunks_taken": sd["chunks_taken"], "stat_blocks": sd["stat_blocks"],
                     "overflow_sims": sd["overflow_sims"], "depth_overflow": sd["depth_overflow"],
                     "mean_depth": sd["sum_depth"] / max(1, sd["sims"]),
-                    "search_round_ms": sk_ms, "tree_memory": eng.search.memory_info(),
+                    "search_round_ms": sk_ms,
+                    "tree_memory": dict(eng.search.memory_info(), when="end of the sustained leg", chunk_bytes=1 << 20),
+                    "finished_games_rank0": {"n": len(sus_games),
+                                             "mean_plies": (sum(g["turns"] for g in sus_games) / len(sus_games)) if sus_games else None,
+                                             "resigned": sum(bool(g["resigned"]) for g in sus_games),
+                                             "red_black_draw": [sum(g["value"] > 0 for g in sus_games),
+                                                                sum(g["value"] < 0 for g in sus_games),
+                                                                sum(g["value"] == 0 for g in sus_games)]},
                     "note": "games_per_hour_measured counts the games that FINISHED inside this leg (started from the "
                             "opening together, so early on only short games end); games_per_hour_steady_state = "
                             "measured plies/s / mean plies per game of the committed complete-games run"}

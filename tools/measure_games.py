@@ -50,7 +50,7 @@ def main():
     out = {"config": a.config, "games_requested": a.games, "first_games_finished": len(done), "seconds": dt,
            "rounds": rounds, "net_dtype": cfg.engine.net_dtype,
            "sims_per_move": cfg.play.simulation_num_per_move, "K": eng.search.K,
-           "counters": c,
+           "counters": c, "tree_memory": eng.search.memory_info(),
            "mean_plies_per_game": sum(plies) / max(1, len(plies)),
            "expansions_per_game": c["expansions"] / max(1, c["plies"]) * sum(plies) / max(1, len(plies)),
            "expansions_per_ply": c["expansions"] / max(1, c["plies"]),
