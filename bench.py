@@ -241,6 +241,68 @@ def pmc_nn(kernel):
             "source": os.path.relpath(files[-1], ROOT)}
 
 
+def run_arena(args, cfg):
+    """BASELINE configs[3]: the evaluator arena on the arena worker (worker/evaluator.py::EvaluateWorker.play_games):
+    BestModel vs NextGenerationModel (two random-init networks, seeds 0 / 1), 200 paired games played concurrently,
+    two trees per game, 400 simulations per move.  A "step" here is one PLY of the whole arena (every live game makes
+    one move: ~sims / K lock-step rounds for the best model's games and as many for the next-generation model's)."""
+    from cchess_alphazero import _native
+    from cchess_alphazero.agent.model import CChessNet, InferenceNet, flops_per_position
+    from cchess_alphazero.worker.evaluator import EvaluateWorker, score_table
+    dtype = getattr(torch, cfg.engine.net_dtype)
+    nets = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        raw = CChessNet.from_model_config(cfg.model)
+        model_cfg = raw.cfg
+        nets.append(InferenceNet(raw, dtype, trunk=cfg.engine.net_trunk).cuda())
+    G = cfg.engine.games_per_gpu
+    K = args.sims_per_round or 32
+    cfg.opts.evaluate = False                                  # like `run.py eval` of the reference (manager.py:94-103)
+    w = EvaluateWorker(cfg, evaluators=tuple((lambda planes, n=n: n(planes)) for n in nets), dtype=_native.U8, seed=20260923)
+    marks = {}
+
+    def on_ply(ply, counters_fn, rounds):
+        if ply in (args.warmup, args.warmup + args.steps):
+            torch.cuda.synchronize()
+            marks[ply] = (time.perf_counter(), counters_fn(), rounds)
+
+    t0 = time.perf_counter()
+    stats = {}
+    results = w.play_games(G, on_ply=on_ply, stats=stats, sims_per_round=K)
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    a, b = marks[args.warmup], marks.get(args.warmup + args.steps)
+    if b is None:
+        raise SystemExit("bench.py --config eval: the arena ended before warmup + steps plies")
+    dt = b[0] - a[0]
+    d = {k: b[1][k] - a[1][k] for k in a[1]}
+    rounds = b[2] - a[2]
+    table = score_table(results)
+    fl = flops_per_position(model_cfg)
+    out = {"metric": "mcts_node_expansions_per_sec", "value": d["expansions"] / dt, "unit": "expansions/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3-split/f32acc+f64/i32 tree", "data": "synthetic",
+           "config": {"workload": f"BASELINE configs[3] 'eval' ARENA (EvaluateWorker.play_games): {G} paired games "
+                                  f"played concurrently, BestModel vs NextGenerationModel = two random-init "
+                                  f"{cfg.model.res_layer_num}x{cfg.model.cnn_filter_num} nets (seeds 0 / 1), two trees "
+                                  f"per game, {cfg.play.simulation_num_per_move} sims/move, K={K} sims/round/game, "
+                                  f"noise_eps {cfg.play.noise_eps}, tau_decay_rate {cfg.play.tau_decay_rate}; "
+                                  f"a step = one ply of the whole arena",
+                      "games": G, "sims_per_round": K, "parallelism": "one GPU"},
+           "sims_per_s": d["sims"] / dt, "rounds_timed": rounds, "ms_per_round": dt / max(1, rounds) * 1e3,
+           "rows_per_forward": G // 2 * K,
+           "network_tflops": fl * d["expansions"] / dt / 1e12,
+           "arena": {"games": G, "plies": stats["plies"], "rounds": stats["rounds"], "seconds": total,
+                     "expansions": stats["expansions"], "expansions_per_s_whole_arena": stats["expansions"] / total,
+                     "games_per_hour": G / total * 3600.0, "tree_resets": stats["tree_resets"],
+                     "overflow_sims": stats["overflow_sims"], "tree_memory": stats["tree_memory"],
+                     "score_table": {"next_generation_score": table[0], "games": G,
+                                     "red_new_win_draw_fail": list(table[1:4]), "black_new_win_draw_fail": list(table[4:7])},
+                     "mean_plies_per_game": sum(t for _, t in results) / len(results)}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -264,6 +326,10 @@ def main():
 
     t_start = time.perf_counter()
     cfg = build_config(args)
+    if args.config == "eval":
+        if world > 1:
+            raise SystemExit("bench.py --config eval runs on one GPU (BASELINE configs[3])")
+        return run_arena(args, cfg)
     dtype = getattr(torch, cfg.engine.net_dtype)
     G = cfg.engine.games_per_gpu
     from cchess_alphazero.agent.model import CChessNet

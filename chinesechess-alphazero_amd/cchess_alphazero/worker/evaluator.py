@@ -79,7 +79,8 @@ class EvaluateWorker:
         return score_table(results)
 
     # ------------------------------------------------------------------------------------------------
-    def play_games(self, n_games, u_fn=None, indices=None, init_state=None, trace=None, stats=None):
+    def play_games(self, n_games, u_fn=None, indices=None, init_state=None, trace=None, stats=None, on_ply=None,
+                   sims_per_round=None):
         """Plays the games idx = 0..n_games-1 (or the given `indices`) concurrently; returns
         [(value from red's view, turns)] in that order.
 
@@ -90,14 +91,19 @@ class EvaluateWorker:
         kernels.  Per-game bookkeeping is vectorised; the only per-game Python work is the (rare) repeated position.
         u_fn(idx, ply) -> uniform draw of np.random.choice (default: NumPy's global RNG, like the reference);
         init_state: start position (default INIT_STATE); trace: dict filled with idx -> [one dict per searched ply];
-        stats: dict that receives the search counters (rounds, expansions, ...)."""
+        stats: dict that receives the search counters (rounds, expansions, ...); on_ply(ply, counters_fn): called at
+        the start of every ply (bench.py times plies with it); sims_per_round: K (default config.play.search_threads)."""
         import torch
         _native.require_gpu()
         pc = self.config.play
         idx = np.arange(n_games) if indices is None else np.asarray(list(indices), dtype=np.int64)
         G = len(idx)
         searches = [Search(pc, G, planes_dtype=self.dtype, evaluate=getattr(self.config.opts, "evaluate", False),
-                           seed=self.seed + k) for k in range(2)]
+                           seed=self.seed + k, sims_per_round=sims_per_round) for k in range(2)]
+
+        def counters_now():
+            c = [s.counters() for s in searches]
+            return {k: c[0][k] + c[1][k] for k in ("sims", "expansions", "tree_resets", "overflow_sims", "sum_depth")}
         dev = searches[0].device
         K = searches[0].K
         max_plies = 2 * int(pc.max_game_length) + 2
@@ -119,6 +125,8 @@ class EvaluateWorker:
             for i in idx:
                 trace[int(i)] = []
         while live.any():
+            if on_ply is not None:
+                on_ply(turns, counters_now, rounds)
             hist[turns] = boards
             # -- repetition handling BEFORE the move (reference :172-189; no be_catched branch here) --
             no_act = np.full((G, MAX_NO_ACT), _native.NOMOVE, dtype=np.uint16)
@@ -239,9 +247,8 @@ class EvaluateWorker:
                 val = -val
             results.append((val, t))
         if stats is not None:
-            c = [s.counters() for s in searches]
-            stats.update(rounds=rounds, plies=turns, games=G, sims_per_round=K,
-                         **{k: c[0][k] + c[1][k] for k in ("sims", "expansions", "tree_resets", "overflow_sims")})
+            stats.update(rounds=rounds, plies=turns, games=G, sims_per_round=K, **counters_now())
+            stats["tree_memory"] = [s.memory_info() for s in searches]
         for s in searches:
             s.close()
         return results

@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--max-seconds", type=float, default=600.0)
     a = ap.parse_args()
     import bench
-    ns = argparse.Namespace(config=a.config, games=a.games, sims_per_round=None, dtype=a.dtype)
+    ns = argparse.Namespace(config=a.config, games=a.games, sims_per_round=None, dtype=a.dtype, trunk=None)
     cfg = bench.build_config(ns)
     from cchess_alphazero.engine import SelfPlayEngine
     eng = SelfPlayEngine(cfg, a.games, dtype=getattr(torch, cfg.engine.net_dtype), seed=7)
