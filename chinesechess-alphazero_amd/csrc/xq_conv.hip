@@ -82,8 +82,14 @@ template <int C, int P, int PARTS> struct Geom {
         if (POW2) return pre ^ (kk << 5);
         return (pre ^ ((kk & 3) << 5)) + ((kk >> 2) << 7);
     }
-    static constexpr int ZROW = P * 90;              // the all-zero row (out-of-board taps, padding pixels)
-    static constexpr int PART_BYTES = (P * 90 + 1) * RB;
+    // 16 all-zero rows for out-of-board taps and padding pixels.  A lane whose tap leaves the board reads zero row
+    // ZROW + (r & 15), r = the row it would have read: every ds_read_b128 lane group (16 lanes, MI355X_MICROARCH.md
+    // section LDS) covers 16 consecutive values of r, so its 16 lanes -- on the board or not -- keep 16 distinct
+    // (row & 15), i.e. 16 distinct 16-byte slots of the 256-byte bank row.  (One shared zero row cost a 2-way conflict in
+    // almost every group that had an off-board lane: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.36 in round 1.)
+    static constexpr int ZROW = (P * 90 + 15) / 16 * 16;
+    static constexpr int ZROWS = 16;
+    static constexpr int PART_BYTES = (ZROW + ZROWS) * RB;
     static constexpr int REGION = PARTS * PART_BYTES;
     static constexpr int NT = P * 3;                 // pixel tiles of 32 (96 slots per board, 90 used)
     static constexpr int KK = C / 16;                // K-steps per tap
@@ -136,7 +142,8 @@ __device__ __forceinline__ void tile_write(unsigned char* region, int gtid,
             if ((it + 1) * NTHR <= G::CHUNKS || i < G::CHUNKS)
                 *reinterpret_cast<uint4*>(dst + row * G::RB + ((ch ^ (row & G::SWZ)) << 4)) = v[part][it];
         }
-        if (gtid < G::CPR) *reinterpret_cast<uint4*>(dst + G::ZROW * G::RB + gtid * 16) = make_uint4(0, 0, 0, 0);
+        for (int i = gtid; i < G::ZROWS * G::CPR; i += NTHR)
+            *reinterpret_cast<uint4*>(dst + G::ZROW * G::RB + i * 16) = make_uint4(0, 0, 0, 0);
     }
 }
 
@@ -165,7 +172,8 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
     auto tap_row = [&](int dy, int dx, int p) {
         const int t = p % 3;
         const bool ok = (unsigned)(qy[t] + dy) < 10u && (unsigned)(qx[t] + dx) < 9u;
-        const int row = ok ? (p / 3) * 90 + t * 32 + ln + dy * 9 + dx : G::ZROW;
+        const int nominal = (p / 3) * 90 + t * 32 + ln + dy * 9 + dx;
+        const int row = ok ? nominal : G::ZROW + (nominal & 15);
         return row * G::RB + (((kb ^ row) & G::SWZ) << 4);
     };
     V8 wf[W_RING][PARTS];
@@ -501,10 +509,12 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
                 }
             }
         }
-        if (gt2 < G::CPR) {
+        if (kiter == 0) {                      // the zero rows of Y: nothing else ever writes them
+            for (int i = gt2; i < G::ZROWS * G::CPR; i += CT * 64) {
 #pragma unroll
-            for (int part = 0; part < PARTS; ++part)
-                *reinterpret_cast<uint4*>(Y + part * G::PART_BYTES + G::ZROW * G::RB + gt2 * 16) = make_uint4(0, 0, 0, 0);
+                for (int part = 0; part < PARTS; ++part)
+                    *reinterpret_cast<uint4*>(Y + part * G::PART_BYTES + G::ZROW * G::RB + i * 16) = make_uint4(0, 0, 0, 0);
+            }
         }
         CZ_STAMP2(2, wall_clock64());
         __syncthreads();                                       // B: Y complete
@@ -574,8 +584,12 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_input_conv(
 {
     typedef typename Mfma<E>::V8 V8;
     constexpr int RBI = IC16 * 32;                  // bytes per pixel row of the input image
-    constexpr int ZROW = P * 90;
-    constexpr int IMG = (P * 90 + 1) * RBI;
+    // 16 zero rows and a swizzle, as in Geom: the 256-byte bank row holds RPB = 8 (or 4) of these short pixel rows, so
+    // the 16 consecutive rows of a ds_read_b128 lane group would share 8 (4) slots; chunk ^= (row / RPB) gives each
+    // of them its own 16-byte slot (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 0.60 here in round 1)
+    constexpr int CPRI = IC16 * 2, RPB = 16 / CPRI;
+    constexpr int ZROW = (P * 90 + 15) / 16 * 16;
+    constexpr int IMG = (ZROW + 16) * RBI;
     constexpr int NT = P * 3, CT = C / 32, NTHR = CT * 64;
     constexpr int NX = NT * IC16;                   // operand reads per tap
     constexpr int NM = NX * PARTS;                  // MFMAs per tap
@@ -594,7 +608,9 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_input_conv(
         for (int i = tid; i < nb * per_board; i += NTHR) {
             const int bb = i / per_board, r = i - bb * per_board;
             const int c = r / 90, pix = r - c * 90;
-            *reinterpret_cast<E*>(img + (bb * 90 + pix) * RBI + c * 2) = (E)plane_to_f(src[i]);
+            const int row = bb * 90 + pix;
+            *reinterpret_cast<E*>(img + row * RBI + (((c >> 3) ^ ((row / RPB) & (CPRI - 1))) << 4) + (c & 7) * 2) =
+                (E)plane_to_f(src[i]);
         }
     }
     __syncthreads();
@@ -607,13 +623,14 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_input_conv(
         qy[t] = q < 90 ? q / 9 : 100;
         qx[t] = q - (q / 9) * 9;
     }
-    auto tap_off = [&](int tap, int p) {            // byte offset of this lane's 16 bytes for (tap, 16-channel group 0)
+    auto tap_off = [&](int tap, int p, int g) {     // byte offset of this lane's 16 bytes for (tap, 16-channel group g)
         const int ky = tap / 5;
         const int dy = ky - 2, dx = tap - ky * 5 - 2;
         const int t = p % 3;
         const bool ok = (unsigned)(qy[t] + dy) < 10u && (unsigned)(qx[t] + dx) < 9u;
-        const int row = ok ? (p / 3) * 90 + t * 32 + ln + dy * 9 + dx : ZROW;
-        return row * RBI + kb * 16;
+        const int nominal = (p / 3) * 90 + t * 32 + ln + dy * 9 + dx;
+        const int row = ok ? nominal : ZROW + (nominal & 15);
+        return row * RBI + ((((g << 1) | kb) ^ ((row / RPB) & (CPRI - 1))) << 4);
     };
     const uint4* wq = reinterpret_cast<const uint4*>(wp) + wave * 64 + lane;
     auto load_w = [&](int tap, int g, int part) {
@@ -634,7 +651,7 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_input_conv(
             for (int part = 0; part < PARTS; ++part) wf[s][g][part] = load_w(s, g, part);
 #pragma unroll
     for (int i = 0; i < NX; ++i)
-        px[0][i] = __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(img + tap_off(0, i % NT) + (i / NT) * 32));
+        px[0][i] = __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(img + tap_off(0, i % NT, i / NT)));
 
     auto tap_body = [&](int tap, const int ring, const int buf) {
         const int tn = tap < 24 ? tap + 1 : 24;
@@ -644,7 +661,7 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_input_conv(
             acc[xi % NT] = Mfma<E>::mma(wf[ring][xi / NT][part], px[buf][xi], acc[xi % NT]);
             if (i < NX)
                 px[buf ^ 1][i] = __builtin_bit_cast(
-                    V8, *reinterpret_cast<const uint4*>(img + tap_off(tn, i % NT) + (i / NT) * 32));
+                    V8, *reinterpret_cast<const uint4*>(img + tap_off(tn, i % NT, i / NT)));
             if (i >= NM - IC16 * PARTS) {
                 const int j = i - (NM - IC16 * PARTS);
                 wf[(ring + 3) & 3][j / PARTS][j % PARTS] = load_w(tap + 3, j / PARTS, j % PARTS);
