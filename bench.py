@@ -291,7 +291,8 @@ def run_arena(args, cfg):
                                   f"a step = one ply of the whole arena",
                       "games": G, "sims_per_round": K, "parallelism": "one GPU"},
            "sims_per_s": d["sims"] / dt, "rounds_timed": rounds, "ms_per_round": dt / max(1, rounds) * 1e3,
-           "rows_per_forward": G // 2 * K,
+           "queue_rows_per_model_round": G // 2 * K,
+           "rows_evaluated_per_round_whole_arena": stats["rows_evaluated"] / max(1, stats["rounds"]),
            "network_tflops": fl * d["expansions"] / dt / 1e12,
            "arena": {"games": G, "plies": stats["plies"], "rounds": stats["rounds"], "seconds": total,
                      "expansions": stats["expansions"], "expansions_per_s_whole_arena": stats["expansions"] / total,

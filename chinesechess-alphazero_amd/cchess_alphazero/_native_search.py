@@ -38,6 +38,8 @@ def declare(L):
     L.cz_search_set_sims.argtypes = [vp, i32]
     L.cz_search_pending.argtypes = [vp, C.POINTER(C.c_int), vp]
     L.cz_search_root_stats.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.cz_search_leaf_rows.argtypes = [vp, vp, vp, C.POINTER(C.c_int), vp]
+    L.cz_search_leaf_rows.restype = i32
     L.cz_search_node_stats.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.cz_search_node_stats.restype = i32
     L.cz_search_stop.argtypes = [vp, vp]
@@ -170,6 +172,19 @@ class Search:
         out = C.c_int(0)
         _native.check(self.L.cz_search_pending(self.h, C.byref(out), self._stream()), "cz_search_pending")
         return out.value
+
+    def leaf_rows(self):
+        """After round(): (searches still running, int64 cuda tensor of the queue rows that hold a new leaf).
+        One stream synchronisation, like pending()."""
+        import torch
+        if getattr(self, "_rows", None) is None:
+            self._rows = torch.empty((self.slots,), dtype=torch.int32, device=self.device)
+            self._row_counts = torch.zeros((2,), dtype=torch.int32, device=self.device)
+        out = (C.c_int * 2)()
+        _native.check(self.L.cz_search_leaf_rows(self.h, C.c_void_p(self._rows.data_ptr()),
+                                                 C.c_void_p(self._row_counts.data_ptr()), out, self._stream()),
+                      "cz_search_leaf_rows")
+        return int(out[0]), self._rows[:int(out[1])].long()
 
     def run_until_idle(self, evaluate, max_rounds=1000000):
         """external mode: rounds until every search is complete.  evaluate(planes) -> (policy, value)."""

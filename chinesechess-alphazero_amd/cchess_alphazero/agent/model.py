@@ -178,15 +178,21 @@ class InferenceNet(nn.Module):
         return out
 
     def _operands(self, n, device):
-        """Three rotating activation buffers ([n, 90, C] per part) + the fp32 output of the last layer."""
-        key = (n, str(device))
-        if key not in self._bufs:
+        """Three rotating activation buffers ([n, 90, C] per part) + the fp32 output of the last layer.  Allocated once
+        for the largest batch seen (the evaluation queue) and sliced for smaller ones (the arena / UCI evaluate only
+        the rows that carry a leaf, a different count every round)."""
+        key = str(device)
+        cap = self._bufs.get(key, (0,))[0]
+        if n > cap:
             od, c = self.operand_dtype, self.filters
             bufs = [tuple(torch.empty((n, 90, c), dtype=od, device=device) for _ in range(self.parts))
                     for _ in range(3)]
             last = torch.empty((n, 90, c), dtype=torch.float32 if self.parts == 2 else od, device=device)
-            self._bufs = {key: (bufs, last)}              # one batch size at a time (the evaluation queue)
-        return self._bufs[key]
+            self._bufs = {key: (n, bufs, last)}           # one device at a time
+        cap, bufs, last = self._bufs[key]
+        if n == cap:
+            return bufs, last
+        return [tuple(t[:n] for t in b) for b in bufs], last[:n]
 
     def _trunk_mfma(self, planes, heads=None):
         """planes: the evaluation queue as the search kernel wrote it ([n, in_planes, 10, 9], any supported dtype).

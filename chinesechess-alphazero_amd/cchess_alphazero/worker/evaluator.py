@@ -86,7 +86,7 @@ class EvaluateWorker:
 
         All games advance ply by ply together: at every ply the games whose mover is the best model are searched on
         search object 0 and the others on search object 1 (one tree per game in each), both run lock-step rounds --
-        tree kernels, then that model's forward over the rows of ITS games only -- until every search is complete;
+        tree kernels, then that model's forward over the queue rows that hold a new leaf -- until every search is complete;
         the moves are picked on the device and the game rules are applied to all boards with the batched rule
         kernels.  Per-game bookkeeping is vectorised; the only per-game Python work is the (rare) repeated position.
         u_fn(idx, ply) -> uniform draw of np.random.choice (default: NumPy's global RNG, like the reference);
@@ -117,8 +117,7 @@ class EvaluateWorker:
         final_move = np.full(G, _native.NOMOVE, dtype=np.int64)
         no_eat_count = np.zeros(G, dtype=np.int64)
         check = np.zeros(G, dtype=bool)
-        rounds = 0
-        kslots = torch.arange(K, device=dev)
+        rounds = rows_evaluated = 0
         if trace is not None:
             from cchess_alphazero.environment.lookup_tables import ActionLabelsRed
             from cchess_alphazero.environment.static_env import array_to_state
@@ -171,13 +170,10 @@ class EvaluateWorker:
             t_na = torch.from_numpy(no_act.view(np.int16)).to(dev).view(torch.uint16)
             t_nn = torch.from_numpy(n_no_act).to(dev)
             t_inc = torch.from_numpy(inc).to(dev)
-            rows = [None, None]
             for k in range(2):
                 if masks[k].any():
                     searches[k].set_roots(boards, turns=t_turns, no_act=t_na, n_no_act=t_nn, increase_temp=t_inc,
                                           select_mask=torch.from_numpy(masks[k].astype(np.uint8)).to(dev))
-                    gk = torch.from_numpy(np.nonzero(masks[k])[0]).to(dev)
-                    rows[k] = (gk[:, None] * K + kslots[None, :]).reshape(-1)     # queue rows of this model's games
             busy = [bool(m.any()) for m in masks]
             while any(busy):
                 for k in range(2):
@@ -186,12 +182,15 @@ class EvaluateWorker:
                     s = searches[k]
                     s.round()
                     rounds += 1
-                    if s.pending() == 0:
+                    pending, leaf = s.leaf_rows()          # only the rows that carry a new position are evaluated
+                    if pending == 0:
                         busy[k] = False
                         continue
-                    p, v = self.evaluators[k](s.planes.index_select(0, rows[k]))
-                    s.policy.index_copy_(0, rows[k], p.float())
-                    s.value.index_copy_(0, rows[k], v.float())
+                    if leaf.numel():
+                        p, v = self.evaluators[k](s.planes.index_select(0, leaf))
+                        s.policy.index_copy_(0, leaf, p.float())
+                        s.value.index_copy_(0, leaf, v.float())
+                        rows_evaluated += int(leaf.numel())
             u = np.array([u_fn(int(idx[g]), turns) if u_fn else np.random.random_sample() for g in range(G)])
             action = np.full(G, -1, dtype=np.int64)
             for k in range(2):
@@ -247,7 +246,8 @@ class EvaluateWorker:
                 val = -val
             results.append((val, t))
         if stats is not None:
-            stats.update(rounds=rounds, plies=turns, games=G, sims_per_round=K, **counters_now())
+            stats.update(rounds=rounds, plies=turns, games=G, sims_per_round=K, rows_evaluated=rows_evaluated,
+                         **counters_now())
             stats["tree_memory"] = [s.memory_info() for s in searches]
         for s in searches:
             s.close()

@@ -1351,6 +1351,18 @@ __global__ void k_pending(SearchParams P, SearchBuffers B)
     if (g < P.G && B.g_phase[g] == PH_SEARCH) atomicAdd(B.pending, 1);
 }
 
+// queue rows that hold a new leaf (a position the network has to evaluate) after a round, compacted; rows[] order is
+// arbitrary.  counts[0] = searches still running, counts[1] = rows written.
+__global__ void k_leaf_rows(SearchParams P, SearchBuffers B, int32_t* __restrict__ rows, int32_t* __restrict__ counts)
+{
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= P.G * P.K) return;
+    const int g = slot / P.K;
+    if (B.g_phase[g] != PH_SEARCH) return;
+    if (slot == g * P.K) atomicAdd(&counts[0], 1);
+    if (B.s_state[slot] == SIM_LEAF) rows[atomicAdd(&counts[1], 1)] = slot;
+}
+
 // statistics of the root, or of the node reached from the root along path[g][0 .. path_len) (move labels, NOMOVE ends
 // the path early); a node that is not linked in the tree reports count 0
 __global__ __launch_bounds__(64) void k_root_stats(SearchParams P, SearchBuffers B, const uint16_t* __restrict__ path,
@@ -1795,6 +1807,24 @@ int cz_search_pending(cz_search* s, int* host_out, void* stream)
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return serr_hip("cz_search_pending", e);
     *host_out = v;
+    return CZ_OK;
+}
+
+int cz_search_leaf_rows(cz_search* s, int32_t* rows, int32_t* counts_dev, int* host_out, void* stream)
+{
+    if (!s || !rows || !counts_dev || !host_out) return serr(CZ_ERR_ARG, "cz_search_leaf_rows: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(counts_dev, 0, 2 * sizeof(int32_t), st);
+    if (e != hipSuccess) return serr_hip("cz_search_leaf_rows", e);
+    const int n = s->P.G * s->P.K;
+    hipLaunchKernelGGL(k_leaf_rows, dim3((n + 255) / 256), dim3(256), 0, st, s->P, s->B, rows, counts_dev);
+    S_LAUNCH_CHECK("cz_search_leaf_rows");
+    int32_t v[2] = {0, 0};
+    e = hipMemcpyAsync(v, counts_dev, sizeof(v), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return serr_hip("cz_search_leaf_rows", e);
+    host_out[0] = v[0];
+    host_out[1] = v[1];
     return CZ_OK;
 }
 

@@ -161,6 +161,13 @@ int cz_search_set_sims(cz_search* s, int simulation_num_per_move);
 int cz_search_reset_trees(cz_search* s, void* stream);
 /* synchronises the stream; *host_out = number of games whose current search is unfinished */
 int cz_search_pending(cz_search* s, int* host_out, void* stream);
+/* After a cz_search_round: the queue rows (slot = game * K + sim) that hold a NEW leaf, i.e. the only rows whose
+ * policy / value the next round will read.  rows [G*K] int32 DEVICE (compacted, arbitrary order), counts_dev [2] int32
+ * DEVICE scratch; HOST host_out[0] = searches still running (as cz_search_pending), host_out[1] = rows written.
+ * Synchronises the stream.  Lets a caller with few games (arena, UCI) evaluate only the rows that carry a position:
+ * with K = 32 simulations per batch roughly half of a batch's rows are simulations parked on a leaf another one
+ * already expanded (player.py:238-242). */
+int cz_search_leaf_rows(cz_search* s, int32_t* rows, int32_t* counts_dev, int* host_out, void* stream);
 /* root edges after a search: moves/n/w/p [G][128], sum_n [G], counts [G] (any may be NULL) */
 int cz_search_root_stats(cz_search* s, uint16_t* moves, int32_t* n, double* w, float* p, int32_t* sum_n,
                          uint8_t* counts, void* stream);

@@ -307,6 +307,42 @@ def test_model_api_hot_reload(tmp_path):
     assert (p1.cpu() - pr).abs().max() < 1e-4 and (v1.cpu() - vr).abs().max() < 1e-4
 
 
+def test_selfplay_worker_reloads_a_new_best_model(tmp_path, monkeypatch):
+    """The reference's self-play picks up a new best model while it runs (get_pipes(need_reload=True) -> the prediction
+    thread re-checks the best-weight digest every 600 s, agent/api.py:37-44).  SelfPlayWorker.run does the same check
+    on its report boundary: after the file on disk changes, the engine's games are played with the new weights
+    (also when the rounds are replayed from a HIP graph); an unchanged file changes nothing."""
+    import torch
+    from cchess_alphazero.agent.model import CChessModel
+    from cchess_alphazero.lib import model_helper
+    from cchess_alphazero.worker.self_play import SelfPlayWorker
+    cfg = _cfg(tmp_path, monkeypatch, simulation_num_per_move=16, search_threads=4, max_game_length=6, noise_eps=0.0)
+    cfg.model.cnn_filter_num, cfg.model.res_layer_num = 32, 2
+    cfg.engine.games_per_gpu, cfg.engine.report_every_rounds, cfg.engine.reload_seconds = 8, 4, 0
+    cfg.resource.create_directories()
+    m = CChessModel(cfg)
+    m.build(seed=1)
+    model_helper.save_as_best_model(m)
+    w = SelfPlayWorker(cfg, model=m)
+    w.run(max_rounds=8)
+    assert not w.reload_best_model()                         # same digest: nothing to do
+    x = w.engine.search.planes[:8].clone()
+    p0, _ = w.engine.net(x)
+    other = CChessModel(cfg)
+    other.build(seed=2)
+    model_helper.save_as_best_model(other)
+    w.run(max_rounds=4)                                      # the report boundary inside run() reloads
+    assert m.digest == other.digest
+    p1, v1 = w.engine.net(x)
+    assert (p1 - p0).abs().max() > 1e-6
+    with torch.no_grad():
+        pr, vr = other.model.eval()(x.float().cpu())
+    assert (p1.cpu() - pr).abs().max() < 1e-4 and (v1.cpu() - vr).abs().max() < 1e-4
+    c = w.run(max_rounds=8)
+    assert c["expansions"] > 0
+    w.close()
+
+
 def test_uci_searches_match_reference_player(tmp_path, monkeypatch):
     """action(depth=...), the principal variation behind `info depth .. pv ..` and the ponder move against the
     REFERENCE's own player run with uci=True (tests/golden/uci_k1.json, make_golden_uci.py)."""

@@ -119,6 +119,41 @@ def test_search_matches_oracle(gpu, K, sims, spec):
     s.close()
 
 
+def test_leaf_rows_are_the_only_rows_the_next_round_reads(gpu):
+    """cz_search_leaf_rows: after a round, exactly the queue rows that hold a new leaf.  A search driven by evaluating
+    ONLY those rows -- every other policy / value row poisoned with NaN -- gives the oracle's visit counts."""
+    t = gpu.torch
+    pc = play_config(simulation_num_per_move=120, search_threads=8)
+    spec = dict(kind="hash", salt=9)
+    states = [xo.INIT_STATE, MID, END]
+    s = gpu.S.Search(pc, len(states), seed=7)
+    s.set_roots(boards_tensor(gpu, states))
+    ev = stub_eval(gpu, spec)
+    total_rows = 0
+    for _ in range(10000):
+        s.round()
+        pending, rows = s.leaf_rows()
+        assert pending == s.pending()
+        if pending == 0:
+            break
+        assert rows.numel() == len(set(rows.tolist())) and rows.numel() <= s.slots
+        total_rows += rows.numel()
+        s.policy.fill_(float("nan"))
+        s.value.fill_(float("nan"))
+        if rows.numel():
+            p, v = ev(s.planes.index_select(0, rows))
+            s.policy.index_copy_(0, rows, p)
+            s.value.index_copy_(0, rows, v)
+    st = s.root_stats()
+    for g, state in enumerate(states):
+        pl = xo.Player(oracle_cfg(pc), spec)
+        pl.search(state)
+        assert_root_equal(st, g, pl.node_stats(state), f"game {g}")
+        pl.close()
+    assert total_rows == s.counters()["expansions"]
+    s.close()
+
+
 def test_no_act_and_choose(gpu):
     pc = play_config(simulation_num_per_move=150, search_threads=1, tau_decay_rate=0.98)
     spec = dict(kind="hash", salt=6)
