@@ -72,6 +72,7 @@ class EvaluateWorker:
         self.evaluators = evaluators
         self.dtype = dtype
         self.seed = seed
+        self.concurrent = True         # the two models' searches of a ply on two streams / host threads
 
     def start(self):
         n = self.config.eval.game_num * max(1, self.config.play.max_processes)
@@ -118,6 +119,9 @@ class EvaluateWorker:
         no_eat_count = np.zeros(G, dtype=np.int64)
         check = np.zeros(G, dtype=bool)
         rounds = rows_evaluated = 0
+        from concurrent.futures import ThreadPoolExecutor
+        streams = [torch.cuda.Stream(dev) for _ in range(2)]
+        pool = ThreadPoolExecutor(max_workers=2)
         if trace is not None:
             from cchess_alphazero.environment.lookup_tables import ActionLabelsRed
             from cchess_alphazero.environment.static_env import array_to_state
@@ -174,23 +178,38 @@ class EvaluateWorker:
                 if masks[k].any():
                     searches[k].set_roots(boards, turns=t_turns, no_act=t_na, n_no_act=t_nn, increase_temp=t_inc,
                                           select_mask=torch.from_numpy(masks[k].astype(np.uint8)).to(dev))
-            busy = [bool(m.any()) for m in masks]
-            while any(busy):
-                for k in range(2):
-                    if not busy[k]:
-                        continue
-                    s = searches[k]
-                    s.round()
-                    rounds += 1
-                    pending, leaf = s.leaf_rows()          # only the rows that carry a new position are evaluated
-                    if pending == 0:
-                        busy[k] = False
-                        continue
-                    if leaf.numel():
-                        p, v = self.evaluators[k](s.planes.index_select(0, leaf))
-                        s.policy.index_copy_(0, leaf, p.float())
-                        s.value.index_copy_(0, leaf, v.float())
-                        rows_evaluated += int(leaf.numel())
+            # The two models' searches of this ply are independent: each runs its rounds (tree kernels, leaf-row
+            # compaction, forward on the rows that carry a new position) on its own HIP stream from its own host
+            # thread, so one model's kernels fill the gaps the other's launch / sync latencies leave.
+            def search_ply(k):
+                s = searches[k]
+                n_rounds = n_rows = 0
+                torch.cuda.set_device(dev)                  # (a fresh host thread starts on device 0)
+                with torch.cuda.stream(streams[k]):
+                    while True:
+                        s.round()
+                        n_rounds += 1
+                        pending, leaf = s.leaf_rows()      # only the rows that carry a new position are evaluated
+                        if pending == 0:
+                            break
+                        if leaf.numel():
+                            p, v = self.evaluators[k](s.planes.index_select(0, leaf))
+                            s.policy.index_copy_(0, leaf, p.float())
+                            s.value.index_copy_(0, leaf, v.float())
+                            n_rows += int(leaf.numel())
+                return n_rounds, n_rows
+            active = [k for k in range(2) if masks[k].any()]
+            main = torch.cuda.current_stream(dev)
+            for k in active:
+                streams[k].wait_stream(main)
+            if len(active) == 2 and self.concurrent:
+                done = list(pool.map(search_ply, active))
+            else:
+                done = [search_ply(k) for k in active]
+            for k in active:
+                main.wait_stream(streams[k])
+            rounds += sum(d[0] for d in done)
+            rows_evaluated += sum(d[1] for d in done)
             u = np.array([u_fn(int(idx[g]), turns) if u_fn else np.random.random_sample() for g in range(G)])
             action = np.full(G, -1, dtype=np.int64)
             for k in range(2):
@@ -249,6 +268,8 @@ class EvaluateWorker:
             stats.update(rounds=rounds, plies=turns, games=G, sims_per_round=K, rows_evaluated=rows_evaluated,
                          **counters_now())
             stats["tree_memory"] = [s.memory_info() for s in searches]
+        pool.shutdown()
+        torch.cuda.synchronize(dev)
         for s in searches:
             s.close()
         return results
