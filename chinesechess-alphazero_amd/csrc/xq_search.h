@@ -62,6 +62,7 @@ struct SearchParams {
     int n_chunks;           // chunks in the pool
     int max_chunks;         // chunk-table entries per game (<= MAX_CHUNKS)
     int keep_chunks;        // chunks a game never gives back: enough for one full search on an empty tree
+    int max_batches;        // lock-step batches one k_sim launch may start for a game
     int planes_dtype;
     int in_planes;          // 14, or 28 with use_history
     int mode;

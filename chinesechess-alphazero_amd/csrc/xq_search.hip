@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include "xq_rules.h"
@@ -37,7 +38,6 @@ namespace {
 constexpr int MAXD_LDS = 128;          // LDS copy of the current path; SearchParams.max_depth <= this
 constexpr int INIT_NIB_WORDS = KEY_WORDS;
 
-constexpr int MAX_BATCHES_PER_LAUNCH = 3;   // lock-step batches one k_sim launch may START for a game
 
 struct SearchLDS {
     RulesLDS r;
@@ -1199,7 +1199,7 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             // A batch whose simulations all end on terminal / repeated positions needs no evaluation and the next one
             // could start at once -- in a won endgame that chains hundreds of batches inside one launch and the whole
             // round waits for this wave.  The order of simulations does not depend on where the chain is cut.
-            if (++batches > MAX_BATCHES_PER_LAUNCH) break;
+            if (++batches > P.max_batches) break;
             new_n = tasks < P.K ? tasks : P.K;
             new_i = 0;
             active = new_n;
@@ -1605,6 +1605,12 @@ int cz_search_create(const cz_search_cfg* c, cz_search** out)
     while ((long long)h * 2 < max_nodes * 3) h <<= 1;              // load factor <= 2/3 at max_nodes
     P.hash_cap = h;
     P.keep_chunks = keep_chunks_for(P.sims);
+    // lock-step batches one k_sim launch may START for a game: 1.  (A batch whose simulations all end on terminal or
+    // repeated positions needs no evaluation and could be followed by the next at once, but then the whole launch
+    // waits for the few waves that chain batches of the slowest kind of simulation: with 3, the sustained k_sim(SELECT)
+    // launch was 0.78 ms mean / 2.3 ms p99 against a 0.64 ms median.)
+    P.max_batches = 1;
+    if (const char* e = getenv("CZ_MAX_BATCHES")) { const int v = atoi(e); if (v >= 1 && v <= 16) P.max_batches = v; }
     // chunk table: the whole-game tree at ~420 B per node (node record + its share of statistics blocks)
     const long long game_chunks = (max_nodes * 420 + (long long)CHUNK_BYTES - 1) / (long long)CHUNK_BYTES;
     long long mc = game_chunks + P.keep_chunks;
