@@ -1095,9 +1095,18 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
             if (!game_over && !d.check) {                               // :161-175
                 int free_move = 0;
                 // earlier states equal to this one, in order (both parities: the reference compares strings)
-                for (int i = 0; i < turns && !game_over; ++i) {
-                    const bool ne = lane < KEY_WORDS && hkeys[(size_t)i * KEY_WORDS + lane] != L.key[lane];
-                    if (__ballot(ne)) continue;
+                // (five earlier plies per step: lanes 12 s .. 12 s + 11 compare the key of ply base + s, one ballot
+                //  tells which of the five are equal; a ply-at-a-time scan is 200 dependent memory round trips)
+                for (int base = 0; base < turns && !game_over; base += 5) {
+                  const int cmp_ply = base + lane / KEY_WORDS, cmp_w = lane % KEY_WORDS;
+                  bool differs = true;
+                  if (lane < 5 * KEY_WORDS && cmp_ply < turns)
+                      differs = hkeys[(size_t)cmp_ply * KEY_WORDS + cmp_w] != L.key[cmp_w];
+                  const uint64_t dm = __ballot(differs);
+                  for (int sub = 0; sub < 5 && !game_over; ++sub) {
+                    const int i = base + sub;
+                    if (i >= turns) break;
+                    if ((dm >> (KEY_WORDS * sub)) & 0xFFFull) continue;
                     const int mv = uni((int)hacts[i]);
                     // the rule helpers need the position in bd[0]
                     L.r.bd[0][lane] = L.r.bd[3][lane];
@@ -1113,6 +1122,7 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
                         free_move += 1;
                         if (free_move >= 3) { game_over = true; value = 0; }
                     }
+                  }
                 }
             }
         }
