@@ -129,6 +129,9 @@ def cpu_baseline(cfg, seconds):
             quota = float(q) / float(per)
     except (OSError, ValueError):
         pass
+    visible = procs
+    if quota is not None and quota >= 1:
+        procs = min(procs, int(quota + 0.999))               # one process per CPU the container may actually use
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "baseline_worker.py"), "--procs", str(procs),
            "--seconds", str(seconds), "--sims", str(pc.simulation_num_per_move), "--threads", str(pc.search_threads),
            "--c-puct", str(pc.c_puct), "--vl", str(pc.virtual_loss), "--max-game-length", str(pc.max_game_length)]
@@ -143,7 +146,7 @@ def cpu_baseline(cfg, seconds):
         pass
     return {"value": sum(per), "unit": "expansions/s", "cores": procs, "kind": "port",
             "per_process": {"median": statistics.median(per), "min": min(per), "max": max(per), "seeds": len(per)},
-            "sims_per_s": sum(sims), "cpu_model": cpu, "cgroup_cpu_quota": quota,
+            "sims_per_s": sum(sims), "cpu_model": cpu, "cgroup_cpu_quota": quota, "cpus_visible": visible,
             "sample": f"oracle/xq_mcts.c + xq_rules.c (C port of player.py / static_env.py), {procs} processes x "
                       f"{seconds:.0f} s of self-play from INIT_STATE, {pc.simulation_num_per_move} sims/move, "
                       f"K={pc.search_threads}, hash-stub net (tree + rules only, no ResNet), one seed per process, "
@@ -212,9 +215,12 @@ def games_per_hour_estimate(expansions_per_s, config):
     if config == "normal" and longs:
         with open(longs[-1]) as f:
             ld = json.load(f)
-        out["sustained_measured"] = {"games_per_hour": ld["plies_per_s"] / d["mean_plies_per_game"] * 3600.0,
-                                     "expansions_per_s": ld["value"], "rounds": ld["steps"],
-                                     "games_finished": ld["games_finished"], "source": os.path.relpath(longs[-1], ROOT)}
+        sl = ld.get("sustained") or {"plies_per_s": ld["plies_per_s"], "value": ld["value"], "rounds": ld["steps"],
+                                      "games_finished": ld["games_finished"]}      # (round-1 files: the whole run)
+        out["sustained_measured"] = {"games_per_hour": sl["plies_per_s"] / d["mean_plies_per_game"] * 3600.0,
+                                     "expansions_per_s": sl["value"], "rounds": sl["rounds"],
+                                     "games_finished": sl["games_finished"], "tree_resets": sl.get("tree_resets"),
+                                     "source": os.path.relpath(longs[-1], ROOT)}
     return out
 
 

@@ -192,11 +192,13 @@ class Search:
         while rounds < max_rounds:
             self.round()
             rounds += 1
-            if self.pending() == 0:
+            pending, rows = self.leaf_rows()
+            if pending == 0:
                 return rounds
-            p, v = evaluate(self.planes)
-            self.policy.copy_(p)
-            self.value.copy_(v)
+            if rows.numel():                       # only the queue rows that carry a new leaf
+                p, v = evaluate(self.planes.index_select(0, rows))
+                self.policy.index_copy_(0, rows, p.float())
+                self.value.index_copy_(0, rows, v.float())
         raise RuntimeError("search did not finish")
 
     def stop(self):

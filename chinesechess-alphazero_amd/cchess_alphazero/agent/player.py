@@ -212,11 +212,13 @@ class CChessPlayer:
             start_time, shown, stopped = time(), 0, False
             while True:
                 s.round()
-                if s.pending() == 0:
+                pending, rows = s.leaf_rows()
+                if pending == 0:
                     break
-                p, v = self._evaluate(s.planes)
-                s.policy.copy_(p)
-                s.value.copy_(v)
+                if rows.numel():                               # exactly the positions the reference would send (:112-120)
+                    p, v = self._evaluate(s.planes.index_select(0, rows))
+                    s.policy.index_copy_(0, rows, p.float())
+                    s.value.index_copy_(0, rows, v.float())
                 if self.job_done and not stopped:
                     s.stop()                                   # the next round backs up what is in flight
                     stopped = True

@@ -142,9 +142,18 @@ __device__ __forceinline__ void tile_write(unsigned char* region, int gtid,
             if ((it + 1) * NTHR <= G::CHUNKS || i < G::CHUNKS)
                 *reinterpret_cast<uint4*>(dst + row * G::RB + ((ch ^ (row & G::SWZ)) << 4)) = v[part][it];
         }
-        for (int i = gtid; i < G::ZROWS * G::CPR; i += NTHR)
-            *reinterpret_cast<uint4*>(dst + G::ZROW * G::RB + i * 16) = make_uint4(0, 0, 0, 0);
     }
+}
+
+// the 16 all-zero rows of an image (written once per workgroup: nothing else ever stores there)
+template <int C, int P, int PARTS, int NTHR = Geom<C, P, PARTS>::GTHREADS>
+__device__ __forceinline__ void zero_rows_write(unsigned char* region, int gtid)
+{
+    typedef Geom<C, P, PARTS> G;
+#pragma unroll
+    for (int part = 0; part < PARTS; ++part)
+        for (int i = gtid; i < G::ZROWS * G::CPR; i += NTHR)
+            *reinterpret_cast<uint4*>(region + part * G::PART_BYTES + G::ZROW * G::RB + i * 16) = make_uint4(0, 0, 0, 0);
 }
 
 // The K loop: 9 taps x C input channels for the 32 output channels of this wave and all NT pixel tiles of the
@@ -258,6 +267,7 @@ __global__ __launch_bounds__(C / 32 * 64, MINW) void k_conv3x3(
         uint4 v[PARTS][G::ITER];
         tile_load<E, C, P, PARTS, (DBG & 2) != 0>(xh, xl, n0, n_boards, tid, v);
         tile_write<C, P, PARTS>(lds, tid, v);
+        zero_rows_write<C, P, PARTS>(lds, tid);
     }
     __syncthreads();
 
@@ -376,6 +386,8 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
         uint4 v[PARTS][LITER];
         tile_load<E, C, P, PARTS, (DBG & 2) != 0, CTHR>(xh, xl, t * P, n_boards, ctid, v);
         tile_write<C, P, PARTS, CTHR>(X, ctid, v);
+        zero_rows_write<C, P, PARTS, CTHR>(X, ctid);
+        zero_rows_write<C, P, PARTS, CTHR>(Y, ctid);
         int t_prev = -1;
         float hw[HEADS ? 6 : 1][8];                            // this thread's slice of the head filters (c8 is fixed)
         if (HEADS) {
@@ -507,13 +519,6 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
                     *reinterpret_cast<Quad<E>*>(Y + off) = hi;
                     if (PARTS == 2) *reinterpret_cast<Quad<E>*>(Y + G::PART_BYTES + off) = lo;
                 }
-            }
-        }
-        if (kiter == 0) {                      // the zero rows of Y: nothing else ever writes them
-            for (int i = gt2; i < G::ZROWS * G::CPR; i += CT * 64) {
-#pragma unroll
-                for (int part = 0; part < PARTS; ++part)
-                    *reinterpret_cast<uint4*>(Y + part * G::PART_BYTES + G::ZROW * G::RB + i * 16) = make_uint4(0, 0, 0, 0);
             }
         }
         CZ_STAMP2(2, wall_clock64());
