@@ -242,7 +242,15 @@ def gen_games():
         dict(name="repeat_a", salt=32, sims=8, tau=0.0, max_game_length=60, seed=1012),
         dict(name="repeat_b", salt=33, sims=12, tau=0.0, max_game_length=60, seed=1013),
         dict(name="repeat_c", salt=34, sims=10, tau=0.0, max_game_length=60, seed=1014, c_puct=0.5),
+        # the production search size: 800 simulations per move with subtree reuse over a whole (short) game
+        dict(name="prod_800", salt=35, sims=800, tau=0.9, max_game_length=12, seed=1015),
     ]
+    only = os.environ.get("GOLDEN_ONLY")          # regenerate just these games and merge them into the file
+    old = {}
+    if only:
+        with open(os.path.join(HERE, "games_k1.json")) as f:
+            old = {g["name"]: g for g in json.load(f)["games"]}
+        specs = [sp for sp in specs if sp["name"] in only.split(",") or sp["name"] not in old]
     games = []
     for s in specs:
         cfg = make_cfg(s["sims"], c_puct=s.get("c_puct", 1.5), tau_decay_rate=s["tau"],
@@ -302,6 +310,9 @@ def gen_games():
         print(s["name"], "turns", turns, "value", v, "store", store, "evals", pipe.n_positions,
               "no_act plies", sum(1 for p in ply_log if p["no_act"]),
               "inc_temp plies", sum(1 for p in ply_log if p["inc"]), flush=True)
+    if only:
+        new = {g["name"]: g for g in games}
+        games = [new.get(n, g) for n, g in old.items()] + [g for n, g in new.items() if n not in old]
     with open(os.path.join(HERE, "games_k1.json"), "w") as f:
         json.dump({"meta": meta(), "games": games}, f, separators=(",", ":"))
 

@@ -367,7 +367,11 @@ def test_golden_reference_lines(gpu):
 
 
 def test_golden_reference_games(gpu):
+    """Complete games of the reference's own SelfPlayWorker.start_game (15 games: length cap, king capture, resignation,
+    repetition bans, and one at the production search size of 800 simulations per move with subtree reuse) reproduced
+    move for move by the device game loop."""
     data = _golden("games_k1.json")
+    assert any(g["sims"] == 800 for g in data["games"])
     for gm in data["games"]:
         pc = play_config(simulation_num_per_move=gm["sims"], search_threads=1, c_puct=gm.get("c_puct", 1.5),
                          tau_decay_rate=gm["tau"], max_game_length=gm["max_game_length"],
@@ -382,6 +386,8 @@ def test_golden_reference_games(gpu):
             ref_moves = [m for m, _ in rec[1:]]
             assert [xo.label_str(int(m)) for m in got["moves"]] == ref_moves, gm["name"]
         assert got["turns"] == gm["turns"] and got["value"] == int(gm["value"]) and got["store"] == gm["store"]
+        # whole-game trees (self_play.py:84,98-100): nothing is dropped, also at the production 800 simulations per move
+        assert ctr["tree_resets"] == 0 and ctr["overflow_sims"] == 0, (gm["name"], ctr)
 
 
 def test_root_noise_changes_visits_but_not_totals(gpu):
