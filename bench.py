@@ -385,11 +385,11 @@ def main():
             if sampled:
                 e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 e[0].record()
-                eng.search.round()
+                eng._round()
                 e[1].record()
                 ev.append(e)
             else:
-                eng.search.round()
+                eng._round()
             eng._forward()
             eng.rounds += 1
             if sampled and eng.net is not None:
@@ -447,6 +447,7 @@ def main():
                                    f"({cfg.engine.net_dtype}, trunk={eng.trunk}), random-init weights, self-play from "
                                    f"INIT_STATE",
                        "games_per_gpu": G, "sims_per_round": K, "queue_slots_per_gpu": slots,
+                       "compact_queue": bool(eng.compact),
                        "parallelism": f"games sharded over {world} rank(s), no data-path collective"},
             "sims_per_s": d["sims"] / dt, "plies_per_s": d["plies"] / dt,
             "games_per_hour_est": games_per_hour_estimate(d["expansions"] / dt, args.config),

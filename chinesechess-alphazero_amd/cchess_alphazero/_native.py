@@ -74,6 +74,11 @@ def _declare(L):
         L.cz_resblock_heads.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
         L.cz_resblock_heads.restype = i32
         L.cz_resblock.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        L.cz_input_conv_q.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+        L.cz_resblock_q.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+        L.cz_resblock_heads_q.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+        for _n in ("cz_input_conv_q", "cz_resblock_q", "cz_resblock_heads_q"):
+            getattr(L, _n).restype = i32
         L.cz_resblock.restype = i32
         L.cz_split_bias_act.argtypes = [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, vp]
         L.cz_split_bias_act.restype = i32
@@ -292,22 +297,24 @@ def pack_input_conv_weights(w_oihw, dtype, parts):
     return out
 
 
-def input_conv(planes, w_packed, bias, out, relu=True):
+def input_conv(planes, w_packed, bias, out, relu=True, rows=None, count=None):
     """planes [N, in_planes, 10, 9] (fp32 / fp16 / bf16 / uint8, contiguous, as the search kernel writes them) ->
-    relu(conv5x5 + bias) as the (hi,) / (hi, lo) operand tuple `out` of [N, 90, C] tensors."""
+    relu(conv5x5 + bias) as the (hi,) / (hi, lo) operand tuple `out` of [N, 90, C] tensors.
+    Compact queue: rows (int32 cuda [N]) / count (int32 cuda [1]) -> board i = planes[rows[i]], i < min(N, count)."""
     import torch
     require_gpu()
     code = U8 if planes.dtype == torch.uint8 else _dt_code(planes.dtype)
     if not planes.is_contiguous():
         raise NativeError("cz_input_conv: planes must be a contiguous [N, in_planes, 10, 9] tensor")
     parts = len(out)
-    check(lib().cz_input_conv(_ptr(planes), code, planes.shape[1], _ptr(w_packed), _ptr(bias), _ptr(out[0]),
-                              _ptr(out[1]) if parts == 2 else None, planes.shape[0], out[0].shape[-1],
-                              _dt_code(out[0].dtype), parts, int(relu), _stream()), "cz_input_conv")
+    check(lib().cz_input_conv_q(_ptr(planes), code, planes.shape[1], _ptr(w_packed), _ptr(bias), _ptr(out[0]),
+                                _ptr(out[1]) if parts == 2 else None, planes.shape[0], out[0].shape[-1],
+                                _dt_code(out[0].dtype), parts, int(relu), _ptr(rows), _ptr(count), _stream()),
+          "cz_input_conv")
     return out
 
 
-def resblock(x, w1_packed, bias1, w2_packed, bias2, out=None, out_f32=None):
+def resblock(x, w1_packed, bias1, w2_packed, bias2, out=None, out_f32=None, count=None):
     """One residual block relu(conv(relu(conv(x, w1) + b1), w2) + b2 + x) in a single launch.  x and out are (hi,) or
     (hi, lo) tuples of [N, 90, C] tensors; out_f32 (split operands only) receives fp32 instead of `out`."""
     require_gpu()
@@ -317,21 +324,22 @@ def resblock(x, w1_packed, bias1, w2_packed, bias2, out=None, out_f32=None):
     xl = x[1] if parts == 2 else None
     yh = out[0] if out is not None else None
     yl = out[1] if out is not None and parts == 2 else None
-    check(lib().cz_resblock(_ptr(xh), _ptr(xl), _ptr(w1_packed), _ptr(bias1), _ptr(w2_packed), _ptr(bias2),
-                            _ptr(yh), _ptr(yl), _ptr(out_f32), n, c, _dt_code(xh.dtype), parts, _stream()),
-          "cz_resblock")
+    check(lib().cz_resblock_q(_ptr(xh), _ptr(xl), _ptr(w1_packed), _ptr(bias1), _ptr(w2_packed), _ptr(bias2),
+                              _ptr(yh), _ptr(yl), _ptr(out_f32), n, c, _dt_code(xh.dtype), parts, _ptr(count),
+                              _stream()), "cz_resblock")
     return out_f32 if out_f32 is not None else out
 
 
-def resblock_heads(x, w1_packed, bias1, w2_packed, bias2, head_w, head_b, n_policy, policy_feat, value_feat):
+def resblock_heads(x, w1_packed, bias1, w2_packed, bias2, head_w, head_b, n_policy, policy_feat, value_feat,
+                   count=None):
     """The last residual block with the 1x1 head convolutions folded in (split operands, 128 filters):
     x = (hi, lo) -> policy_feat [N, n_policy*90], value_feat [N, (6-n_policy)*90] (fp32)."""
     require_gpu()
     xh, xl = x
-    check(lib().cz_resblock_heads(_ptr(xh), _ptr(xl), _ptr(w1_packed), _ptr(bias1), _ptr(w2_packed), _ptr(bias2),
-                                  _ptr(head_w), _ptr(head_b), _ptr(policy_feat), _ptr(value_feat), xh.shape[0],
-                                  xh.shape[-1], _dt_code(xh.dtype), n_policy, head_w.shape[0] - n_policy, _stream()),
-          "cz_resblock_heads")
+    check(lib().cz_resblock_heads_q(_ptr(xh), _ptr(xl), _ptr(w1_packed), _ptr(bias1), _ptr(w2_packed), _ptr(bias2),
+                                    _ptr(head_w), _ptr(head_b), _ptr(policy_feat), _ptr(value_feat), xh.shape[0],
+                                    xh.shape[-1], _dt_code(xh.dtype), n_policy, head_w.shape[0] - n_policy,
+                                    _ptr(count), _stream()), "cz_resblock_heads")
     return policy_feat, value_feat
 
 

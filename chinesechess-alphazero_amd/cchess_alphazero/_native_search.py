@@ -34,6 +34,8 @@ def declare(L):
     L.cz_search_start_selfplay.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     L.cz_search_set_roots.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.cz_search_round.argtypes = [vp, vp, vp, vp, vp]
+    L.cz_search_round_q.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.cz_search_round_q.restype = i32
     L.cz_search_reset_trees.argtypes = [vp, vp]
     L.cz_search_set_sims.argtypes = [vp, i32]
     L.cz_search_pending.argtypes = [vp, C.POINTER(C.c_int), vp]
@@ -163,10 +165,23 @@ class Search:
         _native.check(self.L.cz_search_reset_trees(self.h, self._stream()), "cz_search_reset_trees")
 
     # -- one lock-step round: tree kernel only (the caller runs the network on self.planes) --
-    def round(self):
-        _native.check(self.L.cz_search_round(self.h, C.c_void_p(self.policy.data_ptr()),
-                                             C.c_void_p(self.value.data_ptr()), C.c_void_p(self.planes.data_ptr()),
-                                             self._stream()), "cz_search_round")
+    def round(self, compact=False):
+        """compact=True (cz_search_round_q): after the round self.q_rows[:self.q_count] lists the queue slots that hold a
+        new leaf; the caller writes the network result of planes[q_rows[i]] to policy[i] / value[i].  Use one form
+        for the whole life of a search."""
+        if not compact:
+            _native.check(self.L.cz_search_round(self.h, C.c_void_p(self.policy.data_ptr()),
+                                                 C.c_void_p(self.value.data_ptr()), C.c_void_p(self.planes.data_ptr()),
+                                                 self._stream()), "cz_search_round")
+            return
+        if getattr(self, "q_rows", None) is None:
+            import torch
+            self.q_rows = torch.zeros((self.slots,), dtype=torch.int32, device=self.device)
+            self.q_count = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        _native.check(self.L.cz_search_round_q(self.h, C.c_void_p(self.policy.data_ptr()),
+                                               C.c_void_p(self.value.data_ptr()), C.c_void_p(self.planes.data_ptr()),
+                                               C.c_void_p(self.q_rows.data_ptr()), C.c_void_p(self.q_count.data_ptr()),
+                                               self._stream()), "cz_search_round_q")
 
     def pending(self):
         out = C.c_int(0)

@@ -188,20 +188,23 @@ class InferenceNet(nn.Module):
             bufs = [tuple(torch.empty((n, 90, c), dtype=od, device=device) for _ in range(self.parts))
                     for _ in range(3)]
             last = torch.empty((n, 90, c), dtype=torch.float32 if self.parts == 2 else od, device=device)
-            self._bufs = {key: (n, bufs, last)}           # one device at a time
+            self._bufs[key] = (n, bufs, last)
         cap, bufs, last = self._bufs[key]
         if n == cap:
             return bufs, last
         return [tuple(t[:n] for t in b) for b in bufs], last[:n]
 
-    def _trunk_mfma(self, planes, heads=None):
+    def _trunk_mfma(self, planes, heads=None, rows=None, count=None):
         """planes: the evaluation queue as the search kernel wrote it ([n, in_planes, 10, 9], any supported dtype).
         heads = (n_policy, policy_feat, value_feat): fold the 1x1 head convolutions into the last block where the
         kernel exists for the shape (returns None then), else returns the [n, 90, c] trunk output."""
         from cchess_alphazero import _native
         n, c = planes.shape[0], self.filters
         (cur, tmp, nxt), last = self._operands(n, planes.device)
-        _native.input_conv(planes.contiguous(), self.in_w.view(self.operand_dtype), self.in_bias32, cur)
+        # compact queue (rows / count on the device): board i = planes[rows[i]] for i < count; the launch shapes stay
+        # those of the whole queue, the kernels read the count themselves
+        _native.input_conv(planes.contiguous(), self.in_w.view(self.operand_dtype), self.in_bias32, cur,
+                           rows=rows, count=count)
         nblk = len(self.res)
         # whole residual block in one launch where k_resblock exists for the shape
         fused = self.fused_blocks and ((c == 128) or (c in (192, 256) and self.parts == 1))
@@ -215,15 +218,15 @@ class InferenceNet(nn.Module):
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record()
                 if i + 1 < nblk:
-                    _native.resblock(cur, w1, b1, w2, b2, out=nxt)
+                    _native.resblock(cur, w1, b1, w2, b2, out=nxt, count=count)
                     cur, nxt = nxt, cur
                 elif heads is not None and self.parts == 2 and c == 128:
                     _native.resblock_heads(cur, w1, b1, w2, b2, self.head_w32, self.head_b32, heads[0], heads[1],
-                                           heads[2])
+                                           heads[2], count=count)
                 elif self.parts == 2:
-                    _native.resblock(cur, w1, b1, w2, b2, out_f32=last)
+                    _native.resblock(cur, w1, b1, w2, b2, out_f32=last, count=count)
                 else:
-                    _native.resblock(cur, w1, b1, w2, b2, out=(last,))
+                    _native.resblock(cur, w1, b1, w2, b2, out=(last,), count=count)
                 if ev is not None:
                     ev[1].record()
                     self.block_events.append(ev)
@@ -240,6 +243,13 @@ class InferenceNet(nn.Module):
             return None                                                  # the head features are already written
         return last                                                      # [n, 90, c] channels-last trunk output
 
+    def _head_feats(self, n, npol, device):
+        key = ("hf", n, str(device))
+        if key not in self._bufs:
+            self._bufs[key] = (torch.zeros((n, npol * 90), dtype=torch.float32, device=device),
+                               torch.zeros((n, (6 - npol) * 90), dtype=torch.float32, device=device))
+        return self._bufs[key]
+
     def _trunk_fused(self, x):
         """Trunk with the hand-written epilogue (csrc/xq_nn_epilogue.hip): every convolution is followed by ONE
         in-place pass  y = relu(y + bias (+ skip))  instead of PyTorch's separate bias / add / ReLU passes."""
@@ -254,17 +264,31 @@ class InferenceNet(nn.Module):
             x = _native.bias_act_(conv(c2, y).contiguous(memory_format=cl), c2.bias, residual=x)
         return x
 
+    def supports_compact_queue(self):
+        """True when the whole convolutional part runs on the hand-written kernels that take the board count from the
+        device (cz_*_q): 128-filter tower on the fused residual-block kernel, 4 + 2 head filters."""
+        return (self.trunk == "mfma" and self.fused_blocks and self.filters == 128 and
+                getattr(self, "head_w32", torch.empty(0)).shape[0] == 6)
+
     @torch.no_grad()
-    def forward(self, planes):
+    def forward(self, planes, rows=None, count=None):
+        """planes: the evaluation queue.  rows / count (int32 cuda tensors, cz_search_round_q): evaluate only the
+        boards planes[rows[i]], i < count -- the result rows are indexed by i; rows beyond count are undefined."""
+        if rows is not None and not self.supports_compact_queue():
+            raise RuntimeError("compact queue: needs the hand-written trunk (128 filters, fused blocks)")
         if self.trunk == "mfma":
             if not planes.is_cuda:
                 raise RuntimeError("trunk='mfma' is the hand-written HIP path: it has no CPU implementation")
             n, npol = planes.shape[0], self.policy_conv.out_channels
             if self.head_w32.shape[0] == 6:
                 from cchess_alphazero import _native
-                pf = torch.empty((n, npol * 90), dtype=torch.float32, device=planes.device)
-                vf = torch.empty((n, (6 - npol) * 90), dtype=torch.float32, device=planes.device)
-                last = self._trunk_mfma(planes, heads=(npol, pf, vf) if self.fused_heads else None)
+                if rows is not None:                         # persistent buffers: the tail rows keep old finite values
+                    pf, vf = self._head_feats(n, npol, planes.device)
+                else:
+                    pf = torch.empty((n, npol * 90), dtype=torch.float32, device=planes.device)
+                    vf = torch.empty((n, (6 - npol) * 90), dtype=torch.float32, device=planes.device)
+                last = self._trunk_mfma(planes, heads=(npol, pf, vf) if self.fused_heads else None,
+                                        rows=rows, count=count)
                 if last is not None:
                     _native.head_convs(last, self.head_w32, self.head_b32, npol, pf, vf)
                 p = self.policy_out(pf.to(self.dtype))

@@ -72,6 +72,7 @@ class EngineConfig(_Section):
                          pool_chunks=0,           # tree memory for all games in MiB; 0 = auto (<= 80 % of free HBM)
                          max_depth=0,
                          reload_seconds=600,      # self-play re-checks the best-model digest this often (api.py:37-44)
+                         compact_queue=True,      # evaluate only the queue slots that hold a new leaf (cz_search_round_q)
                          use_hip_graph=False, base_seed=0, report_every_rounds=200,
                          max_rounds=None, max_games=None)   # None = run forever, like the reference
 

@@ -61,6 +61,15 @@ template <> struct Mfma<_Float16> {
     }
 };
 
+// Compact evaluation queue (cz_*_q entry points): the number of boards comes from DEVICE memory (no host
+// synchronisation, the launch shape stays fixed so that a round can be replayed from a HIP graph) and the input
+// convolution gathers its planes through a row list.  Set by the _q entry points around the ordinary dispatch code.
+struct QueueCtx {
+    const int32_t* rows = nullptr;      // [n] queue slot of compact board i (input convolution only)
+    const int32_t* n_dev = nullptr;     // [1] boards to process (<= the n_boards argument)
+};
+thread_local QueueCtx g_q;
+
 constexpr int W_RING_MAX = 4;    // weight fragments in flight (register ring); 3 K-steps of prefetch
 constexpr int W_PAD_STEPS = 3;   // zero K-steps appended to the packed filter so the prefetch never reads past it
 
@@ -355,9 +364,13 @@ template <typename E, int C, int PARTS, int P, int DBG = 0, bool HEADS = false>
 __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_resblock(
     const E* __restrict__ xh, const E* __restrict__ xl, const E* __restrict__ w1p, const float* __restrict__ b1,
     const E* __restrict__ w2p, const float* __restrict__ b2, E* __restrict__ yh, E* __restrict__ yl,
-    float* __restrict__ yf, int n_boards, HeadArgs hd)
+    float* __restrict__ yf, int n_boards, HeadArgs hd, const int32_t* __restrict__ n_dev)
 {
     static_assert(!HEADS || (PARTS == 2 && C / 8 == 16), "fused heads: split operands, 128 filters");
+    if (n_dev) {                                        // compact queue: the board count lives on the device
+        const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
+        n_boards = nd < n_boards ? nd : n_boards;
+    }
     typedef Geom<C, P, PARTS> G;
     constexpr int NT = G::NT, CT = G::CT, CTHR = RB_COPY_THREADS;
     constexpr int SROW = PARTS == 2 ? C * 4 : C * 2;   // staging row (one pixel): fp32, or the final 2-byte values
@@ -585,8 +598,14 @@ template <typename PT> __device__ __forceinline__ float plane_to_f(PT v) { retur
 template <typename E, typename PT, int C, int IC16, int P, int PARTS>
 __global__ __launch_bounds__(C / 32 * 64, 1) void k_input_conv(
     const PT* __restrict__ planes, const E* __restrict__ wp, const float* __restrict__ bias, E* __restrict__ yh,
-    E* __restrict__ yl, int n_boards, int in_planes, int relu)
+    E* __restrict__ yl, int n_boards, int in_planes, int relu, const int32_t* __restrict__ rows,
+    const int32_t* __restrict__ n_dev)
 {
+    if (n_dev) {                                    // compact queue: the board count lives on the device
+        const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
+        n_boards = nd < n_boards ? nd : n_boards;
+        if ((int)blockIdx.x * P >= n_boards) return;
+    }
     typedef typename Mfma<E>::V8 V8;
     constexpr int RBI = IC16 * 32;                  // bytes per pixel row of the input image
     // 16 zero rows and a swizzle, as in Geom: the 256-byte bank row holds RPB = 8 (or 4) of these short pixel rows, so
@@ -609,9 +628,10 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_input_conv(
     {
         const int per_board = in_planes * 90;
         const int nb = n_boards - n0 < P ? n_boards - n0 : P;
-        const PT* src = planes + (size_t)n0 * per_board;
         for (int i = tid; i < nb * per_board; i += NTHR) {
             const int bb = i / per_board, r = i - bb * per_board;
+            // (compact queue: board n0 + bb of the batch is queue slot rows[n0 + bb])
+            const PT* src = planes + (size_t)(rows ? rows[n0 + bb] : n0 + bb) * per_board - (size_t)bb * per_board;
             const int c = r / 90, pix = r - c * 90;
             const int row = bb * 90 + pix;
             *reinterpret_cast<E*>(img + row * RBI + (((c >> 3) ^ ((row / RPB) & (CPRI - 1))) << 4) + (c & 7) * 2) =
@@ -908,7 +928,7 @@ int launch_input_conv(const void* planes, int in_planes, const void* wp, const f
     const unsigned blocks = (unsigned)((n + P - 1) / P);
 #define CZ_IC(IC16, PARTS)                                                                                       \
     hipLaunchKernelGGL((k_input_conv<E, PT, C, IC16, P, PARTS>), dim3(blocks), dim3(C / 32 * 64), 0, st,           \
-                       (const PT*)planes, (const E*)wp, bias, (E*)yh, (E*)yl, n, in_planes, relu)
+                       (const PT*)planes, (const E*)wp, bias, (E*)yh, (E*)yl, n, in_planes, relu, g_q.rows, g_q.n_dev)
     if (in_planes <= 16) {
         if (parts == 2) CZ_IC(1, 2); else CZ_IC(1, 1);
     } else {
@@ -974,7 +994,8 @@ int launch_resblock(const void* xh, const void* xl, const void* w1, const float*
     const int tiles = (n + P - 1) / P;
     const unsigned blocks = (unsigned)(tiles < n_cu ? tiles : n_cu);
     hipLaunchKernelGGL((k_resblock<E, C, PARTS, P, DBG, HEADS>), dim3(blocks), dim3((C / 32 + 4) * 64), 0, st,
-                       (const E*)xh, (const E*)xl, (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, yf, n, hd);
+                       (const E*)xh, (const E*)xl, (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, yf, n, hd,
+                       g_q.n_dev);
     return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
 }
 
@@ -1094,6 +1115,41 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
                       "use cz_conv3x3 otherwise");
     else if (rc != CZ_OK)
         czi_set_error("cz_resblock: launch failed");
+    return rc;
+}
+
+// ---- compact evaluation queue: the same kernels with a device-side board count (and a row gather in the input layer) ----
+extern "C" int cz_input_conv_q(const void* planes, int planes_dtype, int in_planes, const void* w_packed,
+                               const float* bias, void* y_hi, void* y_lo, int n_boards, int channels, int dtype,
+                               int parts, int relu, const int32_t* rows, const int32_t* n_dev, void* stream)
+{
+    g_q = QueueCtx{rows, n_dev};
+    const int rc = cz_input_conv(planes, planes_dtype, in_planes, w_packed, bias, y_hi, y_lo, n_boards, channels, dtype,
+                                 parts, relu, stream);
+    g_q = QueueCtx{};
+    return rc;
+}
+
+extern "C" int cz_resblock_q(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1,
+                             const void* w2_packed, const float* bias2, void* y_hi, void* y_lo, float* y_f32,
+                             int n_boards, int channels, int dtype, int parts, const int32_t* n_dev, void* stream)
+{
+    g_q = QueueCtx{nullptr, n_dev};
+    const int rc = cz_resblock(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo, y_f32, n_boards, channels,
+                               dtype, parts, stream);
+    g_q = QueueCtx{};
+    return rc;
+}
+
+extern "C" int cz_resblock_heads_q(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1,
+                                   const void* w2_packed, const float* bias2, const float* head_w, const float* head_b,
+                                   float* policy_feat, float* value_feat, int n_boards, int channels, int dtype,
+                                   int n_policy, int n_value, const int32_t* n_dev, void* stream)
+{
+    g_q = QueueCtx{nullptr, n_dev};
+    const int rc = cz_resblock_heads(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, head_w, head_b, policy_feat,
+                                     value_feat, n_boards, channels, dtype, n_policy, n_value, stream);
+    g_q = QueueCtx{};
     return rc;
 }
 

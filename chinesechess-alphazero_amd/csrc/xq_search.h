@@ -128,6 +128,7 @@ struct SearchBuffers {
     uint32_t* g_noise_epoch;   // [G]
     int8_t* g_prev_board;   // [G][96] game position two plies before the root (action(hist=...), 28-plane input)
     uint8_t* g_hist_kind;   // [G] 0 no game history, 1 g_prev_board valid, 2 history too short
+    int32_t* s_qrow;        // [G][K] compact evaluation-queue row of the slot's leaf (cz_search_round_q), -1 none
 };
 
 // finished-game record header (followed by uint16 moves[max_plies + 2])

@@ -1162,7 +1162,7 @@ constexpr int SIM_BACKUP = 1, SIM_SELECT = 2;
 
 template <bool HIST>        // HIST: 28 input planes (use_history); kept out of the common 14-plane instantiation
 __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, const float* __restrict__ policy,
-                                           const float* __restrict__ value, void* planes, int mask)
+                                           const float* __restrict__ value, void* planes, int mask, int compact)
 {
     __shared__ SearchLDS L;
     const int g = blockIdx.x;
@@ -1184,7 +1184,8 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             if (uni((int)gv.s_state[i]) != SIM_LEAF) continue;
             const int node = uni(gv.s_node[i]);
             const int depth = uni(gv.s_depth[i]);
-            const size_t slot = (size_t)g * P.K + i;
+            size_t slot = (size_t)g * P.K + i;
+            if (compact) slot = (size_t)uni(B.s_qrow[slot]);          // compact queue: the row k_queue_compact gave this leaf
             attach_policy(gv, L, node, policy + slot * NLABELS);
             load_path(P, gv, L, i, depth);
             backup(P, gv, L, depth, (double)value[slot]);             // float(v) of a float32
@@ -1359,6 +1360,35 @@ __global__ void k_pending(SearchParams P, SearchBuffers B)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < P.G && B.g_phase[g] == PH_SEARCH) atomicAdd(B.pending, 1);
+}
+
+// Compact evaluation queue: rows[0 .. count) = the queue slots that hold a new leaf, in slot order (deterministic);
+// s_qrow[slot] = its compact row.  One workgroup: per-thread counts over contiguous runs of slots, a block-wide
+// exclusive scan, then the writes.  The network then runs on `count` boards read from device memory (cz_*_q).
+__global__ __launch_bounds__(1024) void k_queue_compact(SearchParams P, SearchBuffers B, int32_t* __restrict__ rows,
+                                                        int32_t* __restrict__ count)
+{
+    __shared__ int part[1024];
+    const int n = P.G * P.K, tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = tid * per, hi = lo + per < n ? lo + per : n;
+    int c = 0;
+    for (int s = lo; s < hi; ++s) c += (B.s_state[s] == SIM_LEAF && B.g_phase[s / P.K] == PH_SEARCH) ? 1 : 0;
+    part[tid] = c;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                 // inclusive scan (Hillis-Steele)
+        const int v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int at = part[tid] - c;
+    for (int s = lo; s < hi; ++s) {
+        const bool leaf = B.s_state[s] == SIM_LEAF && B.g_phase[s / P.K] == PH_SEARCH;
+        B.s_qrow[s] = leaf ? at : -1;
+        if (leaf) rows[at++] = s;
+    }
+    if (tid == 1023) *count = part[1023];
 }
 
 // queue rows that hold a new leaf (a position the network has to evaluate) after a round, compacted; rows[] order is
@@ -1543,6 +1573,7 @@ size_t layout(cz_search* s, char* base, bool dry)
     carve(cur, B.g_noise_epoch, G, dry);
     carve(cur, B.g_prev_board, G * BOARD_LDS, dry);
     carve(cur, B.g_hist_kind, G, dry);
+    carve(cur, B.s_qrow, G * K, dry);
     return (size_t)(cur - base);
 }
 
@@ -1775,22 +1806,38 @@ int cz_search_set_roots(cz_search* s, const int8_t* boards, const int32_t* turns
     return CZ_OK;
 }
 
-int cz_search_round(cz_search* s, const float* policy, const float* value, void* planes, void* stream)
+static int search_round_impl(cz_search* s, const float* policy, const float* value, void* planes, int32_t* q_rows,
+                             int32_t* q_count, void* stream)
 {
-    if (!s || !planes || !policy || !value) return serr(CZ_ERR_ARG, "cz_search_round: null argument");
     const dim3 grid(s->P.G), block(64);
     hipStream_t st = (hipStream_t)stream;
     const bool noise = s->P.noise_eps != 0.0;
+    const int compact = q_rows ? 1 : 0;
     if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B, SIM_BACKUP);
     const bool hist = s->P.in_planes == 28;
-    if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP);
-    else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP);
+    if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP, compact);
+    else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP, compact);
     hipLaunchKernelGGL(k_advance, grid, block, 0, st, s->P, s->B);
     if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B, SIM_SELECT);
-    if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT);
-    else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT);
+    if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT, compact);
+    else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT, compact);
+    if (compact) hipLaunchKernelGGL(k_queue_compact, dim3(1), dim3(1024), 0, st, s->P, s->B, q_rows, q_count);
     S_LAUNCH_CHECK("cz_search_round");
     return CZ_OK;
+}
+
+int cz_search_round(cz_search* s, const float* policy, const float* value, void* planes, void* stream)
+{
+    if (!s || !planes || !policy || !value) return serr(CZ_ERR_ARG, "cz_search_round: null argument");
+    return search_round_impl(s, policy, value, planes, nullptr, nullptr, stream);
+}
+
+int cz_search_round_q(cz_search* s, const float* policy, const float* value, void* planes, int32_t* q_rows,
+                      int32_t* q_count, void* stream)
+{
+    if (!s || !planes || !policy || !value || !q_rows || !q_count)
+        return serr(CZ_ERR_ARG, "cz_search_round_q: null argument");
+    return search_round_impl(s, policy, value, planes, q_rows, q_count, stream);
 }
 
 int cz_search_set_sims(cz_search* s, int simulation_num_per_move)

@@ -156,6 +156,17 @@ int cz_search_set_roots(cz_search* s, const int8_t* boards, const int32_t* turns
  * planes written by the previous round; ignored for slots that had no leaf), planes [G*K][14 or 28][10][9]. */
 int cz_search_round(cz_search* s, const float* policy, const float* value, void* planes, void* stream);
 
+/* The same round with a COMPACT evaluation queue: only the slots that hold a new leaf are evaluated.  After the round
+ * q_rows[0 .. *q_count) (int32 DEVICE, slot order) lists those slots and *q_count (int32 DEVICE) their number; the
+ * caller evaluates planes[q_rows[i]] and writes the result to policy[i] / value[i] -- row i, not the slot -- which the
+ * NEXT cz_search_round_q consumes.  Nothing is copied to the host: run the network with the cz_*_q entry points, which
+ * read the board count from q_count on the device (fixed launch shapes: the round still replays from a HIP graph).
+ * Every call of one search object must use the same form (cz_search_round or cz_search_round_q) while simulations are
+ * in flight.  In self-play 2-7 % of the slots carry no leaf (terminal / repeated positions, parked simulations), with
+ * search_threads = 32-40 up to half of them. */
+int cz_search_round_q(cz_search* s, const float* policy, const float* value, void* planes, int32_t* q_rows,
+                      int32_t* q_count, void* stream);
+
 /* simulations per search for the following cz_search_set_roots calls (CChessPlayer.action(depth=...), player.py:160) */
 int cz_search_set_sims(cz_search* s, int simulation_num_per_move);
 int cz_search_reset_trees(cz_search* s, void* stream);
@@ -239,6 +250,20 @@ int cz_conv3x3_pack_weights(const float* w_oihw, int channels, int dtype, int pa
 int cz_input_conv(const void* planes, int planes_dtype, int in_planes, const void* w_packed, const float* bias,
                   void* y_hi, void* y_lo, int n_boards, int channels, int dtype, int parts, int relu, void* stream);
 size_t cz_input_conv_packed_elems(int channels, int in_planes, int parts);
+/* Compact-queue forms of the three kernels above (cz_search_round_q): the number of boards is min(n_boards, *n_dev)
+ * with n_dev in DEVICE memory (n_boards = the capacity of the buffers = the launch shape), and the input convolution
+ * reads board i from planes[rows[i]] (rows DEVICE int32, NULL = identity).  rows / n_dev may be NULL: then exactly the
+ * plain function. */
+int cz_input_conv_q(const void* planes, int planes_dtype, int in_planes, const void* w_packed, const float* bias,
+                    void* y_hi, void* y_lo, int n_boards, int channels, int dtype, int parts, int relu,
+                    const int32_t* rows, const int32_t* n_dev, void* stream);
+int cz_resblock_q(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1, const void* w2_packed,
+                  const float* bias2, void* y_hi, void* y_lo, float* y_f32, int n_boards, int channels, int dtype,
+                  int parts, const int32_t* n_dev, void* stream);
+int cz_resblock_heads_q(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1,
+                        const void* w2_packed, const float* bias2, const float* head_w, const float* head_b,
+                        float* policy_feat, float* value_feat, int n_boards, int channels, int dtype, int n_policy,
+                        int n_value, const int32_t* n_dev, void* stream);
 /* HOST: w_oihw[channels][in_planes][5][5] fp32 -> MFMA fragment order (cz_input_conv_packed_elems() elements) */
 int cz_input_conv_pack_weights(const float* w_oihw, int channels, int in_planes, int dtype, int parts, void* out_host);
 /* fp32 activation x[rows][channels] (+ bias[c], may be NULL) -> ReLU? -> (y_hi, y_lo) operand pair (parts = 2) or

@@ -291,3 +291,33 @@ def test_network_with_history_planes_and_reference_head_shapes():
     assert (p.cpu() - p_ref).abs().max().item() < 1e-4 and (v.cpu() - v_ref).abs().max().item() < 1e-4
     p2, v2 = inf(x.cuda())                                   # fp32 planes give the same answer
     assert torch.equal(p, p2) and torch.equal(v, v2)
+
+
+def test_network_on_a_compact_queue_matches_the_gathered_batch():
+    """cz_*_q (compact evaluation queue): rows / count live on the device.  The network evaluated on
+    (planes, rows, count) gives, in its first `count` result rows, bit for bit what it gives on the gathered batch
+    planes[rows[:count]] -- for count = 0, 1, an odd number and the whole queue -- and leaves the launch shapes alone."""
+    import torch
+    from cchess_alphazero.agent.model import CChessNet, InferenceNet
+    torch.manual_seed(11)
+    raw = CChessNet(cnn_filter_num=128, res_layer_num=3).eval()
+    for m in raw.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    net = InferenceNet(raw, torch.float32, trunk="mfma").cuda()
+    assert net.supports_compact_queue()
+    n = 77
+    planes = (torch.rand((n, 14, 10, 9), device="cuda") < 0.07).to(torch.uint8)
+    perm = torch.randperm(n, device="cuda").to(torch.int32)
+    for count in (0, 1, 33, n):
+        cnt = torch.tensor([count], dtype=torch.int32, device="cuda")
+        p, v = net(planes, rows=perm, count=cnt)
+        assert p.shape == (n, 2086) and v.shape == (n,)
+        if count:
+            pg, vg = net(planes[perm[:count].long()].contiguous())
+            assert torch.equal(p[:count], pg) and torch.equal(v[:count], vg)
+    # a count larger than the queue is clamped to it
+    p, v = net(planes, rows=perm, count=torch.tensor([10 * n], dtype=torch.int32, device="cuda"))
+    pg, vg = net(planes[perm.long()].contiguous())
+    assert torch.equal(p, pg) and torch.equal(v, vg)

@@ -154,6 +154,40 @@ def test_leaf_rows_are_the_only_rows_the_next_round_reads(gpu):
     s.close()
 
 
+def test_compact_queue_round_matches_the_slot_queue(gpu):
+    """cz_search_round_q: the rows q_rows[0 .. q_count) are exactly the leaf slots in slot order, and a search fed
+    through the compact queue (policy / value row i = result for planes[q_rows[i]], everything else NaN) gives the
+    oracle's visit counts -- no host synchronisation needed to know the count."""
+    t = gpu.torch
+    pc = play_config(simulation_num_per_move=150, search_threads=8)
+    spec = dict(kind="hash", salt=13)
+    states = [xo.INIT_STATE, MID, END, xo.step(xo.INIT_STATE, '7242')]
+    s = gpu.S.Search(pc, len(states), seed=7)
+    s.set_roots(boards_tensor(gpu, states))
+    ev = stub_eval(gpu, spec)
+    for _ in range(10000):
+        s.round(compact=True)
+        if s.pending() == 0:
+            break
+        n = int(s.q_count.item())
+        rows = s.q_rows[:n].long()
+        _, leaf = s.leaf_rows()
+        assert rows.tolist() == sorted(leaf.tolist())
+        s.policy.fill_(float("nan"))
+        s.value.fill_(float("nan"))
+        if n:
+            p, v = ev(s.planes.index_select(0, rows))
+            s.policy[:n] = p
+            s.value[:n] = v
+    st = s.root_stats()
+    for g, state in enumerate(states):
+        pl = xo.Player(oracle_cfg(pc), spec)
+        pl.search(state)
+        assert_root_equal(st, g, pl.node_stats(state), f"game {g}")
+        pl.close()
+    s.close()
+
+
 def test_no_act_and_choose(gpu):
     pc = play_config(simulation_num_per_move=150, search_threads=1, tau_decay_rate=0.98)
     spec = dict(kind="hash", salt=6)

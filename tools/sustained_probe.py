@@ -41,7 +41,7 @@ def main():
         for _ in range(a.chunk):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            eng.search.round()
+            eng._round()
             e1.record()
             ev.append((e0, e1))
             eng._forward()
