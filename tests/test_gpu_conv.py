@@ -295,7 +295,7 @@ def test_network_with_history_planes_and_reference_head_shapes():
 
 def test_network_on_a_compact_queue_matches_the_gathered_batch():
     """cz_*_q (compact evaluation queue): rows / count live on the device.  The network evaluated on
-    (planes, rows, count) gives, in its first `count` result rows, bit for bit what it gives on the gathered batch
+    (planes, rows, count) gives, in its first `count` result rows, what it gives on the gathered batch
     planes[rows[:count]] -- for count = 0, 1, an odd number and the whole queue -- and leaves the launch shapes alone."""
     import torch
     from cchess_alphazero.agent.model import CChessNet, InferenceNet
@@ -316,8 +316,9 @@ def test_network_on_a_compact_queue_matches_the_gathered_batch():
         assert p.shape == (n, 2086) and v.shape == (n,)
         if count:
             pg, vg = net(planes[perm[:count].long()].contiguous())
-            assert torch.equal(p[:count], pg) and torch.equal(v[:count], vg)
+            # (the convolutional part is bit-identical; the dense layers may pick another GEMM tiling for another M)
+            assert (p[:count] - pg).abs().max() < 1e-6 and (v[:count] - vg).abs().max() < 1e-6
     # a count larger than the queue is clamped to it
     p, v = net(planes, rows=perm, count=torch.tensor([10 * n], dtype=torch.int32, device="cuda"))
     pg, vg = net(planes[perm.long()].contiguous())
-    assert torch.equal(p, pg) and torch.equal(v, vg)
+    assert (p - pg).abs().max() < 1e-6 and (v - vg).abs().max() < 1e-6
