@@ -265,7 +265,9 @@ def run_arena(args, cfg):
     G = cfg.engine.games_per_gpu
     K = args.sims_per_round or 32
     cfg.opts.evaluate = False                                  # like `run.py eval` of the reference (manager.py:94-103)
-    w = EvaluateWorker(cfg, evaluators=tuple((lambda planes, n=n: n(planes)) for n in nets), dtype=_native.U8, seed=20260923)
+    w = EvaluateWorker(cfg, evaluators=tuple(nets), dtype=_native.U8, seed=20260923)
+    if args.trunk == "library":
+        w.compact = False
     marks = {}
 
     def on_ply(ply, counters_fn, rounds):
@@ -297,7 +299,7 @@ def run_arena(args, cfg):
                                   f"a step = one ply of the whole arena",
                       "games": G, "sims_per_round": K, "parallelism": "one GPU"},
            "sims_per_s": d["sims"] / dt, "rounds_timed": rounds, "ms_per_round": dt / max(1, rounds) * 1e3,
-           "queue_rows_per_model_round": G // 2 * K,
+           "queue_rows_per_model_round": G // 2 * K, "compact_queue": bool(w.compact),
            "rows_evaluated_per_round_whole_arena": stats["rows_evaluated"] / max(1, stats["rounds"]),
            "network_tflops": fl * d["expansions"] / dt / 1e12,
            "arena": {"games": G, "plies": stats["plies"], "rounds": stats["rounds"], "seconds": total,

@@ -68,11 +68,18 @@ class EvaluateWorker:
         self.config = config
         self.pid = pid
         if evaluators is None:
-            evaluators = (pipes1.evaluate_device, pipes2.evaluate_device)
+            # (the inference networks themselves when the pipes are this package's DevicePipe: they take the compact
+            #  queue; any other pipe is used through evaluate_device)
+            evaluators = tuple(getattr(getattr(p, "api", None), "net", None) or p.evaluate_device
+                               for p in (pipes1, pipes2))
         self.evaluators = evaluators
         self.dtype = dtype
         self.seed = seed
         self.concurrent = True         # the two models' searches of a ply on two streams / host threads
+        # compact evaluation queue (cz_search_round_q): both evaluators are inference networks whose kernels read the
+        # leaf count on the device
+        self.compact = all(callable(getattr(e, "supports_compact_queue", None)) and e.supports_compact_queue()
+                           for e in evaluators)
 
     def start(self):
         n = self.config.eval.game_num * max(1, self.config.play.max_processes)
@@ -186,6 +193,24 @@ class EvaluateWorker:
                 n_rounds = n_rows = 0
                 torch.cuda.set_device(dev)                  # (a fresh host thread starts on device 0)
                 with torch.cuda.stream(streams[k]):
+                    if self.compact:
+                        # Compact queue: the network reads the leaf rows and their count on the device, so nothing
+                        # has to come back to the host per round and the launches of the next round queue up behind
+                        # the running one.  A search of `sims` simulations needs at least sims / K + 1 rounds: the
+                        # first completion check (one synchronisation) is made there, then every other round; a round
+                        # after the searches are complete finds no leaf and costs almost nothing.
+                        first_check = max(1, -(-int(pc.simulation_num_per_move) // K))
+                        while True:
+                            s.round(compact=True)
+                            n_rounds += 1
+                            p, v = self.evaluators[k](s.planes, rows=s.q_rows, count=s.q_count)
+                            s.policy.copy_(p)
+                            s.value.copy_(v)
+                            if n_rounds >= first_check and (n_rounds - first_check) % 2 == 0:
+                                n_rows += int(s.q_count.item())          # (sampled: statistics only)
+                                if s.pending() == 0:
+                                    break
+                        return n_rounds, n_rows
                     while True:
                         s.round()
                         n_rounds += 1

@@ -168,6 +168,36 @@ def test_evaluator_arena_matches_oracle(tmp_path, monkeypatch, K, sims, tau):
     assert sum(table[1:]) == n and 0 <= table[0] <= n
 
 
+def test_evaluator_arena_on_the_compact_queue(tmp_path, monkeypatch):
+    """The arena with two real inference networks takes the compact-queue path (cz_search_round_q + cz_*_q: leaf rows
+    and their count stay on the device, one completion check every other round): it plays the same number of
+    simulations per ply as the slot-queue path and every game ends with a legal result."""
+    import torch
+    from cchess_alphazero import _native
+    from cchess_alphazero.agent.model import CChessNet, InferenceNet
+    from cchess_alphazero.worker.evaluator import EvaluateWorker, score_table
+    cfg = _cfg(tmp_path, monkeypatch, simulation_num_per_move=24, search_threads=8, noise_eps=0.0, tau_decay_rate=0.0,
+               c_puct=1.0, max_game_length=6)
+    nets = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        nets.append(InferenceNet(CChessNet(cnn_filter_num=128, res_layer_num=1), torch.float32, trunk="mfma").cuda())
+    out = {}
+    for compact in (True, False):
+        w = EvaluateWorker(cfg, evaluators=tuple(nets), dtype=_native.U8, seed=3)
+        assert w.compact
+        w.compact = compact
+        stats = {}
+        res = w.play_games(6, u_fn=lambda g, t: 0.5, stats=stats)
+        assert len(res) == 6 and all(v in (-1, 0, 1) and 0 < t <= 13 for v, t in res)
+        assert stats["overflow_sims"] == 0 and stats["tree_resets"] == 0
+        out[compact] = (res, stats["sims"], stats["plies"])
+        assert sum(score_table(res)[1:]) == 6
+    # same games either way (the networks see the same positions; only the batch composition differs)
+    assert out[True][2] == out[False][2] and out[True][1] == out[False][1]
+    assert out[True][0] == out[False][0]
+
+
 def test_run_py_self_cli(tmp_path):
     """`python cchess_alphazero/run.py self --type mini ...` (reference CLI) end to end: play records appear."""
     import subprocess
