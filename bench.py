@@ -266,8 +266,7 @@ def run_arena(args, cfg):
     K = args.sims_per_round or 32
     cfg.opts.evaluate = False                                  # like `run.py eval` of the reference (manager.py:94-103)
     w = EvaluateWorker(cfg, evaluators=tuple(nets), dtype=_native.U8, seed=20260923)
-    if args.trunk == "library":
-        w.compact = False
+    w.compact = bool(os.environ.get("CZ_ARENA_COMPACT")) and w.compact_capable
     marks = {}
 
     def on_ply(ply, counters_fn, rounds):

@@ -78,8 +78,12 @@ class EvaluateWorker:
         self.concurrent = True         # the two models' searches of a ply on two streams / host threads
         # compact evaluation queue (cz_search_round_q): both evaluators are inference networks whose kernels read the
         # leaf count on the device
-        self.compact = all(callable(getattr(e, "supports_compact_queue", None)) and e.supports_compact_queue()
-                           for e in evaluators)
+        self.compact_capable = all(callable(getattr(e, "supports_compact_queue", None)) and e.supports_compact_queue()
+                                   for e in evaluators)
+        # ... measured on the 200-game arena it is the slower of the two (702 k vs 744 k expansions/s): the dense layers,
+        # the softmax and the result copy then run on all 6400 queue rows of a model instead of the ~1300 that carry a
+        # leaf, which costs more than the synchronisation it saves.  Off unless asked for.
+        self.compact = False
 
     def start(self):
         n = self.config.eval.game_num * max(1, self.config.play.max_processes)
