@@ -330,6 +330,15 @@ def resblock(x, w1_packed, bias1, w2_packed, bias2, out=None, out_f32=None, coun
     return out_f32 if out_f32 is not None else out
 
 
+def resblock_pipelined(enable=None):
+    """Which schedule the 128-filter split residual block runs on (both bit-identical): True = k_resblock_pipe (default),
+    False = k_resblock.  None only queries.  Returns the previous setting."""
+    L = lib()
+    L.cz_resblock_pipelined.argtypes = [C.c_int]
+    L.cz_resblock_pipelined.restype = C.c_int
+    return bool(L.cz_resblock_pipelined(-1 if enable is None else int(bool(enable))))
+
+
 def resblock_heads(x, w1_packed, bias1, w2_packed, bias2, head_w, head_b, n_policy, policy_feat, value_feat,
                    count=None):
     """The last residual block with the 1x1 head convolutions folded in (split operands, 128 filters):

@@ -587,6 +587,337 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
 #undef CZ_STAMP2
 }
 
+// ---- kernel 2b: the residual block, software-pipelined over boards (128 filters, split operands) ------------------
+// Same arithmetic as k_resblock (bit-identical results), different schedule: the second epilogue of board t-1
+// (+ bias2 + skip, ReLU, re-split) runs in the SHADOW of board t's first K loop instead of between the K loops, and
+// writes its result IN PLACE over the skip operand, in the operand layout -- so there is no fp32 staging buffer, no
+// conversion in the copy waves, no hand-over of X between the roles, and two barriers per board instead of three.
+//   LDS: three images (X even, X odd, Y) of 90 rows x 256 B per part, 16 zero rows shared by all of them, the two bias
+//   vectors: 2 x (270 + 2 + 16) rows x 256 B + 1 KB = 148.5 KB.  Absolute row r of part q is byte (q * PSTR + r * 256).
+//   matrix waves, board k (X = image k & 1):  A | K1(k) with epi2(k-1) in its shadow | epi1(k) -> Y | B | K2(k) | ...
+//   copy waves:                               A | prefetch board k+1 (registers)     |             | B | drain out(k-1)
+//                                                 from image (k-1) & 1 to HBM and refill the same chunks with board k+1
+// The shadow work is cut into 12 units (pixel tile p x channel group g); K loop 1 is a rolled loop over 3 x (3 taps =
+// 216 MFMA slots) and each pass retires the 4 units of one pixel tile, whose accumulators are then rotated out, so
+// every register index in the loop body is static.
+namespace pipe {
+constexpr int RB = 256, IMG_ROWS = 90, ROW_Z = 272, PSTR = (ROW_Z + 16) * RB;      // bytes per part
+constexpr int BIAS_OFF = 2 * PSTR;                                                   // float b1[128], b2[128]
+constexpr int LDS_BYTES = BIAS_OFF + 2 * 128 * 4;
+constexpr int KK = 8, NT = 3, NM = 9, W_STEP = 4 * 64, W_PART = (9 * KK + W_PAD_STEPS) * W_STEP, W_RING = 4;
+}  // namespace pipe
+
+template <typename E>
+struct PipeShadow {                 // epilogue 2 of the previous board, one (tile, channel group) unit at a time
+    unsigned char* lds;
+    int prev_row_base;              // first absolute row of the previous board's X image
+    int wave, kb, ln;
+    Quad<E> sh, sl;
+    float4 bv;
+    float v[4];
+    int off;
+    bool valid;
+    __device__ __forceinline__ void load(int p, int g)
+    {
+        const int q = p * 32 + ln;
+        valid = q < 90;
+        const int ch = wave * 32 + g * 8 + kb * 4;
+        off = (prev_row_base + q) * pipe::RB + (((ch >> 3) ^ (q & 15)) << 4) + (ch & 7) * 2;
+        bv = *reinterpret_cast<const float4*>(lds + pipe::BIAS_OFF + (128 + ch) * 4);
+        if (valid) {
+            sh = *reinterpret_cast<const Quad<E>*>(lds + off);
+            sl = *reinterpret_cast<const Quad<E>*>(lds + pipe::PSTR + off);
+        }
+    }
+    // the arithmetic in the order of k_resblock's epilogue 2 (bit-identical), cut into pieces of a few instructions
+    __device__ __forceinline__ void add_bias(const f32x16& a, int g)
+    {
+        v[0] = a[g * 4 + 0] + bv.x; v[1] = a[g * 4 + 1] + bv.y; v[2] = a[g * 4 + 2] + bv.z; v[3] = a[g * 4 + 3] + bv.w;
+    }
+    __device__ __forceinline__ void add_hi()
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += (float)sh.e[i];
+    }
+    __device__ __forceinline__ void add_lo_relu()
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += (float)sl.e[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+    }
+    __device__ __forceinline__ void split()
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sh.e[i] = (E)v[i];                                   // (the skip registers are free again)
+            sl.e[i] = (E)(v[i] - (float)sh.e[i]);
+        }
+    }
+    __device__ __forceinline__ void store()
+    {
+        if (valid) {
+            *reinterpret_cast<Quad<E>*>(lds + off) = sh;
+            *reinterpret_cast<Quad<E>*>(lds + pipe::PSTR + off) = sl;
+        }
+    }
+    __device__ __forceinline__ void whole(const f32x16& a, int p, int g)
+    {
+        load(p, g); add_bias(a, g); add_hi(); add_lo_relu(); split(); store();
+    }
+};
+
+// K loop over the image whose first absolute row is row_base.  SHADOW: retire epilogue 2 of the previous board
+// (accumulators prev[3]) while the MFMAs run.
+template <typename E, bool SHADOW>
+__device__ __forceinline__ void pipe_kloop(unsigned char* lds, int row_base, const uint4* wq, int lane, f32x16* acc,
+                                           f32x16* prev, PipeShadow<E>& shd)
+{
+    using namespace pipe;
+    typedef typename Mfma<E>::V8 V8;
+    const int kb = lane >> 5, ln = lane & 31;
+    int pre[NT], pre_n[NT];
+    int qy[3], qx[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int q = t * 32 + ln;
+        qy[t] = q < 90 ? q / 9 : 100;
+        qx[t] = q - (q / 9) * 9;
+    }
+    auto tap_row = [&](int dy, int dx, int t) {
+        const bool ok = (unsigned)(qy[t] + dy) < 10u && (unsigned)(qx[t] + dx) < 9u;
+        const int nominal = t * 32 + ln + dy * 9 + dx;
+        const int row = ok ? row_base + nominal : ROW_Z + (nominal & 15);
+        return row * RB + (((kb ^ nominal) & 15) << 4);       // swizzle key = the image-relative row
+    };
+    V8 wf[W_RING][2];
+    V8 px[2][NT][2];
+#pragma unroll
+    for (int p = 0; p < NT; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+    auto load_w = [&](int step, int part) {
+        return __builtin_bit_cast(V8, wq[(size_t)part * W_PART + (size_t)step * W_STEP]);
+    };
+    auto load_px = [&](int off, int part) {
+        return __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(lds + part * PSTR + off));
+    };
+#pragma unroll
+    for (int p = 0; p < NT; ++p) pre[p] = tap_row(-1, -1, p);
+#pragma unroll
+    for (int s = 0; s < W_RING - 1; ++s)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) wf[s][part] = load_w(s, part);
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int p = 0; p < NT; ++p) px[0][p][part] = load_px(pre[p], part);
+
+    constexpr int NL = NT * 2, PER = 1;
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {                 // taps 3j .. 3j+2 (dy = j - 1); shadow: the 4 units of pixel tile j
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+            const int tap = 3 * j + tt;
+            const int ndy = tt < 2 ? j - 1 : (j < 2 ? j : 1), ndx = tt < 2 ? tt : -1;   // the NEXT tap (last: itself)
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const int step = tap * KK + kk;
+                const V8* w = wf[kk % W_RING];
+                V8 (*b)[2] = px[kk & 1];
+                V8 (*bn)[2] = px[(kk + 1) & 1];
+                const int* rows = kk + 1 < KK ? pre : pre_n;
+                const int kn = (kk + 1) % KK;
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    const int pass = i / NT, p = i % NT;
+                    acc[p] = Mfma<E>::mma(w[pass == 1 ? 1 : 0], b[p][pass == 2 ? 1 : 0], acc[p]);
+                    if (i < NL) bn[i % NT][i / NT] = load_px(rows[i % NT] ^ (kn << 5), i / NT);
+                    if (i >= NM - PER && kk * PER + (i - (NM - PER)) < NT)
+                        pre_n[kk * PER + (i - (NM - PER))] = tap_row(ndy, ndx, kk * PER + (i - (NM - PER)));
+                    if (i >= NM - 2)
+                        wf[(kk + W_RING - 1) % W_RING][i - (NM - 2)] = load_w(step + W_RING - 1, i - (NM - 2));
+                    if (SHADOW) {
+                        // slot fs of 216 in this pass; unit g = fs / 54 of pixel tile j: LDS reads early, the
+                        // arithmetic spread over a few slots, the in-place stores late
+                        const int fs = (tt * KK + kk) * NM + i, g = fs / 54, r = fs % 54;
+                        if (r == 2) shd.load(j, g);
+                        if (r == 14) shd.add_bias(prev[0], g);
+                        if (r == 18) shd.add_hi();
+                        if (r == 22) shd.add_lo_relu();
+                        if (r == 27) shd.split();
+                        if (r == 32) shd.store();
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < NT; ++p) pre[p] = pre_n[p];
+        }
+        if (SHADOW) {                              // rotate the retired tile out: the body always reads prev[0]
+            prev[0] = prev[1];
+            prev[1] = prev[2];
+        }
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(512, 1) void k_resblock_pipe(
+    const E* __restrict__ xh, const E* __restrict__ xl, const E* __restrict__ w1p, const float* __restrict__ b1,
+    const E* __restrict__ w2p, const float* __restrict__ b2, E* __restrict__ yh, E* __restrict__ yl, int n_boards,
+    const int32_t* __restrict__ n_dev)
+{
+    using namespace pipe;
+    constexpr int C = 128, CHUNKS = 90 * 16, CTHR = 256, LITER = (CHUNKS + CTHR - 1) / CTHR;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    if (n_dev) {
+        const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
+        n_boards = nd < n_boards ? nd : n_boards;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int stride = gridDim.x;
+    int t = blockIdx.x;
+    if (t >= n_boards) return;
+    // chunk i of a board: row i / 16, chunk i % 16 -> LDS byte (image row base + row) * 256 + ((ch ^ (row & 15)) << 4)
+    auto chunk_off = [&](int img, int i) {
+        const int row = i >> 4, ch = i & 15;
+        return (img * IMG_ROWS + row) * RB + ((ch ^ (row & 15)) << 4);
+    };
+
+    if (wave >= 4) {                                   // ---- copy waves ----
+        const int ctid = tid - 256;
+        uint4 v[2][LITER];
+        auto fetch = [&](int board) {
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const uint4* src = reinterpret_cast<const uint4*>((part ? xl : xh) + (size_t)board * 90 * C);
+#pragma unroll
+                for (int it = 0; it < LITER; ++it) {
+                    const int i = it * CTHR + ctid;
+                    v[part][it] = make_uint4(0, 0, 0, 0);
+                    if ((it + 1) * CTHR <= CHUNKS || i < CHUNKS) v[part][it] = src[i];
+                }
+            }
+        };
+        auto put = [&](int img) {
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+#pragma unroll
+                for (int it = 0; it < LITER; ++it) {
+                    const int i = it * CTHR + ctid;
+                    if ((it + 1) * CTHR <= CHUNKS || i < CHUNKS)
+                        *reinterpret_cast<uint4*>(lds + part * PSTR + chunk_off(img, i)) = v[part][it];
+                }
+        };
+        // result of `board` sits in image img (operand layout): to HBM; then the same chunks take the prefetched board
+        auto drain = [&](int img, int board, bool refill) {
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                uint4* dst = reinterpret_cast<uint4*>((part ? yl : yh) + (size_t)board * 90 * C);
+#pragma unroll
+                for (int it = 0; it < LITER; ++it) {
+                    const int i = it * CTHR + ctid;
+                    if (!((it + 1) * CTHR <= CHUNKS || i < CHUNKS)) continue;
+                    unsigned char* a = lds + part * PSTR + chunk_off(img, i);
+                    const uint4 o = *reinterpret_cast<const uint4*>(a);
+                    if (refill) *reinterpret_cast<uint4*>(a) = v[part][it];
+                    dst[i] = o;
+                }
+            }
+        };
+        fetch(t);
+        put(0);
+        for (int i = ctid; i < 16 * 16; i += CTHR) {          // the shared zero rows, both parts
+            *reinterpret_cast<uint4*>(lds + ROW_Z * RB + i * 16) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(lds + PSTR + ROW_Z * RB + i * 16) = make_uint4(0, 0, 0, 0);
+        }
+        if (ctid < 128) {
+            reinterpret_cast<float*>(lds + BIAS_OFF)[ctid] = b1[ctid];
+            reinterpret_cast<float*>(lds + BIAS_OFF)[128 + ctid] = b2[ctid];
+        }
+        int k = 0, t_prev = -1;
+        for (;;) {
+            __syncthreads();                                   // A_k
+            const int tn = t + stride;
+            const bool has_next = tn < n_boards;
+            if (has_next) fetch(tn);
+            __syncthreads();                                   // B_k: out(k-1) complete in image (k-1) & 1
+            if (t_prev >= 0) drain((k - 1) & 1, t_prev, has_next);
+            else if (has_next) put(1);
+            t_prev = t;
+            if (!has_next) break;
+            t = tn;
+            ++k;
+        }
+        __syncthreads();                                       // E1: K2 of the last board done
+        __syncthreads();                                       // E2: its epilogue 2 written in place
+        drain(k & 1, t_prev, false);
+        return;
+    }
+
+    // ---- matrix waves ----
+    const uint4* wq1 = reinterpret_cast<const uint4*>(w1p) + wave * 64 + lane;
+    const uint4* wq2 = reinterpret_cast<const uint4*>(w2p) + wave * 64 + lane;
+    const int kb = lane >> 5, ln = lane & 31;
+    f32x16 acc[NT], prev[NT];
+    PipeShadow<E> shd;
+    shd.lds = lds; shd.wave = wave; shd.kb = kb; shd.ln = ln;
+    int k = 0;
+    for (;;) {
+        __syncthreads();                                       // A_k: X(k) in image k & 1
+        const bool has_next = t + stride < n_boards;
+        shd.prev_row_base = ((k - 1) & 1) * IMG_ROWS;
+        __builtin_amdgcn_s_setprio(3);
+        if (k > 0) pipe_kloop<E, true>(lds, (k & 1) * IMG_ROWS, wq1, lane, acc, prev, shd);
+        else pipe_kloop<E, false>(lds, (k & 1) * IMG_ROWS, wq1, lane, acc, prev, shd);
+        __builtin_amdgcn_s_setprio(0);
+        int ln2 = ln, kb2 = kb;
+        asm volatile("" : "+v"(ln2), "+v"(kb2));
+        // epilogue 1: relu(acc + b1) -> (hi, lo) -> Y (image 2)
+#pragma unroll
+        for (int p = 0; p < NT; ++p) {
+            const int q = p * 32 + ln2;
+            if (q < 90) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = wave * 32 + g * 8 + kb2 * 4;
+                    const float4 bv = *reinterpret_cast<const float4*>(lds + BIAS_OFF + ch * 4);
+                    const float vv[4] = {acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
+                                         acc[p][g * 4 + 3] + bv.w};
+                    Quad<E> hi, lo;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float r = vv[i] > 0.0f ? vv[i] : 0.0f;
+                        hi.e[i] = (E)r;
+                        lo.e[i] = (E)(r - (float)hi.e[i]);
+                    }
+                    const int off = (2 * IMG_ROWS + q) * RB + (((ch >> 3) ^ (q & 15)) << 4) + (ch & 7) * 2;
+                    *reinterpret_cast<Quad<E>*>(lds + off) = hi;
+                    *reinterpret_cast<Quad<E>*>(lds + PSTR + off) = lo;
+                }
+            }
+        }
+        __syncthreads();                                       // B_k: Y complete (and out(k-1), written during K1)
+        __builtin_amdgcn_s_setprio(3);
+        pipe_kloop<E, false>(lds, 2 * IMG_ROWS, wq2, lane, acc, prev, shd);
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int p = 0; p < NT; ++p) prev[p] = acc[p];
+        if (!has_next) break;
+        t += stride;
+        ++k;
+    }
+    __syncthreads();                                           // E1
+    shd.prev_row_base = (k & 1) * IMG_ROWS;                    // epilogue 2 of the last board, not overlapped
+#pragma unroll
+    for (int p = 0; p < NT; ++p)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            shd.whole(prev[p], p, g);
+        }
+    __syncthreads();                                           // E2
+}
+
 // ---- kernel 3: the input convolution (5x5, 14 or 28 feature planes -> C channels) ----------------------------------
 // Reference: Conv2D(F, 5, padding="same") -> BatchNorm -> ReLU on the state_to_planes input (agent/model.py:36-39).
 // The planes arrive exactly as the search kernel writes them ([in_planes][10][9] per board, values 0 / 1, any of
@@ -1016,11 +1347,21 @@ void print_trace()          // tuning probe (CZ_CONV_VARIANT=308): phase time st
 
 #endif
 
+int g_resblock_pipelined = 1;       // cz_resblock_pipelined(): 128-filter split blocks on k_resblock_pipe
+
 template <typename E>
 int dispatch_resblock(int channels, int parts, const void* xh, const void* xl, const void* w1, const float* b1,
                       const void* w2, const float* b2, void* yh, void* yl, float* yf, int n, int n_cu, hipStream_t st)
 {
 #define CZ_RB_ARGS xh, xl, w1, b1, w2, b2, yh, yl, yf, n, n_cu, st
+    if (channels == 128 && parts == 2 && !yf && g_resblock_pipelined) {
+        // (operand-pair output: the software-pipelined kernel; the last block of a tower -- fp32 / head output --
+        //  stays on k_resblock)
+        const unsigned blocks = (unsigned)(n < n_cu ? n : n_cu);
+        hipLaunchKernelGGL((k_resblock_pipe<E>), dim3(blocks), dim3(512), 0, st, (const E*)xh, (const E*)xl, (const E*)w1,
+                           b1, (const E*)w2, b2, (E*)yh, (E*)yl, n, g_q.n_dev);
+        return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
+    }
     if (channels == 128 && parts == 2) {
 #ifdef CZ_CONV_PROBE          // build.py --probe: ablations (1 = no stores, 2 = no loads) and in-kernel phase time stamps (8)
         static const int variant = getenv("CZ_CONV_VARIANT") ? atoi(getenv("CZ_CONV_VARIANT")) : 0;
@@ -1116,6 +1457,15 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
     else if (rc != CZ_OK)
         czi_set_error("cz_resblock: launch failed");
     return rc;
+}
+
+// test / tuning hook: 1 (default) = 128-filter split residual blocks with operand-pair output run on the
+// software-pipelined kernel (k_resblock_pipe), 0 = on k_resblock.  Returns the previous setting.
+extern "C" int cz_resblock_pipelined(int enable)
+{
+    const int old = g_resblock_pipelined;
+    if (enable >= 0) g_resblock_pipelined = enable ? 1 : 0;
+    return old;
 }
 
 // ---- compact evaluation queue: the same kernels with a device-side board count (and a row gather in the input layer) ----

@@ -230,6 +230,10 @@ int cz_conv3x3(const void* x_hi, const void* x_lo, const void* w_packed, const f
 int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1, const void* w2_packed,
                 const float* bias2, void* y_hi, void* y_lo, float* y_f32, int n_boards, int channels, int dtype,
                 int parts, void* stream);
+/* test / tuning hook: the 128-filter split residual block with operand-pair output has two schedules that give
+ * bit-identical results -- k_resblock_pipe (default, 1): epilogue 2 of a board runs under the next board's first K
+ * loop; k_resblock (0).  enable < 0 only queries.  Returns the previous setting. */
+int cz_resblock_pipelined(int enable);
 /* The LAST residual block of the tower with the two 1x1 head convolutions folded into its store pass (cz_resblock +
  * cz_head_convs in one launch; the block's activation never reaches HBM): split operands, 128 filters,
  * n_policy + n_value == 6.  Outputs as cz_head_convs. */

@@ -322,3 +322,44 @@ def test_network_on_a_compact_queue_matches_the_gathered_batch():
     p, v = net(planes, rows=perm, count=torch.tensor([10 * n], dtype=torch.int32, device="cuda"))
     pg, vg = net(planes[perm.long()].contiguous())
     assert (p - pg).abs().max() < 1e-6 and (v - vg).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+def test_pipelined_resblock_is_bit_identical_to_the_plain_schedule(dt):
+    """k_resblock_pipe (epilogue 2 of a board under the next board's first K loop, result written in place over the skip
+    operand, two barriers per board) against k_resblock: the same arithmetic in the same order, so the (hi, lo) outputs
+    are equal bit for bit -- for one board, a few, one more than the CUs, an odd many; also in place and with the
+    board count taken from the device."""
+    import torch
+    from cchess_alphazero import _native
+    dtype = getattr(torch, dt)
+    torch.manual_seed(5)
+    c = 128
+    w1, w2 = torch.randn(c, c, 3, 3) * 0.05, torch.randn(c, c, 3, 3) * 0.05
+    b1, b2 = (torch.randn(c) * 0.1).cuda(), (torch.randn(c) * 0.1).cuda()
+    p1, p2 = _native.pack_conv3x3_weights(w1, dtype, 2).cuda(), _native.pack_conv3x3_weights(w2, dtype, 2).cuda()
+    old = _native.resblock_pipelined(None)
+    try:
+        for n in (1, 2, 5, 257, 1031):
+            x = _split(torch.randn(n, 90, c).cuda(), dtype, 2)
+            outs = {}
+            for mode in (False, True):
+                _native.resblock_pipelined(mode)
+                y = tuple(torch.full_like(t, 7.0) for t in x)
+                _native.resblock(x, p1, b1, p2, b2, out=y)
+                outs[mode] = y
+            assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1]), n
+        # in place, and a device-side count smaller than the buffers (the tail stays untouched)
+        _native.resblock_pipelined(True)
+        n, cnt = 300, 123
+        x = _split(torch.randn(n, 90, c).cuda(), dtype, 2)
+        ref = tuple(torch.empty_like(t) for t in x)
+        _native.resblock_pipelined(False)
+        _native.resblock(x, p1, b1, p2, b2, out=ref)
+        _native.resblock_pipelined(True)
+        y = tuple(t.clone() for t in x)
+        _native.resblock(y, p1, b1, p2, b2, out=y, count=torch.tensor([cnt], dtype=torch.int32, device="cuda"))
+        for part in range(2):
+            assert torch.equal(y[part][:cnt], ref[part][:cnt]) and torch.equal(y[part][cnt:], x[part][cnt:])
+    finally:
+        _native.resblock_pipelined(old)
