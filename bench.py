@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-micro", action="store_true", help="skip the 1M-board rule-kernel micro-suite")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--graph", action="store_true", help="replay each round from a HIP graph")
+    ap.add_argument("--plain-resblock", action="store_true",
+                    help="A/B: residual blocks on k_resblock instead of the software-pipelined k_resblock_pipe")
     ap.add_argument("--sustained-rounds", type=int, default=None,
                     help="rounds of the sustained leg that follows the timed steps (default 3000 at N=1 for the "
                          "'normal' config, 0 otherwise)")
@@ -333,6 +335,9 @@ def main():
     from cchess_alphazero.engine import SelfPlayEngine, bytes_per_expansion
 
     t_start = time.perf_counter()
+    if args.plain_resblock:
+        from cchess_alphazero import _native
+        _native.resblock_pipelined(False)
     cfg = build_config(args)
     if args.config == "eval":
         if world > 1:
