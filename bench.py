@@ -335,9 +335,9 @@ def main():
     from cchess_alphazero.engine import SelfPlayEngine, bytes_per_expansion
 
     t_start = time.perf_counter()
-    if args.plain_resblock:
+    if args.plain_resblock or os.environ.get("CZ_RESBLOCK_MODE"):
         from cchess_alphazero import _native
-        _native.resblock_pipelined(False)
+        _native.resblock_pipelined(int(os.environ.get("CZ_RESBLOCK_MODE", "0")))
     cfg = build_config(args)
     if args.config == "eval":
         if world > 1:

@@ -336,7 +336,7 @@ def resblock_pipelined(enable=None):
     L = lib()
     L.cz_resblock_pipelined.argtypes = [C.c_int]
     L.cz_resblock_pipelined.restype = C.c_int
-    return bool(L.cz_resblock_pipelined(-1 if enable is None else int(bool(enable))))
+    return L.cz_resblock_pipelined(-1 if enable is None else int(enable))
 
 
 def resblock_heads(x, w1_packed, bias1, w2_packed, bias2, head_w, head_b, n_policy, policy_feat, value_feat,

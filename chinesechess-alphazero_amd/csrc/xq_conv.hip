@@ -616,54 +616,41 @@ struct PipeShadow {                 // epilogue 2 of the previous board, one (ti
     float4 bv;
     float v[4];
     int off;
-    bool valid;
     __device__ __forceinline__ void load(int p, int g)
     {
         const int q = p * 32 + ln;
-        valid = q < 90;
         const int ch = wave * 32 + g * 8 + kb * 4;
-        off = (prev_row_base + q) * pipe::RB + (((ch >> 3) ^ (q & 15)) << 4) + (ch & 7) * 2;
+        // padding pixels (q >= 90) read and write a dump in the two unused rows 270 / 271 (8 bytes per lane) instead of
+        // being predicated: no exec-mask branches inside the MFMA loop
+        off = q < 90 ? (prev_row_base + q) * pipe::RB + (((ch >> 3) ^ (q & 15)) << 4) + (ch & 7) * 2
+                     : 270 * pipe::RB + (kb * 32 + ln) * 8;
         bv = *reinterpret_cast<const float4*>(lds + pipe::BIAS_OFF + (128 + ch) * 4);
-        if (valid) {
-            sh = *reinterpret_cast<const Quad<E>*>(lds + off);
-            sl = *reinterpret_cast<const Quad<E>*>(lds + pipe::PSTR + off);
-        }
+        sh = *reinterpret_cast<const Quad<E>*>(lds + off);
+        sl = *reinterpret_cast<const Quad<E>*>(lds + pipe::PSTR + off);
     }
-    // the arithmetic in the order of k_resblock's epilogue 2 (bit-identical), cut into pieces of a few instructions
-    __device__ __forceinline__ void add_bias(const f32x16& a, int g)
+    // the arithmetic in the order of k_resblock's epilogue 2 (bit-identical), one element and one stage at a time so
+    // that no MFMA slot gets more than a few VALU instructions
+    __device__ __forceinline__ void stage(const f32x16& a, int g, int st, int i)
     {
-        v[0] = a[g * 4 + 0] + bv.x; v[1] = a[g * 4 + 1] + bv.y; v[2] = a[g * 4 + 2] + bv.z; v[3] = a[g * 4 + 3] + bv.w;
-    }
-    __device__ __forceinline__ void add_hi()
-    {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += (float)sh.e[i];
-    }
-    __device__ __forceinline__ void add_lo_relu()
-    {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += (float)sl.e[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
-    }
-    __device__ __forceinline__ void split()
-    {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            sh.e[i] = (E)v[i];                                   // (the skip registers are free again)
-            sl.e[i] = (E)(v[i] - (float)sh.e[i]);
-        }
+        const float b = i == 0 ? bv.x : (i == 1 ? bv.y : (i == 2 ? bv.z : bv.w));
+        if (st == 0) v[i] = a[g * 4 + i] + b;
+        if (st == 1) v[i] += (float)sh.e[i];
+        if (st == 2) { v[i] += (float)sl.e[i]; v[i] = v[i] > 0.0f ? v[i] : 0.0f; }
+        if (st == 3) { sh.e[i] = (E)v[i]; sl.e[i] = (E)(v[i] - (float)sh.e[i]); }   // (the skip registers are free again)
     }
     __device__ __forceinline__ void store()
     {
-        if (valid) {
-            *reinterpret_cast<Quad<E>*>(lds + off) = sh;
-            *reinterpret_cast<Quad<E>*>(lds + pipe::PSTR + off) = sl;
-        }
+        *reinterpret_cast<Quad<E>*>(lds + off) = sh;
+        *reinterpret_cast<Quad<E>*>(lds + pipe::PSTR + off) = sl;
     }
     __device__ __forceinline__ void whole(const f32x16& a, int p, int g)
     {
-        load(p, g); add_bias(a, g); add_hi(); add_lo_relu(); split(); store();
+        load(p, g);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stage(a, g, st, i);
+        store();
     }
 };
 
@@ -742,11 +729,8 @@ __device__ __forceinline__ void pipe_kloop(unsigned char* lds, int row_base, con
                         // arithmetic spread over a few slots, the in-place stores late
                         const int fs = (tt * KK + kk) * NM + i, g = fs / 54, r = fs % 54;
                         if (r == 2) shd.load(j, g);
-                        if (r == 14) shd.add_bias(prev[0], g);
-                        if (r == 18) shd.add_hi();
-                        if (r == 22) shd.add_lo_relu();
-                        if (r == 27) shd.split();
-                        if (r == 32) shd.store();
+                        if (r >= 12 && r < 44 && (r & 1) == 0) shd.stage(prev[0], g, (r - 12) / 8, ((r - 12) / 2) % 4);
+                        if (r == 48) shd.store();
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -761,7 +745,7 @@ __device__ __forceinline__ void pipe_kloop(unsigned char* lds, int row_base, con
     }
 }
 
-template <typename E>
+template <typename E, bool TUNE_NO_SHADOW = false>
 __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
     const E* __restrict__ xh, const E* __restrict__ xl, const E* __restrict__ w1p, const float* __restrict__ b1,
     const E* __restrict__ w2p, const float* __restrict__ b2, E* __restrict__ yh, E* __restrict__ yl, int n_boards,
@@ -868,7 +852,7 @@ __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
         const bool has_next = t + stride < n_boards;
         shd.prev_row_base = ((k - 1) & 1) * IMG_ROWS;
         __builtin_amdgcn_s_setprio(3);
-        if (k > 0) pipe_kloop<E, true>(lds, (k & 1) * IMG_ROWS, wq1, lane, acc, prev, shd);
+        if (k > 0 && !TUNE_NO_SHADOW) pipe_kloop<E, true>(lds, (k & 1) * IMG_ROWS, wq1, lane, acc, prev, shd);
         else pipe_kloop<E, false>(lds, (k & 1) * IMG_ROWS, wq1, lane, acc, prev, shd);
         __builtin_amdgcn_s_setprio(0);
         int ln2 = ln, kb2 = kb;
@@ -1358,8 +1342,12 @@ int dispatch_resblock(int channels, int parts, const void* xh, const void* xl, c
         // (operand-pair output: the software-pipelined kernel; the last block of a tower -- fp32 / head output --
         //  stays on k_resblock)
         const unsigned blocks = (unsigned)(n < n_cu ? n : n_cu);
-        hipLaunchKernelGGL((k_resblock_pipe<E>), dim3(blocks), dim3(512), 0, st, (const E*)xh, (const E*)xl, (const E*)w1,
-                           b1, (const E*)w2, b2, (E*)yh, (E*)yl, n, g_q.n_dev);
+        if (g_resblock_pipelined == 2)      // tuning only (wrong results): the schedule without the shadowed epilogue
+            hipLaunchKernelGGL((k_resblock_pipe<E, true>), dim3(blocks), dim3(512), 0, st, (const E*)xh, (const E*)xl,
+                               (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, n, g_q.n_dev);
+        else
+            hipLaunchKernelGGL((k_resblock_pipe<E>), dim3(blocks), dim3(512), 0, st, (const E*)xh, (const E*)xl,
+                               (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, n, g_q.n_dev);
         return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
     }
     if (channels == 128 && parts == 2) {
@@ -1464,7 +1452,7 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
 extern "C" int cz_resblock_pipelined(int enable)
 {
     const int old = g_resblock_pipelined;
-    if (enable >= 0) g_resblock_pipelined = enable ? 1 : 0;
+    if (enable >= 0) g_resblock_pipelined = enable > 2 ? 1 : enable;
     return old;
 }
 
