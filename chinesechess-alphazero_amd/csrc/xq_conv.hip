@@ -656,7 +656,7 @@ struct PipeShadow {                 // epilogue 2 of the previous board, one (ti
 
 // K loop over the image whose first absolute row is row_base.  SHADOW: retire epilogue 2 of the previous board
 // (accumulators prev[3]) while the MFMAs run.
-template <typename E, bool SHADOW>
+template <typename E, bool SHADOW, int PROBE = 0>      // PROBE (timing only, wrong results): bit 0 no K-step XOR, bit 1 fixed weight address, bit 2 no tap-row arithmetic
 __device__ __forceinline__ void pipe_kloop(unsigned char* lds, int row_base, const uint4* wq, int lane, f32x16* acc,
                                            f32x16* prev, PipeShadow<E>& shd)
 {
@@ -719,11 +719,14 @@ __device__ __forceinline__ void pipe_kloop(unsigned char* lds, int row_base, con
                 for (int i = 0; i < NM; ++i) {
                     const int pass = i / NT, p = i % NT;
                     acc[p] = Mfma<E>::mma(w[pass == 1 ? 1 : 0], b[p][pass == 2 ? 1 : 0], acc[p]);
-                    if (i < NL) bn[i % NT][i / NT] = load_px(rows[i % NT] ^ (kn << 5), i / NT);
+                    if (i < NL) bn[i % NT][i / NT] = load_px((PROBE & 1) ? rows[i % NT] : rows[i % NT] ^ (kn << 5), i / NT);
                     if (i >= NM - PER && kk * PER + (i - (NM - PER)) < NT)
-                        pre_n[kk * PER + (i - (NM - PER))] = tap_row(ndy, ndx, kk * PER + (i - (NM - PER)));
+                        pre_n[kk * PER + (i - (NM - PER))] = (PROBE & 4) ? pre[kk * PER + (i - (NM - PER))]
+                                                                         : tap_row(ndy, ndx, kk * PER + (i - (NM - PER)));
                     if (i >= NM - 2)
-                        wf[(kk + W_RING - 1) % W_RING][i - (NM - 2)] = load_w(step + W_RING - 1, i - (NM - 2));
+                        wf[(kk + W_RING - 1) % W_RING][i - (NM - 2)] =
+                            (PROBE & 2) ? __builtin_bit_cast(V8, wq[(i - (NM - 2)) * W_PART])
+                                        : load_w(step + W_RING - 1, i - (NM - 2));
                     if (SHADOW) {
                         // slot fs of 216 in this pass; unit g = fs / 54 of pixel tile j: LDS reads early, the
                         // arithmetic spread over a few slots, the in-place stores late
@@ -745,7 +748,7 @@ __device__ __forceinline__ void pipe_kloop(unsigned char* lds, int row_base, con
     }
 }
 
-template <typename E, bool TUNE_NO_SHADOW = false>
+template <typename E, bool TUNE_NO_SHADOW = false, int PROBE = 0>
 __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
     const E* __restrict__ xh, const E* __restrict__ xl, const E* __restrict__ w1p, const float* __restrict__ b1,
     const E* __restrict__ w2p, const float* __restrict__ b2, E* __restrict__ yh, E* __restrict__ yl, int n_boards,
@@ -852,8 +855,8 @@ __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
         const bool has_next = t + stride < n_boards;
         shd.prev_row_base = ((k - 1) & 1) * IMG_ROWS;
         __builtin_amdgcn_s_setprio(3);
-        if (k > 0 && !TUNE_NO_SHADOW) pipe_kloop<E, true>(lds, (k & 1) * IMG_ROWS, wq1, lane, acc, prev, shd);
-        else pipe_kloop<E, false>(lds, (k & 1) * IMG_ROWS, wq1, lane, acc, prev, shd);
+        if (k > 0 && !TUNE_NO_SHADOW) pipe_kloop<E, true, PROBE>(lds, (k & 1) * IMG_ROWS, wq1, lane, acc, prev, shd);
+        else pipe_kloop<E, false, PROBE>(lds, (k & 1) * IMG_ROWS, wq1, lane, acc, prev, shd);
         __builtin_amdgcn_s_setprio(0);
         int ln2 = ln, kb2 = kb;
         asm volatile("" : "+v"(ln2), "+v"(kb2));
@@ -883,7 +886,7 @@ __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
         }
         __syncthreads();                                       // B_k: Y complete (and out(k-1), written during K1)
         __builtin_amdgcn_s_setprio(3);
-        pipe_kloop<E, false>(lds, 2 * IMG_ROWS, wq2, lane, acc, prev, shd);
+        pipe_kloop<E, false, PROBE>(lds, 2 * IMG_ROWS, wq2, lane, acc, prev, shd);
         __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int p = 0; p < NT; ++p) prev[p] = acc[p];
@@ -1345,6 +1348,14 @@ int dispatch_resblock(int channels, int parts, const void* xh, const void* xl, c
         if (g_resblock_pipelined == 2)      // tuning only (wrong results): the schedule without the shadowed epilogue
             hipLaunchKernelGGL((k_resblock_pipe<E, true>), dim3(blocks), dim3(512), 0, st, (const E*)xh, (const E*)xl,
                                (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, n, g_q.n_dev);
+#ifdef CZ_CONV_PROBE                    // build.py --probe: instruction-mix probes of the K loop (wrong results)
+#define CZ_PIPE_PROBE(M, PB)                                                                                          \
+        else if (g_resblock_pipelined == M)                                                                           \
+            hipLaunchKernelGGL((k_resblock_pipe<E, false, PB>), dim3(blocks), dim3(512), 0, st, (const E*)xh,            \
+                               (const E*)xl, (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, n, g_q.n_dev);
+        CZ_PIPE_PROBE(11, 1) CZ_PIPE_PROBE(12, 2) CZ_PIPE_PROBE(13, 3) CZ_PIPE_PROBE(14, 4) CZ_PIPE_PROBE(17, 7)
+#undef CZ_PIPE_PROBE
+#endif
         else
             hipLaunchKernelGGL((k_resblock_pipe<E>), dim3(blocks), dim3(512), 0, st, (const E*)xh, (const E*)xl,
                                (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, n, g_q.n_dev);
