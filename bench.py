@@ -497,8 +497,10 @@ def main():
             flops_launch = 2 * 2.0 * 90 * f * f * 9 * slots          # two 3x3 convolutions, 2 flop per MAC
             tfl = flops_launch / (b_ms * 1e-3) / 1e12
             pmc = pmc_nn("k_resblock")
-            out["roofline"] = {"kernel": "k_resblock (csrc/xq_conv.hip): one residual block (2 x conv3x3 + bias + skip "
-                                         "+ ReLU) of the tower per launch, split-bf16 operands",
+            out["roofline"] = {"kernel": "k_resblock_pipe / k_resblock (csrc/xq_conv.hip): one residual block (2 x conv3x3 + "
+                                         "bias + skip + ReLU) of the tower per launch, split-bf16 operands; the inner "
+                                         "blocks run the software-pipelined schedule, the last one (fused head "
+                                         "convolutions) the plain one; mean over all launches of the tower",
                                "bound": "mfma", "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s", "frac": tfl / 2500.0,
                                "traffic": pmc.get("hbm_bytes_per_launch"), "traffic_source": pmc.get("source"),
                                "avg_launch_ms": b_ms, "launches_timed": len(blk),
