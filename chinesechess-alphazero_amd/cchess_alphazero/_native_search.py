@@ -47,6 +47,8 @@ def declare(L):
     L.cz_search_stop.argtypes = [vp, vp]
     L.cz_search_stop.restype = i32
     L.cz_search_choose.argtypes = [vp, vp, vp, vp]
+    L.cz_search_pv.argtypes = [vp, i32, vp, vp, vp]
+    L.cz_search_pv.restype = i32
     L.cz_search_counters.argtypes = [vp, vp, vp]
     L.cz_search_drain_records.argtypes = [vp, C.POINTER(C.c_uint), vp, i32, C.POINTER(C.c_int), vp]
     L.cz_debug_sqrt.argtypes = [vp, vp, i32, vp]
@@ -258,6 +260,16 @@ class Search:
                                                   self._stream()), "cz_search_root_stats")
         return dict(moves=moves.cpu().numpy(), n=n.cpu().numpy(), w=w.cpu().numpy(), p=p.cpu().numpy(),
                     sum_n=sum_n.cpu().numpy(), counts=counts.cpu().numpy())
+
+    def pv(self, max_len=20):
+        """Principal variation of every game (one launch, one copy): list of label lists."""
+        import torch
+        moves = torch.empty((self.G, max_len), dtype=torch.uint16, device=self.device)
+        visits = torch.empty((self.G, max_len), dtype=torch.int32, device=self.device)
+        _native.check(self.L.cz_search_pv(self.h, int(max_len), C.c_void_p(moves.data_ptr()),
+                                          C.c_void_p(visits.data_ptr()), self._stream()), "cz_search_pv")
+        mv = moves.cpu().numpy()
+        return [[int(x) for x in row[row != 0xFFFF]] for row in mv]
 
     def choose(self, u=None):
         import torch

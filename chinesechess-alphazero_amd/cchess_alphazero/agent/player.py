@@ -127,25 +127,9 @@ class CChessPlayer:
 
     def principal_variation(self, state, no_act=None, max_len=20):
         """Most-visited line from the root (print_depth_info, player.py:408-433: `>=` keeps the LAST maximum; banned
-        moves are skipped at the root only).  Returns the moves in the mover's frame of each ply."""
-        path, pv = [], []
-        for ply in range(max_len):
-            node = self._node(self._search.node_stats(path))
-            # the reference creates a node's edges at the first selection from it (player.py:274-286): an expanded but
-            # never-selected node has an empty `a` there and ends the line
-            if node is None or not node.a or all(a.n == 0 for a in node.a.values()):
-                break
-            best, n = None, 0
-            for mov, a in node.a.items():
-                if a.n >= n:
-                    if ply == 0 and no_act and mov in no_act:
-                        continue
-                    n, best = a.n, mov
-            if best is None:
-                break
-            pv.append(best)
-            path.append(self.move_lookup[best])
-        return pv
+        moves are skipped at the root only; the line ends at a node that was never selected from).  One kernel launch
+        (cz_search_pv; the bans are those of the running search).  Returns the moves in the mover's frame of each ply."""
+        return [self.labels[m] for m in self._search.pv(max_len)[0]]
 
     def print_depth_info(self, state, turns, start_time, value, no_act):
         """`info depth .. score .. time .. pv .. nps ..` (player.py:408-450)."""

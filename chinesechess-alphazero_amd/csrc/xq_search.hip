@@ -1458,6 +1458,55 @@ __global__ __launch_bounds__(64) void k_root_stats(SearchParams P, SearchBuffers
     }
 }
 
+// Principal variation (print_depth_info, player.py:408-433): from the root follow the most-visited edge -- `>=` keeps
+// the LAST maximum, banned moves are skipped at the root only -- until a node that was never selected from (the
+// reference creates a node's edges at its first selection: an empty `a` ends the line), a terminal / unlinked child or
+// max_len moves.  moves [G][max_len] (NOMOVE padded), visits [G][max_len].
+__global__ __launch_bounds__(64) void k_pv(SearchParams P, SearchBuffers B, int max_len, uint16_t* __restrict__ moves,
+                                          int32_t* __restrict__ visits)
+{
+    __shared__ uint32_t chtab[MAX_CHUNKS];
+    const int g = blockIdx.x;
+    if (g >= P.G) return;
+    const GameView gv = make_view(B, P, g, B.counters + (size_t)g * CT_COUNT, chtab);
+    const int lane = lane_id();
+    const int n_no_act = B.g_n_no_act[g];
+    const uint16_t* no_act = B.g_no_act + (size_t)g * MAX_NO_ACT;
+    int node = B.g_root[g];
+    int d = 0;
+    for (; d < max_len && node >= 0; ++d) {
+        char* base = rec_ptr(gv, (uint32_t)node);
+        const NodeHdr hdr = load_hdr(base);
+        const int nm = (int)(hdr.meta & 0xFF);
+        if (hdr.stat == 0u || nm == 0) break;
+        const uint16_t* pm = node_mv(base, nm);
+        const EdgeStat* sb = edge_ptr(gv, hdr.stat);
+        int best_n = 0, best_j = -1;                          // per lane: last j with n >= running maximum
+        for (int j = lane; j < nm; j += 64) {
+            const int n = sb[j].n;
+            bool banned = false;
+            if (d == 0) for (int k = 0; k < n_no_act; ++k) banned = banned || (no_act[k] == pm[j]);
+            if (!banned && n >= best_n) { best_n = n; best_j = j; }
+        }
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {                   // arg max of (n, j)
+            const int on = __shfl_xor(best_n, s, 64), oj = __shfl_xor(best_j, s, 64);
+            if (oj >= 0 && (best_j < 0 || on > best_n || (on == best_n && oj > best_j))) { best_n = on; best_j = oj; }
+        }
+        best_n = uni(best_n); best_j = uni(best_j);
+        if (best_j < 0 || best_n <= 0) break;
+        if (lane == 0) {
+            moves[(size_t)g * max_len + d] = pm[best_j];
+            visits[(size_t)g * max_len + d] = best_n;
+        }
+        node = uni(sb[best_j].child);
+    }
+    for (int i = d + lane; i < max_len; i += 64) {
+        moves[(size_t)g * max_len + i] = (uint16_t)NOMOVE;
+        visits[(size_t)g * max_len + i] = 0;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_choose(SearchParams P, SearchBuffers B, const double* __restrict__ u,
                                               int32_t* __restrict__ action)
 {
@@ -1916,6 +1965,14 @@ int cz_search_node_stats(cz_search* s, const uint16_t* path, int path_len, uint1
     hipLaunchKernelGGL(k_root_stats, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, path, path_len, moves, n, w,
                        p, sum_n, counts);
     S_LAUNCH_CHECK("cz_search_node_stats");
+    return CZ_OK;
+}
+
+int cz_search_pv(cz_search* s, int max_len, uint16_t* moves, int32_t* visits, void* stream)
+{
+    if (!s || !moves || !visits || max_len < 1) return serr(CZ_ERR_ARG, "cz_search_pv: bad argument");
+    hipLaunchKernelGGL(k_pv, dim3(s->P.G), dim3(64), 0, (hipStream_t)stream, s->P, s->B, max_len, moves, visits);
+    S_LAUNCH_CHECK("cz_search_pv");
     return CZ_OK;
 }
 

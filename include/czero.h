@@ -188,6 +188,10 @@ int cz_search_root_stats(cz_search* s, uint16_t* moves, int32_t* n, double* w, f
  * principal variation player.py:408-450). */
 int cz_search_node_stats(cz_search* s, const uint16_t* path, int path_len, uint16_t* moves, int32_t* n, double* w,
                          float* p, int32_t* sum_n, uint8_t* counts, void* stream);
+/* principal variation of every game in one launch (player.py:408-433: the most-visited edge at each node, `>=` keeps
+ * the last maximum, the bans of the current search apply at the root): moves [G][max_len] uint16 (0xFFFF padded),
+ * visits [G][max_len] int32, both DEVICE. */
+int cz_search_pv(cz_search* s, int max_len, uint16_t* moves, int32_t* visits, void* stream);
 /* stop starting simulations in every running search (UCI `stop`, CChessPlayer.close_and_return_action,
  * player.py:88-106): the next cz_search_round backs up what is in flight and the searches become idle */
 int cz_search_stop(cz_search* s, void* stream);
