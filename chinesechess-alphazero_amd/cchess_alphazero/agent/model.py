@@ -271,9 +271,11 @@ class InferenceNet(nn.Module):
                 getattr(self, "head_w32", torch.empty(0)).shape[0] == 6)
 
     @torch.no_grad()
-    def forward(self, planes, rows=None, count=None):
+    def forward(self, planes, rows=None, count=None, out=None):
         """planes: the evaluation queue.  rows / count (int32 cuda tensors, cz_search_round_q): evaluate only the
-        boards planes[rows[i]], i < count -- the result rows are indexed by i; rows beyond count are undefined."""
+        boards planes[rows[i]], i < count -- the result rows are indexed by i; rows beyond count are undefined.
+        out = (policy [n, 2086] fp32, value [n] fp32): write the results there (the engine's queue tensors) instead of
+        into fresh tensors."""
         if rows is not None and not self.supports_compact_queue():
             raise RuntimeError("compact queue: needs the hand-written trunk (128 filters, fused blocks)")
         if self.trunk == "mfma":
@@ -293,6 +295,10 @@ class InferenceNet(nn.Module):
                     _native.head_convs(last, self.head_w32, self.head_b32, npol, pf, vf)
                 p = self.policy_out(pf.to(self.dtype))
                 v = F.relu(self.value_dense(vf.to(self.dtype)))
+                if out is not None:                            # straight into the search object's queue tensors
+                    torch.softmax(p.float(), dim=1, out=out[0])
+                    torch.tanh(self.value_out(v).float(), out=out[1].view(-1, 1))
+                    return out
                 v = torch.tanh(self.value_out(v).float())
                 return F.softmax(p.float(), dim=1), v.squeeze(1)
             last = self._trunk_mfma(planes)

@@ -122,10 +122,14 @@ class SelfPlayEngine:
         s = self.search
         if self.evaluator is not None:
             p, v = self.evaluator(s.planes)
-        elif self.compact:
-            p, v = self.net(s.planes, rows=s.q_rows, count=s.q_count)
         else:
-            p, v = self.net(s.planes)
+            out = (s.policy, s.value)
+            if self.compact:
+                p, v = self.net(s.planes, rows=s.q_rows, count=s.q_count, out=out)
+            else:
+                p, v = self.net(s.planes, out=out)
+            if p is s.policy:                                  # written in place (the hand-written network path)
+                return
         s.policy.copy_(p)
         s.value.copy_(v)
 
