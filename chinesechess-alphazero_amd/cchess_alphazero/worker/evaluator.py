@@ -90,6 +90,22 @@ class EvaluateWorker:
         results = self.play_games(n)
         return score_table(results)
 
+    def _capture_round(self, s, k, stream):
+        """One model-round on the compact queue as a HIP graph: cz_search_round_q + the forward of model k straight into
+        the search object's policy / value tensors.  One eager round first (allocations, library warm-up), then the
+        capture (which executes nothing)."""
+        import torch
+
+        def one_round():
+            s.round(compact=True)
+            self.evaluators[k](s.planes, rows=s.q_rows, count=s.q_count, out=(s.policy, s.value))
+        one_round()
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+            one_round()
+        return g
+
     # ------------------------------------------------------------------------------------------------
     def play_games(self, n_games, u_fn=None, indices=None, init_state=None, trace=None, stats=None, on_ply=None,
                    sims_per_round=None):
@@ -132,6 +148,7 @@ class EvaluateWorker:
         rounds = rows_evaluated = 0
         from concurrent.futures import ThreadPoolExecutor
         streams = [torch.cuda.Stream(dev) for _ in range(2)]
+        graphs, warm = [None, None], {}
         pool = ThreadPoolExecutor(max_workers=2)
         if trace is not None:
             from cchess_alphazero.environment.lookup_tables import ActionLabelsRed
@@ -198,18 +215,17 @@ class EvaluateWorker:
                 torch.cuda.set_device(dev)                  # (a fresh host thread starts on device 0)
                 with torch.cuda.stream(streams[k]):
                     if self.compact:
-                        # Compact queue: the network reads the leaf rows and their count on the device, so nothing
-                        # has to come back to the host per round and the launches of the next round queue up behind
-                        # the running one.  A search of `sims` simulations needs at least sims / K + 1 rounds: the
-                        # first completion check (one synchronisation) is made there, then every other round; a round
-                        # after the searches are complete finds no leaf and costs almost nothing.
+                        # Compact queue: the network reads the leaf rows and their count on the device, so a whole
+                        # model-round (tree kernels, compaction, forward into the queue tensors) has fixed launch
+                        # shapes and is replayed from a HIP graph: no host work per round but one graph launch.  A
+                        # search of `sims` simulations needs at least sims / K + 1 rounds: the first completion check
+                        # (one synchronisation) is made there, then every other round; a round after the searches
+                        # are complete finds no leaf and costs almost nothing.
                         first_check = max(1, -(-int(pc.simulation_num_per_move) // K))
+                        n_rounds = warm.pop(k, 0)              # (the eager round that preceded this model's capture)
                         while True:
-                            s.round(compact=True)
+                            graphs[k].replay()
                             n_rounds += 1
-                            p, v = self.evaluators[k](s.planes, rows=s.q_rows, count=s.q_count)
-                            s.policy.copy_(p)
-                            s.value.copy_(v)
                             if n_rounds >= first_check and (n_rounds - first_check) % 2 == 0:
                                 n_rows += int(s.q_count.item())          # (sampled: statistics only)
                                 if s.pending() == 0:
@@ -231,6 +247,12 @@ class EvaluateWorker:
             main = torch.cuda.current_stream(dev)
             for k in active:
                 streams[k].wait_stream(main)
+            if self.compact:                                   # captured here, one after the other: the worker threads only replay
+                for k in active:
+                    if graphs[k] is None:
+                        with torch.cuda.stream(streams[k]):
+                            graphs[k] = self._capture_round(searches[k], k, streams[k])
+                        warm[k] = 1
             if len(active) == 2 and self.concurrent:
                 done = list(pool.map(search_ply, active))
             else:
