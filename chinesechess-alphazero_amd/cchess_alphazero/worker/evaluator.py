@@ -80,9 +80,11 @@ class EvaluateWorker:
         # leaf count on the device
         self.compact_capable = all(callable(getattr(e, "supports_compact_queue", None)) and e.supports_compact_queue()
                                    for e in evaluators)
-        # ... measured on the 200-game arena it is the slower of the two (702 k vs 744 k expansions/s): the dense layers,
-        # the softmax and the result copy then run on all 6400 queue rows of a model instead of the ~1300 that carry a
-        # leaf, which costs more than the synchronisation it saves.  Off unless asked for.
+        # ... measured on the 200-game arena it is the slower of the two (694 k expansions/s replayed from one HIP graph
+        # per model-round, 702 k launched eagerly, against 744 k for gathered leaf rows): host work is not what limits
+        # an arena round -- 200 wavefronts walking K = 32 simulations one after the other are (~1.3 ms per k_sim
+        # launch, as long as the forward it feeds) -- while the compact form runs the dense layers, the softmax and the
+        # input convolution's grid over all 6400 queue rows of a model.  Off unless asked for.
         self.compact = False
 
     def start(self):
