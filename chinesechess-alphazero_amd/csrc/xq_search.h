@@ -117,6 +117,7 @@ struct SearchBuffers {
     uint8_t* g_enable_resign;  // [G]
     int32_t* g_no_eat;      // [G]
     uint32_t* g_hist_key;   // [G][max_plies + 2][12]
+    uint64_t* g_hist_hash;  // [G][max_plies + 2] hash of the key (repetition scan: 64 plies per ballot)
     uint16_t* g_hist_act;   // [G][max_plies + 2]
     // ---- outputs ----
     unsigned long long* counters;   // [G][CT_COUNT]

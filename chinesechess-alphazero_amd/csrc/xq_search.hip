@@ -1012,8 +1012,9 @@ XQ_D void new_game(const SearchParams& P, const SearchBuffers& B, const GameView
     L.r.bd[1][lane] = gb[lane];
     if (lane < 32) L.r.bd[1][lane + 64] = gb[lane + 64];
     wave_sync_global();
-    pack_key(L.r.bd[1], L.key);
+    const uint64_t h0 = pack_key(L.r.bd[1], L.key);
     store_key(B.g_hist_key + (size_t)g * (P.max_plies + 2) * KEY_WORDS, L.key);
+    if (lane == 0) B.g_hist_hash[(size_t)g * (P.max_plies + 2)] = h0;
     if (lane == 0) {
         B.g_game_id[g] = game_id;
         B.g_turns[g] = 0;
@@ -1083,8 +1084,11 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
         int no_eat_count = uni(B.g_no_eat[g]);
         no_eat_count = no_eat ? no_eat_count + 1 : 0;
         const uint64_t h = pack_key(L.r.bd[3], L.key);
-        (void)h;
-        if (turns < P.max_plies + 2) store_key(hkeys + (size_t)turns * KEY_WORDS, L.key);
+        uint64_t* hhash = B.g_hist_hash + (size_t)g * (P.max_plies + 2);
+        if (turns < P.max_plies + 2) {
+            store_key(hkeys + (size_t)turns * KEY_WORDS, L.key);
+            if (lane == 0) hhash[turns] = h;
+        }
         int n_no_act = 0, inc = 0;
         if (no_eat_count >= 120 || turns >= 2 * P.max_game_length) {    // :149-151
             game_over = true; value = 0;
@@ -1095,18 +1099,17 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
             if (!game_over && !d.check) {                               // :161-175
                 int free_move = 0;
                 // earlier states equal to this one, in order (both parities: the reference compares strings)
-                // (five earlier plies per step: lanes 12 s .. 12 s + 11 compare the key of ply base + s, one ballot
-                //  tells which of the five are equal; a ply-at-a-time scan is 200 dependent memory round trips)
-                for (int base = 0; base < turns && !game_over; base += 5) {
-                  const int cmp_ply = base + lane / KEY_WORDS, cmp_w = lane % KEY_WORDS;
-                  bool differs = true;
-                  if (lane < 5 * KEY_WORDS && cmp_ply < turns)
-                      differs = hkeys[(size_t)cmp_ply * KEY_WORDS + cmp_w] != L.key[cmp_w];
-                  const uint64_t dm = __ballot(differs);
-                  for (int sub = 0; sub < 5 && !game_over; ++sub) {
-                    const int i = base + sub;
-                    if (i >= turns) break;
-                    if ((dm >> (KEY_WORDS * sub)) & 0xFFFull) continue;
+                // (64 earlier plies per step: lane l compares the 64-bit hash of ply base + l, one ballot lists the
+                //  candidates, which are then verified word by word; a ply-at-a-time scan was 200 dependent memory
+                //  round trips per move late in a game)
+                for (int base = 0; base < turns && !game_over; base += 64) {
+                  const int cmp_ply = base + lane;
+                  uint64_t cand = __ballot(cmp_ply < turns && hhash[cmp_ply] == h);
+                  while (cand && !game_over) {
+                    const int i = base + __ffsll((long long)cand) - 1;
+                    cand &= cand - 1;
+                    const bool differs = lane < KEY_WORDS && hkeys[(size_t)i * KEY_WORDS + lane] != L.key[lane];
+                    if (__ballot(differs)) continue;                  // a hash collision
                     const int mv = uni((int)hacts[i]);
                     // the rule helpers need the position in bd[0]
                     L.r.bd[0][lane] = L.r.bd[3][lane];
@@ -1612,6 +1615,7 @@ size_t layout(cz_search* s, char* base, bool dry)
     carve(cur, B.g_enable_resign, G, dry);
     carve(cur, B.g_no_eat, G, dry);
     carve(cur, B.g_hist_key, G * PL * KEY_WORDS, dry);
+    carve(cur, B.g_hist_hash, G * PL, dry);
     carve(cur, B.g_hist_act, G * PL, dry);
     carve(cur, B.counters, G * CT_COUNT, dry);
     carve(cur, B.ring, (size_t)P.ring_cap * P.record_stride, dry);
