@@ -1188,7 +1188,10 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             const int node = uni(gv.s_node[i]);
             const int depth = uni(gv.s_depth[i]);
             size_t slot = (size_t)g * P.K + i;
-            if (compact) slot = (size_t)uni(B.s_qrow[slot]);          // compact queue: the row k_queue_compact gave this leaf
+            if (compact) {                                            // compact queue: the row k_queue_compact gave this leaf
+                const int row = uni(B.s_qrow[slot]);
+                if (row >= 0) slot = (size_t)row;                     // (-1: the leaf predates the compact rounds -- a caller that
+            }                                                         //  switched forms mid-search: its result is at the slot)
             attach_policy(gv, L, node, policy + slot * NLABELS);
             load_path(P, gv, L, i, depth);
             backup(P, gv, L, depth, (double)value[slot]);             // float(v) of a float32
