@@ -1188,10 +1188,10 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             const int node = uni(gv.s_node[i]);
             const int depth = uni(gv.s_depth[i]);
             size_t slot = (size_t)g * P.K + i;
-            if (compact) {                                            // compact queue: the row k_queue_compact gave this leaf
-                const int row = uni(B.s_qrow[slot]);
-                if (row >= 0) slot = (size_t)row;                     // (-1: the leaf predates the compact rounds -- a caller that
-            }                                                         //  switched forms mid-search: its result is at the slot)
+            if (compact) {                                            // the previous round built a compact queue: the row
+                const int row = uni(B.s_qrow[slot]);                  // k_queue_compact gave this leaf
+                if (row >= 0) slot = (size_t)row;
+            }
             attach_policy(gv, L, node, policy + slot * NLABELS);
             load_path(P, gv, L, i, depth);
             backup(P, gv, L, depth, (double)value[slot]);             // float(v) of a float32
@@ -1558,6 +1558,7 @@ struct cz_search {
     void* pool = nullptr;             // n_chunks x 1 MiB
     size_t bytes = 0;                 // slab + pool
     int device = 0;
+    int prev_compact = 0;             // the previous round built a compact queue: its results are indexed by compact row
 };
 
 namespace {
@@ -1869,10 +1870,13 @@ static int search_round_impl(cz_search* s, const float* policy, const float* val
     hipStream_t st = (hipStream_t)stream;
     const bool noise = s->P.noise_eps != 0.0;
     const int compact = q_rows ? 1 : 0;
+    // the rows consumed now were written after the PREVIOUS round: by compact row if that round built a compact queue
+    const int consume_compact = s->prev_compact;
+    s->prev_compact = compact;
     if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B, SIM_BACKUP);
     const bool hist = s->P.in_planes == 28;
-    if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP, compact);
-    else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP, compact);
+    if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP, consume_compact);
+    else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP, consume_compact);
     hipLaunchKernelGGL(k_advance, grid, block, 0, st, s->P, s->B);
     if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B, SIM_SELECT);
     if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT, compact);

@@ -161,8 +161,8 @@ int cz_search_round(cz_search* s, const float* policy, const float* value, void*
  * caller evaluates planes[q_rows[i]] and writes the result to policy[i] / value[i] -- row i, not the slot -- which the
  * NEXT cz_search_round_q consumes.  Nothing is copied to the host: run the network with the cz_*_q entry points, which
  * read the board count from q_count on the device (fixed launch shapes: the round still replays from a HIP graph).
- * Every call of one search object must use the same form (cz_search_round or cz_search_round_q) while simulations are
- * in flight.  In self-play 2-7 % of the slots carry no leaf (terminal / repeated positions, parked simulations), with
+ * The two forms may be mixed: a round consumes its results by compact row exactly when the PREVIOUS round of the
+ * object was a cz_search_round_q.  In self-play 2-7 % of the slots carry no leaf (terminal / repeated positions, parked simulations), with
  * search_threads = 32-40 up to half of them. */
 int cz_search_round_q(cz_search* s, const float* policy, const float* value, void* planes, int32_t* q_rows,
                       int32_t* q_count, void* stream);

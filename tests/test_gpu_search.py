@@ -165,20 +165,26 @@ def test_compact_queue_round_matches_the_slot_queue(gpu):
     s = gpu.S.Search(pc, len(states), seed=7)
     s.set_roots(boards_tensor(gpu, states))
     ev = stub_eval(gpu, spec)
-    for _ in range(10000):
-        s.round(compact=True)
+    for it in range(10000):
+        compact = it % 3 != 2                   # the two forms may be mixed: every third round uses the slot queue
+        s.round(compact=compact)
         if s.pending() == 0:
             break
-        n = int(s.q_count.item())
-        rows = s.q_rows[:n].long()
         _, leaf = s.leaf_rows()
-        assert rows.tolist() == sorted(leaf.tolist())
         s.policy.fill_(float("nan"))
         s.value.fill_(float("nan"))
-        if n:
-            p, v = ev(s.planes.index_select(0, rows))
-            s.policy[:n] = p
-            s.value[:n] = v
+        if compact:
+            n = int(s.q_count.item())
+            rows = s.q_rows[:n].long()
+            assert rows.tolist() == sorted(leaf.tolist())
+            if n:
+                p, v = ev(s.planes.index_select(0, rows))
+                s.policy[:n] = p
+                s.value[:n] = v
+        elif leaf.numel():
+            p, v = ev(s.planes.index_select(0, leaf))
+            s.policy.index_copy_(0, leaf, p)
+            s.value.index_copy_(0, leaf, v)
     st = s.root_stats()
     for g, state in enumerate(states):
         pl = xo.Player(oracle_cfg(pc), spec)
