@@ -213,6 +213,21 @@ def test_run_py_self_cli(tmp_path):
     assert os.path.isdir(tmp_path / "data" / "play_data") and os.path.exists(tmp_path / "logs" / "play.log")
 
 
+def test_run_py_eval_cli(tmp_path):
+    """`python cchess_alphazero/run.py eval --type mini` (reference CLI, manager.py:94-103): BestModel vs
+    NextGenerationModel (no files: two random-init networks) through the arena worker; the score table is logged."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "chinesechess-alphazero_amd")
+    env = dict(os.environ, DATA_DIR=str(tmp_path / "data"), PROJECT_DIR=str(tmp_path), PYTHONPATH=pkg)
+    r = subprocess.run([sys.executable, os.path.join(pkg, "cchess_alphazero", "run.py"), "eval", "--type", "mini"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    log = open(tmp_path / "logs" / "eval.log").read()
+    assert "Evaluate over, next generation win" in log and "new\told" in log
+
+
 def test_inference_net_gpu_matches_fp32_reference():
     """The GPU inference network (BN folded, channels-last, hand-written bias+skip+ReLU epilogue) against the plain
     PyTorch fp32 module on the CPU: policy / value within 1e-4 (north_star tolerance); the fused epilogue against

@@ -305,6 +305,44 @@ def test_exhausted_pool_drops_one_tree_and_returns_its_chunks(gpu):
     s.close()
 
 
+def test_starved_pool_keeps_self_play_running(gpu):
+    """Stress of the fallback: 192 concurrent self-play games on a pool with only 48 spare chunks.  Trees are dropped
+    (tree_resets) whenever a ply cannot be reserved, chunks circulate between games, nothing is lost or duplicated,
+    no simulation is dropped, the simulation accounting stays exact and games keep finishing."""
+    pc = play_config(simulation_num_per_move=160, search_threads=8, max_game_length=40, tau_decay_rate=0.9)
+    spec = dict(kind="hash", salt=29)
+    G = 192
+    probe = gpu.S.Search(pc, 1, seed=0)
+    keep = probe.keep_chunks
+    probe.close()
+    s = gpu.S.Search(pc, G, seed=5, pool_chunks=G * keep + 48, max_nodes_per_game=12000)
+    s.start_selfplay(seed=5)
+    ev = stub_eval(gpu, spec)
+    games = 0
+    for r in range(6000):
+        s.round()
+        p, v = ev(s.planes)
+        s.policy.copy_(p)
+        s.value.copy_(v)
+        if r % 250 == 249:
+            m, c = s.memory_info(), s.counters()
+            assert m["free_chunks"] + m["held_chunks"] == m["pool_chunks"], m
+            assert m["held_chunks_max_game"] <= s.max_chunks
+            games = c["games"]
+            if games >= 2 * G and c["tree_resets"] > 0:
+                break
+    c, m = s.counters(), s.memory_info()
+    assert c["games"] >= 2 * G and c["tree_resets"] > 0, c
+    assert c["overflow_sims"] == 0 and c["depth_overflow"] == 0, c
+    # every finished simulation ended one way; the difference is the leaves still waiting for their evaluation
+    in_flight = c["expansions"] + c["terminal_sims"] + c["repetition_sims"] - c["sims"]
+    assert 0 <= in_flight <= G * 8, (c, in_flight)
+    assert m["free_chunks"] + m["held_chunks"] == m["pool_chunks"]
+    recs = s.drain_records(1 << 14)
+    assert recs and all(0 < r["turns"] <= 2 * 40 + 1 for r in recs)
+    s.close()
+
+
 def test_whole_game_tree_is_kept(gpu):
     """Production memory policy (self_play.py:84,98-100): with the default pool nothing is ever dropped -- a 40-ply
     line keeps every node it expanded and each ply's visit counts equal the oracle's unbounded tree."""
