@@ -39,7 +39,9 @@ def run(state, turns, salt, depth):
                 ponder, cnt = mov, a.n
     pl.close(wait=False)
     return dict(state=state, turns=turns, salt=salt, depth=depth, action=action, info_lines=len(infos),
-                final_depth=int(last[2]), pv=pv, ponder=ponder, done_tasks=depth)
+                final_depth=int(last[2]), pv=pv, ponder=ponder, done_tasks=depth,
+                score=int(last[last.index("score") + 1]),            # network value of the END of the line, seen from `side`
+                scores=[int(l.split()[l.split().index("score") + 1]) for l in infos])
 
 
 def main():

@@ -410,6 +410,11 @@ def test_uci_searches_match_reference_player(tmp_path, monkeypatch):
         assert pl.done_tasks == c["done_tasks"]
         lines = [l for l in pl.out.getvalue().splitlines() if l.startswith("info depth")]
         assert lines and int(lines[-1].split()[2]) <= c["final_depth"]
+        # the score of the last line: the network value of the END of the principal variation, seen from `side`
+        # (player.py:442-445) -- the same position and the same stub network as in the reference run
+        last = lines[-1].split()
+        if int(last[2]) == c["final_depth"]:
+            assert int(last[last.index("score") + 1]) == c["score"], (lines[-1], c["score"])
         pv, t = [], c["turns"]
         for mov in pl.principal_variation(c["state"]):
             pv.append(senv.to_uci_move(flip_move(mov) if t % 2 == 1 else mov))
