@@ -6,10 +6,15 @@
 
 A "step" is one lock-step ROUND of the hot path over every concurrent game of the rank:
 the tree kernels (hand-written HIP: backup / PUCT select / expand / game rules, leaf planes into the queue) followed by
-one ResNet forward over the whole evaluation queue.  Workload at N=1 = BASELINE.json configs[1] ("normal"):
+one ResNet forward over the evaluation queue.  Workload at N=1 = BASELINE.json configs[1] ("normal"):
 4096 concurrent games per GPU, 800 sims/move, 7-block x 128-filter net, random-init weights, synthetic self-play
 from the opening position.  Games shard across ranks (disjoint game ids, no data-path collective); RCCL is used
-only to all-reduce the counters.  Rank 0 prints ONE JSON line.
+only to all-reduce the counters.  `--gpus N` without a launcher re-executes itself under torch.distributed.run.
+Rank 0 prints ONE JSON line: the timed steps (`value`), and at N=1 a sustained leg of 3000 more rounds in the same
+invocation (`sustained` / `value_sustained`: games in every phase, finished games replaced, measured plies/s and
+games/hour, tree memory, tree_resets), the roofline of the dominant kernel measured with HIP events on its stream,
+the rule-kernel micro-suite and the CPU baseline (the C port of the reference's tree + rules on every CPU the
+container may use).  `--config eval` times the evaluator arena on the arena worker instead.
 """
 import argparse
 import json
