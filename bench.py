@@ -419,7 +419,10 @@ def main():
             dist.all_reduce(delta, op=dist.ReduceOp.SUM)          # the only collective of the path
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dd = dict(zip(keys + ["ranks"], delta.tolist()))
-        k_ms_ = sum(x.elapsed_time(y) for x, y in ev) / len(ev) if ev else None
+        k_all = sorted(x.elapsed_time(y) for x, y in ev)
+        k_ms_ = sum(k_all) / len(k_all) if ev else None
+        dd["search_round_ms_median"] = k_all[len(k_all) // 2] if ev else None
+        dd["search_round_ms_max"] = k_all[-1] if ev else None
         b_ms_ = [x.elapsed_time(y) for x, y in blk_all]
         return float(tmax.item()), dd, k_ms_, b_ms_
 
@@ -478,6 +481,7 @@ def main():
             out["roofline_search"] = {"kernel": "cz_search_round = k_sim(BACKUP) + k_advance + k_sim(SELECT) (+ k_noise x2)", "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                                "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": bpe * exp_per_launch, "avg_launch_ms": k_ms,
+                               "median_launch_ms": d["search_round_ms_median"], "max_launch_ms": d["search_round_ms_max"],
                                "bytes_per_expansion": bpe, "expansions_per_launch": exp_per_launch,
                                "note": "latency/occupancy-bound pointer chasing (SURVEY 8d), not bandwidth-bound"}
             nn_ms = step_ms - k_ms
@@ -535,7 +539,8 @@ def main():
                     "tree_resets": sd["tree_resets"], "chunks_taken": sd["chunks_taken"], "stat_blocks": sd["stat_blocks"],
                     "overflow_sims": sd["overflow_sims"], "depth_overflow": sd["depth_overflow"],
                     "mean_depth": sd["sum_depth"] / max(1, sd["sims"]),
-                    "search_round_ms": sk_ms,
+                    "search_round_ms": sk_ms, "search_round_ms_median": sd["search_round_ms_median"],
+                    "search_round_ms_max": sd["search_round_ms_max"],
                     "tree_memory": dict(eng.search.memory_info(), when="end of the sustained leg", chunk_bytes=1 << 20),
                     "finished_games_rank0": {"n": len(sus_games),
                                              "mean_plies": (sum(g["turns"] for g in sus_games) / len(sus_games)) if sus_games else None,
