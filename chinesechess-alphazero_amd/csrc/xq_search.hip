@@ -1165,12 +1165,16 @@ constexpr int SIM_BACKUP = 1, SIM_SELECT = 2;
 
 template <bool HIST>        // HIST: 28 input planes (use_history); kept out of the common 14-plane instantiation
 __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, const float* __restrict__ policy,
-                                           const float* __restrict__ value, void* planes, int mask, int compact)
+                                           const float* __restrict__ value, void* planes, int mask, int compact,
+                                           int32_t* __restrict__ q_rows, int32_t* __restrict__ q_count)
 {
     __shared__ SearchLDS L;
     const int g = blockIdx.x;
     // first kernel of a round: chunks returned during the previous round become takeable (see pool_commit)
-    if (g == 0 && (mask & SIM_BACKUP) && lane_id() == 0) pool_commit(B);
+    if (g == 0 && (mask & SIM_BACKUP) && lane_id() == 0) {
+        pool_commit(B);
+        if (q_count) *q_count = 0;          // compact queue of this round: filled by the k_sim(SELECT) launch below
+    }
     if (g >= P.G) return;
     if (uni((int)B.g_phase[g]) != PH_SEARCH) return;
     const GameView gv = make_view(B, P, g, L.ctr, L.chtab);
@@ -1226,6 +1230,27 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
         run_sim<HIST>(P, B, gv, L, io, rc, uni(B.g_root[g]), sim, node, depth, &active, ar, fresh);
     }
     if (lane_id() == 0) { B.g_active[g] = active; B.g_node_count[g] = ar.ncount; B.g_heap_top[g] = ar.top; }
+    if ((mask & SIM_SELECT) && q_rows) {
+        // Compact evaluation queue: this game's slots that hold a new leaf (also those a resumed simulation made in
+        // the BACKUP launch) are appended to q_rows -- one atomic per game, the order of the games is arbitrary -- and
+        // each remembers its row for the next round's attach (s_qrow).
+        wave_sync_global();                                   // lane 0 wrote the slot states
+        const int lane = lane_id();
+        for (int base = 0; base < P.K; base += 64) {
+            const int i = base + lane;
+            const bool leaf = i < P.K && gv.s_state[i] == SIM_LEAF;
+            const uint64_t m = __ballot(leaf);
+            if (m == 0) continue;
+            int at = 0;
+            if (lane == 0) at = atomicAdd(q_count, __popcll(m));
+            at = uni(at);
+            if (leaf) {
+                const int row = at + __popcll(m & ((1ull << lane) - 1ull));
+                q_rows[row] = g * P.K + i;
+                B.s_qrow[(size_t)g * P.K + i] = row;
+            }
+        }
+    }
     counters_flush(gv);
 }
 
@@ -1254,15 +1279,15 @@ __global__ __launch_bounds__(64) void k_advance(SearchParams P, SearchBuffers B)
 // X ~ Gamma(alpha), Y ~ Gamma(alpha (n - 1)).  The reference redraws it per move per root visit (player.py:304);
 // a simulation selects at the root at most once per k_sim launch, so one row per slot per launch is enough:
 // before k_sim(BACKUP) only slots parked on the root need one, before k_sim(SELECT) the slots of the next batch.
-__global__ __launch_bounds__(64) void k_noise(SearchParams P, SearchBuffers B, int mask)
+__global__ __launch_bounds__(256) void k_noise(SearchParams P, SearchBuffers B, int mask)
 {
     const int g = blockIdx.x;
     if (g >= P.G || B.g_phase[g] != PH_SEARCH) return;
     const int root = B.g_root[g];
     if (root < 0) return;
-    const int lane = lane_id();
+    const int tid = threadIdx.x;
     const int active = B.g_active[g];
-    int first = 0, last = 0;                                   // slot range [first, last)
+    int last = 0;                                              // slots [0, last)
     if (mask == SIM_SELECT) {
         // a new batch starts only when nothing is in flight (k_sim(BACKUP) may have finished the old one)
         if (active != 0) return;
@@ -1278,17 +1303,17 @@ __global__ __launch_bounds__(64) void k_noise(SearchParams P, SearchBuffers B, i
     const uint32_t epoch = B.g_noise_epoch[g];
     double* rows = B.noise + (size_t)g * P.K * MAXMOVES;
     const float alpha = (float)P.dirichlet_alpha;
-    for (int sim = first; sim < last; ++sim) {
+    // one (simulation slot, root move) pair per thread and step: 8 x 44 pairs are two steps of the 256 threads
+    for (int item = tid; item < last * nm; item += 256) {
+        const int sim = item / nm, j = item - sim * nm;
         if (mask != SIM_SELECT &&
             !(B.s_state[(size_t)g * P.K + sim] == SIM_PARKED && B.s_node[(size_t)g * P.K + sim] == root)) continue;
-        for (int j = lane; j < nm; j += 64) {
-            NoiseRng rng{P.seed, ((uint64_t)epoch << 32) | ((uint64_t)sim << 20) | ((uint64_t)j << 8),
-                         B.g_game_id[g] + (uint32_t)g * 2654435761u, {0, 0, 0, 0}, 0};
-            rows[(size_t)sim * MAXMOVES + j] = dirichlet0(alpha, nm, rng);
-        }
+        NoiseRng rng{P.seed, ((uint64_t)epoch << 32) | ((uint64_t)sim << 20) | ((uint64_t)j << 8),
+                     B.g_game_id[g] + (uint32_t)g * 2654435761u, {0, 0, 0, 0}, 0};
+        rows[(size_t)sim * MAXMOVES + j] = dirichlet0(alpha, nm, rng);
     }
     __syncthreads();
-    if (lane == 0) B.g_noise_epoch[g] = epoch + 1;
+    if (tid == 0) B.g_noise_epoch[g] = epoch + 1;
 }
 
 // ---- auxiliary kernels ---------------------------------------------------------------------------------------
@@ -1366,35 +1391,6 @@ __global__ void k_pending(SearchParams P, SearchBuffers B)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < P.G && B.g_phase[g] == PH_SEARCH) atomicAdd(B.pending, 1);
-}
-
-// Compact evaluation queue: rows[0 .. count) = the queue slots that hold a new leaf, in slot order (deterministic);
-// s_qrow[slot] = its compact row.  One workgroup: per-thread counts over contiguous runs of slots, a block-wide
-// exclusive scan, then the writes.  The network then runs on `count` boards read from device memory (cz_*_q).
-__global__ __launch_bounds__(1024) void k_queue_compact(SearchParams P, SearchBuffers B, int32_t* __restrict__ rows,
-                                                        int32_t* __restrict__ count)
-{
-    __shared__ int part[1024];
-    const int n = P.G * P.K, tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int lo = tid * per, hi = lo + per < n ? lo + per : n;
-    int c = 0;
-    for (int s = lo; s < hi; ++s) c += (B.s_state[s] == SIM_LEAF && B.g_phase[s / P.K] == PH_SEARCH) ? 1 : 0;
-    part[tid] = c;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {                 // inclusive scan (Hillis-Steele)
-        const int v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int at = part[tid] - c;
-    for (int s = lo; s < hi; ++s) {
-        const bool leaf = B.s_state[s] == SIM_LEAF && B.g_phase[s / P.K] == PH_SEARCH;
-        B.s_qrow[s] = leaf ? at : -1;
-        if (leaf) rows[at++] = s;
-    }
-    if (tid == 1023) *count = part[1023];
 }
 
 // queue rows that hold a new leaf (a position the network has to evaluate) after a round, compacted; rows[] order is
@@ -1873,15 +1869,15 @@ static int search_round_impl(cz_search* s, const float* policy, const float* val
     // the rows consumed now were written after the PREVIOUS round: by compact row if that round built a compact queue
     const int consume_compact = s->prev_compact;
     s->prev_compact = compact;
-    if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B, SIM_BACKUP);
+    const dim3 nblock(256);
+    if (noise) hipLaunchKernelGGL(k_noise, grid, nblock, 0, st, s->P, s->B, SIM_BACKUP);
     const bool hist = s->P.in_planes == 28;
-    if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP, consume_compact);
-    else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP, consume_compact);
+    if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP, consume_compact, q_rows, q_count);
+    else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP, consume_compact, q_rows, q_count);
     hipLaunchKernelGGL(k_advance, grid, block, 0, st, s->P, s->B);
-    if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B, SIM_SELECT);
-    if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT, compact);
-    else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT, compact);
-    if (compact) hipLaunchKernelGGL(k_queue_compact, dim3(1), dim3(1024), 0, st, s->P, s->B, q_rows, q_count);
+    if (noise) hipLaunchKernelGGL(k_noise, grid, nblock, 0, st, s->P, s->B, SIM_SELECT);
+    if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT, compact, q_rows, q_count);
+    else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT, compact, q_rows, q_count);
     S_LAUNCH_CHECK("cz_search_round");
     return CZ_OK;
 }

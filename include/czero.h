@@ -157,7 +157,7 @@ int cz_search_set_roots(cz_search* s, const int8_t* boards, const int32_t* turns
 int cz_search_round(cz_search* s, const float* policy, const float* value, void* planes, void* stream);
 
 /* The same round with a COMPACT evaluation queue: only the slots that hold a new leaf are evaluated.  After the round
- * q_rows[0 .. *q_count) (int32 DEVICE, slot order) lists those slots and *q_count (int32 DEVICE) their number; the
+ * q_rows[0 .. *q_count) (int32 DEVICE, arbitrary order) lists those slots and *q_count (int32 DEVICE) their number; the
  * caller evaluates planes[q_rows[i]] and writes the result to policy[i] / value[i] -- row i, not the slot -- which the
  * NEXT cz_search_round_q consumes.  Nothing is copied to the host: run the network with the cz_*_q entry points, which
  * read the board count from q_count on the device (fixed launch shapes: the round still replays from a HIP graph).
