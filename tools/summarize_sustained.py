@@ -35,5 +35,6 @@ for name, sl in (("first_200_rounds", rounds[24:224]), ("last_1000_rounds", roun
     out[name] = {labels[j]: stats([r[j][1] for r in sl]) for j in range(5)}
     out[name]["sum_of_means"] = sum(out[name][labels[j]]["mean"] for j in range(5))
 rb = [d for _, n, d in rows if n == "k_resblock"]
-out["k_resblock_last_7000"] = stats(rb[-7000:])
+if rb:
+    out["k_resblock_last_7000"] = stats(rb[-7000:])
 print(json.dumps(out, indent=1))
