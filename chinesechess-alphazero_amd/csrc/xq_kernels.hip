@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "xq_rules.h"
 #include "xq_tpb.h"
@@ -340,7 +341,13 @@ __global__ __launch_bounds__(64) void k_movegen_fix(const int8_t* __restrict__ b
 inline int grid_for_tpb(int n)
 {
     const int nblk = (n + 63) / 64;
-    const int cap = 256 * 8;
+    // single-wave workgroups per CU: 14.9 KB of LDS and 146 VGPRs each allow 10; CZ_TPB_BLOCKS_PER_CU overrides (tuning)
+    static const int per_cu = [] {
+        const char* e = getenv("CZ_TPB_BLOCKS_PER_CU");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 && v <= 64 ? v : 8;
+    }();
+    const int cap = 256 * per_cu;
     return nblk < cap ? nblk : cap;
 }
 
