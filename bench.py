@@ -218,7 +218,7 @@ def games_per_hour_estimate(expansions_per_s, config):
            "source": os.path.relpath(files[-1], ROOT)}
     # the sustained figure of the committed long run of this configuration (games in every phase), if there is one
     longs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_f32_*_rounds.json")),
-                   key=lambda f: int(f.split("_")[-2]))
+                   key=lambda f: (int(f.split("_")[-2]), os.path.basename(f)))   # longest run, newest round
     if config == "normal" and longs:
         with open(longs[-1]) as f:
             ld = json.load(f)

@@ -345,7 +345,7 @@ inline int grid_for_tpb(int n)
     static const int per_cu = [] {
         const char* e = getenv("CZ_TPB_BLOCKS_PER_CU");
         const int v = e ? atoi(e) : 0;
-        return v > 0 && v <= 64 ? v : 8;
+        return v > 0 && v <= 64 ? v : 10;   // measured: 2.82 TB/s at 10, 2.53 at 8 and 16, 2.23 at 12
     }();
     const int cap = 256 * per_cu;
     return nblk < cap ? nblk : cap;

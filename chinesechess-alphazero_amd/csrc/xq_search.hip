@@ -47,6 +47,7 @@ struct SearchLDS {
     unsigned long long ctr[CT_COUNT];  // counter accumulators of the running kernel
     uint8_t codes[BOARD_LDS];          // plane codes of the leaf being encoded
     double dsc[MAXMOVES];              // sampling scratch
+    double cdf[MAXMOVES];
     float pr[MAXMOVES];                // prior gather scratch
     uint16_t slab[MAXMOVES];           // labels sorted
     int32_t sn[MAXMOVES];              // visit counts sorted by label
@@ -942,34 +943,62 @@ XQ_D int choose_action(const SearchParams& P, const SearchBuffers& B, const Game
     if (tau < 0.1 || (turns >= 4 && P.evaluate)) tau = 0.0;
     if (inc && !P.evaluate) tau = 0.5;
     int chosen = 0;
-    if (lane == 0) {
-        long long total_n = 0;
-        for (int k = 0; k < nm; ++k) total_n += L.sn[k];
-        if (tau == 0.0) {
+    if (tau == 0.0) {
+        if (lane == 0) {
             int best = -1, bestn = -1;                       // np.argmax: first maximum in label order
             for (int k = 0; k < nm; ++k) if (L.sn[k] > bestn) { bestn = L.sn[k]; best = k; }
             chosen = (best >= 0 && bestn > 0) ? (int)L.slab[best] : 0;
-        } else {
-            const double inv = 1.0 / tau;
-            double s = 0.0;
-            for (int k = 0; k < nm; ++k) {
-                const double pk = (double)L.sn[k] / (double)total_n;         // policy /= np.sum(policy)
-                const double rk = L.sn[k] > 0 ? pow(pk, inv) : 0.0;
-                L.dsc[k] = rk;
-                s += rk;
-            }
-            double total = 0.0;
-            for (int k = 0; k < nm; ++k) { L.dsc[k] = L.dsc[k] / s; total += L.dsc[k]; }
-            double c = 0.0;
-            int pick = -1;
-            for (int k = 0; k < nm; ++k) {                   // cdf.searchsorted(u, side='right')
-                c += L.dsc[k];
-                if (c / total > u) { pick = k; break; }
-            }
-            if (pick < 0) for (int k = nm - 1; k >= 0; --k) if (L.dsc[k] > 0.0) { pick = k; break; }
-            chosen = pick >= 0 ? (int)L.slab[pick] : 0;
+        }
+        wave_sync_global();
+        return uni(chosen);
+    }
+    // policy ** (1 / tau), renormalised, then np.random.choice = cdf.searchsorted(u, side='right').  Everything that is
+    // independent per move (the pow() calls above all: ~1 us each when one lane runs them back to back) is done one move
+    // per lane; the float64 sums keep the order of the NumPy loops and stay on lane 0.
+    long long total_n = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) if (lane + 64 * h < nm) total_n += L.sn[lane + 64 * h];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) total_n += __shfl_xor(total_n, d, 64);     // integers: any order
+    const double inv = 1.0 / tau;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = lane + 64 * h;
+        if (k < nm) {
+            const double pk = (double)L.sn[k] / (double)total_n;             // policy /= np.sum(policy)
+            L.dsc[k] = L.sn[k] > 0 ? pow(pk, inv) : 0.0;
         }
     }
+    wave_sync_global();
+    double s = 0.0;
+    if (lane == 0) for (int k = 0; k < nm; ++k) s += L.dsc[k];
+    s = unid(s);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = lane + 64 * h;
+        if (k < nm) L.dsc[k] = L.dsc[k] / s;
+    }
+    wave_sync_global();
+    double total = 0.0;
+    if (lane == 0) {
+        double c = 0.0;
+        for (int k = 0; k < nm; ++k) { total += L.dsc[k]; c += L.dsc[k]; L.cdf[k] = c; }
+    }
+    total = unid(total);
+    wave_sync_global();
+    bool hit[2], pos[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = lane + 64 * h;
+        hit[h] = k < nm && L.cdf[k] / total > u;
+        pos[h] = k < nm && L.dsc[k] > 0.0;
+    }
+    int pick = lowest_bit(__ballot(hit[0]), __ballot(hit[1]));          // first k with cdf[k] / total > u
+    if (pick < 0) {                                                      // u beyond the last step: the last possible move
+        const uint64_t p0 = __ballot(pos[0]), p1 = __ballot(pos[1]);
+        pick = p1 ? 127 - __clzll((long long)p1) : (p0 ? 63 - __clzll((long long)p0) : -1);
+    }
+    chosen = pick >= 0 ? (int)L.slab[pick] : 0;
     wave_sync_global();
     return uni(chosen);
 }
