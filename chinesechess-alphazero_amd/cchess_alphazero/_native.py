@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libczero.so")
+LIB_PATH = os.environ.get("CZ_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libczero.so")   # CZ_LIB: A/B builds (tools/ab_search.sh)
 
 NSQ, NLABELS, MAXMOVES, NOMOVE = 90, 2086, 128, 0xFFFF
 F32, F16, BF16, U8 = 0, 1, 2, 3

@@ -370,6 +370,54 @@ XQ_D void attach_policy(const GameView& gv, SearchLDS& L, int node, const float*
     wave_sync();
 }
 
+// attach_policy + load_path + backup of one evaluated leaf with their independent loads issued together: the move labels
+// with the path's edge ids, then the priors of those labels with the statistics of those edges -- two dependent memory
+// round trips per leaf instead of five (the BACKUP launch is nothing but such chains, eight leaves one after the other).
+// Same arithmetic, same lanes writing the same words as the three functions it replaces.  depth <= 64.
+XQ_D void attach_and_backup(const SearchParams& P, const GameView& gv, SearchLDS& L, int node, uint32_t meta, int depth,
+                            const float* __restrict__ prow, double v, const int32_t* __restrict__ hp_edge)
+{
+    const int lane = lane_id();
+    char* base = rec_ptr(gv, (uint32_t)node);
+    const int nm = (int)(meta & 0xFF);
+    float* pp = node_p(base);
+    const uint16_t* pm = node_mv(base, nm);
+    uint16_t m0 = 0, m1 = 0;
+    int e = 0;
+    if (lane < nm) m0 = pm[lane];
+    if (lane + 64 < nm) m1 = pm[lane + 64];
+    if (lane < depth) e = hp_edge[lane];
+    float p0 = 0.0f, p1 = 0.0f;
+    EdgeStat cur{0.0, 0, 0};
+    EdgeStat* ep = nullptr;
+    if (lane < nm) p0 = prow[m0];
+    if (lane + 64 < nm) p1 = prow[m1];
+    if (lane < depth) { ep = edge_ptr(gv, (uint32_t)e); cur = *ep; }
+    // prior spreading (select_action_q_and_u, player.py:272-284)
+    if (lane < nm) L.pr[lane] = p0;
+    if (lane + 64 < nm) L.pr[lane + 64] = p1;
+    wave_sync();
+    float all_p = 0.0f;
+    if (nm > 0) {
+        all_p = L.pr[0];                                   // int 0 + float32
+        for (int j = 1; j < nm; ++j) all_p = all_p + L.pr[j];   // float32 accumulation in move order
+    }
+    if (all_p == 0.0f) all_p = 1.0f;
+    if (lane < nm) pp[lane] = p0 / all_p;
+    if (lane + 64 < nm) pp[lane + 64] = p1 / all_p;
+    if (lane == 0) store_meta(base, meta & ~(uint32_t)NODE_WAITING);
+    // update_tree (player.py:357-366): lane i = level i
+    if (lane < depth) {
+        const double vi = ((depth - lane) & 1) ? -v : v;
+        ep->n = cur.n + (1 - P.vl);
+        ep->w = cur.w + (vi + (double)P.vl);
+    }
+    count(gv, CT_SIMS);
+    count(gv, CT_SUM_DEPTH, (unsigned long long)depth);
+    count_max(gv, CT_MAX_DEPTH, (unsigned long long)depth);
+    wave_sync_global();
+}
+
 // ---- select_action_q_and_u, player.py:286-320 --------------------------------------------------------
 struct RootCtx {
     bool is_root;
@@ -1186,10 +1234,32 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
     new_game(P, B, gv, L, game_id + P.game_id_stride);
 }
 
+// Dirichlet(alpha 1_n)[0] for (simulation slot, root edge) pairs: X / (X + Y), X ~ Gamma(alpha), Y ~ Gamma(alpha (n - 1)).
+// The reference redraws it per move per root visit (player.py:304); a simulation selects at the root at most once per
+// descent, so one row per slot is drawn when the slot is about to start from (or resume at) the root: slots
+// [sim_lo, sim_hi) of this game, one pair per lane and step.  `epoch` makes every call a fresh part of the game's stream.
+XQ_D void noise_rows(const SearchParams& P, const SearchBuffers& B, const GameView& gv, int root, int sim_lo, int sim_hi,
+                     uint32_t& epoch)
+{
+    const int g = gv.g;
+    const int nm = (int)(load_hdr(rec_ptr(gv, (uint32_t)root)).meta & 0xFF);
+    double* rows = B.noise + (size_t)g * P.K * MAXMOVES;
+    const float alpha = (float)P.dirichlet_alpha;
+    const uint32_t gid = uniu(B.g_game_id[g]) + (uint32_t)g * 2654435761u;
+    const int items = (sim_hi - sim_lo) * nm;
+    for (int item = lane_id(); item < items; item += 64) {
+        const int ds = item / nm, j = item - ds * nm, sim = sim_lo + ds;
+        NoiseRng rng{P.seed, ((uint64_t)epoch << 32) | ((uint64_t)sim << 20) | ((uint64_t)j << 8), gid, {0, 0, 0, 0}, 0};
+        rows[(size_t)sim * MAXMOVES + j] = dirichlet0(alpha, nm, rng);
+    }
+    epoch += 1u;
+    wave_sync_global();              // select_edge reads row entry j on lane j & 63, not on the lane that drew it
+}
+
 // ---- the round kernels --------------------------------------------------------------------------------------
-// One lock-step round = k_sim(BACKUP) -> k_advance -> k_sim(SELECT)   (+ k_noise before each k_sim when the
-// root noise is on).  Splitting the round keeps the hot simulation kernel free of the cold, register-hungry code
-// (move sampling with pow(), game rules, chunk reservation, Gamma sampling).
+// One lock-step round = k_sim(BACKUP) -> k_advance -> k_sim(SELECT).  Splitting the round keeps the hot simulation
+// kernel free of the cold, register-hungry code (move sampling with pow(), game rules, chunk reservation).  The root
+// noise is drawn by the game's own wave when a batch starts (noise_rows): as two extra launches it cost 70 us a round.
 constexpr int SIM_BACKUP = 1, SIM_SELECT = 2;
 
 template <bool HIST>        // HIST: 28 input planes (use_history); kept out of the common 14-plane instantiation
@@ -1213,16 +1283,58 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
     Arena ar{uniu(B.g_heap_top[g]), uni(B.g_nchunks[g]), uni(B.g_node_count[g])};
     const RootCtx rc{false, uni((int)B.g_n_no_act[g]), B.g_no_act + (size_t)g * MAX_NO_ACT,
                      P.noise_eps != 0.0 ? B.noise + (size_t)g * P.K * MAXMOVES : nullptr, 0};
+    const bool noisy = P.noise_eps != 0.0;
+    const uint32_t epoch0 = noisy ? uniu(B.g_noise_epoch[g]) : 0u;
+    uint32_t epoch = epoch0;
     int resume_i = P.K;
-    if ((mask & SIM_BACKUP) && active > 0) {
+    // the slot table as it is when the launch starts, slot i on lane i: one load per array instead of one dependent
+    // round trip per slot and field (a simulation only ever changes its own slot, and each slot is visited once per list)
+    const bool snap = (mask & SIM_BACKUP) && active > 0 && P.K <= 64;
+    int sn_state = SIM_IDLE, sn_node = 0, sn_depth = 0;
+    if (snap && lane_id() < P.K) {
+        sn_state = gv.s_state[lane_id()];
+        sn_node = gv.s_node[lane_id()];
+        sn_depth = gv.s_depth[lane_id()];
+    }
+    if (snap) {
         // 1. attach + backup evaluated leaves, in simulation order (update_tree, player.py:340-373)
+        const int lane = lane_id();
+        int my_row = g * P.K + lane;
+        uint32_t my_meta = 0u;
+        float my_v = 0.0f;
+        if (sn_state == SIM_LEAF) {
+            if (compact) {                                            // the previous round built a compact queue: the row
+                const int row = B.s_qrow[(size_t)g * P.K + lane];     // it gave this leaf
+                if (row >= 0) my_row = row;
+            }
+            my_meta = *reinterpret_cast<const uint32_t*>(rec_ptr(gv, (uint32_t)sn_node) + NODE_OFF_HDR + 4);
+            my_v = value[my_row];
+        }
+        for (int i = 0; i < P.K; ++i) {
+            if (__builtin_amdgcn_readlane(sn_state, i) != SIM_LEAF) continue;
+            const int node = __builtin_amdgcn_readlane(sn_node, i);
+            const int depth = __builtin_amdgcn_readlane(sn_depth, i);
+            const size_t slot = (size_t)__builtin_amdgcn_readlane(my_row, i);
+            const double v = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), i));   // float(v) of a float32
+            if (depth <= 64) {
+                attach_and_backup(P, gv, L, node, (uint32_t)__builtin_amdgcn_readlane((int)my_meta, i), depth,
+                                  policy + slot * NLABELS, v, gv.path_edge + (size_t)i * P.max_depth);
+            } else {
+                attach_policy(gv, L, node, policy + slot * NLABELS);
+                load_path(P, gv, L, i, depth);
+                backup(P, gv, L, depth, v);
+            }
+            sim_finish(gv, i, &active);
+        }
+        resume_i = 0;                                                 // 2. then resume the parked simulations
+    } else if ((mask & SIM_BACKUP) && active > 0) {                   // (more than 64 slots per game: slot by slot)
         for (int i = 0; i < P.K; ++i) {
             if (uni((int)gv.s_state[i]) != SIM_LEAF) continue;
             const int node = uni(gv.s_node[i]);
             const int depth = uni(gv.s_depth[i]);
             size_t slot = (size_t)g * P.K + i;
-            if (compact) {                                            // the previous round built a compact queue: the row
-                const int row = uni(B.s_qrow[slot]);                  // k_queue_compact gave this leaf
+            if (compact) {
+                const int row = uni(B.s_qrow[slot]);
                 if (row >= 0) slot = (size_t)row;
             }
             attach_policy(gv, L, node, policy + slot * NLABELS);
@@ -1230,17 +1342,25 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             backup(P, gv, L, depth, (double)value[slot]);             // float(v) of a float32
             sim_finish(gv, i, &active);
         }
-        resume_i = 0;                                                 // 2. then resume the parked simulations
+        resume_i = 0;
     }
     int new_i = 0, new_n = 0, batches = 0;
+    int nz_lo = 0, nz_hi = 0;
     for (int guard = 0; guard < (1 << 20); ++guard) {
         int sim, node, depth;
         bool fresh;
         if (resume_i < P.K) {                                         // parked simulations, in index order
             const int i = resume_i++;
-            if (uni((int)gv.s_state[i]) != SIM_PARKED) continue;
-            sim = i; node = uni(gv.s_node[i]); depth = uni(gv.s_depth[i]); fresh = false;
+            if (snap) {
+                if (__builtin_amdgcn_readlane(sn_state, i) != SIM_PARKED) continue;
+                node = __builtin_amdgcn_readlane(sn_node, i); depth = __builtin_amdgcn_readlane(sn_depth, i);
+            } else {
+                if (uni((int)gv.s_state[i]) != SIM_PARKED) continue;
+                node = uni(gv.s_node[i]); depth = uni(gv.s_depth[i]);
+            }
+            sim = i; fresh = false;
             load_path(P, gv, L, i, depth);
+            if (noisy && node == uni(B.g_root[g])) { nz_lo = i; nz_hi = i + 1; }              // parked on the root
         } else if (new_i < new_n) {                                   // the simulations of a fresh batch
             sim = new_i++; node = uni(B.g_root[g]); depth = 0; fresh = true;
         } else if ((mask & SIM_SELECT) && active == 0) {              // 3. next lock-step batch (player.py:169-178)
@@ -1254,11 +1374,19 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             new_i = 0;
             active = new_n;
             if (lane_id() == 0) B.g_tasks_left[g] = tasks - new_n;
+            if (noisy && uni(B.g_root[g]) >= 0) { nz_lo = 0; nz_hi = new_n; }
             continue;
         } else break;
+        if (nz_hi > nz_lo) {                                          // root noise of the slots about to select there
+            noise_rows(P, B, gv, uni(B.g_root[g]), nz_lo, nz_hi, epoch);
+            nz_hi = 0;
+        }
         run_sim<HIST>(P, B, gv, L, io, rc, uni(B.g_root[g]), sim, node, depth, &active, ar, fresh);
     }
-    if (lane_id() == 0) { B.g_active[g] = active; B.g_node_count[g] = ar.ncount; B.g_heap_top[g] = ar.top; }
+    if (lane_id() == 0) {
+        B.g_active[g] = active; B.g_node_count[g] = ar.ncount; B.g_heap_top[g] = ar.top;
+        if (epoch != epoch0) B.g_noise_epoch[g] = epoch;
+    }
     if ((mask & SIM_SELECT) && q_rows) {
         // Compact evaluation queue: this game's slots that hold a new leaf (also those a resumed simulation made in
         // the BACKUP launch) are appended to q_rows -- one atomic per game, the order of the games is arbitrary -- and
@@ -1302,47 +1430,6 @@ __global__ __launch_bounds__(64) void k_advance(SearchParams P, SearchBuffers B)
         B.g_phase[g] = PH_READY;
     }
     counters_flush(gv);
-}
-
-// Dirichlet(alpha 1_n)[0] for every (simulation slot, root edge) the next k_sim launch can consume: X / (X + Y),
-// X ~ Gamma(alpha), Y ~ Gamma(alpha (n - 1)).  The reference redraws it per move per root visit (player.py:304);
-// a simulation selects at the root at most once per k_sim launch, so one row per slot per launch is enough:
-// before k_sim(BACKUP) only slots parked on the root need one, before k_sim(SELECT) the slots of the next batch.
-__global__ __launch_bounds__(256) void k_noise(SearchParams P, SearchBuffers B, int mask)
-{
-    const int g = blockIdx.x;
-    if (g >= P.G || B.g_phase[g] != PH_SEARCH) return;
-    const int root = B.g_root[g];
-    if (root < 0) return;
-    const int tid = threadIdx.x;
-    const int active = B.g_active[g];
-    int last = 0;                                              // slots [0, last)
-    if (mask == SIM_SELECT) {
-        // a new batch starts only when nothing is in flight (k_sim(BACKUP) may have finished the old one)
-        if (active != 0) return;
-        const int tasks = B.g_tasks_left[g];
-        last = tasks < P.K ? tasks : P.K;
-    } else {
-        if (active == 0) return;
-        last = P.K;
-    }
-    const char* rbase = B.pool + ((size_t)B.g_chunk_tab[(size_t)g * P.max_chunks + ((uint32_t)root >> CHUNK_SHIFT)] << 20)
-                        + ((size_t)((uint32_t)root & (uint32_t)(CHUNK_GRANULES - 1)) << 4);
-    const int nm = (int)(*reinterpret_cast<const uint32_t*>(rbase + NODE_OFF_HDR + 4) & 0xFF);
-    const uint32_t epoch = B.g_noise_epoch[g];
-    double* rows = B.noise + (size_t)g * P.K * MAXMOVES;
-    const float alpha = (float)P.dirichlet_alpha;
-    // one (simulation slot, root move) pair per thread and step: 8 x 44 pairs are two steps of the 256 threads
-    for (int item = tid; item < last * nm; item += 256) {
-        const int sim = item / nm, j = item - sim * nm;
-        if (mask != SIM_SELECT &&
-            !(B.s_state[(size_t)g * P.K + sim] == SIM_PARKED && B.s_node[(size_t)g * P.K + sim] == root)) continue;
-        NoiseRng rng{P.seed, ((uint64_t)epoch << 32) | ((uint64_t)sim << 20) | ((uint64_t)j << 8),
-                     B.g_game_id[g] + (uint32_t)g * 2654435761u, {0, 0, 0, 0}, 0};
-        rows[(size_t)sim * MAXMOVES + j] = dirichlet0(alpha, nm, rng);
-    }
-    __syncthreads();
-    if (tid == 0) B.g_noise_epoch[g] = epoch + 1;
 }
 
 // ---- auxiliary kernels ---------------------------------------------------------------------------------------
@@ -1893,18 +1980,14 @@ static int search_round_impl(cz_search* s, const float* policy, const float* val
 {
     const dim3 grid(s->P.G), block(64);
     hipStream_t st = (hipStream_t)stream;
-    const bool noise = s->P.noise_eps != 0.0;
     const int compact = q_rows ? 1 : 0;
     // the rows consumed now were written after the PREVIOUS round: by compact row if that round built a compact queue
     const int consume_compact = s->prev_compact;
     s->prev_compact = compact;
-    const dim3 nblock(256);
-    if (noise) hipLaunchKernelGGL(k_noise, grid, nblock, 0, st, s->P, s->B, SIM_BACKUP);
     const bool hist = s->P.in_planes == 28;
     if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP, consume_compact, q_rows, q_count);
     else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP, consume_compact, q_rows, q_count);
     hipLaunchKernelGGL(k_advance, grid, block, 0, st, s->P, s->B);
-    if (noise) hipLaunchKernelGGL(k_noise, grid, nblock, 0, st, s->P, s->B, SIM_SELECT);
     if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT, compact, q_rows, q_count);
     else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT, compact, q_rows, q_count);
     S_LAUNCH_CHECK("cz_search_round");
