@@ -1234,32 +1234,10 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
     new_game(P, B, gv, L, game_id + P.game_id_stride);
 }
 
-// Dirichlet(alpha 1_n)[0] for (simulation slot, root edge) pairs: X / (X + Y), X ~ Gamma(alpha), Y ~ Gamma(alpha (n - 1)).
-// The reference redraws it per move per root visit (player.py:304); a simulation selects at the root at most once per
-// descent, so one row per slot is drawn when the slot is about to start from (or resume at) the root: slots
-// [sim_lo, sim_hi) of this game, one pair per lane and step.  `epoch` makes every call a fresh part of the game's stream.
-XQ_D void noise_rows(const SearchParams& P, const SearchBuffers& B, const GameView& gv, int root, int sim_lo, int sim_hi,
-                     uint32_t& epoch)
-{
-    const int g = gv.g;
-    const int nm = (int)(load_hdr(rec_ptr(gv, (uint32_t)root)).meta & 0xFF);
-    double* rows = B.noise + (size_t)g * P.K * MAXMOVES;
-    const float alpha = (float)P.dirichlet_alpha;
-    const uint32_t gid = uniu(B.g_game_id[g]) + (uint32_t)g * 2654435761u;
-    const int items = (sim_hi - sim_lo) * nm;
-    for (int item = lane_id(); item < items; item += 64) {
-        const int ds = item / nm, j = item - ds * nm, sim = sim_lo + ds;
-        NoiseRng rng{P.seed, ((uint64_t)epoch << 32) | ((uint64_t)sim << 20) | ((uint64_t)j << 8), gid, {0, 0, 0, 0}, 0};
-        rows[(size_t)sim * MAXMOVES + j] = dirichlet0(alpha, nm, rng);
-    }
-    epoch += 1u;
-    wave_sync_global();              // select_edge reads row entry j on lane j & 63, not on the lane that drew it
-}
-
 // ---- the round kernels --------------------------------------------------------------------------------------
-// One lock-step round = k_sim(BACKUP) -> k_advance -> k_sim(SELECT).  Splitting the round keeps the hot simulation
-// kernel free of the cold, register-hungry code (move sampling with pow(), game rules, chunk reservation).  The root
-// noise is drawn by the game's own wave when a batch starts (noise_rows): as two extra launches it cost 70 us a round.
+// One lock-step round = k_sim(BACKUP) -> k_advance -> k_sim(SELECT)   (+ k_noise before each k_sim when the
+// root noise is on).  Splitting the round keeps the hot simulation kernel free of the cold, register-hungry code
+// (move sampling with pow(), game rules, chunk reservation, Gamma sampling).
 constexpr int SIM_BACKUP = 1, SIM_SELECT = 2;
 
 template <bool HIST>        // HIST: 28 input planes (use_history); kept out of the common 14-plane instantiation
@@ -1283,9 +1261,6 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
     Arena ar{uniu(B.g_heap_top[g]), uni(B.g_nchunks[g]), uni(B.g_node_count[g])};
     const RootCtx rc{false, uni((int)B.g_n_no_act[g]), B.g_no_act + (size_t)g * MAX_NO_ACT,
                      P.noise_eps != 0.0 ? B.noise + (size_t)g * P.K * MAXMOVES : nullptr, 0};
-    const bool noisy = P.noise_eps != 0.0;
-    const uint32_t epoch0 = noisy ? uniu(B.g_noise_epoch[g]) : 0u;
-    uint32_t epoch = epoch0;
     int resume_i = P.K;
     // the slot table as it is when the launch starts, slot i on lane i: one load per array instead of one dependent
     // round trip per slot and field (a simulation only ever changes its own slot, and each slot is visited once per list)
@@ -1345,7 +1320,6 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
         resume_i = 0;
     }
     int new_i = 0, new_n = 0, batches = 0;
-    int nz_lo = 0, nz_hi = 0;
     for (int guard = 0; guard < (1 << 20); ++guard) {
         int sim, node, depth;
         bool fresh;
@@ -1360,7 +1334,6 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             }
             sim = i; fresh = false;
             load_path(P, gv, L, i, depth);
-            if (noisy && node == uni(B.g_root[g])) { nz_lo = i; nz_hi = i + 1; }              // parked on the root
         } else if (new_i < new_n) {                                   // the simulations of a fresh batch
             sim = new_i++; node = uni(B.g_root[g]); depth = 0; fresh = true;
         } else if ((mask & SIM_SELECT) && active == 0) {              // 3. next lock-step batch (player.py:169-178)
@@ -1374,19 +1347,11 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             new_i = 0;
             active = new_n;
             if (lane_id() == 0) B.g_tasks_left[g] = tasks - new_n;
-            if (noisy && uni(B.g_root[g]) >= 0) { nz_lo = 0; nz_hi = new_n; }
             continue;
         } else break;
-        if (nz_hi > nz_lo) {                                          // root noise of the slots about to select there
-            noise_rows(P, B, gv, uni(B.g_root[g]), nz_lo, nz_hi, epoch);
-            nz_hi = 0;
-        }
         run_sim<HIST>(P, B, gv, L, io, rc, uni(B.g_root[g]), sim, node, depth, &active, ar, fresh);
     }
-    if (lane_id() == 0) {
-        B.g_active[g] = active; B.g_node_count[g] = ar.ncount; B.g_heap_top[g] = ar.top;
-        if (epoch != epoch0) B.g_noise_epoch[g] = epoch;
-    }
+    if (lane_id() == 0) { B.g_active[g] = active; B.g_node_count[g] = ar.ncount; B.g_heap_top[g] = ar.top; }
     if ((mask & SIM_SELECT) && q_rows) {
         // Compact evaluation queue: this game's slots that hold a new leaf (also those a resumed simulation made in
         // the BACKUP launch) are appended to q_rows -- one atomic per game, the order of the games is arbitrary -- and
@@ -1430,6 +1395,50 @@ __global__ __launch_bounds__(64) void k_advance(SearchParams P, SearchBuffers B)
         B.g_phase[g] = PH_READY;
     }
     counters_flush(gv);
+}
+
+// Dirichlet(alpha 1_n)[0] for every (simulation slot, root edge) the next k_sim launch can consume: X / (X + Y),
+// X ~ Gamma(alpha), Y ~ Gamma(alpha (n - 1)).  The reference redraws it per move per root visit (player.py:304);
+// a simulation selects at the root at most once per k_sim launch, so one row per slot per launch is enough:
+// before k_sim(BACKUP) only slots parked on the root need one, before k_sim(SELECT) the slots of the next batch.
+// (Drawing the rows inside k_sim, by the game's own wave when a batch starts, was measured and is SLOWER: the 6 x 64
+// draws of a batch are ~6000 dependent instructions for one wave, +125 us on k_sim(SELECT) against the 70 us of the two
+// launches -- here the work spreads over 4 waves per game and 8 resident waves per SIMD.)
+__global__ __launch_bounds__(256) void k_noise(SearchParams P, SearchBuffers B, int mask)
+{
+    const int g = blockIdx.x;
+    if (g >= P.G || B.g_phase[g] != PH_SEARCH) return;
+    const int root = B.g_root[g];
+    if (root < 0) return;
+    const int tid = threadIdx.x;
+    const int active = B.g_active[g];
+    int last = 0;                                              // slots [0, last)
+    if (mask == SIM_SELECT) {
+        // a new batch starts only when nothing is in flight (k_sim(BACKUP) may have finished the old one)
+        if (active != 0) return;
+        const int tasks = B.g_tasks_left[g];
+        last = tasks < P.K ? tasks : P.K;
+    } else {
+        if (active == 0) return;
+        last = P.K;
+    }
+    const char* rbase = B.pool + ((size_t)B.g_chunk_tab[(size_t)g * P.max_chunks + ((uint32_t)root >> CHUNK_SHIFT)] << 20)
+                        + ((size_t)((uint32_t)root & (uint32_t)(CHUNK_GRANULES - 1)) << 4);
+    const int nm = (int)(*reinterpret_cast<const uint32_t*>(rbase + NODE_OFF_HDR + 4) & 0xFF);
+    const uint32_t epoch = B.g_noise_epoch[g];
+    double* rows = B.noise + (size_t)g * P.K * MAXMOVES;
+    const float alpha = (float)P.dirichlet_alpha;
+    // one (simulation slot, root move) pair per thread and step: 8 x 44 pairs are two steps of the 256 threads
+    for (int item = tid; item < last * nm; item += (int)blockDim.x) {
+        const int sim = item / nm, j = item - sim * nm;
+        if (mask != SIM_SELECT &&
+            !(B.s_state[(size_t)g * P.K + sim] == SIM_PARKED && B.s_node[(size_t)g * P.K + sim] == root)) continue;
+        NoiseRng rng{P.seed, ((uint64_t)epoch << 32) | ((uint64_t)sim << 20) | ((uint64_t)j << 8),
+                     B.g_game_id[g] + (uint32_t)g * 2654435761u, {0, 0, 0, 0}, 0};
+        rows[(size_t)sim * MAXMOVES + j] = dirichlet0(alpha, nm, rng);
+    }
+    __syncthreads();
+    if (tid == 0) B.g_noise_epoch[g] = epoch + 1;
 }
 
 // ---- auxiliary kernels ---------------------------------------------------------------------------------------
@@ -1980,14 +1989,20 @@ static int search_round_impl(cz_search* s, const float* policy, const float* val
 {
     const dim3 grid(s->P.G), block(64);
     hipStream_t st = (hipStream_t)stream;
+    const bool noise = s->P.noise_eps != 0.0;
     const int compact = q_rows ? 1 : 0;
     // the rows consumed now were written after the PREVIOUS round: by compact row if that round built a compact queue
     const int consume_compact = s->prev_compact;
     s->prev_compact = compact;
+    const dim3 nblock(256);
+    // (before BACKUP only simulations parked on an unexpanded root need a row -- the first round of a new tree: one wave
+    //  per game is enough to find that out)
+    if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B, SIM_BACKUP);
     const bool hist = s->P.in_planes == 28;
     if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP, consume_compact, q_rows, q_count);
     else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP, consume_compact, q_rows, q_count);
     hipLaunchKernelGGL(k_advance, grid, block, 0, st, s->P, s->B);
+    if (noise) hipLaunchKernelGGL(k_noise, grid, nblock, 0, st, s->P, s->B, SIM_SELECT);
     if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT, compact, q_rows, q_count);
     else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT, compact, q_rows, q_count);
     S_LAUNCH_CHECK("cz_search_round");
