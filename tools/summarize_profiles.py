@@ -59,6 +59,35 @@ def search_rounds(rows, counter):
     return [sum(vals[i:i + 5]) for i in range(0, len(vals) - len(vals) % 5, 5)]
 
 
+def search_launch_counters(rows, skip_rounds=3):
+    """SQ counters of the 5 launches of a cz_search_round, by position, mean over the steady-state rounds; with the
+    fractions of the waves' cycles spent waiting / issuing (SQ_WAIT_ANY etc. over SQ_WAVE_CYCLES)"""
+    per = collections.OrderedDict()
+    for did, k, c, v in rows:
+        if k in SEARCH:
+            per.setdefault(did, {"name": k})[c] = v
+    seq = list(per.values())
+    rounds = [seq[i:i + 5] for i in range(0, len(seq) - len(seq) % 5, 5)]
+    rounds = [r for r in rounds if [x["name"] for x in r] == ["k_noise", "k_sim", "k_advance", "k_noise", "k_sim"]][skip_rounds:]
+    if not rounds:
+        return None
+    labels = ["k_noise(B)", "k_sim(BACKUP)", "k_advance", "k_noise(S)", "k_sim(SELECT)"]
+    out = {"rounds": len(rounds)}
+    for j, lab in enumerate(labels):
+        acc = collections.defaultdict(float)
+        for r in rounds:
+            for c, v in r[j].items():
+                if c != "name":
+                    acc[c] += v / len(rounds)
+        d = dict(acc)
+        wc = d.get("SQ_WAVE_CYCLES")
+        if wc:
+            for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+                d[c + "_frac_of_wave_cycles"] = d.get(c, 0.0) / wc
+        out[lab] = d
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--round", type=int, default=1)
@@ -130,6 +159,12 @@ def main():
                "FETCH_SIZE_KB_per_round": fr[:n], "FETCH_SIZE_KB_steady_mean": fm,
                "WRITE_SIZE_KB_per_round": wr[:n], "WRITE_SIZE_KB_steady_mean": wm,
                "traffic_bytes_per_launch": (2 * fm + wm) * 1024.0, "traffic_bytes_per_launch_raw": (fm + wm) * 1024.0}
+        sqs = search_launch_counters(read_counters(a.src, "pmc_sq"))
+        if sqs:
+            out["sq_counters_per_launch"] = sqs
+            out["sq_note"] = ("SQ pass of tools/collect_profiles.sh (opening-phase rounds of the bench); SQ_WAIT_ANY = wave cycles "
+                              "waiting on anything (memory, LDS, dependencies), SQ_WAIT_INST_ANY = waiting to issue, "
+                              "SQ_ACTIVE_INST_ANY = executing; four waves share a SIMD in k_sim")
         with open(os.path.join(prof, f"{tag}_pmc_search_round.json"), "w") as f:
             json.dump(out, f, indent=1)
         print("wrote", f"{tag}_pmc_search_round.json", out["traffic_bytes_per_launch"] / 1e6, "MB per round")
