@@ -242,6 +242,18 @@ def pmc_traffic():
     return d.get("traffic_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
 
 
+def library_gemm_peak():
+    """what hipBLASLt sustains on an 8192^3 bf16 GEMM on this hardware (tools/gemm_peak.py -> profiles/): the practical
+    matrix-pipe ceiling the kernel's issued_bf16_tflops can be read against; the contract's `peak` stays the nominal one"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_peak.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return {"value": max(r["tflops"] for r in d["runs"]), "source": os.path.relpath(files[-1], ROOT)}
+
+
 def pmc_nn(kernel):
     """MFMA utilisation / HBM bytes per launch of a network kernel from the committed PMC passes (profiles/)."""
     import glob
@@ -517,6 +529,7 @@ def main():
                                "issued_bf16_tflops": 3.0 * tfl * 96.0 / 90.0,
                                "issued_frac_of_peak": 3.0 * tfl * 96.0 / 90.0 / 2500.0,
                                "mfma_util_pmc": pmc.get("mfma_util"),
+                               "library_gemm_bf16_tflops": library_gemm_peak(),
                                "share_of_round": b_ms * len(blk) / args.steps / step_ms,
                                "note": "achieved = fp32-class convolution FLOPs (2 per MAC); every product is three "
                                        "bf16 MFMAs on (hi, lo) operand pairs over 96 pixel slots per 90-pixel board, "
