@@ -8,7 +8,10 @@ from cchess_alphazero import _native
 COUNTER_NAMES = ["sims", "expansions", "terminal_sims", "repetition_sims", "parked", "sum_depth", "max_depth",
                  "edges_visited", "leaf_moves", "plies", "games", "red_wins", "black_wins", "draws", "resigns",
                  "tree_resets", "overflow_sims", "depth_overflow", "root_reused_sims", "ring_dropped", "chunks_taken",
-                 "stat_blocks"]
+                 "stat_blocks",
+                 # only in the CZ_SIM_PROFILE tuning build (the library reports how many counters it has)
+                 "cyc_select", "cyc_rules", "cyc_hash", "cyc_expand", "cyc_rep", "cyc_attach", "cyc_resume_load",
+                 "cyc_kernel_select", "cyc_kernel_backup"]
 MAX_NO_ACT = 32          # csrc/xq_search.h: banned root moves per game and ply
 
 

@@ -46,6 +46,31 @@ XQ_HD uint16_t label_ft(int label)
 // lists, per source square, the 8 same-rank and 9 same-file destinations and then the on-board knight jumps
 // (lookup_tables.py:66-77), so the index is base[from] + a position computed from the coordinates.
 // Advisor and elephant moves live in the literal tail of the set and keep using the table.
+// base = Tables::base[from], valid = Tables::kvalid[from]: the same for every move of a piece, so a caller that emits
+// several moves from one square loads them once (label_block) instead of once per move -- each is a dependent global
+// load, and in the one-wave-per-tree search they were most of the move generator's time.
+XQ_HD uint16_t label_in_block(int base, uint32_t valid, int from, int to)
+{
+    const int x = from % 9, y = from / 9, tx = to % 9, ty = to / 9;
+    if (ty == y) return (uint16_t)(base + (tx < x ? tx : tx - 1));
+    if (tx == x) return (uint16_t)(base + 8 + (ty < y ? ty : ty - 1));
+    // knight: offsets (dy, dx) in label order {-2,-1},{-1,-2},{-2,1},{1,-2},{2,-1},{-1,2},{2,1},{1,2}
+    const int dy = ty - y, dx = tx - x;
+    int k;
+    if (dy == -2) k = dx < 0 ? 0 : 2;
+    else if (dy == 2) k = dx < 0 ? 4 : 6;
+    else if (dy == -1) k = dx < 0 ? 1 : 5;
+    else k = dx < 0 ? 3 : 7;
+    return (uint16_t)(base + 17 + __builtin_popcount(valid & ((1u << k) - 1u)));
+}
+XQ_HD void label_block(int from, int* base, uint32_t* valid)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    *base = d_tab.base[from]; *valid = d_tab.kvalid[from];
+#else
+    *base = h_tab.base[from]; *valid = h_tab.kvalid[from];
+#endif
+}
 XQ_HD uint16_t label_of_line_or_knight(int from, int to)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -82,13 +107,27 @@ struct MoveSink {
     int hit_from;               // its source square
     bool formula;               // label by arithmetic instead of the 16 KB table (one board per lane: the table
                                 // gather is a dependent global load per move and there are few waves to hide it)
+    int base;                   // formula: the source square's label block (label_block), loaded once per piece
+    uint32_t kvalid;
     XQ_HD void put(int from, int to)
     {
         if (to == watch && hit < 0) { hit = off + n; hit_from = from; }
         if (EMIT) {
             const int i = off + n;
             if (i < cap) {
-                lab[i] = formula ? label_of_line_or_knight(from, to) : label_of(from, to);
+                lab[i] = formula ? label_in_block(base, kvalid, from, to) : label_of(from, to);
+                if (ft) ft[i] = (uint16_t)((from << 8) | to);
+            }
+        }
+        ++n;
+    }
+    XQ_HD void put_labelled(int from, int to, uint16_t label)      // the caller already has the label (AeLabels)
+    {
+        if (to == watch && hit < 0) { hit = off + n; hit_from = from; }
+        if (EMIT) {
+            const int i = off + n;
+            if (i < cap) {
+                lab[i] = label;
                 if (ft) ft[i] = (uint16_t)((from << 8) | to);
             }
         }
@@ -99,7 +138,7 @@ struct MoveSink {
 // Step tables of the non-sliding pieces in the reference's direction order (mov_dir, common.py:66-76):
 // packed as (dx + 2) | (dy + 2) << 3.  Row = piece code (KNIGHT, ELEPHANT, ADVISOR, KING, PAWN).
 #define XQ_STEP(dx, dy) (uint8_t)(((dx) + 2) | (((dy) + 2) << 3))
-struct StepTable {
+struct alignas(8) StepTable {
     uint8_t n[8];
     uint8_t d[8][8];
 };
@@ -140,6 +179,60 @@ XQ_HD int step_code(int p, int k)
     return h_steps.d[p][k];
 #endif
 }
+// all (up to 8) step codes of piece p, code k in byte k, and their number, as immediates selected by the piece type:
+// no memory access (a one-byte table load per loop iteration was a dependent global round trip each)
+constexpr uint64_t step_row_of(int p)
+{
+    uint64_t v = 0;
+    for (int k = 0; k < 8; ++k) v |= (uint64_t)h_steps.d[p][k] << (8 * k);
+    return v;
+}
+XQ_HD uint64_t step_row(int p)
+{
+    constexpr uint64_t RK = step_row_of(KING), RA = step_row_of(ADVISOR), RE = step_row_of(ELEPHANT),
+                       RN = step_row_of(KNIGHT), RP = step_row_of(PAWN);
+    return p == KNIGHT ? RN : (p == PAWN ? RP : (p == KING ? RK : (p == ADVISOR ? RA : (p == ELEPHANT ? RE : 0ull))));
+}
+XQ_HD int step_count_imm(int p)
+{
+    return p == KNIGHT ? 8 : (p == PAWN ? 3 : ((p == KING || p == ADVISOR || p == ELEPHANT) ? 4 : 0));
+}
+static_assert(h_steps.n[KNIGHT] == 8 && h_steps.n[PAWN] == 3 && h_steps.n[KING] == 4 && h_steps.n[ADVISOR] == 4 &&
+              h_steps.n[ELEPHANT] == 4 && h_steps.n[ROOK] == 0 && h_steps.n[CANNON] == 0, "step_count_imm");
+
+// Labels of the (up to 4) advisor / elephant moves from every square, step k of the piece's row in 16-bit field k
+// (NOMOVE where the step leaves the board or is not in the label set): one 8-byte load per piece instead of a
+// (from, to) table gather per move.
+struct alignas(8) AeLabels {
+    uint16_t lab[2][NSQ][4];    // [0] advisor, [1] elephant
+};
+constexpr AeLabels make_ae_labels()
+{
+    AeLabels t{};
+    for (int e = 0; e < 2; ++e)
+        for (int sq = 0; sq < NSQ; ++sq)
+            for (int k = 0; k < 4; ++k) {
+                const int code = h_steps.d[e ? ELEPHANT : ADVISOR][k];
+                const int x_ = sq % 9 + (code & 7) - 2, y_ = sq / 9 + (code >> 3) - 2;
+                t.lab[e][sq][k] = (x_ < 0 || x_ > 8 || y_ < 0 || y_ > 9) ? (uint16_t)NOMOVE
+                                                                        : h_tab.label_of[sq * NSQ + y_ * 9 + x_];
+            }
+    return t;
+}
+#if defined(__HIPCC__)
+static __device__ const AeLabels d_ae = make_ae_labels();
+#endif
+static constexpr AeLabels h_ae = make_ae_labels();
+XQ_HD uint64_t ae_label_row(int elephant, int sq)
+{
+    uint64_t v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    v = *reinterpret_cast<const uint64_t*>(d_ae.lab[elephant][sq]);
+#else
+    for (int k = 0; k < 4; ++k) v |= (uint64_t)h_ae.lab[elephant][sq][k] << (16 * k);
+#endif
+    return v;
+}
 
 // 90-bit square sets (bit s = square s): occupancy, the mover's pieces, the opponent's king(s).
 struct Set90 {
@@ -175,7 +268,8 @@ XQ_HD int gen_piece(int p, int s, const Set90& occ, const Set90& own, const Set9
                     bool formula_labels = false, int cap = MAXMOVES, int* hit_from = nullptr)
 {
     // advisor / elephant moves live in the literal tail of the label set: always from the table
-    MoveSink<EMIT> out{lab, ft, off, 0, cap, watch, -1, -1, formula_labels && p != ADVISOR && p != ELEPHANT};
+    MoveSink<EMIT> out{lab, ft, off, 0, cap, watch, -1, -1, formula_labels && p != ADVISOR && p != ELEPHANT, 0, 0u};
+    if (EMIT && out.formula) label_block(s, &out.base, &out.kvalid);
     const int x = s % 9, y = s / 9;
     if (p == ROOK || p == CANNON) {                       // :288-320
         const uint32_t row = rank_bits(occ, y), col = file_bits(occ, x);
@@ -211,12 +305,15 @@ XQ_HD int gen_piece(int p, int s, const Set90& occ, const Set90& own, const Set9
             if (has(oking, u * 9 + x)) fly = u * 9 + x;
         }
     }
-    const int nd = step_count(p);
+    const int nd = step_count_imm(p);
+    const uint64_t codes = step_row(p);
+    const bool ae = EMIT && formula_labels && (p == ADVISOR || p == ELEPHANT);
+    const uint64_t ae_labs = ae ? ae_label_row(p == ELEPHANT, s) : 0ull;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma nounroll
 #endif
     for (int k = 0; k < nd; ++k) {
-        const int code = step_code(p, k);
+        const int code = (int)((codes >> (8 * k)) & 0xFFu);
         const int dx = (code & 7) - 2, dy = (code >> 3) - 2;
         const int x_ = x + dx, y_ = y + dy;
         if (x_ < 0 || x_ > 8 || y_ < 0 || y_ > 9) continue;           // can_move, :323-330
@@ -230,7 +327,8 @@ XQ_HD int gen_piece(int p, int s, const Set90& occ, const Set90& own, const Set9
         } else {                                                      // king, advisor: palace (:277-281)
             if (x_ < 3 || x_ > 5 || y_ > 2) continue;
         }
-        out.put(s, t);
+        if (ae) out.put_labelled(s, t, (uint16_t)((ae_labs >> (16 * k)) & 0xFFFFu));
+        else out.put(s, t);
         if (fly >= 0) out.put(s, fly);                                // once per accepted king step (:283-286)
     }
     if (hit && out.hit >= 0 && *hit < 0) { *hit = out.hit; if (hit_from) *hit_from = out.hit_from; }

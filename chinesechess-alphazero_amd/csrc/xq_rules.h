@@ -220,7 +220,7 @@ XQ_D DoneResult wave_done(const int8_t* b, int8_t* tmpb, MoveList& ml0, MoveList
     }
     if (!winner && need_check) {                               // :61-73
         flip_board(b, tmpb);
-        const int n2 = wave_movegen(tmpb, ml1, plist);
+        const int n2 = wave_movegen<FORMULA>(tmpb, ml1, plist);
         r.check = first_move_to(ml1, n2, 89 - rk) >= 0;
     }
     r.over = winner != 0;
@@ -242,7 +242,7 @@ XQ_D int wave_has_attack(const int8_t* b)
 XQ_D int wave_be_catched(const int8_t* b, int from, int8_t* tmpb, MoveList& ml, uint16_t* plist)
 {
     flip_board(b, tmpb);
-    const int n = wave_movegen(tmpb, ml, plist);
+    const int n = wave_movegen<true>(tmpb, ml, plist);        // only the squares of the list are read: cheap labels
     return first_move_to(ml, n, 89 - from) >= 0;
 }
 
@@ -260,7 +260,7 @@ XQ_D int wave_catch_list(const int8_t* b, const MoveList& moves, int nmoves,
         const int vict = b[t];
         if (vict == 0) continue;                               // no capture
         step_board(b, f, t, nextb);
-        const int nr = wave_movegen(nextb, reply, plist);
+        const int nr = wave_movegen<true>(nextb, reply, plist);
         if (first_move_to(reply, nr, 89 - t) >= 0) continue;   // could be recaptured
         const int a = b[f];
         if (a == PAWN && f / 9 <= 4) continue;                 // :443-444
@@ -292,9 +292,9 @@ XQ_D int wave_will_check_or_catch(RulesLDS& w, const int8_t* b, int label)
     const int q0 = black[lane], q1 = (lane < 26) ? black[lane + 64] : 0;
     const int ksq = lowest_bit(__ballot(q0 == -KING), __ballot(q1 == -KING));
     const int target = ksq >= 0 ? ksq : 89;       // red_k stays [0,0] -> (9,8) when the king is gone
-    const int nb = wave_movegen(black, w.ml[0], w.plist);
+    const int nb = wave_movegen<true>(black, w.ml[0], w.plist);
     if (first_move_to(w.ml[0], nb, target) >= 0) return 1;                        // :406-411
-    const int n1 = wave_movegen(b, w.ml[1], w.plist);
+    const int n1 = wave_movegen<true>(b, w.ml[1], w.plist);
     const int c1 = wave_catch_list(b, w.ml[1], n1, w.bd[2], w.ml[2], w.cset[0], w.plist);  // first_set
     const int c2 = wave_catch_list(black, w.ml[0], nb, w.bd[2], w.ml[2], w.cset[1], w.plist);
     // second_set - first_set != {} and len(second_set) >= len(first_set), :415

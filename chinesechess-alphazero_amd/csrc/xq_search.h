@@ -52,7 +52,12 @@ enum Counter : int {
     CT_SIMS = 0, CT_EXPANSIONS, CT_TERMINAL_SIMS, CT_REPETITION_SIMS, CT_PARKED, CT_SUM_DEPTH, CT_MAX_DEPTH,
     CT_EDGES_VISITED, CT_LEAF_MOVES, CT_PLIES, CT_GAMES, CT_RED_WINS, CT_BLACK_WINS, CT_DRAWS, CT_RESIGNS,
     CT_TREE_RESETS, CT_OVERFLOW_SIMS, CT_DEPTH_OVERFLOW, CT_ROOT_REUSED_SIMS, CT_RING_DROPPED, CT_CHUNKS_TAKEN,
-    CT_STAT_BLOCKS, CT_COUNT
+    CT_STAT_BLOCKS,
+#ifdef CZ_SIM_PROFILE       // tuning build (tools/ab_search.sh): shader-clock cycles of wave time per section of a simulation
+    CT_CYC_SELECT, CT_CYC_RULES, CT_CYC_HASH, CT_CYC_EXPAND, CT_CYC_REP, CT_CYC_ATTACH, CT_CYC_RESUME_LOAD,
+    CT_CYC_KERNEL_SELECT, CT_CYC_KERNEL_BACKUP,
+#endif
+    CT_COUNT
 };
 
 struct SearchParams {

@@ -129,6 +129,13 @@ XQ_D void count_max(const GameView& gv, int which, unsigned long long val)
 {
     if (lane_id() == 0 && gv.lctr[which] < val) gv.lctr[which] = val;
 }
+#ifdef CZ_SIM_PROFILE
+#define PROF_BEGIN() long long prof_t = clock64()
+#define PROF(which) do { const long long t_ = clock64(); count(gv, which, (unsigned long long)(t_ - prof_t)); prof_t = t_; } while (0)
+#else
+#define PROF_BEGIN() do { } while (0)
+#define PROF(which) do { } while (0)
+#endif
 XQ_D void counters_begin(const GameView& gv)
 {
     for (int i = lane_id(); i < CT_COUNT; i += 64) gv.lctr[i] = 0;
@@ -671,6 +678,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
         wave_sync();
         return;
     }
+    PROF_BEGIN();
     for (;;) {
         // state in history[:-1] (player.py:223-236)
         const int rep = find_in_path(L, depth, node);
@@ -684,6 +692,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
             count(gv, CT_REPETITION_SIMS);
             backup(P, gv, L, depth, v);
             sim_finish(gv, sim, active);
+            PROF(CT_CYC_REP);
             return;
         }
         char* base = rec_ptr(gv, (uint32_t)node);
@@ -752,11 +761,14 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
         depth += 1;
         wave_sync();
         int child = pk.have ? pk.child : uni(ep->child);
+        PROF(CT_CYC_SELECT);
         if (child == CHILD_UNKNOWN) {
-            unpack_key(reinterpret_cast<const uint32_t*>(base), L.r.bd[0]);
+            // (the table load of the move's squares is issued before the key's so that the two round trips overlap)
             const int ft = label_ft(pk.have ? pk.mv : uni((int)node_mv(base, nm)[pk.j]));
+            unpack_key(reinterpret_cast<const uint32_t*>(base), L.r.bd[0]);
             step_board(L.r.bd[0], ft >> 8, ft & 0xFF, L.r.bd[1]);
             const DoneResult d = wave_done<true>(L.r.bd[1], L.r.bd[2], L.r.ml[0], L.r.ml[1], L.r.plist, false);   // player.py:204
+            PROF(CT_CYC_RULES);
             if (d.over) {
                 child = d.v > 0 ? CHILD_TERM_WIN : CHILD_TERM_LOSS;
                 if (lane == owner) ep->child = child;
@@ -764,6 +776,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
                 const uint64_t h = pack_key(L.r.bd[1], L.key);
                 int slot;
                 int idx = hash_lookup(gv, P, L.key, h, &slot);
+                PROF(CT_CYC_HASH);
                 if (idx >= 0) {
                     if (lane == owner) ep->child = idx;
                     child = idx;
@@ -779,6 +792,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
                     if (lane == 0) { gv.s_state[sim] = SIM_LEAF; gv.s_node[sim] = idx; gv.s_depth[sim] = depth; }
                     write_planes<HIST>(io, L.r.bd[1], L.codes, (size_t)g * P.K + sim, HIST ? history_board(P, B, gv, L, fresh, depth) : nullptr);
                     wave_sync();
+                    PROF(CT_CYC_EXPAND);
                     return;
                 }
             }
@@ -1170,7 +1184,7 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
         if (no_eat_count >= 120 || turns >= 2 * P.max_game_length) {    // :149-151
             game_over = true; value = 0;
         } else {
-            const DoneResult d = wave_done(L.r.bd[3], L.r.bd[1], L.r.ml[0], L.r.ml[1], L.r.plist, true);   // :153
+            const DoneResult d = wave_done<true>(L.r.bd[3], L.r.bd[1], L.r.ml[0], L.r.ml[1], L.r.plist, true);   // :153
             game_over = d.over != 0; value = d.v; final_move = d.final_move;
             if (!game_over && !wave_has_attack(L.r.bd[3])) { game_over = true; value = 0; }  // :154-158
             if (!game_over && !d.check) {                               // :161-175
@@ -1256,6 +1270,9 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
     if (uni((int)B.g_phase[g]) != PH_SEARCH) return;
     const GameView gv = make_view(B, P, g, L.ctr, L.chtab);
     counters_begin(gv);
+#ifdef CZ_SIM_PROFILE
+    const long long prof_k0 = clock64();
+#endif
     const RoundIO io{planes, P.planes_dtype, P.in_planes};
     int active = uni(B.g_active[g]);
     Arena ar{uniu(B.g_heap_top[g]), uni(B.g_nchunks[g]), uni(B.g_node_count[g])};
@@ -1285,6 +1302,7 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             my_meta = *reinterpret_cast<const uint32_t*>(rec_ptr(gv, (uint32_t)sn_node) + NODE_OFF_HDR + 4);
             my_v = value[my_row];
         }
+        PROF_BEGIN();
         for (int i = 0; i < P.K; ++i) {
             if (__builtin_amdgcn_readlane(sn_state, i) != SIM_LEAF) continue;
             const int node = __builtin_amdgcn_readlane(sn_node, i);
@@ -1301,6 +1319,7 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             }
             sim_finish(gv, i, &active);
         }
+        PROF(CT_CYC_ATTACH);
         resume_i = 0;                                                 // 2. then resume the parked simulations
     } else if ((mask & SIM_BACKUP) && active > 0) {                   // (more than 64 slots per game: slot by slot)
         for (int i = 0; i < P.K; ++i) {
@@ -1373,6 +1392,9 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             }
         }
     }
+#ifdef CZ_SIM_PROFILE
+    count(gv, (mask & SIM_SELECT) ? CT_CYC_KERNEL_SELECT : CT_CYC_KERNEL_BACKUP, (unsigned long long)(clock64() - prof_k0));
+#endif
     counters_flush(gv);
 }
 

@@ -52,6 +52,28 @@ int lane_label_formula_mismatches(void)
         const bool line = dx == 0 || dy == 0;
         const bool knight = (dx * dx + dy * dy) == 5;
         if ((line || knight) && label_of_line_or_knight(f, t) != l) ++bad;
+        if (line || knight) {                          // the per-piece form the move generator uses
+            int base; uint32_t valid;
+            label_block(f, &base, &valid);
+            if (label_in_block(base, valid, f, t) != l) ++bad;
+        }
+    }
+    // advisor / elephant rows: step k of the piece from every square against the (from, to) table
+    for (int e = 0; e < 2; ++e)
+        for (int sq = 0; sq < NSQ; ++sq) {
+            const uint64_t row = ae_label_row(e, sq);
+            const uint64_t codes = step_row(e ? ELEPHANT : ADVISOR);
+            for (int k = 0; k < 4; ++k) {
+                const int code = (int)((codes >> (8 * k)) & 0xFF);
+                const int x_ = sq % 9 + (code & 7) - 2, y_ = sq / 9 + (code >> 3) - 2;
+                const uint16_t want = (x_ < 0 || x_ > 8 || y_ < 0 || y_ > 9) ? (uint16_t)NOMOVE : label_of(sq, y_ * 9 + x_);
+                if ((uint16_t)((row >> (16 * k)) & 0xFFFF) != want) ++bad;
+            }
+        }
+    for (int p = 0; p < 8; ++p) {                      // immediates against the step table
+        if (step_count_imm(p) != step_count(p)) ++bad;
+        for (int k = 0; k < step_count(p); ++k)
+            if ((int)((step_row(p) >> (8 * k)) & 0xFF) != step_code(p, k)) ++bad;
     }
     return bad;
 }

@@ -73,6 +73,10 @@ def main():
            "search_round_ms": {"mean": sum(t) / len(t), "median": t[len(t) // 2], "p99": t[int(len(t) * 0.99)], "max": t[-1]},
            "mean_depth": c["sum_depth"] / max(1, c["sims"]), "plies": c["plies"], "games": c["games"],
            "tree_resets": c["tree_resets"], "nodes": m["nodes"], "tree_gb": m["tree_bytes"] / 1e9}
+    if "cyc_select" in c:                  # CZ_SIM_PROFILE build: shader-clock cycles of wave time per section, per simulation
+        n = max(1, c["sims"])
+        out["cycles_per_sim"] = {k: c[k] / n for k in c if k.startswith("cyc_")}
+        out["levels_per_sim"] = c["sum_depth"] / n
     print(json.dumps(out))
     s.close()
 
