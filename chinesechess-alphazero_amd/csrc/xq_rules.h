@@ -163,7 +163,7 @@ XQ_D int wave_movegen(const int8_t* b, MoveList& ml, uint16_t* plist)
         const int c = act ? gen_piece<false>(p, s, occ, own, oking, nullptr, nullptr, 0) : 0;
         const int inc = wave_incl_scan(c, lane);
         if (c) gen_piece<true>(p, s, occ, own, oking, ml.lab, ml.ft, total + inc - c, -1, nullptr, FORMULA);
-        total += __shfl(inc, 63, 64);
+        total += __builtin_amdgcn_readlane(inc, 63);
     }
     wave_sync();
     return total;

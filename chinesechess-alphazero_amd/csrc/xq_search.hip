@@ -496,24 +496,28 @@ XQ_D Picked select_edge(const SearchParams& P, char* base, const EdgeStat* sb, i
     int pick;
     if (first_win >= 0) pick = first_win;
     else {
-        // arg max of (score, index): `>=` keeps the LAST maximal move (player.py:312-314)
+        // arg max of (score, index): `>=` keeps the LAST maximal move (player.py:312-314).  The maximum itself by a
+        // butterfly on the score alone (never NaN: see `valid`), then the lanes that hold it vote: the largest index wins,
+        // and an index of the second half (lane + 64) beats any of the first.
+        double m = best_s;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double os = __shfl_xor(best_s, d, 64);
-            const int oj = __shfl_xor(best_j, d, 64);
-            if (os > best_s || (os == best_s && oj > best_j)) { best_s = os; best_j = oj; }
-        }
-        pick = uni(best_j);
+        for (int d = 1; d < 64; d <<= 1) m = fmax(m, __shfl_xor(m, d, 64));
+        const bool top = best_j >= 0 && best_s == m;
+        const uint64_t t1 = __ballot(top && best_j >= 64), t0 = __ballot(top);
+        pick = t1 ? 64 + (63 - __clzll((long long)t1)) : (t0 ? 63 - __clzll((long long)t0) : -1);
     }
     Picked r;
     r.j = pick;
     r.have = pick >= 0 && pick < 64;
     r.n = 0; r.child = CHILD_UNKNOWN; r.mv = 0; r.w = 0.0;
-    if (r.have) {
-        r.n = __shfl(n0, pick, 64);
-        r.child = __shfl(child0, pick, 64);
-        r.mv = __shfl(mv0, pick, 64);
-        r.w = __shfl(w0, pick, 64);
+    if (r.have) {                                              // pick is wave-uniform: register reads, no LDS permute
+        r.n = __builtin_amdgcn_readlane(n0, pick);
+        r.child = __builtin_amdgcn_readlane(child0, pick);
+        r.mv = __builtin_amdgcn_readlane(mv0, pick);
+        const long long wb = __double_as_longlong(w0);
+        const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)wb, pick);
+        const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)wb >> 32), pick);
+        r.w = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     }
     return r;
 }
