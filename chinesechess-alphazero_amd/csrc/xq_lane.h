@@ -121,6 +121,19 @@ struct MoveSink {
         }
         ++n;
     }
+    // a rook / cannon move along a rank or a file: in formula mode its label is base + a coordinate the caller has at hand
+    XQ_HD void put_line(int from, int to, int formula_label)
+    {
+        if (to == watch && hit < 0) { hit = off + n; hit_from = from; }
+        if (EMIT) {
+            const int i = off + n;
+            if (i < cap) {
+                lab[i] = formula ? (uint16_t)formula_label : label_of(from, to);
+                if (ft) ft[i] = (uint16_t)((from << 8) | to);
+            }
+        }
+        ++n;
+    }
     XQ_HD void put_labelled(int from, int to, uint16_t label)      // the caller already has the label (AeLabels)
     {
         if (to == watch && hit < 0) { hit = off + n; hit_from = from; }
@@ -278,10 +291,17 @@ XQ_HD int gen_piece(int p, int s, const Set90& occ, const Set90& own, const Set9
         uint32_t dm = col & ((1u << y) - 1u), um = col >> (y + 1);
         int l = lm ? top_bit(lm) : -1, r = rm ? x + 1 + low_bit(rm) : 9;
         int d = dm ? top_bit(dm) : -1, u = um ? y + 1 + low_bit(um) : 10;
-        for (int t = l + 1; t < x; ++t) out.put(s, y * 9 + t);
-        for (int t = x + 1; t < r; ++t) out.put(s, y * 9 + t);
-        for (int t = d + 1; t < y; ++t) out.put(s, t * 9 + x);
-        for (int t = y + 1; t < u; ++t) out.put(s, t * 9 + x);
+        // labels of the block of square s: rank destinations tx -> base + (tx < x ? tx : tx - 1), file destinations
+        // ty -> base + 8 + (ty < y ? ty : ty - 1)   (label_in_block)
+        const int b0 = out.base, b8 = out.base + 8;
+        if (!EMIT && watch < 0) {
+            out.n += (x - l - 1) + (r - x - 1) + (y - d - 1) + (u - y - 1);      // counting only: no loop
+        } else {
+            for (int t = l + 1; t < x; ++t) out.put_line(s, y * 9 + t, b0 + t);
+            for (int t = x + 1; t < r; ++t) out.put_line(s, y * 9 + t, b0 + t - 1);
+            for (int t = d + 1; t < y; ++t) out.put_line(s, t * 9 + x, b8 + t);
+            for (int t = y + 1; t < u; ++t) out.put_line(s, t * 9 + x, b8 + t - 1);
+        }
         if (p == CANNON) {                                // the next blocker beyond each screen
             if (l > -1) { lm &= ~(1u << l); l = lm ? top_bit(lm) : -1; }
             if (r < 9) { rm &= rm - 1u; r = rm ? x + 1 + low_bit(rm) : 9; }
@@ -289,10 +309,10 @@ XQ_HD int gen_piece(int p, int s, const Set90& occ, const Set90& own, const Set9
             if (u < 10) { um &= um - 1u; u = um ? y + 1 + low_bit(um) : 10; }
         }
         // a blocker is never empty, so can_move() == "on board and not the mover's own piece"
-        if (l > -1 && !has(own, y * 9 + l)) out.put(s, y * 9 + l);
-        if (r < 9 && !has(own, y * 9 + r)) out.put(s, y * 9 + r);
-        if (d > -1 && !has(own, d * 9 + x)) out.put(s, d * 9 + x);
-        if (u < 10 && !has(own, u * 9 + x)) out.put(s, u * 9 + x);
+        if (l > -1 && !has(own, y * 9 + l)) out.put_line(s, y * 9 + l, b0 + l);
+        if (r < 9 && !has(own, y * 9 + r)) out.put_line(s, y * 9 + r, b0 + r - 1);
+        if (d > -1 && !has(own, d * 9 + x)) out.put_line(s, d * 9 + x, b8 + d);
+        if (u < 10 && !has(own, u * 9 + x)) out.put_line(s, u * 9 + x, b8 + u - 1);
         if (hit && out.hit >= 0 && *hit < 0) { *hit = out.hit; if (hit_from) *hit_from = out.hit_from; }
         return out.n;
     }
