@@ -160,9 +160,10 @@ XQ_D int wave_movegen(const int8_t* b, MoveList& ml, uint16_t* plist)
         const bool act = base + lane < np;
         const int e = act ? plist[base + lane] : 0;
         const int s = e & 0xFF, p = e >> 8;
-        const int c = act ? gen_piece<false>(p, s, occ, own, oking, nullptr, nullptr, 0) : 0;
+        const PiecePlan pl = act ? plan_piece(p, s, occ, own, oking) : PiecePlan{0, 0ull};
+        const int c = pl.n;
         const int inc = wave_incl_scan(c, lane);
-        if (c) gen_piece<true>(p, s, occ, own, oking, ml.lab, ml.ft, total + inc - c, -1, nullptr, FORMULA);
+        if (c) emit_plan(p, s, pl.st, ml.lab, ml.ft, total + inc - c, FORMULA);
         total += __builtin_amdgcn_readlane(inc, 63);
     }
     wave_sync();

@@ -45,6 +45,33 @@ def test_movegen_and_planes(harness, positions_1k):
         assert (pl.reshape(14, 10, 9) == xo.planes_board(b)).all()
 
 
+def test_plan_emit_movegen_matches_the_oracle(harness, positions_1k):
+    """plan_piece / emit_plan (the two-phase generator of wave_movegen) on the golden suite and on a few thousand
+    oracle playout positions, labels from the table and by arithmetic."""
+    lab = np.zeros(160, dtype=np.uint16)
+    ft = np.zeros(160, dtype=np.uint16)
+    boards = [xo.state_to_board(r["state"]) for r in positions_1k]
+    rng = np.random.default_rng(11)
+    for _ in range(40):
+        b = xo.state_to_board(xo.INIT_STATE)
+        for _ply in range(120):
+            boards.append(b)
+            if xo.done_board(b)[0]:
+                break
+            mv = xo.legal_moves_board(b)
+            b, _ = xo.step_board(b, int(mv[rng.integers(len(mv))]))
+    for b in boards:
+        exp = xo.legal_moves_board(b)
+        for formula in (0, 1):
+            n = harness.lane_movegen_plan(b.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p),
+                                          ft.ctypes.data_as(C.c_void_p), formula)
+            assert n == len(exp) and (lab[:n] == exp).all(), (formula, xo.board_to_state(b))
+        n = harness.lane_movegen(b.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p), ft.ctypes.data_as(C.c_void_p))
+        ft_ref = ft[:n].copy()
+        harness.lane_movegen_plan(b.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p), ft.ctypes.data_as(C.c_void_p), 1)
+        assert (ft[:n] == ft_ref).all()
+
+
 def test_thread_per_board_rules(harness, positions_1k):
     """xq_tpb.h (one board per GPU lane) run on the CPU: move lists, done(need_check) for the golden suite and a
     few thousand oracle playout positions."""
