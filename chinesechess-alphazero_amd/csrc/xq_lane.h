@@ -265,8 +265,15 @@ XQ_HD uint32_t rank_bits(const Set90& m, int y)
 // the 10 squares of file x as bits 0..9
 XQ_HD uint32_t file_bits(const Set90& m, int x)
 {
-    uint32_t v = 0;
-    for (int y = 0; y < 10; ++y) v |= (uint32_t)has(m, 9 * y + x) << y;
+    // ranks 0..6 (squares x + 9k <= 62, all in `lo`): mask the seven bits 9 apart and gather them with one multiply --
+    // bit 9k times 2^(48 - 8j) lands on 48 + k for j = k and on 48 + k + 8 (k - j) otherwise, all distinct, so nothing
+    // carries into bits 48..54.  (A loop of ten has() calls was ~60 instructions; both slider lanes and the king use this.)
+    const uint64_t seven = ((m.lo >> x) & 0x0040201008040201ULL) * 0x0001010101010101ULL;
+    uint32_t v = (uint32_t)(seven >> 48) & 0x7Fu;
+    const uint64_t from63 = (m.lo >> 63) | (m.hi << 1);               // bit i = square 63 + i
+    v |= (uint32_t)((from63 >> x) & 1ull) << 7;                       // rank 7: square 63 + x
+    v |= (uint32_t)((m.hi >> (x + 8)) & 1ull) << 8;                   // rank 8: square 72 + x
+    v |= (uint32_t)((m.hi >> (x + 17)) & 1ull) << 9;                  // rank 9: square 81 + x
     return v;
 }
 XQ_HD int top_bit(uint32_t v) { return 31 - __builtin_clz(v); }       // v != 0

@@ -400,14 +400,14 @@ XQ_D void attach_and_backup(const SearchParams& P, const GameView& gv, SearchLDS
     if (lane < nm) p0 = prow[m0];
     if (lane + 64 < nm) p1 = prow[m1];
     if (lane < depth) { ep = edge_ptr(gv, (uint32_t)e); cur = *ep; }
-    // prior spreading (select_action_q_and_u, player.py:272-284)
-    if (lane < nm) L.pr[lane] = p0;
-    if (lane + 64 < nm) L.pr[lane + 64] = p1;
-    wave_sync();
+    // prior spreading (select_action_q_and_u, player.py:272-284): float32 accumulation in move order, the terms read
+    // straight from the lanes' registers (a loop over an LDS copy paid an LDS round trip per term)
     float all_p = 0.0f;
     if (nm > 0) {
-        all_p = L.pr[0];                                   // int 0 + float32
-        for (int j = 1; j < nm; ++j) all_p = all_p + L.pr[j];   // float32 accumulation in move order
+        all_p = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), 0));          // int 0 + float32
+        const int n0 = nm < 64 ? nm : 64;
+        for (int j = 1; j < n0; ++j) all_p = all_p + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), j));
+        for (int j = 64; j < nm; ++j) all_p = all_p + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p1), j - 64));
     }
     if (all_p == 0.0f) all_p = 1.0f;
     if (lane < nm) pp[lane] = p0 / all_p;
