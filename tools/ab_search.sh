@@ -3,7 +3,7 @@
 #   variants/libczero_<name>.so are built beforehand (git-ignored, they travel with the gpurun snapshot).
 mkdir -p gpurun_out
 : > gpurun_out/ab_search.log
-for rep in 1 2; do
+for rep in ${REPS:-1 2}; do
 for f in variants/libczero_*.so; do
   name=$(basename $f .so); name=${name#libczero_}
   echo "variant=$name rep=$rep" >> gpurun_out/ab_search.log
