@@ -52,6 +52,25 @@ int lane_movegen_plan(const int8_t* board, uint16_t* lab, uint16_t* ft, int form
     return off;
 }
 
+// file_bits (multiply-gather) against the definition, on pseudo-random 90-bit sets
+int lane_file_bits_mismatches(uint64_t seed, int n)
+{
+    int bad = 0;
+    uint64_t z = seed;
+    auto next = [&]() { z += 0x9E3779B97F4A7C15ULL; return mix64(z); };
+    for (int i = 0; i < n; ++i) {
+        Set90 m{next(), next() & ((1ull << 26) - 1ull)};
+        if (i % 7 == 0) m.lo = ~0ull;
+        if (i % 11 == 0) m.hi = (1ull << 26) - 1ull;
+        for (int x = 0; x < 9; ++x) {
+            uint32_t want = 0;
+            for (int y = 0; y < 10; ++y) want |= (uint32_t)has(m, 9 * y + x) << y;
+            if (file_bits(m, x) != want) ++bad;
+        }
+    }
+    return bad;
+}
+
 void lane_planes(const int8_t* board, float* planes)
 {
     for (int o = 0; o < 1260; ++o) planes[o] = (float)plane_bit(board, o);

@@ -72,6 +72,33 @@ def test_plan_emit_movegen_matches_the_oracle(harness, positions_1k):
         assert (ft[:n] == ft_ref).all()
 
 
+def test_file_bits_and_plan_on_arbitrary_boards(harness):
+    """file_bits against its definition on random square sets; plan / emit against gen_piece on boards no game reaches
+    (any piece on any square, up to 40 pieces of the mover)."""
+    harness.lane_file_bits_mismatches.argtypes = [C.c_uint64, C.c_int]
+    assert harness.lane_file_bits_mismatches(12345, 20000) == 0
+    rng = np.random.default_rng(3)
+    lab = np.zeros(512, dtype=np.uint16)
+    ft = np.zeros(512, dtype=np.uint16)
+    lab2 = np.zeros(512, dtype=np.uint16)
+    ft2 = np.zeros(512, dtype=np.uint16)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    for _ in range(3000):
+        b = np.zeros(90, dtype=np.int8)
+        k = int(rng.integers(1, 12))
+        sq = rng.choice(90, size=k, replace=False)
+        b[sq] = rng.integers(-7, 8, size=k).astype(np.int8)
+        n = harness.lane_movegen(vp(b), vp(lab), vp(ft))
+        if n > 128:
+            continue
+        for formula in (0, 1):
+            n2 = harness.lane_movegen_plan(vp(b), vp(lab2), vp(ft2), formula)
+            assert n2 == n, (formula, b.tolist())
+            assert (ft2[:n] == ft[:n]).all(), (formula, b.tolist())
+            if formula == 0:
+                assert (lab2[:n] == lab[:n]).all(), b.tolist()
+
+
 def test_thread_per_board_rules(harness, positions_1k):
     """xq_tpb.h (one board per GPU lane) run on the CPU: move lists, done(need_check) for the golden suite and a
     few thousand oracle playout positions."""
