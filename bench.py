@@ -495,7 +495,10 @@ def main():
                                "algorithmic_bytes_per_launch": bpe * exp_per_launch, "avg_launch_ms": k_ms,
                                "median_launch_ms": d["search_round_ms_median"], "max_launch_ms": d["search_round_ms_max"],
                                "bytes_per_expansion": bpe, "expansions_per_launch": exp_per_launch,
-                               "note": "latency/occupancy-bound pointer chasing (SURVEY 8d), not bandwidth-bound"}
+                               "note": "latency / instruction-issue bound pointer chasing (SURVEY 8d), not bandwidth-bound; the algorithmic "
+                                       "figure is SURVEY 8(d)'s canonical fp32 accounting (5040-byte planes, whole 8344-byte "
+                                       "policy row per expansion) -- the engine writes u8 planes (1260 B) and reads only the "
+                                       "legal moves' priors, so the measured PMC traffic is BELOW it"}
             nn_ms = step_ms - k_ms
             tf = fl * slots / (nn_ms * 1e-3) / 1e12
             if split:
