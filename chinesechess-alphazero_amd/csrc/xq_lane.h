@@ -470,6 +470,114 @@ XQ_HD void emit_plan(int p, int s, uint64_t st, uint16_t* lab, uint16_t* ft, int
     }
 }
 
+// ---- a quad of lanes per piece (prepared for the next round: xq_rules.h::wave_movegen under CZ_MOVEGEN_QUAD) ------------
+// Sub-lane q of a piece's quad does a quarter of its work: ray q of a rook / cannon (0 left, 1 right, 2 down, 3 up), steps
+// q and q + 4 of a stepping piece.  Every lane ends up with two segments of the piece's move list: A = the quiet moves of
+// its ray / its step q, B = the capture of its ray / its step q + 4.  The reference's order inside a piece is all A segments
+// in sub-lane order, then all B segments (quiet l, r, d, u then captures l, r, d, u; steps 0..3 then 4..7), so segment
+// offsets are prefix sums over the quad.  quad_plan analyses, quad_emit writes; tests/lane_harness.cpp::lane_movegen_quad
+// emulates the cross-lane sums and checks the result against gen_piece.
+struct QuadPlan {
+    int n_a, n_b;       // moves in segment A / B
+    uint32_t st;        // slider: (first blocker coordinate + 1) | (capture coordinate + 1) << 8; stepper: 0x80 | fly square
+};
+
+XQ_HD bool step_valid(int p, int x, int y, int code, const Set90& occ, const Set90& own)
+{
+    const int dx = (code & 7) - 2, dy = (code >> 3) - 2;
+    const int x_ = x + dx, y_ = y + dy;
+    if (x_ < 0 || x_ > 8 || y_ < 0 || y_ > 9) return false;               // can_move, :323-330
+    if (has(own, y_ * 9 + x_)) return false;
+    if (p == PAWN) return !(y < 5 && x_ != x);                            // :270
+    if (p == KNIGHT || p == ELEPHANT) {
+        if (has(occ, (y + dy / 2) * 9 + x + dx / 2)) return false;        // leg / eye
+        return !(p == ELEPHANT && y_ > 4);                                // :275
+    }
+    return !(x_ < 3 || x_ > 5 || y_ > 2);                                 // king, advisor: palace (:277-281)
+}
+
+XQ_HD QuadPlan quad_plan(int p, int s, int q, const Set90& occ, const Set90& own, const Set90& oking)
+{
+    const int x = s % 9, y = s / 9;
+    QuadPlan pl{0, 0, 0u};
+    if (p == ROOK || p == CANNON) {
+        const bool horiz = q < 2;
+        const uint32_t line = horiz ? rank_bits(occ, y) : file_bits(occ, x);
+        const int pos = horiz ? x : y, lim = horiz ? 9 : 10;
+        int first, second;                               // along the line; none = -1 towards 0, lim towards the far edge
+        if ((q & 1) == 0) {
+            uint32_t m = line & ((1u << pos) - 1u);
+            first = m ? top_bit(m) : -1;
+            if (m) m &= ~(1u << first);
+            second = m ? top_bit(m) : -1;                // the next blocker beyond the screen (none without a screen)
+            pl.n_a = pos - first - 1;
+        } else {
+            const uint32_t m = line >> (pos + 1);
+            first = m ? pos + 1 + low_bit(m) : lim;
+            const uint32_t m2 = m ? (m & (m - 1u)) : 0u;
+            second = m2 ? pos + 1 + low_bit(m2) : lim;
+            pl.n_a = first - pos - 1;
+        }
+        const int c = (p == CANNON) ? second : first;
+        const bool on = (q & 1) == 0 ? c > -1 : c < lim;
+        const int csq = horiz ? y * 9 + c : c * 9 + x;
+        pl.n_b = (on && !has(own, csq)) ? 1 : 0;
+        pl.st = (uint32_t)(first + 1) | ((uint32_t)(c + 1) << 8);
+        return pl;
+    }
+    int fly = -1;
+    if (p == KING) {
+        const uint32_t um = file_bits(occ, x) >> (y + 1);
+        if (um) {
+            const int u = y + 1 + low_bit(um);
+            if (has(oking, u * 9 + x)) fly = u * 9 + x;
+        }
+    }
+    const int nd = step_count_imm(p);
+    const uint64_t codes = step_row(p);
+    const int mult = fly >= 0 ? 2 : 1;                   // the fly move follows every accepted king step
+    if (q < nd && step_valid(p, x, y, (int)((codes >> (8 * q)) & 0xFFu), occ, own)) pl.n_a = mult;
+    if (q + 4 < nd && step_valid(p, x, y, (int)((codes >> (8 * (q + 4))) & 0xFFu), occ, own)) pl.n_b = mult;
+    pl.st = fly >= 0 ? (0x80u | (uint32_t)fly) : 0u;
+    return pl;
+}
+
+// off_a / off_b: list positions of this lane's two segments
+XQ_HD void quad_emit(int p, int s, int q, const QuadPlan& pl, uint16_t* lab, uint16_t* ft, int off_a, int off_b,
+                     bool formula_labels, int cap = MAXMOVES)
+{
+    const int x = s % 9, y = s / 9;
+    MoveSink<true> out{lab, ft, off_a, 0, cap, -1, -1, -1, formula_labels && p != ADVISOR && p != ELEPHANT, 0, 0u};
+    if (out.formula) label_block(s, &out.base, &out.kvalid);
+    if (p == ROOK || p == CANNON) {
+        const bool horiz = q < 2;
+        const int pos = horiz ? x : y;
+        const int first = (int)(pl.st & 0xFFu) - 1, c = (int)((pl.st >> 8) & 0xFFu) - 1;
+        const int lo = (q & 1) == 0 ? first + 1 : pos + 1, hi = (q & 1) == 0 ? pos : first;     // quiet coordinates [lo, hi)
+        const int lb = horiz ? out.base : out.base + 8;                                         // label of coordinate t: lb + (t < pos ? t : t - 1)
+        for (int t = lo; t < hi; ++t) out.put_line(s, horiz ? y * 9 + t : t * 9 + x, lb + (t < pos ? t : t - 1));
+        if (pl.n_b) {
+            out.off = off_b; out.n = 0;
+            out.put_line(s, horiz ? y * 9 + c : c * 9 + x, lb + (c < pos ? c : c - 1));
+        }
+        return;
+    }
+    const int fly = (pl.st & 0x80u) ? (int)(pl.st & 0x7Fu) : -1;
+    const uint64_t codes = step_row(p);
+    const bool ae = formula_labels && (p == ADVISOR || p == ELEPHANT);
+    const uint64_t ae_labs = ae ? ae_label_row(p == ELEPHANT, s) : 0ull;
+    for (int half = 0; half < 2; ++half) {
+        if ((half ? pl.n_b : pl.n_a) == 0) continue;
+        const int k = q + 4 * half;
+        const int code = (int)((codes >> (8 * k)) & 0xFFu);
+        const int t = (y + (code >> 3) - 2) * 9 + x + (code & 7) - 2;
+        out.off = half ? off_b : off_a; out.n = 0;
+        if (ae) out.put_labelled(s, t, (uint16_t)((ae_labs >> (16 * k)) & 0xFFFFu));
+        else out.put(s, t);
+        if (fly >= 0) out.put(s, fly);
+    }
+}
+
 // Value (0/1) of input-plane element o = c*90 + i*9 + j for a board (static_env.py:137-156):
 // channel = type-1 for the mover, 7 + type-1 for the opponent; row i of the planes is y = 9 - i.
 XQ_HD int plane_bit(const int8_t* b, int o)

@@ -156,6 +156,33 @@ XQ_D int wave_movegen(const int8_t* b, MoveList& ml, uint16_t* plist)
     if (p1 > 0) plist[n_lo + __popcll(own.hi & below)] = (uint16_t)((lane + 64) | (p1 << 8));
     wave_sync();
     int total = 0;
+#ifdef CZ_MOVEGEN_QUAD
+    // (prepared, not the default: validated on the CPU only -- tests/test_lane_cpu.py -- it needs its GPU parity run)
+    // a quad of lanes per piece, 16 pieces per pass: see quad_plan / quad_emit in xq_lane.h
+    for (int base = 0; base < np; base += 16) {
+        const int r = lane >> 2, q = lane & 3;
+        const bool act = base + r < np;
+        const int e = act ? plist[base + r] : 0;
+        const int s = e & 0xFF, p = e >> 8;
+        const QuadPlan pl = act ? quad_plan(p, s, q, occ, own, oking) : QuadPlan{0, 0, 0u};
+        // the quad's segment sizes on every lane of the quad
+        const int mine = pl.n_a | (pl.n_b << 8);
+        int off_a = 0, off_b = 0, sum_a = 0, sum_b = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = __shfl(mine, (lane & ~3) | k, 64);
+            if (k < q) { off_a += v & 0xFF; off_b += v >> 8; }
+            sum_a += v & 0xFF; sum_b += v >> 8;
+        }
+        const int n = sum_a + sum_b;
+        const int inc = wave_incl_scan(q == 0 ? n : 0, lane);     // at lane 4 r + q: the pieces up to and including r
+        const int poff = total + inc - n;
+        if (mine) quad_emit(p, s, q, pl, ml.lab, ml.ft, poff + off_a, poff + sum_a + off_b, FORMULA);
+        total += __builtin_amdgcn_readlane(inc, 63);
+    }
+    wave_sync();
+    return total;
+#endif
     for (int base = 0; base < np; base += 64) {   // one pass for every legal position (<= 16 pieces)
         const bool act = base + lane < np;
         const int e = act ? plist[base + lane] : 0;

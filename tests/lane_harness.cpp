@@ -52,6 +52,34 @@ int lane_movegen_plan(const int8_t* board, uint16_t* lab, uint16_t* ft, int form
     return off;
 }
 
+// the quad-of-lanes generator (quad_plan / quad_emit): the cross-lane sums of wave_movegen emulated with loops
+int lane_movegen_quad(const int8_t* board, uint16_t* lab, uint16_t* ft, int formula)
+{
+    Set90 occ{0, 0}, own{0, 0}, oking{0, 0};
+    auto set = [](Set90& m, int s) { if (s < 64) m.lo |= 1ull << s; else m.hi |= 1ull << (s - 64); };
+    for (int s = 0; s < NSQ; ++s) {
+        if (board[s] != 0) set(occ, s);
+        if (board[s] > 0) set(own, s);
+        if (board[s] == -KING) set(oking, s);
+    }
+    int total = 0;
+    for (int s = 0; s < NSQ; ++s) {
+        if (board[s] <= 0) continue;
+        QuadPlan pl[4];
+        int sum_a = 0, sum_b = 0;
+        for (int q = 0; q < 4; ++q) { pl[q] = quad_plan(board[s], s, q, occ, own, oking); sum_a += pl[q].n_a; sum_b += pl[q].n_b; }
+        if (sum_a + sum_b != gen_piece<false>(board[s], s, occ, own, oking, nullptr, nullptr, 0)) return -1;
+        int off_a = 0, off_b = 0;
+        for (int q = 0; q < 4; ++q) {
+            if (pl[q].n_a | pl[q].n_b)
+                quad_emit(board[s], s, q, pl[q], lab, ft, total + off_a, total + sum_a + off_b, formula != 0, 512);
+            off_a += pl[q].n_a; off_b += pl[q].n_b;
+        }
+        total += sum_a + sum_b;
+    }
+    return total;
+}
+
 // file_bits (multiply-gather) against the definition, on pseudo-random 90-bit sets
 int lane_file_bits_mismatches(uint64_t seed, int n)
 {

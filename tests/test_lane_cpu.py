@@ -62,10 +62,11 @@ def test_plan_emit_movegen_matches_the_oracle(harness, positions_1k):
             b, _ = xo.step_board(b, int(mv[rng.integers(len(mv))]))
     for b in boards:
         exp = xo.legal_moves_board(b)
-        for formula in (0, 1):
-            n = harness.lane_movegen_plan(b.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p),
-                                          ft.ctypes.data_as(C.c_void_p), formula)
-            assert n == len(exp) and (lab[:n] == exp).all(), (formula, xo.board_to_state(b))
+        for gen in (harness.lane_movegen_plan, harness.lane_movegen_quad):      # (the quad form: prepared for CZ_MOVEGEN_QUAD)
+            for formula in (0, 1):
+                n = gen(b.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p),
+                        ft.ctypes.data_as(C.c_void_p), formula)
+                assert n == len(exp) and (lab[:n] == exp).all(), (formula, xo.board_to_state(b))
         n = harness.lane_movegen(b.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p), ft.ctypes.data_as(C.c_void_p))
         ft_ref = ft[:n].copy()
         harness.lane_movegen_plan(b.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p), ft.ctypes.data_as(C.c_void_p), 1)
@@ -91,12 +92,13 @@ def test_file_bits_and_plan_on_arbitrary_boards(harness):
         n = harness.lane_movegen(vp(b), vp(lab), vp(ft))
         if n > 128:
             continue
-        for formula in (0, 1):
-            n2 = harness.lane_movegen_plan(vp(b), vp(lab2), vp(ft2), formula)
-            assert n2 == n, (formula, b.tolist())
-            assert (ft2[:n] == ft[:n]).all(), (formula, b.tolist())
-            if formula == 0:
-                assert (lab2[:n] == lab[:n]).all(), b.tolist()
+        for gen in (harness.lane_movegen_plan, harness.lane_movegen_quad):
+            for formula in (0, 1):
+                n2 = gen(vp(b), vp(lab2), vp(ft2), formula)
+                assert n2 == n, (formula, b.tolist())
+                assert (ft2[:n] == ft[:n]).all(), (formula, b.tolist())
+                if formula == 0:
+                    assert (lab2[:n] == lab[:n]).all(), b.tolist()
 
 
 def test_thread_per_board_rules(harness, positions_1k):
