@@ -168,9 +168,16 @@ XQ_D int wave_movegen(const int8_t* b, MoveList& ml, uint16_t* plist)
         // the quad's segment sizes on every lane of the quad
         const int mine = pl.n_a | (pl.n_b << 8);
         int off_a = 0, off_b = 0, sum_a = 0, sum_b = 0;
+#if CZ_MOVEGEN_QUAD >= 2          // quad broadcasts by DPP quad_perm (one VALU move each, no LDS permute)
+        const int v4[4] = {__builtin_amdgcn_mov_dpp(mine, 0x00, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(mine, 0x55, 0xF, 0xF, true),
+                           __builtin_amdgcn_mov_dpp(mine, 0xAA, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(mine, 0xFF, 0xF, 0xF, true)};
+#else
+        const int v4[4] = {__shfl(mine, (lane & ~3) | 0, 64), __shfl(mine, (lane & ~3) | 1, 64),
+                           __shfl(mine, (lane & ~3) | 2, 64), __shfl(mine, (lane & ~3) | 3, 64)};
+#endif
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int v = __shfl(mine, (lane & ~3) | k, 64);
+            const int v = v4[k];
             if (k < q) { off_a += v & 0xFF; off_b += v >> 8; }
             sum_a += v & 0xFF; sum_b += v >> 8;
         }
