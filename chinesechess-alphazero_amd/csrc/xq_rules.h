@@ -46,6 +46,19 @@ XQ_D void wave_sync_global() { __syncthreads(); }
 
 XQ_D int wave_incl_scan(int v, int lane)
 {
+#ifdef CZ_DPP_SCAN
+    // (prepared, not the default: needs its GPU parity run)  Kogge-Stone inside each row of 16 lanes with DPP row shifts
+    // (a lane without a source adds 0), then the row totals carried across with row_bcast:15 (rows 1, 3) and row_bcast:31
+    // (rows 2, 3): six VALU adds, no LDS permute.
+    (void)lane;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);    // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);    // row_bcast:31 -> rows 2 and 3
+    return v;
+#endif
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const int t = __shfl_up(v, d, 64);
