@@ -50,6 +50,12 @@ def parse():
     ap.add_argument("--sustained-rounds", type=int, default=None,
                     help="rounds of the sustained leg that follows the timed steps (default 3000 at N=1 for the "
                          "'normal' config, 0 otherwise)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs of the other single-GPU BASELINE configurations (other_configs)")
+    ap.add_argument("--other-config-seconds", type=float, default=6.0, help="timed seconds per other_configs leg")
+    ap.add_argument("--no-dist", action="store_true",
+                    help="N = 1 only: do not initialise torch.distributed (by default a single rank also brings RCCL "
+                         "up and runs the counter all-reduce, so that the collective path executes on one GPU)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: only the launch / barrier / counter all-reduce plumbing of the ranks (gloo), with "
                          "synthetic counters; used by the CPU test of --gpus N")
@@ -75,6 +81,48 @@ def spawn_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+def init_collective(world, rank, args):
+    """torch.distributed over RCCL (backend "nccl"), also for ONE rank: the games never exchange data, the only
+    collective of the path is the all-reduce of the counter vector (reference worker/self_play.py:55-60), and
+    with a single rank it still goes through RCCL's communicator set-up and a real all-reduce launch -- so the code the
+    driver's 8-GPU run depends on executes on every 1-GPU run too.  Returns a record for the JSON line.  At world = 1 a
+    failing RCCL is reported, not fatal (the games do not need it)."""
+    if world == 1 and args.no_dist:
+        return {"backend": None, "world": 1, "note": "--no-dist"}
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "MASTER_PORT" not in os.environ:                  # no launcher: a single rank on a free loopback port
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    t0 = time.perf_counter()
+    try:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        probe = torch.ones(8, dtype=torch.int64, device="cuda")
+        dist.all_reduce(probe, op=dist.ReduceOp.SUM)          # creates the communicator
+        torch.cuda.synchronize()
+        ok = bool((probe == world).all())
+        init_s = time.perf_counter() - t0
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(probe, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t1) / 20 * 1e6
+        return {"backend": dist.get_backend(), "world": dist.get_world_size(), "init_seconds": init_s,
+                "all_reduce_int64x8_us": us, "probe_ok": ok,
+                "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ or "LOCAL_RANK" in os.environ
+                else "bench.py itself (single rank)"}
+    except Exception as e:                                    # noqa: BLE001
+        if world > 1:
+            raise
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return {"backend": None, "world": 1, "error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def dry_run(args, world, rank):
@@ -266,7 +314,50 @@ def pmc_nn(kernel):
             "source": os.path.relpath(files[-1], ROOT)}
 
 
-def run_arena(args, cfg):
+def fp16_tolerance(blocks, filters):
+    """Bound for plain fp16 operands (BASELINE configs[4] asks for fp16 MFMA evaluation), derived:
+    every convolution output is a sum of 9 F products of operands rounded to fp16 (relative error <= 2^-11 each, so
+    <= 2^-10 per product), errors of random sign: relative RMS error of a layer's output ~ 2^-10 / sqrt(3) ~ 6e-4, plus
+    2^-11 / sqrt(3) for storing the activation in fp16; the 2 B + 1 layers of the tower add in quadrature (the skip
+    connections carry them forward unamplified): e_trunk ~ 7e-4 sqrt(2 B + 1) (B = 20: 4.5e-3).  The heads are
+    1-Lipschitz in that relative error times the pre-activation size (|z| <~ 2 for the value, tanh contracts; logits of
+    a random-init policy head span <~ 2): value_abs and policy_logit_abs = 4 x e_trunk (margin for the worst of the
+    checked positions against the RMS), policy_abs = p (1 - p) x logit error <= 1e-4 for p ~ 5e-4."""
+    e = 7e-4 * (2 * blocks + 1) ** 0.5
+    return {"policy_abs": 1e-4, "value_abs": 4 * e, "policy_logit_abs": 4 * e,
+            "derivation": "fp16 operand rounding 2^-11, random-sign accumulation, quadrature over 2B+1 layers, x4 margin "
+                          "(bench.py::fp16_tolerance)"}
+
+
+def numerics_check(eng, ref_net, cfg, nq=64):
+    """The network the engine ran vs the plain fp32 PyTorch module (CPU) on positions of the last round's queue."""
+    nq = min(nq, eng.search.planes.shape[0])
+    qp = eng.search.planes[:nq].clone()
+    with torch.no_grad():
+        pg, vg = eng.net(qp)
+        pc_, vc_ = ref_net.eval()(qp.float().cpu())
+        lg_g, lg_c = torch.log(pg.float().cpu().clamp_min(1e-30)), torch.log(pc_.clamp_min(1e-30))
+    lg_g, lg_c = lg_g - lg_g.mean(1, keepdim=True), lg_c - lg_c.mean(1, keepdim=True)   # logits up to a shift
+    if cfg.engine.net_dtype == "float32":
+        tol = {"policy_abs": 1e-4, "value_abs": 1e-4, "policy_logit_abs": 1e-3}
+    elif cfg.engine.net_dtype == "float16":
+        tol = fp16_tolerance(cfg.model.res_layer_num, cfg.model.cnn_filter_num)
+    else:                                                    # bf16 operands: 2^-8 per operand, 8 x the fp16 bound
+        tol = {k: (8 * v if isinstance(v, float) else v)
+               for k, v in fp16_tolerance(cfg.model.res_layer_num, cfg.model.cnn_filter_num).items()}
+    out = {"positions": nq, "against": "plain PyTorch fp32 module on the CPU, same weights",
+           "policy_max_abs_diff": float((pg.float().cpu() - pc_).abs().max()),
+           "policy_max_rel_diff": float(((pg.float().cpu() - pc_).abs() / pc_.clamp_min(1e-12)).max()),
+           "policy_logit_max_abs_diff": float((lg_g - lg_c).abs().max()),
+           "value_max_abs_diff": float((vg.float().cpu() - vc_).abs().max()),
+           "tolerance": tol}
+    out["within_tolerance"] = bool(out["policy_max_abs_diff"] <= tol["policy_abs"] and
+                                   out["value_max_abs_diff"] <= tol["value_abs"] and
+                                   out["policy_logit_max_abs_diff"] <= tol["policy_logit_abs"])
+    return out
+
+
+def run_arena(args, cfg, max_plies=None):
     """BASELINE configs[3]: the evaluator arena on the arena worker (worker/evaluator.py::EvaluateWorker.play_games):
     BestModel vs NextGenerationModel (two random-init networks, seeds 0 / 1), 200 paired games played concurrently,
     two trees per game, 400 simulations per move.  A "step" here is one PLY of the whole arena (every live game makes
@@ -295,7 +386,7 @@ def run_arena(args, cfg):
 
     t0 = time.perf_counter()
     stats = {}
-    results = w.play_games(G, on_ply=on_ply, stats=stats, sims_per_round=K)
+    results = w.play_games(G, on_ply=on_ply, stats=stats, sims_per_round=K, stop_after_plies=max_plies)
     torch.cuda.synchronize()
     total = time.perf_counter() - t0
     a, b = marks[args.warmup], marks.get(args.warmup + args.steps)
@@ -326,8 +417,132 @@ def run_arena(args, cfg):
                      "overflow_sims": stats["overflow_sims"], "tree_memory": stats["tree_memory"],
                      "score_table": {"next_generation_score": table[0], "games": G,
                                      "red_new_win_draw_fail": list(table[1:4]), "black_new_win_draw_fail": list(table[4:7])},
-                     "mean_plies_per_game": sum(t for _, t in results) / len(results)}}
-    print(json.dumps(out), flush=True)
+                     "mean_plies_per_game": sum(t for _, t in results) / len(results),
+                     "stopped_after_plies": max_plies}}
+    return out
+
+
+def short_selfplay_leg(label, config, seconds, log, games=None, K=None, dtype=None, trunk=None, model=None, play=None,
+                       workload=None):
+    """One short self-play leg of another configuration (a few seconds of lock-step rounds from the opening, timed with
+    synchronize on both sides; HIP events around the residual-block launches of every round)."""
+    import gc
+    from cchess_alphazero.agent.model import CChessNet, flops_per_position
+    from cchess_alphazero.engine import SelfPlayEngine
+    ns = argparse.Namespace(config=config, games=games, sims_per_round=K, dtype=dtype, trunk=trunk)
+    cfg = build_config(ns)
+    for k, v in (model or {}).items():
+        setattr(cfg.model, k, v)
+    for k, v in (play or {}).items():
+        setattr(cfg.play, k, v)
+    t_leg = time.perf_counter()
+    torch.manual_seed(0)
+    ref_net = CChessNet.from_model_config(cfg.model)
+    G = cfg.engine.games_per_gpu
+    eng = SelfPlayEngine(cfg, G, net=ref_net, dtype=getattr(torch, cfg.engine.net_dtype), seed=20260923)
+    try:
+        eng.start(0, 0)
+        eng.prewarm()
+        for _ in range(3):
+            eng.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.step()
+        torch.cuda.synchronize()
+        est = max(1e-4, time.perf_counter() - t0)
+        steps = int(min(400, max(4, seconds / est)))
+        keys = ["sims", "expansions", "tree_resets", "overflow_sims", "depth_overflow", "plies"]
+        c0 = eng.counters()
+        eng.net.block_events = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        c1 = eng.counters()
+        d = {k: c1[k] - c0[k] for k in keys}
+        blk = [x.elapsed_time(y) for x, y in eng.net.block_events]
+        eng.net.block_events = None
+        Kq = eng.search.K
+        slots = G * Kq
+        f, nb = cfg.model.cnn_filter_num, cfg.model.res_layer_num
+        split = eng.trunk == "mfma" and cfg.engine.net_dtype == "float32"
+        rec = {"workload": workload or f"{G} games/GPU, {cfg.play.simulation_num_per_move} sims/move, K={Kq}, {nb}x{f} net "
+                                       f"({cfg.engine.net_dtype}, trunk={eng.trunk}), random-init weights, from INIT_STATE",
+               "dtype": ("bf16x3-split/f32acc" if split else {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[
+                   cfg.engine.net_dtype]) + "+f64/i32 tree",
+               "value": d["expansions"] / dt, "unit": "expansions/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+               "sims_per_s": d["sims"] / dt, "queue_slots": slots, "compact_queue": bool(eng.compact),
+               "queue_utilisation": d["expansions"] / max(1, steps * slots),
+               "tree_resets": d["tree_resets"], "overflow_sims": d["overflow_sims"], "depth_overflow": d["depth_overflow"],
+               "tree_gib": eng.search.device_bytes() / 2 ** 30}
+        fl = flops_per_position(eng.model_cfg)
+        if blk:
+            b_ms = sum(blk) / len(blk)
+            flops_launch = 2 * 2.0 * 90 * f * f * 9 * slots
+            tfl = flops_launch / (b_ms * 1e-3) / 1e12
+            rec["roofline"] = {"kernel": "residual block (k_resblock family, one launch per block)", "bound": "mfma",
+                               "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s", "frac": tfl / 2500.0,
+                               "avg_launch_ms": b_ms, "launches_timed": len(blk),
+                               "mfmas_per_product": 3 if split else 1, "share_of_step": b_ms * len(blk) / steps / (dt / steps * 1e3)}
+        else:
+            peak = 157.3 if cfg.engine.net_dtype == "float32" and not split else 2500.0
+            tf = fl * slots / (dt / steps) / 1e12
+            rec["roofline"] = {"kernel": "whole step (tree kernels + network forward; per-convolution launches or library "
+                                         "convolutions: no single dominant kernel was timed)", "bound": "mfma",
+                               "achieved": tf * (3 if split else 1), "peak": peak, "unit": "TFLOP/s",
+                               "frac": tf * (3 if split else 1) / peak, "algorithmic_tflops": tf}
+        rec["numerics_check"] = numerics_check(eng, ref_net, cfg)
+    finally:
+        eng.close()
+        del eng
+        gc.collect()
+        torch.cuda.empty_cache()
+    rec["leg_seconds"] = time.perf_counter() - t_leg
+    log(f"other_configs[{label}]: {rec['value']:.0f} exp/s, {rec['ms_per_step']:.2f} ms/step, {rec['leg_seconds']:.1f}s")
+    return rec
+
+
+def other_configs(args, log):
+    """Short legs of the other single-GPU BASELINE configurations, inside the same invocation:
+    deep = configs[4], eval = configs[3] (the arena worker), K40 = the reference's own search_threads of the normal
+    config (configs/normal.py:36-37), strict fp32 = the normal config on MIOpen fp32 convolutions (no split operands),
+    distribute = the reference's deployed 10 x 192 topology with its play parameters (configs/distribute.py:33-51,84-87)."""
+    out = {}
+    sec = args.other_config_seconds
+
+    def guarded(label, fn):
+        try:
+            out[label] = fn()
+        except Exception as e:                                # noqa: BLE001  (one failing leg must not void the line)
+            out[label] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            log(f"other_configs[{label}] FAILED: {out[label]['error']}")
+        torch.cuda.empty_cache()
+
+    guarded("deep_20x256_fp16_1600sims", lambda: short_selfplay_leg(
+        "deep", "deep", sec, log,
+        workload="BASELINE configs[4] 'deep': 4096 games, 1600 sims/move, K=8, 20x256 net, fp16 MFMA operands / fp32 "
+                 "accumulate, random-init weights, from INIT_STATE"))
+
+    def arena():
+        ns = argparse.Namespace(config="eval", games=None, sims_per_round=None, dtype=None, trunk=None, warmup=2, steps=16)
+        r = run_arena(ns, build_config(ns), max_plies=ns.warmup + ns.steps + 1)
+        keep = ("value", "unit", "steps", "ms_per_step", "dtype", "sims_per_s", "ms_per_round", "rounds_timed",
+                "compact_queue", "rows_evaluated_per_round_whole_arena", "network_tflops")
+        rec = {k: r[k] for k in keep}
+        rec["workload"] = r["config"]["workload"] + f"; timed plies {ns.warmup}..{ns.warmup + ns.steps} of the arena"
+        rec["tree_resets"] = r["arena"]["tree_resets"]
+        rec["overflow_sims"] = r["arena"]["overflow_sims"]
+        log(f"other_configs[eval]: {rec['value']:.0f} exp/s")
+        return rec
+    guarded("eval_arena_400sims_200games", arena)
+    guarded("normal_K40", lambda: short_selfplay_leg("K40", "normal", sec, log, K=40))
+    guarded("normal_strict_fp32_library_trunk", lambda: short_selfplay_leg("library", "normal", sec, log, trunk="library"))
+    guarded("distribute_10x192_K10_cpuct5", lambda: short_selfplay_leg(
+        "distribute", "normal", sec, log, K=10, model=dict(cnn_filter_num=192, res_layer_num=10),
+        play=dict(c_puct=5, noise_eps=0.2, max_game_length=200)))
+    return out
 
 
 def main():
@@ -344,10 +559,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    collective = init_collective(world, rank, args)
+    dist_on = dist.is_initialized()
     from cchess_alphazero.agent.model import flops_per_position
     from cchess_alphazero.engine import SelfPlayEngine, bytes_per_expansion
 
@@ -359,7 +572,8 @@ def main():
     if args.config == "eval":
         if world > 1:
             raise SystemExit("bench.py --config eval runs on one GPU (BASELINE configs[3])")
-        return run_arena(args, cfg)
+        print(json.dumps(run_arena(args, cfg)), flush=True)
+        return
     dtype = getattr(torch, cfg.engine.net_dtype)
     G = cfg.engine.games_per_gpu
     from cchess_alphazero.agent.model import CChessNet
@@ -394,7 +608,7 @@ def main():
         counter deltas summed over ranks + the number of ranks reporting, search-round ms, block ms list)."""
         c0 = eng.counters()
         ev, blk_all = [], []
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -418,7 +632,7 @@ def main():
             if sampled and eng.net is not None:
                 blk_all += eng.net.block_events
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         dt_ = time.perf_counter() - t0
@@ -427,7 +641,7 @@ def main():
         c1 = eng.counters()
         delta = torch.tensor([c1[k] - c0[k] for k in keys] + [1], dtype=torch.int64, device="cuda")
         tmax = torch.tensor([dt_], dtype=torch.float64, device="cuda")
-        if world > 1:
+        if dist_on:
             dist.all_reduce(delta, op=dist.ReduceOp.SUM)          # the only collective of the path
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dd = dict(zip(keys + ["ranks"], delta.tolist()))
@@ -576,21 +790,16 @@ def main():
                                     "launches_timed": len(sblk)}
             out["sustained"] = srec
             out["value_sustained"] = s_exp
-        # the network the engine ran vs the plain fp32 PyTorch module (CPU) on positions of the last round's queue
-        nq = min(64, slots)
-        qp = eng.search.planes[:nq].clone()
-        with torch.no_grad():
-            pg, vg = eng.net(qp)
-            pc_, vc_ = ref_net.eval()(qp.float().cpu())
-            lg_g, lg_c = torch.log(pg.float().cpu().clamp_min(1e-30)), torch.log(pc_.clamp_min(1e-30))
-        lg_g, lg_c = lg_g - lg_g.mean(1, keepdim=True), lg_c - lg_c.mean(1, keepdim=True)   # logits up to a shift
-        out["numerics_check"] = {"positions": nq, "against": "plain PyTorch fp32 module on the CPU, same weights",
-                                 "policy_max_abs_diff": float((pg.float().cpu() - pc_).abs().max()),
-                                 "policy_max_rel_diff": float(((pg.float().cpu() - pc_).abs() / pc_.clamp_min(1e-12)).max()),
-                                 "policy_logit_max_abs_diff": float((lg_g - lg_c).abs().max()),
-                                 "value_max_abs_diff": float((vg.float().cpu() - vc_).abs().max()),
-                                 "tolerance": ({"policy_abs": 1e-4, "value_abs": 1e-4, "policy_logit_abs": 1e-3}
-                                               if cfg.engine.net_dtype == "float32" else None)}
+        out["numerics_check"] = numerics_check(eng, ref_net, cfg)
+        out["collective"] = collective
+    eng.close()                                              # every rank; the legs below need the device memory
+    del eng
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                                 # (the search object sizes its pool from the FREE memory)
+    if rank == 0:
+        if world == 1 and args.config == "normal" and not args.no_other_configs:
+            out["other_configs"] = other_configs(args, log)
         if not args.no_micro and world == 1:
             out["micro_suite"] = micro_suite()
             log("micro-suite done")
@@ -598,8 +807,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_seconds)
             log("cpu baseline done")
         print(json.dumps(out), flush=True)
-    eng.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()                  # rank 0 may still be timing the CPU baseline: leave together
         dist.destroy_process_group()
 

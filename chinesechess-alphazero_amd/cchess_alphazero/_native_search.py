@@ -8,7 +8,7 @@ from cchess_alphazero import _native
 COUNTER_NAMES = ["sims", "expansions", "terminal_sims", "repetition_sims", "parked", "sum_depth", "max_depth",
                  "edges_visited", "leaf_moves", "plies", "games", "red_wins", "black_wins", "draws", "resigns",
                  "tree_resets", "overflow_sims", "depth_overflow", "root_reused_sims", "ring_dropped", "chunks_taken",
-                 "stat_blocks",
+                 "stat_blocks", "no_act_truncated",
                  # only in the CZ_SIM_PROFILE tuning build (the library reports how many counters it has)
                  "cyc_select", "cyc_rules", "cyc_hash", "cyc_expand", "cyc_rep", "cyc_attach", "cyc_resume_load",
                  "cyc_kernel_select", "cyc_kernel_backup"]
@@ -74,10 +74,13 @@ class Search:
 
     def __init__(self, play_config, n_games, planes_dtype=_native.F32, evaluate=False, seed=0,
                  max_nodes_per_game=0, pool_chunks=0, max_depth=0, ring_capacity=0, sims_per_round=None,
-                 device=None, use_history=False):
+                 device=None, use_history=False, pool_fraction=None):
         """max_nodes_per_game: sizes a game's hash / chunk table (0 = the whole tree of the longest game);
         pool_chunks: tree memory shared by all games in MiB (0 = what the games can use, at most 80 % of the free
-        device memory)."""
+        device memory); pool_fraction (or CZ_POOL_FRACTION in the environment): with pool_chunks = 0, that fraction
+        of the currently free device memory instead of 80 % -- for processes that share a GPU (several workers, a
+        co-resident trainer, a UCI engine beside self-play; INTEGRATION.md "Memory")."""
+        import os
         import torch
         _native.require_gpu()
         self.L = _native.lib()
@@ -88,6 +91,14 @@ class Search:
         self.G = int(n_games)
         self.K = int(sims_per_round if sims_per_round is not None else pc.search_threads)
         self.planes_dtype = planes_dtype
+        if not pool_chunks:
+            frac = pool_fraction if pool_fraction is not None else os.environ.get("CZ_POOL_FRACTION")
+            if frac:
+                frac = float(frac)
+                if not 0.0 < frac <= 0.95:
+                    raise ValueError(f"pool_fraction {frac}: expected 0 < f <= 0.95")
+                free_b, _ = torch.cuda.mem_get_info(self.device)
+                pool_chunks = max(1, int(free_b * frac) >> 20)      # (the library raises it to the games' floor if needed)
         cfg = SearchCfg(self.G, self.K, int(pc.simulation_num_per_move), int(pc.virtual_loss), int(max_nodes_per_game),
                         int(pool_chunks), int(max_depth), int(pc.max_game_length), int(planes_dtype),
                         int(pc.min_resign_turn), int(bool(evaluate)), int(ring_capacity),

@@ -118,8 +118,10 @@ class CChessPlayer:
         """debugging=True: the network's (policy, value) of the root, what the reference keeps in self.debug[state]
         (player.py:332-336) and its UCI front-end prints as the score (uci.py:291-292)."""
         t = self._torch
-        if self.use_history and hist:
-            planes = senv.state_history_to_planes(state, hist)
+        if self.use_history:
+            # a history model always gets 28 planes (expand_and_evaluate, player.py:326-333: state_history_to_planes
+            # whether or not the history is long enough; planes 14-27 stay zero without a position two plies back)
+            planes = senv.state_history_to_planes(state, hist or [])
         else:
             planes = senv.state_to_planes(state)
         p, v = self._evaluate(t.from_numpy(np.asarray(planes, dtype=np.float32)[None]).cuda())
@@ -140,15 +142,18 @@ class CChessPlayer:
         pv = ""
         t = turns
         end_state = state
+        line = [state]                                       # the search path of the line: [s0, m1, s1, m2, s2, ...]
         for mov in self.principal_variation(state, no_act):
             pv += " " + senv.to_uci_move(flip_move(mov) if t % 2 == 1 else mov)
             end_state = senv.step(end_state, mov)
+            line += [mov, end_state]
             t += 1
         # the reference prints the network value of the position at the END of the line (self.debug holds every
         # evaluated state when debugging, :442-445), seen from `side`; a line that ends on a position the network
         # never saw (terminal, or debugging off) keeps the root's value as it was passed in, un-negated
         if self.debugging and t != turns and not senv.done(end_state)[0]:
-            value = self._root_value(end_state, None)[1]
+            # (a history model saw this position with the planes of the position two plies up the path, :331-333)
+            value = self._root_value(end_state, line)[1]
             if t % 2 != self.side:
                 value = -value
         duration = max(time() - start_time, 1e-9)
@@ -192,7 +197,8 @@ class CChessPlayer:
                         enable_resign=t.tensor([1 if self.enable_resign else 0], dtype=t.uint8, device="cuda"))
             if self.debugging:
                 self.debug[state] = self._root_value(state, hist)
-            before = s.counters()["sims"]
+            c_before = s.counters()
+            before = c_before["sims"]
             start_time, shown, stopped = time(), 0, False
             while True:
                 s.round()
@@ -211,7 +217,13 @@ class CChessPlayer:
                     if self.done_tasks // 100 != shown:
                         shown = self.done_tasks // 100
                         self.print_depth_info(state, turns, start_time, self.debug.get(state, (None, 0.0))[1], no_act)
-            self.done_tasks = s.counters()["sims"] - before
+            c_after = s.counters()
+            self.done_tasks = c_after["sims"] - before
+            lost = c_after["overflow_sims"] - c_before["overflow_sims"]
+            if lost:                                           # the tree memory of this player ran out: say so
+                logger.warning(f"search of {state}: {lost} simulations found no tree memory and backed up 0 "
+                               f"(tree_resets {c_after['tree_resets'] - c_before['tree_resets']}); "
+                               f"raise engine.max_nodes_per_game / pool_chunks")
             if self.uci and not stopped and self.done_tasks // 100 != shown:      # the last batch reports too
                 self.print_depth_info(state, turns, start_time, self.debug.get(state, (None, 0.0))[1], no_act)
             st = s.root_stats()

@@ -70,6 +70,8 @@ class EngineConfig(_Section):
                          net_trunk="mfma",        # mfma (hand-written convolution kernel) | library (MIOpen)
                          max_nodes_per_game=0,    # sizes a game's hash / chunk table; 0 = the longest game's whole tree
                          pool_chunks=0,           # tree memory for all games in MiB; 0 = auto (<= 80 % of free HBM)
+                         pool_fraction=None,      # with pool_chunks = 0: that fraction of the free HBM instead of 80 %
+                                                  # (several processes on one GPU: max_processes > 1, a trainer, UCI)
                          max_depth=0,
                          reload_seconds=600,      # self-play re-checks the best-model digest this often (api.py:37-44)
                          compact_queue=True,      # evaluate only the queue slots that hold a new leaf (cz_search_round_q)

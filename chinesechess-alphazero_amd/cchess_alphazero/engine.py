@@ -65,7 +65,8 @@ class SelfPlayEngine:
         self.search = Search(config.play, n_games, planes_dtype=planes_code,
                              evaluate=getattr(config.opts, "evaluate", False), seed=seed,
                              max_nodes_per_game=max_nodes_per_game, pool_chunks=pool_chunks, max_depth=max_depth,
-                             sims_per_round=sims_per_round, device=self.device, use_history=use_history)
+                             sims_per_round=sims_per_round, device=self.device, use_history=use_history,
+                             pool_fraction=getattr(getattr(config, "engine", None), "pool_fraction", None))
         if evaluator is None:
             self.net = InferenceNet(net, dtype, trunk=self.trunk).to(self.device)
         # compact evaluation queue: the network runs only on the slots that hold a new leaf (2-7 % of the slots of a

@@ -110,7 +110,7 @@ class EvaluateWorker:
 
     # ------------------------------------------------------------------------------------------------
     def play_games(self, n_games, u_fn=None, indices=None, init_state=None, trace=None, stats=None, on_ply=None,
-                   sims_per_round=None):
+                   sims_per_round=None, stop_after_plies=None):
         """Plays the games idx = 0..n_games-1 (or the given `indices`) concurrently; returns
         [(value from red's view, turns)] in that order.
 
@@ -122,7 +122,8 @@ class EvaluateWorker:
         u_fn(idx, ply) -> uniform draw of np.random.choice (default: NumPy's global RNG, like the reference);
         init_state: start position (default INIT_STATE); trace: dict filled with idx -> [one dict per searched ply];
         stats: dict that receives the search counters (rounds, expansions, ...); on_ply(ply, counters_fn): called at
-        the start of every ply (bench.py times plies with it); sims_per_round: K (default config.play.search_threads)."""
+        the start of every ply (bench.py times plies with it); sims_per_round: K (default config.play.search_threads);
+        stop_after_plies: stop after that many plies (benchmark legs only: the games still running are reported as they stand)."""
         import torch
         _native.require_gpu()
         pc = self.config.play
@@ -157,7 +158,7 @@ class EvaluateWorker:
             from cchess_alphazero.environment.static_env import array_to_state
             for i in idx:
                 trace[int(i)] = []
-        while live.any():
+        while live.any() and (stop_after_plies is None or turns < stop_after_plies):
             if on_ply is not None:
                 on_ply(turns, counters_now, rounds)
             hist[turns] = boards

@@ -46,8 +46,9 @@ def reduce_counters(counters, group=None):
     Returns the global dict.  One int64[len(COUNTER_KEYS)] message: latency-bound, SURVEY 8(e)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return {k: int(counters.get(k, 0)) for k in COUNTER_KEYS}
+    # (a single rank under a launcher still all-reduces: the same RCCL path the multi-GPU run takes)
     dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
     t = torch.tensor([int(counters.get(k, 0)) for k in COUNTER_KEYS], dtype=torch.int64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
@@ -135,7 +136,8 @@ class SelfPlayWorker:
                     lc = self.engine.counters()
                     logger.info(f"rounds={r} games={c['games']} plies={c['plies']} "
                                 f"expansions/s={c['expansions'] / dt:.0f} games/h={c['games'] / dt * 3600:.0f} "
-                                f"tree_resets={lc['tree_resets']} overflow_sims={lc['overflow_sims']}")
+                                f"tree_resets={lc['tree_resets']} overflow_sims={lc['overflow_sims']} "
+                                f"no_act_truncated={lc.get('no_act_truncated', 0)}")
                 if max_games is not None and c["games"] >= max_games:
                     break
             if max_rounds is not None and r >= max_rounds:
@@ -153,14 +155,23 @@ class SelfPlayWorker:
             self.engine = None
 
 
+def free_port():
+    """A free TCP port on the loopback interface for the rendezvous of the ranks spawned here."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _rank_main(rank, world, config, port):
     import torch
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     devices = [int(x) for x in str(config.opts.device_list).split(",")]
     torch.cuda.set_device(devices[rank] if rank < len(devices) else rank)
-    if world > 1:
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    if world > 1 or os.environ.get("CZ_FORCE_DIST") == "1":
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port or free_port()}", rank=rank,
+                                world_size=world)
     model, _ = load_model(config)
     SelfPlayWorker(config, rank=rank, world=world, model=model).start()
 
@@ -168,7 +179,7 @@ def _rank_main(rank, world, config, port):
 def start(config):
     """Entry point of ``run.py self`` (reference :48-60)."""
     import torch
-    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:      # launched by torchrun
+    if "WORLD_SIZE" in os.environ and "RANK" in os.environ:                   # launched by torchrun (any world size)
         import torch.distributed as dist
         rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
@@ -179,6 +190,6 @@ def start(config):
     devices = str(config.opts.device_list).split(",")
     if len(devices) > 1:
         import torch.multiprocessing as mp
-        port = 29500 + (os.getpid() % 2000)
+        port = free_port()
         return mp.spawn(_rank_main, args=(len(devices), config, port), nprocs=len(devices), join=True)
     return _rank_main(0, 1, config, 0)

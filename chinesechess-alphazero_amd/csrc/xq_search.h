@@ -35,7 +35,8 @@ constexpr int CHILD_UNKNOWN = -1;
 constexpr int CHILD_TERM_WIN = -2;     // done() == (True, +1): value for the child's mover +1 -> x2
 constexpr int CHILD_TERM_LOSS = -3;    // done() == (True, -1)
 
-enum SimState : uint8_t { SIM_IDLE = 0, SIM_LEAF = 1, SIM_PARKED = 2 };
+enum SimState : uint8_t { SIM_IDLE = 0, SIM_LEAF = 1, SIM_PARKED = 2,
+                          SIM_DEFERRED = 3 };   // ended on a terminal / repeated position; backed up when the phase's descents are over (never outlives a launch)
 
 enum NodeFlag : uint32_t { NODE_WAITING = 1u << 8 };    // low 8 bits of node_meta = move count
 
@@ -53,6 +54,7 @@ enum Counter : int {
     CT_EDGES_VISITED, CT_LEAF_MOVES, CT_PLIES, CT_GAMES, CT_RED_WINS, CT_BLACK_WINS, CT_DRAWS, CT_RESIGNS,
     CT_TREE_RESETS, CT_OVERFLOW_SIMS, CT_DEPTH_OVERFLOW, CT_ROOT_REUSED_SIMS, CT_RING_DROPPED, CT_CHUNKS_TAKEN,
     CT_STAT_BLOCKS,
+    CT_NO_ACT_TRUNCATED,    // self-play: a perpetual-check ban that did not fit the MAX_NO_ACT list of the ply (dropped, counted)
 #ifdef CZ_SIM_PROFILE       // tuning build (tools/ab_search.sh): shader-clock cycles of wave time per section of a simulation
     CT_CYC_SELECT, CT_CYC_RULES, CT_CYC_HASH, CT_CYC_EXPAND, CT_CYC_REP, CT_CYC_ATTACH, CT_CYC_RESUME_LOAD,
     CT_CYC_KERNEL_SELECT, CT_CYC_KERNEL_BACKUP,

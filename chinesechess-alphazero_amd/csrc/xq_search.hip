@@ -27,6 +27,7 @@
 #include <new>
 #include "xq_rules.h"
 #include "xq_search.h"
+#include "xq_noise.h"
 #include "../../include/czero.h"
 
 using namespace xq;
@@ -168,68 +169,7 @@ XQ_D double philox_uniform(uint64_t seed, uint32_t game_id, uint32_t stream, uin
     return ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6)) / 9007199254740992.0;
 }
 
-// per-lane uniform stream for the root noise: Philox4x32-10 blocks (stream 2), four 24-bit uniforms per block
-struct NoiseRng {
-    uint64_t seed, idx;
-    uint32_t gid, buf[4];
-    int left;
-    XQ_D float next()
-    {
-        if (left == 0) {
-            uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = 2u, c3 = gid;
-            uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-            for (int r = 0; r < 10; ++r) {
-                const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-                const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-                const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-                c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-                k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-            }
-            buf[0] = c0; buf[1] = c1; buf[2] = c2; buf[3] = c3;
-            left = 4;
-            ++idx;
-        }
-        return ((float)(buf[--left] >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
-    }
-};
-
-// Gamma(a, 1) by Marsaglia-Tsang (with the a < 1 boost).  The noise only has to follow the reference's
-// distribution (NumPy's global RNG cannot be matched), so it is sampled in float32 with the hardware
-// log / exp / cos approximations; the tree arithmetic it feeds stays float64.
-XQ_D float gamma_draw(float a, NoiseRng& rng)
-{
-    float boost = 1.0f;
-    if (a <= 0.0f) return 0.0f;
-    if (a < 1.0f) {
-        boost = __expf(__logf(rng.next()) / a);               // U^(1/a)
-        a += 1.0f;
-    }
-    const float d = a - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
-    for (int it = 0; it < 32; ++it) {
-        const float u1 = rng.next(), u2 = rng.next();
-        const float x = sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);   // Box-Muller
-        float v = 1.0f + c * x;
-        if (v <= 0.0f) continue;
-        v = v * v * v;
-        const float u = rng.next();
-        const float x2 = x * x;
-        if (u < 1.0f - 0.0331f * x2 * x2) return boost * d * v;
-        if (__logf(u) < 0.5f * x2 + d * (1.0f - v + __logf(v))) return boost * d * v;
-    }
-    return boost * d;
-}
-
-// np.random.dirichlet(alpha * ones(n))[0] (player.py:304) = X / (X + Y), X ~ Gamma(alpha), Y ~ Gamma(alpha (n - 1)),
-// i.e. Beta(alpha, alpha (n - 1)); tests/test_gpu_noise.py checks the distribution against NumPy's
-XQ_D double dirichlet0(float alpha, int nm, NoiseRng& rng)
-{
-    const double x = (double)gamma_draw(alpha, rng);
-    const double y = nm > 1 ? (double)gamma_draw(alpha * (float)(nm - 1), rng) : 0.0;
-    // the quotient in float64: in float32 every draw with y < 6e-8 x would collapse onto exactly 1.0 (1.8 % of the
-    // mass of Beta(0.2, 0.2), the two-move case) -- found by the KS test of tests/test_gpu_noise.py
-    return (x + y) > 0.0 ? x / (x + y) : 1.0 / (double)nm;
-}
+// (the root noise generator -- NoiseRng, gamma_draw, dirichlet0 -- lives in xq_noise.h: host + device, CPU-tested)
 
 // ---- packed keys and the transposition hash ----------------------------------------------------
 // board (LDS) -> key words in L.key (lanes 0..11), returns the 64-bit hash (wave-uniform)
@@ -529,6 +469,26 @@ XQ_D void sim_finish(const GameView& gv, int sim, int* active)
     *active -= 1;
 }
 
+// ---- deferred terminal / repetition results -----------------------------------------------------------------------
+// MCTS_search does not apply a terminal or repetition value itself: it SUBMITS update_tree to the executor
+// (player.py:206, :228-232), behind the search tasks of the batch that were queued first (:173-174), and a search
+// thread runs its descent to the end before the interpreter switches.  So the descents of a phase (a fresh batch, or
+// the simulations resumed after an evaluation) see each other's virtual losses but not each other's terminal results;
+// those are applied when the descents are over, in index order (oracle: finish / flush_deferred
+// in xq_mcts.c; tests/golden/kgt1_spread.json is the evidence that this is what the reference does).
+// The slot keeps (value, depth) until the flush: written and read back by lane 0 only (its own stores, no fence).
+struct Deferred {
+    uint64_t lo;       // simulations < 64 waiting for their backup, one bit each (wave-uniform)
+    int hi;            // how many with an index >= 64 (found by scanning the slots)
+};
+XQ_D void defer_result(const GameView& gv, int sim, int depth, int value, Deferred& df)
+{
+    if (lane_id() == 0) { gv.s_state[sim] = SIM_DEFERRED; gv.s_node[sim] = value; gv.s_depth[sim] = depth; }
+    if (sim < 64) df.lo |= 1ull << sim;
+    else df.hi += 1;
+    wave_sync();
+}
+
 XQ_D int find_in_path(const SearchLDS& L, int depth, int node)
 {
     const int lane = lane_id();
@@ -656,7 +616,7 @@ XQ_D int edge_move(const GameView& gv, int node, int edge)
 template <bool HIST>
 XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView& gv, SearchLDS& L,
                   const RoundIO& io, const RootCtx& rc0, int root, int sim, int node, int depth, int* active,
-                  Arena& ar, bool fresh)
+                  Arena& ar, bool fresh, Deferred& df)
 {
     const int lane = lane_id();
     const int g = gv.g;
@@ -689,13 +649,12 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
         if (rep >= 0) {
             unpack_key(node_key(gv, node), L.r.bd[0]);
             const int mv = edge_move(gv, L.path_node[rep], L.path_edge[rep]);
-            double v;
-            if (wave_will_check_or_catch(L.r, L.r.bd[0], mv) == 1) v = -1.0;
-            else if (wave_be_catched(L.r.bd[0], label_ft(mv) >> 8, L.r.bd[1], L.r.ml[0], L.r.plist)) v = 1.0;
-            else v = 0.0;
+            int v;
+            if (wave_will_check_or_catch(L.r, L.r.bd[0], mv) == 1) v = -1;
+            else if (wave_be_catched(L.r.bd[0], label_ft(mv) >> 8, L.r.bd[1], L.r.ml[0], L.r.plist)) v = 1;
+            else v = 0;
             count(gv, CT_REPETITION_SIMS);
-            backup(P, gv, L, depth, v);
-            sim_finish(gv, sim, active);
+            defer_result(gv, sim, depth, v, df);                     // update_tree is a queued task (player.py:228-232)
             PROF(CT_CYC_REP);
             return;
         }
@@ -804,8 +763,7 @@ XQ_D void run_sim(const SearchParams& P, const SearchBuffers& B, const GameView&
         }
         if (child == CHILD_TERM_WIN || child == CHILD_TERM_LOSS) {  // player.py:204-208: value doubled
             count(gv, CT_TERMINAL_SIMS);
-            backup(P, gv, L, depth, child == CHILD_TERM_WIN ? 2.0 : -2.0);
-            sim_finish(gv, sim, active);
+            defer_result(gv, sim, depth, child == CHILD_TERM_WIN ? 2 : -2, df);     // queued update_tree (player.py:206)
             return;
         }
         node = child;
@@ -821,6 +779,30 @@ XQ_D void load_path(const SearchParams& P, const GameView& gv, SearchLDS& L, int
     wave_sync();
     for (int i = lane; i < depth; i += 64) { L.path_node[i] = hp_node[i]; L.path_edge[i] = hp_edge[i]; }
     wave_sync();
+}
+
+// apply the deferred terminal / repetition values of the phase that just ended, in index order
+XQ_D void flush_deferred(const SearchParams& P, const GameView& gv, SearchLDS& L, Deferred& df, int* active)
+{
+    if (df.lo == 0 && df.hi == 0) return;
+    wave_sync_global();                  // lane 0's path stores of this launch are complete before the lanes reload paths
+    auto one = [&](int i) {
+        const int depth = uni(gv.s_depth[i]);
+        const double v = (double)uni(gv.s_node[i]);
+        load_path(P, gv, L, i, depth);
+        backup(P, gv, L, depth, v);
+        sim_finish(gv, i, active);
+    };
+    while (df.lo) {
+        const int i = __ffsll((long long)df.lo) - 1;
+        df.lo &= df.lo - 1;
+        one(i);
+    }
+    if (df.hi) {
+        for (int i = 64; i < P.K; ++i)
+            if (uni((int)gv.s_state[i]) == SIM_DEFERRED) one(i);
+        df.hi = 0;
+    }
 }
 
 // ---- the chunk pool ---------------------------------------------------------------------------------------------
@@ -1214,6 +1196,8 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
                         if (n_no_act < MAX_NO_ACT) {
                             if (lane == 0) B.g_no_act[(size_t)g * MAX_NO_ACT + n_no_act] = (uint16_t)mv;
                             n_no_act += 1;
+                        } else {
+                            count(gv, CT_NO_ACT_TRUNCATED);           // (the reference's list is unbounded, self_play.py:161-175)
                         }
                     } else if (!wave_be_catched(L.r.bd[0], label_ft(mv) >> 8, L.r.bd[1], L.r.ml[0], L.r.plist)) {
                         inc = 1;
@@ -1253,7 +1237,7 @@ XQ_D void advance_game(const SearchParams& P, const SearchBuffers& B, const Game
 }
 
 // ---- the round kernels --------------------------------------------------------------------------------------
-// One lock-step round = k_sim(BACKUP) -> k_advance -> k_sim(SELECT)   (+ k_noise before each k_sim when the
+// One lock-step round = k_sim(BACKUP) -> k_advance -> k_sim(SELECT)   (+ k_noise before k_sim(SELECT) when the
 // root noise is on).  Splitting the round keeps the hot simulation kernel free of the cold, register-hungry code
 // (move sampling with pow(), game rules, chunk reservation, Gamma sampling).
 constexpr int SIM_BACKUP = 1, SIM_SELECT = 2;
@@ -1343,6 +1327,7 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
         resume_i = 0;
     }
     int new_i = 0, new_n = 0, batches = 0;
+    Deferred df{0ull, 0};
     for (int guard = 0; guard < (1 << 20); ++guard) {
         int sim, node, depth;
         bool fresh;
@@ -1359,6 +1344,11 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             load_path(P, gv, L, i, depth);
         } else if (new_i < new_n) {                                   // the simulations of a fresh batch
             sim = new_i++; node = uni(B.g_root[g]); depth = 0; fresh = true;
+        } else if (df.lo != 0 || df.hi != 0) {
+            // the descents of this phase (resumed simulations / a fresh batch) are over: the terminal and repetition
+            // values they produced are applied now, in index order
+            flush_deferred(P, gv, L, df, &active);
+            continue;
         } else if ((mask & SIM_SELECT) && active == 0) {              // 3. next lock-step batch (player.py:169-178)
             const int tasks = uni(B.g_tasks_left[g]);
             if (tasks <= 0) break;                                    // search complete: k_advance takes over
@@ -1372,7 +1362,7 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             if (lane_id() == 0) B.g_tasks_left[g] = tasks - new_n;
             continue;
         } else break;
-        run_sim<HIST>(P, B, gv, L, io, rc, uni(B.g_root[g]), sim, node, depth, &active, ar, fresh);
+        run_sim<HIST>(P, B, gv, L, io, rc, uni(B.g_root[g]), sim, node, depth, &active, ar, fresh, df);
     }
     if (lane_id() == 0) { B.g_active[g] = active; B.g_node_count[g] = ar.ncount; B.g_heap_top[g] = ar.top; }
     if ((mask & SIM_SELECT) && q_rows) {
@@ -1423,44 +1413,61 @@ __global__ __launch_bounds__(64) void k_advance(SearchParams P, SearchBuffers B)
     counters_flush(gv);
 }
 
-// Dirichlet(alpha 1_n)[0] for every (simulation slot, root edge) the next k_sim launch can consume: X / (X + Y),
-// X ~ Gamma(alpha), Y ~ Gamma(alpha (n - 1)).  The reference redraws it per move per root visit (player.py:304);
-// a simulation selects at the root at most once per k_sim launch, so one row per slot per launch is enough:
-// before k_sim(BACKUP) only slots parked on the root need one, before k_sim(SELECT) the slots of the next batch.
+// Dirichlet(alpha 1_n)[0] for every (simulation slot, root edge) of the batch that the next k_sim(SELECT) launch starts:
+// X / (X + Y), X ~ Gamma(alpha), Y ~ Gamma(alpha (n - 1)) (xq_noise.h).  The reference redraws it per move per root visit
+// (player.py:304); a simulation selects at the root at most once, so one row per slot per batch is enough.
+// ONE launch per round, before k_sim(SELECT), and only games that start a batch there draw anything.  The rare game
+// whose root is not in the tree yet (first search of a game, a search after a reset) needs rows too: its simulation 0
+// expands the root, the others park on it and select at the root when the NEXT round's k_sim(BACKUP) resumes them --
+// with the rows drawn here, for the move count this kernel works out itself from the root position (round 2 ran a
+// second k_noise launch before every k_sim(BACKUP) for that case: 19 us per round for 4096 waves that found nothing).
 // (Drawing the rows inside k_sim, by the game's own wave when a batch starts, was measured and is SLOWER: the 6 x 64
-// draws of a batch are ~6000 dependent instructions for one wave, +125 us on k_sim(SELECT) against the 70 us of the two
-// launches -- here the work spreads over 4 waves per game and 8 resident waves per SIMD.)
-__global__ __launch_bounds__(256) void k_noise(SearchParams P, SearchBuffers B, int mask)
+// draws of a batch are dependent instruction chains for one wave; here they spread over 4 waves per game.)
+__global__ __launch_bounds__(256) void k_noise(SearchParams P, SearchBuffers B)
 {
+    __shared__ int s_nm;
     const int g = blockIdx.x;
     if (g >= P.G || B.g_phase[g] != PH_SEARCH) return;
+    // a new batch starts only when nothing is in flight (k_sim(BACKUP) may just have finished the old one)
+    if (B.g_active[g] != 0) return;
+    const int tasks = B.g_tasks_left[g];
+    const int last = tasks < P.K ? tasks : P.K;                 // slots [0, last)
+    if (last <= 0) return;
     const int root = B.g_root[g];
-    if (root < 0) return;
     const int tid = threadIdx.x;
-    const int active = B.g_active[g];
-    int last = 0;                                              // slots [0, last)
-    if (mask == SIM_SELECT) {
-        // a new batch starts only when nothing is in flight (k_sim(BACKUP) may have finished the old one)
-        if (active != 0) return;
-        const int tasks = B.g_tasks_left[g];
-        last = tasks < P.K ? tasks : P.K;
+    int nm;
+    if (root >= 0) {
+        const char* rbase = B.pool + ((size_t)B.g_chunk_tab[(size_t)g * P.max_chunks + ((uint32_t)root >> CHUNK_SHIFT)] << 20)
+                            + ((size_t)((uint32_t)root & (uint32_t)(CHUNK_GRANULES - 1)) << 4);
+        nm = (int)(*reinterpret_cast<const uint32_t*>(rbase + NODE_OFF_HDR + 4) & 0xFF);
     } else {
-        if (active == 0) return;
-        last = P.K;
+        // the root position is in g_board: count its moves like wave_movegen does (three ballot sets, plan_piece per
+        // piece), without the lists.  Wave 0 only; the other waves wait at the barrier.
+        if (tid < 64) {
+            const int8_t* gb = B.g_board + (size_t)g * BOARD_LDS;
+            const int p0 = gb[tid];
+            const int p1 = tid < 26 ? gb[tid + 64] : 0;
+            const Set90 occ{__ballot(p0 != 0), __ballot(p1 != 0)};
+            const Set90 own{__ballot(p0 > 0), __ballot(p1 > 0)};
+            const Set90 oking{__ballot(p0 == -KING), __ballot(p1 == -KING)};
+            int c = 0;
+            if (p0 > 0) c += plan_piece(p0, tid, occ, own, oking).n;
+            if (p1 > 0) c += plan_piece(p1, tid + 64, occ, own, oking).n;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+            if (tid == 0) s_nm = c < MAXMOVES ? c : MAXMOVES;      // (expand_node caps the list the same way)
+        }
+        __syncthreads();
+        nm = s_nm;
     }
-    const char* rbase = B.pool + ((size_t)B.g_chunk_tab[(size_t)g * P.max_chunks + ((uint32_t)root >> CHUNK_SHIFT)] << 20)
-                        + ((size_t)((uint32_t)root & (uint32_t)(CHUNK_GRANULES - 1)) << 4);
-    const int nm = (int)(*reinterpret_cast<const uint32_t*>(rbase + NODE_OFF_HDR + 4) & 0xFF);
     const uint32_t epoch = B.g_noise_epoch[g];
     double* rows = B.noise + (size_t)g * P.K * MAXMOVES;
     const float alpha = (float)P.dirichlet_alpha;
+    const uint32_t key = B.g_game_id[g] + (uint32_t)g * 2654435761u;
     // one (simulation slot, root move) pair per thread and step: 8 x 44 pairs are two steps of the 256 threads
     for (int item = tid; item < last * nm; item += (int)blockDim.x) {
         const int sim = item / nm, j = item - sim * nm;
-        if (mask != SIM_SELECT &&
-            !(B.s_state[(size_t)g * P.K + sim] == SIM_PARKED && B.s_node[(size_t)g * P.K + sim] == root)) continue;
-        NoiseRng rng{P.seed, ((uint64_t)epoch << 32) | ((uint64_t)sim << 20) | ((uint64_t)j << 8),
-                     B.g_game_id[g] + (uint32_t)g * 2654435761u, {0, 0, 0, 0}, 0};
+        NoiseRng rng = NoiseRng::make(P.seed, key, epoch, (uint32_t)sim, (uint32_t)j);
         rows[(size_t)sim * MAXMOVES + j] = dirichlet0(alpha, nm, rng);
     }
     __syncthreads();
@@ -1678,14 +1685,14 @@ __global__ void k_stop(SearchParams P, SearchBuffers B)
     if (g < P.G && B.g_phase[g] == PH_SEARCH) B.g_tasks_left[g] = 0;
 }
 
-// test hook: `n` draws of the root noise exactly as k_noise produces them (same generator, same stream layout: one
-// Philox counter block sequence per (epoch, sim, move) triple)
+// test hook: `n` draws of the root noise exactly as k_noise produces them (same generator, same stream addressing: one
+// counter sequence per (epoch, sim, move) triple)
 __global__ void k_debug_noise(uint64_t seed, uint32_t game_key, float alpha, int nm, double* __restrict__ out, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t epoch = (uint32_t)(i / (8 * 128)), sim = (uint32_t)(i / 128) % 8u, j = (uint32_t)i % 128u;
-    NoiseRng rng{seed, ((uint64_t)epoch << 32) | ((uint64_t)sim << 20) | ((uint64_t)j << 8), game_key, {0, 0, 0, 0}, 0};
+    NoiseRng rng = NoiseRng::make(seed, game_key, epoch, sim, j);
     out[i] = dirichlet0(alpha, nm, rng);
 }
 
@@ -1706,6 +1713,7 @@ struct cz_search {
     size_t bytes = 0;                 // slab + pool
     int device = 0;
     int prev_compact = 0;             // the previous round built a compact queue: its results are indexed by compact row
+    int keep_chunks_created = 0;      // P.keep_chunks as sized at creation (cz_search_set_sims never goes below it)
 };
 
 namespace {
@@ -1850,6 +1858,7 @@ int cz_search_create(const cz_search_cfg* c, cz_search** out)
     while ((long long)h * 2 < max_nodes * 3) h <<= 1;              // load factor <= 2/3 at max_nodes
     P.hash_cap = h;
     P.keep_chunks = keep_chunks_for(P.sims);
+    s->keep_chunks_created = P.keep_chunks;
     // lock-step batches one k_sim launch may START for a game: 1.  (A batch whose simulations all end on terminal or
     // repeated positions needs no evaluation and could be followed by the next at once, but then the whole launch
     // waits for the few waves that chain batches of the slowest kind of simulation: with 3, the sustained k_sim(SELECT)
@@ -2021,14 +2030,11 @@ static int search_round_impl(cz_search* s, const float* policy, const float* val
     const int consume_compact = s->prev_compact;
     s->prev_compact = compact;
     const dim3 nblock(256);
-    // (before BACKUP only simulations parked on an unexpanded root need a row -- the first round of a new tree: one wave
-    //  per game is enough to find that out)
-    if (noise) hipLaunchKernelGGL(k_noise, grid, block, 0, st, s->P, s->B, SIM_BACKUP);
     const bool hist = s->P.in_planes == 28;
     if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP, consume_compact, q_rows, q_count);
     else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_BACKUP, consume_compact, q_rows, q_count);
     hipLaunchKernelGGL(k_advance, grid, block, 0, st, s->P, s->B);
-    if (noise) hipLaunchKernelGGL(k_noise, grid, nblock, 0, st, s->P, s->B, SIM_SELECT);
+    if (noise) hipLaunchKernelGGL(k_noise, grid, nblock, 0, st, s->P, s->B);
     if (hist) hipLaunchKernelGGL(k_sim<true>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT, compact, q_rows, q_count);
     else hipLaunchKernelGGL(k_sim<false>, grid, block, 0, st, s->P, s->B, policy, value, planes, SIM_SELECT, compact, q_rows, q_count);
     S_LAUNCH_CHECK("cz_search_round");
@@ -2054,6 +2060,12 @@ int cz_search_set_sims(cz_search* s, int simulation_num_per_move)
     if (!s || simulation_num_per_move < 1) return serr(CZ_ERR_ARG, "cz_search_set_sims: bad argument");
     // (a search longer than the chunks a game can own ends in counted overflow_sims, it is not refused here)
     s->P.sims = simulation_num_per_move;
+    // a game that has to drop its tree keeps enough chunks for one full search of the NEW length (never fewer than it
+    // was created with: the initial pool layout gave every game that many)
+    int keep = keep_chunks_for(simulation_num_per_move);
+    if (keep > s->P.max_chunks) keep = s->P.max_chunks;
+    if (keep > s->keep_chunks_created) s->P.keep_chunks = keep;
+    else s->P.keep_chunks = s->keep_chunks_created;
     return CZ_OK;
 }
 

@@ -42,6 +42,7 @@ typedef struct {
     int8_t board[90];      /* current state */
     Node *leaf;            /* expanded this round, waiting for NN */
     int fresh;             /* started by action() (not resumed from a parked state): player.py:217 */
+    int deferred; double dval; /* ended on a terminal / repeated position: value waiting for its update_tree task */
 } Sim;
 
 struct xqo_player {
@@ -246,6 +247,24 @@ static void park(Node *node, int idx)
     node->parked[node->n_parked++] = idx;
 }
 
+/* A simulation that ends on a terminal or repeated position does not update the tree itself: MCTS_search SUBMITS
+ * update_tree to the executor (player.py:206, :228-232) and returns.  That task sits in the executor's queue behind the
+ * search tasks of the batch, which were all submitted first (player.py:173-174), and the interpreter lets a search
+ * thread run its descent to the end before it switches: in the unmodified reference the K descents of a batch see each
+ * other's virtual losses but none of the batch's terminal results.  Canonical order: such a value
+ * is applied when the descents of the phase are over, in index order -- tests/golden/kgt1_spread.json: with this rule
+ * the canonical result IS one of the visit vectors the reference itself produces in 23 of 24 recorded cases. */
+static void finish(Sim *s, double v)
+{
+    s->deferred = 1;
+    s->dval = v;
+}
+static void flush_deferred(xqo_player *p, int n)
+{
+    int i;
+    for (i = 0; i < n; i++)
+        if (p->sims[i].deferred) { p->sims[i].deferred = 0; backup(p, &p->sims[i], p->sims[i].dval); }
+}
 static void descend(xqo_player *p, int idx)
 {
     Sim *s = &p->sims[idx];
@@ -256,7 +275,7 @@ static void descend(xqo_player *p, int idx)
         xqo_done(s->board, 0, &over, &v, &fm, &ck);
         if (over) {                                                   /* :204-208, value doubled */
             p->ctr.terminal_sims++;
-            backup(p, s, (double)(v * 2));
+            finish(s, (double)(v * 2));
             return;
         }
         node = tree_find(p, s->board);
@@ -278,7 +297,7 @@ static void descend(xqo_player *p, int idx)
             else if (xqo_be_catched(s->board, mv)) val = 1;
             else val = 0;
             p->ctr.repetition_sims++;
-            backup(p, s, val);
+            finish(s, val);
             return;
         }
         if (node->waiting) {                                          /* :238-242 */
@@ -316,10 +335,11 @@ static void run_batch(xqo_player *p, int n)
     int *leaf_sim = (int *)malloc(sizeof(int) * (size_t)n);
     for (i = 0; i < n; i++) {
         Sim *s = &p->sims[i];
-        s->active = 1; s->depth = 0; s->leaf = 0; s->fresh = 1;
+        s->active = 1; s->depth = 0; s->leaf = 0; s->fresh = 1; s->deferred = 0;
         memcpy(s->board, p->root, 90);
     }
     for (i = 0; i < n; i++) descend(p, i);
+    flush_deferred(p, n);
     for (;;) {
         int nl = 0, k;
         for (i = 0; i < n; i++) if (p->sims[i].leaf) leaf_sim[nl++] = i;
@@ -365,6 +385,7 @@ static void run_batch(xqo_player *p, int n)
                     resume[b + 1] = t;
                 }
                 for (a = 0; a < nres; a++) descend(p, resume[a]);
+                flush_deferred(p, n);
             }
             free(resume);
         }

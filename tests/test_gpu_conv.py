@@ -233,7 +233,7 @@ def test_pack_weights_layout_and_errors():
         _native.conv3x3(x, p.cuda(), torch.zeros(64, device="cuda"), out=x)
 
 
-@pytest.mark.parametrize("filters,blocks", [(128, 7), (32, 2), (192, 3)])
+@pytest.mark.parametrize("filters,blocks", [(128, 7), (32, 2), (192, 3), (256, 2)])
 def test_network_with_mfma_trunk_matches_fp32_module(filters, blocks):
     """The whole policy/value network with the hand-written split-precision trunk against the plain PyTorch fp32
     module (CPU): policy and value within 1e-4 (north_star tolerance)."""
@@ -278,6 +278,48 @@ def test_network_with_mfma_trunk_matches_fp32_module(filters, blocks):
         assert (p3.cpu() - p_ref).abs().max().item() < tol and (v3.cpu() - v_ref).abs().max().item() < tol * 10
     with pytest.raises(RuntimeError):
         InferenceNet(net, torch.float32, trunk="mfma")(x)          # no CPU implementation of the HIP trunk
+
+
+def test_deep_network_fp16_matches_fp32_module(positions_1k):
+    """BASELINE configs[4] ("deep net stress: 20-block x 256-filter ResNet, fp16 MFMA eval"; architecture: reference
+    agent/model.py:32-83): the whole 20 x 256 network on plain fp16 operands (k_resblock<256>, fp32 accumulate) against
+    the plain PyTorch fp32 module on the CPU, BatchNorm statistics perturbed so that the folding is exercised, on 64
+    real positions of the 1k suite.  The bound is the derived one bench.py prints for this configuration
+    (bench.py::fp16_tolerance: 2^-11 operand rounding, random-sign accumulation, 41 layers in quadrature, x4 margin:
+    1.8e-2 on the value and on the logits, 1e-4 on the probabilities) -- it is fp16's bound, not north_star's 1e-4, which
+    is the split-precision default's (tested above for 256 filters as well)."""
+    import torch
+    from cchess_alphazero.agent.model import CChessNet, InferenceNet
+    import oracle.xq_oracle as xo
+    import bench                                      # (repo root is on sys.path: tests/conftest.py)
+    torch.manual_seed(13)
+    net = CChessNet(cnn_filter_num=256, res_layer_num=20)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.7, 1.4)
+            m.weight.data.normal_(1, 0.1)
+            m.bias.data.normal_(0, 0.1)
+    net.eval()
+    states = [r["state"] for r in positions_1k if not r["done"][0]][::14][:64]
+    assert len(states) == 64
+    x = torch.from_numpy(np.stack([xo.planes_board(xo.state_to_board(s)) for s in states]))
+    with torch.no_grad():
+        p_ref, v_ref = net(x)
+    tol = bench.fp16_tolerance(20, 256)
+    assert 1e-2 < tol["value_abs"] < 2e-2
+    inf = InferenceNet(net, torch.float16, trunk="mfma").cuda()
+    p, v = inf(x.to(torch.uint8).cuda())
+    lg, lr = torch.log(p.cpu().clamp_min(1e-30)), torch.log(p_ref.clamp_min(1e-30))
+    dlogit = ((lg - lg.mean(1, keepdim=True)) - (lr - lr.mean(1, keepdim=True))).abs().max().item()
+    dp, dv = (p.cpu() - p_ref).abs().max().item(), (v.cpu() - v_ref).abs().max().item()
+    print(f"deep fp16 vs fp32 module: policy {dp:.3e}, logit {dlogit:.3e}, value {dv:.3e}; bound {tol}")
+    assert dp < tol["policy_abs"] and dlogit < tol["policy_logit_abs"] and dv < tol["value_abs"], (dp, dlogit, dv)
+    assert v_ref.abs().max() > 0.05                  # (the value head is not saturated at 0: the check means something)
+    # the same network with split-precision operands stays inside north_star's 1e-4
+    sp = InferenceNet(net, torch.float32, trunk="mfma").cuda()
+    p2, v2 = sp(x.to(torch.uint8).cuda())
+    assert (p2.cpu() - p_ref).abs().max().item() < 1e-4 and (v2.cpu() - v_ref).abs().max().item() < 1e-4
 
 
 def test_network_with_history_planes_and_reference_head_shapes():

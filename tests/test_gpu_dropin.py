@@ -397,15 +397,18 @@ def test_uci_searches_match_reference_player(tmp_path, monkeypatch):
     from cchess_alphazero.environment.lookup_tables import flip_move
     with open(os.path.join(GOLDEN, "uci_k1.json")) as f:
         cases = json.load(f)["cases"]
+    assert sum(c.get("hist") is not None for c in cases) >= 2
     for c in cases:
         cfg = _cfg(tmp_path, monkeypatch, simulation_num_per_move=800, search_threads=1, noise_eps=0,
                    tau_decay_rate=0, c_puct=1.0)
         pipe = stub_net.StubPipe(lambda p, s=c["salt"]: stub_net.hash_stub_numpy(p, s))
         tree = {}
+        # (cases with a `hist` are 28-plane history players: the score of the info line is then the value of the END of
+        #  the line evaluated with the planes of the position two plies up the line, player.py:326-333,442-445)
         pl = CChessPlayer(cfg, search_tree=tree, pipes=pipe, enable_resign=False, debugging=True, uci=True,
-                          side=c["turns"] % 2)
+                          use_history=c.get("hist") is not None, side=c["turns"] % 2)
         pl.out = io.StringIO()
-        action, _ = pl.action(c["state"], c["turns"], depth=c["depth"])
+        action, _ = pl.action(c["state"], c["turns"], depth=c["depth"], hist=c.get("hist"))
         assert action == c["action"]
         assert pl.done_tasks == c["done_tasks"]
         lines = [l for l in pl.out.getvalue().splitlines() if l.startswith("info depth")]

@@ -574,3 +574,37 @@ def test_golden_visit_counts_on_the_1k_suite(gpu, positions_1k):
         assert int(st["sum_n"][g]) == r["sum_n"] and xo.label_str(int(act[g])) == r["action"]
     assert s.counters()["expansions"] == sum(data["results"][i]["evals"] for i in idx)
     s.close()
+
+
+def test_hip_search_lies_inside_the_reference_spread(gpu):
+    """K > 1 on the GPU against the reference itself (not only against the oracle's canonical order): the reference's
+    search_threads race, recorded from the unmodified reference's own CChessPlayer with its own thread timing
+    (tests/golden/kgt1_spread.json: 32 runs of the same 800-simulation search at K = 8 and K = 40 for 12 positions;
+    player.py:173-179,204-208,238-242).  Criterion: tests/test_oracle_mcts.py::check_against_spread -- inside the spread
+    everywhere, equal to the reference where the reference is deterministic, exactly one of the recorded reference
+    vectors in >= 20 of 24 cases -- and equal to the oracle's canonical order bit for bit."""
+    from test_oracle_mcts import check_against_spread
+    data = _golden("kgt1_spread.json")
+    assert len(data["cases"]) >= 24
+
+    def search(c):
+        spec = dict(kind="hash", salt=c["salt"])
+        pc = play_config(simulation_num_per_move=c["sims"], search_threads=c["K"])
+        s = gpu.S.Search(pc, 1, seed=5)
+        kw = {}
+        if c.get("no_act"):
+            na, nn = no_act_tensors(gpu, [c["no_act"]])
+            kw = dict(no_act=na, n_no_act=nn)
+        s.set_roots(boards_tensor(gpu, [c["state"]]), **kw)
+        s.run_until_idle(stub_eval(gpu, spec))
+        st = s.root_stats()
+        ctr = s.counters()
+        s.close()
+        assert ctr["overflow_sims"] == 0 and ctr["tree_resets"] == 0
+        pl = xo.Player(oracle_cfg(pc), spec)                         # it IS the canonical order, bit for bit
+        pl.search(c["state"], 0, c.get("no_act"))
+        assert_root_equal(st, 0, pl.node_stats(c["state"]), c["name"])
+        pl.close()
+        cnt = int(st["counts"][0])
+        return st["n"][0, :cnt], int(st["sum_n"][0]), st["moves"][0, :cnt]
+    assert check_against_spread(data["cases"], search) >= 23

@@ -168,31 +168,68 @@ def test_reference_arena_games():
         assert evals == gm["nn_positions"], gm["name"]
 
 
+def spread_verdict(case, n):
+    """Is the visit vector `n` (root edges in move order) a plausible member of the reference's own population for this
+    case?  Returns (total-variation distance to the mean of the reference runs, the furthest reference run's distance,
+    whether some reference run has the same top move, whether `n` is exactly one of the recorded vectors)."""
+    v = np.array(case["visits"], dtype=np.float64)
+    p = v / v.sum(1, keepdims=True)
+    mean = p.mean(0)
+    spread = 0.5 * np.abs(p - mean).sum(1)
+    q = np.asarray(n, dtype=np.float64)
+    q = q / q.sum()
+    tv = 0.5 * np.abs(q - mean).sum()
+    top_ok = int(np.argmax(q)) in {int(np.argmax(r)) for r in p}
+    exact = tuple(int(x) for x in n) in {tuple(int(y) for y in x) for x in case["visits"]}
+    return float(tv), float(spread.max()), top_ok, exact
+
+
+def check_against_spread(cases, search_fn):
+    """The K > 1 criterion, shared by the CPU oracle test below and the HIP test (tests/test_gpu_search.py): for every
+    recorded case the searched visit vector n (search_fn(case) -> (n in move order, sum_n)) must have the reference's
+    totals, leave banned moves unvisited, have a top move some reference run has and lie no further from the mean of
+    the reference runs than the furthest reference run does (total-variation distance, 1e-9 slack for the cases where
+    every reference run gave the same vector).  Beyond plausibility: where the reference is deterministic (all 32 runs
+    equal) the result must BE that vector, and over all cases it must be exactly one of the recorded reference vectors
+    in at least 20 of 24."""
+    exact_n = 0
+    for c in cases:
+        n, sum_n, moves = search_fn(c)
+        assert sum_n == c["sims"] == c["sum_n"][0], c["name"]
+        assert int(np.sum(n)) == int(sum(c["visits"][0])), c["name"]
+        for mv in c.get("no_act") or []:
+            assert n[list(moves).index(xo.label_of_str(mv))] == 0, c["name"]
+        tv, far, top_ok, exact = spread_verdict(c, n)
+        assert tv <= far + 1e-9, (c["name"], tv, far)
+        assert top_ok, c["name"]
+        if len({tuple(v) for v in c["visits"]}) == 1:
+            assert exact, c["name"]
+        exact_n += exact
+    assert exact_n >= 20, exact_n
+    return exact_n
+
+
 def test_canonical_order_lies_inside_the_reference_spread():
-    """search_threads > 1 in the reference is a thread race (tests/golden/kgt1_spread.json: 48 runs of the same K = 8
-    search give 26-37 different visit vectors), so K > 1 parity is defined against the canonical order of DESIGN.md
-    section 3 -- which must at least be a plausible member of the reference's own population: same totals, and a visit
-    distribution no further from the mean of the reference runs (total-variation distance) than 1.5 x the furthest
-    reference run is.  (For the opening position the canonical result IS one of the recorded reference vectors.)"""
+    """search_threads > 1 in the reference is a thread race, so K > 1 parity is defined against the canonical order of
+    DESIGN.md section 3.  tests/golden/kgt1_spread.json holds what the UNMODIFIED reference does (its own 1 ms sender
+    sleep, CPython's 5 ms switch interval): 32 runs of the same 800-simulation search at K = 8 and at K = 40 for each of
+    12 positions -- opening, middlegames, endgames, a mating position where the proven-win shortcut fires, a search
+    under a ban list.  At K = 8 the reference is nearly deterministic (1-7 distinct visit vectors in 32 runs), at K = 40
+    it is not (19-32).  The canonical order must reproduce it: inside the spread everywhere, EQUAL to the reference
+    where the reference is deterministic, and exactly one of the recorded vectors in >= 20 of the 24 cases (it is in
+    23).  The same check runs on the HIP engine: tests/test_gpu_search.py::test_hip_search_lies_inside_the_reference_spread."""
     data = _golden("kgt1_spread.json")
-    exact = 0
-    for c in data["cases"]:
-        v = np.array(c["visits"], dtype=np.float64)
-        p = v / v.sum(1, keepdims=True)
-        mean = p.mean(0)
-        spread = 0.5 * np.abs(p - mean).sum(1)
+    assert len(data["cases"]) >= 24 and {c["K"] for c in data["cases"]} == {8, 40}
+    assert all(len(c["visits"]) >= 32 and c["sims"] == 800 for c in data["cases"])
+
+    def search(c):
         cfg = xo.play_cfg(simulation_num_per_move=c["sims"], search_threads=c["K"])
         pl = xo.Player(cfg, {"kind": "hash", "salt": c["salt"]})
-        pl.search(c["state"])
+        pl.search(c["state"], 0, c.get("no_act"))
         st = pl.node_stats(c["state"])
         pl.close()
-        assert st["sum_n"] == c["sims"] == c["sum_n"][0] and int(st["n"].sum()) == int(v[0].sum()) == c["sims"] - 1
-        q = st["n"] / st["n"].sum()
-        tv = 0.5 * np.abs(q - mean).sum()
-        assert tv <= 1.5 * spread.max(), (c["name"], tv, spread.max())
-        assert int(np.argmax(q)) in {int(np.argmax(r)) for r in p}, c["name"]      # a top move some reference run has
-        exact += tuple(int(x) for x in st["n"]) in {tuple(int(y) for y in x) for x in c["visits"]}
-    assert exact >= 1
+        return st["n"], st["sum_n"], st["moves"]
+    assert check_against_spread(data["cases"], search) >= 23
 
 
 def test_sampling_matches_numpy_choice():
