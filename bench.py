@@ -320,13 +320,14 @@ def fp16_tolerance(blocks, filters):
     <= 2^-10 per product), errors of random sign: relative RMS error of a layer's output ~ 2^-10 / sqrt(3) ~ 6e-4, plus
     2^-11 / sqrt(3) for storing the activation in fp16; the 2 B + 1 layers of the tower add in quadrature (the skip
     connections carry them forward unamplified): e_trunk ~ 7e-4 sqrt(2 B + 1) (B = 20: 4.5e-3).  The heads are
-    1-Lipschitz in that relative error times the pre-activation size (|z| <~ 2 for the value, tanh contracts; logits of
-    a random-init policy head span <~ 2): value_abs and policy_logit_abs = 4 x e_trunk (margin for the worst of the
-    checked positions against the RMS), policy_abs = p (1 - p) x logit error <= 1e-4 for p ~ 5e-4."""
+    1-Lipschitz in that relative error times the pre-activation size (|z| <~ 1 for the value, tanh contracts; logits of
+    a random-init policy head span <~ 1): value_abs = policy_logit_abs = e_trunk (an upper estimate: the measured worst
+    case is 5 x below it), policy_abs = p (1 - p) x logit error <= 1e-4 for p ~ 5e-4."""
     e = 7e-4 * (2 * blocks + 1) ** 0.5
-    return {"policy_abs": 1e-4, "value_abs": 4 * e, "policy_logit_abs": 4 * e,
-            "derivation": "fp16 operand rounding 2^-11, random-sign accumulation, quadrature over 2B+1 layers, x4 margin "
-                          "(bench.py::fp16_tolerance)"}
+    return {"policy_abs": 1e-4, "value_abs": e, "policy_logit_abs": e,
+            "derivation": "fp16 operand rounding 2^-11, random-sign accumulation, quadrature over 2B+1 layers "
+                          "(bench.py::fp16_tolerance); measured on the MI355X, 20x256 with perturbed BatchNorm statistics, "
+                          "worst of 64 positions: logit 8.4e-4, value 2.3e-4"}
 
 
 def numerics_check(eng, ref_net, cfg, nq=64):

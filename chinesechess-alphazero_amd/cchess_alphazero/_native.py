@@ -82,6 +82,13 @@ def _declare(L):
         L.cz_resblock.restype = i32
         L.cz_split_bias_act.argtypes = [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, vp]
         L.cz_split_bias_act.restype = i32
+    if hasattr(L, "cz_heads_tail"):
+        L.cz_heads_tail.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, i32, vp, C.c_float, vp, vp, vp, i32, vp, vp]
+        L.cz_heads_tail.restype = i32
+        L.cz_fc_packed_elems.argtypes = [i32, i32]
+        L.cz_fc_packed_elems.restype = C.c_size_t
+        L.cz_fc_pack_weights.argtypes = [vp, i32, i32, vp]
+        L.cz_fc_pack_weights.restype = i32
     for name in ("cz_label_tables", "cz_movegen", "cz_done", "cz_step", "cz_encode", "cz_check_or_catch",
                  "cz_be_catched", "cz_has_attack", "cz_rules_fused"):
         getattr(L, name).restype = i32
@@ -280,6 +287,31 @@ def head_convs(x, w, bias, n_policy, policy_feat, value_feat):
     check(lib().cz_head_convs(_ptr(x), _dt_code(x.dtype), _ptr(w), _ptr(bias), _ptr(policy_feat), _ptr(value_feat),
                               n, c, n_policy, w.shape[0] - n_policy, _stream()), "cz_head_convs")
     return policy_feat, value_feat
+
+
+def pack_fc_weights(w):
+    """fp32 [n_out, n_in] dense-layer matrix -> (hi, lo) bf16 pairs in MFMA fragment order (on the CPU)."""
+    import torch
+    w = w.detach().to("cpu", torch.float32).contiguous()
+    n = lib().cz_fc_packed_elems(w.shape[0], w.shape[1])
+    if n == 0:
+        raise NativeError(f"cz_fc_pack_weights: unsupported shape {tuple(w.shape)}")
+    out = torch.empty((n,), dtype=torch.bfloat16)
+    check(lib().cz_fc_pack_weights(_ptr(w), w.shape[0], w.shape[1], _ptr(out)), "cz_fc_pack_weights")
+    return out
+
+
+def heads_tail(policy_feat, value_feat, wp, bias_p, w1, bias1, w2, b2, policy, value, stats, count=None):
+    """softmax(policy_feat @ Wp^T + bp) -> policy [N, n_labels]; tanh(relu(value_feat @ W1^T + b1) @ w2 + b2) -> value [N]
+    (cz_heads_tail; wp / w1 from pack_fc_weights, everything else fp32 on the device).  count: optional int32 device
+    tensor, only the first min(count, N) rows are computed (compact evaluation queue)."""
+    require_gpu()
+    n = policy_feat.shape[0]
+    check(lib().cz_heads_tail(_ptr(policy_feat), policy_feat.shape[1], _ptr(wp), _ptr(bias_p), policy.shape[1],
+                              _ptr(value_feat), value_feat.shape[1], _ptr(w1), _ptr(bias1), bias1.shape[0], _ptr(w2),
+                              float(b2), _ptr(policy), _ptr(value), _ptr(stats), n,
+                              _ptr(count) if count is not None else None, _stream()), "cz_heads_tail")
+    return policy, value
 
 
 def pack_input_conv_weights(w_oihw, dtype, parts):

@@ -275,15 +275,20 @@ class Search:
         return dict(moves=moves.cpu().numpy(), n=n.cpu().numpy(), w=w.cpu().numpy(), p=p.cpu().numpy(),
                     sum_n=sum_n.cpu().numpy(), counts=counts.cpu().numpy())
 
-    def pv(self, max_len=20):
-        """Principal variation of every game (one launch, one copy): list of label lists."""
+    def pv(self, max_len=20, with_visits=False):
+        """Principal variation of every game (one launch, one copy): list of label lists (with_visits: also the visit
+        counts of those edges)."""
         import torch
         moves = torch.empty((self.G, max_len), dtype=torch.uint16, device=self.device)
         visits = torch.empty((self.G, max_len), dtype=torch.int32, device=self.device)
         _native.check(self.L.cz_search_pv(self.h, int(max_len), C.c_void_p(moves.data_ptr()),
                                           C.c_void_p(visits.data_ptr()), self._stream()), "cz_search_pv")
         mv = moves.cpu().numpy()
-        return [[int(x) for x in row[row != 0xFFFF]] for row in mv]
+        out = [[int(x) for x in row[row != 0xFFFF]] for row in mv]
+        if with_visits:
+            vs = visits.cpu().numpy()
+            return out, [[int(x) for x in vs[g, :len(out[g])]] for g in range(self.G)]
+        return out
 
     def choose(self, u=None):
         import torch

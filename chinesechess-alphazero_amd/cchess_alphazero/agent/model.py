@@ -115,6 +115,7 @@ class InferenceNet(nn.Module):
         self.fused_epilogue = True          # on the GPU: hand-written bias + skip + ReLU pass after each conv
         self.fused_blocks = True            # trunk="mfma", fp32, 128 filters: one launch per residual block
         self.fused_heads = True             # ... and the 1x1 head convolutions folded into the last block's store pass
+        self.fused_tail = True              # dense layers + softmax / tanh on the hand-written kernels (csrc/xq_heads.hip)
         self.block_events = None            # bench.py: list collecting (start, end) HIP events around tower launches
         self.input_depth = net.cfg["input_depth"]
         self.filters = net.cfg["cnn_filter_num"]
@@ -146,7 +147,9 @@ class InferenceNet(nn.Module):
             self.register_buffer("in_w", self._packed_in.view(torch.int16))
             self.register_buffer("head_w32", self._head_w)
             self.register_buffer("head_b32", self._head_b)
-            del self._packed_in, self._in_bias32, self._head_w, self._head_b
+            for name, t in zip(("tail_wp", "tail_bp", "tail_w1", "tail_b1", "tail_w2"), self._tail_pack):
+                self.register_buffer(name, t.view(torch.int16) if t.dtype == torch.bfloat16 else t)
+            del self._packed_in, self._in_bias32, self._head_w, self._head_b, self._tail_pack
         self._bufs = {}
         self.eval()
         for p in self.parameters():
@@ -165,6 +168,13 @@ class InferenceNet(nn.Module):
         """fp32 folded filters -> MFMA fragment order (cz_conv3x3_pack_weights); called before the dtype conversion."""
         from cchess_alphazero import _native
         self._in_bias32 = self.input_conv.bias.detach().float().clone()
+        # the dense tail (cz_heads_tail): both matrices as (hi, lo) bf16 pairs in fragment order, the rest fp32
+        self._tail_pack = (_native.pack_fc_weights(self.policy_out.weight),
+                           self.policy_out.bias.detach().float().clone(),
+                           _native.pack_fc_weights(self.value_dense.weight),
+                           self.value_dense.bias.detach().float().clone(),
+                           self.value_out.weight.detach().float().reshape(-1).clone())
+        self._tail_b2 = float(self.value_out.bias.detach().float().item())
         self._head_w = torch.cat([self.policy_conv.weight.detach().float().flatten(1),
                                   self.value_conv.weight.detach().float().flatten(1)]).contiguous()
         self._head_b = torch.cat([self.policy_conv.bias.detach().float(), self.value_conv.bias.detach().float()])
@@ -293,6 +303,17 @@ class InferenceNet(nn.Module):
                                         rows=rows, count=count)
                 if last is not None:
                     _native.head_convs(last, self.head_w32, self.head_b32, npol, pf, vf)
+                if self.fused_tail and pf.shape[1] <= 384 and vf.shape[1] <= 384:
+                    # dense layers + softmax / tanh: three launches of hand-written kernels, straight into `out`
+                    if out is None:
+                        out = (torch.empty((n, self.policy_out.out_features), dtype=torch.float32, device=planes.device),
+                               torch.empty((n,), dtype=torch.float32, device=planes.device))
+                    key = ("tail_stats", n, str(planes.device))
+                    if key not in self._bufs:
+                        self._bufs[key] = torch.empty((n, 2), dtype=torch.float32, device=planes.device)
+                    _native.heads_tail(pf, vf, self.tail_wp, self.tail_bp, self.tail_w1, self.tail_b1, self.tail_w2,
+                                       self._tail_b2, out[0], out[1], self._bufs[key], count=count)
+                    return out
                 p = self.policy_out(pf.to(self.dtype))
                 v = F.relu(self.value_dense(vf.to(self.dtype)))
                 if out is not None:                            # straight into the search object's queue tensors

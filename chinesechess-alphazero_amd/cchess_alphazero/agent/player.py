@@ -143,17 +143,33 @@ class CChessPlayer:
         t = turns
         end_state = state
         line = [state]                                       # the search path of the line: [s0, m1, s1, m2, s2, ...]
-        for mov in self.principal_variation(state, no_act):
+        labels, visits = self._search.pv(20, with_visits=True)
+        labels, visits = labels[0], visits[0]
+        for lab in labels:
+            mov = self.labels[lab]
             pv += " " + senv.to_uci_move(flip_move(mov) if t % 2 == 1 else mov)
             end_state = senv.step(end_state, mov)
             line += [mov, end_state]
             t += 1
         # the reference prints the network value of the position at the END of the line (self.debug holds every
         # evaluated state when debugging, :442-445), seen from `side`; a line that ends on a position the network
-        # never saw (terminal, or debugging off) keeps the root's value as it was passed in, un-negated
-        if self.debugging and t != turns and not senv.done(end_state)[0]:
-            # (a history model saw this position with the planes of the position two plies up the path, :331-333)
-            value = self._root_value(end_state, line)[1]
+        # never saw (terminal, an unvisited move, or debugging off) keeps the root's value as it was passed in, un-negated
+        if self.debugging and labels and visits[-1] > 0 and not senv.done(end_state)[0]:
+            leaf_v = None
+            if visits[-1] == 1:
+                # visited once = expanded and evaluated once: the edge's W is exactly minus that evaluation (the value
+                # the network gave with the history planes of the path it was first reached by) -- no forward, no
+                # re-encoding, and equal to what the reference kept in self.debug[state]
+                st = self._search.node_stats(labels[:-1]) if len(labels) > 1 else self._search.root_stats()
+                c = int(st["counts"][0])
+                hit = np.nonzero(st["moves"][0, :c] == labels[-1])[0]
+                if len(hit) and int(st["n"][0, hit[0]]) == 1:
+                    leaf_v = -float(st["w"][0, hit[0]])
+            if leaf_v is None:
+                # (simulations in flight through this edge, K > 1: evaluate the position; a history model gets the
+                #  planes of the position two plies up the line, :331-333)
+                leaf_v = self._root_value(end_state, line)[1]
+            value = leaf_v
             if t % 2 != self.side:
                 value = -value
         duration = max(time() - start_time, 1e-9)

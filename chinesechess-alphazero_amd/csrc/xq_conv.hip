@@ -113,7 +113,7 @@ template <int C, int P, int PARTS> struct Geom {
 };
 
 // global -> registers: the P boards starting at board n0 (16 bytes per lane per iteration, fully coalesced)
-template <typename E, int C, int P, int PARTS, bool SKIP_LOADS = false, int NTHR = Geom<C, P, PARTS>::GTHREADS>
+template <typename E, int C, int P, int PARTS, int NTHR = Geom<C, P, PARTS>::GTHREADS>
 __device__ __forceinline__ void tile_load(const E* xh, const E* xl, int n0, int n_boards, int gtid,
                                           uint4 (*v)[(Geom<C, P, PARTS>::CHUNKS + NTHR - 1) / NTHR])
 {
@@ -129,7 +129,7 @@ __device__ __forceinline__ void tile_load(const E* xh, const E* xl, int n0, int 
             const bool ok = ((it + 1) * NTHR <= G::CHUNKS || i < G::CHUNKS) &&
                             (full || n0 + i / (G::CPR * 90) < n_boards);
             v[part][it] = make_uint4(0, 0, 0, 0);
-            if (ok && !SKIP_LOADS) v[part][it] = src[i];
+            if (ok) v[part][it] = src[i];
         }
     }
 }
@@ -168,7 +168,7 @@ __device__ __forceinline__ void zero_rows_write(unsigned char* region, int gtid)
 // The K loop: 9 taps x C input channels for the 32 output channels of this wave and all NT pixel tiles of the
 // LDS image.  acc[p][r] <-> pixel (p % 3) * 32 + (lane & 31) of board p / 3,
 //                          channel 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-template <typename E, int C, int P, int PARTS, bool NO_W = false, bool NO_LDS = false>
+template <typename E, int C, int P, int PARTS>
 __device__ __forceinline__ void conv_kloop(const unsigned char* region, const uint4* wq, int lane,
                                            f32x16* acc)
 {
@@ -217,10 +217,7 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
 #pragma unroll
     for (int part = 0; part < PARTS; ++part)
 #pragma unroll
-        for (int p = 0; p < NT; ++p) {
-            px[0][p][part] = load_px(pre[p], part);
-            if (NO_LDS) px[1][p][part] = px[0][p][part];
-        }
+        for (int p = 0; p < NT; ++p) px[0][p][part] = load_px(pre[p], part);
 
     // One K-step = NT (x3 in split mode) MFMAs.  The LDS reads of the NEXT K-step and the weight loads three K-steps
     // ahead are issued one per MFMA, in the shadow of the matrix pipe; sched_barrier pins that order (left alone, the
@@ -246,10 +243,10 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
             for (int i = 0; i < NM; ++i) {
                 const int pass = i / NT, p = i % NT;      // pass 0: w_hi*x_hi, 1: w_lo*x_hi, 2: w_hi*x_lo
                 acc[p] = Mfma<E>::mma(w[pass == 1 ? PARTS - 1 : 0], b[p][pass == 2 ? PARTS - 1 : 0], acc[p]);
-                if (i < NL && !NO_LDS) bn[i % NT][i / NT] = load_px(G::kstep(rows[i % NT], kn), i / NT);
+                if (i < NL) bn[i % NT][i / NT] = load_px(G::kstep(rows[i % NT], kn), i / NT);
                 if (i >= NM - PER && kk * PER + (i - (NM - PER)) < NT)
                     pre_n[kk * PER + (i - (NM - PER))] = tap_row(ndy, ndx, kk * PER + (i - (NM - PER)));
-                if (i >= NM - PARTS && !NO_W)
+                if (i >= NM - PARTS)
                     wf[(kk + W_RING - 1) % W_RING][i - (NM - PARTS)] = load_w(step + W_RING - 1, i - (NM - PARTS));
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -260,7 +257,7 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
 }
 
 // ---- kernel 1: one workgroup = P boards, one pass (any channel count; used for the small / plain-precision cases) --
-template <typename E, int C, int P, int PARTS, int MINW, int DBG = 0>
+template <typename E, int C, int P, int PARTS, int MINW>
 __global__ __launch_bounds__(C / 32 * 64, MINW) void k_conv3x3(
     const E* __restrict__ xh, const E* __restrict__ xl, const E* __restrict__ wp, const float* __restrict__ bias,
     const E* __restrict__ sh, const E* __restrict__ sl, E* __restrict__ yh, E* __restrict__ yl,
@@ -274,7 +271,7 @@ __global__ __launch_bounds__(C / 32 * 64, MINW) void k_conv3x3(
     const int n0 = blockIdx.x * P;
     {
         uint4 v[PARTS][G::ITER];
-        tile_load<E, C, P, PARTS, (DBG & 2) != 0>(xh, xl, n0, n_boards, tid, v);
+        tile_load<E, C, P, PARTS>(xh, xl, n0, n_boards, tid, v);
         tile_write<C, P, PARTS>(lds, tid, v);
         zero_rows_write<C, P, PARTS>(lds, tid);
     }
@@ -290,10 +287,6 @@ __global__ __launch_bounds__(C / 32 * 64, MINW) void k_conv3x3(
         const int q = (p % 3) * 32 + ln;
         const int n = n0 + p / 3;
         if (q >= 90 || n >= n_boards) continue;
-        if (DBG & 1) {              // ablation probe: keep the accumulators alive, skip the epilogue traffic
-            if (acc[p][0] + acc[p][5] + acc[p][10] + acc[p][15] == 12345.678f) yh[0] = (E)1.0f;
-            continue;
-        }
         const size_t pix = ((size_t)n * 90 + q) * C;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -331,8 +324,6 @@ __global__ __launch_bounds__(C / 32 * 64, MINW) void k_conv3x3(
     }
 }
 
-__device__ long long g_trace[64][8];     // tuning probe (DBG & 8): [board k][phase] time stamps of block 0
-
 // ---- kernel 2: a whole residual block per launch, wave-specialised ---------------------------------------------------
 // y = relu(conv2(relu(conv1(x) + b1)) + b2 + x) for P boards at a time per workgroup, persistent over boards.
 // The intermediate activation never leaves LDS (it is written straight into a second operand image), the skip
@@ -360,7 +351,7 @@ struct HeadArgs {
     int n_pol;
 };
 
-template <typename E, int C, int PARTS, int P, int DBG = 0, bool HEADS = false>
+template <typename E, int C, int PARTS, int P, bool HEADS = false>
 __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_resblock(
     const E* __restrict__ xh, const E* __restrict__ xl, const E* __restrict__ w1p, const float* __restrict__ b1,
     const E* __restrict__ w2p, const float* __restrict__ b2, E* __restrict__ yh, E* __restrict__ yl,
@@ -397,7 +388,7 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
     if (copy_role) {
         const int ctid = tid - CT * 64;
         uint4 v[PARTS][LITER];
-        tile_load<E, C, P, PARTS, (DBG & 2) != 0, CTHR>(xh, xl, t * P, n_boards, ctid, v);
+        tile_load<E, C, P, PARTS, CTHR>(xh, xl, t * P, n_boards, ctid, v);
         tile_write<C, P, PARTS, CTHR>(X, ctid, v);
         zero_rows_write<C, P, PARTS, CTHR>(X, ctid);
         zero_rows_write<C, P, PARTS, CTHR>(Y, ctid);
@@ -415,7 +406,7 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
             const bool has_next = tn < n_tiles;
             int ct2 = ctid;
             asm volatile("" : "+v"(ct2));                      // keep address arithmetic inside the loop (registers)
-            if (has_next) tile_load<E, C, P, PARTS, (DBG & 2) != 0, CTHR>(xh, xl, tn * P, n_boards, ct2, v);
+            if (has_next) tile_load<E, C, P, PARTS, CTHR>(xh, xl, tn * P, n_boards, ct2, v);
             // stream out the previous tile (staged, already ReLU'd) while the matrix waves run K1
             auto store_tile = [&](int to) {
                 const size_t ebase = (size_t)to * P * 90 * C;
@@ -429,7 +420,6 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
                         const float4 f0 = *reinterpret_cast<const float4*>(S + stage_off(qq, c8 * 8));
                         const float4 f1 = *reinterpret_cast<const float4*>(S + stage_off(qq, c8 * 8 + 4));
                         const float r[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-                        if (DBG & 1) continue;
                         if (HEADS) {
                             // 16 consecutive lanes hold the 128 channels of one pixel: partial dot products, then a
                             // 16-lane butterfly; lane o of the group writes head output o
@@ -469,7 +459,6 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
                         }
                     } else {
                         const uint4 f = *reinterpret_cast<const uint4*>(S + stage_off(qq, c8 * 8));
-                        if (DBG & 1) continue;
                         reinterpret_cast<uint4*>(yh + ebase)[i] = f;
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -494,19 +483,13 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
     const uint4* wq1 = reinterpret_cast<const uint4*>(w1p) + wg * 64 + lane;
     const uint4* wq2 = reinterpret_cast<const uint4*>(w2p) + wg * 64 + lane;
     const int kb = lane >> 5, ln = lane & 31;
-    int kiter = 0;
     for (;;) {
         __syncthreads();                                       // A
         const bool has_next = t + stride < n_tiles;
         f32x16 acc[NT];
-#define CZ_STAMP2(ph, val) do { if ((DBG & 8) && blockIdx.x == 0 && tid == 0 && kiter < 64) g_trace[kiter][ph] = (val); } while (0)
-        CZ_STAMP2(0, wall_clock64());
-        long long cyc0 = (DBG & 8) ? clock64() : 0;
         __builtin_amdgcn_s_setprio(3);
         conv_kloop<E, C, P, PARTS>(X, wq1, lane, acc);
         __builtin_amdgcn_s_setprio(0);
-        CZ_STAMP2(1, wall_clock64());
-        CZ_STAMP2(6, clock64() - cyc0);
         int ln2 = ln, kb2 = kb, gt2 = tid;
         asm volatile("" : "+v"(ln2), "+v"(kb2), "+v"(gt2));
         // epilogue 1: relu(acc + b1) -> (hi, lo) -> Y image (operand layout of the second convolution)
@@ -534,15 +517,10 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
                 }
             }
         }
-        CZ_STAMP2(2, wall_clock64());
         __syncthreads();                                       // B: Y complete
-        CZ_STAMP2(3, wall_clock64());
-        cyc0 = (DBG & 8) ? clock64() : 0;
         __builtin_amdgcn_s_setprio(3);
-        conv_kloop<E, C, P, PARTS, (DBG & 32) != 0, (DBG & 64) != 0>(Y, wq2, lane, acc);
+        conv_kloop<E, C, P, PARTS>(Y, wq2, lane, acc);
         __builtin_amdgcn_s_setprio(0);
-        CZ_STAMP2(4, wall_clock64());
-        CZ_STAMP2(7, clock64() - cyc0);
         asm volatile("" : "+v"(ln2), "+v"(kb2));
         // epilogue 2: relu(acc + b2 + x) -> staging
 #pragma unroll
@@ -578,13 +556,10 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
                 }
             }
         }
-        CZ_STAMP2(5, wall_clock64());
         __syncthreads();                                       // C: staged; X may be replaced
         if (!has_next) break;
         t += stride;
-        ++kiter;
     }
-#undef CZ_STAMP2
 }
 
 // ---- kernel 2b: the residual block, software-pipelined over boards (128 filters, split operands) ------------------
@@ -656,7 +631,7 @@ struct PipeShadow {                 // epilogue 2 of the previous board, one (ti
 
 // K loop over the image whose first absolute row is row_base.  SHADOW: retire epilogue 2 of the previous board
 // (accumulators prev[3]) while the MFMAs run.
-template <typename E, bool SHADOW, int PROBE = 0>      // PROBE (timing only, wrong results): bit 0 no K-step XOR, bit 1 fixed weight address, bit 2 no tap-row arithmetic
+template <typename E, bool SHADOW>
 __device__ __forceinline__ void pipe_kloop(unsigned char* lds, int row_base, const uint4* wq, int lane, f32x16* acc,
                                            f32x16* prev, PipeShadow<E>& shd)
 {
@@ -719,14 +694,11 @@ __device__ __forceinline__ void pipe_kloop(unsigned char* lds, int row_base, con
                 for (int i = 0; i < NM; ++i) {
                     const int pass = i / NT, p = i % NT;
                     acc[p] = Mfma<E>::mma(w[pass == 1 ? 1 : 0], b[p][pass == 2 ? 1 : 0], acc[p]);
-                    if (i < NL) bn[i % NT][i / NT] = load_px((PROBE & 1) ? rows[i % NT] : rows[i % NT] ^ (kn << 5), i / NT);
+                    if (i < NL) bn[i % NT][i / NT] = load_px(rows[i % NT] ^ (kn << 5), i / NT);
                     if (i >= NM - PER && kk * PER + (i - (NM - PER)) < NT)
-                        pre_n[kk * PER + (i - (NM - PER))] = (PROBE & 4) ? pre[kk * PER + (i - (NM - PER))]
-                                                                         : tap_row(ndy, ndx, kk * PER + (i - (NM - PER)));
+                        pre_n[kk * PER + (i - (NM - PER))] = tap_row(ndy, ndx, kk * PER + (i - (NM - PER)));
                     if (i >= NM - 2)
-                        wf[(kk + W_RING - 1) % W_RING][i - (NM - 2)] =
-                            (PROBE & 2) ? __builtin_bit_cast(V8, wq[(i - (NM - 2)) * W_PART])
-                                        : load_w(step + W_RING - 1, i - (NM - 2));
+                        wf[(kk + W_RING - 1) % W_RING][i - (NM - 2)] = load_w(step + W_RING - 1, i - (NM - 2));
                     if (SHADOW) {
                         // slot fs of 216 in this pass; unit g = fs / 54 of pixel tile j: LDS reads early, the
                         // arithmetic spread over a few slots, the in-place stores late
@@ -748,7 +720,7 @@ __device__ __forceinline__ void pipe_kloop(unsigned char* lds, int row_base, con
     }
 }
 
-template <typename E, bool TUNE_NO_SHADOW = false, int PROBE = 0>
+template <typename E>
 __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
     const E* __restrict__ xh, const E* __restrict__ xl, const E* __restrict__ w1p, const float* __restrict__ b1,
     const E* __restrict__ w2p, const float* __restrict__ b2, E* __restrict__ yh, E* __restrict__ yl, int n_boards,
@@ -855,8 +827,8 @@ __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
         const bool has_next = t + stride < n_boards;
         shd.prev_row_base = ((k - 1) & 1) * IMG_ROWS;
         __builtin_amdgcn_s_setprio(3);
-        if (k > 0 && !TUNE_NO_SHADOW) pipe_kloop<E, true, PROBE>(lds, (k & 1) * IMG_ROWS, wq1, lane, acc, prev, shd);
-        else pipe_kloop<E, false, PROBE>(lds, (k & 1) * IMG_ROWS, wq1, lane, acc, prev, shd);
+        if (k > 0) pipe_kloop<E, true>(lds, (k & 1) * IMG_ROWS, wq1, lane, acc, prev, shd);
+        else pipe_kloop<E, false>(lds, (k & 1) * IMG_ROWS, wq1, lane, acc, prev, shd);
         __builtin_amdgcn_s_setprio(0);
         int ln2 = ln, kb2 = kb;
         asm volatile("" : "+v"(ln2), "+v"(kb2));
@@ -886,7 +858,7 @@ __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
         }
         __syncthreads();                                       // B_k: Y complete (and out(k-1), written during K1)
         __builtin_amdgcn_s_setprio(3);
-        pipe_kloop<E, false, PROBE>(lds, 2 * IMG_ROWS, wq2, lane, acc, prev, shd);
+        pipe_kloop<E, false>(lds, 2 * IMG_ROWS, wq2, lane, acc, prev, shd);
         __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int p = 0; p < NT; ++p) prev[p] = acc[p];
@@ -938,6 +910,7 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_input_conv(
     constexpr int W_STEP = CT * 64;                 // uint4 per (tap, 16-channel group)
     constexpr int W_PART = (25 + 3) * IC16 * W_STEP;
     __shared__ __attribute__((aligned(16))) unsigned char img[IMG];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[PARTS * 90 * C * 2];    // one board of output
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * P;
@@ -946,14 +919,36 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_input_conv(
     {
         const int per_board = in_planes * 90;
         const int nb = n_boards - n0 < P ? n_boards - n0 : P;
-        for (int i = tid; i < nb * per_board; i += NTHR) {
-            const int bb = i / per_board, r = i - bb * per_board;
-            // (compact queue: board n0 + bb of the batch is queue slot rows[n0 + bb])
-            const PT* src = planes + (size_t)(rows ? rows[n0 + bb] : n0 + bb) * per_board - (size_t)bb * per_board;
-            const int c = r / 90, pix = r - c * 90;
+        // the image is all zero: only the occupied squares are written (a position has at most 32 of 1260 planes' bits set)
+        auto put = [&](int bb, int c, int pix, float v) {
             const int row = bb * 90 + pix;
-            *reinterpret_cast<E*>(img + row * RBI + (((c >> 3) ^ ((row / RPB) & (CPRI - 1))) << 4) + (c & 7) * 2) =
-                (E)plane_to_f(src[i]);
+            *reinterpret_cast<E*>(img + row * RBI + (((c >> 3) ^ ((row / RPB) & (CPRI - 1))) << 4) + (c & 7) * 2) = (E)v;
+        };
+        if (sizeof(PT) == 1 && (per_board & 3) == 0) {
+            // byte planes (what the search kernel writes for this network): four squares per load
+            const int wpb = per_board >> 2;
+            for (int i = tid; i < nb * wpb; i += NTHR) {
+                const int bb = i / wpb, w = i - bb * wpb;
+                // (compact queue: board n0 + bb of the batch is queue slot rows[n0 + bb])
+                const uint32_t word = reinterpret_cast<const uint32_t*>(
+                    reinterpret_cast<const unsigned char*>(planes) + (size_t)(rows ? rows[n0 + bb] : n0 + bb) * per_board)[w];
+                if (word == 0u) continue;
+                int c = (w * 4) / 90, pix = w * 4 - c * 90;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned b = (word >> (8 * k)) & 0xFFu;
+                    if (b) put(bb, c, pix, (float)b);
+                    if (++pix == 90) { pix = 0; ++c; }
+                }
+            }
+        } else {
+            for (int i = tid; i < nb * per_board; i += NTHR) {
+                const int bb = i / per_board, r = i - bb * per_board;
+                const PT* src = planes + (size_t)(rows ? rows[n0 + bb] : n0 + bb) * per_board - (size_t)bb * per_board;
+                const int c = r / 90, pix = r - c * 90;
+                const float v = plane_to_f(src[i]);
+                if (v != 0.0f) put(bb, c, pix, v);
+            }
         }
     }
     __syncthreads();
@@ -1021,27 +1016,50 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_input_conv(
     }
     tap_body(24, 0, 0);
 
+    // ---- epilogue: + bias, ReLU, split; one board at a time through an LDS staging image so that HBM sees whole
+    // pixel rows (16 bytes per lane, 1 KiB per wave instruction).  Round 2 stored the accumulators straight from the
+    // MFMA layout -- 8 bytes per lane, 32 different 256-byte rows per instruction -- and the layer ran at 1.5 TB/s:
+    // 94 M sixteen-byte write requests per launch are a request-rate limit, not a bandwidth one.
+    typedef Geom<C, 1, PARTS> GS;                   // staging geometry: [90 pixels][C] per part, chunks swizzled by row
+    constexpr int SROWB = C * 2, SPART = 90 * SROWB;
 #pragma unroll
-    for (int p = 0; p < NT; ++p) {
-        const int q = (p % 3) * 32 + ln;
-        const int n = n0 + p / 3;
-        if (q >= 90 || n >= n_boards) continue;
-        const size_t pix = ((size_t)n * 90 + q) * C;
+    for (int bb = 0; bb < P; ++bb) {
+        if (bb > 0) __syncthreads();                // the previous board has left the staging image
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ch = wave * 32 + g * 8 + kb * 4;
-            const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
-            float v[4] = {acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
-                          acc[p][g * 4 + 3] + bv.w};
-            Quad<E> hi, lo;
+        for (int t = 0; t < 3; ++t) {
+            const int p = bb * 3 + t;
+            const int q = t * 32 + ln;
+            if (q >= 90) continue;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (relu) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
-                hi.e[i] = (E)v[i];
-                lo.e[i] = (E)(v[i] - (float)hi.e[i]);
+            for (int g = 0; g < 4; ++g) {
+                const int ch = wave * 32 + g * 8 + kb * 4;
+                const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
+                float v[4] = {acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
+                              acc[p][g * 4 + 3] + bv.w};
+                Quad<E> hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (relu) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+                    hi.e[i] = (E)v[i];
+                    lo.e[i] = (E)(v[i] - (float)hi.e[i]);
+                }
+                const int off = q * SROWB + (((ch >> 3) ^ (q & GS::SWZ)) << 4) + (ch & 7) * 2;
+                *reinterpret_cast<Quad<E>*>(stage + off) = hi;
+                if (PARTS == 2) *reinterpret_cast<Quad<E>*>(stage + SPART + off) = lo;
             }
-            *reinterpret_cast<Quad<E>*>(yh + pix + ch) = hi;
-            if (PARTS == 2) *reinterpret_cast<Quad<E>*>(yl + pix + ch) = lo;
+        }
+        __syncthreads();
+        const int n = n0 + bb;
+        if (n < n_boards) {
+#pragma unroll
+            for (int part = 0; part < PARTS; ++part) {
+                uint4* dst = reinterpret_cast<uint4*>((part ? yl : yh) + (size_t)n * 90 * C);
+                for (int i = tid; i < 90 * GS::CPR; i += NTHR) {
+                    const int row = i / GS::CPR, chn = i - row * GS::CPR;
+                    dst[i] = *reinterpret_cast<const uint4*>(stage + part * SPART + row * SROWB +
+                                                             ((chn ^ (row & GS::SWZ)) << 4));
+                }
+            }
         }
     }
 }
@@ -1072,12 +1090,12 @@ __global__ __launch_bounds__(256) void k_split_bias_act(const float* __restrict_
     }
 }
 
-template <typename E, int C, int P, int PARTS, int MINW = 1, int DBG = 0>
+template <typename E, int C, int P, int PARTS, int MINW = 1>
 int launch_conv(const void* xh, const void* xl, const void* wp, const float* bias, const void* sh, const void* sl,
                 void* yh, void* yl, float* yf, int n_boards, int relu, hipStream_t st)
 {
     const unsigned blocks = (unsigned)((n_boards + P - 1) / P);
-    hipLaunchKernelGGL((k_conv3x3<E, C, P, PARTS, MINW, DBG>), dim3(blocks), dim3(C / 32 * 64), 0, st, (const E*)xh,
+    hipLaunchKernelGGL((k_conv3x3<E, C, P, PARTS, MINW>), dim3(blocks), dim3(C / 32 * 64), 0, st, (const E*)xh,
                        (const E*)xl, (const E*)wp, bias, (const E*)sh, (const E*)sl, (E*)yh, (E*)yl, yf, n_boards,
                        relu);
     return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
@@ -1305,34 +1323,17 @@ extern "C" int cz_input_conv(const void* planes, int planes_dtype, int in_planes
 }
 
 namespace {
-template <typename E, int C, int PARTS, int P, int DBG = 0, bool HEADS = false>
+template <typename E, int C, int PARTS, int P, bool HEADS = false>
 int launch_resblock(const void* xh, const void* xl, const void* w1, const float* b1, const void* w2, const float* b2,
                     void* yh, void* yl, float* yf, int n, int n_cu, hipStream_t st, HeadArgs hd = HeadArgs{})
 {
     const int tiles = (n + P - 1) / P;
     const unsigned blocks = (unsigned)(tiles < n_cu ? tiles : n_cu);
-    hipLaunchKernelGGL((k_resblock<E, C, PARTS, P, DBG, HEADS>), dim3(blocks), dim3((C / 32 + 4) * 64), 0, st,
+    hipLaunchKernelGGL((k_resblock<E, C, PARTS, P, HEADS>), dim3(blocks), dim3((C / 32 + 4) * 64), 0, st,
                        (const E*)xh, (const E*)xl, (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, yf, n, hd,
                        g_q.n_dev);
     return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
 }
-
-#ifdef CZ_CONV_PROBE
-void print_trace()          // tuning probe (CZ_CONV_VARIANT=308): phase time stamps of workgroup 0, 5th launch
-{
-    static int shots = 0;
-    if (++shots != 5) return;
-    static long long h[64][8];
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h));
-    for (int k = 2; k < 10; ++k) {
-        fprintf(stderr, "rb trace k%2d:", k);
-        for (int ph = 0; ph < 8; ++ph) fprintf(stderr, " %8lld", ph >= 6 ? h[k][ph] : (h[k][ph] - h[2][0]));
-        fprintf(stderr, "\n");
-    }
-}
-
-#endif
 
 int g_resblock_pipelined = 1;       // cz_resblock_pipelined(): 128-filter split blocks on k_resblock_pipe
 
@@ -1345,33 +1346,11 @@ int dispatch_resblock(int channels, int parts, const void* xh, const void* xl, c
         // (operand-pair output: the software-pipelined kernel; the last block of a tower -- fp32 / head output --
         //  stays on k_resblock)
         const unsigned blocks = (unsigned)(n < n_cu ? n : n_cu);
-        if (g_resblock_pipelined == 2)      // tuning only (wrong results): the schedule without the shadowed epilogue
-            hipLaunchKernelGGL((k_resblock_pipe<E, true>), dim3(blocks), dim3(512), 0, st, (const E*)xh, (const E*)xl,
-                               (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, n, g_q.n_dev);
-#ifdef CZ_CONV_PROBE                    // build.py --probe: instruction-mix probes of the K loop (wrong results)
-#define CZ_PIPE_PROBE(M, PB)                                                                                          \
-        else if (g_resblock_pipelined == M)                                                                           \
-            hipLaunchKernelGGL((k_resblock_pipe<E, false, PB>), dim3(blocks), dim3(512), 0, st, (const E*)xh,            \
-                               (const E*)xl, (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, n, g_q.n_dev);
-        CZ_PIPE_PROBE(11, 1) CZ_PIPE_PROBE(12, 2) CZ_PIPE_PROBE(13, 3) CZ_PIPE_PROBE(14, 4) CZ_PIPE_PROBE(17, 7)
-#undef CZ_PIPE_PROBE
-#endif
-        else
-            hipLaunchKernelGGL((k_resblock_pipe<E>), dim3(blocks), dim3(512), 0, st, (const E*)xh, (const E*)xl,
-                               (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, n, g_q.n_dev);
+        hipLaunchKernelGGL((k_resblock_pipe<E>), dim3(blocks), dim3(512), 0, st, (const E*)xh, (const E*)xl,
+                           (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, n, g_q.n_dev);
         return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
     }
     if (channels == 128 && parts == 2) {
-#ifdef CZ_CONV_PROBE          // build.py --probe: ablations (1 = no stores, 2 = no loads) and in-kernel phase time stamps (8)
-        static const int variant = getenv("CZ_CONV_VARIANT") ? atoi(getenv("CZ_CONV_VARIANT")) : 0;
-        if (variant == 301) return launch_resblock<E, 128, 2, 1, 1>(CZ_RB_ARGS);
-        if (variant == 303) return launch_resblock<E, 128, 2, 1, 3>(CZ_RB_ARGS);
-        if (variant == 308) {
-            const int rc = launch_resblock<E, 128, 2, 1, 8>(CZ_RB_ARGS);
-            print_trace();
-            return rc;
-        }
-#endif
         return launch_resblock<E, 128, 2, 1>(CZ_RB_ARGS);
     }
     if (channels == 128 && parts == 1) return launch_resblock<E, 128, 1, 2>(CZ_RB_ARGS);
@@ -1418,10 +1397,10 @@ extern "C" int cz_resblock_heads(const void* x_hi, const void* x_lo, const void*
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (dtype == CZ_BF16)
-        rc = launch_resblock<__bf16, 128, 2, 1, 0, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, nullptr, nullptr,
+        rc = launch_resblock<__bf16, 128, 2, 1, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, nullptr, nullptr,
                                                        nullptr, n_boards, n_cu, st, hd);
     else
-        rc = launch_resblock<_Float16, 128, 2, 1, 0, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, nullptr,
+        rc = launch_resblock<_Float16, 128, 2, 1, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, nullptr,
                                                          nullptr, nullptr, n_boards, n_cu, st, hd);
     if (rc != CZ_OK) czi_set_error("cz_resblock_heads: launch failed");
     return rc;
@@ -1463,7 +1442,7 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
 extern "C" int cz_resblock_pipelined(int enable)
 {
     const int old = g_resblock_pipelined;
-    if (enable >= 0) g_resblock_pipelined = enable > 2 ? 1 : enable;
+    if (enable >= 0) g_resblock_pipelined = enable ? 1 : 0;
     return old;
 }
 

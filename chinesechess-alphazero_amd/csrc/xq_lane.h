@@ -362,115 +362,7 @@ XQ_HD int gen_piece(int p, int s, const Set90& occ, const Set90& own, const Set9
     return out.n;
 }
 
-// ---- two-phase form of gen_piece for the wave-level generator (xq_rules.h::wave_movegen) ---------------------------------
-// plan_piece analyses a piece once -- ray limits and capture squares of a slider, the valid steps of a stepping piece --
-// and returns the move count together with a packed plan; emit_plan writes the moves from the plan without looking at the
-// board again.  Same moves in the same order as gen_piece<true> (tests/lane_harness.cpp::lane_movegen_plan); what it
-// saves is the second evaluation of the rules in the emitting pass (the counting pass and the emitting pass of the
-// ordered compaction are separated by a prefix sum over the pieces).
-struct PiecePlan {
-    int n;
-    uint64_t st;
-};
-
-XQ_HD PiecePlan plan_piece(int p, int s, const Set90& occ, const Set90& own, const Set90& oking)
-{
-    const int x = s % 9, y = s / 9;
-    PiecePlan pl{0, 0ull};
-    if (p == ROOK || p == CANNON) {
-        const uint32_t row = rank_bits(occ, y), col = file_bits(occ, x);
-        uint32_t lm = row & ((1u << x) - 1u), rm = row >> (x + 1);
-        uint32_t dm = col & ((1u << y) - 1u), um = col >> (y + 1);
-        int l = lm ? top_bit(lm) : -1, r = rm ? x + 1 + low_bit(rm) : 9;
-        int d = dm ? top_bit(dm) : -1, u = um ? y + 1 + low_bit(um) : 10;
-        const int ql = l, qr = r, qd = d, qu = u;                     // limits of the quiet moves
-        if (p == CANNON) {                                            // capture: the next blocker beyond each screen
-            if (l > -1) { lm &= ~(1u << l); l = lm ? top_bit(lm) : -1; }
-            if (r < 9) { rm &= rm - 1u; r = rm ? x + 1 + low_bit(rm) : 9; }
-            if (d > -1) { dm &= ~(1u << d); d = dm ? top_bit(dm) : -1; }
-            if (u < 10) { um &= um - 1u; u = um ? y + 1 + low_bit(um) : 10; }
-        }
-        const uint32_t fl = (l > -1 && !has(own, y * 9 + l)) ? 1u : 0u, fr = (r < 9 && !has(own, y * 9 + r)) ? 1u : 0u;
-        const uint32_t fd = (d > -1 && !has(own, d * 9 + x)) ? 1u : 0u, fu = (u < 10 && !has(own, u * 9 + x)) ? 1u : 0u;
-        pl.n = (x - ql - 1) + (qr - x - 1) + (y - qd - 1) + (qu - y - 1) + (int)(fl + fr + fd + fu);
-        const uint32_t lo = (uint32_t)(ql + 1) | ((uint32_t)qr << 4) | ((uint32_t)(qd + 1) << 8) | ((uint32_t)qu << 12) |
-                            ((uint32_t)(l + 1) << 16) | ((uint32_t)r << 20) | ((uint32_t)(d + 1) << 24) | ((uint32_t)u << 28);
-        pl.st = (uint64_t)lo | ((uint64_t)(fl | (fr << 1) | (fd << 2) | (fu << 3)) << 32);
-        return pl;
-    }
-    int fly = -1;                                                     // flying-king capture target, -1 if none
-    if (p == KING) {
-        const uint32_t um = file_bits(occ, x) >> (y + 1);
-        if (um) {
-            const int u = y + 1 + low_bit(um);
-            if (has(oking, u * 9 + x)) fly = u * 9 + x;
-        }
-    }
-    const int nd = step_count_imm(p);
-    const uint64_t codes = step_row(p);
-    uint32_t mask = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma nounroll
-#endif
-    for (int k = 0; k < nd; ++k) {
-        const int code = (int)((codes >> (8 * k)) & 0xFFu);
-        const int dx = (code & 7) - 2, dy = (code >> 3) - 2;
-        const int x_ = x + dx, y_ = y + dy;
-        if (x_ < 0 || x_ > 8 || y_ < 0 || y_ > 9) continue;           // can_move, :323-330
-        const int t = y_ * 9 + x_;
-        if (has(own, t)) continue;
-        if (p == PAWN) {
-            if (y < 5 && x_ != x) continue;                           // :270
-        } else if (p == KNIGHT || p == ELEPHANT) {
-            if (has(occ, (y + dy / 2) * 9 + x + dx / 2)) continue;    // leg / eye
-            if (p == ELEPHANT && y_ > 4) continue;                    // :275
-        } else {                                                      // king, advisor: palace (:277-281)
-            if (x_ < 3 || x_ > 5 || y_ > 2) continue;
-        }
-        mask |= 1u << k;
-    }
-    pl.n = __builtin_popcount(mask) * (fly >= 0 ? 2 : 1);             // the fly move follows every accepted king step
-    pl.st = (uint64_t)mask | (fly >= 0 ? ((uint64_t)(0x80u | (uint32_t)fly) << 8) : 0ull);
-    return pl;
-}
-
-XQ_HD void emit_plan(int p, int s, uint64_t st, uint16_t* lab, uint16_t* ft, int off, bool formula_labels, int cap = MAXMOVES)
-{
-    MoveSink<true> out{lab, ft, off, 0, cap, -1, -1, -1, formula_labels && p != ADVISOR && p != ELEPHANT, 0, 0u};
-    if (out.formula) label_block(s, &out.base, &out.kvalid);
-    const int x = s % 9, y = s / 9;
-    if (p == ROOK || p == CANNON) {
-        const uint32_t w = (uint32_t)st, f = (uint32_t)(st >> 32);
-        const int ql = (int)(w & 15u) - 1, qr = (int)((w >> 4) & 15u), qd = (int)((w >> 8) & 15u) - 1, qu = (int)((w >> 12) & 15u);
-        const int l = (int)((w >> 16) & 15u) - 1, r = (int)((w >> 20) & 15u), d = (int)((w >> 24) & 15u) - 1, u = (int)(w >> 28);
-        const int b0 = out.base, b8 = out.base + 8;
-        for (int t = ql + 1; t < x; ++t) out.put_line(s, y * 9 + t, b0 + t);
-        for (int t = x + 1; t < qr; ++t) out.put_line(s, y * 9 + t, b0 + t - 1);
-        for (int t = qd + 1; t < y; ++t) out.put_line(s, t * 9 + x, b8 + t);
-        for (int t = y + 1; t < qu; ++t) out.put_line(s, t * 9 + x, b8 + t - 1);
-        if (f & 1u) out.put_line(s, y * 9 + l, b0 + l);
-        if (f & 2u) out.put_line(s, y * 9 + r, b0 + r - 1);
-        if (f & 4u) out.put_line(s, d * 9 + x, b8 + d);
-        if (f & 8u) out.put_line(s, u * 9 + x, b8 + u - 1);
-        return;
-    }
-    uint32_t mask = (uint32_t)st & 0xFFu;
-    const int fly = (st & 0x8000ull) ? (int)((st >> 8) & 0x7Full) : -1;
-    const uint64_t codes = step_row(p);
-    const bool ae = formula_labels && (p == ADVISOR || p == ELEPHANT);
-    const uint64_t ae_labs = ae ? ae_label_row(p == ELEPHANT, s) : 0ull;
-    while (mask) {                                                    // the valid steps in table order
-        const int k = low_bit(mask);
-        mask &= mask - 1u;
-        const int code = (int)((codes >> (8 * k)) & 0xFFu);
-        const int t = (y + (code >> 3) - 2) * 9 + x + (code & 7) - 2;
-        if (ae) out.put_labelled(s, t, (uint16_t)((ae_labs >> (16 * k)) & 0xFFFFu));
-        else out.put(s, t);
-        if (fly >= 0) out.put(s, fly);
-    }
-}
-
-// ---- a quad of lanes per piece (prepared for the next round: xq_rules.h::wave_movegen under CZ_MOVEGEN_QUAD) ------------
+// ---- a quad of lanes per piece: the wave-level generator (xq_rules.h::wave_movegen) ------------------------------------
 // Sub-lane q of a piece's quad does a quarter of its work: ray q of a rook / cannon (0 left, 1 right, 2 down, 3 up), steps
 // q and q + 4 of a stepping piece.  Every lane ends up with two segments of the piece's move list: A = the quiet moves of
 // its ray / its step q, B = the capture of its ray / its step q + 4.  The reference's order inside a piece is all A segments

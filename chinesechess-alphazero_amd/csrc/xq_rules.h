@@ -44,26 +44,18 @@ XQ_D void wave_sync()
 }
 XQ_D void wave_sync_global() { __syncthreads(); }
 
-XQ_D int wave_incl_scan(int v, int lane)
+// inclusive prefix sum over the wave's 64 lanes: Kogge-Stone inside each row of 16 lanes with DPP row shifts (a lane
+// without a source adds 0), then the row totals carried across with row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2,
+// 3): six VALU adds, no LDS permute.  (Round 2 ran six __shfl_up steps -- ds_bpermute round trips; this and the quad
+// generator below took the sustained search round from 0.388 to 0.343 ms in the A/B of round 3, all GPU suites bit-exact.)
+XQ_D int wave_incl_scan(int v)
 {
-#ifdef CZ_DPP_SCAN
-    // (prepared, not the default: needs its GPU parity run)  Kogge-Stone inside each row of 16 lanes with DPP row shifts
-    // (a lane without a source adds 0), then the row totals carried across with row_bcast:15 (rows 1, 3) and row_bcast:31
-    // (rows 2, 3): six VALU adds, no LDS permute.
-    (void)lane;
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);     // row_shr:1
     v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);     // row_shr:2
     v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);     // row_shr:4
     v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);     // row_shr:8
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);    // row_bcast:15 -> rows 1 and 3
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);    // row_bcast:31 -> rows 2 and 3
-    return v;
-#endif
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
     return v;
 }
 
@@ -169,25 +161,20 @@ XQ_D int wave_movegen(const int8_t* b, MoveList& ml, uint16_t* plist)
     if (p1 > 0) plist[n_lo + __popcll(own.hi & below)] = (uint16_t)((lane + 64) | (p1 << 8));
     wave_sync();
     int total = 0;
-#ifdef CZ_MOVEGEN_QUAD
-    // (prepared, not the default: validated on the CPU only -- tests/test_lane_cpu.py -- it needs its GPU parity run)
-    // a quad of lanes per piece, 16 pieces per pass: see quad_plan / quad_emit in xq_lane.h
+    // a quad of lanes per piece, 16 pieces per pass (every legal position: one pass): a slider's four rays / a stepper's
+    // steps k and k + 4 on the four lanes of the quad (quad_plan / quad_emit in xq_lane.h), so all 64 lanes work where one
+    // lane per piece kept 16 busy
     for (int base = 0; base < np; base += 16) {
         const int r = lane >> 2, q = lane & 3;
         const bool act = base + r < np;
         const int e = act ? plist[base + r] : 0;
         const int s = e & 0xFF, p = e >> 8;
         const QuadPlan pl = act ? quad_plan(p, s, q, occ, own, oking) : QuadPlan{0, 0, 0u};
-        // the quad's segment sizes on every lane of the quad
+        // the quad's segment sizes on every lane of the quad: DPP quad_perm broadcasts (one VALU move each)
         const int mine = pl.n_a | (pl.n_b << 8);
         int off_a = 0, off_b = 0, sum_a = 0, sum_b = 0;
-#if CZ_MOVEGEN_QUAD >= 2          // quad broadcasts by DPP quad_perm (one VALU move each, no LDS permute)
         const int v4[4] = {__builtin_amdgcn_mov_dpp(mine, 0x00, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(mine, 0x55, 0xF, 0xF, true),
                            __builtin_amdgcn_mov_dpp(mine, 0xAA, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(mine, 0xFF, 0xF, 0xF, true)};
-#else
-        const int v4[4] = {__shfl(mine, (lane & ~3) | 0, 64), __shfl(mine, (lane & ~3) | 1, 64),
-                           __shfl(mine, (lane & ~3) | 2, 64), __shfl(mine, (lane & ~3) | 3, 64)};
-#endif
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int v = v4[k];
@@ -195,22 +182,9 @@ XQ_D int wave_movegen(const int8_t* b, MoveList& ml, uint16_t* plist)
             sum_a += v & 0xFF; sum_b += v >> 8;
         }
         const int n = sum_a + sum_b;
-        const int inc = wave_incl_scan(q == 0 ? n : 0, lane);     // at lane 4 r + q: the pieces up to and including r
+        const int inc = wave_incl_scan(q == 0 ? n : 0);            // at lane 4 r + q: the pieces up to and including r
         const int poff = total + inc - n;
         if (mine) quad_emit(p, s, q, pl, ml.lab, ml.ft, poff + off_a, poff + sum_a + off_b, FORMULA);
-        total += __builtin_amdgcn_readlane(inc, 63);
-    }
-    wave_sync();
-    return total;
-#endif
-    for (int base = 0; base < np; base += 64) {   // one pass for every legal position (<= 16 pieces)
-        const bool act = base + lane < np;
-        const int e = act ? plist[base + lane] : 0;
-        const int s = e & 0xFF, p = e >> 8;
-        const PiecePlan pl = act ? plan_piece(p, s, occ, own, oking) : PiecePlan{0, 0ull};
-        const int c = pl.n;
-        const int inc = wave_incl_scan(c, lane);
-        if (c) emit_plan(p, s, pl.st, ml.lab, ml.ft, total + inc - c, FORMULA);
         total += __builtin_amdgcn_readlane(inc, 63);
     }
     wave_sync();

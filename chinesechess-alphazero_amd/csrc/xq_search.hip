@@ -1441,8 +1441,8 @@ __global__ __launch_bounds__(256) void k_noise(SearchParams P, SearchBuffers B)
                             + ((size_t)((uint32_t)root & (uint32_t)(CHUNK_GRANULES - 1)) << 4);
         nm = (int)(*reinterpret_cast<const uint32_t*>(rbase + NODE_OFF_HDR + 4) & 0xFF);
     } else {
-        // the root position is in g_board: count its moves like wave_movegen does (three ballot sets, plan_piece per
-        // piece), without the lists.  Wave 0 only; the other waves wait at the barrier.
+        // the root position is in g_board: count its moves from wave_movegen's three ballot sets (gen_piece's counting
+        // form, one or two squares per lane), without the lists.  Wave 0 only; the other waves wait at the barrier.
         if (tid < 64) {
             const int8_t* gb = B.g_board + (size_t)g * BOARD_LDS;
             const int p0 = gb[tid];
@@ -1451,8 +1451,8 @@ __global__ __launch_bounds__(256) void k_noise(SearchParams P, SearchBuffers B)
             const Set90 own{__ballot(p0 > 0), __ballot(p1 > 0)};
             const Set90 oking{__ballot(p0 == -KING), __ballot(p1 == -KING)};
             int c = 0;
-            if (p0 > 0) c += plan_piece(p0, tid, occ, own, oking).n;
-            if (p1 > 0) c += plan_piece(p1, tid + 64, occ, own, oking).n;
+            if (p0 > 0) c += gen_piece<false>(p0, tid, occ, own, oking, nullptr, nullptr, 0);
+            if (p1 > 0) c += gen_piece<false>(p1, tid + 64, occ, own, oking, nullptr, nullptr, 0);
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
             if (tid == 0) s_nm = c < MAXMOVES ? c : MAXMOVES;      // (expand_node caps the list the same way)

@@ -8,12 +8,11 @@
 #pragma once
 #include "xq_lane.h"
 
-#ifndef CZ_TPB_FORMULA
-#define CZ_TPB_FORMULA true       // labels by arithmetic from the per-square block (xq_lane.h::label_in_block): 3.28 TB/s on
-                                  // the 1 M-board micro-suite against 3.07 with the (from, to) table gather (false)
-#endif
-
 namespace xq {
+
+// labels by arithmetic from the per-square block (xq_lane.h::label_in_block): 3.28 TB/s on the 1 M-board micro-suite
+// against 3.07 with the (from, to) table gather; both forms are checked against the oracle on the CPU (test_lane_cpu.py)
+constexpr bool TPB_FORMULA_LABELS = true;
 
 XQ_HD uint64_t rev64(uint64_t v)
 {
@@ -139,7 +138,7 @@ XQ_HD void tpb_type_pass(const TypeLists& tl, const BoardSets& t, PieceCounts& p
             pc.set(r, (uint32_t)gen_piece<false>(TYPE, s, t.occ, t.own, t.oking, nullptr, nullptr, 0));
         } else {
             int h = -1, hf = -1;
-            gen_piece<true>(TYPE, s, t.occ, t.own, t.oking, lab, nullptr, (int)pc.get(r), watch, &h, CZ_TPB_FORMULA, cap, &hf);
+            gen_piece<true>(TYPE, s, t.occ, t.own, t.oking, lab, nullptr, (int)pc.get(r), watch, &h, TPB_FORMULA_LABELS, cap, &hf);
             if (h >= 0 && (*hit < 0 || h < *hit)) { *hit = h; *hit_from = hf; }   // first in LIST order, not in type order
         }
     }
@@ -168,7 +167,7 @@ XQ_HD int tpb_movegen_generic(const int8_t* b, const BoardSets& t, uint16_t* lab
         const int s = first_sq(rest);
         if (s < 0) break;
         if (s < 64) rest.lo &= rest.lo - 1; else rest.hi &= rest.hi - 1;
-        n += gen_piece<true>(b[s], s, t.occ, t.own, t.oking, lab, nullptr, n, watch, hit, CZ_TPB_FORMULA, cap, hit_from);
+        n += gen_piece<true>(b[s], s, t.occ, t.own, t.oking, lab, nullptr, n, watch, hit, TPB_FORMULA_LABELS, cap, hit_from);
     }
     return n;
 }

@@ -287,9 +287,29 @@ int cz_split_bias_act(const float* x, const float* bias, void* y_hi, void* y_lo,
 int cz_head_convs(const void* x, int dtype, const float* w, const float* bias, float* policy_feat, float* value_feat,
                   int n_boards, int channels, int n_policy, int n_value, void* stream);
 
+/* The dense tail of both heads (agent/model.py:58-59 and :64-66: Flatten -> Dense(2086, softmax); Flatten -> Dense(256,
+ * relu) -> Dense(1, tanh)) on the head features cz_head_convs / cz_resblock_heads produce, in three launches of
+ * hand-written kernels (csrc/xq_heads.hip: split-bf16 MFMA GEMM tiles of 64 positions with the softmax statistics
+ * kept per lane, one normalising pass, the value head with its hidden layer in the accumulators).
+ *   policy_feat[n][n_policy_feat], value_feat[n][n_value_feat]   fp32 (at most 384 features each)
+ *   wp_packed / w1_packed    cz_fc_pack_weights() of the [n_labels][n_policy_feat] / [n_hidden][n_value_feat] matrices
+ *   bias_p[n_labels], bias1[n_hidden], w2[n_hidden], b2          fp32 (n_labels even)
+ *   policy[n][n_labels] (softmax), value[n] (tanh)               fp32 outputs
+ *   stats_scratch            DEVICE scratch of 2 * n_boards floats (the rows' max / sum of exp between the launches)
+ *   n_dev                    NULL, or the DEVICE int32 count of the compact evaluation queue: only the first
+ *                            min(*n_dev, n_boards) rows are computed and written
+ * Precision: operands as (hi, lo) bf16 pairs, three MFMAs per product, fp32 accumulation -- the tower's arithmetic. */
+int cz_heads_tail(const float* policy_feat, int n_policy_feat, const void* wp_packed, const float* bias_p,
+                  int n_labels, const float* value_feat, int n_value_feat, const void* w1_packed, const float* bias1,
+                  int n_hidden, const float* w2, float b2, float* policy, float* value, float* stats_scratch,
+                  int n_boards, const int32_t* n_dev, void* stream);
+/* number of 2-byte elements of a packed dense layer (0 = bad argument); HOST: w[n_out][n_in] fp32 -> fragment order */
+size_t cz_fc_packed_elems(int n_out, int n_in);
+int cz_fc_pack_weights(const float* w, int n_out, int n_in, void* out_host);
+
 /* test hook: out[n] (DEVICE, float64) = n draws of the root noise np.random.dirichlet(alpha * ones(n_moves))[0]
- * (agent/player.py:304) from the generator the search kernel uses (k_noise: Philox4x32-10 stream keyed by seed /
- * game_key, float32 Marsaglia-Tsang Gamma draws) */
+ * (agent/player.py:304) from the generator the search kernel uses (k_noise; csrc/xq_noise.h: counter-based integer
+ * hash keyed by seed / game_key, float32 Marsaglia-Tsang Gamma draws) */
 int cz_debug_noise(uint64_t seed, uint32_t game_key, double alpha, int n_moves, double* out, int n, void* stream);
 /* test hook: y[i] = sqrt((double)(x[i] + 1)) exactly as the PUCT kernel computes it */
 int cz_debug_sqrt(const int32_t* x, double* y, int n, void* stream);

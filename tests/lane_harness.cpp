@@ -31,28 +31,8 @@ int lane_movegen(const int8_t* board, uint16_t* lab, uint16_t* ft)
     return off;
 }
 
-// the same through plan_piece / emit_plan (what wave_movegen runs); formula: labels by arithmetic
-int lane_movegen_plan(const int8_t* board, uint16_t* lab, uint16_t* ft, int formula)
-{
-    Set90 occ{0, 0}, own{0, 0}, oking{0, 0};
-    auto set = [](Set90& m, int s) { if (s < 64) m.lo |= 1ull << s; else m.hi |= 1ull << (s - 64); };
-    for (int s = 0; s < NSQ; ++s) {
-        if (board[s] != 0) set(occ, s);
-        if (board[s] > 0) set(own, s);
-        if (board[s] == -KING) set(oking, s);
-    }
-    int off = 0;
-    for (int s = 0; s < NSQ; ++s) {
-        if (board[s] <= 0) continue;
-        const PiecePlan pl = plan_piece(board[s], s, occ, own, oking);
-        if (pl.n != gen_piece<false>(board[s], s, occ, own, oking, nullptr, nullptr, 0)) return -1;
-        if (pl.n) emit_plan(board[s], s, pl.st, lab, ft, off, formula != 0);
-        off += pl.n;
-    }
-    return off;
-}
-
-// the quad-of-lanes generator (quad_plan / quad_emit): the cross-lane sums of wave_movegen emulated with loops
+// the quad-of-lanes generator (quad_plan / quad_emit: what wave_movegen runs); the cross-lane sums of the wave emulated
+// with loops; formula: labels by arithmetic
 int lane_movegen_quad(const int8_t* board, uint16_t* lab, uint16_t* ft, int formula)
 {
     Set90 occ{0, 0}, own{0, 0}, oking{0, 0};

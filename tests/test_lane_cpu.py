@@ -45,8 +45,8 @@ def test_movegen_and_planes(harness, positions_1k):
         assert (pl.reshape(14, 10, 9) == xo.planes_board(b)).all()
 
 
-def test_plan_emit_movegen_matches_the_oracle(harness, positions_1k):
-    """plan_piece / emit_plan (the two-phase generator of wave_movegen) on the golden suite and on a few thousand
+def test_quad_movegen_matches_the_oracle(harness, positions_1k):
+    """quad_plan / quad_emit (the quad-of-lanes generator of wave_movegen) on the golden suite and on a few thousand
     oracle playout positions, labels from the table and by arithmetic."""
     lab = np.zeros(160, dtype=np.uint16)
     ft = np.zeros(160, dtype=np.uint16)
@@ -62,20 +62,20 @@ def test_plan_emit_movegen_matches_the_oracle(harness, positions_1k):
             b, _ = xo.step_board(b, int(mv[rng.integers(len(mv))]))
     for b in boards:
         exp = xo.legal_moves_board(b)
-        for gen in (harness.lane_movegen_plan, harness.lane_movegen_quad):      # (the quad form: prepared for CZ_MOVEGEN_QUAD)
+        for gen in (harness.lane_movegen_quad,):
             for formula in (0, 1):
                 n = gen(b.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p),
                         ft.ctypes.data_as(C.c_void_p), formula)
                 assert n == len(exp) and (lab[:n] == exp).all(), (formula, xo.board_to_state(b))
         n = harness.lane_movegen(b.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p), ft.ctypes.data_as(C.c_void_p))
         ft_ref = ft[:n].copy()
-        harness.lane_movegen_plan(b.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p), ft.ctypes.data_as(C.c_void_p), 1)
+        harness.lane_movegen_quad(b.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p), ft.ctypes.data_as(C.c_void_p), 1)
         assert (ft[:n] == ft_ref).all()
 
 
-def test_file_bits_and_plan_on_arbitrary_boards(harness):
-    """file_bits against its definition on random square sets; plan / emit against gen_piece on boards no game reaches
-    (any piece on any square, up to 40 pieces of the mover)."""
+def test_file_bits_and_quad_on_arbitrary_boards(harness):
+    """file_bits against its definition on random square sets; the quad generator against gen_piece on boards no game
+    reaches (any piece on any square, up to 40 pieces of the mover)."""
     harness.lane_file_bits_mismatches.argtypes = [C.c_uint64, C.c_int]
     assert harness.lane_file_bits_mismatches(12345, 20000) == 0
     rng = np.random.default_rng(3)
@@ -92,7 +92,7 @@ def test_file_bits_and_plan_on_arbitrary_boards(harness):
         n = harness.lane_movegen(vp(b), vp(lab), vp(ft))
         if n > 128:
             continue
-        for gen in (harness.lane_movegen_plan, harness.lane_movegen_quad):
+        for gen in (harness.lane_movegen_quad,):
             for formula in (0, 1):
                 n2 = gen(vp(b), vp(lab2), vp(ft2), formula)
                 assert n2 == n, (formula, b.tolist())

@@ -1,6 +1,6 @@
 #!/bin/bash
-# A/B of the residual-block schedules inside the normal bench: CZ_RESBLOCK_MODE = 0 plain, 1 pipelined, 2.. timing probes
-# (--probe build).  usage: bash tools/ab_resblock.sh "1 0 2 3"
+# A/B of the two (bit-identical) residual-block schedules inside the normal bench: CZ_RESBLOCK_MODE = 0 plain (k_resblock),
+# 1 pipelined (k_resblock_pipe).  usage: bash tools/ab_resblock.sh "1 0 1 0"
 export TMPDIR=/tmp
 for v in $1; do
   CZ_RESBLOCK_MODE=$v timeout 200 python bench.py --steps 30 --warmup 6 --sustained-rounds 0 --no-micro --no-cpu-baseline 2>/dev/null > /tmp/ab_$v.json

@@ -3,8 +3,8 @@
 
     python tools/conv_probe.py [--n 32768] [--channels 128] [--out gpurun_out/conv_probe.json]
 
-The ablation / in-kernel trace variants (CZ_CONV_VARIANT=301|303|308) exist only in a probe build of the library:
-    python chinesechess-alphazero_amd/build.py --probe
+(The ablation / in-kernel time-stamp variants this script once drove were tuning aids that computed wrong results; they
+were removed from csrc/xq_conv.hip in round 3 -- what they measured is recorded in DESIGN.md section 7b.)
 """
 import argparse
 import json
