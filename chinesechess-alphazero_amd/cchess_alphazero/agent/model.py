@@ -115,7 +115,9 @@ class InferenceNet(nn.Module):
         self.fused_epilogue = True          # on the GPU: hand-written bias + skip + ReLU pass after each conv
         self.fused_blocks = True            # trunk="mfma", fp32, 128 filters: one launch per residual block
         self.fused_heads = True             # ... and the 1x1 head convolutions folded into the last block's store pass
-        self.fused_tail = True              # dense layers + softmax / tanh on the hand-written kernels (csrc/xq_heads.hip)
+        # dense layers + softmax / tanh on the hand-written kernels (csrc/xq_heads.hip); CZ_FUSED_TAIL=0: the hipBLASLt /
+        # PyTorch tail they replace (A/B runs)
+        self.fused_tail = os.environ.get("CZ_FUSED_TAIL", "1") != "0"
         self.block_events = None            # bench.py: list collecting (start, end) HIP events around tower launches
         self.input_depth = net.cfg["input_depth"]
         self.filters = net.cfg["cnn_filter_num"]
@@ -217,7 +219,7 @@ class InferenceNet(nn.Module):
                            rows=rows, count=count)
         nblk = len(self.res)
         # whole residual block in one launch where k_resblock exists for the shape
-        fused = self.fused_blocks and ((c == 128) or (c in (192, 256) and self.parts == 1))
+        fused = self.fused_blocks and ((c in (128, 192)) or (c == 256 and self.parts == 1))
         for i in range(nblk):
             w1 = getattr(self, f"tw{i}a").view(self.operand_dtype)
             w2 = getattr(self, f"tw{i}b").view(self.operand_dtype)
@@ -276,8 +278,8 @@ class InferenceNet(nn.Module):
 
     def supports_compact_queue(self):
         """True when the whole convolutional part runs on the hand-written kernels that take the board count from the
-        device (cz_*_q): 128-filter tower on the fused residual-block kernel, 4 + 2 head filters."""
-        return (self.trunk == "mfma" and self.fused_blocks and self.filters == 128 and
+        device (cz_*_q): 128- or 192-filter tower on the fused residual-block kernels, 6 head filters."""
+        return (self.trunk == "mfma" and self.fused_blocks and self.filters in (128, 192) and
                 getattr(self, "head_w32", torch.empty(0)).shape[0] == 6)
 
     @torch.no_grad()
@@ -303,7 +305,7 @@ class InferenceNet(nn.Module):
                                         rows=rows, count=count)
                 if last is not None:
                     _native.head_convs(last, self.head_w32, self.head_b32, npol, pf, vf)
-                if self.fused_tail and pf.shape[1] <= 384 and vf.shape[1] <= 384:
+                if self.fused_tail and pf.shape[1] in (180, 360) and vf.shape[1] in (180, 360):
                     # dense layers + softmax / tanh: three launches of hand-written kernels, straight into `out`
                     if out is None:
                         out = (torch.empty((n, self.policy_out.out_features), dtype=torch.float32, device=planes.device),

@@ -168,9 +168,12 @@ __device__ __forceinline__ void zero_rows_write(unsigned char* region, int gtid)
 // The K loop: 9 taps x C input channels for the 32 output channels of this wave and all NT pixel tiles of the
 // LDS image.  acc[p][r] <-> pixel (p % 3) * 32 + (lane & 31) of board p / 3,
 //                          channel 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+//   row_base / zrow / part_bytes: where the image's first row, the 16 zero rows and the second operand part are, for
+//   kernels whose images share one LDS allocation (k_resblock_ip); the defaults are the self-contained layout of Geom.
 template <typename E, int C, int P, int PARTS>
 __device__ __forceinline__ void conv_kloop(const unsigned char* region, const uint4* wq, int lane,
-                                           f32x16* acc)
+                                           f32x16* acc, int row_base = 0, int zrow = Geom<C, P, PARTS>::ZROW,
+                                           int part_bytes = Geom<C, P, PARTS>::PART_BYTES)
 {
     typedef Geom<C, P, PARTS> G;
     typedef typename Mfma<E>::V8 V8;
@@ -191,8 +194,9 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
         const int t = p % 3;
         const bool ok = (unsigned)(qy[t] + dy) < 10u && (unsigned)(qx[t] + dx) < 9u;
         const int nominal = (p / 3) * 90 + t * 32 + ln + dy * 9 + dx;
-        const int row = ok ? nominal : G::ZROW + (nominal & 15);
-        return row * G::RB + (((kb ^ row) & G::SWZ) << 4);
+        const int row = ok ? row_base + nominal : zrow + (nominal & 15);
+        // (swizzle key = the image-relative row; zrow is a multiple of 16, so a zero row keys like the row it stands for)
+        return row * G::RB + (((kb ^ nominal) & G::SWZ) << 4);
     };
     V8 wf[W_RING][PARTS];
     V8 px[2][NT][PARTS];
@@ -205,7 +209,7 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
         return __builtin_bit_cast(V8, wq[(size_t)part * G::W_PART + (size_t)step * G::W_STEP]);
     };
     auto load_px = [&](int off, int part) {
-        return __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(region + part * G::PART_BYTES + off));
+        return __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(region + part * part_bytes + off));
     };
 
 #pragma unroll
@@ -877,6 +881,201 @@ __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
     __syncthreads();                                           // E2
 }
 
+// ---- kernel 2c: the residual block with split operands where three LDS images do not fit (192 filters) --------------
+// The reference's deployed topology is 10 x 192 (configs/distribute.py:84-87, data/model/model_192x10_config.json).
+// With split operands a 192-filter image is 90 rows x 384 B x 2 parts = 69 KB: X + Y + a staging image (k_resblock) or
+// X even + X odd + Y (k_resblock_pipe) need 207 KB, the CU has 160.  This kernel keeps TWO images -- X and Y, 16 zero
+// rows shared by both, the bias vectors: 152 KB -- and gives up the overlap that the third image buys:
+//   matrix waves (6, 32 output channels each):  A | K1 on X | epi1 -> Y | B | K2 on Y | epi2: + b2 + skip, ReLU, re-split,
+//                                               written IN PLACE over the skip operand in X | C |
+//   copy waves (2):                             A | prefetch the next board into registers       | B | C | drain X to
+//                                               HBM (16 B per lane, whole rows) and refill it with the prefetched board
+// so HBM sees one read of x and one write of y per block (two launches of k_conv3x3 read x twice -- operand and skip --
+// and round-trip the intermediate activation, with 8-byte scattered stores), and the matrix waves wait only for the
+// drain + refill of one image (LDS <-> registers; the HBM latency of the prefetch is under the K loops).
+// Same K loop (conv_kloop) and the same epilogue arithmetic in the same order as k_conv3x3: bit-identical to two
+// cz_conv3x3 launches.  The last block of a tower writes fp32 (y_f32) straight from the accumulators' epilogue instead.
+namespace ip {
+constexpr int ROW_Y = 90, ROW_Z = 192, ROWS = ROW_Z + 16, COPY_THREADS = 128;       // (ROW_Z: a multiple of 16)
+}
+
+template <typename E, int C>
+__global__ __launch_bounds__((C / 32) * 64 + ip::COPY_THREADS, 1) void k_resblock_ip(
+    const E* __restrict__ xh, const E* __restrict__ xl, const E* __restrict__ w1p, const float* __restrict__ b1,
+    const E* __restrict__ w2p, const float* __restrict__ b2, E* __restrict__ yh, E* __restrict__ yl,
+    float* __restrict__ yf, int n_boards, const int32_t* __restrict__ n_dev)
+{
+    typedef Geom<C, 1, 2> G;
+    constexpr int RB = G::RB, CPR = G::CPR, CT = G::CT, NT = 3;
+    constexpr int PSTR = ip::ROWS * RB;                         // bytes per operand part
+    constexpr int BIAS_OFF = 2 * PSTR;
+    constexpr int CTHR = ip::COPY_THREADS, CHUNKS = 90 * CPR, LITER = (CHUNKS + CTHR - 1) / CTHR;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BIAS_OFF + 2 * C * 4];
+    static_assert(sizeof(lds) <= 160 * 1024, "two images + zero rows must fit the CU's LDS");
+    if (n_dev) {
+        const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
+        n_boards = nd < n_boards ? nd : n_boards;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int stride = gridDim.x;
+    int t = blockIdx.x;
+    if (t >= n_boards) return;
+    // chunk i of a board (row i / CPR, chunk i % CPR) in the X image
+    auto chunk_off = [&](int i) {
+        const int row = i / CPR, ch = i - row * CPR;
+        return row * RB + ((ch ^ (row & G::SWZ)) << 4);
+    };
+
+    if (wave >= CT) {                                           // ---- copy waves ----
+        const int ctid = tid - CT * 64;
+        uint4 v[2][LITER];
+        auto fetch = [&](int board) {
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const uint4* src = reinterpret_cast<const uint4*>((part ? xl : xh) + (size_t)board * 90 * C);
+#pragma unroll
+                for (int it = 0; it < LITER; ++it) {
+                    const int i = it * CTHR + ctid;
+                    v[part][it] = make_uint4(0, 0, 0, 0);
+                    if ((it + 1) * CTHR <= CHUNKS || i < CHUNKS) v[part][it] = src[i];
+                }
+            }
+        };
+        auto put = [&]() {
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+#pragma unroll
+                for (int it = 0; it < LITER; ++it) {
+                    const int i = it * CTHR + ctid;
+                    if ((it + 1) * CTHR <= CHUNKS || i < CHUNKS)
+                        *reinterpret_cast<uint4*>(lds + part * PSTR + chunk_off(i)) = v[part][it];
+                }
+        };
+        // the block's result sits in X (operand layout): to HBM; the same chunks then take the prefetched board
+        auto drain = [&](int board, bool refill) {
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                uint4* dst = reinterpret_cast<uint4*>((part ? yl : yh) + (size_t)board * 90 * C);
+#pragma unroll
+                for (int it = 0; it < LITER; ++it) {
+                    const int i = it * CTHR + ctid;
+                    if (!((it + 1) * CTHR <= CHUNKS || i < CHUNKS)) continue;
+                    unsigned char* a = lds + part * PSTR + chunk_off(i);
+                    if (!yf) dst[i] = *reinterpret_cast<const uint4*>(a);
+                    if (refill) *reinterpret_cast<uint4*>(a) = v[part][it];
+                }
+            }
+        };
+        fetch(t);
+        put();
+        for (int i = ctid; i < 16 * CPR; i += CTHR) {           // the shared zero rows, both parts
+            *reinterpret_cast<uint4*>(lds + ip::ROW_Z * RB + i * 16) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(lds + PSTR + ip::ROW_Z * RB + i * 16) = make_uint4(0, 0, 0, 0);
+        }
+        for (int i = ctid; i < C; i += CTHR) {
+            reinterpret_cast<float*>(lds + BIAS_OFF)[i] = b1[i];
+            reinterpret_cast<float*>(lds + BIAS_OFF)[C + i] = b2[i];
+        }
+        for (;;) {
+            __syncthreads();                                    // A: X holds board t
+            const int tn = t + stride;
+            const bool has_next = tn < n_boards;
+            if (has_next) fetch(tn);
+            __syncthreads();                                    // B: Y complete
+            __syncthreads();                                    // C: the result is in X
+            drain(t, has_next);
+            if (!has_next) break;
+            t = tn;
+        }
+        return;
+    }
+
+    // ---- matrix waves ----
+    const uint4* wq1 = reinterpret_cast<const uint4*>(w1p) + wave * 64 + lane;
+    const uint4* wq2 = reinterpret_cast<const uint4*>(w2p) + wave * 64 + lane;
+    const int kb = lane >> 5, ln = lane & 31;
+    const float* bias1 = reinterpret_cast<const float*>(lds + BIAS_OFF);
+    const float* bias2 = bias1 + C;
+    for (;;) {
+        __syncthreads();                                        // A
+        const bool has_next = t + stride < n_boards;
+        f32x16 acc[NT];
+        __builtin_amdgcn_s_setprio(3);
+        conv_kloop<E, C, 1, 2>(lds, wq1, lane, acc, 0, ip::ROW_Z, PSTR);
+        __builtin_amdgcn_s_setprio(0);
+        int ln2 = ln, kb2 = kb;
+        asm volatile("" : "+v"(ln2), "+v"(kb2));
+        // epilogue 1: relu(acc + b1) -> (hi, lo) -> Y image (operand layout of the second convolution)
+#pragma unroll
+        for (int p = 0; p < NT; ++p) {
+            const int q = p * 32 + ln2;
+            if (q < 90) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = wave * 32 + g * 8 + kb2 * 4;
+                    const float4 bv = *reinterpret_cast<const float4*>(bias1 + ch);
+                    const float vv[4] = {acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
+                                         acc[p][g * 4 + 3] + bv.w};
+                    Quad<E> hi, lo;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float r = vv[i] > 0.0f ? vv[i] : 0.0f;
+                        hi.e[i] = (E)r;
+                        lo.e[i] = (E)(r - (float)hi.e[i]);
+                    }
+                    const int off = (ip::ROW_Y + q) * RB + (((ch >> 3) ^ (q & G::SWZ)) << 4) + (ch & 7) * 2;
+                    *reinterpret_cast<Quad<E>*>(lds + off) = hi;
+                    *reinterpret_cast<Quad<E>*>(lds + PSTR + off) = lo;
+                }
+            }
+        }
+        __syncthreads();                                        // B: Y complete
+        __builtin_amdgcn_s_setprio(3);
+        conv_kloop<E, C, 1, 2>(lds, wq2, lane, acc, ip::ROW_Y, ip::ROW_Z, PSTR);
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("" : "+v"(ln2), "+v"(kb2));
+        // epilogue 2: relu(acc + b2 + x) -> (hi, lo) in place over the skip operand (each lane reads and writes only its own
+        // 8 bytes of each part), or fp32 straight to HBM for the last block of a tower
+#pragma unroll
+        for (int p = 0; p < NT; ++p) {
+            const int q = p * 32 + ln2;
+            if (q < 90) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = wave * 32 + g * 8 + kb2 * 4;
+                    const float4 bv = *reinterpret_cast<const float4*>(bias2 + ch);
+                    const int off = q * RB + (((ch >> 3) ^ (q & G::SWZ)) << 4) + (ch & 7) * 2;
+                    const Quad<E> sh = *reinterpret_cast<const Quad<E>*>(lds + off);
+                    const Quad<E> sl = *reinterpret_cast<const Quad<E>*>(lds + PSTR + off);
+                    float vv[4] = {acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
+                                   acc[p][g * 4 + 3] + bv.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) vv[i] += (float)sh.e[i];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) vv[i] += (float)sl.e[i];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) vv[i] = vv[i] > 0.0f ? vv[i] : 0.0f;
+                    if (yf) {
+                        *reinterpret_cast<float4*>(yf + ((size_t)t * 90 + q) * C + ch) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    } else {
+                        Quad<E> hi, lo;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            hi.e[i] = (E)vv[i];
+                            lo.e[i] = (E)(vv[i] - (float)hi.e[i]);
+                        }
+                        *reinterpret_cast<Quad<E>*>(lds + off) = hi;
+                        *reinterpret_cast<Quad<E>*>(lds + PSTR + off) = lo;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                        // C: the result is in X
+        if (!has_next) break;
+        t += stride;
+    }
+}
+
 // ---- kernel 3: the input convolution (5x5, 14 or 28 feature planes -> C channels) ----------------------------------
 // Reference: Conv2D(F, 5, padding="same") -> BatchNorm -> ReLU on the state_to_planes input (agent/model.py:36-39).
 // The planes arrive exactly as the search kernel writes them ([in_planes][10][9] per board, values 0 / 1, any of
@@ -1353,6 +1552,12 @@ int dispatch_resblock(int channels, int parts, const void* xh, const void* xl, c
     if (channels == 128 && parts == 2) {
         return launch_resblock<E, 128, 2, 1>(CZ_RB_ARGS);
     }
+    if (channels == 192 && parts == 2) {
+        const unsigned blocks = (unsigned)(n < n_cu ? n : n_cu);
+        hipLaunchKernelGGL((k_resblock_ip<E, 192>), dim3(blocks), dim3(192 / 32 * 64 + ip::COPY_THREADS), 0, st,
+                           (const E*)xh, (const E*)xl, (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, yf, n, g_q.n_dev);
+        return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
+    }
     if (channels == 128 && parts == 1) return launch_resblock<E, 128, 1, 2>(CZ_RB_ARGS);
     if (channels == 192 && parts == 1) return launch_resblock<E, 192, 1, 1>(CZ_RB_ARGS);
     if (channels == 256 && parts == 1) return launch_resblock<E, 256, 1, 1>(CZ_RB_ARGS);
@@ -1430,7 +1635,7 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
         rc = dispatch_resblock<_Float16>(channels, parts, x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo,
                                          y_f32, n_boards, n_cu, st);
     if (rc == CZ_ERR_ARG)
-        czi_set_error("cz_resblock: supported: 128 filters (split or plain operands), 192 / 256 filters (plain), bf16 / f16; "
+        czi_set_error("cz_resblock: supported: 128 / 192 filters (split or plain operands), 256 filters (plain), bf16 / f16; "
                       "use cz_conv3x3 otherwise");
     else if (rc != CZ_OK)
         czi_set_error("cz_resblock: launch failed");

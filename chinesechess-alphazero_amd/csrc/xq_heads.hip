@@ -53,9 +53,21 @@ struct FcArgs {
     float* value;             // [n]
 };
 
-template <int MODE>
+// F: features per position (180 or 360: 2 or 4 head filters x 90 squares; compile-time so that the staging loop divides
+// by a constant and the K loop unrolls around a weight ring)
+// exp for the running softmax statistics: v_exp_f32 (2^x) on x * log2(e) -- 2 instructions instead of libm's ~25; the
+// statistics only scale the row (relative error ~1e-6 of the sum), the probabilities themselves are formed with expf in
+// k_policy_normalize.  Half of this kernel's issue slots went to libm exps before (0.277 -> see profiles/r03_*).
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
+template <int MODE, int F>
 __global__ __launch_bounds__(FC_THREADS) void k_fc_tile(FcArgs a, int n, const int32_t* __restrict__ n_dev)
 {
+    constexpr int KS = (F + 15) / 16;                 // K-steps
+    constexpr int RB = KS * 32 + 16;                  // bytes per position row of the feature image; RB / 16 is odd, so
+    constexpr int PART = TILE_ROWS * RB;              // the 16 lanes of a ds_read_b128 group (16 consecutive positions, same
+    constexpr int RING = 6;                           // chunk) fall on 16 different 16-byte slots of the 256-byte bank row
+    static_assert(F % 4 == 0 && KS <= FC_MAX_KSTEPS, "whole float4s per row");
     __shared__ __attribute__((aligned(16))) unsigned char lds[FC_LDS_BYTES];
     if (n_dev) {
         const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
@@ -64,25 +76,38 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_tile(FcArgs a, int n, const i
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ln = lane & 31, kb = lane >> 5;
     const int bt = wave & 1, lq = wave >> 1;
-    // feature image: [part][64 positions][RB bytes]; RB / 16 is odd, so the 16 lanes of a ds_read_b128 group (16
-    // consecutive positions, same chunk) fall on 16 different 16-byte slots of the 256-byte bank row
-    const int RB = a.ksteps * 32 + 16;
-    const int PART = TILE_ROWS * RB;
     float* red = reinterpret_cast<float*>(lds + FC_LDS_BYTES - 2 * 256 * (int)sizeof(float));   // [2 values][2 position tiles][4 wave classes][32]
     const int n_row_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
+    struct alignas(8) Q4 { __bf16 e[4]; };
     for (int rt = blockIdx.x; rt < n_row_tiles; rt += gridDim.x) {
         const int row0 = rt * TILE_ROWS;
-        // ---- stage the tile's features as (hi, lo) bf16, zero-padded in K and in rows ----
-        const int kpad = a.ksteps * 16;
-        for (int i = tid; i < TILE_ROWS * kpad; i += FC_THREADS) {
-            const int r = i / kpad, k = i - r * kpad;
-            float v = 0.0f;
-            if (k < a.F && row0 + r < n) v = a.feat[(size_t)(row0 + r) * a.F + k];
-            const __bf16 hi = (__bf16)v;
-            const __bf16 lo = (__bf16)(v - (float)hi);
-            const int off = r * RB + k * 2;
-            *reinterpret_cast<__bf16*>(lds + off) = hi;
-            *reinterpret_cast<__bf16*>(lds + PART + off) = lo;
+        // ---- stage the tile's features as (hi, lo) bf16: the tile is one contiguous block of 64 x F floats ----
+        {
+            const float4* src = reinterpret_cast<const float4*>(a.feat + (size_t)row0 * F);
+            const int rows_here = n - row0 < TILE_ROWS ? n - row0 : TILE_ROWS;
+            for (int i = tid; i < TILE_ROWS * (F / 4); i += FC_THREADS) {
+                const int r = i / (F / 4), k = (i - r * (F / 4)) * 4;
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (r < rows_here) v = src[i];
+                const float f[4] = {v.x, v.y, v.z, v.w};
+                Q4 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    hi.e[j] = (__bf16)f[j];
+                    lo.e[j] = (__bf16)(f[j] - (float)hi.e[j]);
+                }
+                *reinterpret_cast<Q4*>(lds + r * RB + k * 2) = hi;
+                *reinterpret_cast<Q4*>(lds + PART + r * RB + k * 2) = lo;
+            }
+            if (KS * 16 > F) {                        // zero the K padding of the last step
+                constexpr int PADQ = (KS * 16 - F) / 4;
+                for (int i = tid; i < TILE_ROWS * PADQ; i += FC_THREADS) {
+                    const int r = i / PADQ, k = F + (i - r * PADQ) * 4;
+                    const Q4 z{};
+                    *reinterpret_cast<Q4*>(lds + r * RB + k * 2) = z;
+                    *reinterpret_cast<Q4*>(lds + PART + r * RB + k * 2) = z;
+                }
+            }
         }
         __syncthreads();
 
@@ -90,56 +115,85 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_tile(FcArgs a, int n, const i
         float m_run = -3.0e38f, s_run = 0.0f;      // policy: running max / sum of exp of this lane's labels
         float dot = 0.0f;                          // value: partial hidden . w2
         const int board = row0 + bt * 32 + ln;
-        for (int lt = lq; lt < a.n_tiles; lt += 4) {
-            const uint4* wq = reinterpret_cast<const uint4*>(a.wp) + (size_t)lt * (a.ksteps + FC_PAD_STEPS) * 128 + lane;
-            f32x16 acc;
+        // two label tiles per pass and wave (two independent MFMA chains, one set of position operands), weights through a
+        // register ring RING K-steps deep: an L2 round trip is several hundred cycles, a K-step of one tile only 96
+        for (int lt0 = lq * 2; lt0 < a.n_tiles; lt0 += 8) {
+            const bool two = lt0 + 1 < a.n_tiles;
+            const uint4* wq0 = reinterpret_cast<const uint4*>(a.wp) + (size_t)lt0 * (KS + FC_PAD_STEPS) * 128 + lane;
+            const uint4* wq1 = wq0 + (two ? (size_t)(KS + FC_PAD_STEPS) * 128 : 0);
+            f32x16 acc0, acc1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            uint4 wh = wq[0], wl = wq[64];
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+            uint4 w[RING][4];                      // [ring slot][tile 0 hi, tile 0 lo, tile 1 hi, tile 1 lo]
+#pragma unroll
+            for (int s = 0; s < RING - 1; ++s) {
+                if (s < KS) {
+                    w[s][0] = wq0[(size_t)s * 128]; w[s][1] = wq0[(size_t)s * 128 + 64];
+                    w[s][2] = wq1[(size_t)s * 128]; w[s][3] = wq1[(size_t)s * 128 + 64];
+                }
+            }
             uint4 xh = *reinterpret_cast<const uint4*>(brow), xl = *reinterpret_cast<const uint4*>(brow + PART);
-            for (int ks = 0; ks < a.ksteps; ++ks) {
-                // next step's operands first (the padded steps make the last prefetch harmless)
-                const uint4 wh_n = wq[(size_t)(ks + 1) * 128], wl_n = wq[(size_t)(ks + 1) * 128 + 64];
-                const int nb = ks + 1 < a.ksteps ? (ks + 1) * 32 : 0;
-                const uint4 xh_n = *reinterpret_cast<const uint4*>(brow + nb);
-                const uint4 xl_n = *reinterpret_cast<const uint4*>(brow + PART + nb);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh), __builtin_bit_cast(bf16x8, xh), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wl), __builtin_bit_cast(bf16x8, xh), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh), __builtin_bit_cast(bf16x8, xl), acc, 0, 0, 0);
-                wh = wh_n; wl = wl_n; xh = xh_n; xl = xl_n;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + RING - 1 < KS) {
+                    const int sl = (ks + RING - 1) % RING;
+                    const size_t o = (size_t)(ks + RING - 1) * 128;
+                    w[sl][0] = wq0[o]; w[sl][1] = wq0[o + 64]; w[sl][2] = wq1[o]; w[sl][3] = wq1[o + 64];
+                }
+                uint4 xh_n = xh, xl_n = xl;
+                if (ks + 1 < KS) {
+                    xh_n = *reinterpret_cast<const uint4*>(brow + (ks + 1) * 32);
+                    xl_n = *reinterpret_cast<const uint4*>(brow + PART + (ks + 1) * 32);
+                }
+                const uint4* c = w[ks % RING];
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, xh), bl = __builtin_bit_cast(bf16x8, xl);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[0]), bh, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[2]), bh, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[1]), bh, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[3]), bh, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[0]), bl, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[2]), bl, acc1, 0, 0, 0);
+                xh = xh_n; xl = xl_n;
+                __builtin_amdgcn_sched_barrier(0);       // keep the loads where they are issued: RING - 1 steps ahead
             }
             // acc[4 g + i] <-> label lt * 32 + 8 g + 4 kb + i of position `board`
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int lab = lt * 32 + g * 8 + kb * 4;
-                float v[4];
+            for (int tile = 0; tile < 2; ++tile) {
+                if (tile == 1 && !two) break;
+                const int lt = lt0 + tile;
+                const f32x16& acc = tile ? acc1 : acc0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = lab + i < a.n_out ? acc[g * 4 + i] + a.bias[lab + i] : 0.0f;
-                if (MODE == FC_POLICY) {
-                    float mx = m_run;
+                for (int g = 0; g < 4; ++g) {
+                    const int lab = lt * 32 + g * 8 + kb * 4;
+                    float v[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (lab + i < a.n_out) mx = v[i] > mx ? v[i] : mx;
-                    float s = s_run * expf(m_run - mx);
+                    for (int i = 0; i < 4; ++i) v[i] = lab + i < a.n_out ? acc[g * 4 + i] + a.bias[lab + i] : 0.0f;
+                    if (MODE == FC_POLICY) {
+                        float mx = m_run;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (lab + i < a.n_out) s += expf(v[i] - mx);
-                    m_run = mx;
-                    s_run = s;
-                    if (board < n) {
-                        float* dst = a.logits + (size_t)board * a.n_out + lab;     // 8-byte aligned (n_out is even)
-                        if (lab + 1 < a.n_out) *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
-                        else if (lab < a.n_out) dst[0] = v[0];
-                        if (lab + 3 < a.n_out) *reinterpret_cast<float2*>(dst + 2) = make_float2(v[2], v[3]);
-                        else if (lab + 2 < a.n_out) dst[2] = v[2];
-                    }
-                } else {
+                        for (int i = 0; i < 4; ++i)
+                            if (lab + i < a.n_out) mx = v[i] > mx ? v[i] : mx;
+                        float s = s_run * fexp(m_run - mx);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (lab + i < a.n_out) {
-                            const float h = v[i] > 0.0f ? v[i] : 0.0f;
-                            dot += h * a.w2[lab + i];
+                        for (int i = 0; i < 4; ++i)
+                            if (lab + i < a.n_out) s += fexp(v[i] - mx);
+                        m_run = mx;
+                        s_run = s;
+                        if (board < n) {
+                            float* dst = a.logits + (size_t)board * a.n_out + lab;     // 8-byte aligned (n_out is even)
+                            if (lab + 1 < a.n_out) *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
+                            else if (lab < a.n_out) dst[0] = v[0];
+                            if (lab + 3 < a.n_out) *reinterpret_cast<float2*>(dst + 2) = make_float2(v[2], v[3]);
+                            else if (lab + 2 < a.n_out) dst[2] = v[2];
                         }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (lab + i < a.n_out) {
+                                const float h = v[i] > 0.0f ? v[i] : 0.0f;
+                                dot += h * a.w2[lab + i];
+                            }
+                    }
                 }
             }
         }
@@ -147,7 +201,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_tile(FcArgs a, int n, const i
         if (MODE == FC_POLICY) {
             const float m_o = __shfl_xor(m_run, 32, 64), s_o = __shfl_xor(s_run, 32, 64);
             const float mx = m_run > m_o ? m_run : m_o;
-            const float s = s_run * expf(m_run - mx) + s_o * expf(m_o - mx);
+            const float s = s_run * fexp(m_run - mx) + s_o * fexp(m_o - mx);
             if (kb == 0) {
                 red[(bt * 4 + lq) * 32 + ln] = mx;
                 red[256 + (bt * 4 + lq) * 32 + ln] = s;
@@ -168,7 +222,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_tile(FcArgs a, int n, const i
                 float s = 0.0f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    s += red[256 + (bt * 4 + q) * 32 + ln] * expf(red[(bt * 4 + q) * 32 + ln] - mx);
+                    s += red[256 + (bt * 4 + q) * 32 + ln] * fexp(red[(bt * 4 + q) * 32 + ln] - mx);
                 a.stats[board] = make_float2(mx, s);
             } else {
                 float d = 0.0f;
@@ -271,8 +325,8 @@ extern "C" int cz_heads_tail(const float* policy_feat, int n_policy_feat, const 
 {
     if (!policy_feat || !wp_packed || !bias_p || !value_feat || !w1_packed || !bias1 || !w2 || !policy || !value ||
         !stats_scratch || n_boards < 0 || n_labels < 2 || (n_labels & 1) || n_hidden < 1 || n_policy_feat < 1 ||
-        n_value_feat < 1 || n_policy_feat > FC_MAX_KSTEPS * 16 || n_value_feat > FC_MAX_KSTEPS * 16) {
-        czi_set_error("cz_heads_tail: bad argument (n_labels even, at most 384 features per head)");
+        (n_policy_feat != 180 && n_policy_feat != 360) || (n_value_feat != 180 && n_value_feat != 360)) {
+        czi_set_error("cz_heads_tail: bad argument (n_labels even; 180 or 360 features per head: 2 or 4 filters x 90 squares)");
         return CZ_ERR_ARG;
     }
     if (n_boards == 0) return CZ_OK;
@@ -289,7 +343,8 @@ extern "C" int cz_heads_tail(const float* policy_feat, int n_policy_feat, const 
         a.ksteps = (n_policy_feat + 15) / 16; a.n_out = n_labels; a.n_tiles = (n_labels + 31) / 32;
         a.logits = policy; a.stats = reinterpret_cast<float2*>(stats_scratch);
         const unsigned blocks = (unsigned)(row_tiles < 2 * n_cu ? row_tiles : 2 * n_cu);
-        hipLaunchKernelGGL((k_fc_tile<FC_POLICY>), dim3(blocks), dim3(FC_THREADS), 0, st, a, n_boards, n_dev);
+        if (n_policy_feat == 360) hipLaunchKernelGGL((k_fc_tile<FC_POLICY, 360>), dim3(blocks), dim3(FC_THREADS), 0, st, a, n_boards, n_dev);
+        else hipLaunchKernelGGL((k_fc_tile<FC_POLICY, 180>), dim3(blocks), dim3(FC_THREADS), 0, st, a, n_boards, n_dev);
         size_t nb = ((size_t)n_boards + 3) / 4;
         if (nb > (size_t)n_cu * 16) nb = (size_t)n_cu * 16;
         hipLaunchKernelGGL(k_policy_normalize, dim3((unsigned)nb), dim3(256), 0, st, policy,
@@ -301,7 +356,8 @@ extern "C" int cz_heads_tail(const float* policy_feat, int n_policy_feat, const 
         a.ksteps = (n_value_feat + 15) / 16; a.n_out = n_hidden; a.n_tiles = (n_hidden + 31) / 32;
         a.w2 = w2; a.b2 = b2; a.value = value;
         const unsigned blocks = (unsigned)(row_tiles < 2 * n_cu ? row_tiles : 2 * n_cu);
-        hipLaunchKernelGGL((k_fc_tile<FC_VALUE>), dim3(blocks), dim3(FC_THREADS), 0, st, a, n_boards, n_dev);
+        if (n_value_feat == 180) hipLaunchKernelGGL((k_fc_tile<FC_VALUE, 180>), dim3(blocks), dim3(FC_THREADS), 0, st, a, n_boards, n_dev);
+        else hipLaunchKernelGGL((k_fc_tile<FC_VALUE, 360>), dim3(blocks), dim3(FC_THREADS), 0, st, a, n_boards, n_dev);
     }
     if (hipGetLastError() != hipSuccess) {
         czi_set_error("cz_heads_tail: launch failed");

@@ -291,7 +291,7 @@ int cz_head_convs(const void* x, int dtype, const float* w, const float* bias, f
  * relu) -> Dense(1, tanh)) on the head features cz_head_convs / cz_resblock_heads produce, in three launches of
  * hand-written kernels (csrc/xq_heads.hip: split-bf16 MFMA GEMM tiles of 64 positions with the softmax statistics
  * kept per lane, one normalising pass, the value head with its hidden layer in the accumulators).
- *   policy_feat[n][n_policy_feat], value_feat[n][n_value_feat]   fp32 (at most 384 features each)
+ *   policy_feat[n][n_policy_feat], value_feat[n][n_value_feat]   fp32 (180 or 360 features each: 2 or 4 head filters)
  *   wp_packed / w1_packed    cz_fc_pack_weights() of the [n_labels][n_policy_feat] / [n_hidden][n_value_feat] matrices
  *   bias_p[n_labels], bias1[n_hidden], w2[n_hidden], b2          fp32 (n_labels even)
  *   policy[n][n_labels] (softmax), value[n] (tanh)               fp32 outputs

@@ -81,7 +81,8 @@ def test_conv3x3_identity_filter_is_a_shift():
 
 
 @pytest.mark.parametrize("c,dt,parts", [(128, "bfloat16", 2), (128, "bfloat16", 1), (128, "float16", 1),
-                                        (256, "float16", 1), (256, "bfloat16", 1), (192, "float16", 1)])
+                                        (256, "float16", 1), (256, "bfloat16", 1), (192, "float16", 1),
+                                        (192, "bfloat16", 2), (192, "float16", 2)])      # (192 split: k_resblock_ip)
 @pytest.mark.parametrize("n", [1, 3, 257, 700])
 def test_resblock_equals_two_convolutions(c, dt, parts, n):
     """cz_resblock (one launch, intermediate in LDS) must be BIT-identical to two cz_conv3x3 launches: same
@@ -340,14 +341,16 @@ def test_network_with_history_planes_and_reference_head_shapes():
     assert torch.equal(p, p2) and torch.equal(v, v2)
 
 
-def test_network_on_a_compact_queue_matches_the_gathered_batch():
+@pytest.mark.parametrize("filters", [128, 192])
+def test_network_on_a_compact_queue_matches_the_gathered_batch(filters):
     """cz_*_q (compact evaluation queue): rows / count live on the device.  The network evaluated on
     (planes, rows, count) gives, in its first `count` result rows, what it gives on the gathered batch
-    planes[rows[:count]] -- for count = 0, 1, an odd number and the whole queue -- and leaves the launch shapes alone."""
+    planes[rows[:count]] -- for count = 0, 1, an odd number and the whole queue -- and leaves the launch shapes alone.
+    128 filters (k_resblock_pipe / k_resblock with fused heads) and 192 (k_resblock_ip + cz_head_convs)."""
     import torch
     from cchess_alphazero.agent.model import CChessNet, InferenceNet
     torch.manual_seed(11)
-    raw = CChessNet(cnn_filter_num=128, res_layer_num=3).eval()
+    raw = CChessNet(cnn_filter_num=filters, res_layer_num=3).eval()
     for m in raw.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
             m.running_mean.normal_(0, 0.1)
