@@ -35,7 +35,11 @@ constexpr int TILE_ROWS = 64;         // positions per workgroup pass (two MFMA 
 constexpr int FC_THREADS = 512;       // 8 waves: wave w -> position tile w & 1, label tiles (w >> 1) mod 4
 constexpr int FC_PAD_STEPS = 2;       // zero K-steps appended per label tile (the prefetch reads one step ahead)
 constexpr int FC_MAX_KSTEPS = 24;     // features per position <= 384 (the reference's heads: 2 or 4 filters x 90 squares)
-constexpr int FC_LDS_BYTES = 2 * TILE_ROWS * (FC_MAX_KSTEPS * 32 + 16) + 2 * 256 * (int)sizeof(float);
+constexpr int FC_IMG_BYTES = 2 * TILE_ROWS * (FC_MAX_KSTEPS * 32 + 16);
+constexpr int FC_RED_BYTES = 2 * 256 * (int)sizeof(float);
+constexpr int FC_STAGE_ROW = 144;     // bytes per position row of a wave's logit staging tile (32 floats + 16 B: odd in 16-B units)
+constexpr int FC_STAGE_BYTES = 32 * FC_STAGE_ROW;            // per wave
+constexpr int FC_LDS_BYTES = FC_IMG_BYTES + FC_RED_BYTES + (FC_THREADS / 64) * FC_STAGE_BYTES;
 
 enum FcMode { FC_POLICY = 0, FC_VALUE = 1 };
 
@@ -76,7 +80,8 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_tile(FcArgs a, int n, const i
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ln = lane & 31, kb = lane >> 5;
     const int bt = wave & 1, lq = wave >> 1;
-    float* red = reinterpret_cast<float*>(lds + FC_LDS_BYTES - 2 * 256 * (int)sizeof(float));   // [2 values][2 position tiles][4 wave classes][32]
+    float* red = reinterpret_cast<float*>(lds + FC_IMG_BYTES);   // [2 values][2 position tiles][4 wave classes][32]
+    unsigned char* stg = lds + FC_IMG_BYTES + FC_RED_BYTES + wave * FC_STAGE_BYTES;      // this wave's logit tile
     const int n_row_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
     struct alignas(8) Q4 { __bf16 e[4]; };
     for (int rt = blockIdx.x; rt < n_row_tiles; rt += gridDim.x) {
@@ -179,13 +184,8 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_tile(FcArgs a, int n, const i
                             if (lab + i < a.n_out) s += fexp(v[i] - mx);
                         m_run = mx;
                         s_run = s;
-                        if (board < n) {
-                            float* dst = a.logits + (size_t)board * a.n_out + lab;     // 8-byte aligned (n_out is even)
-                            if (lab + 1 < a.n_out) *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
-                            else if (lab < a.n_out) dst[0] = v[0];
-                            if (lab + 3 < a.n_out) *reinterpret_cast<float2*>(dst + 2) = make_float2(v[2], v[3]);
-                            else if (lab + 2 < a.n_out) dst[2] = v[2];
-                        }
+                        // into the wave's staging tile [position][32 labels]; written out in whole rows below
+                        *reinterpret_cast<float4*>(stg + ln * FC_STAGE_ROW + (g * 8 + kb * 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
@@ -194,6 +194,31 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_tile(FcArgs a, int n, const i
                                 dot += h * a.w2[lab + i];
                             }
                     }
+                }
+                if (MODE == FC_POLICY) {
+                    // the tile leaves through LDS so that HBM sees 128 contiguous bytes per position (8 lanes x 16 B) instead of
+                    // 8-byte pieces from the accumulator layout (34 M write requests per launch: a request-rate limit)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = (lane >> 3) + 8 * j, c4 = (lane & 7) * 4;
+                        const float4 o = *reinterpret_cast<const float4*>(stg + r * FC_STAGE_ROW + c4 * 4);
+                        const int brd = row0 + bt * 32 + r, l0 = lt * 32 + c4;
+                        if (brd < n) {
+                            float* dst = a.logits + (size_t)brd * a.n_out + l0;      // 8-byte aligned (n_out is even)
+                            if (l0 + 3 < a.n_out) {
+                                *reinterpret_cast<float2*>(dst) = make_float2(o.x, o.y);
+                                *reinterpret_cast<float2*>(dst + 2) = make_float2(o.z, o.w);
+                            } else {
+                                if (l0 < a.n_out) dst[0] = o.x;
+                                if (l0 + 1 < a.n_out) dst[1] = o.y;
+                                if (l0 + 2 < a.n_out) dst[2] = o.z;
+                            }
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
         }

@@ -261,7 +261,9 @@ size_t cz_input_conv_packed_elems(int channels, int in_planes, int parts);
 /* Compact-queue forms of the three kernels above (cz_search_round_q): the number of boards is min(n_boards, *n_dev)
  * with n_dev in DEVICE memory (n_boards = the capacity of the buffers = the launch shape), and the input convolution
  * reads board i from planes[rows[i]] (rows DEVICE int32, NULL = identity).  rows / n_dev may be NULL: then exactly the
- * plain function. */
+ * plain function.  Threading: rows / n_dev travel to the launch through thread-local state inside the call, so each
+ * call is self-contained on its thread; like every cz_* entry point these may be called from several host threads at
+ * once as long as each thread uses its own stream. */
 int cz_input_conv_q(const void* planes, int planes_dtype, int in_planes, const void* w_packed, const float* bias,
                     void* y_hi, void* y_lo, int n_boards, int channels, int dtype, int parts, int relu,
                     const int32_t* rows, const int32_t* n_dev, void* stream);

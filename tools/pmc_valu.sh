@@ -5,7 +5,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/pmc_valu
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-micro --sustained-rounds 0"
+BENCH="python $ROOT/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-micro --sustained-rounds 0 --no-other-configs --no-dist"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES \
     --output-format csv -d "$OUT/a" -o p -- $BENCH > /dev/null 2> "$OUT/a.err"
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_INST_CYCLES_SALU \
@@ -24,9 +24,11 @@ for sub in ("a", "b"):
             if name:
                 per.setdefault(int(r["Dispatch_Id"]), {"name": name})[r["Counter_Name"]] = float(r["Counter_Value"])
     seq = [per[i] for i in sorted(per)]
-    rounds = [seq[i:i + 5] for i in range(0, len(seq) - len(seq) % 5, 5)]
-    rounds = [r for r in rounds if [x["name"] for x in r] == ["k_noise", "k_sim", "k_advance", "k_noise", "k_sim"]][3:]
-    labels = ["k_noise(B)", "k_sim(BACKUP)", "k_advance", "k_noise(S)", "k_sim(SELECT)"]
+    first = next((i for i, x in enumerate(seq) if x["name"] == "k_sim"), 0)
+    seq = seq[first:]
+    rounds = [seq[i:i + 4] for i in range(0, len(seq) - len(seq) % 4, 4)]
+    rounds = [r for r in rounds if [x["name"] for x in r] == ["k_sim", "k_advance", "k_noise", "k_sim"]][3:]
+    labels = ["k_sim(BACKUP)", "k_advance", "k_noise", "k_sim(SELECT)"]
     for j, lab in enumerate(labels):
         acc = collections.defaultdict(float)
         for r in rounds:

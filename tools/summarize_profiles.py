@@ -18,7 +18,10 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEARCH = ("k_noise", "k_sim", "k_advance")
-NN = ("k_resblock", "k_input_conv", "k_conv3x3", "k_split_bias_act", "k_bias_act")
+ROUND_LAUNCHES = 4            # k_sim(BACKUP), k_advance, k_noise, k_sim(SELECT)   (round 2: five, k_noise twice)
+ROUND_NAMES = ["k_sim", "k_advance", "k_noise", "k_sim"]
+NN = ("k_resblock_ip", "k_resblock", "k_input_conv", "k_conv3x3", "k_split_bias_act", "k_bias_act", "k_fc_tile<0", "k_fc_tile<1",
+      "k_policy_normalize", "k_head_convs")
 
 
 def short(name):
@@ -54,24 +57,25 @@ def per_kernel(rows, skip_first=2):
 
 
 def search_rounds(rows, counter):
-    """sum of `counter` over the 5 launches of each cz_search_round (k_noise, k_sim, k_advance, k_noise, k_sim)"""
+    """sum of `counter` over the 4 launches of each cz_search_round (k_sim, k_advance, k_noise, k_sim)"""
     vals = [v for did, k, c, v in rows if c == counter and k in SEARCH]
-    return [sum(vals[i:i + 5]) for i in range(0, len(vals) - len(vals) % 5, 5)]
+    return [sum(vals[i:i + ROUND_LAUNCHES]) for i in range(0, len(vals) - len(vals) % ROUND_LAUNCHES, ROUND_LAUNCHES)]
 
 
 def search_launch_counters(rows, skip_rounds=3):
-    """SQ counters of the 5 launches of a cz_search_round, by position, mean over the steady-state rounds; with the
+    """SQ counters of the launches of a cz_search_round, by position, mean over the steady-state rounds; with the
     fractions of the waves' cycles spent waiting / issuing (SQ_WAIT_ANY etc. over SQ_WAVE_CYCLES)"""
     per = collections.OrderedDict()
     for did, k, c, v in rows:
         if k in SEARCH:
             per.setdefault(did, {"name": k})[c] = v
     seq = list(per.values())
-    rounds = [seq[i:i + 5] for i in range(0, len(seq) - len(seq) % 5, 5)]
-    rounds = [r for r in rounds if [x["name"] for x in r] == ["k_noise", "k_sim", "k_advance", "k_noise", "k_sim"]][skip_rounds:]
+    n = ROUND_LAUNCHES
+    rounds = [seq[i:i + n] for i in range(0, len(seq) - len(seq) % n, n)]
+    rounds = [r for r in rounds if [x["name"] for x in r] == ROUND_NAMES][skip_rounds:]
     if not rounds:
         return None
-    labels = ["k_noise(B)", "k_sim(BACKUP)", "k_advance", "k_noise(S)", "k_sim(SELECT)"]
+    labels = ["k_sim(BACKUP)", "k_advance", "k_noise", "k_sim(SELECT)"]
     out = {"rounds": len(rounds)}
     for j, lab in enumerate(labels):
         acc = collections.defaultdict(float)
@@ -108,7 +112,8 @@ def main():
         lines = [f"# rocprofv3 --kernel-trace --stats of `bench.py` (normal config, split-bf16 network), round {a.round}",
                  "",
                  "Command (GPU box): `cd /tmp && export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv "
-                 "-d gpurun_out/prof/stats -o s -- python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-micro`",
+                 "-d gpurun_out/prof/stats -o s -- python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-micro "
+                 "--sustained-rounds 0 --no-other-configs --no-dist`",
                  ""]
         if bench:
             lines += [f"bench.py under the profiler: {bench.get('value', 0):.0f} expansions/s, "
@@ -122,20 +127,23 @@ def main():
         tf = glob.glob(os.path.join(a.src, "stats", "**", "*kernel_trace.csv"), recursive=True)
         if tf:
             tr = [r for r in csv.DictReader(open(tf[0])) if short(r["Kernel_Name"]) in SEARCH]
+            first_sim = next((i for i, r in enumerate(tr) if short(r["Kernel_Name"]) == "k_sim"), 0)
+            tr = tr[first_sim:]                                   # (align on a round's first launch)
             seq = [(short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
                     r.get("VGPR_Count", r.get("Arch_VGPR_Count", "")), r.get("Scratch_Size", ""),
                     r.get("LDS_Block_Size", "")) for r in tr]
-            nr = len(seq) // 5
+            L = ROUND_LAUNCHES
+            nr = len(seq) // L
             if nr >= 4:
-                lines += ["", f"## One lock-step round = 5 launches on one stream (mean of the last {nr - 3} rounds, us)", "",
+                lines += ["", f"## One lock-step round = {L} launches on one stream (mean of the last {nr - 3} rounds, us)", "",
                           "| launch | mean us | VGPR | scratch B | LDS B |", "|---|---|---|---|---|"]
-                names = ["k_noise (before BACKUP)", "k_sim(BACKUP)", "k_advance", "k_noise (before SELECT)", "k_sim(SELECT)"]
+                names = ["k_sim(BACKUP)", "k_advance", "k_noise", "k_sim(SELECT)"]
                 tot = 0.0
-                for j in range(5):
-                    v = [seq[i * 5 + j][1] for i in range(3, nr)]
+                for j in range(L):
+                    v = [seq[i * L + j][1] for i in range(3, nr)]
                     m = sum(v) / len(v)
                     tot += m
-                    lines.append(f"| {names[j]} | {m:.1f} | {seq[3 * 5 + j][2]} | {seq[3 * 5 + j][3]} | {seq[3 * 5 + j][4]} |")
+                    lines.append(f"| {names[j]} | {m:.1f} | {seq[3 * L + j][2]} | {seq[3 * L + j][3]} | {seq[3 * L + j][4]} |")
                 lines.append(f"| **sum** | **{tot:.1f}** | | | |")
         with open(os.path.join(prof, f"{tag}_bench_f32_kernel_stats.md"), "w") as f:
             f.write("\n".join(lines) + "\n")
@@ -149,7 +157,7 @@ def main():
         n = min(len(fr), len(wr))
         fm = sum(fr[3:n]) / max(1, n - 3)
         wm = sum(wr[3:n]) / max(1, n - 3)
-        out = {"kernels": "k_noise + k_sim(BACKUP) + k_advance + k_noise + k_sim(SELECT) = one cz_search_round",
+        out = {"kernels": "k_sim(BACKUP) + k_advance + k_noise + k_sim(SELECT) = one cz_search_round",
                "workload": "bench.py normal config (4096 games, K=8, 7x128 split-bf16 network, u8 planes queue), "
                            f"steady-state rounds (first 3 of {n} excluded)",
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs (tools/collect_profiles.sh)",

@@ -17,12 +17,14 @@ with open(f) as fh:
         if n:
             rows.append((int(r["Start_Timestamp"]), n, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
 rows.sort()
-# label the search launches of a round: k_noise, k_sim(B), k_advance, k_noise, k_sim(S)
+# label the search launches of a round: k_sim(BACKUP), k_advance, k_noise, k_sim(SELECT)   (round 3: one k_noise launch)
 seq = [(n, d) for _, n, d in rows if n in ("k_noise", "k_sim", "k_advance")]
-labels = ["k_noise(B)", "k_sim(BACKUP)", "k_advance", "k_noise(S)", "k_sim(SELECT)"]
-# find the first full round boundary: the start_selfplay precedes; rounds are strictly periodic with 5 launches
-rounds = [seq[i:i + 5] for i in range(0, len(seq) - len(seq) % 5, 5)]
-rounds = [r for r in rounds if [x[0] for x in r] == ["k_noise", "k_sim", "k_advance", "k_noise", "k_sim"]]
+labels = ["k_sim(BACKUP)", "k_advance", "k_noise", "k_sim(SELECT)"]
+L = len(labels)
+first = next((i for i, x in enumerate(seq) if x[0] == "k_sim"), 0)
+seq = seq[first:]
+rounds = [seq[i:i + L] for i in range(0, len(seq) - len(seq) % L, L)]
+rounds = [r for r in rounds if [x[0] for x in r] == ["k_sim", "k_advance", "k_noise", "k_sim"]]
 
 
 def stats(v):
@@ -32,8 +34,8 @@ def stats(v):
 
 out = {"rounds_traced": len(rounds), "unit": "us"}
 for name, sl in (("first_200_rounds", rounds[24:224]), ("last_1000_rounds", rounds[-1000:])):
-    out[name] = {labels[j]: stats([r[j][1] for r in sl]) for j in range(5)}
-    out[name]["sum_of_means"] = sum(out[name][labels[j]]["mean"] for j in range(5))
+    out[name] = {labels[j]: stats([r[j][1] for r in sl]) for j in range(L)}
+    out[name]["sum_of_means"] = sum(out[name][labels[j]]["mean"] for j in range(L))
 rb = [d for _, n, d in rows if n == "k_resblock"]
 if rb:
     out["k_resblock_last_7000"] = stats(rb[-7000:])
