@@ -82,6 +82,9 @@ def _declare(L):
         L.cz_resblock.restype = i32
         L.cz_split_bias_act.argtypes = [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, vp]
         L.cz_split_bias_act.restype = i32
+    if hasattr(L, "cz_input_resblock"):
+        L.cz_input_resblock.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
+        L.cz_input_resblock.restype = i32
     if hasattr(L, "cz_heads_tail"):
         L.cz_heads_tail.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, i32, vp, C.c_float, vp, vp, vp, i32, vp, vp]
         L.cz_heads_tail.restype = i32
@@ -287,6 +290,29 @@ def head_convs(x, w, bias, n_policy, policy_feat, value_feat):
     check(lib().cz_head_convs(_ptr(x), _dt_code(x.dtype), _ptr(w), _ptr(bias), _ptr(policy_feat), _ptr(value_feat),
                               n, c, n_policy, w.shape[0] - n_policy, _stream()), "cz_head_convs")
     return policy_feat, value_feat
+
+
+def input_table(w_oihw):
+    """fp32 [C, in_planes, 5, 5] input filter (BatchNorm folded) -> the gather table of cz_input_resblock:
+    table[c][ky * 5 + kx][o] = w[o][c][ky][kx], fp32 [in_planes, 25, C]."""
+    import torch
+    w = w_oihw.detach().to(torch.float32)
+    return w.permute(1, 2, 3, 0).reshape(w.shape[1], 25, w.shape[0]).contiguous()
+
+
+def input_resblock(planes, table, in_bias, w1, b1, w2, b2, out, rows=None, count=None):
+    """cz_input_resblock: planes [N, in_planes, 10, 9] uint8 -> input layer + first residual block -> out = (hi, lo)
+    [N, 90, 128] operand pair.  rows / count: the compact evaluation queue (int32 device tensors)."""
+    require_gpu()
+    import torch
+    if planes.dtype != torch.uint8:
+        raise NativeError("cz_input_resblock reads uint8 planes")
+    n = planes.shape[0]
+    check(lib().cz_input_resblock(_ptr(planes), planes.shape[1], _ptr(table), _ptr(in_bias), _ptr(w1), _ptr(b1), _ptr(w2),
+                                  _ptr(b2), _ptr(out[0]), _ptr(out[1]), n, out[0].shape[-1], _dt_code(out[0].dtype),
+                                  _ptr(rows) if rows is not None else None, _ptr(count) if count is not None else None,
+                                  _stream()), "cz_input_resblock")
+    return out
 
 
 def pack_fc_weights(w):

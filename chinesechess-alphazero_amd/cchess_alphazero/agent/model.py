@@ -115,6 +115,8 @@ class InferenceNet(nn.Module):
         self.fused_epilogue = True          # on the GPU: hand-written bias + skip + ReLU pass after each conv
         self.fused_blocks = True            # trunk="mfma", fp32, 128 filters: one launch per residual block
         self.fused_heads = True             # ... and the 1x1 head convolutions folded into the last block's store pass
+        # ... and the input layer computed by the first block's copy waves (uint8 planes; CZ_FUSED_INPUT=0: cz_input_conv)
+        self.fused_input = os.environ.get("CZ_FUSED_INPUT", "1") != "0"
         # dense layers + softmax / tanh on the hand-written kernels (csrc/xq_heads.hip); CZ_FUSED_TAIL=0: the hipBLASLt /
         # PyTorch tail they replace (A/B runs)
         self.fused_tail = os.environ.get("CZ_FUSED_TAIL", "1") != "0"
@@ -147,11 +149,12 @@ class InferenceNet(nn.Module):
                 self.register_buffer(f"tb{i}b", b2)
             self.register_buffer("in_bias32", self._in_bias32)
             self.register_buffer("in_w", self._packed_in.view(torch.int16))
+            self.register_buffer("in_table32", self._in_table)
             self.register_buffer("head_w32", self._head_w)
             self.register_buffer("head_b32", self._head_b)
             for name, t in zip(("tail_wp", "tail_bp", "tail_w1", "tail_b1", "tail_w2"), self._tail_pack):
                 self.register_buffer(name, t.view(torch.int16) if t.dtype == torch.bfloat16 else t)
-            del self._packed_in, self._in_bias32, self._head_w, self._head_b, self._tail_pack
+            del self._packed_in, self._in_table, self._in_bias32, self._head_w, self._head_b, self._tail_pack
         self._bufs = {}
         self.eval()
         for p in self.parameters():
@@ -181,6 +184,7 @@ class InferenceNet(nn.Module):
                                   self.value_conv.weight.detach().float().flatten(1)]).contiguous()
         self._head_b = torch.cat([self.policy_conv.bias.detach().float(), self.value_conv.bias.detach().float()])
         self._packed_in = _native.pack_input_conv_weights(self.input_conv.weight, self.operand_dtype, self.parts)
+        self._in_table = _native.input_table(self.input_conv.weight)      # the gather form of the input layer
         out = []
         for c1, c2 in self.res:
             out.append((_native.pack_conv3x3_weights(c1.weight, self.operand_dtype, self.parts),
@@ -215,11 +219,15 @@ class InferenceNet(nn.Module):
         (cur, tmp, nxt), last = self._operands(n, planes.device)
         # compact queue (rows / count on the device): board i = planes[rows[i]] for i < count; the launch shapes stay
         # those of the whole queue, the kernels read the count themselves
-        _native.input_conv(planes.contiguous(), self.in_w.view(self.operand_dtype), self.in_bias32, cur,
-                           rows=rows, count=count)
         nblk = len(self.res)
         # whole residual block in one launch where k_resblock exists for the shape
         fused = self.fused_blocks and ((c in (128, 192)) or (c == 256 and self.parts == 1))
+        # input layer + first block in one launch: 128 filters, split operands, byte planes, a tower of >= 2 blocks
+        first_fused = (fused and self.fused_input and c == 128 and self.parts == 2 and nblk >= 2 and
+                       planes.dtype == torch.uint8)
+        if not first_fused:
+            _native.input_conv(planes.contiguous(), self.in_w.view(self.operand_dtype), self.in_bias32, cur,
+                               rows=rows, count=count)
         for i in range(nblk):
             w1 = getattr(self, f"tw{i}a").view(self.operand_dtype)
             w2 = getattr(self, f"tw{i}b").view(self.operand_dtype)
@@ -229,7 +237,11 @@ class InferenceNet(nn.Module):
                 if self.block_events is not None:
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record()
-                if i + 1 < nblk:
+                if i == 0 and first_fused:
+                    _native.input_resblock(planes.contiguous(), self.in_table32, self.in_bias32, w1, b1, w2, b2, out=nxt,
+                                           rows=rows, count=count)
+                    cur, nxt = nxt, cur
+                elif i + 1 < nblk:
                     _native.resblock(cur, w1, b1, w2, b2, out=nxt, count=count)
                     cur, nxt = nxt, cur
                 elif heads is not None and self.parts == 2 and c == 128:

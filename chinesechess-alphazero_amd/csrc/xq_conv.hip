@@ -582,7 +582,8 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
 namespace pipe {
 constexpr int RB = 256, IMG_ROWS = 90, ROW_Z = 272, PSTR = (ROW_Z + 16) * RB;      // bytes per part
 constexpr int BIAS_OFF = 2 * PSTR;                                                   // float b1[128], b2[128]
-constexpr int LDS_BYTES = BIAS_OFF + 2 * 128 * 4;
+constexpr int MASK_OFF = BIAS_OFF + 2 * 128 * 4;                                     // FIRST: 4 x uint32 mask[96], one per copy wave
+constexpr int LDS_BYTES = MASK_OFF + 4 * 96 * 4;
 constexpr int KK = 8, NT = 3, NM = 9, W_STEP = 4 * 64, W_PART = (9 * KK + W_PAD_STEPS) * W_STEP, W_RING = 4;
 }  // namespace pipe
 
@@ -724,11 +725,28 @@ __device__ __forceinline__ void pipe_kloop(unsigned char* lds, int row_base, con
     }
 }
 
-template <typename E>
+// FIRST: the block is the first of the tower and its input is the 5 x 5 input convolution of the feature planes
+// (Conv2D(F, 5) -> BatchNorm -> ReLU, agent/model.py:36-39), computed HERE by the copy waves instead of by a kernel of
+// its own.  The planes are one-hot -- a position has at most 32 pieces, 64 plane bits with the history planes -- so the
+// layer is a gather: output pixel p, channel o = bias[o] + sum over the occupied squares q of p's 5 x 5 window of
+// w[o][plane at q][tap].  A copy thread owns the 8 channels of its 16-byte chunk for 6 pixels (the chunks it writes into
+// the X image anyway): 48 fp32 accumulators, ~55 weight loads of 32 bytes from an L2-resident table
+// (table[plane][tap][128], 179 KB) per board, exact fp32 sums in a fixed order (bias, taps 0..24, planes ascending) --
+// no MFMA, no second kernel, no 46 KB per board written and read back.  The work is split over the two windows a copy
+// wave has per board (under K loop 1 and under K loop 2), since all waves meet at the barrier between them.
+struct FirstArgs {
+    const unsigned char* planes;   // u8 [n][in_planes][90], 0 / 1
+    const float* table;            // [in_planes][25][128]
+    const float* in_bias;          // [128]
+    const int32_t* rows;           // compact queue: board i of the batch is planes[rows[i]] (NULL: identity)
+    int in_planes;
+};
+
+template <typename E, bool FIRST = false>
 __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
     const E* __restrict__ xh, const E* __restrict__ xl, const E* __restrict__ w1p, const float* __restrict__ b1,
     const E* __restrict__ w2p, const float* __restrict__ b2, E* __restrict__ yh, E* __restrict__ yl, int n_boards,
-    const int32_t* __restrict__ n_dev)
+    const int32_t* __restrict__ n_dev, FirstArgs fa)
 {
     using namespace pipe;
     constexpr int C = 128, CHUNKS = 90 * 16, CTHR = 256, LITER = (CHUNKS + CTHR - 1) / CTHR;
@@ -788,7 +806,134 @@ __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
                 }
             }
         };
-        fetch(t);
+        // ---- FIRST: the input layer of board `board` into v[][] (the chunk layout put() / drain() write), in two halves ----
+        float acc[FIRST ? LITER : 1][8];
+        uint32_t occ[FIRST ? LITER : 1], cur_m[FIRST ? LITER : 1];
+        int cur_tap[FIRST ? LITER : 1];
+        uint32_t* mk = reinterpret_cast<uint32_t*>(lds + MASK_OFF) + (wave - 4) * 96;     // this wave's own mask board
+        const int c8 = ctid & 15, prow = ctid >> 4;            // chunk = channels 8 c8 .. 8 c8 + 7 of pixels prow + 16 it
+        constexpr int PW = 12;                                 // plane words per lane: 32 planes x 90 bytes / 4 / 64 lanes
+        uint32_t pw[FIRST ? PW : 1];
+        auto planes_prefetch = [&](int board) {                // HBM -> registers, consumed by the next first_begin
+            const int per_board = fa.in_planes * 90;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(
+                fa.planes + (size_t)(fa.rows ? fa.rows[board] : board) * per_board);
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+                const int w = lane + 64 * j;
+                pw[j] = w < per_board / 4 ? src[w] : 0u;
+            }
+        };
+        auto first_begin = [&]() {
+            // the occupied planes of every square as a bit mask, built by each copy wave for itself (no barrier with
+            // the other copy waves: they share nothing)
+            mk[lane] = 0u;
+            if (lane < 32) mk[64 + lane] = 0u;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            // (the board's plane words are already in registers: planes_prefetch ran a window earlier)
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+                const int w = lane + 64 * j;
+                const uint32_t word = pw[j];
+                if (word == 0u) continue;
+                int c = (w * 4) / 90, pix = w * 4 - c * 90;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    if ((word >> (8 * k4)) & 0xFFu) atomicOr(&mk[pix], 1u << c);
+                    if (++pix == 90) { pix = 0; ++c; }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const float4 b0 = *reinterpret_cast<const float4*>(fa.in_bias + c8 * 8);
+            const float4 b1v = *reinterpret_cast<const float4*>(fa.in_bias + c8 * 8 + 4);
+#pragma unroll
+            for (int it = 0; it < LITER; ++it) {
+                acc[it][0] = b0.x; acc[it][1] = b0.y; acc[it][2] = b0.z; acc[it][3] = b0.w;
+                acc[it][4] = b1v.x; acc[it][5] = b1v.y; acc[it][6] = b1v.z; acc[it][7] = b1v.w;
+                // the taps of pixel `it` whose square is occupied, as a 25-bit set
+                const int p = prow + 16 * it;
+                const int py = p / 9, px = p - py * 9;
+                uint32_t o = 0u;
+                if (p < 90) {
+#pragma unroll
+                    for (int tap = 0; tap < 25; ++tap) {
+                        const int dy = tap / 5 - 2, dx = tap % 5 - 2;
+                        if ((unsigned)(py + dy) < 10u && (unsigned)(px + dx) < 9u && mk[p + dy * 9 + dx] != 0u) o |= 1u << tap;
+                    }
+                }
+                occ[it] = o;
+                cur_m[it] = 0u;
+                cur_tap[it] = 0;
+            }
+        };
+        // One round = the next (tap, plane) term of each of the thread's six pixels: up to twelve 16-byte loads in flight,
+        // then the adds.  A pixel's terms are taken taps ascending, planes ascending -- the summation order does not
+        // depend on how the rounds fall.  Iterating over the terms a pixel HAS (9 on average, 25 at most) instead of over
+        // the 25 taps halves the number of L2 round trips, which is all this loop costs.
+        auto first_rounds = [&](int max_rounds) {
+#pragma unroll 1
+            for (int round = 0; round < max_rounds; ++round) {
+                uint32_t any = 0u;
+#pragma unroll
+                for (int it = 0; it < LITER; ++it) {
+                    if (cur_m[it] == 0u && occ[it] != 0u) {
+                        const int tap = __builtin_ctz(occ[it]);
+                        occ[it] &= occ[it] - 1u;
+                        const int p = prow + 16 * it;
+                        cur_tap[it] = tap;
+                        cur_m[it] = mk[p + (tap / 5 - 2) * 9 + (tap % 5 - 2)];
+                    }
+                    any |= cur_m[it];
+                }
+                if (!__ballot(any != 0u)) break;
+                float4 wa[LITER], wb[LITER];
+#pragma unroll
+                for (int it = 0; it < LITER; ++it) {
+                    wa[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    wb[it] = wa[it];
+                    if (cur_m[it]) {
+                        const int c = __builtin_ctz(cur_m[it]);
+                        const float4* tp = reinterpret_cast<const float4*>(fa.table + ((size_t)(c * 25 + cur_tap[it]) * 128 + c8 * 8));
+                        wa[it] = tp[0];
+                        wb[it] = tp[1];
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < LITER; ++it) {
+                    if (cur_m[it]) {
+                        acc[it][0] += wa[it].x; acc[it][1] += wa[it].y; acc[it][2] += wa[it].z; acc[it][3] += wa[it].w;
+                        acc[it][4] += wb[it].x; acc[it][5] += wb[it].y; acc[it][6] += wb[it].z; acc[it][7] += wb[it].w;
+                        cur_m[it] &= cur_m[it] - 1u;
+                    }
+                }
+            }
+        };
+        auto first_end = [&]() {                              // ReLU, split, pack: v[part][it] = chunk (pixel prow + 16 it, c8)
+            struct alignas(16) E8 { E e[8]; };
+#pragma unroll
+            for (int it = 0; it < LITER; ++it) {
+                E8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float r = acc[it][j] > 0.0f ? acc[it][j] : 0.0f;
+                    hi.e[j] = (E)r;
+                    lo.e[j] = (E)(r - (float)hi.e[j]);
+                }
+                v[0][it] = __builtin_bit_cast(uint4, hi);
+                v[1][it] = __builtin_bit_cast(uint4, lo);
+            }
+        };
+        if (FIRST) {
+            planes_prefetch(t);
+            first_begin();
+            if (t + stride < n_boards) planes_prefetch(t + stride);
+            first_rounds(25 * 32);       // (to the end: a pixel has at most 25 taps x in_planes terms)
+            first_end();
+        } else {
+            fetch(t);
+        }
         put(0);
         for (int i = ctid; i < 16 * 16; i += CTHR) {          // the shared zero rows, both parts
             *reinterpret_cast<uint4*>(lds + ROW_Z * RB + i * 16) = make_uint4(0, 0, 0, 0);
@@ -803,10 +948,27 @@ __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
             __syncthreads();                                   // A_k
             const int tn = t + stride;
             const bool has_next = tn < n_boards;
-            if (has_next) fetch(tn);
+            if (FIRST) {
+                if (has_next) {                                // first half of the next board's input layer, under K loop 1
+                    first_begin();                             // (board tn: its planes were fetched a window ago)
+                    if (tn + stride < n_boards) planes_prefetch(tn + stride);
+                    first_rounds(10);          // (window 1 is the longer one: K loop 1 + epilogue 1, and window 2 also drains)
+                }
+            } else if (has_next) {
+                fetch(tn);
+            }
             __syncthreads();                                   // B_k: out(k-1) complete in image (k-1) & 1
-            if (t_prev >= 0) drain((k - 1) & 1, t_prev, has_next);
-            else if (has_next) put(1);
+            if (FIRST) {
+                if (t_prev >= 0) drain((k - 1) & 1, t_prev, false);
+                if (has_next) {                                // second half, under K loop 2; then into the free image
+                    first_rounds(25 * 32);       // (to the end: a pixel has at most 25 taps x in_planes terms)
+                    first_end();
+                    put((k - 1) & 1);
+                }
+            } else {
+                if (t_prev >= 0) drain((k - 1) & 1, t_prev, has_next);
+                else if (has_next) put(1);
+            }
             t_prev = t;
             if (!has_next) break;
             t = tn;
@@ -1546,7 +1708,7 @@ int dispatch_resblock(int channels, int parts, const void* xh, const void* xl, c
         //  stays on k_resblock)
         const unsigned blocks = (unsigned)(n < n_cu ? n : n_cu);
         hipLaunchKernelGGL((k_resblock_pipe<E>), dim3(blocks), dim3(512), 0, st, (const E*)xh, (const E*)xl,
-                           (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, n, g_q.n_dev);
+                           (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, n, g_q.n_dev, FirstArgs{});
         return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
     }
     if (channels == 128 && parts == 2) {
@@ -1640,6 +1802,46 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
     else if (rc != CZ_OK)
         czi_set_error("cz_resblock: launch failed");
     return rc;
+}
+
+// The input layer and the first residual block in one launch (k_resblock_pipe<FIRST>): the 5 x 5 input convolution of
+// the one-hot feature planes is a gather over the occupied squares, done by the block's copy waves.
+extern "C" int cz_input_resblock(const void* planes_u8, int in_planes, const float* in_table, const float* in_bias,
+                                 const void* w1_packed, const float* bias1, const void* w2_packed, const float* bias2,
+                                 void* y_hi, void* y_lo, int n_boards, int channels, int dtype, const int32_t* rows,
+                                 const int32_t* n_dev, void* stream)
+{
+    if (n_boards < 0 || !planes_u8 || !in_table || !in_bias || !w1_packed || !w2_packed || !bias1 || !bias2 || !y_hi ||
+        !y_lo || in_planes < 1 || in_planes > 32 || (in_planes * 90) % 4 != 0) {
+        czi_set_error("cz_input_resblock: bad argument (u8 planes, in_planes even and <= 32)");
+        return CZ_ERR_ARG;
+    }
+    if (channels != 128 || (dtype != CZ_BF16 && dtype != CZ_F16)) {
+        czi_set_error("cz_input_resblock: 128 filters, bf16 / f16 split operands only (use cz_input_conv + cz_resblock)");
+        return CZ_ERR_ARG;
+    }
+    if (n_boards == 0) return CZ_OK;
+    const int n_cu = device_cu_count();
+    if (n_cu < 0) {
+        czi_set_error("cz_input_resblock: cannot query the device");
+        return CZ_ERR_HIP;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
+    const FirstArgs fa{(const unsigned char*)planes_u8, in_table, in_bias, rows, in_planes};
+    if (dtype == CZ_BF16)
+        hipLaunchKernelGGL((k_resblock_pipe<__bf16, true>), dim3(blocks), dim3(512), 0, st, (const __bf16*)nullptr,
+                           (const __bf16*)nullptr, (const __bf16*)w1_packed, bias1, (const __bf16*)w2_packed, bias2,
+                           (__bf16*)y_hi, (__bf16*)y_lo, n_boards, n_dev, fa);
+    else
+        hipLaunchKernelGGL((k_resblock_pipe<_Float16, true>), dim3(blocks), dim3(512), 0, st, (const _Float16*)nullptr,
+                           (const _Float16*)nullptr, (const _Float16*)w1_packed, bias1, (const _Float16*)w2_packed, bias2,
+                           (_Float16*)y_hi, (_Float16*)y_lo, n_boards, n_dev, fa);
+    if (hipGetLastError() != hipSuccess) {
+        czi_set_error("cz_input_resblock: launch failed");
+        return CZ_ERR_HIP;
+    }
+    return CZ_OK;
 }
 
 // test / tuning hook: 1 (default) = 128-filter split residual blocks with operand-pair output run on the

@@ -245,6 +245,19 @@ int cz_resblock_heads(const void* x_hi, const void* x_lo, const void* w1_packed,
                       const void* w2_packed, const float* bias2, const float* head_w, const float* head_b,
                       float* policy_feat, float* value_feat, int n_boards, int channels, int dtype, int n_policy,
                       int n_value, void* stream);
+/* The input layer AND the first residual block in one launch (128 filters, split operands): the 5x5 input convolution
+ * (Conv2D(F, 5, "same") -> BatchNorm -> ReLU, agent/model.py:36-39) of the one-hot feature planes is a gather over the
+ * occupied squares, computed in exact fp32 by the block's copy waves while its matrix waves run the previous board.
+ *   planes_u8   [n_boards][in_planes][90] uint8, 0 / 1 (what the search kernel writes; in_planes 14 or 28)
+ *   in_table    DEVICE fp32 [in_planes][25][128]: in_table[c][ky * 5 + kx][o] = w[o][c][ky][kx] (BatchNorm folded)
+ *   in_bias     DEVICE fp32 [128]
+ *   rows/n_dev  compact evaluation queue (may be NULL): board i = planes_u8[rows[i]], min(n_boards, *n_dev) boards
+ * The rest as cz_resblock with operand-pair output.  Equal to cz_input_conv followed by cz_resblock up to the rounding of
+ * the input layer (fp32 sums here, split-bf16 products there). */
+int cz_input_resblock(const void* planes_u8, int in_planes, const float* in_table, const float* in_bias,
+                      const void* w1_packed, const float* bias1, const void* w2_packed, const float* bias2, void* y_hi,
+                      void* y_lo, int n_boards, int channels, int dtype, const int32_t* rows, const int32_t* n_dev,
+                      void* stream);
 /* number of 2-byte elements of the packed filter (all parts, including the prefetch padding); 0 = bad argument */
 size_t cz_conv3x3_packed_elems(int channels, int parts);
 /* HOST: w_oihw[channels][channels][3][3] fp32 -> MFMA fragment order, split into parts; out_host holds

@@ -337,8 +337,11 @@ def test_network_with_history_planes_and_reference_head_shapes():
     inf = InferenceNet(net, torch.float32, trunk="mfma").cuda()
     p, v = inf(x.to(torch.uint8).cuda())
     assert (p.cpu() - p_ref).abs().max().item() < 1e-4 and (v.cpu() - v_ref).abs().max().item() < 1e-4
-    p2, v2 = inf(x.cuda())                                   # fp32 planes give the same answer
-    assert torch.equal(p, p2) and torch.equal(v, v2)
+    p2, v2 = inf(x.cuda())                                   # fp32 planes take the separate input-layer kernel (split-bf16
+    assert (p - p2).abs().max().item() < 1e-6 and (v - v2).abs().max().item() < 1e-5      # products): same answer to rounding
+    inf.fused_input = False                                  # ... which uint8 planes take too when the fusion is off: identical
+    p3, v3 = inf(x.to(torch.uint8).cuda())
+    assert torch.equal(p2, p3) and torch.equal(v2, v3)
 
 
 @pytest.mark.parametrize("filters", [128, 192])
@@ -473,4 +476,73 @@ def test_network_tail_switch_gives_the_same_outputs():
     assert (p - p0).abs().max().item() < 2e-7 and (v - v0).abs().max().item() < 2e-6
     with torch.no_grad():
         pr, vr = raw(planes.float().cpu())
+    assert (p.cpu() - pr).abs().max().item() < 1e-4 and (v.cpu() - vr).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("in_planes,dt", [(14, "bfloat16"), (28, "bfloat16"), (14, "float16")])
+def test_input_resblock_matches_input_layer_then_resblock(in_planes, dt):
+    """cz_input_resblock (k_resblock_pipe<FIRST>: the 5x5 input layer as an fp32 gather over the occupied squares, done by
+    the first block's copy waves; reference agent/model.py:36-45) against the float64 input layer followed by
+    cz_resblock on its (hi, lo) split.  The only difference is the rounding of the input layer: fp32 sums of <= 51 terms
+    (<= 4e-6 relative to the largest term sum) against float64 rounded to fp32 -- the block's output, two split-precision
+    convolutions later, agrees to 2e-5 of its largest value.  One-hot planes as the engine writes them (and a second bit
+    per square for the history planes), board counts around the CU count, the compact queue's rows / count."""
+    import torch
+    import torch.nn.functional as F
+    from cchess_alphazero import _native
+    dtype = getattr(torch, dt)
+    c = 128
+    g = torch.Generator().manual_seed(in_planes)
+    w_in = torch.randn((c, in_planes, 5, 5), generator=g) * 0.2
+    b_in = torch.randn((c,), generator=g) * 0.1
+    ws = [torch.randn((c, c, 3, 3), generator=g) / (3.0 * c ** 0.5) for _ in range(2)]
+    bs = [(torch.randn((c,), generator=g) * 0.1).cuda() for _ in range(2)]
+    ps = [_native.pack_conv3x3_weights(w, dtype, 2).cuda() for w in ws]
+    table, bias = _native.input_table(w_in).cuda(), b_in.cuda()
+    for n in (1, 2, 255, 257, 700):
+        planes = torch.zeros((n, in_planes, 10, 9), dtype=torch.uint8)
+        for grp in range(in_planes // 14):                       # one plane per occupied square and 14-plane group
+            occ = torch.rand((n, 10, 9), generator=g) < 0.36
+            which = torch.randint(0, 14, (n, 10, 9), generator=g)
+            planes[:, grp * 14:(grp + 1) * 14].scatter_(1, which.unsqueeze(1), occ.unsqueeze(1).to(torch.uint8))
+        x = F.relu(F.conv2d(planes.double(), w_in.double(), b_in.double(), padding=2)).float()      # [n, c, 10, 9]
+        xs = _split(x.permute(0, 2, 3, 1).reshape(n, 90, c).contiguous().cuda(), dtype, 2)
+        want = tuple(torch.empty_like(xs[0]) for _ in range(2))
+        old = _native.resblock_pipelined(None)
+        try:
+            _native.resblock(xs, ps[0], bs[0], ps[1], bs[1], out=want)
+        finally:
+            _native.resblock_pipelined(old)
+        got = tuple(torch.full_like(xs[0], 7.0) for _ in range(2))
+        _native.input_resblock(planes.cuda(), table, bias, ps[0], bs[0], ps[1], bs[1], out=got)
+        y, y_ref = got[0].float() + got[1].float(), want[0].float() + want[1].float()
+        assert torch.isfinite(y).all()
+        assert (y - y_ref).abs().max().item() <= 2e-5 * y_ref.abs().max().item(), n
+        if n == 700:                                              # compact queue: gathered rows, device-side count
+            perm = torch.randperm(n, generator=g).to(torch.int32).cuda()
+            cnt = torch.tensor([333], dtype=torch.int32, device="cuda")
+            got2 = tuple(torch.full_like(xs[0], 7.0) for _ in range(2))
+            _native.input_resblock(planes.cuda(), table, bias, ps[0], bs[0], ps[1], bs[1], out=got2, rows=perm, count=cnt)
+            for part in range(2):
+                assert torch.equal(got2[part][:333], got[part][perm[:333].long()])
+                assert torch.all(got2[part][333:] == 7.0)
+
+
+def test_network_with_fused_input_layer_switch():
+    """InferenceNet with the input layer inside the first block's launch (default) vs the separate cz_input_conv kernel."""
+    import torch
+    from cchess_alphazero.agent.model import CChessNet, InferenceNet
+    torch.manual_seed(6)
+    raw = CChessNet(cnn_filter_num=128, res_layer_num=3).eval()
+    net = InferenceNet(raw, torch.float32, trunk="mfma").cuda()
+    planes = torch.zeros((150, 14, 10, 9), dtype=torch.uint8)
+    occ = torch.rand((150, 10, 9)) < 0.3
+    planes.scatter_(1, torch.randint(0, 14, (150, 1, 10, 9)), occ.unsqueeze(1).to(torch.uint8))
+    assert net.fused_input
+    p, v = net(planes.cuda())
+    net.fused_input = False
+    p0, v0 = net(planes.cuda())
+    assert (p - p0).abs().max().item() < 1e-6 and (v - v0).abs().max().item() < 1e-5
+    with torch.no_grad():
+        pr, vr = raw(planes.float())
     assert (p.cpu() - pr).abs().max().item() < 1e-4 and (v.cpu() - vr).abs().max().item() < 1e-4
