@@ -30,6 +30,37 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
+def _load_profile(path):
+    """A committed profile: a JSON document, or a bench line (first line of the file).  None when unreadable -- a
+    damaged evidence file must never break the benchmark itself."""
+    try:
+        with open(path) as f:
+            text = f.read()
+        try:
+            return json.loads(text)
+        except ValueError:
+            return json.loads(text.splitlines()[0])
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+class _stdout_to_stderr:
+    """RCCL prints a version banner on stdout (at communicator set-up or tear-down, depending on NCCL_DEBUG): while this
+    is active file descriptor 1 points at stderr, so that rank 0's stdout carries the ONE JSON line and nothing else."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,23 +131,24 @@ def init_collective(world, rank, args):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     t0 = time.perf_counter()
     try:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-        probe = torch.ones(8, dtype=torch.int64, device="cuda")
-        dist.all_reduce(probe, op=dist.ReduceOp.SUM)          # creates the communicator
-        torch.cuda.synchronize()
-        ok = bool((probe == world).all())
-        init_s = time.perf_counter() - t0
-        dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(20):
-            dist.all_reduce(probe, op=dist.ReduceOp.MAX)
-        torch.cuda.synchronize()
-        us = (time.perf_counter() - t1) / 20 * 1e6
-        return {"backend": dist.get_backend(), "world": dist.get_world_size(), "init_seconds": init_s,
-                "all_reduce_int64x8_us": us, "probe_ok": ok,
-                "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ or "LOCAL_RANK" in os.environ
-                else "bench.py itself (single rank)"}
+        with _stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world)
+            probe = torch.ones(8, dtype=torch.int64, device="cuda")
+            dist.all_reduce(probe, op=dist.ReduceOp.SUM)          # creates the communicator
+            torch.cuda.synchronize()
+            ok = bool((probe == world).all())
+            init_s = time.perf_counter() - t0
+            dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                dist.all_reduce(probe, op=dist.ReduceOp.MAX)
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t1) / 20 * 1e6
+            return {"backend": dist.get_backend(), "world": dist.get_world_size(), "init_seconds": init_s,
+                    "all_reduce_int64x8_us": us, "probe_ok": ok,
+                    "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ or "LOCAL_RANK" in os.environ
+                    else "bench.py itself (single rank)"}
     except Exception as e:                                    # noqa: BLE001
         if world > 1:
             raise
@@ -216,8 +248,9 @@ def reference_cpu_timing():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reference_cpu.json")))
     if not files:
         return None
-    with open(files[-1]) as f:
-        d = json.load(f)
+    d = _load_profile(files[-1])
+    if d is None:
+        return None
     out = {"source": os.path.relpath(files[-1], ROOT)}
     for k in ("host", "summary"):
         if k in d:
@@ -259,17 +292,17 @@ def games_per_hour_estimate(expansions_per_s, config):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_games_{config}.json")))
     if not files:
         return None
-    with open(files[-1]) as f:
-        d = json.load(f)
+    d = _load_profile(files[-1])
+    if d is None or "expansions_per_game" not in d:
+        return None
     out = {"value": expansions_per_s / d["expansions_per_game"] * 3600.0, "unit": "games/hour",
            "expansions_per_game": d["expansions_per_game"], "mean_plies_per_game": d["mean_plies_per_game"],
            "source": os.path.relpath(files[-1], ROOT)}
     # the sustained figure of the committed long run of this configuration (games in every phase), if there is one
     longs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_f32_*_rounds.json")),
                    key=lambda f: (int(f.split("_")[-2]), os.path.basename(f)))   # longest run, newest round
-    if config == "normal" and longs:
-        with open(longs[-1]) as f:
-            ld = json.load(f)
+    ld = _load_profile(longs[-1]) if (config == "normal" and longs) else None
+    if ld is not None:
         sl = ld.get("sustained") or {"plies_per_s": ld["plies_per_s"], "value": ld["value"], "rounds": ld["steps"],
                                       "games_finished": ld["games_finished"]}      # (round-1 files: the whole run)
         out["sustained_measured"] = {"games_per_hour": sl["plies_per_s"] / d["mean_plies_per_game"] * 3600.0,
@@ -285,8 +318,7 @@ def pmc_traffic():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_search_round.json")))
     if not files:
         return None, None
-    with open(files[-1]) as f:
-        d = json.load(f)
+    d = _load_profile(files[-1]) or {}
     return d.get("traffic_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
 
 
@@ -297,8 +329,9 @@ def library_gemm_peak():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_peak.json")))
     if not files:
         return None
-    with open(files[-1]) as f:
-        d = json.load(f)
+    d = _load_profile(files[-1])
+    if not d or not d.get("runs"):
+        return None
     return {"value": max(r["tflops"] for r in d["runs"]), "source": os.path.relpath(files[-1], ROOT)}
 
 
@@ -308,8 +341,7 @@ def pmc_nn(kernel):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_nn.json")))
     if not files:
         return {}
-    with open(files[-1]) as f:
-        d = json.load(f).get("kernels", {}).get(kernel, {})
+    d = (_load_profile(files[-1]) or {}).get("kernels", {}).get(kernel, {})
     return {"hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "mfma_util": d.get("mfma_util"),
             "source": os.path.relpath(files[-1], ROOT)}
 
@@ -737,8 +769,9 @@ def main():
             tfl = flops_launch / (b_ms * 1e-3) / 1e12
             pmc = pmc_nn("k_resblock")
             out["roofline"] = {"kernel": "k_resblock_pipe / k_resblock (csrc/xq_conv.hip): one residual block (2 x conv3x3 + "
-                                         "bias + skip + ReLU) of the tower per launch, split-bf16 operands; the inner "
-                                         "blocks run the software-pipelined schedule, the last one (fused head "
+                                         "bias + skip + ReLU) of the tower per launch, split-bf16 operands; the first "
+                                         "launch also computes the 5x5 input layer (fp32 gather by its copy waves), the "
+                                         "inner blocks run the software-pipelined schedule, the last one (fused head "
                                          "convolutions) the plain one; mean over all launches of the tower",
                                "bound": "mfma", "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s", "frac": tfl / 2500.0,
                                "traffic": pmc.get("hbm_bytes_per_launch"), "traffic_source": pmc.get("source"),
@@ -791,6 +824,9 @@ def main():
                                     "launches_timed": len(sblk)}
             out["sustained"] = srec
             out["value_sustained"] = s_exp
+            out["quote"] = ("value = the K timed steps the contract asks for (games in the opening phase); "
+                            "value_sustained = the 3000-round leg of the same invocation, games in every phase: the figure "
+                            "to quote for self-play throughput")
         out["numerics_check"] = numerics_check(eng, ref_net, cfg)
         out["collective"] = collective
     eng.close()                                              # every rank; the legs below need the device memory
@@ -809,6 +845,8 @@ def main():
             log("cpu baseline done")
         print(json.dumps(out), flush=True)
     if dist_on:
+        sys.stdout.flush()
+        os.dup2(2, 1)                   # (RCCL's tear-down banner must not follow the JSON line on stdout)
         dist.barrier()                  # rank 0 may still be timing the CPU baseline: leave together
         dist.destroy_process_group()
 

@@ -740,6 +740,7 @@ struct FirstArgs {
     const float* in_bias;          // [128]
     const int32_t* rows;           // compact queue: board i of the batch is planes[rows[i]] (NULL: identity)
     int in_planes;
+    int w1_rounds;                 // term rounds done in the first window (under K loop 1), the rest under K loop 2
 };
 
 template <typename E, bool FIRST = false>
@@ -846,6 +847,9 @@ __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            // the occupied squares as one 90-bit set (wave-uniform): a pixel's occupied taps are five 5-bit windows of it
+            const uint64_t occ_lo = __ballot(mk[lane] != 0u);
+            const uint64_t occ_hi = __ballot(lane < 26 && mk[64 + (lane & 31)] != 0u);
             const float4 b0 = *reinterpret_cast<const float4*>(fa.in_bias + c8 * 8);
             const float4 b1v = *reinterpret_cast<const float4*>(fa.in_bias + c8 * 8 + 4);
 #pragma unroll
@@ -858,9 +862,15 @@ __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
                 uint32_t o = 0u;
                 if (p < 90) {
 #pragma unroll
-                    for (int tap = 0; tap < 25; ++tap) {
-                        const int dy = tap / 5 - 2, dx = tap % 5 - 2;
-                        if ((unsigned)(py + dy) < 10u && (unsigned)(px + dx) < 9u && mk[p + dy * 9 + dx] != 0u) o |= 1u << tap;
+                    for (int ky = 0; ky < 5; ++ky) {
+                        const int r = py + ky - 2;
+                        if ((unsigned)r < 10u) {
+                            // the 9 squares of board row r, then columns px - 2 .. px + 2 (columns off the board shift in zeros)
+                            const int sh = r * 9;
+                            const uint32_t rowbits = (uint32_t)((sh < 64 ? (occ_lo >> sh) | (sh > 55 ? occ_hi << (64 - sh) : 0ull)
+                                                                         : occ_hi >> (sh - 64)) & 0x1FFull);
+                            o |= (((rowbits << 2) >> px) & 31u) << (5 * ky);
+                        }
                     }
                 }
                 occ[it] = o;
@@ -952,7 +962,7 @@ __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
                 if (has_next) {                                // first half of the next board's input layer, under K loop 1
                     first_begin();                             // (board tn: its planes were fetched a window ago)
                     if (tn + stride < n_boards) planes_prefetch(tn + stride);
-                    first_rounds(10);          // (window 1 is the longer one: K loop 1 + epilogue 1, and window 2 also drains)
+                    first_rounds(fa.w1_rounds);
                 }
             } else if (has_next) {
                 fetch(tn);
@@ -1828,7 +1838,9 @@ extern "C" int cz_input_resblock(const void* planes_u8, int in_planes, const flo
     }
     hipStream_t st = (hipStream_t)stream;
     const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
-    const FirstArgs fa{(const unsigned char*)planes_u8, in_table, in_bias, rows, in_planes};
+    // 6 of the ~12-16 term rounds of a board under K loop 1, the rest under K loop 2: measured on one box, extra time of
+    // the launch against an inner block's: 0 rounds +0.43 ms, 3: +0.26, 6: +0.14, 9: +0.22 (window 2 also drains the result)
+    const FirstArgs fa{(const unsigned char*)planes_u8, in_table, in_bias, rows, in_planes, 6};
     if (dtype == CZ_BF16)
         hipLaunchKernelGGL((k_resblock_pipe<__bf16, true>), dim3(blocks), dim3(512), 0, st, (const __bf16*)nullptr,
                            (const __bf16*)nullptr, (const __bf16*)w1_packed, bias1, (const __bf16*)w2_packed, bias2,

@@ -30,9 +30,11 @@ def _env():
 
 
 def _line(out):
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert out.returncode == 0 and lines, out.stderr[-3000:]
-    return json.loads(lines[-1])
+    # ONE JSON line on stdout and nothing else (RCCL's version banner, which it prints on stdout, is kept off it)
+    assert len(lines) == 1 and lines[0].startswith("{"), lines[:8]
+    return json.loads(lines[0])
 
 
 def test_bench_under_the_launcher_with_one_rank_all_reduces_over_rccl():
