@@ -70,8 +70,14 @@ class EvaluateWorker:
         if evaluators is None:
             # (the inference networks themselves when the pipes are this package's DevicePipe: they take the compact
             #  queue; any other pipe is used through evaluate_device)
-            evaluators = tuple(getattr(getattr(p, "api", None), "net", None) or p.evaluate_device
-                               for p in (pipes1, pipes2))
+            # (... but only when that service never swaps its network: a reload-enabled api replaces api.net, and a
+            #  net bound here once would go stale -- those pipes are called through predict_device every time)
+            def pick(p):
+                api = getattr(p, "api", None)
+                if api is not None and getattr(api, "net", None) is not None and not getattr(api, "need_reload", True):
+                    return api.net
+                return p.evaluate_device
+            evaluators = tuple(pick(p) for p in (pipes1, pipes2))
         self.evaluators = evaluators
         self.dtype = dtype
         self.seed = seed

@@ -95,6 +95,7 @@ def test_sqrt_is_correctly_rounded(gpu):
     (1, 120, dict(kind="uniform", value=0.25)),
     (8, 400, dict(kind="hash", salt=2)),
     (5, 203, dict(kind="hash", salt=3)),
+    (80, 400, dict(kind="hash", salt=4)),          # more than 64 slots per game: the slot-by-slot paths of k_sim
 ])
 def test_search_matches_oracle(gpu, K, sims, spec):
     states = [xo.INIT_STATE, MID, END, MATE, xo.step(xo.INIT_STATE, '1242'), xo.fliped_state(MID)]

@@ -10,6 +10,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 timeout 1500 python -m pytest tests -m gpu -q --maxfail=15 -p no:cacheprovider --timeout 900 > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest rc=$?"; grep -E "passed|failed|FAILED" gpurun_out/pytest_gpu.log | tail -5
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 bash tools/collect_profiles.sh > gpurun_out/collect.log 2>&1
 cd $ROOT
 bash tools/pmc_valu.sh > gpurun_out/pmc_valu.log 2>&1
