@@ -6,9 +6,10 @@ N x [Conv3x3 -> BN -> ReLU -> Conv3x3 -> BN -> +skip -> ReLU] -> policy: Conv1x1
 Flatten(C,H,W) -> Dense(2086) softmax; value: Conv1x1(2) -> BN -> ReLU -> Flatten -> Dense(256) ReLU ->
 Dense(1) tanh.  Convs have no bias; BN eps = 1e-3 (Keras default, data/model/*.json).
 
-The MFMA work of the engine lives here (MIOpen / hipBLASLt kernels); the tree and rule kernels are
-hand-written HIP (csrc/).  ``InferenceNet`` is the eval-mode form used by self-play: BN folded into
-the convolutions, channels_last, optional fp16/bf16, captured into a HIP graph.
+``InferenceNet`` is the eval-mode form used by self-play: BatchNorm folded into the convolutions and, with
+trunk="mfma" (the default), every layer on hand-written HIP kernels (csrc/xq_conv.hip, xq_nn_epilogue.hip,
+xq_heads.hip: input layer fused into the first residual block, one launch per block, head convolutions, dense heads
+with softmax / tanh); trunk="library" keeps the MIOpen / hipBLASLt path for comparison.
 """
 import hashlib
 import json

@@ -4,7 +4,7 @@ One engine = one GPU = one process.  Each ROUND is
     cz_search_round (hand-written HIP, one wavefront per game: k_sim(BACKUP) -> k_advance -> k_sim(SELECT);
              backup / select / expand / game rules, leaf planes written straight into the evaluation queue)
  -> one ResNet forward over the whole queue (agent/model.py InferenceNet: hand-written MFMA kernels for the input
-    convolution, the residual tower and the head convolutions, hipBLASLt for the two dense layers)
+    layer fused into the first residual block, the residual tower, the head convolutions, the dense heads)
 with no host decision and no device->host copy in between.  Finished games are appended to a device
 ring and drained by the host only when it wants to write play-record files.
 
