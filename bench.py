@@ -231,7 +231,17 @@ def cpu_baseline(cfg, seconds):
             cpu = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
     except (OSError, StopIteration):
         pass
+    net_cpu = cpu_network_rate(cfg, procs)
+    combined = None
+    if net_cpu and net_cpu.get("positions_per_s"):
+        combined = 1.0 / (1.0 / sum(per) + 1.0 / net_cpu["positions_per_s"])
     return {"value": sum(per), "unit": "expansions/s", "cores": procs, "kind": "port",
+            "network_on_the_same_cores": net_cpu,
+            "with_network_estimate": {"value": combined, "unit": "expansions/s",
+                                      "note": "tree + rules (value) and the network evaluation of every expansion "
+                                              "(network_on_the_same_cores) taking turns on the same cores: 1 / (1 / tree "
+                                              "rate + 1 / network rate) -- the like-for-like figure next to the GPU line, "
+                                              "which includes the network"},
             "per_process": {"median": statistics.median(per), "min": min(per), "max": max(per), "seeds": len(per)},
             "sims_per_s": sum(sims), "cpu_model": cpu, "cgroup_cpu_quota": quota, "cpus_visible": visible,
             "sample": f"oracle/xq_mcts.c + xq_rules.c (C port of player.py / static_env.py), {procs} processes x "
@@ -239,6 +249,32 @@ def cpu_baseline(cfg, seconds):
                       f"K={pc.search_threads}, hash-stub net (tree + rules only, no ResNet), one seed per process, "
                       f"new tree per game; value = sum over processes",
             "reference_python_timing": reference_cpu_timing()}
+
+
+def cpu_network_rate(cfg, threads, seconds=3.0):
+    """The policy/value network of the benchmarked configuration as a plain PyTorch fp32 module on the host cores the
+    container may use: positions per second on batches of 256 (a few seconds).  The CPU leg above has no network in it;
+    this is what its expansions would additionally cost on the same machine."""
+    try:
+        from cchess_alphazero.agent.model import CChessNet
+        old = torch.get_num_threads()
+        torch.set_num_threads(max(1, int(threads)))
+        torch.manual_seed(0)
+        net = CChessNet.from_model_config(cfg.model).eval()
+        x = (torch.rand((256, 14, 10, 9)) < 0.1).float()
+        with torch.no_grad():
+            net(x)
+            t0 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t0 < seconds:
+                net(x)
+                n += x.shape[0]
+            dt = time.perf_counter() - t0
+        torch.set_num_threads(old)
+        return {"positions_per_s": n / dt, "threads": int(threads), "batch": 256,
+                "what": f"{cfg.model.res_layer_num}x{cfg.model.cnn_filter_num} CChessNet, PyTorch CPU fp32"}
+    except Exception as e:                                    # noqa: BLE001
+        return {"positions_per_s": None, "error": f"{type(e).__name__}: {e}"[:200]}
 
 
 def reference_cpu_timing():

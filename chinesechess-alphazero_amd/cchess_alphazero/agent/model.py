@@ -323,8 +323,8 @@ class InferenceNet(nn.Module):
                     if out is None:
                         out = (torch.empty((n, self.policy_out.out_features), dtype=torch.float32, device=planes.device),
                                torch.empty((n,), dtype=torch.float32, device=planes.device))
-                    key = ("tail_stats", n, str(planes.device))
-                    if key not in self._bufs:
+                    key = ("tail_stats", str(planes.device))          # scratch for the rows' (max, sum): grown, never per size
+                    if key not in self._bufs or self._bufs[key].shape[0] < n:
                         self._bufs[key] = torch.empty((n, 2), dtype=torch.float32, device=planes.device)
                     _native.heads_tail(pf, vf, self.tail_wp, self.tail_bp, self.tail_w1, self.tail_b1, self.tail_w2,
                                        self._tail_b2, out[0], out[1], self._bufs[key], count=count)

@@ -3,7 +3,7 @@
 # 1 pipelined (k_resblock_pipe).  usage: bash tools/ab_resblock.sh "1 0 1 0"
 export TMPDIR=/tmp
 for v in $1; do
-  CZ_RESBLOCK_MODE=$v timeout 200 python bench.py --steps 30 --warmup 6 --sustained-rounds 0 --no-micro --no-cpu-baseline 2>/dev/null > /tmp/ab_$v.json
+  CZ_RESBLOCK_MODE=$v timeout 200 python bench.py --steps 30 --warmup 6 --sustained-rounds 0 --no-micro --no-cpu-baseline --no-other-configs 2>/dev/null > /tmp/ab_$v.json
   python - "$v" <<'PY'
 import json, sys
 v = sys.argv[1]
