@@ -170,7 +170,11 @@ __device__ __forceinline__ void zero_rows_write(unsigned char* region, int gtid)
 //                          channel 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 //   row_base / zrow / part_bytes: where the image's first row, the 16 zero rows and the second operand part are, for
 //   kernels whose images share one LDS allocation (k_resblock_ip); the defaults are the self-contained layout of Geom.
-template <typename E, int C, int P, int PARTS>
+//   CTW: channel tiles per wave (wq points at the wave's FIRST tile; the tiles of a K-step are 64 uint4 apart).  Every
+//   pixel fragment read from LDS then feeds CTW MFMAs: with plain operands and one tile per wave there is one
+//   ds_read_b128 (8 LDS cycles) per MFMA (32 cycles of one of four SIMDs), i.e. the LDS port is as busy as the matrix
+//   pipes; two tiles per wave halve that.  acc[c * NT + p] <-> channel tile c of the wave.
+template <typename E, int C, int P, int PARTS, int CTW = 1>
 __device__ __forceinline__ void conv_kloop(const unsigned char* region, const uint4* wq, int lane,
                                            f32x16* acc, int row_base = 0, int zrow = Geom<C, P, PARTS>::ZROW,
                                            int part_bytes = Geom<C, P, PARTS>::PART_BYTES)
@@ -178,6 +182,7 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
     typedef Geom<C, P, PARTS> G;
     typedef typename Mfma<E>::V8 V8;
     constexpr int NT = G::NT, KK = G::KK, W_RING = G::W_RING;
+    static_assert(CTW == 1 || PARTS == 1, "several channel tiles per wave: plain operands only");
     const int kb = lane >> 5, ln = lane & 31;
     // byte offset (within a part) of this lane's 16-byte fragment piece for K-step 0 of a tap: row*RB + swizzle bits.
     // chunk = 2*kk + kb, swizzled chunk = chunk ^ (row & SWZ) = (2*kk) ^ (kb ^ (row & SWZ)): the lane part is folded
@@ -198,15 +203,17 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
         // (swizzle key = the image-relative row; zrow is a multiple of 16, so a zero row keys like the row it stands for)
         return row * G::RB + (((kb ^ nominal) & G::SWZ) << 4);
     };
-    V8 wf[W_RING][PARTS];
+    constexpr int WP = PARTS * CTW;                    // weight fragments per K-step: [part] (CTW == 1) or [tile]
+    V8 wf[W_RING][WP];
     V8 px[2][NT][PARTS];
 #pragma unroll
-    for (int p = 0; p < NT; ++p)
+    for (int p = 0; p < CTW * NT; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
 
-    auto load_w = [&](int step, int part) {
-        return __builtin_bit_cast(V8, wq[(size_t)part * G::W_PART + (size_t)step * G::W_STEP]);
+    auto load_w = [&](int step, int f) {               // f: part (CTW == 1) or channel tile of the wave
+        const int part = CTW == 1 ? f : 0, c = CTW == 1 ? 0 : f;
+        return __builtin_bit_cast(V8, wq[(size_t)part * G::W_PART + (size_t)step * G::W_STEP + c * 64]);
     };
     auto load_px = [&](int off, int part) {
         return __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(region + part * part_bytes + off));
@@ -217,7 +224,7 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
 #pragma unroll
     for (int s = 0; s < W_RING - 1; ++s)
 #pragma unroll
-        for (int part = 0; part < PARTS; ++part) wf[s][part] = load_w(s, part);
+        for (int f = 0; f < WP; ++f) wf[s][f] = load_w(s, f);
 #pragma unroll
     for (int part = 0; part < PARTS; ++part)
 #pragma unroll
@@ -226,7 +233,7 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
     // One K-step = NT (x3 in split mode) MFMAs.  The LDS reads of the NEXT K-step and the weight loads three K-steps
     // ahead are issued one per MFMA, in the shadow of the matrix pipe; sched_barrier pins that order (left alone, the
     // compiler sinks every load to just before its use and the pipe drains at each K-step).
-    constexpr int NM = NT * (PARTS == 2 ? 3 : 1);
+    constexpr int NM = CTW * NT * (PARTS == 2 ? 3 : 1);
     constexpr int NL = NT * PARTS;
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
@@ -246,12 +253,13 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* region, const ui
 #pragma unroll
             for (int i = 0; i < NM; ++i) {
                 const int pass = i / NT, p = i % NT;      // pass 0: w_hi*x_hi, 1: w_lo*x_hi, 2: w_hi*x_lo
-                acc[p] = Mfma<E>::mma(w[pass == 1 ? PARTS - 1 : 0], b[p][pass == 2 ? PARTS - 1 : 0], acc[p]);
+                if (CTW == 1) acc[p] = Mfma<E>::mma(w[pass == 1 ? PARTS - 1 : 0], b[p][pass == 2 ? PARTS - 1 : 0], acc[p]);
+                else acc[i] = Mfma<E>::mma(w[pass], b[p][0], acc[i]);      // pass = channel tile of the wave
                 if (i < NL) bn[i % NT][i / NT] = load_px(G::kstep(rows[i % NT], kn), i / NT);
                 if (i >= NM - PER && kk * PER + (i - (NM - PER)) < NT)
                     pre_n[kk * PER + (i - (NM - PER))] = tap_row(ndy, ndx, kk * PER + (i - (NM - PER)));
-                if (i >= NM - PARTS)
-                    wf[(kk + W_RING - 1) % W_RING][i - (NM - PARTS)] = load_w(step + W_RING - 1, i - (NM - PARTS));
+                if (i >= NM - WP)
+                    wf[(kk + W_RING - 1) % W_RING][i - (NM - WP)] = load_w(step + W_RING - 1, i - (NM - WP));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -355,8 +363,8 @@ struct HeadArgs {
     int n_pol;
 };
 
-template <typename E, int C, int PARTS, int P, bool HEADS = false>
-__global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_resblock(
+template <typename E, int C, int PARTS, int P, bool HEADS = false, int CTW = 1>
+__global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4) void k_resblock(
     const E* __restrict__ xh, const E* __restrict__ xl, const E* __restrict__ w1p, const float* __restrict__ b1,
     const E* __restrict__ w2p, const float* __restrict__ b2, E* __restrict__ yh, E* __restrict__ yl,
     float* __restrict__ yf, int n_boards, HeadArgs hd, const int32_t* __restrict__ n_dev)
@@ -367,7 +375,8 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
         n_boards = nd < n_boards ? nd : n_boards;
     }
     typedef Geom<C, P, PARTS> G;
-    constexpr int NT = G::NT, CT = G::CT, CTHR = RB_COPY_THREADS;
+    constexpr int NT = G::NT, CT = G::CT / CTW, CTHR = RB_COPY_THREADS;      // CT: matrix waves, CTW channel tiles each
+    static_assert(G::CT % CTW == 0, "channel tiles per wave must divide the channel tiles");
     constexpr int SROW = PARTS == 2 ? C * 4 : C * 2;   // staging row (one pixel): fp32, or the final 2-byte values
     constexpr int PIECES = P * 90 * (C / 8);           // 8-channel output pieces per tile
     constexpr int EITER = (PIECES + CTHR - 1) / CTHR;
@@ -483,31 +492,32 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
     }
 
     // ---- matrix waves ----
-    const int wg = wave;
+    const int wg = wave * CTW;                                 // first channel tile of this wave
     const uint4* wq1 = reinterpret_cast<const uint4*>(w1p) + wg * 64 + lane;
     const uint4* wq2 = reinterpret_cast<const uint4*>(w2p) + wg * 64 + lane;
     const int kb = lane >> 5, ln = lane & 31;
     for (;;) {
         __syncthreads();                                       // A
         const bool has_next = t + stride < n_tiles;
-        f32x16 acc[NT];
+        f32x16 acc[CTW * NT];
         __builtin_amdgcn_s_setprio(3);
-        conv_kloop<E, C, P, PARTS>(X, wq1, lane, acc);
+        conv_kloop<E, C, P, PARTS, CTW>(X, wq1, lane, acc);
         __builtin_amdgcn_s_setprio(0);
         int ln2 = ln, kb2 = kb, gt2 = tid;
         asm volatile("" : "+v"(ln2), "+v"(kb2), "+v"(gt2));
         // epilogue 1: relu(acc + b1) -> (hi, lo) -> Y image (operand layout of the second convolution)
 #pragma unroll
-        for (int p = 0; p < NT; ++p) {
+        for (int cp = 0; cp < CTW * NT; ++cp) {
+            const int p = cp % NT, c = cp / NT;
             const int q = (p % 3) * 32 + ln2;
             const int row = (p / 3) * 90 + q;
             if (q < 90) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int ch = wg * 32 + g * 8 + kb2 * 4;
+                    const int ch = (wg + c) * 32 + g * 8 + kb2 * 4;
                     const float4 bv = *reinterpret_cast<const float4*>(b1 + ch);
-                    const float vv[4] = {acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
-                                         acc[p][g * 4 + 3] + bv.w};
+                    const float vv[4] = {acc[cp][g * 4 + 0] + bv.x, acc[cp][g * 4 + 1] + bv.y, acc[cp][g * 4 + 2] + bv.z,
+                                         acc[cp][g * 4 + 3] + bv.w};
                     Quad<E> hi, lo;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -523,23 +533,24 @@ __global__ __launch_bounds__((C / 32 + 4) * 64, (C / 32 + 4 + 3) / 4) void k_res
         }
         __syncthreads();                                       // B: Y complete
         __builtin_amdgcn_s_setprio(3);
-        conv_kloop<E, C, P, PARTS>(Y, wq2, lane, acc);
+        conv_kloop<E, C, P, PARTS, CTW>(Y, wq2, lane, acc);
         __builtin_amdgcn_s_setprio(0);
         asm volatile("" : "+v"(ln2), "+v"(kb2));
         // epilogue 2: relu(acc + b2 + x) -> staging
 #pragma unroll
-        for (int p = 0; p < NT; ++p) {
+        for (int cp = 0; cp < CTW * NT; ++cp) {
+            const int p = cp % NT, c = cp / NT;
             const int q = (p % 3) * 32 + ln2;
             const int row = (p / 3) * 90 + q;
             if (q < 90) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int ch = wg * 32 + g * 8 + kb2 * 4;
+                    const int ch = (wg + c) * 32 + g * 8 + kb2 * 4;
                     const float4 bv = *reinterpret_cast<const float4*>(b2 + ch);
                     const int off = row * G::RB + (((ch >> 3) ^ (row & G::SWZ)) << 4) + (ch & 7) * 2;
                     const Quad<E> sh = *reinterpret_cast<const Quad<E>*>(X + off);
-                    float vv[4] = {acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
-                                   acc[p][g * 4 + 3] + bv.w};
+                    float vv[4] = {acc[cp][g * 4 + 0] + bv.x, acc[cp][g * 4 + 1] + bv.y, acc[cp][g * 4 + 2] + bv.z,
+                                   acc[cp][g * 4 + 3] + bv.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) vv[i] += (float)sh.e[i];
                     if (PARTS == 2) {
@@ -1694,13 +1705,13 @@ extern "C" int cz_input_conv(const void* planes, int planes_dtype, int in_planes
 }
 
 namespace {
-template <typename E, int C, int PARTS, int P, bool HEADS = false>
+template <typename E, int C, int PARTS, int P, bool HEADS = false, int CTW = 1>
 int launch_resblock(const void* xh, const void* xl, const void* w1, const float* b1, const void* w2, const float* b2,
                     void* yh, void* yl, float* yf, int n, int n_cu, hipStream_t st, HeadArgs hd = HeadArgs{})
 {
     const int tiles = (n + P - 1) / P;
     const unsigned blocks = (unsigned)(tiles < n_cu ? tiles : n_cu);
-    hipLaunchKernelGGL((k_resblock<E, C, PARTS, P, HEADS>), dim3(blocks), dim3((C / 32 + 4) * 64), 0, st,
+    hipLaunchKernelGGL((k_resblock<E, C, PARTS, P, HEADS, CTW>), dim3(blocks), dim3((C / 32 / CTW + 4) * 64), 0, st,
                        (const E*)xh, (const E*)xl, (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, yf, n, hd,
                        g_q.n_dev);
     return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
@@ -1732,6 +1743,9 @@ int dispatch_resblock(int channels, int parts, const void* xh, const void* xl, c
     }
     if (channels == 128 && parts == 1) return launch_resblock<E, 128, 1, 2>(CZ_RB_ARGS);
     if (channels == 192 && parts == 1) return launch_resblock<E, 192, 1, 1>(CZ_RB_ARGS);
+    // 256 filters, plain operands: two channel tiles per matrix wave (4 + 4 waves), see conv_kloop; the tuning hook's
+    // 0 keeps the one-tile schedule (8 + 4 waves) for A/B runs
+    if (channels == 256 && parts == 1 && g_resblock_pipelined) return launch_resblock<E, 256, 1, 1, false, 2>(CZ_RB_ARGS);
     if (channels == 256 && parts == 1) return launch_resblock<E, 256, 1, 1>(CZ_RB_ARGS);
 #undef CZ_RB_ARGS
     return CZ_ERR_ARG;

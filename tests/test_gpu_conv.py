@@ -115,6 +115,34 @@ def test_resblock_equals_two_convolutions(c, dt, parts, n):
     assert all(torch.equal(a, b) for a, b in zip(xi, want))
 
 
+@pytest.mark.parametrize("dt", ["float16", "bfloat16"])
+def test_resblock_256_two_channel_tiles_per_wave_is_bit_identical(dt):
+    """256 filters, plain operands (BASELINE configs[4] 'deep'): the default schedule gives every matrix wave two
+    channel tiles (half the LDS reads per MFMA); the tuning hook's 0 selects the one-tile schedule.  Same MFMA order per
+    accumulator, so the results must be identical bit for bit."""
+    import torch
+    from cchess_alphazero import _native
+    dtype = getattr(torch, dt)
+    c = 256
+    g = torch.Generator(device="cuda").manual_seed(11)
+    ws = [torch.randn((c, c, 3, 3), device="cuda", generator=g) / (3.0 * c ** 0.5) for _ in range(2)]
+    bs = [torch.randn((c,), device="cuda", generator=g) for _ in range(2)]
+    ps = [_native.pack_conv3x3_weights(w, dtype, 1).cuda() for w in ws]
+    old = _native.resblock_pipelined(None)
+    try:
+        for n in (1, 2, 255, 513, 1500):
+            xs = _split(torch.randn((n, 90, c), device="cuda", generator=g).relu(), dtype, 1)
+            outs = {}
+            for mode in (False, True):
+                _native.resblock_pipelined(mode)
+                y = (torch.full_like(xs[0], 7.0),)
+                _native.resblock(xs, ps[0], bs[0], ps[1], bs[1], out=y)
+                outs[mode] = y[0]
+            assert torch.equal(outs[True], outs[False]), n
+    finally:
+        _native.resblock_pipelined(old)
+
+
 @pytest.mark.parametrize("n,npol", [(1, 4), (5, 2), (300, 4)])
 def test_resblock_heads_equals_resblock_then_head_convs(n, npol):
     """cz_resblock_heads = cz_resblock (fp32 out) followed by cz_head_convs; only the summation order of the 128-term
