@@ -1,0 +1,135 @@
+"""Runs in its OWN process (tests/test_oracle_live_reference.py starts it): imports the reference from /root/reference
+-- whose package name, cchess_alphazero, is also the name of this repository's host package, so the two must not share
+an interpreter -- and compares the oracle's restatement with the reference's own functions on freshly drawn positions.
+
+    python tests/live_reference_check.py rules   SEED GAMES MAX_PLIES CAPTURE_BIAS
+    python tests/live_reference_check.py history SEED GAMES MAX_PLIES CAPTURE_BIAS
+    python tests/live_reference_check.py mcts    SEED N_POSITIONS SIMS
+
+Exit status 0 and a line "ok <mode> <count>" when everything matched; an AssertionError names the first difference.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(REF, "cchess_alphazero"))
+sys.path.insert(0, REF)
+
+import cchess_alphazero.environment.static_env as senv  # noqa: E402  (the REFERENCE's)
+import xq_oracle as xo  # noqa: E402
+
+
+def playout_positions(seed, games, max_plies, capture_bias):
+    """Random playouts with the reference's own move generator; positions are always 'red to move' strings, as everywhere
+    in the reference (step() flips the board)."""
+    rng = random.Random(seed)
+    out = []
+    for _ in range(games):
+        state = senv.INIT_STATE
+        hist = [state]
+        for _ply in range(max_plies):
+            moves = senv.get_legal_moves(state)
+            if not moves or senv.done(state)[0]:
+                break
+            out.append((state, list(hist)))
+            board = senv.state_to_board(state)
+            captures = [m for m in moves if board[int(m[3])][int(m[2])] != '.']
+            mv = rng.choice(captures) if captures and rng.random() < capture_bias else rng.choice(moves)
+            state = senv.step(state, mv)
+            hist.append(mv)
+            hist.append(state)
+    return out
+
+
+def check_rules(seed, games, max_plies, capture_bias):
+    positions = playout_positions(seed, games, max_plies, capture_bias)
+    rng = random.Random(seed + 1)
+    for state, _ in positions:
+        moves = senv.get_legal_moves(state)
+        assert xo.get_legal_moves(state) == moves, state
+        want = senv.done(state, need_check=True)
+        got = xo.done(state, need_check=True)
+        assert (bool(got[0]), int(got[1]), got[2], bool(got[3])) == \
+               (bool(want[0]), int(want[1]), want[2], bool(want[3])), state
+        assert np.array_equal(np.asarray(xo.state_to_planes(state), dtype=np.float32),
+                              senv.state_to_planes(state).astype(np.float32)), state
+        assert xo.fliped_state(state) == senv.fliped_state(state)
+        assert bool(xo.has_attack_chessman(state)) == bool(senv.has_attack_chessman(state)), state
+        for mv in moves:
+            try:
+                w = senv.new_step(state, mv)
+            except ValueError:
+                w = None                       # the reference raises when a king is captured (static_env.py:93-95)
+            try:
+                g = xo.new_step(state, mv)
+            except ValueError:
+                g = None
+            assert (g is None) == (w is None), (state, mv)
+            if w is not None:
+                assert g[0] == w[0] and bool(g[1]) == bool(w[1]), (state, mv)
+        for mv in rng.sample(moves, min(4, len(moves))):
+            assert bool(xo.will_check_or_catch(state, mv)) == bool(senv.will_check_or_catch(state, mv)), (state, mv)
+            assert bool(xo.be_catched(state, mv)) == bool(senv.be_catched(state, mv)), (state, mv)
+    return len(positions)
+
+
+def check_history(seed, games, max_plies, capture_bias):
+    positions = playout_positions(seed, games, max_plies, capture_bias)
+    for state, hist in positions:
+        want = senv.state_history_to_planes(state, hist)
+        got = np.asarray(xo.state_history_to_planes(state, hist), dtype=np.float32)
+        assert got.shape == want.shape and np.array_equal(got, want.astype(np.float32)), (state, len(hist))
+    return len(positions)
+
+
+def check_mcts(seed, n_positions, sims):
+    """The reference's CChessPlayer (search_threads = 1, no noise, tests/stub_net.py as the network) against the oracle's
+    search on positions drawn here: action, visit counts, W (float64 bits) and priors (float32 bits) of every root edge."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_mcts as gm              # configuration / stub helpers of the golden generator (patches sleep)
+    import stub_net
+    ref_player = gm.ref_player
+    np.random.dirichlet = lambda alpha, size=None: np.full(len(alpha), 1.0 / len(alpha))
+    positions = playout_positions(seed, 6, 70, 0.3)
+    rng = random.Random(seed)
+    picked = rng.sample(positions, n_positions)
+    for i, (state, _) in enumerate(picked):
+        spec = dict(kind="hash", salt=seed + i)
+        c_puct, vl = (1.5, 3) if i % 2 == 0 else (5.0, 1)
+        cfg = gm.make_cfg(sims, c_puct=c_puct, vl=vl)
+        pipe = stub_net.StubPipe(gm.stub_fn(spec))
+        pl = ref_player.CChessPlayer(cfg, search_tree=None, pipes=pipe, enable_resign=False, debugging=False)
+        action, _policy = pl.action(state, 0, None)
+        want = gm.root_stats(pl, state)
+        pl.close()
+        ocfg = xo.play_cfg(simulation_num_per_move=sims, search_threads=1, c_puct=c_puct, virtual_loss=vl)
+        op = xo.Player(ocfg, spec)
+        got_action, _ = op.action(state, 0)
+        st = op.node_stats(state)
+        op.close()
+        assert got_action == action, (state, got_action, action)
+        assert " ".join(xo.label_str(m) for m in st["moves"]) == want["moves"], state
+        assert [int(x) for x in st["n"]] == want["n"], (state, list(st["n"]), want["n"])
+        assert [float(x).hex() for x in st["w"]] == want["w_hex"], state
+        assert [float(np.float32(x)).hex() for x in st["p"]] == want["p_hex"], state
+    return len(picked)
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    xo.build()
+    if mode == "rules":
+        n = check_rules(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
+    elif mode == "history":
+        n = check_history(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
+    elif mode == "mcts":
+        n = check_mcts(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
+    else:
+        raise SystemExit("mode?")
+    print("ok", mode, n)

@@ -1,0 +1,49 @@
+"""The oracle against the REFERENCE ITSELF, imported live from /root/reference (build container only).
+
+The committed golden vectors (tests/golden/*.json) are fixed samples of the reference's behaviour; these tests draw
+NEW random positions (seeds below) and compare the oracle's restatement (oracle/xq_rules.c, oracle/xq_mcts.c through
+oracle/xq_oracle.py) with the reference's own functions on each of them:
+
+    get_legal_moves (order included)   static_env.py:256-321      done(need_check=True)        static_env.py:14-62
+    new_step for every legal move      static_env.py:77-108       state_to_planes / history    static_env.py:144-191
+    fliped_state                       static_env.py:131-142      has_attack_chessman          static_env.py:431-438
+    will_check_or_catch / be_catched   static_env.py:390-470      CChessPlayer.action (K = 1)  agent/player.py:139-330
+
+The comparison runs in a child process (tests/live_reference_check.py): the reference's package is called
+cchess_alphazero like this repository's host package.  /root/reference does not exist on the GPU box, so the tests
+SKIP there (and they are not gpu tests): the -m gpu suites compare the HIP kernels with the oracle and with the
+committed vectors, never with this import.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "cchess_alphazero")),
+                                reason="the reference checkout is only present in the build container")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run_check(*args, timeout=600):
+    r = subprocess.run([sys.executable, os.path.join(HERE, "live_reference_check.py")] + [str(a) for a in args],
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    last = r.stdout.strip().splitlines()[-1].split()
+    assert last[0] == "ok" and last[1] == args[0], r.stdout[-500:]
+    return int(last[2])
+
+
+@pytest.mark.parametrize("seed,games,max_plies,capture_bias", [(101, 40, 120, 0.3), (202, 30, 200, 0.7),
+                                                               (303, 40, 300, 0.9)])
+def test_rules_match_the_reference_on_fresh_random_positions(seed, games, max_plies, capture_bias):
+    assert run_check("rules", seed, games, max_plies, capture_bias) > 300
+
+
+def test_history_planes_match_the_reference():
+    assert run_check("history", 404, 10, 80, 0.5) > 100
+
+
+def test_search_matches_the_reference_player_on_fresh_positions():
+    assert run_check("mcts", 505, 16, 200) == 16
