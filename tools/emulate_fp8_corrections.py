@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""CPU emulation of candidate split arithmetics for the residual tower ("cheaper correction terms").
+
+The tower's 3 x 3 convolutions compute  w x  as  w_hi x_hi + w_lo x_hi + w_hi x_lo  on bf16 matrix instructions (three per
+product).  tools/mfma_mix.py measured that an fp16 main term + two block-scaled fp8 (e4m3, K = 64) correction MFMAs retires
+1.47x faster in the power-capped state.  This script answers the numerical half of the question on the CPU, layer by layer
+and end to end: with the operands rounded exactly as those instructions would see them, how far are policy / value from
+the float64 network?  (north_star tolerance: 1e-4; today's bf16x3 path: logit 2e-6, value 1e-7.)
+
+Operand models (activation x and folded filter w, both float32; blocks of 32 input channels share a power-of-two scale,
+the MX convention of v_mfma_scale_f32_32x32x64_f8f6f4):
+    bf16x3      x_hi = bf16(x), x_lo = bf16(x - x_hi), same for w; three exact products                       (today)
+    f16+fp8     x_hi = f16(x), x_lo8 = fp8(x - x_hi), x_hi8 = fp8(x);  w likewise;   w_hi x_hi + w_hi8 x_lo8 + w_lo8 x_hi8
+    f16+fp6     the same with e2m3 correction operands
+    f16 only    w_hi x_hi                                                                              (no corrections)
+Products and sums are evaluated in float64 (the instructions' own accumulation error is measured separately:
+tools/probes/mfma_mix_probe check -> 6e-5 of the sum of |terms| of a K = 64 fp8 block, i.e. 2^-26 of the main term).
+
+    python tools/emulate_fp8_corrections.py [--filters 128 --blocks 7 --positions 24]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "chinesechess-alphazero_amd"))
+sys.path.insert(0, ROOT)
+
+
+UNIFORM = False     # --uniform-scales: one power-of-two scale per tensor (what a constant scale operand gives) instead of per block
+
+
+def block_scaled(x, dim, fmt):
+    """Round x (float64 tensor) to `fmt` elements with one power-of-two scale per block of 32 along `dim`
+    (or per tensor with --uniform-scales: then the element format's own exponent range carries the dynamics)."""
+    x = x.movedim(dim, -1)
+    shp = x.shape
+    c = shp[-1]
+    assert c % 32 == 0
+    xb = x.reshape(*shp[:-1], c // 32, 32)
+    emax = {"e4m3": 8, "e2m3": 2}[fmt]                     # largest binade of the element format (448 = 1.75 * 2^8; 7.5 = 1.875 * 2^2)
+    if UNIFORM:
+        amax = xb.abs().max().clamp_min(1e-300)
+    else:
+        amax = xb.abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)
+    scale = torch.exp2(torch.floor(torch.log2(amax)) - emax)
+    y = xb / scale
+    if fmt == "e4m3":
+        q = y.clamp(-448.0, 448.0).to(torch.float32).to(torch.float8_e4m3fn).to(torch.float64)      # MX: saturating
+    else:                                                   # e2m3: sign, 2 exponent bits (bias 1), 3 mantissa bits; max 7.5, subnormal step 0.125
+        a = y.abs().clamp_max(7.5)
+        e = torch.floor(torch.log2(a.clamp_min(1e-300))).clamp(min=0.0, max=2.0)
+        step = torch.exp2(e - 3)
+        q = torch.sign(y) * torch.round(a / step) * step    # (round-half-even of torch.round on the grid)
+    return (q * scale).reshape(shp).movedim(-1, dim)
+
+
+def conv_model(x, w, b, mode, pad):
+    """x [n, c, 10, 9] float64 (exact activations of the previous layer as the kernel would hold them), w [o, c, k, k]."""
+    conv = lambda a, ww: F.conv2d(a, ww, None, padding=pad)
+    if mode == "f64":
+        y = conv(x, w)
+    elif mode == "bf16x3":
+        xh = x.to(torch.float32).to(torch.bfloat16).to(torch.float64)
+        xl = (x - xh).to(torch.float32).to(torch.bfloat16).to(torch.float64)
+        wh = w.to(torch.float32).to(torch.bfloat16).to(torch.float64)
+        wl = (w - wh).to(torch.float32).to(torch.bfloat16).to(torch.float64)
+        y = conv(xh, wh) + conv(xh, wl) + conv(xl, wh)
+    else:
+        xh = x.to(torch.float32).to(torch.float16).to(torch.float64)
+        wh = w.to(torch.float32).to(torch.float16).to(torch.float64)
+        y = conv(xh, wh)
+        if mode != "f16":
+            fmt = "e4m3" if mode == "f16+fp8" else "e2m3"
+            xl8 = block_scaled(x - xh, 1, fmt)
+            xh8 = block_scaled(x, 1, fmt)
+            wl8 = block_scaled(w - wh, 1, fmt)
+            wh8 = block_scaled(w, 1, fmt)
+            y = y + conv(xl8, wh8) + conv(xh8, wl8)
+    return y + b.view(1, -1, 1, 1)
+
+
+def stored(x, mode):
+    """The activation as the NEXT layer / the skip connection reads it back: the kernels keep (hi, lo) pairs."""
+    if mode == "f64":
+        return x
+    if mode == "bf16x3":
+        xh = x.to(torch.float32).to(torch.bfloat16).to(torch.float64)
+        return xh + (x - xh).to(torch.float32).to(torch.bfloat16).to(torch.float64)
+    xh = x.to(torch.float32).to(torch.float16).to(torch.float64)
+    if mode == "f16":
+        return xh
+    return xh + block_scaled(x - xh, 1, "e4m3" if mode == "f16+fp8" else "e2m3")
+
+
+def run(net, planes, mode):
+    from cchess_alphazero.agent.model import _fold
+    d = torch.float64
+    with torch.no_grad():
+        ic = _fold(net.input_conv, net.input_bn)
+        x = F.relu(F.conv2d(planes.to(d), ic.weight.to(d), ic.bias.to(d), padding=ic.padding))     # input layer: exact fp32 gather in the engine
+        x = stored(x.to(torch.float32).to(d), mode)
+        for blk in net.res:
+            c1, c2 = _fold(blk.conv1, blk.bn1), _fold(blk.conv2, blk.bn2)
+            y = F.relu(conv_model(x, c1.weight.to(d), c1.bias.to(d), mode, 1)).to(torch.float32).to(d)   # fp32 accumulators
+            y = stored(y, mode)
+            z = conv_model(y, c2.weight.to(d), c2.bias.to(d), mode, 1).to(torch.float32).to(d)
+            x = stored(F.relu(z + x).to(torch.float32).to(d), mode)
+        pc, vc = _fold(net.policy_conv, net.policy_bn), _fold(net.value_conv, net.value_bn)
+        p = F.relu(F.conv2d(x, pc.weight.to(d), pc.bias.to(d)))
+        logits = F.linear(p.flatten(1), net.policy_out.weight.to(d), net.policy_out.bias.to(d))
+        v = F.relu(F.conv2d(x, vc.weight.to(d), vc.bias.to(d)))
+        v = F.relu(F.linear(v.flatten(1), net.value_dense.weight.to(d), net.value_dense.bias.to(d)))
+        vpre = F.linear(v, net.value_out.weight.to(d), net.value_out.bias.to(d)).squeeze(1)
+        v = torch.tanh(vpre)
+    return x, logits, F.softmax(logits, dim=1), v, vpre
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--filters", type=int, default=128)
+    ap.add_argument("--blocks", type=int, default=7)
+    ap.add_argument("--positions", type=int, default=24)
+    ap.add_argument("--seed", type=int, default=11)
+    ap.add_argument("--peaked", type=float, default=1.0, help="scale of the policy layer's weights (sharper softmax)")
+    ap.add_argument("--uniform-scales", action="store_true")
+    a = ap.parse_args()
+    global UNIFORM
+    UNIFORM = a.uniform_scales
+    from cchess_alphazero.agent.model import CChessNet
+    import oracle.xq_oracle as xo
+    torch.manual_seed(a.seed)
+    net = CChessNet(cnn_filter_num=a.filters, res_layer_num=a.blocks)
+    for m in net.modules():                                  # the perturbed BatchNorm statistics of the GPU numerics tests
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.normal_(1, 0.2)
+            m.bias.data.normal_(0, 0.2)
+    net.policy_out.weight.data.mul_(a.peaked)
+    net.eval()
+    rng = np.random.default_rng(a.seed)
+    boards, state = [], xo.INIT_STATE
+    while len(boards) < a.positions:                         # a random playout's positions
+        mv = xo.get_legal_moves(state)
+        if not mv or xo.done(state)[0]:
+            state = xo.INIT_STATE
+            continue
+        boards.append(xo.state_to_board(state))
+        state = xo.step(state, mv[rng.integers(len(mv))])
+    planes = torch.from_numpy(np.stack([xo.planes_board(b) for b in boards]))
+    ref = run(net, planes, "f64")
+    out = {"uniform_scales": UNIFORM, "filters": a.filters, "blocks": a.blocks, "positions": a.positions, "policy_scale": a.peaked,
+           "max_policy_probability": float(ref[2].max()), "value_range": [float(ref[3].min()), float(ref[3].max())],
+           "value_preactivation_range": [float(ref[4].min()), float(ref[4].max())], "modes": {}}
+    for mode in ("bf16x3", "f16+fp8", "f16+fp6", "f16"):
+        x, lg, p, v, vpre = run(net, planes, mode)
+        c = lambda t: t - t.mean(1, keepdim=True)
+        out["modes"][mode] = {
+            "trunk_rel_err": float((x - ref[0]).norm() / ref[0].norm()),
+            "logit_max_abs": float((c(lg) - c(ref[1])).abs().max()),
+            "policy_max_abs": float((p - ref[2]).abs().max()),
+            "value_max_abs": float((v - ref[3]).abs().max()),
+            "value_preactivation_max_abs": float((vpre - ref[4]).abs().max())}
+        print(mode, out["modes"][mode], flush=True)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
