@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CZ_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libczero.so")   # CZ_LIB: A/B builds (tools/ab_search.sh)
 
 NSQ, NLABELS, MAXMOVES, NOMOVE = 90, 2086, 128, 0xFFFF
-F32, F16, BF16, U8 = 0, 1, 2, 3
+F32, F16, BF16, U8, F16C8 = 0, 1, 2, 3, 4
 
 _lib = None
 
@@ -82,6 +82,13 @@ def _declare(L):
         L.cz_resblock.restype = i32
         L.cz_split_bias_act.argtypes = [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, vp]
         L.cz_split_bias_act.restype = i32
+    if hasattr(L, "cz_conv3x3_c8"):
+        L.cz_conv3x3_c8_packed_bytes.argtypes = [i32]
+        L.cz_conv3x3_c8_packed_bytes.restype = C.c_size_t
+        L.cz_conv3x3_c8_pack_weights.argtypes = [vp, i32, vp]
+        L.cz_conv3x3_c8_pack_weights.restype = i32
+        L.cz_conv3x3_c8.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+        L.cz_conv3x3_c8.restype = i32
     if hasattr(L, "cz_input_resblock"):
         L.cz_input_resblock.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
         L.cz_input_resblock.restype = i32
@@ -237,6 +244,15 @@ def bias_act_(x, bias, residual=None, relu=True):
     return x
 
 
+def _pair_code(x):
+    """dtype code of an operand tuple: (f16, uint8 c8 image) is the prototype arithmetic's pair (CZ_F16C8)."""
+    import torch
+    if len(x) == 2 and x[1].dtype == torch.uint8:
+        assert x[0].dtype == torch.float16 and x[1].shape[-1] == 2 * x[0].shape[-1]
+        return F16C8
+    return _dt_code(x[0].dtype)
+
+
 def _dt_code(dtype):
     import torch
     global _DT_CODE
@@ -262,6 +278,54 @@ def pack_conv3x3_weights(w_oihw, dtype, parts):
     out = torch.empty((n,), dtype=dtype)
     check(lib().cz_conv3x3_pack_weights(_ptr(w), c, _dt_code(dtype), parts, _ptr(out)), "cz_conv3x3_pack_weights")
     return out
+
+
+# ---- prototype arithmetic: fp16 main term + two scaled-fp8 correction terms (csrc/xq_conv.hip, k_conv3x3_c8) -------------
+C8_X_LO_SHIFT = 11
+
+
+def pack_conv3x3_c8_weights(w_oihw):
+    """fp32 [128, 128, 3, 3] filter -> packed bytes (f16 fragments, e4m3 correction fragments, the two scale exponents)."""
+    import torch
+    w = w_oihw.detach().to("cpu", torch.float32).contiguous()
+    c = w.shape[0]
+    n = lib().cz_conv3x3_c8_packed_bytes(c)
+    if n == 0:
+        raise NativeError(f"cz_conv3x3_c8: unsupported channels={c}")
+    out = torch.empty((n,), dtype=torch.uint8)
+    check(lib().cz_conv3x3_c8_pack_weights(_ptr(w), c, _ptr(out)), "cz_conv3x3_c8_pack_weights")
+    return out
+
+
+def split_c8(x):
+    """fp32 [N, 90, C] -> (x_hi f16 [N, 90, C], x_c8 uint8 [N, 90, 2C]): the operand pair of cz_conv3x3_c8
+    (x_c8 = e4m3(x_lo * 2^11) for the C channels, then e4m3(x) for them; saturating at 448)."""
+    import torch
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()) * float(2 ** C8_X_LO_SHIFT)
+    l8 = lo.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    h8 = x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    return hi.contiguous(), torch.cat([l8, h8], dim=-1).contiguous()
+
+
+def conv3x3_c8(x, w_packed, bias, skip=None, out=None, out_f32=None, relu=True):
+    """x, skip, out: pairs (hi f16 [N, 90, C], c8 uint8 [N, 90, 2C]); out_f32: fp32 [N, 90, C] instead of `out`."""
+    require_gpu()
+    n, c = x[0].shape[0], x[0].shape[-1]
+    assert x[1].shape[-1] == 2 * c
+    sh, sc = (skip[0], skip[1]) if skip is not None else (None, None)
+    yh, yc = (out[0], out[1]) if out is not None else (None, None)
+    check(lib().cz_conv3x3_c8(_ptr(x[0]), _ptr(x[1]), _ptr(w_packed), _ptr(bias), _ptr(sh), _ptr(sc), _ptr(yh), _ptr(yc),
+                              _ptr(out_f32), n, c, int(relu), _stream()), "cz_conv3x3_c8")
+    return out_f32 if out_f32 is not None else out
+
+
+def join_c8(pair):
+    """The fp32 value an operand pair stands for: hi + e4m3(lo) * 2^-11."""
+    import torch
+    c = pair[0].shape[-1]
+    l8 = pair[1][..., :c].contiguous().view(torch.float8_e4m3fn).float()
+    return pair[0].float() + l8 * float(2.0 ** -C8_X_LO_SHIFT)
 
 
 def conv3x3(x, w_packed, bias, skip=None, out=None, out_f32=None, relu=True):
@@ -383,7 +447,7 @@ def resblock(x, w1_packed, bias1, w2_packed, bias2, out=None, out_f32=None, coun
     yh = out[0] if out is not None else None
     yl = out[1] if out is not None and parts == 2 else None
     check(lib().cz_resblock_q(_ptr(xh), _ptr(xl), _ptr(w1_packed), _ptr(bias1), _ptr(w2_packed), _ptr(bias2),
-                              _ptr(yh), _ptr(yl), _ptr(out_f32), n, c, _dt_code(xh.dtype), parts, _ptr(count),
+                              _ptr(yh), _ptr(yl), _ptr(out_f32), n, c, _pair_code(x), parts, _ptr(count),
                               _stream()), "cz_resblock")
     return out_f32 if out_f32 is not None else out
 
@@ -405,7 +469,7 @@ def resblock_heads(x, w1_packed, bias1, w2_packed, bias2, head_w, head_b, n_poli
     xh, xl = x
     check(lib().cz_resblock_heads_q(_ptr(xh), _ptr(xl), _ptr(w1_packed), _ptr(bias1), _ptr(w2_packed), _ptr(bias2),
                                     _ptr(head_w), _ptr(head_b), _ptr(policy_feat), _ptr(value_feat), xh.shape[0],
-                                    xh.shape[-1], _dt_code(xh.dtype), n_policy, head_w.shape[0] - n_policy,
+                                    xh.shape[-1], _pair_code(x), n_policy, head_w.shape[0] - n_policy,
                                     _ptr(count), _stream()), "cz_resblock_heads")
     return policy_feat, value_feat
 

@@ -35,6 +35,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <stdio.h>
+#include <math.h>
 #include "../../include/czero.h"
 
 extern "C" void czi_set_error(const char* msg);
@@ -336,6 +337,233 @@ __global__ __launch_bounds__(C / 32 * 64, MINW) void k_conv3x3(
     }
 }
 
+// ---- prototype of the next tower arithmetic: fp16 main term + two block-scaled fp8 correction terms ("c8") -----------
+// The tower is bound by the socket's power cap and spends three bf16 MFMAs per product.  With an fp16 main
+// term (11 bits) the correction terms  w_hi x_lo  and  w_lo x_hi  need four significant bits, which is what an e4m3 operand
+// holds:   w x  ~  f16(w) f16(x)  +  e4m3(w) e4m3(x - f16(x))  +  e4m3(w - f16(w)) e4m3(x)
+// as v_mfma_f32_32x32x16_f16 + 2 x v_mfma_scale_f32_32x32x64_f8f6f4 per 64 input channels: 2.0 instead of 3.0 MFMA-equivalents
+// per product (measured 1.47x in register-resident loops, profiles/r03_fp8_corrections_study.json; per-product accuracy
+// 2^-16, policy within 2e-5 of float64 in the emulated 7 x 128 network, same file).  This kernel is the single-convolution
+// form (cz_conv3x3_c8): it pins the operand format, the fragment maps and the scale plumbing on hardware and measures the
+// K loop against k_conv3x3 with split bf16 operands; the residual-block kernels still run the bf16 arithmetic.
+//   operands: x_hi f16 [n][90][C];  x_c8 bytes [n][90][2C] = e4m3(x_lo * 2^11) for the C channels, then e4m3(x) for them
+//   LDS:      part 0 = x_hi rows, part 1 = x_c8 rows (same 2C bytes per pixel: the image code of the split kernels serves)
+//   weights:  f16 fragments as in cz_conv3x3_pack_weights, then per (tap, 64-channel block, kind) two 16-byte pieces per
+//             lane: kind 0 = e4m3(w * 2^sh) (meets x_lo), kind 1 = e4m3((w - f16(w)) * 2^sl) (meets e4m3(x)); lane l holds
+//             output channel l % 32, input channels 32 (l / 32) .. + 31 of the block -- the same k map as the pixels;
+//             the power-of-two scales sh, sl follow the fragments
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+namespace cf8 {
+constexpr int X_LO_SHIFT = 11;        // x_lo8 = e4m3(x_lo * 2^11): |x_lo| <= 2^-12 |x|, so |x| up to 2^9 stays below e4m3's 448
+constexpr float X_LO_SCALE = 2048.0f, X_LO_INV = 1.0f / 2048.0f;
+__device__ __forceinline__ float sat(float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); }   // e4m3's range
+// four fp32 values -> the operand triple: f16(v), e4m3((v - f16(v)) * 2^11), e4m3(v)   (round to nearest even, saturating)
+struct Split4 {
+    Quad<_Float16> hi;
+    uint32_t l8, h8;
+};
+__device__ __forceinline__ Split4 split4(const float* v)
+{
+    Split4 s;
+    float lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s.hi.e[i] = (_Float16)v[i];
+        lo[i] = sat((v[i] - (float)s.hi.e[i]) * X_LO_SCALE);
+    }
+    int l = 0, h = 0;
+    l = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], l, false);
+    l = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], l, true);
+    h = __builtin_amdgcn_cvt_pk_fp8_f32(sat(v[0]), sat(v[1]), h, false);
+    h = __builtin_amdgcn_cvt_pk_fp8_f32(sat(v[2]), sat(v[3]), h, true);
+    s.l8 = (uint32_t)l;
+    s.h8 = (uint32_t)h;
+    return s;
+}
+// the value an operand pair stands for (skip connection): f16 + lo8 * 2^-11
+__device__ __forceinline__ void add_pair4(float* v, Quad<_Float16> hi, uint32_t l8)
+{
+    v[0] += (float)hi.e[0] + __builtin_amdgcn_cvt_f32_fp8((int)l8, 0) * X_LO_INV;
+    v[1] += (float)hi.e[1] + __builtin_amdgcn_cvt_f32_fp8((int)l8, 1) * X_LO_INV;
+    v[2] += (float)hi.e[2] + __builtin_amdgcn_cvt_f32_fp8((int)l8, 2) * X_LO_INV;
+    v[3] += (float)hi.e[3] + __builtin_amdgcn_cvt_f32_fp8((int)l8, 3) * X_LO_INV;
+}
+// where the c8 weight fragments and the two scale exponents sit behind the f16 fragments of a packed filter
+template <int C> struct Pack {
+    static constexpr size_t MAIN_U4 = (size_t)(9 * (C / 16) + W_PAD_STEPS) * (C / 32) * 64;
+    static constexpr size_t C8_U4 = (size_t)(9 * (C / 64) + 1) * 2 * (C / 32) * 2 * 64;
+};
+}  // namespace cf8
+
+template <int C, int P>
+__device__ __forceinline__ void conv_kloop_c8(const unsigned char* region, const uint4* wq, const uint4* wc, int lane,
+                                              f32x16* acc, int scale_w_hi, int scale_w_lo)
+{
+    typedef Geom<C, P, 2> G;
+    typedef Mfma<_Float16>::V8 V8;
+    constexpr int NT = G::NT, KK = G::KK, W_RING = G::W_RING, NB = C / 64, CT = G::CT;
+    static_assert(G::POW2 && G::SWZ == 15 && KK % 4 == 0 && NB % 2 == 0, "128 / 256 filters");
+    const int kb = lane >> 5, ln = lane & 31;
+    int pre[NT], pre_n[NT];
+    int qy[3], qx[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int q = t * 32 + ln;
+        qy[t] = q < 90 ? q / 9 : 100;
+        qx[t] = q - (q / 9) * 9;
+    }
+    auto tap_row = [&](int dy, int dx, int p) {
+        const int t = p % 3;
+        const bool ok = (unsigned)(qy[t] + dy) < 10u && (unsigned)(qx[t] + dx) < 9u;
+        const int nominal = (p / 3) * 90 + t * 32 + ln + dy * 9 + dx;
+        const int row = ok ? nominal : G::ZROW + (nominal & 15);
+        return row * G::RB + (((kb ^ nominal) & G::SWZ) << 4);
+    };
+    // c8 piece h of (kind q, block b): chunk q * CPR/2 + 4 b + 2 kb + h of the row; pre[] already holds row * RB + ((kb ^ key) << 4)
+    const int lane_c = (kb * 3) << 4;
+    auto load_c8 = [&](int pre_p, int q, int b, int h) {
+        const int off = pre_p ^ lane_c ^ ((q * (G::CPR / 2) + 4 * b + h) << 4);
+        return *reinterpret_cast<const uint4*>(region + G::PART_BYTES + off);
+    };
+    auto load_px = [&](int off) { return __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(region + off)); };
+    auto load_w = [&](int step) { return __builtin_bit_cast(V8, wq[(size_t)step * G::W_STEP]); };
+    auto load_wc = [&](int blk, int q, int h) { return wc[(size_t)((blk * 2 + q) * CT * 2 + h) * 64]; };
+
+    V8 wf[W_RING];
+    V8 px[2][NT];
+    i32x8 cx[2][NT];
+    i32x8 wcr[2][2];                                   // [ring][kind]
+#pragma unroll
+    for (int p = 0; p < NT; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+#pragma unroll
+    for (int p = 0; p < NT; ++p) pre[p] = tap_row(-1, -1, p);
+#pragma unroll
+    for (int s = 0; s < W_RING - 1; ++s) wf[s] = load_w(s);
+#pragma unroll
+    for (int p = 0; p < NT; ++p) px[0][p] = load_px(pre[p]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint4 t = load_wc(0, q, h);
+            wcr[0][q][4 * h + 0] = t.x; wcr[0][q][4 * h + 1] = t.y; wcr[0][q][4 * h + 2] = t.z; wcr[0][q][4 * h + 3] = t.w;
+        }
+    const int scale_x_lo = 127 - cf8::X_LO_SHIFT, scale_one = 127;
+
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const int tn = tap < 8 ? tap + 1 : 8;
+        const int ndy = tn / 3 - 1, ndx = tn - (tn / 3) * 3 - 1;
+        constexpr int PER = (NT + KK - 2) / (KK - 1);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int blk = tap * NB + b;
+            // ---- the four fp16 K-steps of this 64-channel block; every MFMA slot also carries one LDS read of the next
+            //      K-step, one of this block's c8 pixel pieces, and (last tile) the weight loads
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int kk = b * 4 + k4, step = tap * KK + kk;
+                V8* bcur = px[kk & 1];
+                V8* bnxt = px[(kk + 1) & 1];
+                const int* rows = kk + 1 < KK ? pre : pre_n;
+                const int kn = (kk + 1) % KK;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    acc[i] = Mfma<_Float16>::mma(wf[kk % W_RING], bcur[i], acc[i]);
+                    bnxt[i] = load_px(G::kstep(rows[i], kn));
+                    {
+                        const int e = k4 * NT + i;                       // 0 .. 4 NT - 1 = the 2 x NT x 2 pieces of the block
+                        const int q = e / (2 * NT), tile = (e % (2 * NT)) / 2, h = e & 1;
+                        const uint4 t = load_c8(pre[tile], q, b, h);
+                        cx[q][tile][4 * h + 0] = t.x; cx[q][tile][4 * h + 1] = t.y;
+                        cx[q][tile][4 * h + 2] = t.z; cx[q][tile][4 * h + 3] = t.w;
+                    }
+                    if (i >= NT - PER && kk * PER + (i - (NT - PER)) < NT)
+                        pre_n[kk * PER + (i - (NT - PER))] = tap_row(ndy, ndx, kk * PER + (i - (NT - PER)));
+                    if (i == NT - 1) {
+                        wf[(kk + W_RING - 1) % W_RING] = load_w(step + W_RING - 1);
+                        const int q2 = k4 >> 1, h2 = k4 & 1;             // the next block's c8 filter pieces, one per K-step
+                        const uint4 t = load_wc(blk + 1, q2, h2);
+                        i32x8& d = wcr[(b + 1) & 1][q2];
+                        d[4 * h2 + 0] = t.x; d[4 * h2 + 1] = t.y; d[4 * h2 + 2] = t.z; d[4 * h2 + 3] = t.w;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- the block's correction terms: e4m3(w) x_lo8 and w_lo8 e4m3(x), K = 64 each
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wcr[b & 1][q], cx[q][i], acc[i], 0, 0, 0,
+                                                                              q ? scale_w_lo : scale_w_hi, 0,
+                                                                              q ? scale_one : scale_x_lo);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+#pragma unroll
+        for (int p = 0; p < NT; ++p) pre[p] = pre_n[p];
+    }
+}
+
+template <int C, int P>
+__global__ __launch_bounds__(C / 32 * 64, 1) void k_conv3x3_c8(
+    const _Float16* __restrict__ xh, const unsigned char* __restrict__ xc, const uint4* __restrict__ wp,
+    const float* __restrict__ bias, const _Float16* __restrict__ sh, const unsigned char* __restrict__ sc8,
+    _Float16* __restrict__ yh, unsigned char* __restrict__ yc, float* __restrict__ yf, int n_boards, int relu)
+{
+    typedef Geom<C, P, 2> G;
+    constexpr int NT = G::NT;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[G::REGION];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * P;
+    {
+        uint4 v[2][G::ITER];
+        tile_load<_Float16, C, P, 2>(xh, reinterpret_cast<const _Float16*>(xc), n0, n_boards, tid, v);
+        tile_write<C, P, 2>(lds, tid, v);
+        zero_rows_write<C, P, 2>(lds, tid);
+    }
+    __syncthreads();
+    const int* scl = reinterpret_cast<const int*>(wp + cf8::Pack<C>::MAIN_U4 + cf8::Pack<C>::C8_U4);
+    const int s_hi = __builtin_amdgcn_readfirstlane(scl[0]), s_lo = __builtin_amdgcn_readfirstlane(scl[1]);
+    f32x16 acc[NT];
+    conv_kloop_c8<C, P>(lds, wp + wave * 64 + lane, wp + cf8::Pack<C>::MAIN_U4 + (size_t)wave * 2 * 64 + lane, lane, acc,
+                        127 - s_hi, 127 - s_lo);
+
+    const int kb = lane >> 5, ln = lane & 31;
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+        const int q = (p % 3) * 32 + ln;
+        const int n = n0 + p / 3;
+        if (q >= 90 || n >= n_boards) continue;
+        const size_t pixel = (size_t)n * 90 + q;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = wave * 32 + g * 8 + kb * 4;
+            const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
+            float v[4] = {acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
+                          acc[p][g * 4 + 3] + bv.w};
+            if (sh)
+                cf8::add_pair4(v, *reinterpret_cast<const Quad<_Float16>*>(sh + pixel * C + ch),
+                              *reinterpret_cast<const uint32_t*>(sc8 + pixel * 2 * C + ch));
+            if (relu) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+            }
+            if (yf) {
+                *reinterpret_cast<float4*>(yf + pixel * C + ch) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                const cf8::Split4 o = cf8::split4(v);
+                *reinterpret_cast<Quad<_Float16>*>(yh + pixel * C + ch) = o.hi;
+                *reinterpret_cast<uint32_t*>(yc + pixel * 2 * C + ch) = o.l8;
+                *reinterpret_cast<uint32_t*>(yc + pixel * 2 * C + C + ch) = o.h8;
+            }
+        }
+    }
+}
+
 // ---- kernel 2: a whole residual block per launch, wave-specialised ---------------------------------------------------
 // y = relu(conv2(relu(conv1(x) + b1)) + b2 + x) for P boards at a time per workgroup, persistent over boards.
 // The intermediate activation never leaves LDS (it is written straight into a second operand image), the skip
@@ -363,13 +591,16 @@ struct HeadArgs {
     int n_pol;
 };
 
-template <typename E, int C, int PARTS, int P, bool HEADS = false, int CTW = 1>
+// C8: the prototype arithmetic of k_conv3x3_c8 (fp16 main term + two scaled-fp8 correction terms): E = _Float16, PARTS = 2,
+// the second operand part is the c8 image (e4m3 lo, e4m3 value), the packed filters are cz_conv3x3_c8_pack_weights'.
+template <typename E, int C, int PARTS, int P, bool HEADS = false, int CTW = 1, bool C8 = false>
 __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4) void k_resblock(
     const E* __restrict__ xh, const E* __restrict__ xl, const E* __restrict__ w1p, const float* __restrict__ b1,
     const E* __restrict__ w2p, const float* __restrict__ b2, E* __restrict__ yh, E* __restrict__ yl,
     float* __restrict__ yf, int n_boards, HeadArgs hd, const int32_t* __restrict__ n_dev)
 {
     static_assert(!HEADS || (PARTS == 2 && C / 8 == 16), "fused heads: split operands, 128 filters");
+    static_assert(!C8 || (PARTS == 2 && CTW == 1 && sizeof(E) == 2), "c8 arithmetic: fp16 operand pairs");
     if (n_dev) {                                        // compact queue: the board count lives on the device
         const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
         n_boards = nd < n_boards ? nd : n_boards;
@@ -459,6 +690,13 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
                             float4* o = reinterpret_cast<float4*>(yf + ebase) + 2 * i;
                             o[0] = f0;
                             o[1] = f1;
+                        } else if (C8) {
+                            const cf8::Split4 s0 = cf8::split4(r), s1 = cf8::split4(r + 4);
+                            struct alignas(16) H8 { Quad<_Float16> a, b; };
+                            reinterpret_cast<uint4*>(yh + ebase)[i] = __builtin_bit_cast(uint4, H8{s0.hi, s1.hi});
+                            unsigned char* row = reinterpret_cast<unsigned char*>(yl + ebase) + (size_t)qq * 2 * C + c8 * 8;
+                            *reinterpret_cast<uint2*>(row) = make_uint2(s0.l8, s1.l8);
+                            *reinterpret_cast<uint2*>(row + C) = make_uint2(s0.h8, s1.h8);
                         } else {
                             struct alignas(16) E8 { E e[8]; };
                             E8 hi, lo;
@@ -496,12 +734,23 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
     const uint4* wq1 = reinterpret_cast<const uint4*>(w1p) + wg * 64 + lane;
     const uint4* wq2 = reinterpret_cast<const uint4*>(w2p) + wg * 64 + lane;
     const int kb = lane >> 5, ln = lane & 31;
+    // c8 arithmetic: the correction fragments and the filters' two scale exponents behind the f16 fragments
+    const uint4* wc1 = reinterpret_cast<const uint4*>(w1p) + cf8::Pack<C>::MAIN_U4 + (size_t)wg * 2 * 64 + lane;
+    const uint4* wc2 = reinterpret_cast<const uint4*>(w2p) + cf8::Pack<C>::MAIN_U4 + (size_t)wg * 2 * 64 + lane;
+    int sc1h = 0, sc1l = 0, sc2h = 0, sc2l = 0;
+    if (C8) {
+        const int* a = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(w1p) + cf8::Pack<C>::MAIN_U4 + cf8::Pack<C>::C8_U4);
+        const int* b = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(w2p) + cf8::Pack<C>::MAIN_U4 + cf8::Pack<C>::C8_U4);
+        sc1h = 127 - __builtin_amdgcn_readfirstlane(a[0]); sc1l = 127 - __builtin_amdgcn_readfirstlane(a[1]);
+        sc2h = 127 - __builtin_amdgcn_readfirstlane(b[0]); sc2l = 127 - __builtin_amdgcn_readfirstlane(b[1]);
+    }
     for (;;) {
         __syncthreads();                                       // A
         const bool has_next = t + stride < n_tiles;
         f32x16 acc[CTW * NT];
         __builtin_amdgcn_s_setprio(3);
-        conv_kloop<E, C, P, PARTS, CTW>(X, wq1, lane, acc);
+        if constexpr (C8) conv_kloop_c8<C, P>(X, wq1, wc1, lane, acc, sc1h, sc1l);
+        else conv_kloop<E, C, P, PARTS, CTW>(X, wq1, lane, acc);
         __builtin_amdgcn_s_setprio(0);
         int ln2 = ln, kb2 = kb, gt2 = tid;
         asm volatile("" : "+v"(ln2), "+v"(kb2), "+v"(gt2));
@@ -518,6 +767,18 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
                     const float4 bv = *reinterpret_cast<const float4*>(b1 + ch);
                     const float vv[4] = {acc[cp][g * 4 + 0] + bv.x, acc[cp][g * 4 + 1] + bv.y, acc[cp][g * 4 + 2] + bv.z,
                                          acc[cp][g * 4 + 3] + bv.w};
+                    const int off = row * G::RB + (((ch >> 3) ^ (row & G::SWZ)) << 4) + (ch & 7) * 2;
+                    if constexpr (C8) {
+                        float r[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) r[i] = vv[i] > 0.0f ? vv[i] : 0.0f;
+                        const cf8::Split4 o = cf8::split4(r);
+                        *reinterpret_cast<Quad<_Float16>*>(Y + off) = o.hi;
+                        // c8 row: byte ch of the lo half, byte C + ch of the value half (16-byte chunks ch / 16 and CPR / 2 + ch / 16)
+                        unsigned char* crow = Y + G::PART_BYTES + row * G::RB + (ch & 15);
+                        *reinterpret_cast<uint32_t*>(crow + ((((ch >> 4)) ^ (row & G::SWZ)) << 4)) = o.l8;
+                        *reinterpret_cast<uint32_t*>(crow + (((G::CPR / 2 + (ch >> 4)) ^ (row & G::SWZ)) << 4)) = o.h8;
+                    } else {
                     Quad<E> hi, lo;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -525,15 +786,16 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
                         hi.e[i] = (E)r;
                         lo.e[i] = (E)(r - (float)hi.e[i]);
                     }
-                    const int off = row * G::RB + (((ch >> 3) ^ (row & G::SWZ)) << 4) + (ch & 7) * 2;
                     *reinterpret_cast<Quad<E>*>(Y + off) = hi;
                     if (PARTS == 2) *reinterpret_cast<Quad<E>*>(Y + G::PART_BYTES + off) = lo;
+                    }
                 }
             }
         }
         __syncthreads();                                       // B: Y complete
         __builtin_amdgcn_s_setprio(3);
-        conv_kloop<E, C, P, PARTS, CTW>(Y, wq2, lane, acc);
+        if constexpr (C8) conv_kloop_c8<C, P>(Y, wq2, wc2, lane, acc, sc2h, sc2l);
+        else conv_kloop<E, C, P, PARTS, CTW>(Y, wq2, lane, acc);
         __builtin_amdgcn_s_setprio(0);
         asm volatile("" : "+v"(ln2), "+v"(kb2));
         // epilogue 2: relu(acc + b2 + x) -> staging
@@ -551,12 +813,18 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
                     const Quad<E> sh = *reinterpret_cast<const Quad<E>*>(X + off);
                     float vv[4] = {acc[cp][g * 4 + 0] + bv.x, acc[cp][g * 4 + 1] + bv.y, acc[cp][g * 4 + 2] + bv.z,
                                    acc[cp][g * 4 + 3] + bv.w};
+                    if constexpr (C8) {
+                        const uint32_t l8 = *reinterpret_cast<const uint32_t*>(
+                            X + G::PART_BYTES + row * G::RB + (ch & 15) + (((ch >> 4) ^ (row & G::SWZ)) << 4));
+                        cf8::add_pair4(vv, __builtin_bit_cast(Quad<_Float16>, sh), l8);
+                    } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) vv[i] += (float)sh.e[i];
                     if (PARTS == 2) {
                         const Quad<E> sl = *reinterpret_cast<const Quad<E>*>(X + G::PART_BYTES + off);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) vv[i] += (float)sl.e[i];
+                    }
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) vv[i] = vv[i] > 0.0f ? vv[i] : 0.0f;
@@ -1570,6 +1838,113 @@ extern "C" int cz_conv3x3_pack_weights(const float* w_oihw, int channels, int dt
     return CZ_OK;
 }
 
+// ---- prototype arithmetic (k_conv3x3_c8): packing and launch ------------------------------------------------------------
+namespace {
+// float -> OCP e4m3 (bias 7, no infinities, 0x7f = NaN), round to nearest even, saturating at 448
+inline uint8_t f32_to_e4m3_bits(float f)
+{
+    uint32_t fb;
+    memcpy(&fb, &f, 4);
+    const uint8_t sign = (uint8_t)((fb >> 24) & 0x80);
+    float a = fabsf(f);
+    if (!(a == a)) return 0x7f;
+    if (a >= 448.0f) return sign | 0x7e;
+    if (a < ldexpf(1.0f, -10)) return sign;                        // below half the smallest subnormal (2^-9): 0 (tie -> even = 0)
+    int e;
+    frexpf(a, &e);
+    e -= 1;                                                        // a = m * 2^e, m in [1, 2)
+    if (e < -6) {                                                  // subnormal: multiples of 2^-9
+        const int q = (int)nearbyintf(ldexpf(a, 9));               // 0 .. 8 (8 = the smallest normal, code 0x08)
+        return sign | (uint8_t)q;
+    }
+    int m = (int)nearbyintf(ldexpf(a, 3 - e)) - 8;                 // 0 .. 8
+    if (m == 8) { m = 0; e += 1; }
+    if (e > 8 || (e == 8 && m > 6)) return sign | 0x7e;
+    return sign | (uint8_t)(((e + 7) << 3) | m);
+}
+inline int pow2_shift_for(float amax, int top)                     // s with amax * 2^s in [2^top, 2^(top + 1))
+{
+    if (!(amax > 0.0f)) return 0;
+    int e;
+    frexpf(amax, &e);
+    return top - (e - 1);
+}
+}  // namespace
+
+extern "C" size_t cz_conv3x3_c8_packed_bytes(int channels)
+{
+    if (channels != 128) return 0;
+    const size_t C = channels, KK = C / 16, CT = C / 32, NB = C / 64;
+    const size_t main_u4 = (9 * KK + W_PAD_STEPS) * CT * 64, c8_u4 = (9 * NB + 1) * 2 * CT * 2 * 64;
+    return (main_u4 + c8_u4 + 1) * 16;
+}
+
+extern "C" int cz_conv3x3_c8_pack_weights(const float* w_oihw, int channels, void* out_host)
+{
+    if (!w_oihw || !out_host || channels != 128) {
+        czi_set_error("cz_conv3x3_c8_pack_weights: bad argument (prototype: 128 filters)");
+        return CZ_ERR_ARG;
+    }
+    const int C = channels, KK = C / 16, CT = C / 32, NB = C / 64;
+    const size_t main_u4 = (size_t)(9 * KK + W_PAD_STEPS) * CT * 64, c8_u4 = (size_t)(9 * NB + 1) * 2 * CT * 2 * 64;
+    memset(out_host, 0, (main_u4 + c8_u4 + 1) * 16);
+    uint16_t* hi = (uint16_t*)out_host;
+    uint8_t* c8p = (uint8_t*)out_host + main_u4 * 16;
+    int32_t* sc = (int32_t*)((uint8_t*)out_host + (main_u4 + c8_u4) * 16);
+    float wmax = 0.0f, lmax = 0.0f;
+    for (size_t i = 0; i < (size_t)C * C * 9; ++i) {
+        const float w = w_oihw[i], l = w - f16_bits_to_f32(f32_to_f16_bits(w));
+        wmax = fabsf(w) > wmax ? fabsf(w) : wmax;
+        lmax = fabsf(l) > lmax ? fabsf(l) : lmax;
+    }
+    const int sh = pow2_shift_for(wmax, 7), sl = pow2_shift_for(lmax, 7);      // largest magnitude in [128, 256): below 448
+    sc[0] = sh;
+    sc[1] = sl;
+    for (int tap = 0; tap < 9; ++tap)
+        for (int ct = 0; ct < CT; ++ct)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int o = ct * 32 + (lane & 31);
+                for (int kk = 0; kk < KK; ++kk)
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = kk * 16 + (lane >> 5) * 8 + j;
+                        const float w = w_oihw[((size_t)o * C + c) * 9 + tap];
+                        hi[((((size_t)tap * KK + kk) * CT + ct) * 64 + lane) * 8 + j] = f32_to_f16_bits(w);
+                    }
+                for (int b = 0; b < NB; ++b)
+                    for (int q = 0; q < 2; ++q)
+                        for (int j = 0; j < 32; ++j) {
+                            const int c = b * 64 + (lane >> 5) * 32 + j;
+                            const float w = w_oihw[((size_t)o * C + c) * 9 + tap];
+                            const float v = q == 0 ? ldexpf(w, sh) : ldexpf(w - f16_bits_to_f32(f32_to_f16_bits(w)), sl);
+                            const size_t u4 = ((((size_t)(tap * NB + b) * 2 + q) * CT + ct) * 2 + j / 16) * 64 + lane;
+                            c8p[u4 * 16 + j % 16] = f32_to_e4m3_bits(v);
+                        }
+            }
+    return CZ_OK;
+}
+
+extern "C" int cz_conv3x3_c8(const void* x_hi, const void* x_c8, const void* w_packed, const float* bias,
+                             const void* skip_hi, const void* skip_c8, void* y_hi, void* y_c8, float* y_f32,
+                             int n_boards, int channels, int relu, void* stream)
+{
+    if (n_boards < 0 || !x_hi || !x_c8 || !w_packed || !bias || channels != 128 || (!y_f32 && (!y_hi || !y_c8)) ||
+        (skip_hi && !skip_c8)) {
+        czi_set_error("cz_conv3x3_c8: bad argument (128 filters; output: y_f32, or the operand pair y_hi + y_c8)");
+        return CZ_ERR_ARG;
+    }
+    if (n_boards == 0) return CZ_OK;
+    constexpr int P = 2;
+    hipLaunchKernelGGL((k_conv3x3_c8<128, P>), dim3((unsigned)((n_boards + P - 1) / P)), dim3(128 / 32 * 64), 0,
+                       (hipStream_t)stream, (const _Float16*)x_hi, (const unsigned char*)x_c8, (const uint4*)w_packed, bias,
+                       (const _Float16*)skip_hi, (const unsigned char*)skip_c8, (_Float16*)y_hi, (unsigned char*)y_c8,
+                       y_f32, n_boards, relu);
+    if (hipGetLastError() != hipSuccess) {
+        czi_set_error("cz_conv3x3_c8: launch failed");
+        return CZ_ERR_HIP;
+    }
+    return CZ_OK;
+}
+
 extern "C" int cz_conv3x3(const void* x_hi, const void* x_lo, const void* w_packed, const float* bias,
                           const void* skip_hi, const void* skip_lo, void* y_hi, void* y_lo, float* y_f32,
                           int n_boards, int channels, int dtype, int parts, int relu, void* stream)
@@ -1705,13 +2080,13 @@ extern "C" int cz_input_conv(const void* planes, int planes_dtype, int in_planes
 }
 
 namespace {
-template <typename E, int C, int PARTS, int P, bool HEADS = false, int CTW = 1>
+template <typename E, int C, int PARTS, int P, bool HEADS = false, int CTW = 1, bool C8 = false>
 int launch_resblock(const void* xh, const void* xl, const void* w1, const float* b1, const void* w2, const float* b2,
                     void* yh, void* yl, float* yf, int n, int n_cu, hipStream_t st, HeadArgs hd = HeadArgs{})
 {
     const int tiles = (n + P - 1) / P;
     const unsigned blocks = (unsigned)(tiles < n_cu ? tiles : n_cu);
-    hipLaunchKernelGGL((k_resblock<E, C, PARTS, P, HEADS, CTW>), dim3(blocks), dim3((C / 32 / CTW + 4) * 64), 0, st,
+    hipLaunchKernelGGL((k_resblock<E, C, PARTS, P, HEADS, CTW, C8>), dim3(blocks), dim3((C / 32 / CTW + 4) * 64), 0, st,
                        (const E*)xh, (const E*)xl, (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, yf, n, hd,
                        g_q.n_dev);
     return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
@@ -1775,7 +2150,7 @@ extern "C" int cz_resblock_heads(const void* x_hi, const void* x_lo, const void*
         return CZ_ERR_ARG;
     }
     if (n_boards == 0) return CZ_OK;
-    if (channels != 128 || (dtype != CZ_BF16 && dtype != CZ_F16)) {
+    if (channels != 128 || (dtype != CZ_BF16 && dtype != CZ_F16 && dtype != CZ_F16C8)) {
         czi_set_error("cz_resblock_heads: 128 filters, bf16 / f16 split operands only (use cz_resblock + cz_head_convs)");
         return CZ_ERR_ARG;
     }
@@ -1790,6 +2165,9 @@ extern "C" int cz_resblock_heads(const void* x_hi, const void* x_lo, const void*
     if (dtype == CZ_BF16)
         rc = launch_resblock<__bf16, 128, 2, 1, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, nullptr, nullptr,
                                                        nullptr, n_boards, n_cu, st, hd);
+    else if (dtype == CZ_F16C8)
+        rc = launch_resblock<_Float16, 128, 2, 1, true, 1, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, nullptr,
+                                                                   nullptr, nullptr, n_boards, n_cu, st, hd);
     else
         rc = launch_resblock<_Float16, 128, 2, 1, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, nullptr,
                                                          nullptr, nullptr, n_boards, n_cu, st, hd);
@@ -1820,6 +2198,9 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
     else if (dtype == CZ_F16)
         rc = dispatch_resblock<_Float16>(channels, parts, x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo,
                                          y_f32, n_boards, n_cu, st);
+    else if (dtype == CZ_F16C8 && channels == 128 && parts == 2)
+        rc = launch_resblock<_Float16, 128, 2, 1, false, 1, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, y_hi,
+                                                                    y_lo, y_f32, n_boards, n_cu, st);
     if (rc == CZ_ERR_ARG)
         czi_set_error("cz_resblock: supported: 128 / 192 filters (split or plain operands), 256 filters (plain), bf16 / f16; "
                       "use cz_conv3x3 otherwise");

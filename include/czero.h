@@ -46,6 +46,7 @@ extern "C" {
 #define CZ_F16 1
 #define CZ_BF16 2
 #define CZ_U8 3
+#define CZ_F16C8 4   /* fp16 operand + c8 correction image (cz_conv3x3_c8): the residual-block entry points only */
 
 int cz_version(void);
 const char* cz_last_error(void);
@@ -234,6 +235,19 @@ int cz_conv3x3(const void* x_hi, const void* x_lo, const void* w_packed, const f
 int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1, const void* w2_packed,
                 const float* bias2, void* y_hi, void* y_lo, float* y_f32, int n_boards, int channels, int dtype,
                 int parts, void* stream);
+/* Prototype of the next tower arithmetic (csrc/xq_conv.hip, k_conv3x3_c8): one 3x3 convolution, 128
+ * filters, computed as  f16(w) f16(x) + e4m3(w) e4m3(x - f16(x)) + e4m3(w - f16(w)) e4m3(x)  (one fp16 and two block-scaled
+ * fp8 matrix instructions per 64 input channels instead of three bf16 ones).  x_hi: f16 [n][90][128]; x_c8: bytes
+ * [n][90][256] = e4m3(x_lo * 2^11) for the 128 channels, then e4m3(x) for them; y = conv + bias (+ skip pair) (ReLU if
+ * relu), written as fp32 (y_f32) or as the operand pair (y_hi, y_c8).
+ * Not used by the network path (reference arithmetic there: Keras float32, agent/model.py:32-83): it exists to pin the
+ * operand format on hardware and to measure the K loop. */
+size_t cz_conv3x3_c8_packed_bytes(int channels);
+int cz_conv3x3_c8_pack_weights(const float* w_oihw, int channels, void* out_host);
+int cz_conv3x3_c8(const void* x_hi, const void* x_c8, const void* w_packed, const float* bias,
+                  const void* skip_hi, const void* skip_c8, void* y_hi, void* y_c8, float* y_f32,
+                  int n_boards, int channels, int relu, void* stream);
+
 /* test / tuning hook: the 128-filter split residual block with operand-pair output has two schedules that give
  * bit-identical results -- k_resblock_pipe (default, 1): epilogue 2 of a board runs under the next board's first K
  * loop; k_resblock (0).  enable < 0 only queries.  Returns the previous setting. */

@@ -115,6 +115,136 @@ def test_resblock_equals_two_convolutions(c, dt, parts, n):
     assert all(torch.equal(a, b) for a, b in zip(xi, want))
 
 
+@pytest.mark.parametrize("n", [1, 2, 5, 301])
+def test_conv3x3_c8_prototype_matches_its_operands_and_the_float64_convolution(n):
+    """cz_conv3x3_c8 (prototype of the next tower arithmetic: one fp16 and two scaled-fp8 matrix instructions per 64 input
+    channels).  (1) Against float64 arithmetic on EXACTLY the operand values the kernel is given (decoded fragments and
+    images): only the instructions' accumulation differs -- bounded by 1e-5 of the sum of |terms| of an output (the fp8
+    instruction accumulates to ~6e-5 of ITS terms, which are 2^-12 of the main ones).  (2) Against the float64
+    convolution of the unrounded tensors: the arithmetic's own error, which must stay in the class of the split-bf16
+    kernel's (both are checked on the same data)."""
+    import torch
+    import torch.nn.functional as F
+    from cchess_alphazero import _native
+    from test_c8_pack_cpu import decode_c8_pack
+    c = 128
+    g = torch.Generator(device="cuda").manual_seed(40 + n)
+    x = (torch.randn((n, 90, c), device="cuda", generator=g) * 1.5).relu()
+    x[0, 0, :4] = torch.tensor([300.0, 2e-3, 5e-5, 0.0], device="cuda")           # large / tiny activations
+    w = torch.randn((c, c, 3, 3), device="cuda", generator=g) / (3.0 * c ** 0.5)
+    bias = torch.randn((c,), device="cuda", generator=g)
+    packed = _native.pack_conv3x3_c8_weights(w)
+    x_hi, x_c8 = _native.split_c8(x)
+    out = torch.full((n, 90, c), 7.0, device="cuda")
+    _native.conv3x3_c8((x_hi, x_c8), packed.cuda(), bias, out_f32=out, relu=False)
+
+    d = torch.float64
+    img = lambda t: t.to(d).view(n, 10, 9, c).permute(0, 3, 1, 2)
+    conv = lambda a, ww: F.conv2d(a, ww, None, padding=1).permute(0, 2, 3, 1).reshape(n, 90, c)
+    w_hi, k0, k1, sh, sl = decode_c8_pack(packed)
+    tw = lambda a: torch.from_numpy(a).to("cuda", d).view(c, c, 3, 3)
+    l8 = x_c8[..., :c].contiguous().view(torch.float8_e4m3fn).to(d)
+    h8 = x_c8[..., c:].contiguous().view(torch.float8_e4m3fn).to(d)
+    main = conv(img(x_hi), tw(w_hi))
+    corr = conv(img(l8), tw(k0)) * 2.0 ** (-sh - _native.C8_X_LO_SHIFT) + conv(img(h8), tw(k1)) * 2.0 ** (-sl)
+    want_ops = main + corr + bias.to(d)
+    mag = conv(img(x_hi).abs(), tw(w_hi).abs()) + 1e-30
+    err_ops = ((out.to(d) - want_ops).abs() / mag).max().item()
+    assert err_ops < 1e-5, err_ops
+
+    exact = conv(img(x), w.to(d)) + bias.to(d)
+    mag_x = conv(img(x).abs(), w.to(d).abs())
+    err_c8 = ((out.to(d) - exact).abs() / mag_x).max().item()
+    ps = _native.pack_conv3x3_weights(w, torch.bfloat16, 2).cuda()
+    ref = torch.empty((n, 90, c), device="cuda")
+    _native.conv3x3(_split(x, torch.bfloat16, 2), ps, bias, out_f32=ref, relu=False)
+    err_bf16x3 = ((ref.to(d) - exact).abs() / mag_x).max().item()
+    assert err_c8 < 3e-5 and err_c8 < 16 * err_bf16x3 + 1e-6, (err_c8, err_bf16x3)
+    # ReLU flag
+    out2 = torch.empty_like(out)
+    _native.conv3x3_c8((x_hi, x_c8), packed.cuda(), bias, out_f32=out2, relu=True)
+    assert torch.equal(out2, out.relu())
+
+
+@pytest.mark.parametrize("n", [1, 3, 257])
+def test_conv3x3_c8_operand_pair_output_and_skip(n):
+    """The operand-pair output of cz_conv3x3_c8 is the split of its own fp32 output (device conversions = PyTorch's:
+    round to nearest even, saturating at 448), and the skip input adds the value the pair stands for."""
+    import torch
+    from cchess_alphazero import _native
+    c = 128
+    g = torch.Generator(device="cuda").manual_seed(70 + n)
+    x = (torch.randn((n, 90, c), device="cuda", generator=g) * 2.0).relu()
+    x[0, 1, :3] = torch.tensor([700.0, 3e-4, 1.0], device="cuda")
+    skip = torch.randn((n, 90, c), device="cuda", generator=g) * 3.0
+    w = torch.randn((c, c, 3, 3), device="cuda", generator=g) / (3.0 * c ** 0.5)
+    bias = torch.randn((c,), device="cuda", generator=g)
+    pk = _native.pack_conv3x3_c8_weights(w).cuda()
+    xs, ss = _native.split_c8(x), _native.split_c8(skip)
+    f = torch.empty((n, 90, c), device="cuda")
+    _native.conv3x3_c8(xs, pk, bias, out_f32=f, relu=False)
+    for relu in (False, True):
+        pair = (torch.full((n, 90, c), 7.0, device="cuda", dtype=torch.float16),
+                torch.full((n, 90, 2 * c), 7, device="cuda", dtype=torch.uint8))
+        _native.conv3x3_c8(xs, pk, bias, out=pair, relu=relu)
+        want = _native.split_c8(f.relu() if relu else f)
+        assert torch.equal(pair[0], want[0]) and torch.equal(pair[1], want[1])
+        fs = torch.empty_like(f)
+        _native.conv3x3_c8(xs, pk, bias, skip=ss, out_f32=fs, relu=relu)
+        ws = f + _native.join_c8(ss)
+        assert torch.equal(fs, ws.relu() if relu else ws)
+    # the pair reproduces the value to 2^-16 of its magnitude (f16 hi + 4-bit lo; the lo image's smallest step is
+    # 2^-9 / 2^11 = 2^-20, which is what small values get), below e4m3's saturation
+    v = torch.randn((4, 90, c), device="cuda", generator=g) * 50.0
+    back = _native.join_c8(_native.split_c8(v))
+    assert ((back - v).abs() <= torch.maximum(v.abs() * 2.0 ** -15, torch.tensor(2.0 ** -20, device="cuda"))).all()
+
+
+@pytest.mark.parametrize("n", [1, 3, 257, 700])
+def test_resblock_c8_equals_two_c8_convolutions(n):
+    """cz_resblock with the prototype arithmetic (dtype CZ_F16C8: k_resblock<..., C8>) is bit-identical to two
+    cz_conv3x3_c8 launches: pair output, fp32 output, in place, device-side count."""
+    import torch
+    from cchess_alphazero import _native
+    c = 128
+    g = torch.Generator(device="cuda").manual_seed(90 + n)
+    x = torch.randn((n, 90, c), device="cuda", generator=g).relu()
+    ws = [torch.randn((c, c, 3, 3), device="cuda", generator=g) / (3.0 * c ** 0.5) for _ in range(2)]
+    bs = [torch.randn((c,), device="cuda", generator=g) for _ in range(2)]
+    ps = [_native.pack_conv3x3_c8_weights(w).cuda() for w in ws]
+    xs = _native.split_c8(x)
+    empty = lambda: (torch.full((n, 90, c), 7.0, device="cuda", dtype=torch.float16),
+                     torch.full((n, 90, 2 * c), 7, device="cuda", dtype=torch.uint8))
+    t, want, got = empty(), empty(), empty()
+    _native.conv3x3_c8(xs, ps[0], bs[0], out=t)
+    _native.conv3x3_c8(t, ps[1], bs[1], skip=xs, out=want)
+    _native.resblock(xs, ps[0], bs[0], ps[1], bs[1], out=got)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    want_f = torch.empty((n, 90, c), device="cuda")
+    _native.conv3x3_c8(t, ps[1], bs[1], skip=xs, out_f32=want_f)
+    got_f = torch.full((n, 90, c), 7.0, device="cuda")
+    _native.resblock(xs, ps[0], bs[0], ps[1], bs[1], out_f32=got_f)
+    assert torch.equal(got_f, want_f)
+    xi = tuple(a.clone() for a in xs)
+    _native.resblock(xi, ps[0], bs[0], ps[1], bs[1], out=xi)
+    assert torch.equal(xi[0], want[0]) and torch.equal(xi[1], want[1])
+    if n > 3:
+        cnt = n // 2
+        y = empty()
+        _native.resblock(xs, ps[0], bs[0], ps[1], bs[1], out=y, count=torch.tensor([cnt], dtype=torch.int32, device="cuda"))
+        assert torch.equal(y[0][:cnt], want[0][:cnt]) and torch.equal(y[1][:cnt], want[1][:cnt])
+        assert (y[0][cnt:] == 7.0).all() and (y[1][cnt:] == 7).all()
+    # the fused head convolutions on this arithmetic: the same block, then the 1x1 convolutions of its fp32 output
+    hw = torch.randn((6, c), device="cuda", generator=g) / c ** 0.5
+    hb = torch.randn((6,), device="cuda", generator=g)
+    pf, vf = torch.empty((n, 4 * 90), device="cuda"), torch.empty((n, 2 * 90), device="cuda")
+    _native.resblock_heads(xs, ps[0], bs[0], ps[1], bs[1], hw, hb, 4, pf, vf)
+    hd = (want_f.double() @ hw.double().t() + hb.double()).relu()              # [n, 90, 6]
+    want_p = hd[..., :4].permute(0, 2, 1).reshape(n, 360)
+    want_v = hd[..., 4:].permute(0, 2, 1).reshape(n, 180)
+    assert (pf.double() - want_p).abs().max().item() < 2e-5 and (vf.double() - want_v).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("dt", ["float16", "bfloat16"])
 def test_resblock_256_two_channel_tiles_per_wave_is_bit_identical(dt):
     """256 filters, plain operands (BASELINE configs[4] 'deep'): the default schedule gives every matrix wave two
