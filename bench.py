@@ -492,7 +492,7 @@ def run_arena(args, cfg, max_plies=None):
 
 
 def short_selfplay_leg(label, config, seconds, log, games=None, K=None, dtype=None, trunk=None, model=None, play=None,
-                       workload=None):
+                       workload=None, arith=None):
     """One short self-play leg of another configuration (a few seconds of lock-step rounds from the opening, timed with
     synchronize on both sides; HIP events around the residual-block launches of every round)."""
     import gc
@@ -508,7 +508,16 @@ def short_selfplay_leg(label, config, seconds, log, games=None, K=None, dtype=No
     torch.manual_seed(0)
     ref_net = CChessNet.from_model_config(cfg.model)
     G = cfg.engine.games_per_gpu
-    eng = SelfPlayEngine(cfg, G, net=ref_net, dtype=getattr(torch, cfg.engine.net_dtype), seed=20260923)
+    prev_arith = os.environ.get("CZ_TOWER_ARITH")
+    if arith:
+        os.environ["CZ_TOWER_ARITH"] = arith                  # read by InferenceNet when the engine builds its network
+    try:
+        eng = SelfPlayEngine(cfg, G, net=ref_net, dtype=getattr(torch, cfg.engine.net_dtype), seed=20260923)
+    finally:
+        if arith:
+            os.environ.pop("CZ_TOWER_ARITH", None)
+            if prev_arith is not None:
+                os.environ["CZ_TOWER_ARITH"] = prev_arith
     try:
         eng.start(0, 0)
         eng.prewarm()
@@ -539,7 +548,8 @@ def short_selfplay_leg(label, config, seconds, log, games=None, K=None, dtype=No
         split = eng.trunk == "mfma" and cfg.engine.net_dtype == "float32"
         rec = {"workload": workload or f"{G} games/GPU, {cfg.play.simulation_num_per_move} sims/move, K={Kq}, {nb}x{f} net "
                                        f"({cfg.engine.net_dtype}, trunk={eng.trunk}), random-init weights, from INIT_STATE",
-               "dtype": ("bf16x3-split/f32acc" if split else {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[
+               "dtype": (("f16+2xfp8corr-split/f32acc" if getattr(eng.net, "arith", "") == "c8" else "bf16x3-split/f32acc")
+                         if split else {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[
                    cfg.engine.net_dtype]) + "+f64/i32 tree",
                "value": d["expansions"] / dt, "unit": "expansions/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
                "sims_per_s": d["sims"] / dt, "queue_slots": slots, "compact_queue": bool(eng.compact),
@@ -554,7 +564,11 @@ def short_selfplay_leg(label, config, seconds, log, games=None, K=None, dtype=No
             rec["roofline"] = {"kernel": "residual block (k_resblock family, one launch per block)", "bound": "mfma",
                                "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s", "frac": tfl / 2500.0,
                                "avg_launch_ms": b_ms, "launches_timed": len(blk),
-                               "mfmas_per_product": 3 if split else 1, "share_of_step": b_ms * len(blk) / steps / (dt / steps * 1e3)}
+                               "mfmas_per_product": (2 if getattr(eng.net, "arith", "") == "c8" else 3) if split else 1,
+                               "share_of_step": b_ms * len(blk) / steps / (dt / steps * 1e3)}
+            if getattr(eng.net, "arith", "") == "c8":
+                rec["roofline"]["arithmetic"] = ("one fp16 MFMA (K = 16) per 16 input channels + two block-scaled fp8 MFMAs "
+                                                 "(K = 64) per 64: 2.0 bf16-MFMA-equivalents of matrix-pipe time per product")
         else:
             peak = 157.3 if cfg.engine.net_dtype == "float32" and not split else 2500.0
             tf = fl * slots / (dt / steps) / 1e12
@@ -607,6 +621,11 @@ def other_configs(args, log):
         return rec
     guarded("eval_arena_400sims_200games", arena)
     guarded("normal_K40", lambda: short_selfplay_leg("K40", "normal", sec, log, K=40))
+    guarded("normal_c8_tower", lambda: short_selfplay_leg(
+        "c8", "normal", sec, log, arith="c8",
+        workload="BASELINE configs[1] 'normal' (4096 games, 800 sims/move, K=8, 7x128 net) with the prototype tower "
+                 "arithmetic: fp16 main term + two scaled-fp8 correction terms per product (k_resblock<C8>, plain "
+                 "schedule, separate input-layer launch), random-init weights, from INIT_STATE"))
     guarded("normal_strict_fp32_library_trunk", lambda: short_selfplay_leg("library", "normal", sec, log, trunk="library"))
     guarded("distribute_10x192_K10_cpuct5", lambda: short_selfplay_leg(
         "distribute", "normal", sec, log, K=10, model=dict(cnn_filter_num=192, res_layer_num=10),

@@ -431,7 +431,7 @@ def input_conv(planes, w_packed, bias, out, relu=True, rows=None, count=None):
     parts = len(out)
     check(lib().cz_input_conv_q(_ptr(planes), code, planes.shape[1], _ptr(w_packed), _ptr(bias), _ptr(out[0]),
                                 _ptr(out[1]) if parts == 2 else None, planes.shape[0], out[0].shape[-1],
-                                _dt_code(out[0].dtype), parts, int(relu), _ptr(rows), _ptr(count), _stream()),
+                                _pair_code(out), parts, int(relu), _ptr(rows), _ptr(count), _stream()),
           "cz_input_conv")
     return out
 

@@ -105,14 +105,22 @@ class InferenceNet(nn.Module):
     trunk="mfma":    the tower's 3x3 convolutions run on the hand-written MFMA kernel (csrc/xq_conv.hip) with the
                      epilogue fused.  With dtype=float32 the operands are (hi, lo) bf16 pairs -- three bf16 MFMAs per
                      product, fp32 accumulate, fp32-class results (policy / value within 1e-4 of the fp32 network) --
-                     with bf16 / fp16 they are plain 2-byte operands."""
+                     with bf16 / fp16 they are plain 2-byte operands.
+    arith="c8" (trunk="mfma", float32, 128 filters; CZ_TOWER_ARITH=c8): the tower's products are formed as an fp16 main
+                     term plus two block-scaled fp8 correction terms (csrc/xq_conv.hip, k_resblock<C8>): one fp16 and two
+                     fp8 matrix instructions per 64 input channels instead of three bf16 ones, 2^-16 per product."""
 
-    def __init__(self, net: CChessNet, dtype=torch.float32, trunk="library"):
+    def __init__(self, net: CChessNet, dtype=torch.float32, trunk="library", arith=None):
         super().__init__()
         net = net.eval()
         assert trunk in ("library", "mfma")
         self.dtype = dtype
         self.trunk = trunk
+        arith = arith or os.environ.get("CZ_TOWER_ARITH") or "bf16x3"
+        assert arith in ("bf16x3", "c8")
+        if arith == "c8" and not (trunk == "mfma" and dtype == torch.float32 and net.cfg["cnn_filter_num"] == 128):
+            arith = "bf16x3"                # the prototype arithmetic exists for the 128-filter split tower only
+        self.arith = arith
         self.fused_epilogue = True          # on the GPU: hand-written bias + skip + ReLU pass after each conv
         self.fused_blocks = True            # trunk="mfma", fp32, 128 filters: one launch per residual block
         self.fused_heads = True             # ... and the 1x1 head convolutions folded into the last block's store pass
@@ -168,6 +176,8 @@ class InferenceNet(nn.Module):
 
     @property
     def operand_dtype(self):
+        if self.arith == "c8":
+            return torch.float16
         return torch.bfloat16 if self.dtype == torch.float32 else self.dtype
 
     def _pack_trunk(self):
@@ -187,11 +197,13 @@ class InferenceNet(nn.Module):
         self._packed_in = _native.pack_input_conv_weights(self.input_conv.weight, self.operand_dtype, self.parts)
         self._in_table = _native.input_table(self.input_conv.weight)      # the gather form of the input layer
         out = []
+        if self.arith == "c8":
+            pack = lambda w: _native.pack_conv3x3_c8_weights(w).view(torch.float16)    # raw bytes, like the others
+        else:
+            pack = lambda w: _native.pack_conv3x3_weights(w, self.operand_dtype, self.parts)
         for c1, c2 in self.res:
-            out.append((_native.pack_conv3x3_weights(c1.weight, self.operand_dtype, self.parts),
-                        c1.bias.detach().float().clone(),
-                        _native.pack_conv3x3_weights(c2.weight, self.operand_dtype, self.parts),
-                        c2.bias.detach().float().clone()))
+            out.append((pack(c1.weight), c1.bias.detach().float().clone(),
+                        pack(c2.weight), c2.bias.detach().float().clone()))
         return out
 
     def _operands(self, n, device):
@@ -202,8 +214,12 @@ class InferenceNet(nn.Module):
         cap = self._bufs.get(key, (0,))[0]
         if n > cap:
             od, c = self.operand_dtype, self.filters
-            bufs = [tuple(torch.empty((n, 90, c), dtype=od, device=device) for _ in range(self.parts))
-                    for _ in range(3)]
+            if self.arith == "c8":          # (f16 operand, c8 correction image: e4m3 lo, e4m3 value)
+                bufs = [(torch.empty((n, 90, c), dtype=od, device=device),
+                         torch.empty((n, 90, 2 * c), dtype=torch.uint8, device=device)) for _ in range(3)]
+            else:
+                bufs = [tuple(torch.empty((n, 90, c), dtype=od, device=device) for _ in range(self.parts))
+                        for _ in range(3)]
             last = torch.empty((n, 90, c), dtype=torch.float32 if self.parts == 2 else od, device=device)
             self._bufs[key] = (n, bufs, last)
         cap, bufs, last = self._bufs[key]
@@ -225,7 +241,7 @@ class InferenceNet(nn.Module):
         fused = self.fused_blocks and ((c in (128, 192)) or (c == 256 and self.parts == 1))
         # input layer + first block in one launch: 128 filters, split operands, byte planes, a tower of >= 2 blocks
         first_fused = (fused and self.fused_input and c == 128 and self.parts == 2 and nblk >= 2 and
-                       planes.dtype == torch.uint8)
+                       planes.dtype == torch.uint8 and self.arith != "c8")
         if not first_fused:
             _native.input_conv(planes.contiguous(), self.in_w.view(self.operand_dtype), self.in_bias32, cur,
                                rows=rows, count=count)
@@ -256,14 +272,15 @@ class InferenceNet(nn.Module):
                     ev[1].record()
                     self.block_events.append(ev)
                 continue
-            _native.conv3x3(cur, w1, getattr(self, f"tb{i}a"), out=tmp)
+            conv = _native.conv3x3_c8 if self.arith == "c8" else _native.conv3x3
+            conv(cur, w1, getattr(self, f"tb{i}a"), out=tmp)
             if i + 1 < nblk:
-                _native.conv3x3(tmp, w2, getattr(self, f"tb{i}b"), skip=cur, out=nxt)
+                conv(tmp, w2, getattr(self, f"tb{i}b"), skip=cur, out=nxt)
                 cur, nxt = nxt, cur
             elif self.parts == 2:
-                _native.conv3x3(tmp, w2, getattr(self, f"tb{i}b"), skip=cur, out_f32=last)
+                conv(tmp, w2, getattr(self, f"tb{i}b"), skip=cur, out_f32=last)
             else:
-                _native.conv3x3(tmp, w2, getattr(self, f"tb{i}b"), skip=cur, out=(last,))
+                conv(tmp, w2, getattr(self, f"tb{i}b"), skip=cur, out=(last,))
         if heads is not None and fused and self.parts == 2 and c == 128:
             return None                                                  # the head features are already written
         return last                                                      # [n, 90, c] channels-last trunk output

@@ -1535,7 +1535,7 @@ __global__ __launch_bounds__((C / 32) * 64 + ip::COPY_THREADS, 1) void k_resbloc
 // One K-step per tap and 16 input channels; output written as the (hi, lo) operand pair of the residual tower.
 template <typename PT> __device__ __forceinline__ float plane_to_f(PT v) { return (float)v; }
 
-template <typename E, typename PT, int C, int IC16, int P, int PARTS>
+template <typename E, typename PT, int C, int IC16, int P, int PARTS, bool C8 = false>
 __global__ __launch_bounds__(C / 32 * 64, 1) void k_input_conv(
     const PT* __restrict__ planes, const E* __restrict__ wp, const float* __restrict__ bias, E* __restrict__ yh,
     E* __restrict__ yl, int n_boards, int in_planes, int relu, const int32_t* __restrict__ rows,
@@ -1686,6 +1686,19 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_input_conv(
                 const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
                 float v[4] = {acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
                               acc[p][g * 4 + 3] + bv.w};
+                const int off = q * SROWB + (((ch >> 3) ^ (q & GS::SWZ)) << 4) + (ch & 7) * 2;
+                if constexpr (C8) {                 // the operand pair of the c8 arithmetic (k_conv3x3_c8): f16 row, then the c8 row
+                    static_assert(!C8 || (PARTS == 2 && sizeof(E) == 2), "c8 output: fp16 operand pairs");
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (relu) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+                    const cf8::Split4 o = cf8::split4(v);
+                    *reinterpret_cast<Quad<_Float16>*>(stage + off) = o.hi;
+                    unsigned char* crow = stage + SPART + q * SROWB + (ch & 15);
+                    *reinterpret_cast<uint32_t*>(crow + (((ch >> 4) ^ (q & GS::SWZ)) << 4)) = o.l8;
+                    *reinterpret_cast<uint32_t*>(crow + (((GS::CPR / 2 + (ch >> 4)) ^ (q & GS::SWZ)) << 4)) = o.h8;
+                    continue;
+                }
                 Quad<E> hi, lo;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1693,7 +1706,6 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_input_conv(
                     hi.e[i] = (E)v[i];
                     lo.e[i] = (E)(v[i] - (float)hi.e[i]);
                 }
-                const int off = q * SROWB + (((ch >> 3) ^ (q & GS::SWZ)) << 4) + (ch & 7) * 2;
                 *reinterpret_cast<Quad<E>*>(stage + off) = hi;
                 if (PARTS == 2) *reinterpret_cast<Quad<E>*>(stage + SPART + off) = lo;
             }
@@ -2074,6 +2086,19 @@ extern "C" int cz_input_conv(const void* planes, int planes_dtype, int in_planes
     else if (dtype == CZ_F16)
         rc = dispatch_input_conv_pt<_Float16>(planes_dtype, channels, planes, in_planes, w_packed, bias, y_hi, y_lo,
                                               n_boards, parts, relu, st);
+    else if (dtype == CZ_F16C8 && channels == 128 && parts == 2 && (planes_dtype == CZ_U8 || planes_dtype == CZ_F32)) {
+        // f16-split filters (cz_input_conv_pack_weights with CZ_F16), output = the c8 operand pair (y_lo = the c8 image)
+        constexpr int P = 2;
+        const unsigned blocks = (unsigned)((n_boards + P - 1) / P);
+#define CZ_IC8(PT, IC16)                                                                                             \
+        hipLaunchKernelGGL((k_input_conv<_Float16, PT, 128, IC16, P, 2, true>), dim3(blocks), dim3(128 / 32 * 64), 0, st, \
+                           (const PT*)planes, (const _Float16*)w_packed, bias, (_Float16*)y_hi, (_Float16*)y_lo, n_boards,    \
+                           in_planes, relu, g_q.rows, g_q.n_dev)
+        if (planes_dtype == CZ_U8) { if (in_planes <= 16) CZ_IC8(unsigned char, 1); else CZ_IC8(unsigned char, 2); }
+        else { if (in_planes <= 16) CZ_IC8(float, 1); else CZ_IC8(float, 2); }
+#undef CZ_IC8
+        rc = hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
+    }
     if (rc == CZ_ERR_ARG) czi_set_error("cz_input_conv: unsupported channels / dtype");
     else if (rc != CZ_OK) czi_set_error("cz_input_conv: launch failed");
     return rc;

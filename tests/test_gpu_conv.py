@@ -166,6 +166,63 @@ def test_conv3x3_c8_prototype_matches_its_operands_and_the_float64_convolution(n
     assert torch.equal(out2, out.relu())
 
 
+@pytest.mark.parametrize("blocks", [7, 2, 1])
+def test_network_with_c8_tower_matches_fp32_module(blocks):
+    """The whole policy / value network with the prototype tower arithmetic (InferenceNet(arith="c8"): fp16 main term +
+    two scaled-fp8 correction terms per product; reference architecture agent/model.py:32-83) against the plain PyTorch
+    fp32 module on the CPU: the north_star tolerance (policy / value within 1e-4), the logit and relative bounds of the
+    split-bf16 test, and agreement with the split-bf16 network itself."""
+    import torch
+    from cchess_alphazero.agent.model import CChessNet, InferenceNet
+    import oracle.xq_oracle as xo
+    torch.manual_seed(11)
+    net = CChessNet(cnn_filter_num=128, res_layer_num=blocks)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.normal_(1, 0.2)
+            m.bias.data.normal_(0, 0.2)
+    net.policy_out.weight.data.mul_(10.0)                     # a sharper policy than random initialisation gives
+    net.eval()
+    rng = np.random.default_rng(5)
+    boards, state = [], xo.INIT_STATE
+    while len(boards) < 40:
+        mv = xo.get_legal_moves(state)
+        if not mv or xo.done(state)[0]:
+            state = xo.INIT_STATE
+            continue
+        boards.append(xo.state_to_board(state))
+        state = xo.step(state, mv[rng.integers(len(mv))])
+    x = torch.from_numpy(np.stack([xo.planes_board(b) for b in boards]))
+    with torch.no_grad():
+        p_ref, v_ref = net.double()(x.double())
+    net.float()
+    inf = InferenceNet(net, torch.float32, trunk="mfma", arith="c8").cuda()
+    assert inf.arith == "c8"
+    for planes in (x.cuda(), x.to(torch.uint8).cuda()):
+        p, v = inf(planes)
+        p, v = p.cpu().double(), v.cpu().double()
+        assert (p - p_ref).abs().max().item() < 1e-4 and (v - v_ref).abs().max().item() < 1e-4
+        lg, lr = torch.log(p.clamp_min(1e-300)), torch.log(p_ref.clamp_min(1e-300))
+        assert ((lg - lg.mean(1, keepdim=True)) - (lr - lr.mean(1, keepdim=True))).abs().max().item() < 1e-3
+        assert ((p - p_ref).abs() / p_ref.clamp_min(1e-12)).max().item() < 1e-3
+    ref = InferenceNet(net, torch.float32, trunk="mfma").cuda()
+    assert ref.arith == "bf16x3"
+    p2, v2 = ref(x.cuda())
+    assert (p2.cpu().double() - p).abs().max().item() < 1e-4 and (v2.cpu().double() - v).abs().max().item() < 1e-4
+    inf.fused_blocks = False                                  # per-convolution launches: the same tower arithmetic (the head
+    p3, v3 = inf(x.to(torch.uint8).cuda())                    # convolutions then run as their own kernel: summation order)
+    assert (p3.cpu().double() - p).abs().max().item() < 1e-6 and (v3.cpu().double() - v).abs().max().item() < 1e-5
+    # compact queue: rows + device-side count
+    inf.fused_blocks = True
+    n = x.shape[0]
+    rows = torch.arange(n - 1, -1, -1, dtype=torch.int32, device="cuda")
+    cnt = torch.tensor([n - 7], dtype=torch.int32, device="cuda")
+    pq, vq = inf(x.to(torch.uint8).cuda(), rows=rows, count=cnt)
+    assert torch.equal(pq[:n - 7].cpu().double(), p.flip(0)[:n - 7]) and torch.equal(vq[:n - 7].cpu().double(), v.flip(0)[:n - 7])
+
+
 @pytest.mark.parametrize("n", [1, 3, 257])
 def test_conv3x3_c8_operand_pair_output_and_skip(n):
     """The operand-pair output of cz_conv3x3_c8 is the split of its own fp32 output (device conversions = PyTorch's:
