@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", default="normal", choices=["mini", "normal", "deep", "eval"])
+    ap.add_argument("--arith", default=None, choices=["c8", "bf16x3"],
+                    help="products of the 128-filter float32 tower (default: the config's engine.net_arith = c8): c8 = fp16 "
+                         "main term + two scaled-fp8 correction MFMAs, bf16x3 = three bf16 MFMAs")
     ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (default: config)")
     ap.add_argument("--sims-per-round", type=int, default=None, help="K, lock-step batch per game")
     ap.add_argument("--dtype", default=None, choices=["float32", "bfloat16", "float16"])
@@ -440,7 +443,8 @@ def run_arena(args, cfg, max_plies=None):
         torch.manual_seed(seed)
         raw = CChessNet.from_model_config(cfg.model)
         model_cfg = raw.cfg
-        nets.append(InferenceNet(raw, dtype, trunk=cfg.engine.net_trunk).cuda())
+        nets.append(InferenceNet(raw, dtype, trunk=cfg.engine.net_trunk,
+                                 arith=os.environ.get("CZ_TOWER_ARITH") or cfg.engine.net_arith).cuda())
     G = cfg.engine.games_per_gpu
     K = args.sims_per_round or 32
     cfg.opts.evaluate = False                                  # like `run.py eval` of the reference (manager.py:94-103)
@@ -468,7 +472,9 @@ def run_arena(args, cfg, max_plies=None):
     fl = flops_per_position(model_cfg)
     out = {"metric": "mcts_node_expansions_per_sec", "value": d["expansions"] / dt, "unit": "expansions/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3-split/f32acc+f64/i32 tree", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None,
+           "dtype": {"c8": "f16+2xfp8corr-split/f32acc", "bf16x3": "bf16x3-split/f32acc"}[nets[0].arith] + "+f64/i32 tree",
+           "data": "synthetic",
            "config": {"workload": f"BASELINE configs[3] 'eval' ARENA (EvaluateWorker.play_games): {G} paired games "
                                   f"played concurrently, BestModel vs NextGenerationModel = two random-init "
                                   f"{cfg.model.res_layer_num}x{cfg.model.cnn_filter_num} nets (seeds 0 / 1), two trees "
@@ -621,11 +627,11 @@ def other_configs(args, log):
         return rec
     guarded("eval_arena_400sims_200games", arena)
     guarded("normal_K40", lambda: short_selfplay_leg("K40", "normal", sec, log, K=40))
-    guarded("normal_c8_tower", lambda: short_selfplay_leg(
-        "c8", "normal", sec, log, arith="c8",
-        workload="BASELINE configs[1] 'normal' (4096 games, 800 sims/move, K=8, 7x128 net) with the prototype tower "
-                 "arithmetic: fp16 main term + two scaled-fp8 correction terms per product (k_resblock<C8>, plain "
-                 "schedule, separate input-layer launch), random-init weights, from INIT_STATE"))
+    guarded("normal_bf16x3_tower", lambda: short_selfplay_leg(
+        "bf16x3", "normal", sec, log, arith="bf16x3",
+        workload="BASELINE configs[1] 'normal' (4096 games, 800 sims/move, K=8, 7x128 net) with round 2's tower "
+                 "arithmetic: three bf16 MFMAs per product on (hi, lo) bf16 operand pairs (k_resblock_pipe, fused input "
+                 "layer), random-init weights, from INIT_STATE"))
     guarded("normal_strict_fp32_library_trunk", lambda: short_selfplay_leg("library", "normal", sec, log, trunk="library"))
     guarded("distribute_10x192_K10_cpuct5", lambda: short_selfplay_leg(
         "distribute", "normal", sec, log, K=10, model=dict(cnn_filter_num=192, res_layer_num=10),
@@ -635,6 +641,8 @@ def other_configs(args, log):
 
 def main():
     args = parse()
+    if getattr(args, "arith", None):
+        os.environ["CZ_TOWER_ARITH"] = args.arith
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -672,8 +680,11 @@ def main():
     K = eng.search.K
     split = eng.trunk == "mfma" and cfg.engine.net_dtype == "float32"
     # the arithmetic the network computes in: split = (hi, lo) bf16 operand pairs, 3 MFMAs per product, fp32 accumulate
-    net_label = "bf16x3-split/f32acc" if split else {"float32": "f32", "bfloat16": "bf16",
-                                                     "float16": "f16"}[cfg.engine.net_dtype]
+    arith = getattr(eng.net, "arith", "bf16x3") if split else None
+    # c8: fp16 main term + two block-scaled fp8 (e4m3) correction terms per product; bf16x3: three bf16 MFMAs per product
+    net_label = ({"c8": "f16+2xfp8corr-split/f32acc", "bf16x3": "bf16x3-split/f32acc"}[arith] if split else
+                 {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[cfg.engine.net_dtype])
+    mfma_equiv = {"c8": 2.0, "bf16x3": 3.0}.get(arith, 1.0)   # matrix-pipe time per product in bf16-MFMA units
 
     def log(msg):
         if rank == 0:
@@ -804,11 +815,11 @@ def main():
             nn_ms = step_ms - k_ms
             tf = fl * slots / (nn_ms * 1e-3) / 1e12
             if split:
-                # every product is three bf16 MFMAs: price the issued matrix work against the dense bf16 peak
-                out["roofline_nn"] = {"kernel": "ResNet forward (k_conv3x3 split-bf16 trunk + MIOpen/hipBLASLt ends)",
-                                      "bound": "mfma", "achieved": 3.0 * tf, "peak": 2500.0, "unit": "TFLOP/s",
-                                      "frac": 3.0 * tf / 2500.0, "algorithmic_tflops": tf, "ms": nn_ms,
-                                      "positions_per_forward": slots}
+                # a product costs mfma_equiv bf16-MFMA units of matrix-pipe time: price that against the dense bf16 peak
+                out["roofline_nn"] = {"kernel": f"ResNet forward (hand-written kernels end to end, tower arithmetic {arith})",
+                                      "bound": "mfma", "achieved": mfma_equiv * tf, "peak": 2500.0, "unit": "TFLOP/s",
+                                      "frac": mfma_equiv * tf / 2500.0, "algorithmic_tflops": tf, "ms": nn_ms,
+                                      "positions_per_forward": slots, "mfma_equivalents_per_product": mfma_equiv}
             else:
                 peak = 157.3 if cfg.engine.net_dtype == "float32" else 2500.0
                 out["roofline_nn"] = {"kernel": "ResNet forward (" + ("k_conv3x3 trunk + " if eng.trunk == "mfma"
@@ -823,24 +834,33 @@ def main():
             flops_launch = 2 * 2.0 * 90 * f * f * 9 * slots          # two 3x3 convolutions, 2 flop per MAC
             tfl = flops_launch / (b_ms * 1e-3) / 1e12
             pmc = pmc_nn("k_resblock")
-            out["roofline"] = {"kernel": "k_resblock_pipe / k_resblock (csrc/xq_conv.hip): one residual block (2 x conv3x3 + "
-                                         "bias + skip + ReLU) of the tower per launch, split-bf16 operands; the first "
-                                         "launch also computes the 5x5 input layer (fp32 gather by its copy waves), the "
-                                         "inner blocks run the software-pipelined schedule, the last one (fused head "
-                                         "convolutions) the plain one; mean over all launches of the tower",
+            kdesc = ("k_resblock<C8> (csrc/xq_conv.hip): one residual block (2 x conv3x3 + bias + skip + ReLU) of the tower "
+                     "per launch; every product = one fp16 MFMA term + two block-scaled fp8 (e4m3, K = 64) correction terms, "
+                     "fp32 accumulate; the last launch also applies the fused head convolutions; mean over all launches of "
+                     "the tower" if arith == "c8" else
+                     "k_resblock_pipe / k_resblock (csrc/xq_conv.hip): one residual block (2 x conv3x3 + "
+                     "bias + skip + ReLU) of the tower per launch, split-bf16 operands; the first "
+                     "launch also computes the 5x5 input layer (fp32 gather by its copy waves), the "
+                     "inner blocks run the software-pipelined schedule, the last one (fused head "
+                     "convolutions) the plain one; mean over all launches of the tower")
+            out["roofline"] = {"kernel": kdesc,
                                "bound": "mfma", "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s", "frac": tfl / 2500.0,
                                "traffic": pmc.get("hbm_bytes_per_launch"), "traffic_source": pmc.get("source"),
                                "avg_launch_ms": b_ms, "launches_timed": len(blk),
                                "algorithmic_flops_per_launch": flops_launch,
-                               "issued_bf16_tflops": 3.0 * tfl * 96.0 / 90.0,
-                               "issued_frac_of_peak": 3.0 * tfl * 96.0 / 90.0 / 2500.0,
+                               "tower_arithmetic": arith, "mfma_equivalents_per_product": mfma_equiv,
+                               "issued_bf16_tflops": mfma_equiv * tfl * 96.0 / 90.0,
+                               "issued_frac_of_peak": mfma_equiv * tfl * 96.0 / 90.0 / 2500.0,
                                "mfma_util_pmc": pmc.get("mfma_util"),
                                "library_gemm_bf16_tflops": library_gemm_peak(),
                                "share_of_round": b_ms * len(blk) / args.steps / step_ms,
-                               "note": "achieved = fp32-class convolution FLOPs (2 per MAC); every product is three "
-                                       "bf16 MFMAs on (hi, lo) operand pairs over 96 pixel slots per 90-pixel board, "
-                                       "hence issued_bf16_tflops = 3.2 x achieved; against the fp32 matrix peak "
-                                       "(157.3 TFLOP/s) the same number is > 1"}
+                               "note": "achieved = fp32-class convolution FLOPs (2 per MAC) / launch time; every product "
+                                       "occupies the matrix pipes for mfma_equivalents_per_product bf16-MFMA units (c8: one "
+                                       "fp16 MFMA + two fp8 MFMAs at twice the rate = 2.0; bf16x3: 3.0) over 96 pixel slots "
+                                       "per 90-pixel board, hence issued_bf16_tflops = that x 96/90 x achieved; against the "
+                                       "fp32 matrix peak (157.3 TFLOP/s) the same number is > 1; the chip runs this kernel at "
+                                       "its 1.4 kW power cap at ~1.84 GHz (profiles/r03_clock_power.json), not the 2.4 GHz "
+                                       "the nominal peak assumes"}
         else:
             out["roofline"] = out.get("roofline_search")
         if sus is not None:

@@ -11,6 +11,7 @@ The reference runs a prediction thread that drains multiprocessing pipes and cal
 from logging import getLogger
 from time import time
 
+import os
 import numpy as np
 import torch
 
@@ -53,9 +54,10 @@ class CChessModelAPI:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         dtype = dtype or getattr(torch, getattr(getattr(config, "engine", None), "net_dtype", "float32"))
         trunk = getattr(getattr(config, "engine", None), "net_trunk", "mfma")
+        self._arith = os.environ.get("CZ_TOWER_ARITH") or getattr(getattr(config, "engine", None), "net_arith", "bf16x3")
         if agent_model.model.cfg["cnn_filter_num"] not in (32, 128, 192, 256):
             trunk = "library"
-        self.net = InferenceNet(agent_model.model, dtype, trunk=trunk).to(self.device)
+        self.net = InferenceNet(agent_model.model, dtype, trunk=trunk, arith=self._arith).to(self.device)
         self._dtype, self._trunk = dtype, trunk
         self.done = False
         self.need_reload = True
@@ -75,7 +77,7 @@ class CChessModelAPI:
                     trunk = self._trunk
                     if self.agent_model.model.cfg["cnn_filter_num"] not in (32, 128, 192, 256):
                         trunk = "library"
-                    self.net = InferenceNet(self.agent_model.model, self._dtype, trunk=trunk).to(self.device)
+                    self.net = InferenceNet(self.agent_model.model, self._dtype, trunk=trunk, arith=self._arith).to(self.device)
                     return True
         except Exception as e:                    # a half-written file: keep serving the old weights
             logger.error(e)

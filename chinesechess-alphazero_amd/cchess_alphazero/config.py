@@ -68,6 +68,8 @@ class EngineConfig(_Section):
                          sims_per_round=None,     # lock-step batch per game; None = play.search_threads
                          net_dtype="float32",     # float32 (reference precision) | bfloat16 | float16
                          net_trunk="mfma",        # mfma (hand-written convolution kernel) | library (MIOpen)
+                         net_arith="c8",          # products of the 128-filter float32 tower: c8 (fp16 + two scaled-fp8
+                                                  # correction MFMAs) | bf16x3 (three bf16 MFMAs); CZ_TOWER_ARITH overrides
                          max_nodes_per_game=0,    # sizes a game's hash / chunk table; 0 = the longest game's whole tree
                          pool_chunks=0,           # tree memory for all games in MiB; 0 = auto (<= 80 % of free HBM)
                          pool_fraction=None,      # with pool_chunks = 0: that fraction of the free HBM instead of 80 %

@@ -11,6 +11,7 @@ ring and drained by the host only when it wants to write play-record files.
 This replaces the reference's process/thread topology (worker/self_play.py:48-60 ProcessPoolExecutor,
 agent/player.py ThreadPoolExecutor + sender/receiver threads, agent/api.py prediction thread + pipes).
 """
+import os
 import time
 from logging import getLogger
 
@@ -60,6 +61,7 @@ class SelfPlayEngine:
             if net.cfg["cnn_filter_num"] not in (32, 128, 192, 256):
                 trunk = "library"
             self.trunk = trunk
+            self.arith = os.environ.get("CZ_TOWER_ARITH") or getattr(getattr(config, "engine", None), "net_arith", "bf16x3")
             if trunk == "mfma":
                 planes_code = _native.U8      # the hand-written input convolution reads the 0/1 planes as bytes
         self.search = Search(config.play, n_games, planes_dtype=planes_code,
@@ -68,7 +70,7 @@ class SelfPlayEngine:
                              sims_per_round=sims_per_round, device=self.device, use_history=use_history,
                              pool_fraction=getattr(getattr(config, "engine", None), "pool_fraction", None))
         if evaluator is None:
-            self.net = InferenceNet(net, dtype, trunk=self.trunk).to(self.device)
+            self.net = InferenceNet(net, dtype, trunk=self.trunk, arith=self.arith).to(self.device)
         # compact evaluation queue: the network runs only on the slots that hold a new leaf (2-7 % of the slots of a
         # sustained self-play round carry none, more with large K); needs the kernels that read the count on the device
         want = getattr(getattr(config, "engine", None), "compact_queue", True)
@@ -88,7 +90,7 @@ class SelfPlayEngine:
         had_graph = self._graph is not None
         self._graph = None
         torch.cuda.synchronize(self.device)
-        self.net = InferenceNet(net, self.dtype, trunk=self.trunk).to(self.device)
+        self.net = InferenceNet(net, self.dtype, trunk=self.trunk, arith=self.arith).to(self.device)
         if had_graph:
             self.capture_graph()
 
