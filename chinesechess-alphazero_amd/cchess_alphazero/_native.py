@@ -245,7 +245,7 @@ def bias_act_(x, bias, residual=None, relu=True):
 
 
 def _pair_code(x):
-    """dtype code of an operand tuple: (f16, uint8 c8 image) is the prototype arithmetic's pair (CZ_F16C8)."""
+    """dtype code of an operand tuple: (f16, uint8 c8 image) is the c8 arithmetic's pair (CZ_F16C8)."""
     import torch
     if len(x) == 2 and x[1].dtype == torch.uint8:
         assert x[0].dtype == torch.float16 and x[1].shape[-1] == 2 * x[0].shape[-1]
@@ -280,7 +280,7 @@ def pack_conv3x3_weights(w_oihw, dtype, parts):
     return out
 
 
-# ---- prototype arithmetic: fp16 main term + two scaled-fp8 correction terms (csrc/xq_conv.hip, k_conv3x3_c8) -------------
+# ---- the c8 tower arithmetic: fp16 main term + two scaled-fp8 correction terms (csrc/xq_conv.hip, k_conv3x3_c8) ----------
 C8_X_LO_SHIFT = 11
 
 

@@ -119,7 +119,7 @@ class InferenceNet(nn.Module):
         arith = arith or os.environ.get("CZ_TOWER_ARITH") or "bf16x3"
         assert arith in ("bf16x3", "c8")
         if arith == "c8" and not (trunk == "mfma" and dtype == torch.float32 and net.cfg["cnn_filter_num"] == 128):
-            arith = "bf16x3"                # the prototype arithmetic exists for the 128-filter split tower only
+            arith = "bf16x3"                # the c8 arithmetic exists for the 128-filter split tower only
         self.arith = arith
         self.fused_epilogue = True          # on the GPU: hand-written bias + skip + ReLU pass after each conv
         self.fused_blocks = True            # trunk="mfma", fp32, 128 filters: one launch per residual block

@@ -337,15 +337,15 @@ __global__ __launch_bounds__(C / 32 * 64, MINW) void k_conv3x3(
     }
 }
 
-// ---- prototype of the next tower arithmetic: fp16 main term + two block-scaled fp8 correction terms ("c8") -----------
+// ---- the c8 tower arithmetic: fp16 main term + two block-scaled fp8 correction terms --------------------------------
 // The tower is bound by the socket's power cap and spends three bf16 MFMAs per product.  With an fp16 main
 // term (11 bits) the correction terms  w_hi x_lo  and  w_lo x_hi  need four significant bits, which is what an e4m3 operand
 // holds:   w x  ~  f16(w) f16(x)  +  e4m3(w) e4m3(x - f16(x))  +  e4m3(w - f16(w)) e4m3(x)
 // as v_mfma_f32_32x32x16_f16 + 2 x v_mfma_scale_f32_32x32x64_f8f6f4 per 64 input channels: 2.0 instead of 3.0 MFMA-equivalents
 // per product (measured 1.47x in register-resident loops, profiles/r03_fp8_corrections_study.json; per-product accuracy
-// 2^-16, policy within 2e-5 of float64 in the emulated 7 x 128 network, same file).  This kernel is the single-convolution
-// form (cz_conv3x3_c8): it pins the operand format, the fragment maps and the scale plumbing on hardware and measures the
-// K loop against k_conv3x3 with split bf16 operands; the residual-block kernels still run the bf16 arithmetic.
+// 2^-16, policy within 2e-5 of float64 in the emulated 7 x 128 network, same file).  k_conv3x3_c8 is the single-convolution
+// form (cz_conv3x3_c8); k_resblock<..., C8> (dtype CZ_F16C8) is the residual block the self-play engine runs by default,
+// k_input_conv<..., C8> produces its operands; the pipelined block (k_resblock_pipe) still computes the bf16 arithmetic.
 //   operands: x_hi f16 [n][90][C];  x_c8 bytes [n][90][2C] = e4m3(x_lo * 2^11) for the C channels, then e4m3(x) for them
 //   LDS:      part 0 = x_hi rows, part 1 = x_c8 rows (same 2C bytes per pixel: the image code of the split kernels serves)
 //   weights:  f16 fragments as in cz_conv3x3_pack_weights, then per (tap, 64-channel block, kind) two 16-byte pieces per
@@ -591,7 +591,7 @@ struct HeadArgs {
     int n_pol;
 };
 
-// C8: the prototype arithmetic of k_conv3x3_c8 (fp16 main term + two scaled-fp8 correction terms): E = _Float16, PARTS = 2,
+// C8: the arithmetic of k_conv3x3_c8 (fp16 main term + two scaled-fp8 correction terms): E = _Float16, PARTS = 2,
 // the second operand part is the c8 image (e4m3 lo, e4m3 value), the packed filters are cz_conv3x3_c8_pack_weights'.
 template <typename E, int C, int PARTS, int P, bool HEADS = false, int CTW = 1, bool C8 = false>
 __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4) void k_resblock(
@@ -1850,7 +1850,7 @@ extern "C" int cz_conv3x3_pack_weights(const float* w_oihw, int channels, int dt
     return CZ_OK;
 }
 
-// ---- prototype arithmetic (k_conv3x3_c8): packing and launch ------------------------------------------------------------
+// ---- c8 arithmetic (k_conv3x3_c8, k_resblock<C8>): packing and launch ------------------------------------------------------------
 namespace {
 // float -> OCP e4m3 (bias 7, no infinities, 0x7f = NaN), round to nearest even, saturating at 448
 inline uint8_t f32_to_e4m3_bits(float f)
@@ -1894,7 +1894,7 @@ extern "C" size_t cz_conv3x3_c8_packed_bytes(int channels)
 extern "C" int cz_conv3x3_c8_pack_weights(const float* w_oihw, int channels, void* out_host)
 {
     if (!w_oihw || !out_host || channels != 128) {
-        czi_set_error("cz_conv3x3_c8_pack_weights: bad argument (prototype: 128 filters)");
+        czi_set_error("cz_conv3x3_c8_pack_weights: bad argument (128 filters)");
         return CZ_ERR_ARG;
     }
     const int C = channels, KK = C / 16, CT = C / 32, NB = C / 64;

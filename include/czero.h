@@ -231,17 +231,20 @@ int cz_conv3x3(const void* x_hi, const void* x_lo, const void* w_packed, const f
  * The intermediate activation and the skip operand stay in LDS; HBM sees one read of x and one write of y.
  * Same layouts and `parts` as cz_conv3x3; y_f32 != NULL (parts = 2 only) writes the fp32 result instead of
  * (y_hi, y_lo); y may alias x.  Supported: 128 filters (parts 1 or 2), 192 / 256 filters (parts 1); anything else returns
- * CZ_ERR_ARG (use two cz_conv3x3 calls).  Bit-identical to the two-call form. */
+ * CZ_ERR_ARG (use two cz_conv3x3 calls).  Bit-identical to the two-call form.
+ * dtype CZ_F16C8 (128 filters, parts = 2): the c8 arithmetic -- x_lo / y_lo are c8 images, the filters are
+ * cz_conv3x3_c8_pack_weights' (see cz_conv3x3_c8 below); bit-identical to two cz_conv3x3_c8 calls.  cz_resblock_heads,
+ * cz_input_conv (filters packed with CZ_F16, parts 2; u8 or fp32 planes) and the _q forms take the same code. */
 int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1, const void* w2_packed,
                 const float* bias2, void* y_hi, void* y_lo, float* y_f32, int n_boards, int channels, int dtype,
                 int parts, void* stream);
-/* Prototype of the next tower arithmetic (csrc/xq_conv.hip, k_conv3x3_c8): one 3x3 convolution, 128
- * filters, computed as  f16(w) f16(x) + e4m3(w) e4m3(x - f16(x)) + e4m3(w - f16(w)) e4m3(x)  (one fp16 and two block-scaled
+/* The c8 tower arithmetic (csrc/xq_conv.hip, k_conv3x3_c8 / k_resblock<C8>; the self-play default
+ * since the end of round 3): one 3x3 convolution, 128 filters, computed as  f16(w) f16(x) + e4m3(w) e4m3(x - f16(x)) + e4m3(w - f16(w)) e4m3(x)  (one fp16 and two block-scaled
  * fp8 matrix instructions per 64 input channels instead of three bf16 ones).  x_hi: f16 [n][90][128]; x_c8: bytes
  * [n][90][256] = e4m3(x_lo * 2^11) for the 128 channels, then e4m3(x) for them; y = conv + bias (+ skip pair) (ReLU if
  * relu), written as fp32 (y_f32) or as the operand pair (y_hi, y_c8).
- * Not used by the network path (reference arithmetic there: Keras float32, agent/model.py:32-83): it exists to pin the
- * operand format on hardware and to measure the K loop. */
+ * Reference arithmetic: Keras float32 (agent/model.py:32-83); per-product accuracy 2^-16 like the split-bf16 form, two
+ * thirds of its matrix-pipe time.  Activations above 448 lose the w_lo x correction (e4m3 saturates). */
 size_t cz_conv3x3_c8_packed_bytes(int channels);
 int cz_conv3x3_c8_pack_weights(const float* w_oihw, int channels, void* out_host);
 int cz_conv3x3_c8(const void* x_hi, const void* x_c8, const void* w_packed, const float* bias,

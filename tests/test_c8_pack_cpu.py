@@ -1,4 +1,4 @@
-"""Host side of the prototype arithmetic (csrc/xq_conv.hip, cz_conv3x3_c8_pack_weights): the fragment layout and the
+"""Host side of the c8 tower arithmetic (csrc/xq_conv.hip, cz_conv3x3_c8_pack_weights): the fragment layout and the
 float -> e4m3 conversion, decoded back with PyTorch's own float8_e4m3fn type.  No GPU involved."""
 import os
 import sys

@@ -116,8 +116,8 @@ def test_resblock_equals_two_convolutions(c, dt, parts, n):
 
 
 @pytest.mark.parametrize("n", [1, 2, 5, 301])
-def test_conv3x3_c8_prototype_matches_its_operands_and_the_float64_convolution(n):
-    """cz_conv3x3_c8 (prototype of the next tower arithmetic: one fp16 and two scaled-fp8 matrix instructions per 64 input
+def test_conv3x3_c8_matches_its_operands_and_the_float64_convolution(n):
+    """cz_conv3x3_c8 (the c8 tower arithmetic: one fp16 and two scaled-fp8 matrix instructions per 64 input
     channels).  (1) Against float64 arithmetic on EXACTLY the operand values the kernel is given (decoded fragments and
     images): only the instructions' accumulation differs -- bounded by 1e-5 of the sum of |terms| of an output (the fp8
     instruction accumulates to ~6e-5 of ITS terms, which are 2^-12 of the main ones).  (2) Against the float64
@@ -168,7 +168,7 @@ def test_conv3x3_c8_prototype_matches_its_operands_and_the_float64_convolution(n
 
 @pytest.mark.parametrize("blocks", [7, 2, 1])
 def test_network_with_c8_tower_matches_fp32_module(blocks):
-    """The whole policy / value network with the prototype tower arithmetic (InferenceNet(arith="c8"): fp16 main term +
+    """The whole policy / value network with the c8 tower arithmetic (InferenceNet(arith="c8"): fp16 main term +
     two scaled-fp8 correction terms per product; reference architecture agent/model.py:32-83) against the plain PyTorch
     fp32 module on the CPU: the north_star tolerance (policy / value within 1e-4), the logit and relative bounds of the
     split-bf16 test, and agreement with the split-bf16 network itself."""
@@ -259,7 +259,7 @@ def test_conv3x3_c8_operand_pair_output_and_skip(n):
 
 @pytest.mark.parametrize("n", [1, 3, 257, 700])
 def test_resblock_c8_equals_two_c8_convolutions(n):
-    """cz_resblock with the prototype arithmetic (dtype CZ_F16C8: k_resblock<..., C8>) is bit-identical to two
+    """cz_resblock with the c8 arithmetic (dtype CZ_F16C8: k_resblock<..., C8>) is bit-identical to two
     cz_conv3x3_c8 launches: pair output, fp32 output, in place, device-side count."""
     import torch
     from cchess_alphazero import _native

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU: the prototype convolution (cz_conv3x3_c8: fp16 + two scaled-fp8 correction terms) against the split-bf16 one
+"""GPU: the c8 convolution (cz_conv3x3_c8: fp16 + two scaled-fp8 correction terms) against the split-bf16 one
 (cz_conv3x3, three bf16 MFMAs per product), same shape (128 filters, two boards per workgroup, fp32 output), back to
 back for a few seconds each so that both run in the power-capped state.
 
