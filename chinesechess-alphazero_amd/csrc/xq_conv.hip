@@ -451,7 +451,22 @@ __device__ __forceinline__ void conv_kloop_c8(const unsigned char* region, const
             wcr[0][q][4 * h + 0] = t.x; wcr[0][q][4 * h + 1] = t.y; wcr[0][q][4 * h + 2] = t.z; wcr[0][q][4 * h + 3] = t.w;
         }
     const int scale_x_lo = 127 - cf8::X_LO_SHIFT, scale_one = 127;
+    auto load_cx = [&](i32x8& d, int pre_p, int q, int b, int h) {
+        const uint4 t = load_c8(pre_p, q, b, h);
+        d[4 * h + 0] = t.x; d[4 * h + 1] = t.y; d[4 * h + 2] = t.z; d[4 * h + 3] = t.w;
+    };
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {                     // the lo-part pieces of the first block
+        load_cx(cx[0][p], pre[p], 0, 0, 0);
+        load_cx(cx[0][p], pre[p], 0, 0, 1);
+    }
 
+    // Schedule of a 64-channel block: two fp16 K-steps, the block's e4m3(w) x_lo8 MFMAs, two fp16 K-steps, its w_lo8 e4m3(x)
+    // MFMAs.  The LDS port is as loaded as the matrix pipes in this kernel (the fp8 fragments are as many bytes as the bf16
+    // lo fragments they replace, the matrix time shrank by a third), so the reads are spread evenly: an fp16 slot
+    // (32 cycles) carries ONE ds_read_b128 -- a pixel fragment of the next K-step -- and an fp8 slot (64 cycles) two: the
+    // c8 pieces of the OTHER kind's next use (kind 1 of this block under kind 0's MFMAs, kind 0 of the next block -- next
+    // tap's rows at a tap boundary -- under kind 1's).
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
         const int tn = tap < 8 ? tap + 1 : 8;
@@ -460,48 +475,49 @@ __device__ __forceinline__ void conv_kloop_c8(const unsigned char* region, const
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int blk = tap * NB + b;
-            // ---- the four fp16 K-steps of this 64-channel block; every MFMA slot also carries one LDS read of the next
-            //      K-step, one of this block's c8 pixel pieces, and (last tile) the weight loads
 #pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                const int kk = b * 4 + k4, step = tap * KK + kk;
-                V8* bcur = px[kk & 1];
-                V8* bnxt = px[(kk + 1) & 1];
-                const int* rows = kk + 1 < KK ? pre : pre_n;
-                const int kn = (kk + 1) % KK;
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int k4 = half * 2 + k2, kk = b * 4 + k4, step = tap * KK + kk;
+                    V8* bcur = px[kk & 1];
+                    V8* bnxt = px[(kk + 1) & 1];
+                    const int* rows = kk + 1 < KK ? pre : pre_n;
+                    const int kn = (kk + 1) % KK;
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) {
+                        acc[i] = Mfma<_Float16>::mma(wf[kk % W_RING], bcur[i], acc[i]);
+                        bnxt[i] = load_px(G::kstep(rows[i], kn));
+                        if (i >= NT - PER && kk * PER + (i - (NT - PER)) < NT)
+                            pre_n[kk * PER + (i - (NT - PER))] = tap_row(ndy, ndx, kk * PER + (i - (NT - PER)));
+                        if (i == NT - 1) {
+                            wf[(kk + W_RING - 1) % W_RING] = load_w(step + W_RING - 1);
+                            const int q2 = k4 >> 1, h2 = k4 & 1;         // the next block's c8 filter pieces, one per K-step
+                            const uint4 t = load_wc(blk + 1, q2, h2);
+                            i32x8& d = wcr[(b + 1) & 1][q2];
+                            d[4 * h2 + 0] = t.x; d[4 * h2 + 1] = t.y; d[4 * h2 + 2] = t.z; d[4 * h2 + 3] = t.w;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                // ---- correction term `half` of this block (K = 64), the other kind's pieces arriving underneath
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
-                    acc[i] = Mfma<_Float16>::mma(wf[kk % W_RING], bcur[i], acc[i]);
-                    bnxt[i] = load_px(G::kstep(rows[i], kn));
-                    {
-                        const int e = k4 * NT + i;                       // 0 .. 4 NT - 1 = the 2 x NT x 2 pieces of the block
-                        const int q = e / (2 * NT), tile = (e % (2 * NT)) / 2, h = e & 1;
-                        const uint4 t = load_c8(pre[tile], q, b, h);
-                        cx[q][tile][4 * h + 0] = t.x; cx[q][tile][4 * h + 1] = t.y;
-                        cx[q][tile][4 * h + 2] = t.z; cx[q][tile][4 * h + 3] = t.w;
-                    }
-                    if (i >= NT - PER && kk * PER + (i - (NT - PER)) < NT)
-                        pre_n[kk * PER + (i - (NT - PER))] = tap_row(ndy, ndx, kk * PER + (i - (NT - PER)));
-                    if (i == NT - 1) {
-                        wf[(kk + W_RING - 1) % W_RING] = load_w(step + W_RING - 1);
-                        const int q2 = k4 >> 1, h2 = k4 & 1;             // the next block's c8 filter pieces, one per K-step
-                        const uint4 t = load_wc(blk + 1, q2, h2);
-                        i32x8& d = wcr[(b + 1) & 1][q2];
-                        d[4 * h2 + 0] = t.x; d[4 * h2 + 1] = t.y; d[4 * h2 + 2] = t.z; d[4 * h2 + 3] = t.w;
+                    acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wcr[b & 1][half], cx[half][i], acc[i], 0, 0, 0,
+                                                                              half ? scale_w_lo : scale_w_hi, 0,
+                                                                              half ? scale_one : scale_x_lo);
+                    if (half == 0) {
+                        load_cx(cx[1][i], pre[i], 1, b, 0);
+                        load_cx(cx[1][i], pre[i], 1, b, 1);
+                    } else {
+                        const int* r = b + 1 < NB ? pre : pre_n;
+                        const int bn = b + 1 < NB ? b + 1 : 0;
+                        load_cx(cx[0][i], r[i], 0, bn, 0);
+                        load_cx(cx[0][i], r[i], 0, bn, 1);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // ---- the block's correction terms: e4m3(w) x_lo8 and w_lo8 e4m3(x), K = 64 each
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wcr[b & 1][q], cx[q][i], acc[i], 0, 0, 0,
-                                                                              q ? scale_w_lo : scale_w_hi, 0,
-                                                                              q ? scale_one : scale_x_lo);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
         }
 #pragma unroll
         for (int p = 0; p < NT; ++p) pre[p] = pre_n[p];
