@@ -201,6 +201,36 @@ def test_weight_packers_on_the_host():
         _native.pack_input_conv_weights(torch.randn(128, 40, 5, 5), torch.bfloat16, 2)
 
 
+def test_tower_arithmetic_selection_on_the_host(monkeypatch):
+    """engine.net_arith = "c8" is the self-play default; InferenceNet takes the c8 arithmetic only where its kernels exist
+    (hand-written trunk, float32, 128 filters) and otherwise stays on the bf16 pairs; CZ_TOWER_ARITH overrides the
+    configuration; the c8 network packs its block filters with cz_conv3x3_c8_pack_weights (byte count of the C-ABI) and
+    its input-layer filters as fp16 pairs.  No GPU: construction and packing only."""
+    import torch
+    from cchess_alphazero import _native
+    from cchess_alphazero.agent.model import CChessNet, InferenceNet
+    from cchess_alphazero.config import Config
+    monkeypatch.delenv("CZ_TOWER_ARITH", raising=False)
+    assert Config("normal").engine.net_arith == "c8"
+    net = CChessNet(cnn_filter_num=128, res_layer_num=2)
+    inf = InferenceNet(net, torch.float32, trunk="mfma", arith="c8")
+    assert inf.arith == "c8" and inf.operand_dtype == torch.float16 and inf.parts == 2
+    nb = _native.lib().cz_conv3x3_c8_packed_bytes(128)
+    assert nb > 0 and inf.tw0a.numel() * 2 == nb and inf.tw1b.numel() * 2 == nb
+    assert inf.in_w.numel() == _native.lib().cz_input_conv_packed_elems(128, 14, 2)
+    assert InferenceNet(net, torch.float32, trunk="mfma").arith == "bf16x3"                 # explicit default of the class
+    assert InferenceNet(net, torch.float32, trunk="library", arith="c8").arith == "bf16x3"  # no hand-written trunk
+    assert InferenceNet(net, torch.float16, trunk="mfma", arith="c8").arith == "bf16x3"     # plain fp16 operands
+    assert InferenceNet(CChessNet(cnn_filter_num=192, res_layer_num=1), torch.float32, trunk="mfma", arith="c8").arith == "bf16x3"
+    monkeypatch.setenv("CZ_TOWER_ARITH", "c8")
+    assert InferenceNet(net, torch.float32, trunk="mfma").arith == "c8"
+    monkeypatch.setenv("CZ_TOWER_ARITH", "bf16x3")
+    assert InferenceNet(net, torch.float32, trunk="mfma").arith == "bf16x3"
+    assert _native.lib().cz_conv3x3_c8_packed_bytes(192) == 0
+    with pytest.raises(_native.NativeError):
+        _native.pack_conv3x3_c8_weights(torch.randn(192, 192, 3, 3))
+
+
 def test_uci_position_parsing_without_a_gpu():
     """The command parser of cchess_alphazero/uci.py (reference uci.py:116-170): `position fen ... w|b`, move counters,
     side to move, unknown commands ignored; nothing here needs the device."""
