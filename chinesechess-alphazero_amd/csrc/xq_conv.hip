@@ -490,7 +490,8 @@ __device__ __forceinline__ void conv_kloop_c8(const unsigned char* region, const
                         bnxt[i] = load_px(G::kstep(rows[i], kn));
                         if (i >= NT - PER && kk * PER + (i - (NT - PER)) < NT)
                             pre_n[kk * PER + (i - (NT - PER))] = tap_row(ndy, ndx, kk * PER + (i - (NT - PER)));
-                        if (i == NT - 1) {
+                        if (i == 0) {                                    // (first slot: the ring slot being refilled fed the
+                            //  previous K-step, whose MFMAs have issued; a K-step is only 96 cycles here, every slot of lead counts)
                             wf[(kk + W_RING - 1) % W_RING] = load_w(step + W_RING - 1);
                             const int q2 = k4 >> 1, h2 = k4 & 1;         // the next block's c8 filter pieces, one per K-step
                             const uint4 t = load_wc(blk + 1, q2, h2);
