@@ -217,6 +217,70 @@ def _shim_tf():
         sys.modules.setdefault(name, MagicMock())
 
 
+def record_game(sp, s):
+    """One game of the reference's own SelfPlayWorker.start_game under the environment control described at the top
+    (stub network, Philox-driven np.random.choice / random.random, constant Dirichlet); s: a spec dict as in
+    gen_games.  sp: the imported cchess_alphazero.worker.self_play module."""
+    from collections import defaultdict
+    cfg = make_cfg(s["sims"], c_puct=s.get("c_puct", 1.5), tau_decay_rate=s["tau"],
+                   max_game_length=s["max_game_length"],
+                   enable_resign_rate=s.get("enable_resign_rate", 1.0),
+                   resign_threshold=s.get("resign_threshold", -0.92),
+                   min_resign_turn=s.get("min_resign_turn", 20))
+    cfg.play_data.nb_game_in_file = 1
+    seed, game_id = s["seed"], 0
+    calls = {"choice": 0, "random": 0}
+    ply_log = []
+
+    def fake_choice(a, p=None, _c=calls):
+        u = stub_net.philox_uniform(seed, game_id, 1, _c["choice"])
+        _c["choice"] += 1
+        return stub_net.numpy_choice(p, u)
+
+    def fake_random(_c=calls):
+        u = stub_net.philox_uniform(seed, game_id, 0, _c["random"])
+        _c["random"] += 1
+        return u
+
+    np.random.choice = fake_choice
+    np.random.dirichlet = lambda alpha, size=None: np.full(len(alpha), 1.0 / len(alpha))
+    sp.random = fake_random
+
+    orig_action = ref_player.CChessPlayer.action
+
+    def logged_action(self, state, turns, no_act=None, depth=None, infinite=False, hist=None,
+                      increase_temp=False, _orig=orig_action, _log=ply_log):
+        r = _orig(self, state, turns, no_act, depth, infinite, hist, increase_temp)
+        node = self.tree[state]
+        n = [int(node.a[m].n) if m in node.a else 0 for m in node.legal_moves]
+        _log.append({"crc": visit_crc(node.legal_moves, n), "sum_n": int(node.sum_n),
+                     "no_act": list(no_act or []), "inc": bool(increase_temp)})
+        return r
+
+    ref_player.CChessPlayer.action = logged_action
+    sp.CChessPlayer.action = logged_action
+    saved = {}
+
+    def fake_save(self, idx, data, _s=saved):
+        _s["data"] = data
+
+    sp.SelfPlayWorker.save_play_data = fake_save
+    sp.SelfPlayWorker.remove_play_data = lambda self: None
+    pipe = stub_net.StubPipe(stub_fn(dict(kind="hash", salt=s["salt"])))
+    worker = sp.SelfPlayWorker(cfg, pipes=[pipe], pid=0, use_history=False)
+    v, turns, state, store = worker.start_game(1, defaultdict(ref_player.VisitState))
+    ref_player.CChessPlayer.action = orig_action
+    sp.CChessPlayer.action = orig_action
+    rec = dict(s)
+    rec.update({"value": v, "turns": turns, "final_state": state, "store": bool(store),
+                "record": saved.get("data"), "plies": ply_log, "nn_positions": pipe.n_positions,
+                "n_random_calls": calls["random"], "n_choice_calls": calls["choice"]})
+    print(s["name"], "turns", turns, "value", v, "store", store, "evals", pipe.n_positions,
+          "no_act plies", sum(1 for p in ply_log if p["no_act"]),
+          "inc_temp plies", sum(1 for p in ply_log if p["inc"]), flush=True)
+    return rec
+
+
 def gen_games():
     _shim_tf()
     import cchess_alphazero.worker.self_play as sp
@@ -251,65 +315,7 @@ def gen_games():
         with open(os.path.join(HERE, "games_k1.json")) as f:
             old = {g["name"]: g for g in json.load(f)["games"]}
         specs = [sp for sp in specs if sp["name"] in only.split(",") or sp["name"] not in old]
-    games = []
-    for s in specs:
-        cfg = make_cfg(s["sims"], c_puct=s.get("c_puct", 1.5), tau_decay_rate=s["tau"],
-                       max_game_length=s["max_game_length"],
-                       enable_resign_rate=s.get("enable_resign_rate", 1.0),
-                       resign_threshold=s.get("resign_threshold", -0.92),
-                       min_resign_turn=s.get("min_resign_turn", 20))
-        cfg.play_data.nb_game_in_file = 1
-        seed, game_id = s["seed"], 0
-        calls = {"choice": 0, "random": 0}
-        ply_log = []
-
-        def fake_choice(a, p=None, _c=calls):
-            u = stub_net.philox_uniform(seed, game_id, 1, _c["choice"])
-            _c["choice"] += 1
-            return stub_net.numpy_choice(p, u)
-
-        def fake_random(_c=calls):
-            u = stub_net.philox_uniform(seed, game_id, 0, _c["random"])
-            _c["random"] += 1
-            return u
-
-        np.random.choice = fake_choice
-        np.random.dirichlet = lambda alpha, size=None: np.full(len(alpha), 1.0 / len(alpha))
-        sp.random = fake_random
-
-        orig_action = ref_player.CChessPlayer.action
-
-        def logged_action(self, state, turns, no_act=None, depth=None, infinite=False, hist=None,
-                          increase_temp=False, _orig=orig_action, _log=ply_log):
-            r = _orig(self, state, turns, no_act, depth, infinite, hist, increase_temp)
-            node = self.tree[state]
-            n = [int(node.a[m].n) if m in node.a else 0 for m in node.legal_moves]
-            _log.append({"crc": visit_crc(node.legal_moves, n), "sum_n": int(node.sum_n),
-                         "no_act": list(no_act or []), "inc": bool(increase_temp)})
-            return r
-
-        ref_player.CChessPlayer.action = logged_action
-        sp.CChessPlayer.action = logged_action
-        saved = {}
-
-        def fake_save(self, idx, data, _s=saved):
-            _s["data"] = data
-
-        sp.SelfPlayWorker.save_play_data = fake_save
-        sp.SelfPlayWorker.remove_play_data = lambda self: None
-        pipe = stub_net.StubPipe(stub_fn(dict(kind="hash", salt=s["salt"])))
-        worker = sp.SelfPlayWorker(cfg, pipes=[pipe], pid=0, use_history=False)
-        v, turns, state, store = worker.start_game(1, defaultdict(ref_player.VisitState))
-        ref_player.CChessPlayer.action = orig_action
-        sp.CChessPlayer.action = orig_action
-        rec = dict(s)
-        rec.update({"value": v, "turns": turns, "final_state": state, "store": bool(store),
-                    "record": saved.get("data"), "plies": ply_log, "nn_positions": pipe.n_positions,
-                    "n_random_calls": calls["random"], "n_choice_calls": calls["choice"]})
-        games.append(rec)
-        print(s["name"], "turns", turns, "value", v, "store", store, "evals", pipe.n_positions,
-              "no_act plies", sum(1 for p in ply_log if p["no_act"]),
-              "inc_temp plies", sum(1 for p in ply_log if p["inc"]), flush=True)
+    games = [record_game(sp, s) for s in specs]
     if only:
         new = {g["name"]: g for g in games}
         games = [new.get(n, g) for n, g in old.items()] + [g for n, g in new.items() if n not in old]

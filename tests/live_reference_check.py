@@ -5,6 +5,7 @@ an interpreter -- and compares the oracle's restatement with the reference's own
     python tests/live_reference_check.py rules   SEED GAMES MAX_PLIES CAPTURE_BIAS
     python tests/live_reference_check.py history SEED GAMES MAX_PLIES CAPTURE_BIAS
     python tests/live_reference_check.py mcts    SEED N_POSITIONS SIMS
+    python tests/live_reference_check.py games   SEED N_GAMES
 
 Exit status 0 and a line "ok <mode> <count>" when everything matched; an AssertionError names the first difference.
 """
@@ -121,6 +122,39 @@ def check_mcts(seed, n_positions, sims):
     return len(picked)
 
 
+def check_games(seed, n_games):
+    """The reference's own SelfPlayWorker.start_game (tests/golden/make_golden_mcts.py::record_game: stub network, the
+    engine's counter-based uniforms behind np.random.choice / random.random) against the oracle's game loop on specs
+    drawn here: length, result, every move, the visit-count CRC of every action() call, the evaluation count."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_mcts as gm
+    gm._shim_tf()
+    import cchess_alphazero.worker.self_play as sp
+    rng = random.Random(seed)
+    for i in range(n_games):
+        spec = dict(name=f"live_{seed}_{i}", salt=seed + i, seed=seed * 7 + i,
+                    sims=rng.choice([4, 6, 10, 25, 40]), tau=rng.choice([0.0, 0.9, 0.98]),
+                    max_game_length=rng.choice([16, 30, 60]), c_puct=rng.choice([0.5, 1.5, 3.0]))
+        if i % 3 == 2:
+            spec.update(enable_resign_rate=0.0, resign_threshold=rng.choice([-0.35, 0.3]), min_resign_turn=6)
+        gmr = gm.record_game(sp, spec)
+        cfg = xo.play_cfg(simulation_num_per_move=spec["sims"], search_threads=1, c_puct=spec["c_puct"],
+                          tau_decay_rate=spec["tau"], max_game_length=spec["max_game_length"],
+                          enable_resign_rate=spec.get("enable_resign_rate", 1.0),
+                          resign_threshold=spec.get("resign_threshold", -0.92),
+                          min_resign_turn=spec.get("min_resign_turn", 20))
+        r = xo.selfplay_game(cfg, {"kind": "hash", "salt": spec["salt"]}, spec["seed"], 0)
+        assert r["turns"] == gmr["turns"], (spec, r["turns"], gmr["turns"])
+        assert r["value"] == gmr["value"] and r["store"] == gmr["store"], spec
+        if gmr["record"] is not None:
+            rec = gmr["record"]
+            assert rec[0] == xo.INIT_STATE
+            assert r["moves"] == [m for m, _ in rec[1:]], spec
+        assert r["visit_crc"][:len(gmr["plies"])].tolist() == [p["crc"] for p in gmr["plies"]], spec
+        assert r["counters"]["nn_positions"] == gmr["nn_positions"], spec
+    return n_games
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     xo.build()
@@ -130,6 +164,8 @@ if __name__ == "__main__":
         n = check_history(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
     elif mode == "mcts":
         n = check_mcts(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
+    elif mode == "games":
+        n = check_games(int(sys.argv[2]), int(sys.argv[3]))
     else:
         raise SystemExit("mode?")
     print("ok", mode, n)

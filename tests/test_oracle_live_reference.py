@@ -8,6 +8,7 @@ oracle/xq_oracle.py) with the reference's own functions on each of them:
     new_step for every legal move      static_env.py:77-108       state_to_planes / history    static_env.py:144-191
     fliped_state                       static_env.py:131-142      has_attack_chessman          static_env.py:431-438
     will_check_or_catch / be_catched   static_env.py:390-470      CChessPlayer.action (K = 1)  agent/player.py:139-330
+    SelfPlayWorker.start_game          worker/self_play.py:95-212 (whole games: moves, result, resignation, visit CRCs)
 
 The comparison runs in a child process (tests/live_reference_check.py): the reference's package is called
 cchess_alphazero like this repository's host package.  /root/reference does not exist on the GPU box, so the tests
@@ -47,3 +48,7 @@ def test_history_planes_match_the_reference():
 
 def test_search_matches_the_reference_player_on_fresh_positions():
     assert run_check("mcts", 505, 16, 200) == 16
+
+
+def test_selfplay_games_match_the_reference_worker_on_fresh_specs():
+    assert run_check("games", 606, 12) == 12
