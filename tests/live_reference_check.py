@@ -6,6 +6,7 @@ an interpreter -- and compares the oracle's restatement with the reference's own
     python tests/live_reference_check.py history SEED GAMES MAX_PLIES CAPTURE_BIAS
     python tests/live_reference_check.py mcts    SEED N_POSITIONS SIMS
     python tests/live_reference_check.py games   SEED N_GAMES
+    python tests/live_reference_check.py arena   SEED N_GAMES
 
 Exit status 0 and a line "ok <mode> <count>" when everything matched; an AssertionError names the first difference.
 """
@@ -17,6 +18,7 @@ import numpy as np
 
 REF = "/root/reference"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)                                   # `from oracle import xq_oracle` (tests/arena_oracle.py)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(REF, "cchess_alphazero"))
@@ -155,6 +157,41 @@ def check_games(seed, n_games):
     return n_games
 
 
+def check_arena(seed, n_games):
+    """The reference's own EvaluateWorker.start_game (two players, two stub networks, colours by game index, the arena's
+    repetition handling; tests/golden/make_golden_mcts.py::_arena_game) against tests/arena_oracle.py over two oracle
+    players, on specs drawn here: ply by ply state, action, visit CRC, bans and temperature flags, result."""
+    import types
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_mcts as gm
+    import stub_net
+    from arena_oracle import arena_game
+    gm._shim_tf()
+    import cchess_alphazero.worker.evaluator as ev
+    rng = random.Random(seed)
+    endgame = '3s5/4m4/9/9/4p4/2R6/9/4C4/4M4/3MS4'
+    for i in range(n_games):
+        spec = dict(name=f"live_arena_{seed}_{i}", idx=i, salts=(seed + 2 * i, seed + 2 * i + 1), seed=seed * 5 + i,
+                    sims=rng.choice([4, 6, 8, 12, 30]), max_game_length=rng.choice([20, 40, 80]),
+                    c_puct=rng.choice([0.5, 1.0, 1.5]), evaluate=bool(i % 4 == 3))
+        if i % 3 == 1:
+            spec["init_state"] = endgame
+        g = gm._arena_game(ev, spec)
+        pc = types.SimpleNamespace(simulation_num_per_move=spec["sims"], search_threads=1, c_puct=spec["c_puct"],
+                                   dirichlet_alpha=0.2, tau_decay_rate=0.0, virtual_loss=3,
+                                   max_game_length=spec["max_game_length"])
+        trace = []
+        value, turns, _evals = arena_game(spec["idx"], pc, tuple(dict(kind="hash", salt=x) for x in spec["salts"]),
+                                          lambda idx, ply, _s=spec["seed"]: stub_net.philox_uniform(_s, idx, 1, ply),
+                                          init_state=spec.get("init_state"), evaluate=spec["evaluate"], trace=trace)
+        assert (value, turns) == (g["value"], g["turns"]), (spec, value, turns, g["value"], g["turns"])
+        assert len(trace) == len(g["plies"]), spec
+        for t, r in zip(trace, g["plies"]):
+            assert (t["state"], t["action"], t["crc"], t["sum_n"]) == (r["state"], r["action"], r["crc"], r["sum_n"]), spec
+            assert t["no_act"] == r["no_act"] and t["inc"] == r["inc"], spec
+    return n_games
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     xo.build()
@@ -166,6 +203,8 @@ if __name__ == "__main__":
         n = check_mcts(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
     elif mode == "games":
         n = check_games(int(sys.argv[2]), int(sys.argv[3]))
+    elif mode == "arena":
+        n = check_arena(int(sys.argv[2]), int(sys.argv[3]))
     else:
         raise SystemExit("mode?")
     print("ok", mode, n)

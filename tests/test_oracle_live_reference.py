@@ -9,6 +9,7 @@ oracle/xq_oracle.py) with the reference's own functions on each of them:
     fliped_state                       static_env.py:131-142      has_attack_chessman          static_env.py:431-438
     will_check_or_catch / be_catched   static_env.py:390-470      CChessPlayer.action (K = 1)  agent/player.py:139-330
     SelfPlayWorker.start_game          worker/self_play.py:95-212 (whole games: moves, result, resignation, visit CRCs)
+    EvaluateWorker.start_game          worker/evaluator.py:147-250 (arena games over two players, via tests/arena_oracle.py)
 
 The comparison runs in a child process (tests/live_reference_check.py): the reference's package is called
 cchess_alphazero like this repository's host package.  /root/reference does not exist on the GPU box, so the tests
@@ -52,3 +53,7 @@ def test_search_matches_the_reference_player_on_fresh_positions():
 
 def test_selfplay_games_match_the_reference_worker_on_fresh_specs():
     assert run_check("games", 606, 12) == 12
+
+
+def test_arena_games_match_the_reference_evaluator_on_fresh_specs():
+    assert run_check("arena", 707, 4) == 4
