@@ -41,11 +41,13 @@ def test_c8_arithmetic_stays_inside_the_tolerance_where_fp16_alone_does_not():
     ref = emu.run(net, planes, "f64")
     assert float(ref[2].max()) > 0.03
     err = {}
-    for mode in ("bf16x3", "f16+fp8", "f16"):
+    for mode in ("bf16x3", "f16+fp8", "c8-kernel", "f16"):
         x, lg, p, v, _ = emu.run(net, planes, mode)
         err[mode] = (float((x - ref[0]).norm() / ref[0].norm()), float((p - ref[2]).abs().max()),
                      float((v - ref[3]).abs().max()))
     assert err["f16+fp8"][0] < 4e-5 and err["f16+fp8"][1] < 4e-5 and err["f16+fp8"][2] < 2e-5, err
+    # 'c8-kernel': exactly the kernels' operand model (fixed activation scales 2^11 / 1, saturation at 448, one scale per filter)
+    assert err["c8-kernel"][0] < 4e-5 and err["c8-kernel"][1] < 4e-5 and err["c8-kernel"][2] < 2e-5, err
     assert err["bf16x3"][0] < 2e-5 and err["bf16x3"][1] < 2e-5, err
     assert err["f16+fp8"][0] < 8 * err["bf16x3"][0], err                     # the same class as the split-bf16 form
     assert err["f16"][1] > 1e-4 and err["f16"][0] > 10 * err["f16+fp8"][0], err   # fp16 alone: outside the tolerance

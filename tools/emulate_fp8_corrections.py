@@ -71,6 +71,19 @@ def conv_model(x, w, b, mode, pad):
         wh = w.to(torch.float32).to(torch.bfloat16).to(torch.float64)
         wl = (w - wh).to(torch.float32).to(torch.bfloat16).to(torch.float64)
         y = conv(xh, wh) + conv(xh, wl) + conv(xl, wh)
+    elif mode == "c8-kernel":
+        # exactly the kernels' operand model (csrc/xq_conv.hip): FIXED activation scales -- x_lo8 = e4m3(sat(x_lo * 2^11)),
+        # x_hi8 = e4m3(sat(x)), saturation at +-448 -- and one power-of-two scale per filter tensor (largest magnitude
+        # in [128, 256))
+        f8 = lambda t: t.clamp(-448.0, 448.0).to(torch.float32).to(torch.float8_e4m3fn).to(torch.float64)
+        xh = x.to(torch.float32).to(torch.float16).to(torch.float64)
+        wh = w.to(torch.float32).to(torch.float16).to(torch.float64)
+        xl8 = f8((x - xh) * 2048.0) / 2048.0
+        xh8 = f8(x)
+        sh = 2.0 ** (7 - torch.floor(torch.log2(w.abs().max())))
+        wl = w - wh
+        sl = 2.0 ** (7 - torch.floor(torch.log2(wl.abs().max().clamp_min(1e-300))))
+        y = conv(xh, wh) + conv(xl8, f8(w * sh) / sh) + conv(xh8, f8(wl * sl) / sl)
     else:
         xh = x.to(torch.float32).to(torch.float16).to(torch.float64)
         wh = w.to(torch.float32).to(torch.float16).to(torch.float64)
@@ -95,6 +108,9 @@ def stored(x, mode):
     xh = x.to(torch.float32).to(torch.float16).to(torch.float64)
     if mode == "f16":
         return xh
+    if mode == "c8-kernel":
+        lo = ((x - xh) * 2048.0).clamp(-448.0, 448.0).to(torch.float32).to(torch.float8_e4m3fn).to(torch.float64)
+        return xh + lo / 2048.0
     return xh + block_scaled(x - xh, 1, "e4m3" if mode == "f16+fp8" else "e2m3")
 
 
@@ -129,6 +145,8 @@ def main():
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--peaked", type=float, default=1.0, help="scale of the policy layer's weights (sharper softmax)")
     ap.add_argument("--uniform-scales", action="store_true")
+    ap.add_argument("--act-scale", type=float, default=1.0,
+                    help="multiplies the input layer's filters and bias: activations of the whole tower grow by about this factor")
     a = ap.parse_args()
     global UNIFORM
     UNIFORM = a.uniform_scales
@@ -143,6 +161,9 @@ def main():
             m.weight.data.normal_(1, 0.2)
             m.bias.data.normal_(0, 0.2)
     net.policy_out.weight.data.mul_(a.peaked)
+    if a.act_scale != 1.0:                                   # (BatchNorm folded: scale its affine output)
+        net.input_bn.weight.data.mul_(a.act_scale)
+        net.input_bn.bias.data.mul_(a.act_scale)
     net.eval()
     rng = np.random.default_rng(a.seed)
     boards, state = [], xo.INIT_STATE
@@ -155,10 +176,11 @@ def main():
         state = xo.step(state, mv[rng.integers(len(mv))])
     planes = torch.from_numpy(np.stack([xo.planes_board(b) for b in boards]))
     ref = run(net, planes, "f64")
-    out = {"uniform_scales": UNIFORM, "filters": a.filters, "blocks": a.blocks, "positions": a.positions, "policy_scale": a.peaked,
+    out = {"uniform_scales": UNIFORM, "act_scale": a.act_scale, "trunk_max_activation": float(ref[0].abs().max()),
+           "filters": a.filters, "blocks": a.blocks, "positions": a.positions, "policy_scale": a.peaked,
            "max_policy_probability": float(ref[2].max()), "value_range": [float(ref[3].min()), float(ref[3].max())],
            "value_preactivation_range": [float(ref[4].min()), float(ref[4].max())], "modes": {}}
-    for mode in ("bf16x3", "f16+fp8", "f16+fp6", "f16"):
+    for mode in ("bf16x3", "c8-kernel", "f16+fp8", "f16+fp6", "f16"):
         x, lg, p, v, vpre = run(net, planes, mode)
         c = lambda t: t - t.mean(1, keepdim=True)
         out["modes"][mode] = {
