@@ -538,9 +538,11 @@ def test_deep_network_fp16_matches_fp32_module(positions_1k):
     assert (p2.cpu() - p_ref).abs().max().item() < 1e-4 and (v2.cpu() - v_ref).abs().max().item() < 1e-4
 
 
-def test_network_with_history_planes_and_reference_head_shapes():
+@pytest.mark.parametrize("arith", ["bf16x3", "c8"])
+def test_network_with_history_planes_and_reference_head_shapes(arith):
     """28 input planes (use_history) and the 2-policy / 4-value head filters of the reference's published topologies
-    (data/model/model_128f.json) through the hand-written path, uint8 planes as the engine feeds them."""
+    (data/model/model_128f.json) through the hand-written path, uint8 planes as the engine feeds them; both tower
+    arithmetics."""
     import torch
     from cchess_alphazero.agent.model import CChessNet, InferenceNet
     torch.manual_seed(5)
@@ -549,7 +551,8 @@ def test_network_with_history_planes_and_reference_head_shapes():
     x = (torch.rand((9, 28, 10, 9), generator=g) < 0.12).float()
     with torch.no_grad():
         p_ref, v_ref = net(x)
-    inf = InferenceNet(net, torch.float32, trunk="mfma").cuda()
+    inf = InferenceNet(net, torch.float32, trunk="mfma", arith=arith).cuda()
+    assert inf.arith == arith
     p, v = inf(x.to(torch.uint8).cuda())
     assert (p.cpu() - p_ref).abs().max().item() < 1e-4 and (v.cpu() - v_ref).abs().max().item() < 1e-4
     p2, v2 = inf(x.cuda())                                   # fp32 planes take the separate input-layer kernel (split-bf16
