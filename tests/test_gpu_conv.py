@@ -562,12 +562,13 @@ def test_network_with_history_planes_and_reference_head_shapes(arith):
     assert torch.equal(p2, p3) and torch.equal(v2, v3)
 
 
-@pytest.mark.parametrize("filters", [128, 192])
-def test_network_on_a_compact_queue_matches_the_gathered_batch(filters):
+@pytest.mark.parametrize("filters,arith", [(128, "bf16x3"), (128, "c8"), (192, "bf16x3")])
+def test_network_on_a_compact_queue_matches_the_gathered_batch(filters, arith):
     """cz_*_q (compact evaluation queue): rows / count live on the device.  The network evaluated on
     (planes, rows, count) gives, in its first `count` result rows, what it gives on the gathered batch
     planes[rows[:count]] -- for count = 0, 1, an odd number and the whole queue -- and leaves the launch shapes alone.
-    128 filters (k_resblock_pipe / k_resblock with fused heads) and 192 (k_resblock_ip + cz_head_convs)."""
+    128 filters (k_resblock_pipe / k_resblock with fused heads; the c8 tower: k_input_conv<C8> + k_resblock<C8>) and 192
+    (k_resblock_ip + cz_head_convs)."""
     import torch
     from cchess_alphazero.agent.model import CChessNet, InferenceNet
     torch.manual_seed(11)
@@ -576,8 +577,8 @@ def test_network_on_a_compact_queue_matches_the_gathered_batch(filters):
         if isinstance(m, torch.nn.BatchNorm2d):
             m.running_mean.normal_(0, 0.1)
             m.running_var.uniform_(0.5, 1.5)
-    net = InferenceNet(raw, torch.float32, trunk="mfma").cuda()
-    assert net.supports_compact_queue()
+    net = InferenceNet(raw, torch.float32, trunk="mfma", arith=arith).cuda()
+    assert net.supports_compact_queue() and net.arith == arith
     n = 77
     planes = (torch.rand((n, 14, 10, 9), device="cuda") < 0.07).to(torch.uint8)
     perm = torch.randperm(n, device="cuda").to(torch.int32)
