@@ -778,6 +778,14 @@ def main():
             "n_gpus": d["ranks"], "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": net_label + "+f64/i32 tree",
+            "dtype_note": ({"c8": "tower products = f16(w) f16(x) + e4m3(w) e4m3(x - f16(x)) + e4m3(w - f16(w)) e4m3(x), fp32 "
+                                  "accumulate: 2^-16 per product like the split-bf16 form (three bf16 MFMAs per product, "
+                                  "other_configs.normal_bf16x3_tower), fp32-class results -- numerics_check in this line "
+                                  "compares the network that just ran with the plain fp32 PyTorch module (north_star "
+                                  "tolerance 1e-4 on policy / value); strict fp32: other_configs.normal_strict_fp32_library_trunk",
+                            "bf16x3": "tower products = three bf16 MFMAs on (hi, lo) bf16 operand pairs, fp32 accumulate: "
+                                      "2^-17 per product, fp32-class results (numerics_check in this line)"}.get(arith)
+                           if split else None),
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{dict(mini=0, normal=1, eval=3, deep=4)[args.config]}] "
                                    f"'{args.config}': {G} concurrent games/GPU, "
