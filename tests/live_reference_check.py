@@ -7,6 +7,7 @@ an interpreter -- and compares the oracle's restatement with the reference's own
     python tests/live_reference_check.py mcts    SEED N_POSITIONS SIMS
     python tests/live_reference_check.py games   SEED N_GAMES
     python tests/live_reference_check.py arena   SEED N_GAMES
+    python tests/live_reference_check.py kgt1    SEED N_POSITIONS K SIMS RUNS
 
 Exit status 0 and a line "ok <mode> <count>" when everything matched; an AssertionError names the first difference.
 """
@@ -192,6 +193,61 @@ def check_arena(seed, n_games):
     return n_games
 
 
+def check_kgt1(seed, n_positions, K, sims, runs):
+    """search_threads = K > 1: the unmodified reference (its own thread timing: 1 ms sender sleep, 5 ms switch interval,
+    as in tests/golden/make_golden_kgt1.py) searched `runs` times per freshly drawn position, against the oracle's
+    canonical order.  Where the reference's runs all agree the oracle must give exactly that visit
+    vector; where they differ it must have a top move some run has and lie no further from their mean than 1.5 x the
+    furthest run (few runs: a crude spread)."""
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_mcts as gm
+    import stub_net
+    gm.ref_player.sleep = time.sleep
+    sys.setswitchinterval(0.005)
+    np.random.dirichlet = lambda alpha, size=None: np.full(len(alpha), 1.0 / len(alpha))
+    positions = playout_positions(seed, 8, 60, 0.3)
+    picked = random.Random(seed).sample(positions, n_positions)
+    exact_n = deterministic = 0
+    for i, (state, _) in enumerate(picked):
+        spec = dict(kind="hash", salt=seed + i)
+        visits = []
+        for _run in range(runs):
+            cfg = gm.make_cfg(sims)
+            cfg.play.search_threads = K
+            pipe = stub_net.StubPipe(gm.stub_fn(spec))
+            pl = gm.ref_player.CChessPlayer(cfg, search_tree=None, pipes=pipe, enable_resign=False)
+            pl.action(state, 0, None)
+            node = pl.tree[state]
+            visits.append([int(node.a[mv].n) if mv in node.a else 0 for mv in node.legal_moves])
+            pl.close()
+        ocfg = xo.play_cfg(simulation_num_per_move=sims, search_threads=K)
+        op = xo.Player(ocfg, spec)
+        op.search(state)
+        n = [int(x) for x in op.node_stats(state)["n"]]
+        op.close()
+        assert sum(n) == sum(visits[0]), (state, sum(n), sum(visits[0]))
+        v = np.array(visits, dtype=np.float64)
+        p = v / v.sum(1, keepdims=True)
+        mean = p.mean(0)
+        far = float((0.5 * np.abs(p - mean).sum(1)).max())
+        q = np.array(n, dtype=np.float64) / sum(n)
+        tv = float(0.5 * np.abs(q - mean).sum())
+        same = len({tuple(x) for x in visits}) == 1
+        exact = tuple(n) in {tuple(x) for x in visits}
+        deterministic += same
+        exact_n += exact
+        print("kgt1", i, "distinct reference vectors", len({tuple(x) for x in visits}), "tv %.4f far %.4f" % (tv, far),
+              "exact" if exact else "", flush=True)
+        if same:
+            assert exact, (state, n, visits[0])
+        else:
+            assert int(np.argmax(q)) in {int(np.argmax(r)) for r in p}, state
+            assert tv <= 1.5 * far + 1e-9, (state, tv, far)
+    print("kgt1: deterministic positions", deterministic, "of", n_positions, "; oracle equals a recorded run in", exact_n)
+    return n_positions
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     xo.build()
@@ -205,6 +261,8 @@ if __name__ == "__main__":
         n = check_games(int(sys.argv[2]), int(sys.argv[3]))
     elif mode == "arena":
         n = check_arena(int(sys.argv[2]), int(sys.argv[3]))
+    elif mode == "kgt1":
+        n = check_kgt1(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]))
     else:
         raise SystemExit("mode?")
     print("ok", mode, n)

@@ -10,6 +10,7 @@ oracle/xq_oracle.py) with the reference's own functions on each of them:
     will_check_or_catch / be_catched   static_env.py:390-470      CChessPlayer.action (K = 1)  agent/player.py:139-330
     SelfPlayWorker.start_game          worker/self_play.py:95-212 (whole games: moves, result, resignation, visit CRCs)
     EvaluateWorker.start_game          worker/evaluator.py:147-250 (arena games over two players, via tests/arena_oracle.py)
+    CChessPlayer.action, search_threads = 8 / 40, unmodified thread timing (agent/player.py:173-179,238-242)
 
 The comparison runs in a child process (tests/live_reference_check.py): the reference's package is called
 cchess_alphazero like this repository's host package.  /root/reference does not exist on the GPU box, so the tests
@@ -57,3 +58,11 @@ def test_selfplay_games_match_the_reference_worker_on_fresh_specs():
 
 def test_arena_games_match_the_reference_evaluator_on_fresh_specs():
     assert run_check("arena", 707, 4) == 4
+
+
+@pytest.mark.parametrize("seed,positions,K,sims,runs", [(808, 4, 8, 200, 3), (811, 1, 40, 200, 3)])
+def test_search_threads_gt_1_matches_the_unmodified_reference(seed, positions, K, sims, runs):
+    """search_threads = K > 1 (the production regime: K = 8 in the benchmark, 40 in configs/normal.py): the reference
+    with its own thread timing, run alone, is deterministic on these searches -- and the oracle's canonical order
+     gives exactly its visit counts."""
+    assert run_check("kgt1", seed, positions, K, sims, runs, timeout=900) == positions
