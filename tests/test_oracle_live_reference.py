@@ -59,9 +59,14 @@ def test_arena_games_match_the_reference_evaluator_on_fresh_specs():
     assert run_check("arena", 707, 3) == 3
 
 
-@pytest.mark.parametrize("seed,positions,K,sims,runs", [(808, 3, 8, 200, 2), (811, 1, 40, 200, 2)])
+@pytest.mark.skipif(os.environ.get("CZ_LIVE_KGT1") != "1",
+                    reason="opt-in (CZ_LIVE_KGT1=1): the unmodified reference's threaded search takes 2 s or 3 minutes for the "
+                           "same position, depending on how its sender thread happens to hold the queue lock (SURVEY C-12)")
+@pytest.mark.parametrize("seed,positions,K,sims,runs", [(808, 4, 8, 200, 3), (811, 2, 40, 200, 3)])
 def test_search_threads_gt_1_matches_the_unmodified_reference(seed, positions, K, sims, runs):
     """search_threads = K > 1 (the production regime: K = 8 in the benchmark, 40 in configs/normal.py): the reference
     with its own thread timing, run alone, is deterministic on these searches -- and the oracle's canonical order
-     gives exactly its visit counts."""
-    assert run_check("kgt1", seed, positions, K, sims, runs, timeout=900) == positions
+    (DESIGN section 3) gives exactly its visit counts.  Not part of the default run (its duration is erratic);
+    `CZ_LIVE_KGT1=1 python -m pytest tests/test_oracle_live_reference.py -k search_threads`, or the script directly:
+    `python tests/live_reference_check.py kgt1 SEED N_POSITIONS K SIMS RUNS`."""
+    assert run_check("kgt1", seed, positions, K, sims, runs, timeout=3600) == positions
