@@ -67,9 +67,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", default="normal", choices=["mini", "normal", "deep", "eval"])
-    ap.add_argument("--arith", default=None, choices=["c8", "bf16x3"],
-                    help="products of the 128-filter float32 tower (default: the config's engine.net_arith = c8): c8 = fp16 "
-                         "main term + two scaled-fp8 correction MFMAs, bf16x3 = three bf16 MFMAs")
+    ap.add_argument("--arith", default=None,
+                    help="REQUESTED products of the float32 tower (default: the config's engine.net_arith = c8): c8 = fp16 "
+                         "main term + two scaled-fp8 correction MFMAs, c8>N = the first N blocks on c8, f16x3 / bf16x3 = three "
+                         "MFMAs on (hi, lo) fp16 / bf16 pairs.  The engine measures the request against float64 when it loads "
+                         "the weights and may fall back (net_arith_effective in the line)")
     ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (default: config)")
     ap.add_argument("--sims-per-round", type=int, default=None, help="K, lock-step batch per game")
     ap.add_argument("--dtype", default=None, choices=["float32", "bfloat16", "float16"])
@@ -385,6 +387,27 @@ def pmc_nn(kernel):
             "source": os.path.relpath(files[-1], ROOT)}
 
 
+def arith_label(name):
+    """dtype label of a tower arithmetic name (agent/model.py InferenceNet.arith_name)."""
+    if name is None:
+        return None
+    if name.startswith("c8>"):
+        return f"f16+2xfp8corr-split(first {name[3:]} blocks)/f16x3-split/f32acc"
+    return {"c8": "f16+2xfp8corr-split/f32acc", "f16x3": "f16x3-split/f32acc", "bf16x3": "bf16x3-split/f32acc",
+            "fp32-library": "f32"}[name]
+
+
+def arith_mfma_equivalents(name, n_blocks):
+    """matrix-pipe time per product in bf16-MFMA units: c8 = one fp16 MFMA + two fp8 MFMAs at twice the rate = 2.0, the
+    three-MFMA pairs 3.0, a hybrid tower the mean over its blocks."""
+    if name is None or name == "fp32-library":
+        return 1.0
+    if name.startswith("c8>"):
+        n8 = int(name[3:])
+        return (2.0 * n8 + 3.0 * (n_blocks - n8)) / n_blocks
+    return {"c8": 2.0, "f16x3": 3.0, "bf16x3": 3.0}[name]
+
+
 def fp16_tolerance(blocks, filters):
     """Bound for plain fp16 operands (BASELINE configs[4] asks for fp16 MFMA evaluation), derived:
     every convolution output is a sum of 9 F products of operands rounded to fp16 (relative error <= 2^-11 each, so
@@ -426,7 +449,42 @@ def numerics_check(eng, ref_net, cfg, nq=64):
     out["within_tolerance"] = bool(out["policy_max_abs_diff"] <= tol["policy_abs"] and
                                    out["value_max_abs_diff"] <= tol["value_abs"] and
                                    out["policy_logit_max_abs_diff"] <= tol["policy_logit_abs"])
+    out["primary_figure"] = "policy_logit_max_abs_diff (a random-init policy is ~1/2086 everywhere: absolute policy " \
+                            "differences say nothing there; `sharpened` below is the same check on a peaked policy)"
+    if cfg.engine.net_dtype == "float32" and getattr(eng, "trunk", None) == "mfma":
+        try:
+            out["sharpened"] = sharpened_numerics(eng, ref_net, qp)
+        except Exception as e:                                # noqa: BLE001
+            out["sharpened"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
+
+
+def sharpened_numerics(eng, ref_net, planes):
+    """north_star's 1e-4 on a PEAKED policy: the benchmark's weights with the policy layer scaled until
+    the largest probability on these positions is >= 0.85, evaluated (a) by the arithmetic the engine REQUESTED, unguarded,
+    and (b) by what the load-time guard selects for those weights (agent/model.py guarded_inference_net), both against the
+    float64 network on the same live-queue positions."""
+    import copy
+    from cchess_alphazero.agent.model import (InferenceNet, guarded_inference_net, measure_against_reference,
+                                              reference_forward_f64)
+    sharp = copy.deepcopy(ref_net).eval()
+    scale = 1.0
+    for scale in (30.0, 60.0, 120.0, 240.0, 480.0, 960.0):
+        sharp.policy_out.weight.data.copy_(ref_net.policy_out.weight.data * scale)
+        ref = reference_forward_f64(sharp, planes)
+        if float(ref[0].max()) >= 0.85:
+            break
+    requested = eng.net.arith_requested
+    raw = measure_against_reference(InferenceNet(sharp, torch.float32, trunk="mfma", arith=requested).cuda(), ref, planes)
+    g = guarded_inference_net(sharp, torch.float32, trunk="mfma", arith=requested, device=planes.device)
+    m = measure_against_reference(g, ref, planes)
+    return {"policy_layer_scale": scale, "max_policy_probability": float(ref[0].max()), "positions": int(planes.shape[0]),
+            "against": "float64 evaluation of the same weights on the device (reference_forward_f64)",
+            "requested": requested, "requested_unguarded": raw,
+            "guard_selected": g.arith_effective, "guard_selected_measured": m,
+            "guard_candidates_on_calibration_positions": g.calibration["candidates"] if g.calibration else None,
+            "policy_margin": 1e-4 / max(m["policy_max_abs"], 1e-30),
+            "within_tolerance": bool(m["policy_max_abs"] <= 1e-4 and m["value_max_abs"] <= 1e-4)}
 
 
 def run_arena(args, cfg, max_plies=None):
@@ -435,7 +493,7 @@ def run_arena(args, cfg, max_plies=None):
     two trees per game, 400 simulations per move.  A "step" here is one PLY of the whole arena (every live game makes
     one move: ~sims / K lock-step rounds for the best model's games and as many for the next-generation model's)."""
     from cchess_alphazero import _native
-    from cchess_alphazero.agent.model import CChessNet, InferenceNet, flops_per_position
+    from cchess_alphazero.agent.model import CChessNet, flops_per_position, guarded_inference_net
     from cchess_alphazero.worker.evaluator import EvaluateWorker, score_table
     dtype = getattr(torch, cfg.engine.net_dtype)
     nets = []
@@ -443,8 +501,8 @@ def run_arena(args, cfg, max_plies=None):
         torch.manual_seed(seed)
         raw = CChessNet.from_model_config(cfg.model)
         model_cfg = raw.cfg
-        nets.append(InferenceNet(raw, dtype, trunk=cfg.engine.net_trunk,
-                                 arith=os.environ.get("CZ_TOWER_ARITH") or cfg.engine.net_arith).cuda())
+        nets.append(guarded_inference_net(raw, dtype, trunk=cfg.engine.net_trunk,
+                                          arith=os.environ.get("CZ_TOWER_ARITH") or cfg.engine.net_arith))
     G = cfg.engine.games_per_gpu
     K = args.sims_per_round or 32
     cfg.opts.evaluate = False                                  # like `run.py eval` of the reference (manager.py:94-103)
@@ -473,7 +531,8 @@ def run_arena(args, cfg, max_plies=None):
     out = {"metric": "mcts_node_expansions_per_sec", "value": d["expansions"] / dt, "unit": "expansions/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None,
-           "dtype": {"c8": "f16+2xfp8corr-split/f32acc", "bf16x3": "bf16x3-split/f32acc"}[nets[0].arith] + "+f64/i32 tree",
+           "dtype": arith_label(nets[0].arith_effective) + "+f64/i32 tree",
+           "net_arith_requested": nets[0].arith_requested, "net_arith_effective": [n_.arith_effective for n_ in nets],
            "data": "synthetic",
            "config": {"workload": f"BASELINE configs[3] 'eval' ARENA (EvaluateWorker.play_games): {G} paired games "
                                   f"played concurrently, BestModel vs NextGenerationModel = two random-init "
@@ -554,9 +613,11 @@ def short_selfplay_leg(label, config, seconds, log, games=None, K=None, dtype=No
         split = eng.trunk == "mfma" and cfg.engine.net_dtype == "float32"
         rec = {"workload": workload or f"{G} games/GPU, {cfg.play.simulation_num_per_move} sims/move, K={Kq}, {nb}x{f} net "
                                        f"({cfg.engine.net_dtype}, trunk={eng.trunk}), random-init weights, from INIT_STATE",
-               "dtype": (("f16+2xfp8corr-split/f32acc" if getattr(eng.net, "arith", "") == "c8" else "bf16x3-split/f32acc")
+               "dtype": (arith_label(eng.net_arith_effective)
                          if split else {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[
                    cfg.engine.net_dtype]) + "+f64/i32 tree",
+               "net_arith_requested": eng.net.arith_requested if split else None,
+               "net_arith_effective": eng.net_arith_effective if split else None,
                "value": d["expansions"] / dt, "unit": "expansions/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
                "sims_per_s": d["sims"] / dt, "queue_slots": slots, "compact_queue": bool(eng.compact),
                "queue_utilisation": d["expansions"] / max(1, steps * slots),
@@ -565,12 +626,14 @@ def short_selfplay_leg(label, config, seconds, log, games=None, K=None, dtype=No
         fl = flops_per_position(eng.model_cfg)
         if blk:
             b_ms = sum(blk) / len(blk)
-            flops_launch = 2 * 2.0 * 90 * f * f * 9 * slots
+            # boards a launch actually processes: the compact queue's rows (= new leaves), else every slot
+            rows_launch = d["expansions"] / steps if eng.compact else slots
+            flops_launch = 2 * 2.0 * 90 * f * f * 9 * rows_launch
             tfl = flops_launch / (b_ms * 1e-3) / 1e12
             rec["roofline"] = {"kernel": "residual block (k_resblock family, one launch per block)", "bound": "mfma",
                                "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s", "frac": tfl / 2500.0,
-                               "avg_launch_ms": b_ms, "launches_timed": len(blk),
-                               "mfmas_per_product": (2 if getattr(eng.net, "arith", "") == "c8" else 3) if split else 1,
+                               "avg_launch_ms": b_ms, "launches_timed": len(blk), "boards_per_launch": rows_launch,
+                               "mfmas_per_product": arith_mfma_equivalents(eng.net_arith_effective, nb) if split else 1,
                                "share_of_step": b_ms * len(blk) / steps / (dt / steps * 1e3)}
             if getattr(eng.net, "arith", "") == "c8":
                 rec["roofline"]["arithmetic"] = ("one fp16 MFMA (K = 16) per 16 input channels + two block-scaled fp8 MFMAs "
@@ -632,6 +695,16 @@ def other_configs(args, log):
         workload="BASELINE configs[1] 'normal' (4096 games, 800 sims/move, K=8, 7x128 net) with round 2's tower "
                  "arithmetic: three bf16 MFMAs per product on (hi, lo) bf16 operand pairs (k_resblock_pipe, fused input "
                  "layer), random-init weights, from INIT_STATE"))
+    guarded("normal_f16x3_tower", lambda: short_selfplay_leg(
+        "f16x3", "normal", sec, log, arith="f16x3",
+        workload="BASELINE configs[1] 'normal' (4096 games, 800 sims/move, K=8, 7x128 net) on the arithmetic the load-time "
+                 "guard falls back to for peaked policies: three fp16 MFMAs per product on (hi, lo) fp16 operand pairs "
+                 "(22 bits per operand; k_resblock_pipe, fused input layer), random-init weights, from INIT_STATE"))
+    guarded("mini_1game_50sims_2x32", lambda: short_selfplay_leg(
+        "mini", "mini", min(sec, 3.0), log,
+        workload="BASELINE configs[0] 'mini' (the reference's own CPU-runnable case): 1 game, 50 sims/move, random-init "
+                 "2-block x 32-filter net, from INIT_STATE -- one wavefront and a 1-row network batch on a 256-CU chip: a "
+                 "latency figure, reported for completeness"))
     guarded("normal_strict_fp32_library_trunk", lambda: short_selfplay_leg("library", "normal", sec, log, trunk="library"))
     guarded("distribute_10x192_K10_cpuct5", lambda: short_selfplay_leg(
         "distribute", "normal", sec, log, K=10, model=dict(cnn_filter_num=192, res_layer_num=10),
@@ -680,11 +753,14 @@ def main():
     K = eng.search.K
     split = eng.trunk == "mfma" and cfg.engine.net_dtype == "float32"
     # the arithmetic the network computes in: split = (hi, lo) bf16 operand pairs, 3 MFMAs per product, fp32 accumulate
-    arith = getattr(eng.net, "arith", "bf16x3") if split else None
-    # c8: fp16 main term + two block-scaled fp8 (e4m3) correction terms per product; bf16x3: three bf16 MFMAs per product
-    net_label = ({"c8": "f16+2xfp8corr-split/f32acc", "bf16x3": "bf16x3-split/f32acc"}[arith] if split else
+    # (what the load-time guard left of the request: agent/model.py guarded_inference_net)
+    arith = eng.net_arith_effective if split else None
+    if arith == "fp32-library":
+        split = False
+    # c8: fp16 main term + two block-scaled fp8 (e4m3) correction terms per product; f16x3 / bf16x3: three MFMAs per product
+    net_label = (arith_label(arith) if split else
                  {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[cfg.engine.net_dtype])
-    mfma_equiv = {"c8": 2.0, "bf16x3": 3.0}.get(arith, 1.0)   # matrix-pipe time per product in bf16-MFMA units
+    mfma_equiv = arith_mfma_equivalents(arith, cfg.model.res_layer_num) if split else 1.0
 
     def log(msg):
         if rank == 0:
@@ -744,6 +820,13 @@ def main():
             dist.all_reduce(delta, op=dist.ReduceOp.SUM)          # the only collective of the path
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dd = dict(zip(keys + ["ranks"], delta.tolist()))
+        # every rank's own rate (a straggler must be visible): one more all-reduce(SUM) of a vector in which a rank fills only
+        # its own slot -- still nothing but counter all-reduces on the path
+        mine = torch.zeros(world, dtype=torch.float64, device="cuda")
+        mine[rank] = (c1["expansions"] - c0["expansions"]) / dt_
+        if dist_on:
+            dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        dd["per_rank_value"] = mine.tolist()
         k_all = sorted(x.elapsed_time(y) for x, y in ev)
         k_ms_ = sum(k_all) / len(k_all) if ev else None
         dd["search_round_ms_median"] = k_all[len(k_all) // 2] if ev else None
@@ -775,7 +858,8 @@ def main():
         step_ms = dt / args.steps * 1e3
         out = {
             "metric": "mcts_node_expansions_per_sec", "value": d["expansions"] / dt, "unit": "expansions/s",
-            "n_gpus": d["ranks"], "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
+            "n_gpus": d["ranks"], "per_rank_value": d["per_rank_value"], "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": step_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": net_label + "+f64/i32 tree",
             "dtype_note": ({"c8": "tower products = f16(w) f16(x) + e4m3(w) e4m3(x - f16(x)) + e4m3(w - f16(w)) e4m3(x), fp32 "
@@ -784,8 +868,17 @@ def main():
                                   "compares the network that just ran with the plain fp32 PyTorch module (north_star "
                                   "tolerance 1e-4 on policy / value); strict fp32: other_configs.normal_strict_fp32_library_trunk",
                             "bf16x3": "tower products = three bf16 MFMAs on (hi, lo) bf16 operand pairs, fp32 accumulate: "
-                                      "2^-17 per product, fp32-class results (numerics_check in this line)"}.get(arith)
+                                      "2^-17 per product, fp32-class results (numerics_check in this line)",
+                            "f16x3": "tower products = three fp16 MFMAs on (hi, lo) fp16 operand pairs (22 bits per operand), "
+                                     "fp32 accumulate, fp32-class results (numerics_check in this line)"}.get(arith)
                            if split else None),
+            "net_arith_requested": eng.net.arith_requested if eng.net is not None else None,
+            "net_arith_effective": arith,
+            "net_arith_guard": (None if eng.net is None or eng.net.calibration is None else
+                                {"tol": eng.net.calibration["tol"], "positions": eng.net.calibration["positions"],
+                                 "candidates": eng.net.calibration["candidates"],
+                                 "tower_activation_max": max(eng.net.calibration["activation_max"]),
+                                 "c8_saturating_layers": eng.net.calibration["c8_saturating_layers"]}),
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{dict(mini=0, normal=1, eval=3, deep=4)[args.config]}] "
                                    f"'{args.config}': {G} concurrent games/GPU, "
@@ -839,7 +932,10 @@ def main():
             # the dominant kernel: k_resblock (one residual block of the tower per launch), > 90 % of a round
             b_ms = sum(blk) / len(blk)
             f = cfg.model.cnn_filter_num
-            flops_launch = 2 * 2.0 * 90 * f * f * 9 * slots          # two 3x3 convolutions, 2 flop per MAC
+            # two 3x3 convolutions, 2 flop per MAC, on the boards a launch actually processes: the compact queue's
+            # rows (= the new leaves of the round), every slot otherwise
+            rows_launch = exp_per_launch if eng.compact else slots
+            flops_launch = 2 * 2.0 * 90 * f * f * 9 * rows_launch
             tfl = flops_launch / (b_ms * 1e-3) / 1e12
             pmc = pmc_nn("k_resblock")
             kdesc = ("k_resblock<C8> (csrc/xq_conv.hip): one residual block (2 x conv3x3 + bias + skip + ReLU) of the tower "
@@ -854,7 +950,7 @@ def main():
             out["roofline"] = {"kernel": kdesc,
                                "bound": "mfma", "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s", "frac": tfl / 2500.0,
                                "traffic": pmc.get("hbm_bytes_per_launch"), "traffic_source": pmc.get("source"),
-                               "avg_launch_ms": b_ms, "launches_timed": len(blk),
+                               "avg_launch_ms": b_ms, "launches_timed": len(blk), "boards_per_launch": rows_launch,
                                "algorithmic_flops_per_launch": flops_launch,
                                "tower_arithmetic": arith, "mfma_equivalents_per_product": mfma_equiv,
                                "issued_bf16_tflops": mfma_equiv * tfl * 96.0 / 90.0,
@@ -901,16 +997,26 @@ def main():
             if sblk:
                 sb_ms = sum(sblk) / len(sblk)
                 f = cfg.model.cnn_filter_num
-                stfl = 2 * 2.0 * 90 * f * f * 9 * slots / (sb_ms * 1e-3) / 1e12
+                srows = sd["expansions"] / max(1, n_sus * world) if eng.compact else slots
+                stfl = 2 * 2.0 * 90 * f * f * 9 * srows / (sb_ms * 1e-3) / 1e12
                 srec["roofline"] = {"kernel": "k_resblock", "bound": "mfma", "achieved": stfl, "peak": 2500.0,
                                     "unit": "TFLOP/s", "frac": stfl / 2500.0, "avg_launch_ms": sb_ms,
-                                    "launches_timed": len(sblk)}
+                                    "launches_timed": len(sblk), "boards_per_launch": srows}
             out["sustained"] = srec
             out["value_sustained"] = s_exp
+            out["games_per_hour_steady_state"] = srec["games_per_hour_steady_state"]
+            out["roofline_frac_sustained"] = srec.get("roofline", {}).get("frac")
             out["quote"] = ("value = the K timed steps the contract asks for (games in the opening phase); "
                             "value_sustained = the 3000-round leg of the same invocation, games in every phase: the figure "
                             "to quote for self-play throughput")
         out["numerics_check"] = numerics_check(eng, ref_net, cfg)
+        # (top-level scalars: the driver's parsed copy of the line drops nested objects)
+        out["numerics_logit_max_abs"] = out["numerics_check"]["policy_logit_max_abs_diff"]
+        sh = out["numerics_check"].get("sharpened") or {}
+        if "guard_selected_measured" in sh:
+            out["numerics_peaked_policy_max_abs"] = sh["guard_selected_measured"]["policy_max_abs"]
+            out["numerics_peaked_arith"] = sh["guard_selected"]
+        out["roofline_frac"] = (out.get("roofline") or {}).get("frac")
         out["collective"] = collective
     eng.close()                                              # every rank; the legs below need the device memory
     del eng
@@ -925,6 +1031,8 @@ def main():
             log("micro-suite done")
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_seconds)
+            out["cpu_tree_only_expansions_per_s"] = out["cpu_baseline"]["value"]
+            out["cpu_with_network_estimate"] = out["cpu_baseline"]["with_network_estimate"]["value"]
             log("cpu baseline done")
         print(json.dumps(out), flush=True)
     if dist_on:

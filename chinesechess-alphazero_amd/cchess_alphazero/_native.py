@@ -93,11 +93,11 @@ def _declare(L):
         L.cz_input_resblock.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
         L.cz_input_resblock.restype = i32
     if hasattr(L, "cz_heads_tail"):
-        L.cz_heads_tail.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, i32, vp, C.c_float, vp, vp, vp, i32, vp, vp]
+        L.cz_heads_tail.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, i32, vp, C.c_float, vp, vp, vp, i32, i32, vp, vp]
         L.cz_heads_tail.restype = i32
         L.cz_fc_packed_elems.argtypes = [i32, i32]
         L.cz_fc_packed_elems.restype = C.c_size_t
-        L.cz_fc_pack_weights.argtypes = [vp, i32, i32, vp]
+        L.cz_fc_pack_weights.argtypes = [vp, i32, i32, i32, vp]
         L.cz_fc_pack_weights.restype = i32
     for name in ("cz_label_tables", "cz_movegen", "cz_done", "cz_step", "cz_encode", "cz_check_or_catch",
                  "cz_be_catched", "cz_has_attack", "cz_rules_fused"):
@@ -379,27 +379,29 @@ def input_resblock(planes, table, in_bias, w1, b1, w2, b2, out, rows=None, count
     return out
 
 
-def pack_fc_weights(w):
-    """fp32 [n_out, n_in] dense-layer matrix -> (hi, lo) bf16 pairs in MFMA fragment order (on the CPU)."""
+def pack_fc_weights(w, dtype=None):
+    """fp32 [n_out, n_in] dense-layer matrix -> (hi, lo) pairs of `dtype` (fp16, the default, or bf16) in MFMA fragment
+    order (on the CPU)."""
     import torch
+    dtype = dtype or torch.float16
     w = w.detach().to("cpu", torch.float32).contiguous()
     n = lib().cz_fc_packed_elems(w.shape[0], w.shape[1])
     if n == 0:
         raise NativeError(f"cz_fc_pack_weights: unsupported shape {tuple(w.shape)}")
-    out = torch.empty((n,), dtype=torch.bfloat16)
-    check(lib().cz_fc_pack_weights(_ptr(w), w.shape[0], w.shape[1], _ptr(out)), "cz_fc_pack_weights")
+    out = torch.empty((n,), dtype=dtype)
+    check(lib().cz_fc_pack_weights(_ptr(w), w.shape[0], w.shape[1], _dt_code(dtype), _ptr(out)), "cz_fc_pack_weights")
     return out
 
 
 def heads_tail(policy_feat, value_feat, wp, bias_p, w1, bias1, w2, b2, policy, value, stats, count=None):
     """softmax(policy_feat @ Wp^T + bp) -> policy [N, n_labels]; tanh(relu(value_feat @ W1^T + b1) @ w2 + b2) -> value [N]
-    (cz_heads_tail; wp / w1 from pack_fc_weights, everything else fp32 on the device).  count: optional int32 device
+    (cz_heads_tail; wp / w1 from pack_fc_weights -- both of the same pair dtype --, everything else fp32 on the device).  count: optional int32 device
     tensor, only the first min(count, N) rows are computed (compact evaluation queue)."""
     require_gpu()
     n = policy_feat.shape[0]
     check(lib().cz_heads_tail(_ptr(policy_feat), policy_feat.shape[1], _ptr(wp), _ptr(bias_p), policy.shape[1],
                               _ptr(value_feat), value_feat.shape[1], _ptr(w1), _ptr(bias1), bias1.shape[0], _ptr(w2),
-                              float(b2), _ptr(policy), _ptr(value), _ptr(stats), n,
+                              float(b2), _ptr(policy), _ptr(value), _ptr(stats), n, _dt_code(wp.dtype),
                               _ptr(count) if count is not None else None, _stream()), "cz_heads_tail")
     return policy, value
 

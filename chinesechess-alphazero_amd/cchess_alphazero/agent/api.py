@@ -15,7 +15,7 @@ import os
 import numpy as np
 import torch
 
-from cchess_alphazero.agent.model import InferenceNet
+from cchess_alphazero.agent.model import guarded_inference_net
 
 
 logger = getLogger(__name__)
@@ -57,7 +57,11 @@ class CChessModelAPI:
         self._arith = os.environ.get("CZ_TOWER_ARITH") or getattr(getattr(config, "engine", None), "net_arith", "bf16x3")
         if agent_model.model.cfg["cnn_filter_num"] not in (32, 128, 192, 256):
             trunk = "library"
-        self.net = InferenceNet(agent_model.model, dtype, trunk=trunk, arith=self._arith).to(self.device)
+        self._guard = None if getattr(getattr(config, "engine", None), "arith_guard", True) else False
+        # (the tower arithmetic is a request: it is measured against the float64 network on calibration positions and
+        #  replaced by a more exact one when these weights need it -- agent/model.py guarded_inference_net)
+        self.net = guarded_inference_net(agent_model.model, dtype, trunk=trunk, arith=self._arith, device=self.device,
+                                         guard=self._guard)
         self._dtype, self._trunk = dtype, trunk
         self.done = False
         self.need_reload = True
@@ -77,7 +81,8 @@ class CChessModelAPI:
                     trunk = self._trunk
                     if self.agent_model.model.cfg["cnn_filter_num"] not in (32, 128, 192, 256):
                         trunk = "library"
-                    self.net = InferenceNet(self.agent_model.model, self._dtype, trunk=trunk, arith=self._arith).to(self.device)
+                    self.net = guarded_inference_net(self.agent_model.model, self._dtype, trunk=trunk, arith=self._arith,
+                                                     device=self.device, guard=self._guard)
                     return True
         except Exception as e:                    # a half-written file: keep serving the old weights
             logger.error(e)

@@ -106,9 +106,16 @@ class InferenceNet(nn.Module):
                      epilogue fused.  With dtype=float32 the operands are (hi, lo) bf16 pairs -- three bf16 MFMAs per
                      product, fp32 accumulate, fp32-class results (policy / value within 1e-4 of the fp32 network) --
                      with bf16 / fp16 they are plain 2-byte operands.
-    arith="c8" (trunk="mfma", float32, 128 filters; CZ_TOWER_ARITH=c8): the tower's products are formed as an fp16 main
-                     term plus two block-scaled fp8 correction terms (csrc/xq_conv.hip, k_resblock<C8>): one fp16 and two
-                     fp8 matrix instructions per 64 input channels instead of three bf16 ones, 2^-16 per product."""
+    arith (trunk="mfma", dtype float32; CZ_TOWER_ARITH overrides the default) -- how an fp32 product is formed:
+      "bf16x3"  (hi, lo) bf16 pairs, w_hi x_hi + w_lo x_hi + w_hi x_lo: 2^-17 per product whatever the operands' range;
+      "f16x3"   the same three MFMAs on (hi, lo) fp16 pairs: 22 bits per operand, ~8x more accurate on networks whose
+                activations and folded filters sit in fp16's range (round 4; tools/f16x3_probe.py: the matrix unit honours
+                fp16 subnormals, which the filters' lo parts are), less accurate than bf16x3 when they are tiny;
+      "c8"      (128 filters) an fp16 main term plus two block-scaled fp8 correction terms (csrc/xq_conv.hip,
+                k_resblock<C8>): one fp16 and two fp8 matrix instructions per 64 input channels, 2^-16 per product;
+      "c8>N"    the first N residual blocks on c8, the rest on f16x3 (error ~ sqrt(N): the guard's middle ground).
+    None of the reduced forms is trusted blindly: guarded_inference_net() below measures the candidate against float64 on
+    calibration positions when weights are loaded and falls back along c8 -> c8>N -> f16x3 -> bf16x3."""
 
     def __init__(self, net: CChessNet, dtype=torch.float32, trunk="library", arith=None):
         super().__init__()
@@ -117,10 +124,19 @@ class InferenceNet(nn.Module):
         self.dtype = dtype
         self.trunk = trunk
         arith = arith or os.environ.get("CZ_TOWER_ARITH") or "bf16x3"
-        assert arith in ("bf16x3", "c8")
-        if arith == "c8" and not (trunk == "mfma" and dtype == torch.float32 and net.cfg["cnn_filter_num"] == 128):
-            arith = "bf16x3"                # the c8 arithmetic exists for the 128-filter split tower only
-        self.arith = arith
+        nblk = net.cfg["res_layer_num"]
+        c8_blocks = 0
+        if arith.startswith("c8"):
+            c8_blocks = int(arith[3:]) if arith.startswith("c8>") else nblk
+            assert 0 <= c8_blocks <= nblk, arith
+            if not (trunk == "mfma" and dtype == torch.float32 and net.cfg["cnn_filter_num"] == 128):
+                c8_blocks = 0               # the c8 arithmetic exists for the 128-filter split tower only
+            arith = "c8" if c8_blocks else "f16x3"
+        assert arith in ("bf16x3", "f16x3", "c8"), arith
+        if arith == "f16x3" and not (trunk == "mfma" and dtype == torch.float32):
+            arith = "bf16x3"
+        self.arith = arith                  # the family; arith_name says how many blocks run c8
+        self.c8_blocks = c8_blocks
         self.fused_epilogue = True          # on the GPU: hand-written bias + skip + ReLU pass after each conv
         self.fused_blocks = True            # trunk="mfma", fp32, 128 filters: one launch per residual block
         self.fused_heads = True             # ... and the 1x1 head convolutions folded into the last block's store pass
@@ -161,8 +177,9 @@ class InferenceNet(nn.Module):
             self.register_buffer("in_table32", self._in_table)
             self.register_buffer("head_w32", self._head_w)
             self.register_buffer("head_b32", self._head_b)
+            self._tail_dtype = self._tail_pack[0].dtype
             for name, t in zip(("tail_wp", "tail_bp", "tail_w1", "tail_b1", "tail_w2"), self._tail_pack):
-                self.register_buffer(name, t.view(torch.int16) if t.dtype == torch.bfloat16 else t)
+                self.register_buffer(name, t.view(torch.int16) if t.dtype in (torch.bfloat16, torch.float16) else t)
             del self._packed_in, self._in_table, self._in_bias32, self._head_w, self._head_b, self._tail_pack
         self._bufs = {}
         self.eval()
@@ -176,18 +193,26 @@ class InferenceNet(nn.Module):
 
     @property
     def operand_dtype(self):
-        if self.arith == "c8":
+        if self.arith in ("c8", "f16x3"):
             return torch.float16
         return torch.bfloat16 if self.dtype == torch.float32 else self.dtype
+
+    @property
+    def arith_name(self):
+        """"bf16x3" / "f16x3" / "c8" / "c8>N" (the first N residual blocks on c8, the rest on f16x3)."""
+        if self.arith == "c8" and self.c8_blocks < len(self.res):
+            return f"c8>{self.c8_blocks}"
+        return self.arith
 
     def _pack_trunk(self):
         """fp32 folded filters -> MFMA fragment order (cz_conv3x3_pack_weights); called before the dtype conversion."""
         from cchess_alphazero import _native
         self._in_bias32 = self.input_conv.bias.detach().float().clone()
         # the dense tail (cz_heads_tail): both matrices as (hi, lo) bf16 pairs in fragment order, the rest fp32
-        self._tail_pack = (_native.pack_fc_weights(self.policy_out.weight),
+        tail_dt = torch.bfloat16 if self.operand_dtype == torch.bfloat16 else torch.float16
+        self._tail_pack = (_native.pack_fc_weights(self.policy_out.weight, tail_dt),
                            self.policy_out.bias.detach().float().clone(),
-                           _native.pack_fc_weights(self.value_dense.weight),
+                           _native.pack_fc_weights(self.value_dense.weight, tail_dt),
                            self.value_dense.bias.detach().float().clone(),
                            self.value_out.weight.detach().float().reshape(-1).clone())
         self._tail_b2 = float(self.value_out.bias.detach().float().item())
@@ -197,13 +222,12 @@ class InferenceNet(nn.Module):
         self._packed_in = _native.pack_input_conv_weights(self.input_conv.weight, self.operand_dtype, self.parts)
         self._in_table = _native.input_table(self.input_conv.weight)      # the gather form of the input layer
         out = []
-        if self.arith == "c8":
-            pack = lambda w: _native.pack_conv3x3_c8_weights(w).view(torch.float16)    # raw bytes, like the others
-        else:
-            pack = lambda w: _native.pack_conv3x3_weights(w, self.operand_dtype, self.parts)
-        for c1, c2 in self.res:
-            out.append((pack(c1.weight), c1.bias.detach().float().clone(),
-                        pack(c2.weight), c2.bias.detach().float().clone()))
+        pack_c8 = lambda w: _native.pack_conv3x3_c8_weights(w).view(torch.float16)    # raw bytes, like the others
+        pack = lambda w: _native.pack_conv3x3_weights(w, self.operand_dtype, self.parts)
+        for i, (c1, c2) in enumerate(self.res):
+            pk = pack_c8 if i < self.c8_blocks else pack
+            out.append((pk(c1.weight), c1.bias.detach().float().clone(),
+                        pk(c2.weight), c2.bias.detach().float().clone()))
         return out
 
     def _operands(self, n, device):
@@ -227,6 +251,11 @@ class InferenceNet(nn.Module):
             return bufs, last
         return [tuple(t[:n] for t in b) for b in bufs], last[:n]
 
+    @staticmethod
+    def _as_f16_pair(pair):
+        """A c8 operand pair's storage seen as an (hi, lo) fp16 pair (same bytes: [n, 90, 2C] u8 = [n, 90, C] f16)."""
+        return pair[0], pair[1].view(torch.float16)
+
     def _trunk_mfma(self, planes, heads=None, rows=None, count=None):
         """planes: the evaluation queue as the search kernel wrote it ([n, in_planes, 10, 9], any supported dtype).
         heads = (n_policy, policy_feat, value_feat): fold the 1x1 head convolutions into the last block where the
@@ -237,12 +266,15 @@ class InferenceNet(nn.Module):
         # compact queue (rows / count on the device): board i = planes[rows[i]] for i < count; the launch shapes stay
         # those of the whole queue, the kernels read the count themselves
         nblk = len(self.res)
+        n8 = self.c8_blocks if self.arith == "c8" else 0        # blocks [0, n8) on the c8 arithmetic
         # whole residual block in one launch where k_resblock exists for the shape
         fused = self.fused_blocks and ((c in (128, 192)) or (c == 256 and self.parts == 1))
         # input layer + first block in one launch: 128 filters, split operands, byte planes, a tower of >= 2 blocks
         first_fused = (fused and self.fused_input and c == 128 and self.parts == 2 and nblk >= 2 and
-                       planes.dtype == torch.uint8 and self.arith != "c8")
+                       planes.dtype == torch.uint8 and n8 == 0)
         if not first_fused:
+            if self.arith == "c8" and n8 == 0:                  # (cannot happen through the constructor; kept total)
+                cur, tmp, nxt = (self._as_f16_pair(t) for t in (cur, tmp, nxt))
             _native.input_conv(planes.contiguous(), self.in_w.view(self.operand_dtype), self.in_bias32, cur,
                                rows=rows, count=count)
         for i in range(nblk):
@@ -258,6 +290,11 @@ class InferenceNet(nn.Module):
                     _native.input_resblock(planes.contiguous(), self.in_table32, self.in_bias32, w1, b1, w2, b2, out=nxt,
                                            rows=rows, count=count)
                     cur, nxt = nxt, cur
+                elif i + 1 == n8 and n8 < nblk:
+                    # the last c8 block of a hybrid tower: fp32 out, re-split into (hi, lo) fp16 pairs for the f16x3 blocks
+                    _native.resblock(cur, w1, b1, w2, b2, out_f32=last, count=count)
+                    cur, tmp, nxt = (self._as_f16_pair(t) for t in (cur, tmp, nxt))
+                    _native.split_bias_act(last, None, cur, relu=False)
                 elif i + 1 < nblk:
                     _native.resblock(cur, w1, b1, w2, b2, out=nxt, count=count)
                     cur, nxt = nxt, cur
@@ -272,9 +309,12 @@ class InferenceNet(nn.Module):
                     ev[1].record()
                     self.block_events.append(ev)
                 continue
-            conv = _native.conv3x3_c8 if self.arith == "c8" else _native.conv3x3
+            if i == n8 and 0 < n8:          # (per-convolution launches, hybrid tower: the same re-split)
+                cur, tmp, nxt = (self._as_f16_pair(t) for t in (cur, tmp, nxt))
+                _native.split_bias_act(last, None, cur, relu=False)
+            conv = _native.conv3x3_c8 if i < n8 else _native.conv3x3
             conv(cur, w1, getattr(self, f"tb{i}a"), out=tmp)
-            if i + 1 < nblk:
+            if i + 1 < nblk and i + 1 != n8:
                 conv(tmp, w2, getattr(self, f"tb{i}b"), skip=cur, out=nxt)
                 cur, nxt = nxt, cur
             elif self.parts == 2:
@@ -343,7 +383,8 @@ class InferenceNet(nn.Module):
                     key = ("tail_stats", str(planes.device))          # scratch for the rows' (max, sum): grown, never per size
                     if key not in self._bufs or self._bufs[key].shape[0] < n:
                         self._bufs[key] = torch.empty((n, 2), dtype=torch.float32, device=planes.device)
-                    _native.heads_tail(pf, vf, self.tail_wp, self.tail_bp, self.tail_w1, self.tail_b1, self.tail_w2,
+                    _native.heads_tail(pf, vf, self.tail_wp.view(self._tail_dtype), self.tail_bp,
+                                       self.tail_w1.view(self._tail_dtype), self.tail_b1, self.tail_w2,
                                        self._tail_b2, out[0], out[1], self._bufs[key], count=count)
                     return out
                 p = self.policy_out(pf.to(self.dtype))
@@ -371,6 +412,173 @@ class InferenceNet(nn.Module):
         v = F.relu(self.value_dense(v.flatten(1)))
         v = torch.tanh(self.value_out(v).float())
         return F.softmax(p.float(), dim=1), v.squeeze(1)
+
+
+# ---- load-time guard of the reduced tower arithmetics -------------------------------------------------------------
+# north_star's tolerance (policy / value within 1e-4 of the reference network, agent/model.py:32-83 evaluated as
+# api.py:63-74 does) is the only licence the split arithmetics have.  It is a property of a NETWORK, not of a kernel: a
+# peaked policy amplifies the trunk's relative error by its logit scale, large activations saturate the c8 image, tiny
+# ones underflow fp16's lo parts.  So every time weights enter (engine construction, hot reload, keras_io load) the
+# candidate arithmetic is measured against a float64 evaluation of the same network on calibration positions and the
+# first one of  c8 -> c8>N -> f16x3 -> bf16x3 -> fp32 library trunk  that stays inside GUARD_TOL is used.
+GUARD_TOL = 5e-5            # half of north_star's 1e-4: the calibration set is a sample
+CALIBRATION_POSITIONS = 256
+
+
+def calibration_planes(n=CALIBRATION_POSITIONS, input_depth=14, device=None, seed=20260924):
+    """uint8 [n, input_depth, 10, 9]: positions of random playouts from the opening, generated with the engine's own rule
+    kernels (cz_movegen / cz_step / cz_done / cz_encode) -- openings, middlegames and thinned-out endgames.  For 28-plane
+    (history) networks the second half is the previous position's planes (zero at the start of a game)."""
+    import numpy as np
+    from cchess_alphazero import _native
+    from cchess_alphazero.environment.static_env import INIT_STATE, state_to_array
+    _native.require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    games = 32
+    rng = np.random.default_rng(seed)
+    init = torch.from_numpy(state_to_array(INIT_STATE)).to(dev)
+    boards = init.repeat(games, 1).contiguous()
+    prev = torch.zeros((games, 14, 10, 9), dtype=torch.uint8, device=dev)
+    out, plies = [], 0
+    stride = 3                                     # keep every third ply of every game
+    while sum(t.shape[0] for t in out) < n:
+        planes = _native.encode(boards, _native.U8)
+        if plies % stride == 0:
+            out.append(planes if input_depth <= 14 else torch.cat([planes, prev], dim=1))
+        moves, counts = _native.movegen(boards)
+        over = _native.done(boards)[0].cpu().numpy() != 0
+        cnt = counts.cpu().numpy().astype(np.int64)
+        pick = (rng.random(games) * np.maximum(cnt, 1)).astype(np.int64)
+        mv = moves.to(torch.int32)[torch.arange(games, device=dev), torch.from_numpy(pick).to(dev)]
+        nxt, _ = _native.step(boards, mv.to(torch.uint16).contiguous())
+        restart = torch.from_numpy(over | (cnt == 0) | (rng.random(games) < 0.004)).to(dev)
+        boards = torch.where(restart[:, None], init[None, :], nxt).contiguous()
+        prev = torch.where(restart[:, None, None, None], torch.zeros_like(planes), planes)
+        plies += 1
+    planes = torch.cat(out)[:n].contiguous()
+    if input_depth < planes.shape[1]:
+        planes = planes[:, :input_depth].contiguous()
+    return planes
+
+
+@torch.no_grad()
+def reference_forward_f64(net: CChessNet, planes, with_activations=False):
+    """The reference network (agent/model.py:32-83; BatchNorm in inference mode as Keras predict_on_batch runs it) in float64
+    on the device of `planes`: (policy [n, 2086], value [n], logits) and, on request, max |activation| of every tower
+    tensor (input layer, each block's intermediate and output)."""
+    import copy
+    dev = planes.device
+    ref = copy.deepcopy(net).eval().double().to(dev)
+    x = planes.double()
+    acts = []
+
+    def bn(m, t):
+        scale = m.weight / torch.sqrt(m.running_var + m.eps)
+        return t * scale.view(1, -1, 1, 1) + (m.bias - m.running_mean * scale).view(1, -1, 1, 1)
+
+    def conv(m, t):                                 # unfold + matmul: float64 has no library convolution on this stack
+        k = m.kernel_size[0]
+        n, c, h, w = t.shape
+        cols = F.unfold(t, k, padding=k // 2)       # [n, c k k, h w]
+        return (m.weight.view(m.out_channels, -1) @ cols).view(n, m.out_channels, h, w)
+
+    x = F.relu(bn(ref.input_bn, conv(ref.input_conv, x)))
+    acts.append(float(x.abs().max()))
+    for blk in ref.res:
+        y = F.relu(bn(blk.bn1, conv(blk.conv1, x)))
+        acts.append(float(y.abs().max()))
+        x = F.relu(x + bn(blk.bn2, conv(blk.conv2, y)))
+        acts.append(float(x.abs().max()))
+    p = F.relu(bn(ref.policy_bn, conv(ref.policy_conv, x)))
+    logits = ref.policy_out(p.flatten(1))
+    v = F.relu(bn(ref.value_bn, conv(ref.value_conv, x)))
+    v = torch.tanh(ref.value_out(F.relu(ref.value_dense(v.flatten(1))))).squeeze(1)
+    out = (F.softmax(logits, dim=1), v, logits)
+    return out + (acts,) if with_activations else out
+
+
+def measure_against_reference(inf, ref_out, planes):
+    """Max deviations of an InferenceNet from reference_forward_f64's outputs on the same planes."""
+    p, v = inf(planes)
+    p, v = p.double(), v.double()
+    pr, vr, lr = ref_out[:3]
+    # the logit deviation up to the softmax's free constant: log p - log p_ref where both are representable
+    ok = (pr > 1e-30) & (p > 1e-30)
+    dl = torch.where(ok, torch.log(p.clamp_min(1e-300)) - torch.log(pr.clamp_min(1e-300)), torch.zeros_like(p))
+    dl = dl - dl.sum(1, keepdim=True) / ok.sum(1, keepdim=True).clamp_min(1)
+    return dict(policy_max_abs=float((p - pr).abs().max()), value_max_abs=float((v - vr).abs().max()),
+                logit_max_abs=float(torch.where(ok, dl, torch.zeros_like(dl)).abs().max()),
+                finite=bool(torch.isfinite(p).all() and torch.isfinite(v).all()))
+
+
+def guard_chain(arith, c8_blocks, n_blocks, activation_max):
+    """The candidates guarded_inference_net tries, most reduced first, for a requested arithmetic family and the tower's
+    measured activation ranges: a c8 image saturates above 448 (such a tower is not even tried), fp16 pairs overflow at
+    65504 (kept a factor of two away), bf16 pairs have fp32's range."""
+    chain = []
+    top = max(activation_max) if activation_max else 0.0
+    if arith == "c8" and top <= 448.0:
+        chain += [f"c8>{k}" if k < n_blocks else "c8" for k in (c8_blocks, c8_blocks - 2, c8_blocks - 4) if k >= 1]
+    if arith in ("c8", "f16x3") and top < 3.0e4:
+        chain.append("f16x3")
+    chain.append("bf16x3")
+    return chain
+
+
+def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", arith=None, device=None, tol=GUARD_TOL,
+                          planes=None, guard=None):
+    """InferenceNet(net, ...) on `device` with the tower arithmetic CHECKED: the requested arithmetic is measured against
+    the float64 network on calibration positions and replaced by the next more exact one while policy or value deviate by
+    more than `tol` (c8 -> c8>N with fewer and fewer c8 blocks -> f16x3 -> bf16x3 -> the fp32 library trunk).  The result
+    carries  .arith_requested, .arith_effective, .calibration (every candidate's measurements, the tower's activation
+    ranges, the c8 image's predicted saturation / underflow counts).  guard=False (or CZ_ARITH_GUARD=0) skips the
+    measurement -- tests of a specific kernel path want exactly what they ask for."""
+    from cchess_alphazero import _native
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    requested = arith or os.environ.get("CZ_TOWER_ARITH") or "bf16x3"
+    if guard is None:
+        guard = os.environ.get("CZ_ARITH_GUARD", "1") != "0"
+    first = InferenceNet(net, dtype, trunk=trunk, arith=requested).to(dev)
+    first.arith_requested = requested
+    first.arith_effective = first.arith_name
+    first.calibration = None
+    reduced = trunk == "mfma" and dtype == torch.float32        # (a caller asking for bf16 / fp16 operands asked for them)
+    if not guard or not reduced or dev.type != "cuda":
+        return first
+    with torch.cuda.device(dev):
+        if planes is None:
+            planes = calibration_planes(CALIBRATION_POSITIONS, net.cfg["input_depth"], dev)
+        ref = reference_forward_f64(net, planes, with_activations=True)
+        acts = ref[3]
+        report = dict(tol=tol, positions=int(planes.shape[0]), max_policy_probability=float(ref[0].max()),
+                      activation_max=acts, candidates=[])
+        # what the c8 image would do to these activations (value byte saturates above 448; below 2^-9 it is 0; its
+        # lo byte e4m3(x_lo * 2^11) saturates when |x| > ~2^9 * 448 / 2^-... i.e. with the value byte): reported, and a
+        # saturating tower is not even tried
+        report["c8_saturating_layers"] = [i for i, a in enumerate(acts) if a > 448.0]
+        chain = guard_chain(first.arith, first.c8_blocks, len(net.res), acts)
+        cand = first
+        for name in chain:
+            if cand is None or cand.arith_name != name:
+                cand = InferenceNet(net, dtype, trunk=trunk, arith=name).to(dev)
+            m = measure_against_reference(cand, ref, planes)
+            m["arith"] = name
+            report["candidates"].append(m)
+            if m["finite"] and m["policy_max_abs"] <= tol and m["value_max_abs"] <= tol:
+                break
+            cand = None
+        else:
+            logger.warning("no split arithmetic keeps this network within %g of float64 (%s): using the fp32 library trunk",
+                           tol, report["candidates"])
+            cand = InferenceNet(net, dtype, trunk="library").to(dev)
+            name = "fp32-library"
+        if name != first.arith_name:
+            logger.warning("tower arithmetic %s deviates from the float64 network by more than %g on the calibration "
+                           "positions (%s): using %s", requested, tol, report["candidates"][0], name)
+        cand.arith_requested = requested
+        cand.arith_effective = name
+        cand.calibration = report
+    return cand
 
 
 def flops_per_position(cfg):

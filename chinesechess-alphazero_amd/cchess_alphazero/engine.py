@@ -19,7 +19,7 @@ import torch
 
 from cchess_alphazero import _native
 from cchess_alphazero._native_search import Search
-from cchess_alphazero.agent.model import CChessNet, InferenceNet
+from cchess_alphazero.agent.model import CChessNet, guarded_inference_net
 from cchess_alphazero.environment.lookup_tables import ActionLabelsRed
 from cchess_alphazero.environment.static_env import INIT_STATE
 
@@ -70,14 +70,24 @@ class SelfPlayEngine:
                              sims_per_round=sims_per_round, device=self.device, use_history=use_history,
                              pool_fraction=getattr(getattr(config, "engine", None), "pool_fraction", None))
         if evaluator is None:
-            self.net = InferenceNet(net, dtype, trunk=self.trunk, arith=self.arith).to(self.device)
+            self._install(net)
         # compact evaluation queue: the network runs only on the slots that hold a new leaf (2-7 % of the slots of a
         # sustained self-play round carry none, more with large K); needs the kernels that read the count on the device
         want = getattr(getattr(config, "engine", None), "compact_queue", True)
+        self._want_compact = want
         self.compact = bool(want and self.net is not None and self.net.supports_compact_queue())
         self.rounds = 0
         self.seed = seed
         self._graph = None
+
+    def _install(self, net):
+        """Build the inference network for these weights with the tower arithmetic checked against float64 (agent/model.py
+        guarded_inference_net): engine.net_arith is the REQUEST, net_arith_effective what the weights allow."""
+        guard = getattr(getattr(self.config, "engine", None), "arith_guard", True)
+        self.net = guarded_inference_net(net, self.dtype, trunk=self.trunk, arith=self.arith, device=self.device,
+                                         guard=None if guard else False)
+        self.net_arith_effective = self.net.arith_effective
+        self.net_calibration = self.net.calibration
 
     # ---- control ----
     def set_network(self, net):
@@ -90,7 +100,8 @@ class SelfPlayEngine:
         had_graph = self._graph is not None
         self._graph = None
         torch.cuda.synchronize(self.device)
-        self.net = InferenceNet(net, self.dtype, trunk=self.trunk, arith=self.arith).to(self.device)
+        self._install(net)
+        self.compact = bool(self._want_compact and self.net.supports_compact_queue())
         if had_graph:
             self.capture_graph()
 

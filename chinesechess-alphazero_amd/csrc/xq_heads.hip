@@ -11,9 +11,11 @@
 //                       the loop: the positions are the COLUMNS of the MFMA, so a lane owns one position
 //   k_policy_normalize  p = exp(logit - max) / sum in place (one streaming pass, rows of 8344 bytes, 8-byte accesses)
 //   k_fc_tile<VALUE>    hidden = relu(feat . W1^T + b1) stays in the accumulators, value = tanh(hidden . w2 + b2)
-// Arithmetic: the same split-operand scheme as the tower (xq_conv.hip): every fp32 operand is a (hi, lo) pair of bf16,
-// a product is accumulated as w_hi x_hi + w_lo x_hi + w_hi x_lo in fp32 by v_mfma_f32_32x32x16_bf16 (dropped term and
-// representation error: 2^-17 relative per product, the tower's own precision).  Order: K-steps of 16 features in index
+// Arithmetic: the same split-operand scheme as the tower (xq_conv.hip): every fp32 operand is a (hi, lo) pair of 2-byte
+// values, a product is accumulated as w_hi x_hi + w_lo x_hi + w_hi x_lo in fp32 by v_mfma_f32_32x32x16_{bf16,f16}.
+// dtype CZ_BF16: dropped term and representation error 2^-17 relative per product; CZ_F16 (round 4, what the network
+// uses unless bf16x3 was asked for): (hi, lo) fp16 pairs hold 22 bits where fp16's range holds the lo part (features are
+// O(1), fp16 subnormal inputs are honoured by the matrix unit -- tools/f16x3_probe.py), 2^-21 class, same cost.  Order: K-steps of 16 features in index
 // order, the three terms of a step in the order above; the softmax statistics are accumulated per lane over its label
 // tiles in index order, combined across the two half-waves and the four waves of a position tile in a fixed order.
 // Weights are packed on the host in fragment order (cz_fc_pack_weights); they stream from L2 (3 MB for the policy
@@ -29,7 +31,22 @@ extern "C" void czi_set_error(const char* msg);
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <typename E> struct FcMma;
+template <> struct FcMma<__bf16> {
+    static __device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct FcMma<_Float16> {
+    static __device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
 
 constexpr int TILE_ROWS = 64;         // positions per workgroup pass (two MFMA column tiles)
 constexpr int FC_THREADS = 512;       // 8 waves: wave w -> position tile w & 1, label tiles (w >> 1) mod 4
@@ -45,7 +62,7 @@ enum FcMode { FC_POLICY = 0, FC_VALUE = 1 };
 
 struct FcArgs {
     const float* feat;        // [n][F]
-    const __bf16* wp;         // packed weights [label tiles][ksteps + pad][2 parts][64 lanes][8]
+    const void* wp;           // packed weights [label tiles][ksteps + pad][2 parts][64 lanes][8]
     const float* bias;        // [n_out]
     int F, ksteps, n_out, n_tiles;
     // policy
@@ -64,7 +81,7 @@ struct FcArgs {
 // k_policy_normalize.  Half of this kernel's issue slots went to libm exps before (0.277 -> see profiles/r03_*).
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
-template <int MODE, int F>
+template <int MODE, int F, typename E>
 __global__ __launch_bounds__(FC_THREADS) void k_fc_tile(FcArgs a, int n, const int32_t* __restrict__ n_dev)
 {
     constexpr int KS = (F + 15) / 16;                 // K-steps
@@ -83,7 +100,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_tile(FcArgs a, int n, const i
     float* red = reinterpret_cast<float*>(lds + FC_IMG_BYTES);   // [2 values][2 position tiles][4 wave classes][32]
     unsigned char* stg = lds + FC_IMG_BYTES + FC_RED_BYTES + wave * FC_STAGE_BYTES;      // this wave's logit tile
     const int n_row_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
-    struct alignas(8) Q4 { __bf16 e[4]; };
+    struct alignas(8) Q4 { E e[4]; };
     for (int rt = blockIdx.x; rt < n_row_tiles; rt += gridDim.x) {
         const int row0 = rt * TILE_ROWS;
         // ---- stage the tile's features as (hi, lo) bf16: the tile is one contiguous block of 64 x F floats ----
@@ -98,8 +115,8 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_tile(FcArgs a, int n, const i
                 Q4 hi, lo;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    hi.e[j] = (__bf16)f[j];
-                    lo.e[j] = (__bf16)(f[j] - (float)hi.e[j]);
+                    hi.e[j] = (E)f[j];
+                    lo.e[j] = (E)(f[j] - (float)hi.e[j]);
                 }
                 *reinterpret_cast<Q4*>(lds + r * RB + k * 2) = hi;
                 *reinterpret_cast<Q4*>(lds + PART + r * RB + k * 2) = lo;
@@ -151,13 +168,12 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_tile(FcArgs a, int n, const i
                     xl_n = *reinterpret_cast<const uint4*>(brow + PART + (ks + 1) * 32);
                 }
                 const uint4* c = w[ks % RING];
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, xh), bl = __builtin_bit_cast(bf16x8, xl);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[0]), bh, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[2]), bh, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[1]), bh, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[3]), bh, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[0]), bl, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c[2]), bl, acc1, 0, 0, 0);
+                acc0 = FcMma<E>::mma(c[0], xh, acc0);
+                acc1 = FcMma<E>::mma(c[2], xh, acc1);
+                acc0 = FcMma<E>::mma(c[1], xh, acc0);
+                acc1 = FcMma<E>::mma(c[3], xh, acc1);
+                acc0 = FcMma<E>::mma(c[0], xl, acc0);
+                acc1 = FcMma<E>::mma(c[2], xl, acc1);
                 xh = xh_n; xl = xl_n;
                 __builtin_amdgcn_sched_barrier(0);       // keep the loads where they are issued: RING - 1 steps ahead
             }
@@ -297,6 +313,20 @@ inline float host_bf16_f(uint16_t h)
     return f;
 }
 
+inline uint16_t host_f16(float f)
+{
+    const _Float16 h = (_Float16)f;
+    uint16_t b;
+    memcpy(&b, &h, 2);
+    return b;
+}
+inline float host_f16_f(uint16_t b)
+{
+    _Float16 h;
+    memcpy(&h, &b, 2);
+    return (float)h;
+}
+
 int device_cus()
 {
     static int n_cu = 0;
@@ -318,11 +348,11 @@ extern "C" size_t cz_fc_packed_elems(int n_out, int n_in)
     return tiles * (ksteps + FC_PAD_STEPS) * 2 * 64 * 8;
 }
 
-extern "C" int cz_fc_pack_weights(const float* w, int n_out, int n_in, void* out_host)
+extern "C" int cz_fc_pack_weights(const float* w, int n_out, int n_in, int dtype, void* out_host)
 {
     const size_t elems = cz_fc_packed_elems(n_out, n_in);
-    if (!w || !out_host || elems == 0) {
-        czi_set_error("cz_fc_pack_weights: bad argument");
+    if (!w || !out_host || elems == 0 || (dtype != CZ_BF16 && dtype != CZ_F16)) {
+        czi_set_error("cz_fc_pack_weights: bad argument (dtype: CZ_BF16 or CZ_F16 pairs)");
         return CZ_ERR_ARG;
     }
     uint16_t* out = (uint16_t*)out_host;
@@ -335,10 +365,11 @@ extern "C" int cz_fc_pack_weights(const float* w, int n_out, int n_in, void* out
                     const int o = lt * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8 + j;
                     if (o >= n_out || k >= n_in) continue;
                     const float v = w[(size_t)o * n_in + k];
-                    const uint16_t hi = host_bf16(v);
+                    const uint16_t hi = dtype == CZ_BF16 ? host_bf16(v) : host_f16(v);
                     const size_t base = (((size_t)lt * (ksteps + FC_PAD_STEPS) + ks) * 2) * 64 * 8;
                     out[base + (size_t)lane * 8 + j] = hi;
-                    out[base + 64 * 8 + (size_t)lane * 8 + j] = host_bf16(v - host_bf16_f(hi));
+                    out[base + 64 * 8 + (size_t)lane * 8 + j] =
+                        dtype == CZ_BF16 ? host_bf16(v - host_bf16_f(hi)) : host_f16(v - host_f16_f(hi));
                 }
     return CZ_OK;
 }
@@ -346,12 +377,13 @@ extern "C" int cz_fc_pack_weights(const float* w, int n_out, int n_in, void* out
 extern "C" int cz_heads_tail(const float* policy_feat, int n_policy_feat, const void* wp_packed, const float* bias_p,
                              int n_labels, const float* value_feat, int n_value_feat, const void* w1_packed,
                              const float* bias1, int n_hidden, const float* w2, float b2, float* policy, float* value,
-                             float* stats_scratch, int n_boards, const int32_t* n_dev, void* stream)
+                             float* stats_scratch, int n_boards, int dtype, const int32_t* n_dev, void* stream)
 {
     if (!policy_feat || !wp_packed || !bias_p || !value_feat || !w1_packed || !bias1 || !w2 || !policy || !value ||
-        !stats_scratch || n_boards < 0 || n_labels < 2 || (n_labels & 1) || n_hidden < 1 || n_policy_feat < 1 ||
+        !stats_scratch || n_boards < 0 || (dtype != CZ_BF16 && dtype != CZ_F16) || n_labels < 2 || (n_labels & 1) || n_hidden < 1 || n_policy_feat < 1 ||
         (n_policy_feat != 180 && n_policy_feat != 360) || (n_value_feat != 180 && n_value_feat != 360)) {
-        czi_set_error("cz_heads_tail: bad argument (n_labels even; 180 or 360 features per head: 2 or 4 filters x 90 squares)");
+        czi_set_error("cz_heads_tail: bad argument (n_labels even; 180 or 360 features per head: 2 or 4 filters x 90 squares; "
+                      "dtype of the packed pairs: CZ_BF16 or CZ_F16)");
         return CZ_ERR_ARG;
     }
     if (n_boards == 0) return CZ_OK;
@@ -364,12 +396,17 @@ extern "C" int cz_heads_tail(const float* policy_feat, int n_policy_feat, const 
     const int row_tiles = (n_boards + TILE_ROWS - 1) / TILE_ROWS;
     {
         FcArgs a{};
-        a.feat = policy_feat; a.wp = (const __bf16*)wp_packed; a.bias = bias_p; a.F = n_policy_feat;
+        a.feat = policy_feat; a.wp = wp_packed; a.bias = bias_p; a.F = n_policy_feat;
         a.ksteps = (n_policy_feat + 15) / 16; a.n_out = n_labels; a.n_tiles = (n_labels + 31) / 32;
         a.logits = policy; a.stats = reinterpret_cast<float2*>(stats_scratch);
         const unsigned blocks = (unsigned)(row_tiles < 2 * n_cu ? row_tiles : 2 * n_cu);
-        if (n_policy_feat == 360) hipLaunchKernelGGL((k_fc_tile<FC_POLICY, 360>), dim3(blocks), dim3(FC_THREADS), 0, st, a, n_boards, n_dev);
-        else hipLaunchKernelGGL((k_fc_tile<FC_POLICY, 180>), dim3(blocks), dim3(FC_THREADS), 0, st, a, n_boards, n_dev);
+#define CZ_FC(MODE, FEAT)                                                                                              \
+        do {                                                                                                          \
+            if (dtype == CZ_BF16) hipLaunchKernelGGL((k_fc_tile<MODE, FEAT, __bf16>), dim3(blocks), dim3(FC_THREADS), 0, st, a, n_boards, n_dev); \
+            else hipLaunchKernelGGL((k_fc_tile<MODE, FEAT, _Float16>), dim3(blocks), dim3(FC_THREADS), 0, st, a, n_boards, n_dev);                \
+        } while (0)
+        if (n_policy_feat == 360) CZ_FC(FC_POLICY, 360);
+        else CZ_FC(FC_POLICY, 180);
         size_t nb = ((size_t)n_boards + 3) / 4;
         if (nb > (size_t)n_cu * 16) nb = (size_t)n_cu * 16;
         hipLaunchKernelGGL(k_policy_normalize, dim3((unsigned)nb), dim3(256), 0, st, policy,
@@ -377,12 +414,13 @@ extern "C" int cz_heads_tail(const float* policy_feat, int n_policy_feat, const 
     }
     {
         FcArgs a{};
-        a.feat = value_feat; a.wp = (const __bf16*)w1_packed; a.bias = bias1; a.F = n_value_feat;
+        a.feat = value_feat; a.wp = w1_packed; a.bias = bias1; a.F = n_value_feat;
         a.ksteps = (n_value_feat + 15) / 16; a.n_out = n_hidden; a.n_tiles = (n_hidden + 31) / 32;
         a.w2 = w2; a.b2 = b2; a.value = value;
         const unsigned blocks = (unsigned)(row_tiles < 2 * n_cu ? row_tiles : 2 * n_cu);
-        if (n_value_feat == 180) hipLaunchKernelGGL((k_fc_tile<FC_VALUE, 180>), dim3(blocks), dim3(FC_THREADS), 0, st, a, n_boards, n_dev);
-        else hipLaunchKernelGGL((k_fc_tile<FC_VALUE, 360>), dim3(blocks), dim3(FC_THREADS), 0, st, a, n_boards, n_dev);
+        if (n_value_feat == 180) CZ_FC(FC_VALUE, 180);
+        else CZ_FC(FC_VALUE, 360);
+#undef CZ_FC
     }
     if (hipGetLastError() != hipSuccess) {
         czi_set_error("cz_heads_tail: launch failed");

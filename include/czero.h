@@ -330,14 +330,18 @@ int cz_head_convs(const void* x, int dtype, const float* w, const float* bias, f
  *   stats_scratch            DEVICE scratch of 2 * n_boards floats (the rows' max / sum of exp between the launches)
  *   n_dev                    NULL, or the DEVICE int32 count of the compact evaluation queue: only the first
  *                            min(*n_dev, n_boards) rows are computed and written
- * Precision: operands as (hi, lo) bf16 pairs, three MFMAs per product, fp32 accumulation -- the tower's arithmetic. */
+ *   dtype                    the element type of the packed pairs (the one given to cz_fc_pack_weights): CZ_BF16 or CZ_F16
+ * Precision: operands as (hi, lo) pairs, three MFMAs per product, fp32 accumulation -- the tower's arithmetic: 2^-17 per
+ * product with bf16 pairs, 2^-21 class with fp16 pairs (22 bits per operand; the head features are O(1), well inside
+ * fp16's range, and the matrix unit honours fp16 subnormals -- tools/f16x3_probe.py). */
 int cz_heads_tail(const float* policy_feat, int n_policy_feat, const void* wp_packed, const float* bias_p,
                   int n_labels, const float* value_feat, int n_value_feat, const void* w1_packed, const float* bias1,
                   int n_hidden, const float* w2, float b2, float* policy, float* value, float* stats_scratch,
-                  int n_boards, const int32_t* n_dev, void* stream);
-/* number of 2-byte elements of a packed dense layer (0 = bad argument); HOST: w[n_out][n_in] fp32 -> fragment order */
+                  int n_boards, int dtype, const int32_t* n_dev, void* stream);
+/* number of 2-byte elements of a packed dense layer (0 = bad argument); HOST: w[n_out][n_in] fp32 -> (hi, lo) pairs of
+ * `dtype` (CZ_BF16 / CZ_F16) in fragment order */
 size_t cz_fc_packed_elems(int n_out, int n_in);
-int cz_fc_pack_weights(const float* w, int n_out, int n_in, void* out_host);
+int cz_fc_pack_weights(const float* w, int n_out, int n_in, int dtype, void* out_host);
 
 /* test hook: out[n] (DEVICE, float64) = n draws of the root noise np.random.dirichlet(alpha * ones(n_moves))[0]
  * (agent/player.py:304) from the generator the search kernel uses (k_noise; csrc/xq_noise.h: counter-based integer

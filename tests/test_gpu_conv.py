@@ -637,22 +637,27 @@ def test_pipelined_resblock_is_bit_identical_to_the_plain_schedule(dt):
         _native.resblock_pipelined(old)
 
 
+@pytest.mark.parametrize("pair", ["bfloat16", "float16"])
 @pytest.mark.parametrize("fp,fv", [(360, 180), (180, 360)])
-def test_heads_tail_matches_float64(fp, fv):
+def test_heads_tail_matches_float64(fp, fv, pair):
     """cz_heads_tail (csrc/xq_heads.hip: Dense(2086) + softmax, Dense(256) + ReLU + Dense(1) + tanh; reference
     agent/model.py:58-59,64-66) against float64 PyTorch on the same fp32 inputs.  Tolerance, derived: every product is
     formed from (hi, lo) bf16 pairs with the lo*lo term dropped -- relative error <= 3 * 2^-17 < 2^-15 per product -- and
     accumulated in fp32, so |d logit| <= B = 2^-15 * sum_k |w_k| |x_k| (+ 1e-6 for the accumulation); a softmax output
-    then moves by at most 2 B relative, tanh is 1-Lipschitz.  Sizes around the 64-position tile, the reference's two
-    head shapes (4 + 2 and 2 + 4 filters), and the compact queue's device-side count."""
+    then moves by at most 2 B relative, tanh is 1-Lipschitz.  With (hi, lo) fp16 pairs (the default since round 4: 22 bits per
+    operand, the weights' lo parts are fp16 subnormals here and must be honoured) the per-product bound is 2^-19.  Sizes
+    around the 64-position tile, the reference's two head shapes (4 + 2 and 2 + 4 filters), and the compact queue's
+    device-side count."""
     import torch
     from cchess_alphazero import _native
     torch.manual_seed(3)
+    pdt = getattr(torch, pair)
+    eps = 2.0 ** -15 if pair == "bfloat16" else 2.0 ** -19
     n_lab, n_hid = 2086, 256
     wp, bp = torch.randn(n_lab, fp) * 0.08, torch.randn(n_lab) * 0.5
     w1, b1 = torch.randn(n_hid, fv) * 0.1, torch.randn(n_hid) * 0.2
     w2, b2 = torch.randn(n_hid) * 0.2, 0.13
-    pk_p, pk_1 = _native.pack_fc_weights(wp).cuda(), _native.pack_fc_weights(w1).cuda()
+    pk_p, pk_1 = _native.pack_fc_weights(wp, pdt).cuda(), _native.pack_fc_weights(w1, pdt).cuda()
     for n, cnt in ((1, None), (63, None), (64, None), (65, None), (1000, None), (300, 123), (70, 0)):
         pf = torch.relu(torch.randn(n, fp)) * 1.5
         vf = torch.relu(torch.randn(n, fv)) * 1.5
@@ -667,13 +672,13 @@ def test_heads_tail_matches_float64(fp, fv):
             continue
         lg = pf[:m].double() @ wp.double().T + bp.double()
         p_ref = torch.softmax(lg, dim=1)
-        bound = 2.0 ** -15 * (pf[:m].abs().double() @ wp.abs().double().T).max().item() + 1e-6
+        bound = eps * (pf[:m].abs().double() @ wp.abs().double().T).max().item() + 1e-6
         p = pol[:m].cpu().double()
         assert torch.isfinite(p).all() and (p.sum(1) - 1).abs().max() < 1e-5
         assert ((p - p_ref).abs() <= 2.5 * bound * p_ref + 1e-12).all(), ((p - p_ref).abs() / p_ref).max()
         hid = torch.relu(vf[:m].double() @ w1.double().T + b1.double())
         v_ref = torch.tanh(hid @ w2.double() + b2)
-        vb = ((2.0 ** -15 * (vf[:m].abs().double() @ w1.abs().double().T) + 1e-6) @ w2.abs().double()).max().item() + 1e-5
+        vb = ((eps * (vf[:m].abs().double() @ w1.abs().double().T) + 1e-6) @ w2.abs().double()).max().item() + 1e-5
         assert (val[:m].cpu().double() - v_ref).abs().max().item() <= vb
         # and against what the library path computes in fp32 (the path it replaces): well inside 1e-5
         p32 = torch.softmax(pf[:m].cuda() @ wp.cuda().T + bp.cuda(), dim=1)

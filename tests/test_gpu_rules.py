@@ -142,23 +142,48 @@ def test_random_playouts_vs_oracle(nat):
     assert (N.be_catched(boards_d, moves_d).cpu().numpy() == np.array(eb, dtype=np.uint8)).all()
 
 
-def test_full_size_replicated_suite(nat, positions_1k):
-    """1M boards (the micro-suite size of SURVEY 8(d)): every replica must reproduce its source row."""
+def test_full_size_suite_against_the_oracle(nat, positions_1k):
+    """1M boards (the micro-suite size of SURVEY 8(d)) through the lane-per-board kernel at full size, pinned DIRECTLY: the
+    fixed 1k-position suite replicated and then diversified on the device by 0-3 random legal plies per board (inputs
+    only: whatever boards come out, the oracle judges the outputs), 64k boards drawn at random from the million compared
+    bit for bit with the oracle (xo.batch_rules = static_env.py:14-77,137-194,256-321 restated), plus two properties on all
+    of them (one-hot planes; replicas that were not moved reproduce their source row)."""
     N, torch = nat
     base = torch.from_numpy(_boards([r["state"] for r in positions_1k])).cuda()
-    ref = N.rules_fused(base, N.U8)
     n = 1 << 20
     g = torch.Generator(device="cuda").manual_seed(1)
     src = torch.randint(0, base.shape[0], (n,), device="cuda", generator=g)
     big = base[src].contiguous()
+    plies = torch.randint(0, 4, (n,), device="cuda", generator=g)
+    for k in range(3):
+        mv, ct = N.movegen(big)
+        over = N.done(big)[0]
+        pick = (torch.rand((n,), device="cuda", generator=g) * ct.float()).long().clamp_max(127)
+        m = mv.to(torch.int32)[torch.arange(n, device="cuda"), pick].to(torch.uint16).contiguous()
+        nxt, _ = N.step(big, m)
+        go = (plies > k) & (ct > 0) & (over == 0)
+        big = torch.where(go[:, None], nxt, big).contiguous()
+        plies = torch.where(go, plies, torch.zeros_like(plies))          # a board that stopped stays stopped
     out = N.rules_fused(big, N.U8)
+    assert len(torch.unique(big, dim=0)) > 300000                        # a million boards, not a thousand
+    # (1) 64k random boards of the million against the oracle, every output
+    idx = torch.randperm(n, device="cuda", generator=g)[:1 << 16]
+    sub = big[idx].cpu().numpy()
+    exp = xo.batch_rules(sub)
     for k in ("counts", "over", "v", "check"):
-        assert torch.equal(out[k], ref[k][src]), k
-    assert torch.equal(out["moves"].view(torch.int16), ref["moves"].view(torch.int16)[src])
-    assert torch.equal(out["final_move"].view(torch.int16), ref["final_move"].view(torch.int16)[src])
-    assert torch.equal(out["planes"], ref["planes"][src])
-    # planes are one-hot per piece: sum == piece count
+        assert (out[k][idx].cpu().numpy() == exp[k]).all(), k
+    for k in ("moves", "final_move"):
+        assert (out[k].view(torch.int16)[idx].cpu().numpy().view(np.uint16) == exp[k]).all(), k
+    assert (out["planes"][idx].cpu().numpy() == exp["planes"].astype(np.uint8)).all()
+    # (2) planes are one-hot per piece on all of them: sum == piece count
     assert torch.equal(out["planes"].sum(dim=(1, 2, 3), dtype=torch.int32), (big != 0).sum(dim=1, dtype=torch.int32))
+    # (3) the boards that were never moved reproduce their source row of the (golden-pinned) 1k suite
+    ref = N.rules_fused(base, N.U8)
+    same = (big == base[src]).all(dim=1)
+    assert int(same.sum()) > n // 8
+    for k in ("counts", "over", "v", "check"):
+        assert torch.equal(out[k][same], ref[k][src][same]), k
+    assert torch.equal(out["moves"].view(torch.int16)[same], ref["moves"].view(torch.int16)[src][same])
 
 
 def test_edge_cases(nat):

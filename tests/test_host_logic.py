@@ -221,7 +221,8 @@ def test_tower_arithmetic_selection_on_the_host(monkeypatch):
     assert InferenceNet(net, torch.float32, trunk="mfma").arith == "bf16x3"                 # explicit default of the class
     assert InferenceNet(net, torch.float32, trunk="library", arith="c8").arith == "bf16x3"  # no hand-written trunk
     assert InferenceNet(net, torch.float16, trunk="mfma", arith="c8").arith == "bf16x3"     # plain fp16 operands
-    assert InferenceNet(CChessNet(cnn_filter_num=192, res_layer_num=1), torch.float32, trunk="mfma", arith="c8").arith == "bf16x3"
+    # (192 filters have no c8 kernels: the request degrades to the fp16 pairs, the next more exact arithmetic)
+    assert InferenceNet(CChessNet(cnn_filter_num=192, res_layer_num=1), torch.float32, trunk="mfma", arith="c8").arith == "f16x3"
     monkeypatch.setenv("CZ_TOWER_ARITH", "c8")
     assert InferenceNet(net, torch.float32, trunk="mfma").arith == "c8"
     monkeypatch.setenv("CZ_TOWER_ARITH", "bf16x3")
@@ -297,3 +298,38 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"],
                          env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "--gpus 2" in (bad.stderr + bad.stdout)
+
+
+def test_guard_chain_orders_the_candidates_by_exactness():
+    """agent/model.py guard_chain: which tower arithmetics the load-time guard tries for a request and a tower's measured
+    activation ranges (c8 image saturates at 448, fp16 pairs overflow at 65504)."""
+    from cchess_alphazero.agent.model import guard_chain
+    assert guard_chain("c8", 7, 7, [3.0, 9.5]) == ["c8", "c8>5", "c8>3", "f16x3", "bf16x3"]
+    assert guard_chain("c8", 5, 7, [3.0]) == ["c8>5", "c8>3", "c8>1", "f16x3", "bf16x3"]
+    assert guard_chain("c8", 2, 2, [1.0]) == ["c8", "f16x3", "bf16x3"]
+    assert guard_chain("c8", 7, 7, [3.0, 500.0]) == ["f16x3", "bf16x3"]
+    assert guard_chain("c8", 7, 7, [4.0e4]) == ["bf16x3"]
+    assert guard_chain("f16x3", 0, 7, [3.0]) == ["f16x3", "bf16x3"]
+    assert guard_chain("bf16x3", 0, 7, [3.0]) == ["bf16x3"]
+
+
+def test_reference_forward_f64_is_the_module_in_float64_on_the_cpu():
+    import copy
+    import torch
+    from cchess_alphazero.agent.model import CChessNet, InferenceNet, reference_forward_f64
+    torch.manual_seed(5)
+    net = CChessNet(cnn_filter_num=32, res_layer_num=2).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 2.0)
+    planes = (torch.rand((5, 14, 10, 9)) < 0.07).to(torch.uint8)
+    p, v, lg, acts = reference_forward_f64(net, planes, with_activations=True)
+    with torch.no_grad():
+        pr, vr = copy.deepcopy(net).double()(planes.double())
+    assert (p - pr).abs().max().item() < 1e-13 and (v - vr).abs().max().item() < 1e-13 and len(acts) == 5
+    # arithmetic names: requests the constructor can serve, degraded where the kernels do not exist
+    assert InferenceNet(net, torch.float32, trunk="library", arith="c8").arith_name == "bf16x3"
+    n128 = CChessNet(cnn_filter_num=128, res_layer_num=3).eval()
+    for req, name in (("c8", "c8"), ("c8>2", "c8>2"), ("c8>3", "c8"), ("c8>0", "f16x3"), ("f16x3", "f16x3"), ("bf16x3", "bf16x3")):
+        assert InferenceNet(n128, torch.float32, trunk="mfma", arith=req).arith_name == name, req

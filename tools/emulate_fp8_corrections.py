@@ -71,6 +71,17 @@ def conv_model(x, w, b, mode, pad):
         wh = w.to(torch.float32).to(torch.bfloat16).to(torch.float64)
         wl = (w - wh).to(torch.float32).to(torch.bfloat16).to(torch.float64)
         y = conv(xh, wh) + conv(xh, wl) + conv(xl, wh)
+    elif mode in ("f16x3", "f16x3-ftz"):
+        # (hi, lo) pairs of fp16: 22 bits per operand where fp16's range holds them; -ftz: the matrix unit flushing fp16
+        # subnormals to zero (worst case for the lo parts)
+        def h(t):
+            r = t.to(torch.float32).to(torch.float16).to(torch.float64)
+            if mode == "f16x3-ftz":
+                r = torch.where(r.abs() < 2.0 ** -14, torch.zeros_like(r), r)
+            return r
+        xh, wh = h(x), h(w)
+        xl, wl = h(x - xh), h(w - wh)
+        y = conv(xh, wh) + conv(xh, wl) + conv(xl, wh)
     elif mode == "c8-kernel":
         # exactly the kernels' operand model (csrc/xq_conv.hip): FIXED activation scales -- x_lo8 = e4m3(sat(x_lo * 2^11)),
         # x_hi8 = e4m3(sat(x)), saturation at +-448 -- and one power-of-two scale per filter tensor (largest magnitude
@@ -108,6 +119,11 @@ def stored(x, mode):
     xh = x.to(torch.float32).to(torch.float16).to(torch.float64)
     if mode == "f16":
         return xh
+    if mode in ("f16x3", "f16x3-ftz"):
+        lo = (x - xh).to(torch.float32).to(torch.float16).to(torch.float64)
+        if mode == "f16x3-ftz":
+            lo = torch.where(lo.abs() < 2.0 ** -14, torch.zeros_like(lo), lo)
+        return xh + lo
     if mode == "c8-kernel":
         lo = ((x - xh) * 2048.0).clamp(-448.0, 448.0).to(torch.float32).to(torch.float8_e4m3fn).to(torch.float64)
         return xh + lo / 2048.0
@@ -120,8 +136,13 @@ def run(net, planes, mode):
     with torch.no_grad():
         ic = _fold(net.input_conv, net.input_bn)
         x = F.relu(F.conv2d(planes.to(d), ic.weight.to(d), ic.bias.to(d), padding=ic.padding))     # input layer: exact fp32 gather in the engine
+        hybrid = None
+        if ">" in mode:                      # "c8-kernel>5": blocks 0..4 on the c8 arithmetic, the rest on (hi, lo) fp16 pairs
+            mode, hybrid = mode.split(">")[0], int(mode.split(">")[1])
         x = stored(x.to(torch.float32).to(d), mode)
-        for blk in net.res:
+        for bi, blk in enumerate(net.res):
+            if hybrid is not None and bi == hybrid:
+                mode = "f16x3"
             c1, c2 = _fold(blk.conv1, blk.bn1), _fold(blk.conv2, blk.bn2)
             y = F.relu(conv_model(x, c1.weight.to(d), c1.bias.to(d), mode, 1)).to(torch.float32).to(d)   # fp32 accumulators
             y = stored(y, mode)
@@ -147,6 +168,8 @@ def main():
     ap.add_argument("--uniform-scales", action="store_true")
     ap.add_argument("--act-scale", type=float, default=1.0,
                     help="multiplies the input layer's filters and bias: activations of the whole tower grow by about this factor")
+    ap.add_argument("--modes", default="bf16x3,f16x3,c8-kernel,f16+fp8,f16+fp6,f16",
+                    help="comma-separated; also f16x3-ftz, c8-kernel>N (first N blocks c8, the rest f16x3)")
     a = ap.parse_args()
     global UNIFORM
     UNIFORM = a.uniform_scales
@@ -180,7 +203,7 @@ def main():
            "filters": a.filters, "blocks": a.blocks, "positions": a.positions, "policy_scale": a.peaked,
            "max_policy_probability": float(ref[2].max()), "value_range": [float(ref[3].min()), float(ref[3].max())],
            "value_preactivation_range": [float(ref[4].min()), float(ref[4].max())], "modes": {}}
-    for mode in ("bf16x3", "c8-kernel", "f16+fp8", "f16+fp6", "f16"):
+    for mode in a.modes.split(","):
         x, lg, p, v, vpre = run(net, planes, mode)
         c = lambda t: t - t.mean(1, keepdim=True)
         out["modes"][mode] = {
