@@ -1,0 +1,204 @@
+// xq_c8_kloop.h -- the K loop of the c8 tower arithmetic (round 4), shared by csrc/xq_conv.hip (k_conv3x3_c8, the c8
+// residual-block kernels) and tools/probes/c8_kloop_probe.hip (which times exactly this instruction stream).
+//
+// One call = 9 taps x 128 input channels for the 32 output channels of this wave and NT pixel tiles of 32 of an LDS
+// image; per 64-channel block  two fp16 K-steps -> the block's e4m3(w) x_lo8 MFMAs (K = 64) -> two fp16 K-steps -> its
+// w_lo8 e4m3(x) MFMAs: the accumulation order of round 3's loop, so results are bit-identical to it.
+//
+// What changed against round 3's conv_kloop_c8 (3.34 ms per block launch, MFMA busy 0.55: the loop ran at 59 % of its
+// MFMA floor, profiles/r03_c8_kloop_probe.log) -- read off its ISA:
+//   * every second fp16 K-step waited with lgkmcnt(2): its pixel fragments had been requested ONE K-step (96 cycles)
+//     earlier, less than a loaded LDS round trip.  Fragments are now requested TWO K-steps ahead (ring of three).
+//   * an fp16 MFMA slot is 32 cycles = 8 issue slots of which ~5 are usable (MI355X_MICROARCH.md); round 3 put the next
+//     tap's row arithmetic (~10 VALU), the 64-bit address arithmetic of the filter loads (5 VALU + s_nop per pair) and
+//     the loads themselves into fp16 slots -- 9 to 15 instructions in one slot of three.  Now an fp16 slot carries the
+//     MFMA, one ds_read_b128, one v_xor (and, twice per half block, one buffer_load whose address is an SGPR); everything
+//     else sits in the 64-cycle fp8 slots, which have twice the room.
+//   * filter fragments come through buffer_load_dwordx4 with a wave-uniform SGPR offset: no per-lane 64-bit adds.
+//   * the c8 filter pieces are single-buffered (16 registers instead of 32): a kind's pieces are re-requested right after
+//     the fp8 MFMAs that used them have issued, one block (768 cycles) before their next use.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace c8k {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr int C = 128, RB = 2 * C, CPR = RB / 16, SWZ = 15, KK = C / 16, NB = C / 64, CT = C / 32;
+constexpr int W_PAD_STEPS = 3;
+constexpr int MAIN_U4 = (9 * KK + W_PAD_STEPS) * CT * 64;          // uint4 of the fp16 fragments of a packed filter
+constexpr int C8_U4 = (9 * NB + 1) * 2 * CT * 2 * 64;              // ... of its e4m3 fragments (one zero block appended)
+constexpr int X_LO_SHIFT = 11;
+
+// where an image sits in LDS: byte offsets of its first pixel row and of the 16 all-zero rows inside a part, and the
+// distance between the fp16 part and the c8 part
+struct Image {
+    int row_base;       // first row of the image (rows are RB bytes)
+    int zrow;           // first of the 16 zero rows (a multiple of 16)
+    int part_bytes;     // c8 part = fp16 part + part_bytes
+};
+
+// A packed filter as the loop reads it: a buffer resource over the whole packed tensor and this lane's byte offset
+// (wave * 1024 + lane * 16 for the fp16 fragments; the c8 pieces add their own base).
+struct Filter {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int lane_main;      // byte offset of this lane inside a K-step of fp16 fragments
+    int lane_c8;        // byte offset of this lane inside a (block, kind) group of c8 pieces, counted from the c8 base
+    int scale_w_hi, scale_w_lo;      // E8M0 scale bytes of the two correction MFMAs (127 - shift)
+};
+
+__device__ __forceinline__ Filter make_filter(const void* packed, int wave, int lane)
+{
+    Filter f;
+    f.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(packed), 0, (MAIN_U4 + C8_U4 + 1) * 16, 0x00020000);
+    f.lane_main = wave * 1024 + lane * 16;
+    f.lane_c8 = MAIN_U4 * 16 + wave * 2048 + lane * 16;
+    const int* sc = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(packed) + MAIN_U4 + C8_U4);
+    f.scale_w_hi = 127 - __builtin_amdgcn_readfirstlane(sc[0]);
+    f.scale_w_lo = 127 - __builtin_amdgcn_readfirstlane(sc[1]);
+    return f;
+}
+
+// Hooks: work another part of a kernel wants done in the shadow of the MFMAs (a residual block's second epilogue).
+// fp8(j, slot) is called once in every fp8 slot: j = 0 .. 2 is the (rolled) loop iteration, slot = 0 .. 12 NT - 1 the slot's
+// position inside it -- a compile-time constant after unrolling, so that register indices derived from it are static.
+struct NoShadow {
+    __device__ __forceinline__ void fp8(int, int) {}
+};
+
+// PROBE (tools/probes only; 0 in the product): bit 0 = no filter loads inside the loop (the prologue's fragments are reused),
+// bit 1 = no LDS reads inside the loop -- timing experiments with wrong results.
+template <int NT, typename Shadow = NoShadow, int PROBE = 0>
+__device__ __forceinline__ void kloop(const unsigned char* lds, const Image img, const Filter& flt, int lane, f32x16* acc,
+                                      int scale_x_lo, int scale_x, Shadow&& shadow = NoShadow())
+{
+    const int kb = lane >> 5, ln = lane & 31;
+    int qy[3], qx[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int q = t * 32 + ln;
+        qy[t] = q < 90 ? q / 9 : 100;                  // 100: never on the board, whatever the tap
+        qx[t] = q - (q / 9) * 9;
+    }
+    // byte offset (within a part) of this lane's fp16 fragment for K-step 0 of tap (dy, dx), pixel tile p
+    auto tap_row = [&](int dy, int dx, int p) {
+        const int t = p % 3;
+        const bool ok = (unsigned)(qy[t] + dy) < 10u && (unsigned)(qx[t] + dx) < 9u;
+        const int nominal = (p / 3) * 90 + t * 32 + ln + dy * 9 + dx;
+        const int row = ok ? img.row_base + nominal : img.zrow + (nominal & 15);
+        return row * RB + (((kb ^ nominal) & SWZ) << 4);
+    };
+    const int lane_c = (kb * 3) << 4;
+    auto load_px = [&](int pre_p, int kk) {
+        return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(lds + (pre_p ^ (kk << 5))));
+    };
+    // c8 piece h of (kind q, block b): chunk q * CPR/2 + 4 b + 2 kb + h of the row
+    auto load_c8 = [&](i32x8& d, int pre_p, int q, int b, int h) {
+        const uint4 t = *reinterpret_cast<const uint4*>(lds + img.part_bytes + (pre_p ^ lane_c ^ ((q * (CPR / 2) + 4 * b + h) << 4)));
+        d[4 * h + 0] = t.x; d[4 * h + 1] = t.y; d[4 * h + 2] = t.z; d[4 * h + 3] = t.w;
+    };
+    auto load_w = [&](int step_soff) {                 // fp16 fragment of K-step `step` (soffset = step * 4096, wave-uniform)
+        return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(flt.rsrc, flt.lane_main, step_soff, 0));
+    };
+    auto load_wc = [&](i32x8& d, int blk_soff, int q, int h) {      // blk_soff = blk * 16384 (one block = 2 kinds x 4 waves x 2 KB)
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(flt.rsrc, flt.lane_c8 + h * 1024, blk_soff + q * 8192, 0);
+        d[4 * h + 0] = (int)t.x; d[4 * h + 1] = (int)t.y; d[4 * h + 2] = (int)t.z; d[4 * h + 3] = (int)t.w;
+    };
+
+    f16x8 wf[4];                                        // fp16 filter fragments, slot = K-step % 4
+    f16x8 px[3][NT];                                    // pixel fragments, slot = K-step % 3 (24 K-steps per loop iteration)
+    i32x8 cx[2][NT];                                    // c8 pixel pieces by kind
+    i32x8 wcr[2];                                       // c8 filter pieces by kind
+    int pre[NT], pre_n[NT];
+#pragma unroll
+    for (int p = 0; p < NT; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+#pragma unroll
+    for (int p = 0; p < NT; ++p) pre[p] = tap_row(-1, -1, p);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wf[s] = load_w(s * 4096);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        load_wc(wcr[q], 0, q, 0);
+        load_wc(wcr[q], 0, q, 1);
+    }
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+        px[0][p] = load_px(pre[p], 0);
+        px[1][p] = load_px(pre[p], 1);
+        load_c8(cx[0][p], pre[p], 0, 0, 0);
+        load_c8(cx[0][p], pre[p], 0, 0, 1);
+    }
+
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {                       // taps 3 j .. 3 j + 2 (dy = j - 1)
+        const int soff_j = j * (3 * KK * 4096), boff_j = j * (3 * NB * 16384);
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+            const int tap3 = tt;                         // tap inside the iteration
+            // the NEXT tap (the last one: itself; its prefetches read valid rows and are never used)
+            const int ndy = tt < 2 ? j - 1 : (j < 2 ? j : 1), ndx = tt < 2 ? tt : (j < 2 ? -1 : 1);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        const int kk = b * 4 + half * 2 + k2;                 // K-step inside the tap
+                        const int g = tap3 * KK + kk;                         // K-step inside the iteration (ring indices)
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) {
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk & 3], px[g % 3][i], acc[i], 0, 0, 0);
+                            const int kn = kk + 2;                             // fragments of the K-step after next
+                            if (!(PROBE & 2)) px[(g + 2) % 3][i] = kn < KK ? load_px(pre[i], kn) : load_px(pre_n[i], kn - KK);
+                            // the c8 filter pieces of the kind whose MFMAs have just issued, for its next block
+                            if (i == 0 && !(PROBE & 1)) {
+                                const int q = 1 - half;                        // kind used in the PREVIOUS fp8 group
+                                const int blk_next = tap3 * NB + b + (half == 0 ? 0 : 1);     // its next block (half 0: kind 1 of b - 1 -> b)
+                                load_wc(wcr[q], boff_j + blk_next * 16384, q, k2);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    // ---- correction term `half` of this block (K = 64)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) {
+                        acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wcr[half], cx[half][i], acc[i], 0, 0, 0,
+                                                                                  half ? flt.scale_w_lo : flt.scale_w_hi, 0,
+                                                                                  half ? scale_x : scale_x_lo);
+                        // the OTHER kind's pixel pieces for its next use: kind 1 of this block, or kind 0 of the next one
+                        if (PROBE & 2) {
+                        } else if (half == 0) {
+                            load_c8(cx[1][i], pre[i], 1, b, 0);
+                            load_c8(cx[1][i], pre[i], 1, b, 1);
+                        } else if (b + 1 < NB) {
+                            load_c8(cx[0][i], pre[i], 0, b + 1, 0);
+                            load_c8(cx[0][i], pre[i], 0, b + 1, 1);
+                        } else {
+                            load_c8(cx[0][i], pre_n[i], 0, 0, 0);
+                            load_c8(cx[0][i], pre_n[i], 0, 0, 1);
+                        }
+                        // the fp16 filter fragments of the two K-steps just retired, one block ahead (their ring slots are free)
+                        if (i < 2 && !(PROBE & 1)) {
+                            const int kk = b * 4 + half * 2 + i;
+                            wf[kk & 3] = load_w(soff_j + (tap3 * KK + kk + 4) * 4096);
+                        }
+                        // the next tap's rows: one per fp8 slot of the tap's first block (needed from K-step 6 on)
+                        if (b == 0 && half == 0) pre_n[i] = tap_row(ndy, ndx, i);
+                        shadow.fp8(j, ((tt * NB + b) * 2 + half) * NT + i);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < NT; ++p) pre[p] = pre_n[p];
+        }
+    }
+}
+
+}  // namespace c8k

@@ -37,6 +37,7 @@
 #include <stdio.h>
 #include <math.h>
 #include "../../include/czero.h"
+#include "xq_c8_kloop.h"
 
 extern "C" void czi_set_error(const char* msg);
 
@@ -396,136 +397,6 @@ template <int C> struct Pack {
 }  // namespace cf8
 
 template <int C, int P>
-__device__ __forceinline__ void conv_kloop_c8(const unsigned char* region, const uint4* wq, const uint4* wc, int lane,
-                                              f32x16* acc, int scale_w_hi, int scale_w_lo)
-{
-    typedef Geom<C, P, 2> G;
-    typedef Mfma<_Float16>::V8 V8;
-    constexpr int NT = G::NT, KK = G::KK, W_RING = G::W_RING, NB = C / 64, CT = G::CT;
-    static_assert(G::POW2 && G::SWZ == 15 && KK % 4 == 0 && NB % 2 == 0, "128 / 256 filters");
-    const int kb = lane >> 5, ln = lane & 31;
-    int pre[NT], pre_n[NT];
-    int qy[3], qx[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int q = t * 32 + ln;
-        qy[t] = q < 90 ? q / 9 : 100;
-        qx[t] = q - (q / 9) * 9;
-    }
-    auto tap_row = [&](int dy, int dx, int p) {
-        const int t = p % 3;
-        const bool ok = (unsigned)(qy[t] + dy) < 10u && (unsigned)(qx[t] + dx) < 9u;
-        const int nominal = (p / 3) * 90 + t * 32 + ln + dy * 9 + dx;
-        const int row = ok ? nominal : G::ZROW + (nominal & 15);
-        return row * G::RB + (((kb ^ nominal) & G::SWZ) << 4);
-    };
-    // c8 piece h of (kind q, block b): chunk q * CPR/2 + 4 b + 2 kb + h of the row; pre[] already holds row * RB + ((kb ^ key) << 4)
-    const int lane_c = (kb * 3) << 4;
-    auto load_c8 = [&](int pre_p, int q, int b, int h) {
-        const int off = pre_p ^ lane_c ^ ((q * (G::CPR / 2) + 4 * b + h) << 4);
-        return *reinterpret_cast<const uint4*>(region + G::PART_BYTES + off);
-    };
-    auto load_px = [&](int off) { return __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(region + off)); };
-    auto load_w = [&](int step) { return __builtin_bit_cast(V8, wq[(size_t)step * G::W_STEP]); };
-    auto load_wc = [&](int blk, int q, int h) { return wc[(size_t)((blk * 2 + q) * CT * 2 + h) * 64]; };
-
-    V8 wf[W_RING];
-    V8 px[2][NT];
-    i32x8 cx[2][NT];
-    i32x8 wcr[2][2];                                   // [ring][kind]
-#pragma unroll
-    for (int p = 0; p < NT; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
-#pragma unroll
-    for (int p = 0; p < NT; ++p) pre[p] = tap_row(-1, -1, p);
-#pragma unroll
-    for (int s = 0; s < W_RING - 1; ++s) wf[s] = load_w(s);
-#pragma unroll
-    for (int p = 0; p < NT; ++p) px[0][p] = load_px(pre[p]);
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint4 t = load_wc(0, q, h);
-            wcr[0][q][4 * h + 0] = t.x; wcr[0][q][4 * h + 1] = t.y; wcr[0][q][4 * h + 2] = t.z; wcr[0][q][4 * h + 3] = t.w;
-        }
-    const int scale_x_lo = 127 - cf8::X_LO_SHIFT, scale_one = 127;
-    auto load_cx = [&](i32x8& d, int pre_p, int q, int b, int h) {
-        const uint4 t = load_c8(pre_p, q, b, h);
-        d[4 * h + 0] = t.x; d[4 * h + 1] = t.y; d[4 * h + 2] = t.z; d[4 * h + 3] = t.w;
-    };
-#pragma unroll
-    for (int p = 0; p < NT; ++p) {                     // the lo-part pieces of the first block
-        load_cx(cx[0][p], pre[p], 0, 0, 0);
-        load_cx(cx[0][p], pre[p], 0, 0, 1);
-    }
-
-    // Schedule of a 64-channel block: two fp16 K-steps, the block's e4m3(w) x_lo8 MFMAs, two fp16 K-steps, its w_lo8 e4m3(x)
-    // MFMAs.  The LDS port is as loaded as the matrix pipes in this kernel (the fp8 fragments are as many bytes as the bf16
-    // lo fragments they replace, the matrix time shrank by a third), so the reads are spread evenly: an fp16 slot
-    // (32 cycles) carries ONE ds_read_b128 -- a pixel fragment of the next K-step -- and an fp8 slot (64 cycles) two: the
-    // c8 pieces of the OTHER kind's next use (kind 1 of this block under kind 0's MFMAs, kind 0 of the next block -- next
-    // tap's rows at a tap boundary -- under kind 1's).
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-        const int tn = tap < 8 ? tap + 1 : 8;
-        const int ndy = tn / 3 - 1, ndx = tn - (tn / 3) * 3 - 1;
-        constexpr int PER = (NT + KK - 2) / (KK - 1);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int blk = tap * NB + b;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-                    const int k4 = half * 2 + k2, kk = b * 4 + k4, step = tap * KK + kk;
-                    V8* bcur = px[kk & 1];
-                    V8* bnxt = px[(kk + 1) & 1];
-                    const int* rows = kk + 1 < KK ? pre : pre_n;
-                    const int kn = (kk + 1) % KK;
-#pragma unroll
-                    for (int i = 0; i < NT; ++i) {
-                        acc[i] = Mfma<_Float16>::mma(wf[kk % W_RING], bcur[i], acc[i]);
-                        bnxt[i] = load_px(G::kstep(rows[i], kn));
-                        if (i >= NT - PER && kk * PER + (i - (NT - PER)) < NT)
-                            pre_n[kk * PER + (i - (NT - PER))] = tap_row(ndy, ndx, kk * PER + (i - (NT - PER)));
-                        if (i == 0) {                                    // (first slot: the ring slot being refilled fed the
-                            //  previous K-step, whose MFMAs have issued; a K-step is only 96 cycles here, every slot of lead counts)
-                            wf[(kk + W_RING - 1) % W_RING] = load_w(step + W_RING - 1);
-                            const int q2 = k4 >> 1, h2 = k4 & 1;         // the next block's c8 filter pieces, one per K-step
-                            const uint4 t = load_wc(blk + 1, q2, h2);
-                            i32x8& d = wcr[(b + 1) & 1][q2];
-                            d[4 * h2 + 0] = t.x; d[4 * h2 + 1] = t.y; d[4 * h2 + 2] = t.z; d[4 * h2 + 3] = t.w;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                // ---- correction term `half` of this block (K = 64), the other kind's pieces arriving underneath
-#pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wcr[b & 1][half], cx[half][i], acc[i], 0, 0, 0,
-                                                                              half ? scale_w_lo : scale_w_hi, 0,
-                                                                              half ? scale_one : scale_x_lo);
-                    if (half == 0) {
-                        load_cx(cx[1][i], pre[i], 1, b, 0);
-                        load_cx(cx[1][i], pre[i], 1, b, 1);
-                    } else {
-                        const int* r = b + 1 < NB ? pre : pre_n;
-                        const int bn = b + 1 < NB ? b + 1 : 0;
-                        load_cx(cx[0][i], r[i], 0, bn, 0);
-                        load_cx(cx[0][i], r[i], 0, bn, 1);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < NT; ++p) pre[p] = pre_n[p];
-    }
-}
-
-template <int C, int P>
 __global__ __launch_bounds__(C / 32 * 64, 1) void k_conv3x3_c8(
     const _Float16* __restrict__ xh, const unsigned char* __restrict__ xc, const uint4* __restrict__ wp,
     const float* __restrict__ bias, const _Float16* __restrict__ sh, const unsigned char* __restrict__ sc8,
@@ -543,11 +414,10 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_conv3x3_c8(
         zero_rows_write<C, P, 2>(lds, tid);
     }
     __syncthreads();
-    const int* scl = reinterpret_cast<const int*>(wp + cf8::Pack<C>::MAIN_U4 + cf8::Pack<C>::C8_U4);
-    const int s_hi = __builtin_amdgcn_readfirstlane(scl[0]), s_lo = __builtin_amdgcn_readfirstlane(scl[1]);
     f32x16 acc[NT];
-    conv_kloop_c8<C, P>(lds, wp + wave * 64 + lane, wp + cf8::Pack<C>::MAIN_U4 + (size_t)wave * 2 * 64 + lane, lane, acc,
-                        127 - s_hi, 127 - s_lo);
+    static_assert(C == c8k::C && cf8::Pack<C>::MAIN_U4 == c8k::MAIN_U4 && cf8::Pack<C>::C8_U4 == c8k::C8_U4, "packed layout");
+    c8k::kloop<NT>(lds, c8k::Image{0, G::ZROW, G::PART_BYTES}, c8k::make_filter(wp, wave, lane), lane, acc,
+                   127 - cf8::X_LO_SHIFT, 127);
 
     const int kb = lane >> 5, ln = lane & 31;
 #pragma unroll
@@ -751,22 +621,18 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
     const uint4* wq1 = reinterpret_cast<const uint4*>(w1p) + wg * 64 + lane;
     const uint4* wq2 = reinterpret_cast<const uint4*>(w2p) + wg * 64 + lane;
     const int kb = lane >> 5, ln = lane & 31;
-    // c8 arithmetic: the correction fragments and the filters' two scale exponents behind the f16 fragments
-    const uint4* wc1 = reinterpret_cast<const uint4*>(w1p) + cf8::Pack<C>::MAIN_U4 + (size_t)wg * 2 * 64 + lane;
-    const uint4* wc2 = reinterpret_cast<const uint4*>(w2p) + cf8::Pack<C>::MAIN_U4 + (size_t)wg * 2 * 64 + lane;
-    int sc1h = 0, sc1l = 0, sc2h = 0, sc2l = 0;
-    if (C8) {
-        const int* a = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(w1p) + cf8::Pack<C>::MAIN_U4 + cf8::Pack<C>::C8_U4);
-        const int* b = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(w2p) + cf8::Pack<C>::MAIN_U4 + cf8::Pack<C>::C8_U4);
-        sc1h = 127 - __builtin_amdgcn_readfirstlane(a[0]); sc1l = 127 - __builtin_amdgcn_readfirstlane(a[1]);
-        sc2h = 127 - __builtin_amdgcn_readfirstlane(b[0]); sc2l = 127 - __builtin_amdgcn_readfirstlane(b[1]);
+    // c8 arithmetic: buffer resources over the packed filters (fp16 fragments, c8 pieces, the two scale exponents)
+    c8k::Filter flt1{}, flt2{};
+    if constexpr (C8) {
+        flt1 = c8k::make_filter(w1p, wave, lane);
+        flt2 = c8k::make_filter(w2p, wave, lane);
     }
     for (;;) {
         __syncthreads();                                       // A
         const bool has_next = t + stride < n_tiles;
         f32x16 acc[CTW * NT];
         __builtin_amdgcn_s_setprio(3);
-        if constexpr (C8) conv_kloop_c8<C, P>(X, wq1, wc1, lane, acc, sc1h, sc1l);
+        if constexpr (C8) c8k::kloop<NT>(X, c8k::Image{0, G::ZROW, G::PART_BYTES}, flt1, lane, acc, 127 - cf8::X_LO_SHIFT, 127);
         else conv_kloop<E, C, P, PARTS, CTW>(X, wq1, lane, acc);
         __builtin_amdgcn_s_setprio(0);
         int ln2 = ln, kb2 = kb, gt2 = tid;
@@ -811,7 +677,7 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
         }
         __syncthreads();                                       // B: Y complete
         __builtin_amdgcn_s_setprio(3);
-        if constexpr (C8) conv_kloop_c8<C, P>(Y, wq2, wc2, lane, acc, sc2h, sc2l);
+        if constexpr (C8) c8k::kloop<NT>(Y, c8k::Image{0, G::ZROW, G::PART_BYTES}, flt2, lane, acc, 127 - cf8::X_LO_SHIFT, 127);
         else conv_kloop<E, C, P, PARTS, CTW>(Y, wq2, lane, acc);
         __builtin_amdgcn_s_setprio(0);
         asm volatile("" : "+v"(ln2), "+v"(kb2));

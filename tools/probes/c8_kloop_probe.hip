@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include "../../chinesechess-alphazero_amd/csrc/xq_c8_kloop.h"
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -155,6 +156,39 @@ __global__ __launch_bounds__(256, 1) void k_probe(const uint4* __restrict__ wmai
     out[blockIdx.x * 256 + tid] = s;
 }
 
+// ---- round 4: the product's K loop (csrc/xq_c8_kloop.h), WGS workgroups of four waves per CU ----------------------------
+template <int WGS, int PROBE>
+__global__ __launch_bounds__(256, WGS) void k_probe_r4(const uint4* __restrict__ packed, const uint4* __restrict__ image,
+                                                        float* __restrict__ out, int convs, long long* __restrict__ cycles)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[REGION];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < REGION / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = image[i];
+    __syncthreads();
+    const c8k::Filter flt = c8k::make_filter(packed, wave, lane);
+    const c8k::Image img{0, ZROW, PART_BYTES};
+    c8k::f32x16 acc[NT], sum[NT];
+#pragma unroll
+    for (int p = 0; p < NT; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum[p][r] = 0.0f;
+    const long long t0 = clock64();                    // s_memtime: shader cycles
+    for (int conv = 0; conv < convs; ++conv) {
+        c8k::kloop<NT, c8k::NoShadow, PROBE>(lds, img, flt, lane, acc, 127 - 11, 127);
+        if (conv + 1 == convs) {
+#pragma unroll
+            for (int p = 0; p < NT; ++p) sum[p] += acc[p];
+        }
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int p = 0; p < NT; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += sum[p][r];
+    out[blockIdx.x * 256 + tid] = s;
+    if (blockIdx.x == 7 && tid == 0) cycles[0] = clock64() - t0;
+}
+
 static uint32_t rnd_state = 7;
 static uint32_t rnd() { rnd_state = rnd_state * 1664525u + 1013904223u; return rnd_state >> 8; }
 
@@ -195,6 +229,47 @@ int main(int argc, char** argv)
     CK(hipMemcpy(dwm, wm.data(), wm.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dwc, wc.data(), wc.size(), hipMemcpyHostToDevice));
     CK(hipMemcpy(dimg, img.data(), REGION, hipMemcpyHostToDevice));
+    {
+        // the product's loop: packed filter = fp16 fragments, c8 pieces, the two scale exponents
+        std::vector<uint8_t> pk((size_t)(c8k::MAIN_U4 + c8k::C8_U4 + 1) * 16, 0);
+        for (size_t i = 0; i < (size_t)c8k::MAIN_U4 * 8; ++i) memcpy(&pk[2 * i], &wm[i % wm.size()], 2);
+        for (size_t i = 0; i < (size_t)c8k::C8_U4 * 16; ++i) pk[(size_t)c8k::MAIN_U4 * 16 + i] = wc[i % wc.size()];
+        uint4* dpk;
+        CK(hipMalloc(&dpk, pk.size()));
+        CK(hipMemcpy(dpk, pk.data(), pk.size(), hipMemcpyHostToDevice));
+        long long* dcyc;
+        CK(hipMalloc(&dcyc, 8));
+        for (int var = 0; var < 5; ++var) {
+            const int wgs = var == 1 ? 2 : 1;      // variants: 1 WG, 2 WGs, no filter loads, no LDS reads, neither
+            auto go = [&](int convs) {
+                hipEvent_t e0, e1;
+                CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                CK(hipEventRecord(e0));
+                if (var == 0) hipLaunchKernelGGL((k_probe_r4<1, 0>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
+                else if (var == 1) hipLaunchKernelGGL((k_probe_r4<2, 0>), dim3(2 * blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
+                else if (var == 2) hipLaunchKernelGGL((k_probe_r4<1, 1>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
+                else if (var == 3) hipLaunchKernelGGL((k_probe_r4<1, 2>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
+                else hipLaunchKernelGGL((k_probe_r4<1, 3>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms = 0.0f;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                return (double)ms;
+            };
+            go(20);
+            const double probe = go(200);
+            const int chunk = (int)(200 * 500.0 / probe);
+            double last = 0.0;
+            for (int i = 0; i < (int)(seconds / 0.5) + 1; ++i) last = go(chunk);
+            long long cyc = 0;
+            CK(hipMemcpy(&cyc, dcyc, 8, hipMemcpyDeviceToHost));
+            const char* what[5] = {"as in the product", "2 workgroups per CU", "no filter loads in the loop", "no LDS reads in the loop",
+                                   "no loads at all in the loop"};
+            printf("RESULT r4 loop (%s): %.2f us per K loop of a wave, %.2f us per K loop and CU; %.0f shader cycles per K loop "
+                   "(MFMA floor 13824) -> %.2f GHz\n", what[var], last * 1e3 / chunk, last * 1e3 / chunk / wgs,
+                   (double)cyc / chunk, (double)cyc / chunk / (last * 1e3 / chunk) / 1e3);
+        }
+    }
     for (int ctw = 1; ctw <= 2; ++ctw) {
         auto go = [&](int convs) { return ctw == 1 ? run<1>(dwm, dwc, dimg, out, blocks, convs) : run<2>(dwm, dwc, dimg, out, blocks, convs); };
         go(20);
