@@ -366,14 +366,15 @@ def input_table(w_oihw):
 
 def input_resblock(planes, table, in_bias, w1, b1, w2, b2, out, rows=None, count=None):
     """cz_input_resblock: planes [N, in_planes, 10, 9] uint8 -> input layer + first residual block -> out = (hi, lo)
-    [N, 90, 128] operand pair.  rows / count: the compact evaluation queue (int32 device tensors)."""
+    [N, 90, 128] operand pair, or the c8 pair (f16 [N, 90, 128], uint8 [N, 90, 256]) with cz_conv3x3_c8_pack_weights
+    filters.  rows / count: the compact evaluation queue (int32 device tensors)."""
     require_gpu()
     import torch
     if planes.dtype != torch.uint8:
         raise NativeError("cz_input_resblock reads uint8 planes")
     n = planes.shape[0]
     check(lib().cz_input_resblock(_ptr(planes), planes.shape[1], _ptr(table), _ptr(in_bias), _ptr(w1), _ptr(b1), _ptr(w2),
-                                  _ptr(b2), _ptr(out[0]), _ptr(out[1]), n, out[0].shape[-1], _dt_code(out[0].dtype),
+                                  _ptr(b2), _ptr(out[0]), _ptr(out[1]), n, out[0].shape[-1], _pair_code(out),
                                   _ptr(rows) if rows is not None else None, _ptr(count) if count is not None else None,
                                   _stream()), "cz_input_resblock")
     return out

@@ -270,8 +270,9 @@ class InferenceNet(nn.Module):
         # whole residual block in one launch where k_resblock exists for the shape
         fused = self.fused_blocks and ((c in (128, 192)) or (c == 256 and self.parts == 1))
         # input layer + first block in one launch: 128 filters, split operands, byte planes, a tower of >= 2 blocks
+        # (a hybrid tower whose only c8 block is the first hands fp32 over after it: that block stays on cz_resblock)
         first_fused = (fused and self.fused_input and c == 128 and self.parts == 2 and nblk >= 2 and
-                       planes.dtype == torch.uint8 and n8 == 0)
+                       planes.dtype == torch.uint8 and n8 != 1)
         if not first_fused:
             if self.arith == "c8" and n8 == 0:                  # (cannot happen through the constructor; kept total)
                 cur, tmp, nxt = (self._as_f16_pair(t) for t in (cur, tmp, nxt))

@@ -414,12 +414,31 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_conv3x3_c8(
         zero_rows_write<C, P, 2>(lds, tid);
     }
     __syncthreads();
-    f32x16 acc[NT];
     static_assert(C == c8k::C && cf8::Pack<C>::MAIN_U4 == c8k::MAIN_U4 && cf8::Pack<C>::C8_U4 == c8k::C8_U4, "packed layout");
-    c8k::kloop<NT>(lds, c8k::Image{0, G::ZROW, G::PART_BYTES}, c8k::make_filter(wp, wave, lane), lane, acc,
-                   127 - cf8::X_LO_SHIFT, 127);
-
+    // The accumulators start at bias (+ the skip operand, hi + lo8 * 2^-11): the products are added on top and the epilogue
+    // has only the ReLU and the split left.  Same order in k_resblock_c8, so the two stay bit-identical.
     const int kb = lane >> 5, ln = lane & 31;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+        const int q = (p % 3) * 32 + ln;
+        const int n = n0 + p / 3;
+        const bool live = q < 90 && n < n_boards;
+        const size_t pixel = (size_t)(live ? n : 0) * 90 + (live ? q : 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = wave * 32 + g * 8 + kb * 4;
+            const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
+            float v[4] = {bv.x, bv.y, bv.z, bv.w};
+            if (sh && live)
+                cf8::add_pair4(v, *reinterpret_cast<const Quad<_Float16>*>(sh + pixel * C + ch),
+                              *reinterpret_cast<const uint32_t*>(sc8 + pixel * 2 * C + ch));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[p][g * 4 + i] = v[i];
+        }
+    }
+    c8k::kloop<NT, c8k::NoShadow, 0, false>(lds, c8k::Image{0, G::ZROW, G::PART_BYTES}, c8k::make_filter(wp, wave, lane), lane,
+                                            acc, 127 - cf8::X_LO_SHIFT, 127);
 #pragma unroll
     for (int p = 0; p < NT; ++p) {
         const int q = (p % 3) * 32 + ln;
@@ -429,12 +448,7 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_conv3x3_c8(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int ch = wave * 32 + g * 8 + kb * 4;
-            const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
-            float v[4] = {acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
-                          acc[p][g * 4 + 3] + bv.w};
-            if (sh)
-                cf8::add_pair4(v, *reinterpret_cast<const Quad<_Float16>*>(sh + pixel * C + ch),
-                              *reinterpret_cast<const uint32_t*>(sc8 + pixel * 2 * C + ch));
+            float v[4] = {acc[p][g * 4 + 0], acc[p][g * 4 + 1], acc[p][g * 4 + 2], acc[p][g * 4 + 3]};
             if (relu) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
@@ -478,16 +492,13 @@ struct HeadArgs {
     int n_pol;
 };
 
-// C8: the arithmetic of k_conv3x3_c8 (fp16 main term + two scaled-fp8 correction terms): E = _Float16, PARTS = 2,
-// the second operand part is the c8 image (e4m3 lo, e4m3 value), the packed filters are cz_conv3x3_c8_pack_weights'.
-template <typename E, int C, int PARTS, int P, bool HEADS = false, int CTW = 1, bool C8 = false>
+template <typename E, int C, int PARTS, int P, bool HEADS = false, int CTW = 1>
 __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4) void k_resblock(
     const E* __restrict__ xh, const E* __restrict__ xl, const E* __restrict__ w1p, const float* __restrict__ b1,
     const E* __restrict__ w2p, const float* __restrict__ b2, E* __restrict__ yh, E* __restrict__ yl,
     float* __restrict__ yf, int n_boards, HeadArgs hd, const int32_t* __restrict__ n_dev)
 {
     static_assert(!HEADS || (PARTS == 2 && C / 8 == 16), "fused heads: split operands, 128 filters");
-    static_assert(!C8 || (PARTS == 2 && CTW == 1 && sizeof(E) == 2), "c8 arithmetic: fp16 operand pairs");
     if (n_dev) {                                        // compact queue: the board count lives on the device
         const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
         n_boards = nd < n_boards ? nd : n_boards;
@@ -577,13 +588,6 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
                             float4* o = reinterpret_cast<float4*>(yf + ebase) + 2 * i;
                             o[0] = f0;
                             o[1] = f1;
-                        } else if (C8) {
-                            const cf8::Split4 s0 = cf8::split4(r), s1 = cf8::split4(r + 4);
-                            struct alignas(16) H8 { Quad<_Float16> a, b; };
-                            reinterpret_cast<uint4*>(yh + ebase)[i] = __builtin_bit_cast(uint4, H8{s0.hi, s1.hi});
-                            unsigned char* row = reinterpret_cast<unsigned char*>(yl + ebase) + (size_t)qq * 2 * C + c8 * 8;
-                            *reinterpret_cast<uint2*>(row) = make_uint2(s0.l8, s1.l8);
-                            *reinterpret_cast<uint2*>(row + C) = make_uint2(s0.h8, s1.h8);
                         } else {
                             struct alignas(16) E8 { E e[8]; };
                             E8 hi, lo;
@@ -621,19 +625,12 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
     const uint4* wq1 = reinterpret_cast<const uint4*>(w1p) + wg * 64 + lane;
     const uint4* wq2 = reinterpret_cast<const uint4*>(w2p) + wg * 64 + lane;
     const int kb = lane >> 5, ln = lane & 31;
-    // c8 arithmetic: buffer resources over the packed filters (fp16 fragments, c8 pieces, the two scale exponents)
-    c8k::Filter flt1{}, flt2{};
-    if constexpr (C8) {
-        flt1 = c8k::make_filter(w1p, wave, lane);
-        flt2 = c8k::make_filter(w2p, wave, lane);
-    }
     for (;;) {
         __syncthreads();                                       // A
         const bool has_next = t + stride < n_tiles;
         f32x16 acc[CTW * NT];
         __builtin_amdgcn_s_setprio(3);
-        if constexpr (C8) c8k::kloop<NT>(X, c8k::Image{0, G::ZROW, G::PART_BYTES}, flt1, lane, acc, 127 - cf8::X_LO_SHIFT, 127);
-        else conv_kloop<E, C, P, PARTS, CTW>(X, wq1, lane, acc);
+        conv_kloop<E, C, P, PARTS, CTW>(X, wq1, lane, acc);
         __builtin_amdgcn_s_setprio(0);
         int ln2 = ln, kb2 = kb, gt2 = tid;
         asm volatile("" : "+v"(ln2), "+v"(kb2), "+v"(gt2));
@@ -651,17 +648,6 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
                     const float vv[4] = {acc[cp][g * 4 + 0] + bv.x, acc[cp][g * 4 + 1] + bv.y, acc[cp][g * 4 + 2] + bv.z,
                                          acc[cp][g * 4 + 3] + bv.w};
                     const int off = row * G::RB + (((ch >> 3) ^ (row & G::SWZ)) << 4) + (ch & 7) * 2;
-                    if constexpr (C8) {
-                        float r[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) r[i] = vv[i] > 0.0f ? vv[i] : 0.0f;
-                        const cf8::Split4 o = cf8::split4(r);
-                        *reinterpret_cast<Quad<_Float16>*>(Y + off) = o.hi;
-                        // c8 row: byte ch of the lo half, byte C + ch of the value half (16-byte chunks ch / 16 and CPR / 2 + ch / 16)
-                        unsigned char* crow = Y + G::PART_BYTES + row * G::RB + (ch & 15);
-                        *reinterpret_cast<uint32_t*>(crow + ((((ch >> 4)) ^ (row & G::SWZ)) << 4)) = o.l8;
-                        *reinterpret_cast<uint32_t*>(crow + (((G::CPR / 2 + (ch >> 4)) ^ (row & G::SWZ)) << 4)) = o.h8;
-                    } else {
                     Quad<E> hi, lo;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -671,14 +657,12 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
                     }
                     *reinterpret_cast<Quad<E>*>(Y + off) = hi;
                     if (PARTS == 2) *reinterpret_cast<Quad<E>*>(Y + G::PART_BYTES + off) = lo;
-                    }
                 }
             }
         }
         __syncthreads();                                       // B: Y complete
         __builtin_amdgcn_s_setprio(3);
-        if constexpr (C8) c8k::kloop<NT>(Y, c8k::Image{0, G::ZROW, G::PART_BYTES}, flt2, lane, acc, 127 - cf8::X_LO_SHIFT, 127);
-        else conv_kloop<E, C, P, PARTS, CTW>(Y, wq2, lane, acc);
+        conv_kloop<E, C, P, PARTS, CTW>(Y, wq2, lane, acc);
         __builtin_amdgcn_s_setprio(0);
         asm volatile("" : "+v"(ln2), "+v"(kb2));
         // epilogue 2: relu(acc + b2 + x) -> staging
@@ -696,18 +680,12 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
                     const Quad<E> sh = *reinterpret_cast<const Quad<E>*>(X + off);
                     float vv[4] = {acc[cp][g * 4 + 0] + bv.x, acc[cp][g * 4 + 1] + bv.y, acc[cp][g * 4 + 2] + bv.z,
                                    acc[cp][g * 4 + 3] + bv.w};
-                    if constexpr (C8) {
-                        const uint32_t l8 = *reinterpret_cast<const uint32_t*>(
-                            X + G::PART_BYTES + row * G::RB + (ch & 15) + (((ch >> 4) ^ (row & G::SWZ)) << 4));
-                        cf8::add_pair4(vv, __builtin_bit_cast(Quad<_Float16>, sh), l8);
-                    } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) vv[i] += (float)sh.e[i];
                     if (PARTS == 2) {
                         const Quad<E> sl = *reinterpret_cast<const Quad<E>*>(X + G::PART_BYTES + off);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) vv[i] += (float)sl.e[i];
-                    }
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) vv[i] = vv[i] > 0.0f ? vv[i] : 0.0f;
@@ -726,6 +704,446 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
         if (!has_next) break;
         t += stride;
     }
+}
+
+#ifdef CZ_RB_STAMPS
+// timing build (tools/rb_stamps.py; never the default library): shader-cycle stamps of one matrix wave's and one copy
+// wave's sections of one steady-state board of k_resblock_c8
+__device__ long long g_rb_stamps[32];
+#define RB_STAMP(i) do { if (stamp_on) g_rb_stamps[i] = clock64(); } while (0)
+#else
+#define RB_STAMP(i) do { } while (0)
+#endif
+
+// ---- kernel 2c8: the residual block on the c8 arithmetic (round 4) -------------------------------------------------------
+// k_resblock's roles and LDS images (X | Y | fp32 staging; 4 matrix waves + 4 copy waves, one workgroup per CU), with the
+// critical path of a board cut down to what in-kernel cycle stamps showed it to be (tools/rb_stamps.py on round 3's
+// schedule: 44.2 k shader cycles per board = two K loops 20.0 + 16.2 k, epilogue 1 3.8 k, epilogue 2 2.8 k, 1.2 k waiting for
+// the copy waves to hand X over):
+//   * accumulators START at bias (K loop 1) and at bias + skip (K loop 2; read from X by the lane that owns the element,
+//     unit by unit as epilogue 1 frees the registers): no additions left in the epilogues, and X is dead once K loop 2 starts;
+//   * epilogue 2 is only  relu -> fp32 staging  and is DEFERRED into the fp8 slots of the next board's first K loop
+//     (12 ds_write_b128 per wave, one every ninth slot; c8k::kloop's shadow hook) -- the conversion to the c8 triple stays
+//     with the copy waves, whose instructions do not compete with the matrix waves' issue slots the way shadow VALU work
+//     does (the fully in-place pipelined form, 45 VALU per unit in the shadow, measured 7 % SLOWER than the plain one);
+//   * the copy waves write the next board into X during K loop 2 (X is free from barrier B on) and store the previous
+//     board from the staging image there too; under K loop 1 they only issue the next board's loads.  Two barriers per
+//     board instead of three, none of them waited at by the matrix waves.
+//   matrix waves, board k:  A | K1(k) + shadow: staging <- relu(acc2(k-1)) | epi1 -> Y, acc <- b2 + skip | B | K2(k) | ...
+//   copy waves:             A | loads of board k+1 -> registers            |                            | B | store board
+//                               k-1 from staging (c8 split, or fp32, or the head convolutions); X <- board k+1
+// FIRST: the block is the first of the tower; its copy waves compute the 5 x 5 input layer of board k+1 as an fp32 gather
+// over the occupied squares (see k_resblock_pipe<FIRST> below: the same algorithm, here producing the c8 triple) instead
+// of loading it.  HEADS: the last block; the copy waves apply the two 1 x 1 head convolutions to the staged activation.
+// Arithmetic and its order are k_conv3x3_c8's: bit-identical to two cz_conv3x3_c8 launches.
+struct FirstArgs {
+    const unsigned char* planes;   // u8 [n][in_planes][90], 0 / 1
+    const float* table;            // [in_planes][25][128]
+    const float* in_bias;          // [128]
+    const int32_t* rows;           // compact queue: board i of the batch is planes[rows[i]] (NULL: identity)
+    int in_planes;
+    int w1_rounds;                 // term rounds done in the first window (under K loop 1), the rest under K loop 2
+};
+
+namespace rb8 {
+constexpr int C = 128, RB = 256, ZROW = 96, PART = (ZROW + 16) * RB, REGION = 2 * PART;
+constexpr int SROW = 512, S_BYTES = 90 * SROW;
+constexpr int Y_OFF = REGION, S_OFF = 2 * REGION, BIAS_OFF = S_OFF + S_BYTES, MASK_OFF = BIAS_OFF + 2 * C * 4;
+constexpr int LDS_BYTES = MASK_OFF + 4 * 96 * 4;
+constexpr int DUMP_OFF = Y_OFF + 90 * RB;      // rows 90 .. 95 of Y are never read: the shadow's padding lanes write here
+static_assert(LDS_BYTES <= 160 * 1024, "X + Y + staging + bias + mask boards must fit the CU's LDS");
+// staging offset of channels ch .. ch + 3 of pixel q (fp32, 32 chunks of 16 bytes per row, swizzled by the row)
+__device__ __forceinline__ int stage_off(int q, int ch) { return q * SROW + ((((ch >> 2) & ~7) | (((ch >> 2) ^ q) & 7)) << 4); }
+
+struct Shadow {                         // relu(acc2 of the previous board) -> staging, one (tile, channel group) unit per 9 fp8 slots
+    unsigned char* lds;
+    f32x16* prev;                       // the body always reads prev[0]; rotated at the end of an iteration
+    int wave, kb, ln;
+    __device__ __forceinline__ void unit(const f32x16& a, int q, int g)
+    {
+        const int ch = wave * 32 + g * 8 + kb * 4;
+        const int addr = q < 90 ? S_OFF + stage_off(q, ch) : DUMP_OFF + (kb * 6 + (ln - 26)) * 16;
+        float4 v;
+        v.x = a[g * 4 + 0] > 0.0f ? a[g * 4 + 0] : 0.0f;
+        v.y = a[g * 4 + 1] > 0.0f ? a[g * 4 + 1] : 0.0f;
+        v.z = a[g * 4 + 2] > 0.0f ? a[g * 4 + 2] : 0.0f;
+        v.w = a[g * 4 + 3] > 0.0f ? a[g * 4 + 3] : 0.0f;
+        *reinterpret_cast<float4*>(lds + addr) = v;
+    }
+    __device__ __forceinline__ void fp8(int j, int slot)
+    {
+        if (slot % 9 == 4) unit(prev[0], j * 32 + ln, slot / 9);
+        if (slot == 35) {
+            prev[0] = prev[1];
+            prev[1] = prev[2];
+        }
+    }
+};
+}  // namespace rb8
+
+template <bool FIRST, bool HEADS>
+__global__ __launch_bounds__(512, 2) void k_resblock_c8(
+    const _Float16* __restrict__ xh, const unsigned char* __restrict__ xc, const void* __restrict__ w1p,
+    const float* __restrict__ b1, const void* __restrict__ w2p, const float* __restrict__ b2, _Float16* __restrict__ yh,
+    unsigned char* __restrict__ yc, float* __restrict__ yf, int n_boards, HeadArgs hd, const int32_t* __restrict__ n_dev,
+    FirstArgs fa)
+{
+    using namespace rb8;
+    static_assert(!(FIRST && HEADS), "a one-block tower runs cz_input_conv + the HEADS block");
+    typedef Geom<C, 1, 2> G;
+    static_assert(G::ZROW == ZROW && G::PART_BYTES == PART && G::REGION == REGION, "LDS image geometry");
+    constexpr int NT = 3, CTHR = 256, CHUNKS = 90 * 16, LITER = (CHUNKS + CTHR - 1) / CTHR;
+    constexpr int PIECES = 90 * (C / 8), EITER = (PIECES + CTHR - 1) / CTHR;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    if (n_dev) {                                        // compact queue: the board count lives on the device
+        const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
+        n_boards = nd < n_boards ? nd : n_boards;
+    }
+    unsigned char* X = lds;
+    unsigned char* Y = lds + Y_OFF;
+    unsigned char* S = lds + S_OFF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int stride = gridDim.x;
+    int t = blockIdx.x;
+    if (t >= n_boards) return;
+
+    if (wave >= 4) {                                    // ---- copy waves ----
+        const int ctid = tid - 256;
+        uint4 v[2][LITER];
+        float hw[HEADS ? 6 : 1][8];                     // this thread's slice of the head filters
+        if (HEADS) {
+#pragma unroll
+            for (int o = 0; o < 6; ++o)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) hw[o][k] = hd.w[o * C + (ctid % (C / 8)) * 8 + k];
+        }
+        // board `to` from the staging image (fp32, already ReLU'd) to HBM
+        auto store_tile = [&](int to, int ct2) {
+            const size_t ebase = (size_t)to * 90 * C;
+#pragma unroll
+            for (int it = 0; it < EITER; ++it) {
+                const int i = it * CTHR + ct2;
+                if (!((it + 1) * CTHR <= PIECES || i < PIECES)) continue;
+                const int qq = i / (C / 8), c8 = i % (C / 8);
+                const float4 f0 = *reinterpret_cast<const float4*>(S + stage_off(qq, c8 * 8));
+                const float4 f1 = *reinterpret_cast<const float4*>(S + stage_off(qq, c8 * 8 + 4));
+                const float r[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                if (HEADS) {
+                    // 16 consecutive lanes hold the 128 channels of one pixel: partial dot products, then a 16-lane
+                    // butterfly; lane o of the group writes head output o
+                    float hs[6];
+#pragma unroll
+                    for (int o = 0; o < 6; ++o) {
+                        float a = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) a += r[k] * hw[o][k];
+#pragma unroll
+                        for (int d = 1; d < 16; d <<= 1) a += __shfl_xor(a, d, 64);
+                        hs[o] = a;
+                    }
+#pragma unroll
+                    for (int o = 0; o < 6; ++o)
+                        if (c8 == o) {
+                            float hv = hs[o] + hd.b[o];
+                            hv = hv > 0.0f ? hv : 0.0f;
+                            if (o < hd.n_pol) hd.pol[(size_t)to * (hd.n_pol * 90) + o * 90 + qq] = hv;
+                            else hd.val[(size_t)to * ((6 - hd.n_pol) * 90) + (o - hd.n_pol) * 90 + qq] = hv;
+                        }
+                } else if (yf) {
+                    float4* o = reinterpret_cast<float4*>(yf + ebase) + 2 * i;
+                    o[0] = f0;
+                    o[1] = f1;
+                } else {
+                    const cf8::Split4 s0 = cf8::split4(r), s1 = cf8::split4(r + 4);
+                    struct alignas(16) H8 { Quad<_Float16> a, b; };
+                    reinterpret_cast<uint4*>(yh + ebase)[i] = __builtin_bit_cast(uint4, H8{s0.hi, s1.hi});
+                    unsigned char* row = yc + ebase * 2 + (size_t)qq * 2 * C + c8 * 8;
+                    *reinterpret_cast<uint2*>(row) = make_uint2(s0.l8, s1.l8);
+                    *reinterpret_cast<uint2*>(row + C) = make_uint2(s0.h8, s1.h8);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // registers -> X image.  Loaded boards: 16-byte chunks of both parts; FIRST: the thread's 8 channels of a pixel are
+        // one 16-byte chunk of the f16 row and two 8-byte pieces of the c8 row [lo8 x 128 | e4m3(x) x 128]
+        auto write_x = [&](int ct2) {
+#pragma unroll
+            for (int it = 0; it < LITER; ++it) {
+                const int i = it * CTHR + ct2;
+                if (!((it + 1) * CTHR <= CHUNKS || i < CHUNKS)) continue;
+                const int row = i >> 4, ch = i & 15;
+                *reinterpret_cast<uint4*>(X + row * RB + ((ch ^ (row & 15)) << 4)) = v[0][it];
+                if (FIRST) {
+                    unsigned char* r = X + PART + row * RB + (ch & 1) * 8;
+                    *reinterpret_cast<uint2*>(r + (((ch >> 1) ^ (row & 15)) << 4)) = make_uint2(v[1][it].x, v[1][it].y);
+                    *reinterpret_cast<uint2*>(r + (((8 + (ch >> 1)) ^ (row & 15)) << 4)) = make_uint2(v[1][it].z, v[1][it].w);
+                } else {
+                    *reinterpret_cast<uint4*>(X + PART + row * RB + ((ch ^ (row & 15)) << 4)) = v[1][it];
+                }
+            }
+        };
+        // ---- FIRST: the input layer of a board into v[][], in two halves (k_resblock_pipe<FIRST> documents the algorithm)
+        float acc[FIRST ? LITER : 1][8];
+        uint32_t occ[FIRST ? LITER : 1], cur_m[FIRST ? LITER : 1];
+        int cur_tap[FIRST ? LITER : 1];
+        uint32_t* mk = reinterpret_cast<uint32_t*>(lds + MASK_OFF) + (wave - 4) * 96;     // this wave's own mask board
+        const int c8 = ctid & 15, prow = ctid >> 4;            // chunk = channels 8 c8 .. 8 c8 + 7 of pixels prow + 16 it
+        constexpr int PW = 12;                                 // plane words per lane: 32 planes x 90 bytes / 4 / 64 lanes
+        uint32_t pw[FIRST ? PW : 1];
+        auto planes_prefetch = [&](int board) {
+            const int per_board = fa.in_planes * 90;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(
+                fa.planes + (size_t)(fa.rows ? fa.rows[board] : board) * per_board);
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+                const int w = lane + 64 * j;
+                pw[j] = w < per_board / 4 ? src[w] : 0u;
+            }
+        };
+        auto first_begin = [&]() {
+            mk[lane] = 0u;
+            if (lane < 32) mk[64 + lane] = 0u;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+                const int w = lane + 64 * j;
+                const uint32_t word = pw[j];
+                if (word == 0u) continue;
+                int c = (w * 4) / 90, pix = w * 4 - c * 90;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    if ((word >> (8 * k4)) & 0xFFu) atomicOr(&mk[pix], 1u << c);
+                    if (++pix == 90) { pix = 0; ++c; }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t occ_lo = __ballot(mk[lane] != 0u);
+            const uint64_t occ_hi = __ballot(lane < 26 && mk[64 + (lane & 31)] != 0u);
+            const float4 b0 = *reinterpret_cast<const float4*>(fa.in_bias + c8 * 8);
+            const float4 b1v = *reinterpret_cast<const float4*>(fa.in_bias + c8 * 8 + 4);
+#pragma unroll
+            for (int it = 0; it < LITER; ++it) {
+                acc[it][0] = b0.x; acc[it][1] = b0.y; acc[it][2] = b0.z; acc[it][3] = b0.w;
+                acc[it][4] = b1v.x; acc[it][5] = b1v.y; acc[it][6] = b1v.z; acc[it][7] = b1v.w;
+                const int p = prow + 16 * it;
+                const int py = p / 9, px = p - py * 9;
+                uint32_t o = 0u;
+                if (p < 90) {
+#pragma unroll
+                    for (int ky = 0; ky < 5; ++ky) {
+                        const int r = py + ky - 2;
+                        if ((unsigned)r < 10u) {
+                            const int sh = r * 9;
+                            const uint32_t rowbits = (uint32_t)((sh < 64 ? (occ_lo >> sh) | (sh > 55 ? occ_hi << (64 - sh) : 0ull)
+                                                                         : occ_hi >> (sh - 64)) & 0x1FFull);
+                            o |= (((rowbits << 2) >> px) & 31u) << (5 * ky);
+                        }
+                    }
+                }
+                occ[it] = o;
+                cur_m[it] = 0u;
+                cur_tap[it] = 0;
+            }
+        };
+        auto first_rounds = [&](int max_rounds) {
+#pragma unroll 1
+            for (int round = 0; round < max_rounds; ++round) {
+                uint32_t any = 0u;
+#pragma unroll
+                for (int it = 0; it < LITER; ++it) {
+                    if (cur_m[it] == 0u && occ[it] != 0u) {
+                        const int tap = __builtin_ctz(occ[it]);
+                        occ[it] &= occ[it] - 1u;
+                        const int p = prow + 16 * it;
+                        cur_tap[it] = tap;
+                        cur_m[it] = mk[p + (tap / 5 - 2) * 9 + (tap % 5 - 2)];
+                    }
+                    any |= cur_m[it];
+                }
+                if (!__ballot(any != 0u)) break;
+                float4 wa[LITER], wb[LITER];
+#pragma unroll
+                for (int it = 0; it < LITER; ++it) {
+                    wa[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    wb[it] = wa[it];
+                    if (cur_m[it]) {
+                        const int c = __builtin_ctz(cur_m[it]);
+                        const float4* tp = reinterpret_cast<const float4*>(fa.table + ((size_t)(c * 25 + cur_tap[it]) * 128 + c8 * 8));
+                        wa[it] = tp[0];
+                        wb[it] = tp[1];
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < LITER; ++it) {
+                    if (cur_m[it]) {
+                        acc[it][0] += wa[it].x; acc[it][1] += wa[it].y; acc[it][2] += wa[it].z; acc[it][3] += wa[it].w;
+                        acc[it][4] += wb[it].x; acc[it][5] += wb[it].y; acc[it][6] += wb[it].z; acc[it][7] += wb[it].w;
+                        cur_m[it] &= cur_m[it] - 1u;
+                    }
+                }
+            }
+        };
+        auto first_end = [&]() {                              // ReLU, c8 split, pack (see write_x)
+#pragma unroll
+            for (int it = 0; it < LITER; ++it) {
+                float r[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = acc[it][j] > 0.0f ? acc[it][j] : 0.0f;
+                const cf8::Split4 s0 = cf8::split4(r), s1 = cf8::split4(r + 4);
+                struct alignas(16) H8 { Quad<_Float16> a, b; };
+                v[0][it] = __builtin_bit_cast(uint4, H8{s0.hi, s1.hi});
+                v[1][it] = make_uint4(s0.l8, s1.l8, s0.h8, s1.h8);
+            }
+        };
+        if (FIRST) {
+            planes_prefetch(t);
+            first_begin();
+            if (t + stride < n_boards) planes_prefetch(t + stride);
+            first_rounds(25 * 32);
+            first_end();
+        } else {
+            tile_load<_Float16, C, 1, 2, CTHR>(xh, reinterpret_cast<const _Float16*>(xc), t, n_boards, ctid, v);
+        }
+        write_x(ctid);
+        zero_rows_write<C, 1, 2, CTHR>(X, ctid);
+        zero_rows_write<C, 1, 2, CTHR>(Y, ctid);
+        if (ctid < C) {
+            reinterpret_cast<float*>(lds + BIAS_OFF)[ctid] = b1[ctid];
+            reinterpret_cast<float*>(lds + BIAS_OFF)[C + ctid] = b2[ctid];
+        }
+        int t_prev = -1;
+#ifdef CZ_RB_STAMPS
+        int it_no = 0;
+#endif
+        for (;;) {
+#ifdef CZ_RB_STAMPS
+            const bool stamp_on = blockIdx.x == 5 && ctid == 0 && it_no++ == 40;
+#endif
+            RB_STAMP(16);
+            __syncthreads();                                   // A_k: X holds board t
+            RB_STAMP(17);
+            const int tn = t + stride;
+            const bool has_next = tn < n_boards;
+            int ct2 = ctid;
+            asm volatile("" : "+v"(ct2));                      // keep address arithmetic inside the loop (registers)
+            if (FIRST) {
+                if (has_next) {                                // first part of the next board's input layer, under K loop 1
+                    first_begin();                             // (board tn: its planes were fetched a window ago)
+                    if (tn + stride < n_boards) planes_prefetch(tn + stride);
+                    first_rounds(fa.w1_rounds);
+                }
+            } else if (has_next) {
+                tile_load<_Float16, C, 1, 2, CTHR>(xh, reinterpret_cast<const _Float16*>(xc), tn, n_boards, ct2, v);
+            }
+            RB_STAMP(18);
+            __syncthreads();                                   // B_k: staging holds board t_prev; X is free
+            RB_STAMP(19);
+            if (t_prev >= 0) store_tile(t_prev, ct2);
+            RB_STAMP(20);
+            if (has_next) {
+                if (FIRST) {
+                    first_rounds(25 * 32);
+                    RB_STAMP(21);
+                    first_end();
+                }
+                RB_STAMP(22);
+                write_x(ct2);
+            }
+            RB_STAMP(23);
+            t_prev = t;
+            if (!has_next) break;
+            t = tn;
+        }
+        __syncthreads();                                       // E0: the staging image is free (the store above is done)
+        __syncthreads();                                       // E1: the last board is staged
+        store_tile(t_prev, ctid);
+        return;
+    }
+
+    // ---- matrix waves ----
+    const int kb = lane >> 5, ln = lane & 31;
+    const c8k::Filter flt1 = c8k::make_filter(w1p, wave, lane), flt2 = c8k::make_filter(w2p, wave, lane);
+    const float* bias1 = reinterpret_cast<const float*>(lds + BIAS_OFF);
+    const float* bias2 = bias1 + C;
+    f32x16 acc[NT], prev[NT];
+    rb8::Shadow shd{lds, prev, wave, kb, ln};
+    bool have_prev = false;
+#ifdef CZ_RB_STAMPS
+    int it_no = 0;
+#endif
+    for (;;) {
+#ifdef CZ_RB_STAMPS
+        const bool stamp_on = blockIdx.x == 5 && tid == 0 && it_no++ == 40;
+#endif
+        RB_STAMP(0);
+        __syncthreads();                                       // A_k
+        RB_STAMP(1);
+        const bool has_next = t + stride < n_boards;
+        // K loop 1 on X, accumulators starting at b1
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias1 + wave * 32 + g * 8 + kb * 4);
+#pragma unroll
+            for (int p = 0; p < NT; ++p) {
+                acc[p][g * 4 + 0] = bv.x; acc[p][g * 4 + 1] = bv.y; acc[p][g * 4 + 2] = bv.z; acc[p][g * 4 + 3] = bv.w;
+            }
+        }
+        __builtin_amdgcn_s_setprio(3);
+        if (have_prev) c8k::kloop<NT, rb8::Shadow&, 0, false>(X, c8k::Image{0, ZROW, PART}, flt1, lane, acc, 127 - cf8::X_LO_SHIFT, 127, shd);
+        else c8k::kloop<NT, c8k::NoShadow, 0, false>(X, c8k::Image{0, ZROW, PART}, flt1, lane, acc, 127 - cf8::X_LO_SHIFT, 127);
+        __builtin_amdgcn_s_setprio(0);
+        RB_STAMP(2);
+        int ln2 = ln, kb2 = kb;
+        asm volatile("" : "+v"(ln2), "+v"(kb2));
+        // epilogue 1: relu(acc) -> c8 triple -> Y; the freed accumulators restart at b2 + skip (this lane's own elements of X)
+#pragma unroll
+        for (int p = 0; p < NT; ++p) {
+            const int q = p * 32 + ln2;
+            const int row = q < 90 ? q : 89;                   // (padding lanes compute on row 89 and store nothing)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = wave * 32 + g * 8 + kb2 * 4;
+                const int off = row * RB + (((ch >> 3) ^ (row & 15)) << 4) + (ch & 7) * 2;
+                const int off_lo = PART + row * RB + (ch & 15) + (((ch >> 4) ^ (row & 15)) << 4);
+                const int off_hi = PART + row * RB + (ch & 15) + (((8 + (ch >> 4)) ^ (row & 15)) << 4);
+                float r[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] = acc[p][g * 4 + i] > 0.0f ? acc[p][g * 4 + i] : 0.0f;
+                const cf8::Split4 o = cf8::split4(r);
+                if (q < 90) {
+                    *reinterpret_cast<Quad<_Float16>*>(Y + off) = o.hi;
+                    *reinterpret_cast<uint32_t*>(Y + off_lo) = o.l8;
+                    *reinterpret_cast<uint32_t*>(Y + off_hi) = o.h8;
+                }
+                const float4 bv = *reinterpret_cast<const float4*>(bias2 + ch);
+                float vv[4] = {bv.x, bv.y, bv.z, bv.w};
+                cf8::add_pair4(vv, *reinterpret_cast<const Quad<_Float16>*>(X + off), *reinterpret_cast<const uint32_t*>(X + off_lo));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[p][g * 4 + i] = vv[i];
+            }
+        }
+        RB_STAMP(3);
+        __syncthreads();                                       // B_k: Y complete, X and the previous staging contents free
+        RB_STAMP(4);
+        __builtin_amdgcn_s_setprio(3);
+        c8k::kloop<NT, c8k::NoShadow, 0, false>(Y, c8k::Image{0, ZROW, PART}, flt2, lane, acc, 127 - cf8::X_LO_SHIFT, 127);
+        __builtin_amdgcn_s_setprio(0);
+        RB_STAMP(5);
+#pragma unroll
+        for (int p = 0; p < NT; ++p) prev[p] = acc[p];
+        have_prev = true;
+        if (!has_next) break;
+        t += stride;
+    }
+    // the last board's second epilogue, not overlapped (once the copy waves have let go of the staging image)
+    __syncthreads();                                           // E0
+#pragma unroll
+    for (int p = 0; p < NT; ++p)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) shd.unit(prev[p], p * 32 + ln, g);
+    __syncthreads();                                           // E1
 }
 
 // ---- kernel 2b: the residual block, software-pipelined over boards (128 filters, split operands) ------------------
@@ -896,14 +1314,6 @@ __device__ __forceinline__ void pipe_kloop(unsigned char* lds, int row_base, con
 // (table[plane][tap][128], 179 KB) per board, exact fp32 sums in a fixed order (bias, taps 0..24, planes ascending) --
 // no MFMA, no second kernel, no 46 KB per board written and read back.  The work is split over the two windows a copy
 // wave has per board (under K loop 1 and under K loop 2), since all waves meet at the barrier between them.
-struct FirstArgs {
-    const unsigned char* planes;   // u8 [n][in_planes][90], 0 / 1
-    const float* table;            // [in_planes][25][128]
-    const float* in_bias;          // [128]
-    const int32_t* rows;           // compact queue: board i of the batch is planes[rows[i]] (NULL: identity)
-    int in_planes;
-    int w1_rounds;                 // term rounds done in the first window (under K loop 1), the rest under K loop 2
-};
 
 template <typename E, bool FIRST = false>
 __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
@@ -1694,6 +2104,13 @@ inline float f16_bits_to_f32(uint16_t b)
 
 }  // namespace
 
+#ifdef CZ_RB_STAMPS
+extern "C" int cz_debug_rb_stamps(long long* out32_host)
+{
+    return hipMemcpyFromSymbol(out32_host, HIP_SYMBOL(g_rb_stamps), sizeof(long long) * 32) == hipSuccess ? CZ_OK : CZ_ERR_HIP;
+}
+#endif
+
 extern "C" size_t cz_conv3x3_packed_elems(int channels, int parts)
 {
     if (channels <= 0 || channels % 32 != 0 || parts < 1 || parts > 2) return 0;
@@ -1988,19 +2405,31 @@ extern "C" int cz_input_conv(const void* planes, int planes_dtype, int in_planes
 }
 
 namespace {
-template <typename E, int C, int PARTS, int P, bool HEADS = false, int CTW = 1, bool C8 = false>
+template <typename E, int C, int PARTS, int P, bool HEADS = false, int CTW = 1>
 int launch_resblock(const void* xh, const void* xl, const void* w1, const float* b1, const void* w2, const float* b2,
                     void* yh, void* yl, float* yf, int n, int n_cu, hipStream_t st, HeadArgs hd = HeadArgs{})
 {
     const int tiles = (n + P - 1) / P;
     const unsigned blocks = (unsigned)(tiles < n_cu ? tiles : n_cu);
-    hipLaunchKernelGGL((k_resblock<E, C, PARTS, P, HEADS, CTW, C8>), dim3(blocks), dim3((C / 32 / CTW + 4) * 64), 0, st,
+    hipLaunchKernelGGL((k_resblock<E, C, PARTS, P, HEADS, CTW>), dim3(blocks), dim3((C / 32 / CTW + 4) * 64), 0, st,
                        (const E*)xh, (const E*)xl, (const E*)w1, b1, (const E*)w2, b2, (E*)yh, (E*)yl, yf, n, hd,
                        g_q.n_dev);
     return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
 }
 
+template <bool FIRST, bool HEADS>
+int launch_resblock_c8(const void* xh, const void* xc, const void* w1, const float* b1, const void* w2, const float* b2,
+                       void* yh, void* yc, float* yf, int n, int n_cu, hipStream_t st, HeadArgs hd, const int32_t* n_dev,
+                       FirstArgs fa)
+{
+    const unsigned blocks = (unsigned)(n < n_cu ? n : n_cu);
+    hipLaunchKernelGGL((k_resblock_c8<FIRST, HEADS>), dim3(blocks), dim3(512), 0, st, (const _Float16*)xh,
+                       (const unsigned char*)xc, w1, b1, w2, b2, (_Float16*)yh, (unsigned char*)yc, yf, n, hd, n_dev, fa);
+    return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
+}
+
 int g_resblock_pipelined = 1;       // cz_resblock_pipelined(): 128-filter split blocks on k_resblock_pipe
+int g_first_w1_rounds = 6;          // cz_input_resblock: gather rounds done under K loop 1 (tuning hook: CZ_FIRST_W1_ROUNDS)
 
 template <typename E>
 int dispatch_resblock(int channels, int parts, const void* xh, const void* xl, const void* w1, const float* b1,
@@ -2039,6 +2468,7 @@ static int device_cu_count()
 {
     static int n_cu = 0;
     if (n_cu == 0) {
+        if (const char* e = getenv("CZ_FIRST_W1_ROUNDS")) g_first_w1_rounds = atoi(e);      // (A/B runs of the fused input layer)
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
@@ -2074,8 +2504,8 @@ extern "C" int cz_resblock_heads(const void* x_hi, const void* x_lo, const void*
         rc = launch_resblock<__bf16, 128, 2, 1, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, nullptr, nullptr,
                                                        nullptr, n_boards, n_cu, st, hd);
     else if (dtype == CZ_F16C8)
-        rc = launch_resblock<_Float16, 128, 2, 1, true, 1, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, nullptr,
-                                                                   nullptr, nullptr, n_boards, n_cu, st, hd);
+        rc = launch_resblock_c8<false, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, nullptr, nullptr, nullptr,
+                                             n_boards, n_cu, st, hd, g_q.n_dev, FirstArgs{});
     else
         rc = launch_resblock<_Float16, 128, 2, 1, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, nullptr,
                                                          nullptr, nullptr, n_boards, n_cu, st, hd);
@@ -2107,8 +2537,8 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
         rc = dispatch_resblock<_Float16>(channels, parts, x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo,
                                          y_f32, n_boards, n_cu, st);
     else if (dtype == CZ_F16C8 && channels == 128 && parts == 2)
-        rc = launch_resblock<_Float16, 128, 2, 1, false, 1, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, y_hi,
-                                                                    y_lo, y_f32, n_boards, n_cu, st);
+        rc = launch_resblock_c8<false, false>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo, y_f32, n_boards,
+                                              n_cu, st, HeadArgs{}, g_q.n_dev, FirstArgs{});
     if (rc == CZ_ERR_ARG)
         czi_set_error("cz_resblock: supported: 128 / 192 filters (split or plain operands), 256 filters (plain), bf16 / f16; "
                       "use cz_conv3x3 otherwise");
@@ -2129,8 +2559,8 @@ extern "C" int cz_input_resblock(const void* planes_u8, int in_planes, const flo
         czi_set_error("cz_input_resblock: bad argument (u8 planes, in_planes even and <= 32)");
         return CZ_ERR_ARG;
     }
-    if (channels != 128 || (dtype != CZ_BF16 && dtype != CZ_F16)) {
-        czi_set_error("cz_input_resblock: 128 filters, bf16 / f16 split operands only (use cz_input_conv + cz_resblock)");
+    if (channels != 128 || (dtype != CZ_BF16 && dtype != CZ_F16 && dtype != CZ_F16C8)) {
+        czi_set_error("cz_input_resblock: 128 filters; bf16 / f16 split operands or the c8 pair (use cz_input_conv + cz_resblock)");
         return CZ_ERR_ARG;
     }
     if (n_boards == 0) return CZ_OK;
@@ -2143,7 +2573,15 @@ extern "C" int cz_input_resblock(const void* planes_u8, int in_planes, const flo
     const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
     // 6 of the ~12-16 term rounds of a board under K loop 1, the rest under K loop 2: measured on one box, extra time of
     // the launch against an inner block's: 0 rounds +0.43 ms, 3: +0.26, 6: +0.14, 9: +0.22 (window 2 also drains the result)
-    const FirstArgs fa{(const unsigned char*)planes_u8, in_table, in_bias, rows, in_planes, 6};
+    const FirstArgs fa{(const unsigned char*)planes_u8, in_table, in_bias, rows, in_planes, g_first_w1_rounds};
+    if (dtype == CZ_F16C8) {          // y_lo = the c8 image, the filters are cz_conv3x3_c8_pack_weights' (k_resblock_c8<FIRST>)
+        if (launch_resblock_c8<true, false>(nullptr, nullptr, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo, nullptr, n_boards,
+                                            n_cu, st, HeadArgs{}, n_dev, fa) != CZ_OK) {
+            czi_set_error("cz_input_resblock: launch failed");
+            return CZ_ERR_HIP;
+        }
+        return CZ_OK;
+    }
     if (dtype == CZ_BF16)
         hipLaunchKernelGGL((k_resblock_pipe<__bf16, true>), dim3(blocks), dim3(512), 0, st, (const __bf16*)nullptr,
                            (const __bf16*)nullptr, (const __bf16*)w1_packed, bias1, (const __bf16*)w2_packed, bias2,

@@ -226,7 +226,10 @@ def test_network_with_c8_tower_matches_fp32_module(blocks):
 @pytest.mark.parametrize("n", [1, 3, 257])
 def test_conv3x3_c8_operand_pair_output_and_skip(n):
     """The operand-pair output of cz_conv3x3_c8 is the split of its own fp32 output (device conversions = PyTorch's:
-    round to nearest even, saturating at 448), and the skip input adds the value the pair stands for."""
+    round to nearest even, saturating at 448), and the skip input adds the value the pair stands for.  Since round 4 the
+    accumulators START at bias (+ skip) and the products are added on top (no additions left in the epilogue), so the
+    skip result equals  (conv + bias) + skip  up to the fp32 rounding of a different summation order -- every one of the
+    ~110 accumulation steps rounds at the magnitude of a different partial sum: 2^-18 of the largest, not bit for bit."""
     import torch
     from cchess_alphazero import _native
     c = 128
@@ -249,7 +252,9 @@ def test_conv3x3_c8_operand_pair_output_and_skip(n):
         fs = torch.empty_like(f)
         _native.conv3x3_c8(xs, pk, bias, skip=ss, out_f32=fs, relu=relu)
         ws = f + _native.join_c8(ss)
-        assert torch.equal(fs, ws.relu() if relu else ws)
+        ws = ws.relu() if relu else ws
+        scale = (f.abs() + _native.join_c8(ss).abs()).max().item()
+        assert (fs - ws).abs().max().item() <= 2.0 ** -18 * scale, ((fs - ws).abs().max().item(), scale)
     # the pair reproduces the value to 2^-16 of its magnitude (f16 hi + 4-bit lo; the lo image's smallest step is
     # 2^-9 / 2^11 = 2^-20, which is what small values get), below e4m3's saturation
     v = torch.randn((4, 90, c), device="cuda", generator=g) * 50.0
@@ -596,6 +601,39 @@ def test_network_on_a_compact_queue_matches_the_gathered_batch(filters, arith):
     assert (p - pg).abs().max() < 1e-6 and (v - vg).abs().max() < 1e-6
 
 
+def test_resblock_c8_deferred_epilogue_is_bit_identical_to_two_convolutions():
+    """k_resblock_c8 (round 4: accumulators start at bias / bias + skip, the second epilogue of a board deferred into the
+    fp8 slots of the next board's first K loop, X rewritten under K loop 2) against two cz_conv3x3_c8 launches: bit for
+    bit, for one board per workgroup, several, one more than the CUs, an odd many (every workgroup's first, middle and
+    last board take different paths); large / tiny activations; in place; device-side count."""
+    import torch
+    from cchess_alphazero import _native
+    c = 128
+    g = torch.Generator(device="cuda").manual_seed(17)
+    ws = [torch.randn((c, c, 3, 3), device="cuda", generator=g) / (3.0 * c ** 0.5) for _ in range(2)]
+    bs = [torch.randn((c,), device="cuda", generator=g) * 0.3 for _ in range(2)]
+    ps = [_native.pack_conv3x3_c8_weights(w).cuda() for w in ws]
+    for n in (1, 2, 5, 257, 1031, 2100):
+        x = (torch.randn((n, 90, c), device="cuda", generator=g) * 1.5).relu()
+        x[0, 0, :4] = torch.tensor([300.0, 2e-3, 5e-5, 0.0], device="cuda")
+        xs = _native.split_c8(x)
+        empty = lambda: (torch.full((n, 90, c), 7.0, device="cuda", dtype=torch.float16),
+                         torch.full((n, 90, 2 * c), 7, device="cuda", dtype=torch.uint8))
+        got = _native.resblock(xs, ps[0], bs[0], ps[1], bs[1], out=empty())
+        t, want = empty(), empty()
+        _native.conv3x3_c8(xs, ps[0], bs[0], out=t)
+        _native.conv3x3_c8(t, ps[1], bs[1], skip=xs, out=want)
+        for part in range(2):
+            assert torch.equal(got[part], want[part]), (n, part)
+    n, cnt = 300, 123
+    xs = _native.split_c8((torch.randn((n, 90, c), device="cuda", generator=g) * 1.5).relu())
+    ref = _native.resblock(xs, ps[0], bs[0], ps[1], bs[1], out=(torch.empty_like(xs[0]), torch.empty_like(xs[1])))
+    y = tuple(t.clone() for t in xs)
+    _native.resblock(y, ps[0], bs[0], ps[1], bs[1], out=y, count=torch.tensor([cnt], dtype=torch.int32, device="cuda"))
+    for part in range(2):
+        assert torch.equal(y[part][:cnt], ref[part][:cnt]) and torch.equal(y[part][cnt:], xs[part][cnt:])
+
+
 @pytest.mark.parametrize("dt", ["bfloat16", "float16"])
 def test_pipelined_resblock_is_bit_identical_to_the_plain_schedule(dt):
     """k_resblock_pipe (epilogue 2 of a board under the next board's first K loop, result written in place over the skip
@@ -703,6 +741,50 @@ def test_network_tail_switch_gives_the_same_outputs():
     assert (p.cpu() - pr).abs().max().item() < 1e-4 and (v.cpu() - vr).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("in_planes", [14, 28])
+def test_input_resblock_c8_matches_input_layer_then_resblock(in_planes):
+    """cz_input_resblock with dtype CZ_F16C8 (k_resblock_c8<FIRST>: the copy waves' fp32 gather produces the c8 operand
+    triple) against the float64 input layer, split with split_c8, followed by cz_resblock on the c8
+    arithmetic.  The input layers differ by fp32 summation only (<= 4e-6 relative), the blocks are the same arithmetic:
+    outputs agree to 3e-5 of the largest value; the compact queue's gathered rows reproduce the plain batch bit for bit."""
+    import torch
+    import torch.nn.functional as F
+    from cchess_alphazero import _native
+    c = 128
+    g = torch.Generator().manual_seed(100 + in_planes)
+    w_in = torch.randn((c, in_planes, 5, 5), generator=g) * 0.2
+    b_in = torch.randn((c,), generator=g) * 0.1
+    ws = [torch.randn((c, c, 3, 3), generator=g) / (3.0 * c ** 0.5) for _ in range(2)]
+    bs = [(torch.randn((c,), generator=g) * 0.1).cuda() for _ in range(2)]
+    ps = [_native.pack_conv3x3_c8_weights(w).cuda() for w in ws]
+    table, bias = _native.input_table(w_in).cuda(), b_in.cuda()
+    for n in (1, 2, 255, 257, 700):
+        planes = torch.zeros((n, in_planes, 10, 9), dtype=torch.uint8)
+        for grp in range(in_planes // 14):
+            occ = torch.rand((n, 10, 9), generator=g) < 0.36
+            which = torch.randint(0, 14, (n, 10, 9), generator=g)
+            planes[:, grp * 14:(grp + 1) * 14].scatter_(1, which.unsqueeze(1), occ.unsqueeze(1).to(torch.uint8))
+        x = F.relu(F.conv2d(planes.double(), w_in.double(), b_in.double(), padding=2)).float()
+        xs = _native.split_c8(x.permute(0, 2, 3, 1).reshape(n, 90, c).contiguous().cuda())
+        empty = lambda: (torch.full((n, 90, c), 7.0, device="cuda", dtype=torch.float16),
+                         torch.full((n, 90, 2 * c), 7, device="cuda", dtype=torch.uint8))
+        want = _native.resblock(xs, ps[0], bs[0], ps[1], bs[1], out=empty())
+        got = _native.input_resblock(planes.cuda(), table, bias, ps[0], bs[0], ps[1], bs[1], out=empty())
+        y, y_ref = _native.join_c8(got), _native.join_c8(want)
+        assert torch.isfinite(y).all()
+        assert (y - y_ref).abs().max().item() <= 3e-5 * y_ref.abs().max().item(), n
+        # the value bytes are the e4m3 of the value the pair stands for (what the next block's correction term reads)
+        h8 = got[1][..., c:].contiguous().view(torch.float8_e4m3fn).float()
+        assert (h8 - y).abs().max().item() <= 2.0 ** -4 * y.abs().max().item() + 2.0 ** -9
+        if n == 700:
+            perm = torch.randperm(n, generator=g).to(torch.int32).cuda()
+            cnt = torch.tensor([333], dtype=torch.int32, device="cuda")
+            got2 = _native.input_resblock(planes.cuda(), table, bias, ps[0], bs[0], ps[1], bs[1], out=empty(), rows=perm, count=cnt)
+            for part in range(2):
+                assert torch.equal(got2[part][:333], got[part][perm[:333].long()])
+                assert torch.all(got2[part][333:] == 7)
+
+
 @pytest.mark.parametrize("in_planes,dt", [(14, "bfloat16"), (28, "bfloat16"), (14, "float16")])
 def test_input_resblock_matches_input_layer_then_resblock(in_planes, dt):
     """cz_input_resblock (k_resblock_pipe<FIRST>: the 5x5 input layer as an fp32 gather over the occupied squares, done by
@@ -752,13 +834,14 @@ def test_input_resblock_matches_input_layer_then_resblock(in_planes, dt):
                 assert torch.all(got2[part][333:] == 7.0)
 
 
-def test_network_with_fused_input_layer_switch():
+@pytest.mark.parametrize("arith", ["bf16x3", "f16x3", "c8"])
+def test_network_with_fused_input_layer_switch(arith):
     """InferenceNet with the input layer inside the first block's launch (default) vs the separate cz_input_conv kernel."""
     import torch
     from cchess_alphazero.agent.model import CChessNet, InferenceNet
     torch.manual_seed(6)
     raw = CChessNet(cnn_filter_num=128, res_layer_num=3).eval()
-    net = InferenceNet(raw, torch.float32, trunk="mfma").cuda()
+    net = InferenceNet(raw, torch.float32, trunk="mfma", arith=arith).cuda()
     planes = torch.zeros((150, 14, 10, 9), dtype=torch.uint8)
     occ = torch.rand((150, 10, 9)) < 0.3
     planes.scatter_(1, torch.randint(0, 14, (150, 1, 10, 9)), occ.unsqueeze(1).to(torch.uint8))

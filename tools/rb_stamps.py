@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Where a residual-block launch of the c8 tower spends its shader cycles: a -DCZ_RB_STAMPS build of the library (variant,
+never the default) stamps s_memtime in one matrix wave and one copy wave of one workgroup around the sections of one
+steady-state board.  Run on the MI355X:
+
+    python chinesechess-alphazero_amd/build.py --out variants/libczero_stamps.so -DCZ_RB_STAMPS      (here, cross-compiles)
+    CZ_LIB=variants/libczero_stamps.so python tools/rb_stamps.py
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "chinesechess-alphazero_amd"))
+from cchess_alphazero import _native  # noqa: E402
+
+
+def main():
+    n, c = 32768, 128
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = (torch.randn((n, 90, c), device="cuda", generator=g) * 1.5).relu()
+    gw = torch.Generator().manual_seed(2)
+    w1, w2 = (torch.randn((c, c, 3, 3), generator=gw) / (3.0 * c ** 0.5) for _ in range(2))
+    w_in = torch.randn((c, 14, 5, 5), generator=gw) * 0.2
+    b = torch.zeros(c, device="cuda")
+    p1, p2 = _native.pack_conv3x3_c8_weights(w1).cuda(), _native.pack_conv3x3_c8_weights(w2).cuda()
+    table = _native.input_table(w_in).cuda()
+    planes = torch.zeros((n, 14, 10, 9), dtype=torch.uint8)
+    occ = torch.rand((n, 10, 9), generator=gw) < 0.3
+    planes.scatter_(1, torch.randint(0, 14, (n, 1, 10, 9), generator=gw), occ.unsqueeze(1).to(torch.uint8))
+    planes = planes.cuda()
+    xin = _native.split_c8(x)
+    out = (torch.empty_like(xin[0]), torch.empty_like(xin[1]))
+    L = _native.lib()
+    L.cz_debug_rb_stamps.argtypes = [C.c_void_p]
+    res = {}
+    for name, fn in (("block", lambda: _native.resblock(xin, p1, b, p2, b, out=out)),
+                     ("first_block_with_fused_input_layer", lambda: _native.input_resblock(planes, table, b, p1, b, p2, b, out=out))):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for _ in range(30):                               # warm: the clock settles under the sustained load
+            fn()
+        ev[0].record()
+        for _ in range(20):
+            fn()
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1]) / 20
+        st = (C.c_longlong * 32)()
+        assert L.cz_debug_rb_stamps(st) == 0
+        s = list(st)
+        m = {"wait_A": s[1] - s[0], "kloop_1_with_deferred_epilogue_2": s[2] - s[1], "epilogue_1_and_skip_init": s[3] - s[2],
+             "wait_B": s[4] - s[3], "kloop_2": s[5] - s[4]}
+        cw = {"wait_A": s[17] - s[16], "window_1_loads_or_gather": s[18] - s[17], "wait_B": s[19] - s[18],
+              "store_previous_board": s[20] - s[19], "gather_rest": s[21] - s[20] if s[21] > s[20] else 0,
+              "first_end_split": s[22] - max(s[21], s[20]), "write_X": s[23] - s[22]}
+        us_per_board = ms * 1e3 / (n / 256.0)
+        res[name] = {"ms_per_launch": ms, "us_per_board": us_per_board, "matrix_wave_cycles": m, "copy_wave_cycles": cw,
+                     "cycles_stamped": sum(m.values()), "effective_GHz": sum(m.values()) / us_per_board / 1e3}
+    res["mfma_floor_cycles_per_kloop"] = 13824
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
