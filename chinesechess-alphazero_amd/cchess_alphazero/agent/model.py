@@ -117,7 +117,13 @@ class InferenceNet(nn.Module):
     None of the reduced forms is trusted blindly: guarded_inference_net() below measures the candidate against float64 on
     calibration positions when weights are loaded and falls back along c8 -> c8>N -> f16x3 -> bf16x3."""
 
-    def __init__(self, net: CChessNet, dtype=torch.float32, trunk="library", arith=None):
+    def __init__(self, net: CChessNet, dtype=torch.float32, trunk="library", arith=None, act_shift=None):
+        """act_shift = (s_x, [s_mid per block]): power-of-two activation scales of the residual stream and of every block's
+        intermediate tensor, applied as an EXACT reparametrisation of the folded network (ReLU commutes with a positive
+        scale): the input layer is multiplied by 2^s_x, block i's first convolution by 2^(s_mid_i - s_x) (bias 2^s_mid_i), its
+        second by 2^(s_x - s_mid_i) (bias 2^s_x), the head convolutions by 2^-s_x.  Outputs are unchanged; the tower's tensors
+        move into the range the reduced operand formats resolve (e4m3 saturates at 448, fp16 at 65504).  Chosen by
+        guarded_inference_net from the measured activation ranges; None = no scaling."""
         super().__init__()
         net = net.eval()
         assert trunk in ("library", "mfma")
@@ -161,6 +167,20 @@ class InferenceNet(nn.Module):
             self.policy_out.load_state_dict(net.policy_out.state_dict())
             self.value_dense.load_state_dict(net.value_dense.state_dict())
             self.value_out.load_state_dict(net.value_out.state_dict())
+            self.act_shift = None
+            if act_shift is not None and (act_shift[0] != 0 or any(act_shift[1])):
+                sx, smid = int(act_shift[0]), [int(v) for v in act_shift[1]]
+                assert len(smid) == len(self.res)
+                self.act_shift = (sx, smid)
+                self.input_conv.weight.mul_(2.0 ** sx)
+                self.input_conv.bias.mul_(2.0 ** sx)
+                for (c1, c2), sm in zip(self.res, smid):
+                    c1.weight.mul_(2.0 ** (sm - sx))
+                    c1.bias.mul_(2.0 ** sm)
+                    c2.weight.mul_(2.0 ** (sx - sm))
+                    c2.bias.mul_(2.0 ** sx)
+                self.policy_conv.weight.mul_(2.0 ** -sx)      # (their biases act on the unscaled head features)
+                self.value_conv.weight.mul_(2.0 ** -sx)
             packed = self._pack_trunk() if trunk == "mfma" else None
         self.to(dtype)
         self.to(memory_format=torch.channels_last)
@@ -512,6 +532,28 @@ def measure_against_reference(inf, ref_out, planes):
                 finite=bool(torch.isfinite(p).all() and torch.isfinite(v).all()))
 
 
+def choose_act_shift(activation_max, n_blocks, target=128.0, max_dev=3):
+    """Power-of-two scales (exponents) for the residual stream and each block's intermediate tensor from the measured
+    max |activation| of [input layer, block 0 mid, block 0 out, block 1 mid, ...].
+    A COMMON shift moves the whole tower (all tensors by the same power of two: the tower's filters are untouched, only
+    biases, the input layer and the head convolutions change) when its largest tensor lies outside [2^-3, 224]: e4m3
+    resolves 2^-6 .. 448, and a factor of two is kept over the calibration sample.  On top of it a single tensor may
+    deviate by at most 2^max_dev -- a deviation moves the factor into the neighbouring filters, and fp16 filter pairs
+    lose their lo parts when scaled down far -- and only if it would otherwise still overflow.
+    Networks in the usual range get (0, [0, ...]) and are left bit for bit as they were."""
+    import math
+
+    def want(m):                                    # exponent that brings a maximum m to ~target
+        return int(math.floor(math.log2(target / m))) if m > 0.0 else 0
+    top = max(activation_max)
+    base = 0 if 2.0 ** -3 <= top <= 224.0 or not top > 0.0 else max(-40, min(40, want(top)))
+
+    def dev(m):                                     # per-tensor deviation: only against overflow, bounded
+        return max(-max_dev, min(0, want(m) - base)) if m * 2.0 ** base > 224.0 else 0
+    stream = max([activation_max[0]] + [activation_max[2 * i + 2] for i in range(n_blocks)])
+    return base + dev(stream), [base + dev(activation_max[2 * i + 1]) for i in range(n_blocks)]
+
+
 def guard_chain(arith, c8_blocks, n_blocks, activation_max):
     """The candidates guarded_inference_net tries, most reduced first, for a requested arithmetic family and the tower's
     measured activation ranges: a c8 image saturates above 448 (such a tower is not even tried), fp16 pairs overflow at
@@ -557,11 +599,20 @@ def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", ari
         # lo byte e4m3(x_lo * 2^11) saturates when |x| > ~2^9 * 448 / 2^-... i.e. with the value byte): reported, and a
         # saturating tower is not even tried
         report["c8_saturating_layers"] = [i for i, a in enumerate(acts) if a > 448.0]
-        chain = guard_chain(first.arith, first.c8_blocks, len(net.res), acts)
-        cand = first
+        # tensors outside the range the operand formats resolve are moved into it by an exact power-of-two reparametrisation
+        nblk = len(net.res)
+        sx, smid = choose_act_shift(acts, nblk) if first.arith in ("c8", "f16x3") else (0, [0] * nblk)
+        shift = (sx, smid) if (sx or any(smid)) else None
+        report["act_shift"] = {"stream": sx, "mid": smid}
+        # (acts: [input layer, block 0 mid, block 0 out, block 1 mid, ...] -- odd entries are intermediate tensors)
+        scaled = [a * 2.0 ** (smid[(i - 1) // 2] if i % 2 else sx) for i, a in enumerate(acts)]
+        report["activation_max_scaled"] = scaled
+        report["c8_saturating_layers_after_scaling"] = [i for i, a in enumerate(scaled) if a > 448.0]
+        chain = guard_chain(first.arith, first.c8_blocks, nblk, scaled)
+        cand = first if shift is None else None
         for name in chain:
             if cand is None or cand.arith_name != name:
-                cand = InferenceNet(net, dtype, trunk=trunk, arith=name).to(dev)
+                cand = InferenceNet(net, dtype, trunk=trunk, arith=name, act_shift=shift).to(dev)
             m = measure_against_reference(cand, ref, planes)
             m["arith"] = name
             report["candidates"].append(m)
@@ -573,6 +624,7 @@ def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", ari
                            tol, report["candidates"])
             cand = InferenceNet(net, dtype, trunk="library").to(dev)
             name = "fp32-library"
+            chain = chain + [name]
         if name != first.arith_name:
             logger.warning("tower arithmetic %s deviates from the float64 network by more than %g on the calibration "
                            "positions (%s): using %s", requested, tol, report["candidates"][0], name)

@@ -100,7 +100,8 @@ def test_peaked_policy_networks_stay_within_tolerance(policy_scale, min_peak):
     assert g.arith_requested == "c8" and g.calibration["max_policy_probability"] >= min_peak
     assert m["policy_max_abs"] < 5e-5 and m["value_max_abs"] < 5e-5, (g.arith_effective, m)
     last = g.calibration["candidates"][-1]
-    assert last["arith"] == g.arith_effective and last["policy_max_abs"] <= g.calibration["tol"]
+    assert g.arith_effective in (last["arith"], "fp32-library") and \
+        (g.arith_effective == "fp32-library" or last["policy_max_abs"] <= g.calibration["tol"])
 
 
 def test_guard_keeps_the_requested_arithmetic_where_it_is_exact_enough():
@@ -122,21 +123,35 @@ def test_guard_keeps_the_requested_arithmetic_where_it_is_exact_enough():
     assert g1.arith_effective == "f16x3"
 
 
-def test_guard_leaves_c8_when_the_activations_saturate_its_image():
-    """Activations above e4m3's 448 lose the w_lo x correction silently in the kernels (xq_conv.hip cf8::sat): the guard
-    sees the range in the float64 pass and does not try c8; fp16 pairs hold up to 65504."""
+def test_guard_moves_out_of_range_activations_into_the_operand_formats():
+    """Activations above e4m3's 448 would lose the w_lo x correction silently in the kernels (xq_conv.hip cf8::sat), tiny
+    ones fall into its subnormals.  The guard sees every tower tensor's range in the float64 pass and applies exact
+    power-of-two scales (InferenceNet act_shift: a reparametrisation of the folded network, outputs unchanged) before it
+    measures the candidates; the report carries the ranges before and after."""
     import torch
-    from cchess_alphazero.agent.model import (calibration_planes, guarded_inference_net, measure_against_reference,
-                                              reference_forward_f64)
-    net = peaked_net(1.0, blocks=3)
-    net.input_bn.weight.data.mul_(3000.0)
-    net.input_bn.bias.data.mul_(3000.0)
-    g = guarded_inference_net(net, torch.float32, trunk="mfma", arith="c8")
-    assert max(g.calibration["activation_max"]) > 448.0 and g.calibration["c8_saturating_layers"]
-    assert g.arith_effective in ("f16x3", "bf16x3") and all(not c["arith"].startswith("c8") for c in g.calibration["candidates"])
-    fresh = calibration_planes(64, 14, seed=5)
-    m = measure_against_reference(g, reference_forward_f64(net, fresh), fresh)
-    assert m["policy_max_abs"] < 1e-4 and m["value_max_abs"] < 1e-4, m
+    from cchess_alphazero.agent.model import (InferenceNet, calibration_planes, guarded_inference_net,
+                                              measure_against_reference, reference_forward_f64)
+    for factor in (3000.0, 40000.0):
+        net = peaked_net(1.0, blocks=3)
+        net.input_bn.weight.data.mul_(factor)
+        net.input_bn.bias.data.mul_(factor)
+        g = guarded_inference_net(net, torch.float32, trunk="mfma", arith="c8")
+        cal = g.calibration
+        assert cal["act_shift"]["stream"] < 0 and all(v < 0 for v in cal["act_shift"]["mid"])
+        assert max(cal["activation_max"]) > 448.0 and cal["c8_saturating_layers"]
+        assert max(cal["activation_max_scaled"]) <= 448.0 and not cal["c8_saturating_layers_after_scaling"]
+        assert cal["candidates"][0]["arith"] == "c8"                 # tried, now that its image holds the tensors
+        fresh = calibration_planes(64, 14, seed=5)
+        ref = reference_forward_f64(net, fresh)
+        m = measure_against_reference(g, ref, fresh)
+        assert m["policy_max_abs"] < 1e-4 and m["value_max_abs"] < 1e-4, (factor, g.arith_effective, m)
+        # the scales are an exact reparametrisation: the same network, shifted and unshifted, on the range-free bf16 pairs
+        a = InferenceNet(net, torch.float32, trunk="mfma", arith="bf16x3").cuda()(fresh)
+        b = InferenceNet(net, torch.float32, trunk="mfma", arith="bf16x3", act_shift=g.act_shift).cuda()(fresh)
+        assert (a[0] - b[0]).abs().max().item() < 2e-6 and (a[1] - b[1]).abs().max().item() < 2e-6
+    # a network in the usual range is left alone
+    g = guarded_inference_net(peaked_net(1.0, blocks=2), torch.float32, trunk="mfma", arith="c8")
+    assert g.act_shift is None and g.calibration["act_shift"] == {"stream": 0, "mid": [0, 0]}
 
 
 @pytest.mark.parametrize("n8", [0, 3, 5, 7])

@@ -311,6 +311,15 @@ def test_guard_chain_orders_the_candidates_by_exactness():
     assert guard_chain("c8", 7, 7, [4.0e4]) == ["bf16x3"]
     assert guard_chain("f16x3", 0, 7, [3.0]) == ["f16x3", "bf16x3"]
     assert guard_chain("bf16x3", 0, 7, [3.0]) == ["bf16x3"]
+    # power-of-two activation scales from the measured ranges [input, b0 mid, b0 out, b1 mid, b1 out]: a common shift for a
+    # tower outside [2^-3, 224] (filters untouched), bounded per-tensor deviations against overflow only
+    from cchess_alphazero.agent.model import choose_act_shift
+    assert choose_act_shift([5.0, 9.0, 30.0, 3.0, 100.0], 2) == (0, [0, 0])
+    assert choose_act_shift([5.0, 0.4, 30.0, 0.01, 100.0], 2) == (0, [0, 0])              # small tensors are left alone
+    assert choose_act_shift([5.0, 3000.0, 30.0, 1.0, 100.0], 2) == (-5, [-5, -5])          # one large tensor moves the tower
+    assert choose_act_shift([900.0, 9.0, 30.0, 3.0, 100.0], 2) == (-3, [-3, -3])
+    sx, sm = choose_act_shift([1e-3, 1e-3, 2e-3, 1e-2, 1e-3], 2)                           # a tiny tower moves up as a whole
+    assert sx == sm[0] == sm[1] == 13 and 64.0 <= 1e-2 * 2.0 ** sx <= 128.0
 
 
 def test_reference_forward_f64_is_the_module_in_float64_on_the_cpu():
