@@ -157,13 +157,16 @@ class CChessPlayer:
         if self.debugging and labels and visits[-1] > 0 and not senv.done(end_state)[0]:
             leaf_v = None
             if visits[-1] == 1:
-                # visited once = expanded and evaluated once: the edge's W is exactly minus that evaluation (the value
-                # the network gave with the history planes of the path it was first reached by) -- no forward, no
-                # re-encoding, and equal to what the reference kept in self.debug[state]
+                # visited once AND nothing selected from the end node yet = that visit expanded and evaluated it: the edge's W is
+                # exactly minus that evaluation (the value the network gave with the history planes of the path it was
+                # first reached by) -- no forward, no re-encoding, and equal to what the reference kept in self.debug[state].
+                # (A once-visited edge into a node that another path created, or into a repeated position, carries a
+                #  deeper value or a rule value instead -- ADVICE r03: those fall through to the evaluation below.)
                 st = self._search.node_stats(labels[:-1]) if len(labels) > 1 else self._search.root_stats()
                 c = int(st["counts"][0])
                 hit = np.nonzero(st["moves"][0, :c] == labels[-1])[0]
-                if len(hit) and int(st["n"][0, hit[0]]) == 1:
+                end = self._search.node_stats(labels)
+                if len(hit) and int(st["n"][0, hit[0]]) == 1 and int(end["counts"][0]) > 0 and int(end["sum_n"][0]) == 0:
                     leaf_v = -float(st["w"][0, hit[0]])
             if leaf_v is None:
                 # (simulations in flight through this edge, K > 1: evaluate the position; a history model gets the

@@ -155,31 +155,41 @@ class SelfPlayWorker:
             self.engine = None
 
 
-def free_port():
-    """A free TCP port on the loopback interface for the rendezvous of the ranks spawned here."""
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
+def rendezvous_file():
+    """A fresh file for the FileStore rendezvous of the ranks spawned here.  (A TCP port found free and then closed can
+    be taken by another process before the ranks bind it -- ADVICE r03; a file in a private temporary directory cannot.)"""
+    import tempfile
+    d = tempfile.mkdtemp(prefix="czero_rdzv_")
+    return os.path.join(d, "store")
 
 
-def _rank_main(rank, world, config, port):
+def _rank_main(rank, world, config, store_path):
     import torch
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     devices = [int(x) for x in str(config.opts.device_list).split(",")]
     torch.cuda.set_device(devices[rank] if rank < len(devices) else rank)
     if world > 1 or os.environ.get("CZ_FORCE_DIST") == "1":
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port or free_port()}", rank=rank,
+        dist.init_process_group("nccl", init_method=f"file://{store_path or rendezvous_file()}", rank=rank,
                                 world_size=world)
     model, _ = load_model(config)
     SelfPlayWorker(config, rank=rank, world=world, model=model).start()
 
 
+def launched_by_torchrun():
+    """True when a launcher set up a rendezvous for this process: torch.distributed.run / torchrun (TORCHELASTIC_RUN_ID), or
+    RANK + WORLD_SIZE + MASTER_PORT by hand.  A scheduler that merely exports RANK / WORLD_SIZE (no MASTER_PORT) does not
+    count: init_process_group could not rendezvous, and the run used to go single-process -- it still does."""
+    import torch.distributed as dist
+    if not ("WORLD_SIZE" in os.environ and "RANK" in os.environ):
+        return False
+    return dist.is_torchelastic_launched() or "MASTER_PORT" in os.environ
+
+
 def start(config):
     """Entry point of ``run.py self`` (reference :48-60)."""
     import torch
-    if "WORLD_SIZE" in os.environ and "RANK" in os.environ:                   # launched by torchrun (any world size)
+    if launched_by_torchrun():                                                # (any world size)
         import torch.distributed as dist
         rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
@@ -190,6 +200,5 @@ def start(config):
     devices = str(config.opts.device_list).split(",")
     if len(devices) > 1:
         import torch.multiprocessing as mp
-        port = free_port()
-        return mp.spawn(_rank_main, args=(len(devices), config, port), nprocs=len(devices), join=True)
-    return _rank_main(0, 1, config, 0)
+        return mp.spawn(_rank_main, args=(len(devices), config, rendezvous_file()), nprocs=len(devices), join=True)
+    return _rank_main(0, 1, config, None)

@@ -28,8 +28,10 @@ namespace xq {
 
 struct NoiseRng {
     uint32_t a, b, i;
-    // key of one draw: a from (seed, game, epoch) -- uniform over the wave's lanes, the compiler keeps it on the scalar
-    // unit -- and b from (a, slot, move)
+    // key of one draw: TWO independently mixed words (a, a1) from (seed, game, epoch) -- uniform over the wave's lanes, the
+    // compiler keeps them on the scalar unit -- and b from (a1, slot, move).  mix() is a bijection, so two (game, epoch)
+    // pairs share a stream only when both words collide: a 64-bit key.  (Round 3 derived b from a: ~4e7 (game, epoch) keys
+    // per run on a 32-bit word meant ~1e5 pairs of root batches with bit-identical noise rows -- ADVICE r03.)
     static XQ_HD uint32_t mix(uint32_t x)
     {
         x ^= x >> 17; x *= 0xed5ad4bbu;
@@ -42,8 +44,16 @@ struct NoiseRng {
     {
         const uint32_t t = mix(game_key * 0x9E3779B1u + (uint32_t)seed);
         const uint32_t a = mix(t ^ (epoch * 0x85EBCA77u + (uint32_t)(seed >> 32)));
-        const uint32_t b = mix(a + ((sim << 8) | move) * 0xC2B2AE3Du + 0x27D4EB2Fu);
+        const uint32_t t1 = mix(game_key * 0xB5297A4Du + ((uint32_t)(seed >> 32) ^ 0x68E31DA4u));
+        const uint32_t a1 = mix(t1 ^ (epoch * 0x1B56C4E9u + (uint32_t)seed));
+        const uint32_t b = mix(a1 + ((sim << 8) | move) * 0xC2B2AE3Du + 0x27D4EB2Fu);
         return NoiseRng{a, b, 0u};
+    }
+    // the two key words of a (seed, game, epoch) triple (tests: no two triples may share both)
+    static XQ_HD uint64_t key64(uint64_t seed, uint32_t game_key, uint32_t epoch)
+    {
+        const NoiseRng r = make(seed, game_key, epoch, 0u, 0u);
+        return ((uint64_t)r.a << 32) | r.b;
     }
     XQ_HD uint32_t bits()
     {

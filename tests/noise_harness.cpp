@@ -34,6 +34,12 @@ void noise_first_uniforms(uint64_t seed, uint32_t game_key, uint32_t epoch, floa
         }
 }
 
+// the 64-bit stream key of n (game, epoch) pairs: game = i % n_games, epoch = i / n_games
+void noise_keys(uint64_t seed, int n_games, uint64_t* out, int n)
+{
+    for (int i = 0; i < n; ++i) out[i] = NoiseRng::key64(seed, (uint32_t)(i % n_games), (uint32_t)(i / n_games));
+}
+
 int noise_uniforms_used(uint64_t seed, uint32_t game_key, double alpha, int nm, int n, double* mean_out)
 {
     long long used = 0;

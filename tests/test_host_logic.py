@@ -342,3 +342,33 @@ def test_reference_forward_f64_is_the_module_in_float64_on_the_cpu():
     n128 = CChessNet(cnn_filter_num=128, res_layer_num=3).eval()
     for req, name in (("c8", "c8"), ("c8>2", "c8>2"), ("c8>3", "c8"), ("c8>0", "f16x3"), ("f16x3", "f16x3"), ("bf16x3", "bf16x3")):
         assert InferenceNet(n128, torch.float32, trunk="mfma", arith=req).arith_name == name, req
+
+
+def test_self_play_rank_rendezvous(monkeypatch):
+    """worker/self_play.py: ranks spawned by `run.py self` meet through a FileStore in a private temporary directory (no
+    port to lose between finding and binding it); the torchrun branch is taken only when a launcher really set up a
+    rendezvous (RANK + WORLD_SIZE without MASTER_PORT used to make init_process_group fail)."""
+    import torch.distributed as dist
+    from cchess_alphazero.worker import self_play as sp
+    a, b = sp.rendezvous_file(), sp.rendezvous_file()
+    assert a != b and os.path.isdir(os.path.dirname(a)) and not os.path.exists(a)
+    for k in ("RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        monkeypatch.delenv(k, raising=False)
+    assert not sp.launched_by_torchrun()
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    assert not sp.launched_by_torchrun()                      # a scheduler's variables alone: single-process run
+    monkeypatch.setenv("MASTER_PORT", "29511")
+    assert sp.launched_by_torchrun()
+    monkeypatch.delenv("MASTER_PORT")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "x")
+    assert sp.launched_by_torchrun() == dist.is_torchelastic_launched()
+    # two processes do rendezvous through such a file (gloo here; nccl on the GPUs)
+    import subprocess
+    import sys
+    store = sp.rendezvous_file()
+    code = ("import sys, torch, torch.distributed as d; r = int(sys.argv[1]); "
+            f"d.init_process_group('gloo', init_method='file://{store}', rank=r, world_size=2); "
+            "t = torch.tensor([r + 1]); d.all_reduce(t); print(int(t)); d.destroy_process_group()")
+    ps = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, text=True) for r in range(2)]
+    assert [p.communicate(timeout=120)[0].strip().splitlines()[-1] for p in ps] == ["3", "3"]

@@ -95,3 +95,22 @@ def test_cost_in_uniforms(harness):
     mean = C.c_double()
     worst = harness.noise_uniforms_used(9, 9, 0.2, 44, 20000, C.byref(mean))
     assert 5.0 <= mean.value < 5.6 and worst < 40, (mean.value, worst)
+
+
+def test_stream_keys_are_64_bit(harness):
+    """a self-play run addresses ~4e7 (game, epoch) root batches; with a 32-bit key ~1e5 pairs of them would draw
+    bit-identical noise rows (birthday bound).  The key is two independently mixed words: over 2e6 (game, epoch) pairs of a
+    4096-game run the first word alone DOES collide, the pair never."""
+    n = 2_000_000
+    keys = np.zeros(n, dtype=np.uint64)
+    harness.noise_keys.argtypes = [C.c_uint64, C.c_int, C.c_void_p, C.c_int]
+    harness.noise_keys(20260923, 4096, keys.ctypes.data_as(C.c_void_p), n)
+    assert len(np.unique(keys)) == n
+    first_word = (keys >> np.uint64(32)).astype(np.uint32)
+    assert len(np.unique(first_word)) < n                    # ~470 expected collisions at 2e6 keys on 32 bits
+    # and two triples that differ only in the seed's high word, or only in the game, get different streams
+    a = np.zeros(8, dtype=np.float32)
+    b = np.zeros(8, dtype=np.float32)
+    harness.noise_uniforms(1, 7, 3, 2, 11, a.ctypes.data_as(C.c_void_p), 8)
+    harness.noise_uniforms(1 + (1 << 32), 7, 3, 2, 11, b.ctypes.data_as(C.c_void_p), 8)
+    assert not np.array_equal(a, b)
