@@ -745,6 +745,9 @@ struct FirstArgs {
     int w1_rounds;                 // term rounds done in the first window (under K loop 1), the rest under K loop 2
 };
 
+#ifndef CZ_FIRST_PRIO
+#define CZ_FIRST_PRIO 3     // issue priority of the copy waves while they compute the fused input layer (matrix waves: 3 in K loops)
+#endif
 namespace rb8 {
 constexpr int C = 128, RB = 256, ZROW = 96, PART = (ZROW + 16) * RB, REGION = 2 * PART;
 constexpr int SROW = 512, S_BYTES = 90 * SROW;
@@ -1030,9 +1033,11 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
             asm volatile("" : "+v"(ct2));                      // keep address arithmetic inside the loop (registers)
             if (FIRST) {
                 if (has_next) {                                // first part of the next board's input layer, under K loop 1
+                    __builtin_amdgcn_s_setprio(CZ_FIRST_PRIO);
                     first_begin();                             // (board tn: its planes were fetched a window ago)
                     if (tn + stride < n_boards) planes_prefetch(tn + stride);
                     first_rounds(fa.w1_rounds);
+                    __builtin_amdgcn_s_setprio(0);
                 }
             } else if (has_next) {
                 tile_load<_Float16, C, 1, 2, CTHR>(xh, reinterpret_cast<const _Float16*>(xc), tn, n_boards, ct2, v);
@@ -1044,9 +1049,11 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
             RB_STAMP(20);
             if (has_next) {
                 if (FIRST) {
+                    __builtin_amdgcn_s_setprio(CZ_FIRST_PRIO);
                     first_rounds(25 * 32);
                     RB_STAMP(21);
                     first_end();
+                    __builtin_amdgcn_s_setprio(0);
                 }
                 RB_STAMP(22);
                 write_x(ct2);

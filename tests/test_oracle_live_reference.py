@@ -59,6 +59,19 @@ def test_arena_games_match_the_reference_evaluator_on_fresh_specs():
     assert run_check("arena", 707, 3) == 3
 
 
+def test_one_small_search_threads_8_search_matches_the_unmodified_reference():
+    """the deferred terminal / repetition backup order of the canonical K > 1 schedule is pinned live by the opt-in
+    test below only.  This is its smallest case in the DEFAULT run -- one fresh position, search_threads = 8, 120
+    simulations, the reference's own thread timing, two runs -- under a hard timeout: the reference's threaded search
+    needs 2 s or minutes for the same position (its sender thread holds the queue lock, SURVEY C-12), so a timeout is an
+    expected failure, a mismatch is a real one."""
+    try:
+        n = run_check("kgt1", 909, 1, 8, 120, 2, timeout=240)
+    except subprocess.TimeoutExpired:
+        pytest.xfail("the unmodified reference's threaded search did not finish within 240 s (erratic by construction)")
+    assert n == 1
+
+
 @pytest.mark.skipif(os.environ.get("CZ_LIVE_KGT1") != "1",
                     reason="opt-in (CZ_LIVE_KGT1=1): the unmodified reference's threaded search takes 2 s or 3 minutes for the "
                            "same position, depending on how its sender thread happens to hold the queue lock (SURVEY C-12)")
