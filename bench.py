@@ -938,10 +938,11 @@ def main():
             flops_launch = 2 * 2.0 * 90 * f * f * 9 * rows_launch
             tfl = flops_launch / (b_ms * 1e-3) / 1e12
             pmc = pmc_nn("k_resblock")
-            kdesc = ("k_resblock<C8> (csrc/xq_conv.hip): one residual block (2 x conv3x3 + bias + skip + ReLU) of the tower "
-                     "per launch; every product = one fp16 MFMA term + two block-scaled fp8 (e4m3, K = 64) correction terms, "
-                     "fp32 accumulate; the last launch also applies the fused head convolutions; mean over all launches of "
-                     "the tower" if arith == "c8" else
+            kdesc = ("k_resblock_c8 (csrc/xq_conv.hip, K loop csrc/xq_c8_kloop.h): one residual block (2 x conv3x3 + bias + skip + "
+                     "ReLU) of the tower per launch; every product = one fp16 MFMA term + two block-scaled fp8 (e4m3, K = 64) "
+                     "correction terms, fp32 accumulate; the first launch also computes the 5x5 input layer (fp32 gather by its "
+                     "copy waves), the last one the fused head convolutions; mean over all launches of the tower"
+                     if arith == "c8" else
                      "k_resblock_pipe / k_resblock (csrc/xq_conv.hip): one residual block (2 x conv3x3 + "
                      "bias + skip + ReLU) of the tower per launch, split-bf16 operands; the first "
                      "launch also computes the 5x5 input layer (fp32 gather by its copy waves), the "
@@ -963,8 +964,10 @@ def main():
                                        "fp16 MFMA + two fp8 MFMAs at twice the rate = 2.0; bf16x3: 3.0) over 96 pixel slots "
                                        "per 90-pixel board, hence issued_bf16_tflops = that x 96/90 x achieved; against the "
                                        "fp32 matrix peak (157.3 TFLOP/s) the same number is > 1; the chip runs this kernel at "
-                                       "its 1.4 kW power cap at ~1.84 GHz (profiles/r03_clock_power.json), not the 2.4 GHz "
-                                       "the nominal peak assumes"}
+                                       "its 1.4 kW power cap (profiles/r03_clock_power*.json), not the 2.4 GHz the nominal peak "
+                                       "assumes: in shader cycles the c8 K loop runs at 88 % of its MFMA floor (15.7 k cycles per "
+                                       "13.8 k of matrix work, profiles/r04_c8_kloop_probe.log), the clock it is granted is "
+                                       "1.5-1.8 GHz (in-kernel cycle stamps: profiles/r04_rb_stamps.json)"}
         else:
             out["roofline"] = out.get("roofline_search")
         if sus is not None:

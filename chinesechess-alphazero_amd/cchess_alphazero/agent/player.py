@@ -157,16 +157,19 @@ class CChessPlayer:
         if self.debugging and labels and visits[-1] > 0 and not senv.done(end_state)[0]:
             leaf_v = None
             if visits[-1] == 1:
-                # visited once AND nothing selected from the end node yet = that visit expanded and evaluated it: the edge's W is
-                # exactly minus that evaluation (the value the network gave with the history planes of the path it was
-                # first reached by) -- no forward, no re-encoding, and equal to what the reference kept in self.debug[state].
-                # (A once-visited edge into a node that another path created, or into a repeated position, carries a
-                #  deeper value or a rule value instead -- ADVICE r03: those fall through to the evaluation below.)
+                # visited once = (almost always) expanded and evaluated by that visit: the edge's W is exactly minus that
+                # evaluation (the value the network gave with the history planes of the path it was first reached by) -- no
+                # forward, no re-encoding, and equal to what the reference kept in self.debug[state]: the recorded reference
+                # scores of tests/golden/uci_k1.json are reproduced this way, history models included.
+                # Known limit: when the end node had been created through ANOTHER path before this edge's
+                # single visit, that visit descended further and W holds the deeper value, where the reference prints the
+                # end node's own network value.  The tree does not record which edge created a node, and the obvious
+                # proxies reject valid lines (requiring "nothing selected from the end node yet" breaks two of the recorded
+                # reference cases: a later transposition into the node is indistinguishable).  Debug / info line only.
                 st = self._search.node_stats(labels[:-1]) if len(labels) > 1 else self._search.root_stats()
                 c = int(st["counts"][0])
                 hit = np.nonzero(st["moves"][0, :c] == labels[-1])[0]
-                end = self._search.node_stats(labels)
-                if len(hit) and int(st["n"][0, hit[0]]) == 1 and int(end["counts"][0]) > 0 and int(end["sum_n"][0]) == 0:
+                if len(hit) and int(st["n"][0, hit[0]]) == 1:
                     leaf_v = -float(st["w"][0, hit[0]])
             if leaf_v is None:
                 # (simulations in flight through this edge, K > 1: evaluate the position; a history model gets the

@@ -36,11 +36,19 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-constexpr int C = 128, RB = 2 * C, CPR = RB / 16, SWZ = 15, KK = C / 16, NB = C / 64, CT = C / 32;
 constexpr int W_PAD_STEPS = 3;
-constexpr int MAIN_U4 = (9 * KK + W_PAD_STEPS) * CT * 64;          // uint4 of the fp16 fragments of a packed filter
-constexpr int C8_U4 = (9 * NB + 1) * 2 * CT * 2 * 64;              // ... of its e4m3 fragments (one zero block appended)
 constexpr int X_LO_SHIFT = 11;
+// geometry of a tower of CH filters (128: 256-byte pixel rows, 16 chunks swizzled by the row's low four bits; 192: 384-byte
+// rows, 24 chunks, swizzled inside aligned groups of eight so that the XOR stays inside the row)
+template <int CH> struct Geo {
+    static constexpr int C = CH, RB = 2 * CH, CPR = RB / 16, KK = CH / 16, NB = CH / 64, CT = CH / 32;
+    static constexpr bool POW2 = (RB & (RB - 1)) == 0;
+    static constexpr int SWZ = POW2 ? 15 : 7;
+    static constexpr int MAIN_U4 = (9 * KK + W_PAD_STEPS) * CT * 64;      // uint4 of the fp16 fragments of a packed filter
+    static constexpr int C8_U4 = (9 * NB + 1) * 2 * CT * 2 * 64;          // ... of its e4m3 fragments (one zero block appended)
+    static_assert(CH % 64 == 0 && KK % 4 == 0 && (3 * KK) % 3 == 0 && (POW2 || CPR % 8 == 0), "128 / 192 filters");
+};
+constexpr int C = 128, MAIN_U4 = Geo<128>::MAIN_U4, C8_U4 = Geo<128>::C8_U4;       // (the 128-filter tower's, for its callers)
 
 // where an image sits in LDS: byte offsets of its first pixel row and of the 16 all-zero rows inside a part, and the
 // distance between the fp16 part and the c8 part
@@ -59,8 +67,10 @@ struct Filter {
     int scale_w_hi, scale_w_lo;      // E8M0 scale bytes of the two correction MFMAs (127 - shift)
 };
 
+template <int CH = 128>
 __device__ __forceinline__ Filter make_filter(const void* packed, int wave, int lane)
 {
+    constexpr int MAIN_U4 = Geo<CH>::MAIN_U4, C8_U4 = Geo<CH>::C8_U4;
     Filter f;
     f.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(packed), 0, (MAIN_U4 + C8_U4 + 1) * 16, 0x00020000);
     f.lane_main = wave * 1024 + lane * 16;
@@ -82,10 +92,12 @@ struct NoShadow {
 // bit 1 = no LDS reads inside the loop -- timing experiments with wrong results.
 // ZERO_INIT = false: the caller has put the accumulators' start values into acc (bias, bias + skip connection): the
 // products are added on top, so the epilogue that follows has no additions left to do.
-template <int NT, typename Shadow = NoShadow, int PROBE = 0, bool ZERO_INIT = true>
+template <int NT, typename Shadow = NoShadow, int PROBE = 0, bool ZERO_INIT = true, int CH = 128>
 __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img, const Filter& flt, int lane, f32x16* acc,
                                       int scale_x_lo, int scale_x, Shadow&& shadow = NoShadow())
 {
+    typedef Geo<CH> G;
+    constexpr int RB = G::RB, CPR = G::CPR, SWZ = G::SWZ, KK = G::KK, NB = G::NB, CT = G::CT;
     const int kb = lane >> 5, ln = lane & 31;
     int qy[3], qx[3];
 #pragma unroll
@@ -103,19 +115,24 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
         return row * RB + (((kb ^ nominal) & SWZ) << 4);
     };
     const int lane_c = (kb * 3) << 4;
+    // fp16 fragment of K-step kk: chunk 2 kk + kb of the row, swizzled; pre_p already holds the lane's (kb ^ row) bits
     auto load_px = [&](int pre_p, int kk) {
-        return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(lds + (pre_p ^ (kk << 5))));
+        const int off = G::POW2 ? pre_p ^ (kk << 5) : (pre_p ^ ((kk & 3) << 5)) + ((kk >> 2) << 7);
+        return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(lds + off));
     };
-    // c8 piece h of (kind q, block b): chunk q * CPR/2 + 4 b + 2 kb + h of the row
+    // c8 piece h of (kind q, block b): chunk c0 + 2 kb of the row, c0 = q * CPR/2 + 4 b + h (bit 1 of c0 is never set)
     auto load_c8 = [&](i32x8& d, int pre_p, int q, int b, int h) {
-        const uint4 t = *reinterpret_cast<const uint4*>(lds + img.part_bytes + (pre_p ^ lane_c ^ ((q * (CPR / 2) + 4 * b + h) << 4)));
+        const int c0 = q * (CPR / 2) + 4 * b + h;
+        const int off = G::POW2 ? pre_p ^ lane_c ^ (c0 << 4) : (pre_p ^ lane_c ^ ((c0 & 7) << 4)) + ((c0 >> 3) << 7);
+        const uint4 t = *reinterpret_cast<const uint4*>(lds + img.part_bytes + off);
         d[4 * h + 0] = t.x; d[4 * h + 1] = t.y; d[4 * h + 2] = t.z; d[4 * h + 3] = t.w;
     };
-    auto load_w = [&](int step_soff) {                 // fp16 fragment of K-step `step` (soffset = step * 4096, wave-uniform)
+    constexpr int STEP_B = CT * 1024, BLK_B = 2 * CT * 2048;     // bytes of a K-step of fp16 fragments / of a block's c8 pieces
+    auto load_w = [&](int step_soff) {                 // fp16 fragment of K-step `step` (soffset = step * STEP_B, wave-uniform)
         return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(flt.rsrc, flt.lane_main, step_soff, 0));
     };
-    auto load_wc = [&](i32x8& d, int blk_soff, int q, int h) {      // blk_soff = blk * 16384 (one block = 2 kinds x 4 waves x 2 KB)
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(flt.rsrc, flt.lane_c8 + h * 1024, blk_soff + q * 8192, 0);
+    auto load_wc = [&](i32x8& d, int blk_soff, int q, int h) {      // blk_soff = blk * BLK_B (one block = 2 kinds x CT waves x 2 KB)
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(flt.rsrc, flt.lane_c8 + h * 1024, blk_soff + q * (BLK_B / 2), 0);
         d[4 * h + 0] = (int)t.x; d[4 * h + 1] = (int)t.y; d[4 * h + 2] = (int)t.z; d[4 * h + 3] = (int)t.w;
     };
 
@@ -133,7 +150,7 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
 #pragma unroll
     for (int p = 0; p < NT; ++p) pre[p] = tap_row(-1, -1, p);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wf[s] = load_w(s * 4096);
+    for (int s = 0; s < 4; ++s) wf[s] = load_w(s * STEP_B);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         load_wc(wcr[q], 0, q, 0);
@@ -151,7 +168,7 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
 
 #pragma unroll 1
     for (int j = 0; j < 3; ++j) {                       // taps 3 j .. 3 j + 2 (dy = j - 1)
-        const int soff_j = j * (3 * KK * 4096), boff_j = j * (3 * NB * 16384);
+        const int soff_j = j * (3 * KK * STEP_B), boff_j = j * (3 * NB * BLK_B);
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt) {
             const int tap3 = tt;                         // tap inside the iteration
@@ -179,7 +196,7 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
                             if (i == 0 && !(PROBE & 1)) {
                                 const int q = 1 - half;                        // kind used in the PREVIOUS fp8 group
                                 const int blk_next = tap3 * NB + b + (half == 0 ? 0 : 1);     // its next block (half 0: kind 1 of b - 1 -> b)
-                                load_wc(wcr[q], boff_j + blk_next * 16384, q, k2);
+                                load_wc(wcr[q], boff_j + blk_next * BLK_B, q, k2);
                             }
                             __builtin_amdgcn_sched_barrier(0);
                         }
@@ -205,7 +222,7 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
                         // the fp16 filter fragments of the two K-steps just retired, one block ahead (their ring slots are free)
                         if (i < 2 && !(PROBE & 1)) {
                             const int kk = b * 4 + half * 2 + i;
-                            wf[kk & 3] = load_w(soff_j + (tap3 * KK + kk + 4) * 4096);
+                            wf[kk & 3] = load_w(soff_j + (tap3 * KK + kk + 4) * STEP_B);
                         }
                         // the next tap's rows: one per fp8 slot of the tap's first block (needed from K-step 6 on)
                         if (b == 0 && half == 0) pre_n[i] = tap_row(ndy, ndx, i);

@@ -414,7 +414,7 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_conv3x3_c8(
         zero_rows_write<C, P, 2>(lds, tid);
     }
     __syncthreads();
-    static_assert(C == c8k::C && cf8::Pack<C>::MAIN_U4 == c8k::MAIN_U4 && cf8::Pack<C>::C8_U4 == c8k::C8_U4, "packed layout");
+    static_assert(cf8::Pack<C>::MAIN_U4 == c8k::Geo<C>::MAIN_U4 && cf8::Pack<C>::C8_U4 == c8k::Geo<C>::C8_U4, "packed layout");
     // The accumulators start at bias (+ the skip operand, hi + lo8 * 2^-11): the products are added on top and the epilogue
     // has only the ReLU and the split left.  Same order in k_resblock_c8, so the two stay bit-identical.
     const int kb = lane >> 5, ln = lane & 31;
@@ -437,8 +437,8 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_conv3x3_c8(
             for (int i = 0; i < 4; ++i) acc[p][g * 4 + i] = v[i];
         }
     }
-    c8k::kloop<NT, c8k::NoShadow, 0, false>(lds, c8k::Image{0, G::ZROW, G::PART_BYTES}, c8k::make_filter(wp, wave, lane), lane,
-                                            acc, 127 - cf8::X_LO_SHIFT, 127);
+    c8k::kloop<NT, c8k::NoShadow, 0, false, C>(lds, c8k::Image{0, G::ZROW, G::PART_BYTES}, c8k::make_filter<C>(wp, wave, lane),
+                                               lane, acc, 127 - cf8::X_LO_SHIFT, 127);
 #pragma unroll
     for (int p = 0; p < NT; ++p) {
         const int q = (p % 3) * 32 + ln;
@@ -1827,6 +1827,198 @@ __global__ __launch_bounds__((C / 32) * 64 + ip::COPY_THREADS, 1) void k_resbloc
     }
 }
 
+// ---- kernel 2c / c8: the two-image residual block on the c8 arithmetic (192 filters; round 4) --------------------------------
+// k_resblock_ip's roles, images and barriers (X | Y | 16 shared zero rows; six matrix waves + two copy waves; the second
+// epilogue in place over X; the copy waves drain X to HBM and refill it at barrier C) with c8k::kloop<..., 192> -- 384-byte
+// pixel rows [f16 x 192] / [lo8 x 192 | e4m3(x) x 192], swizzled inside aligned groups of eight chunks, three 64-channel
+// blocks per tap -- and k_resblock_c8's arithmetic: accumulators start at bias (K loop 1) / bias + skip (K loop 2, read from
+// X by the owning lane), the epilogues only apply ReLU and split.  2.0 instead of 3.0 MFMA-equivalents per product for the
+// reference's deployed 10 x 192 topology (configs/distribute.py:84-87).  Bit-identical to two cz_conv3x3_c8 launches.
+template <int C>
+__global__ __launch_bounds__((C / 32) * 64 + ip::COPY_THREADS, 1) void k_resblock_ip_c8(
+    const _Float16* __restrict__ xh, const unsigned char* __restrict__ xc, const void* __restrict__ w1p,
+    const float* __restrict__ b1, const void* __restrict__ w2p, const float* __restrict__ b2, _Float16* __restrict__ yh,
+    unsigned char* __restrict__ yc, float* __restrict__ yf, int n_boards, const int32_t* __restrict__ n_dev)
+{
+    typedef Geom<C, 1, 2> G;
+    constexpr int RB = G::RB, CPR = G::CPR, CT = G::CT, NT = 3;
+    constexpr int PSTR = ip::ROWS * RB;                         // bytes per operand part
+    constexpr int BIAS_OFF = 2 * PSTR;
+    constexpr int CTHR = ip::COPY_THREADS, CHUNKS = 90 * CPR, LITER = (CHUNKS + CTHR - 1) / CTHR;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BIAS_OFF + 2 * C * 4];
+    static_assert(sizeof(lds) <= 160 * 1024, "two images + zero rows must fit the CU's LDS");
+    if (n_dev) {
+        const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
+        n_boards = nd < n_boards ? nd : n_boards;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int stride = gridDim.x;
+    int t = blockIdx.x;
+    if (t >= n_boards) return;
+    auto chunk_off = [&](int i) {                               // chunk i of a board (row i / CPR, chunk i % CPR) in the X image
+        const int row = i / CPR, ch = i - row * CPR;
+        return row * RB + ((ch & ~G::SWZ) << 4) + (((ch ^ row) & G::SWZ) << 4);
+    };
+
+    if (wave >= CT) {                                           // ---- copy waves ----
+        const int ctid = tid - CT * 64;
+        uint4 v[2][LITER];
+        auto fetch = [&](int board) {
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const uint4* src = part ? reinterpret_cast<const uint4*>(xc + (size_t)board * 90 * 2 * C)
+                                        : reinterpret_cast<const uint4*>(xh + (size_t)board * 90 * C);
+#pragma unroll
+                for (int it = 0; it < LITER; ++it) {
+                    const int i = it * CTHR + ctid;
+                    v[part][it] = make_uint4(0, 0, 0, 0);
+                    if ((it + 1) * CTHR <= CHUNKS || i < CHUNKS) v[part][it] = src[i];
+                }
+            }
+        };
+        auto put = [&]() {
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+#pragma unroll
+                for (int it = 0; it < LITER; ++it) {
+                    const int i = it * CTHR + ctid;
+                    if ((it + 1) * CTHR <= CHUNKS || i < CHUNKS)
+                        *reinterpret_cast<uint4*>(lds + part * PSTR + chunk_off(i)) = v[part][it];
+                }
+        };
+        auto drain = [&](int board, bool refill) {
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                uint4* dst = part ? reinterpret_cast<uint4*>(yc + (size_t)board * 90 * 2 * C)
+                                  : reinterpret_cast<uint4*>(yh + (size_t)board * 90 * C);
+#pragma unroll
+                for (int it = 0; it < LITER; ++it) {
+                    const int i = it * CTHR + ctid;
+                    if (!((it + 1) * CTHR <= CHUNKS || i < CHUNKS)) continue;
+                    unsigned char* a = lds + part * PSTR + chunk_off(i);
+                    if (!yf) dst[i] = *reinterpret_cast<const uint4*>(a);
+                    if (refill) *reinterpret_cast<uint4*>(a) = v[part][it];
+                }
+            }
+        };
+        fetch(t);
+        put();
+        for (int i = ctid; i < 16 * CPR; i += CTHR) {           // the shared zero rows, both parts
+            *reinterpret_cast<uint4*>(lds + ip::ROW_Z * RB + i * 16) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(lds + PSTR + ip::ROW_Z * RB + i * 16) = make_uint4(0, 0, 0, 0);
+        }
+        for (int i = ctid; i < C; i += CTHR) {
+            reinterpret_cast<float*>(lds + BIAS_OFF)[i] = b1[i];
+            reinterpret_cast<float*>(lds + BIAS_OFF)[C + i] = b2[i];
+        }
+        for (;;) {
+            __syncthreads();                                    // A: X holds board t
+            const int tn = t + stride;
+            const bool has_next = tn < n_boards;
+            if (has_next) fetch(tn);
+            __syncthreads();                                    // B: Y complete
+            __syncthreads();                                    // C: the result is in X
+            drain(t, has_next);
+            if (!has_next) break;
+            t = tn;
+        }
+        return;
+    }
+
+    // ---- matrix waves ----
+    const int kb = lane >> 5, ln = lane & 31;
+    const c8k::Filter flt1 = c8k::make_filter<C>(w1p, wave, lane), flt2 = c8k::make_filter<C>(w2p, wave, lane);
+    const float* bias1 = reinterpret_cast<const float*>(lds + BIAS_OFF);
+    const float* bias2 = bias1 + C;
+    // offsets of this lane's four channels ch .. ch + 3 of pixel row `row` (image-relative key for the swizzle): the f16 quad,
+    // its lo8 word, its e4m3(x) word
+    auto offs = [&](int row_abs, int key, int ch, int& off, int& off_lo, int& off_hi) {
+        const int c_f = ch >> 3, c_lo = ch >> 4, c_hi = CPR / 2 + (ch >> 4);
+        off = row_abs * RB + ((c_f & ~G::SWZ) << 4) + (((c_f ^ key) & G::SWZ) << 4) + (ch & 7) * 2;
+        off_lo = PSTR + row_abs * RB + ((c_lo & ~G::SWZ) << 4) + (((c_lo ^ key) & G::SWZ) << 4) + (ch & 15);
+        off_hi = PSTR + row_abs * RB + ((c_hi & ~G::SWZ) << 4) + (((c_hi ^ key) & G::SWZ) << 4) + (ch & 15);
+    };
+    for (;;) {
+        __syncthreads();                                        // A
+        const bool has_next = t + stride < n_boards;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias1 + wave * 32 + g * 8 + kb * 4);
+#pragma unroll
+            for (int p = 0; p < NT; ++p) {
+                acc[p][g * 4 + 0] = bv.x; acc[p][g * 4 + 1] = bv.y; acc[p][g * 4 + 2] = bv.z; acc[p][g * 4 + 3] = bv.w;
+            }
+        }
+        __builtin_amdgcn_s_setprio(3);
+        c8k::kloop<NT, c8k::NoShadow, 0, false, C>(lds, c8k::Image{0, ip::ROW_Z, PSTR}, flt1, lane, acc, 127 - cf8::X_LO_SHIFT, 127);
+        __builtin_amdgcn_s_setprio(0);
+        int ln2 = ln, kb2 = kb;
+        asm volatile("" : "+v"(ln2), "+v"(kb2));
+        // epilogue 1: relu(acc) -> c8 triple -> Y; the freed accumulators restart at b2 + skip (this lane's own elements of X)
+#pragma unroll
+        for (int p = 0; p < NT; ++p) {
+            const int q = p * 32 + ln2;
+            const int row = q < 90 ? q : 89;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = wave * 32 + g * 8 + kb2 * 4;
+                int ox, oxl, oxh, oy, oyl, oyh;
+                offs(row, row, ch, ox, oxl, oxh);
+                offs(ip::ROW_Y + row, row, ch, oy, oyl, oyh);
+                float r[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] = acc[p][g * 4 + i] > 0.0f ? acc[p][g * 4 + i] : 0.0f;
+                const cf8::Split4 o = cf8::split4(r);
+                if (q < 90) {
+                    *reinterpret_cast<Quad<_Float16>*>(lds + oy) = o.hi;
+                    *reinterpret_cast<uint32_t*>(lds + oyl) = o.l8;
+                    *reinterpret_cast<uint32_t*>(lds + oyh) = o.h8;
+                }
+                const float4 bv = *reinterpret_cast<const float4*>(bias2 + ch);
+                float vv[4] = {bv.x, bv.y, bv.z, bv.w};
+                cf8::add_pair4(vv, *reinterpret_cast<const Quad<_Float16>*>(lds + ox), *reinterpret_cast<const uint32_t*>(lds + oxl));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[p][g * 4 + i] = vv[i];
+            }
+        }
+        __syncthreads();                                        // B: Y complete
+        __builtin_amdgcn_s_setprio(3);
+        c8k::kloop<NT, c8k::NoShadow, 0, false, C>(lds, c8k::Image{ip::ROW_Y, ip::ROW_Z, PSTR}, flt2, lane, acc,
+                                                   127 - cf8::X_LO_SHIFT, 127);
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("" : "+v"(ln2), "+v"(kb2));
+        // epilogue 2: relu(acc) -> the c8 triple in place over the skip operand (each lane writes only its own bytes of X), or
+        // fp32 straight to HBM for the last block of a tower
+#pragma unroll
+        for (int p = 0; p < NT; ++p) {
+            const int q = p * 32 + ln2;
+            if (q < 90) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = wave * 32 + g * 8 + kb2 * 4;
+                    float r[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] = acc[p][g * 4 + i] > 0.0f ? acc[p][g * 4 + i] : 0.0f;
+                    if (yf) {
+                        *reinterpret_cast<float4*>(yf + ((size_t)t * 90 + q) * C + ch) = make_float4(r[0], r[1], r[2], r[3]);
+                    } else {
+                        int ox, oxl, oxh;
+                        offs(q, q, ch, ox, oxl, oxh);
+                        const cf8::Split4 o = cf8::split4(r);
+                        *reinterpret_cast<Quad<_Float16>*>(lds + ox) = o.hi;
+                        *reinterpret_cast<uint32_t*>(lds + oxl) = o.l8;
+                        *reinterpret_cast<uint32_t*>(lds + oxh) = o.h8;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                        // C: the result is in X
+        if (!has_next) break;
+        t += stride;
+    }
+}
+
 // ---- kernel 3: the input convolution (5x5, 14 or 28 feature planes -> C channels) ----------------------------------
 // Reference: Conv2D(F, 5, padding="same") -> BatchNorm -> ReLU on the state_to_planes input (agent/model.py:36-39).
 // The planes arrive exactly as the search kernel writes them ([in_planes][10][9] per board, values 0 / 1, any of
@@ -2192,7 +2384,7 @@ inline int pow2_shift_for(float amax, int top)                     // s with ama
 
 extern "C" size_t cz_conv3x3_c8_packed_bytes(int channels)
 {
-    if (channels != 128) return 0;
+    if (channels != 128 && channels != 192) return 0;
     const size_t C = channels, KK = C / 16, CT = C / 32, NB = C / 64;
     const size_t main_u4 = (9 * KK + W_PAD_STEPS) * CT * 64, c8_u4 = (9 * NB + 1) * 2 * CT * 2 * 64;
     return (main_u4 + c8_u4 + 1) * 16;
@@ -2200,8 +2392,8 @@ extern "C" size_t cz_conv3x3_c8_packed_bytes(int channels)
 
 extern "C" int cz_conv3x3_c8_pack_weights(const float* w_oihw, int channels, void* out_host)
 {
-    if (!w_oihw || !out_host || channels != 128) {
-        czi_set_error("cz_conv3x3_c8_pack_weights: bad argument (128 filters)");
+    if (!w_oihw || !out_host || (channels != 128 && channels != 192)) {
+        czi_set_error("cz_conv3x3_c8_pack_weights: bad argument (128 or 192 filters)");
         return CZ_ERR_ARG;
     }
     const int C = channels, KK = C / 16, CT = C / 32, NB = C / 64;
@@ -2246,17 +2438,24 @@ extern "C" int cz_conv3x3_c8(const void* x_hi, const void* x_c8, const void* w_p
                              const void* skip_hi, const void* skip_c8, void* y_hi, void* y_c8, float* y_f32,
                              int n_boards, int channels, int relu, void* stream)
 {
-    if (n_boards < 0 || !x_hi || !x_c8 || !w_packed || !bias || channels != 128 || (!y_f32 && (!y_hi || !y_c8)) ||
-        (skip_hi && !skip_c8)) {
-        czi_set_error("cz_conv3x3_c8: bad argument (128 filters; output: y_f32, or the operand pair y_hi + y_c8)");
+    if (n_boards < 0 || !x_hi || !x_c8 || !w_packed || !bias || (channels != 128 && channels != 192) ||
+        (!y_f32 && (!y_hi || !y_c8)) || (skip_hi && !skip_c8)) {
+        czi_set_error("cz_conv3x3_c8: bad argument (128 or 192 filters; output: y_f32, or the operand pair y_hi + y_c8)");
         return CZ_ERR_ARG;
     }
     if (n_boards == 0) return CZ_OK;
-    constexpr int P = 2;
-    hipLaunchKernelGGL((k_conv3x3_c8<128, P>), dim3((unsigned)((n_boards + P - 1) / P)), dim3(128 / 32 * 64), 0,
-                       (hipStream_t)stream, (const _Float16*)x_hi, (const unsigned char*)x_c8, (const uint4*)w_packed, bias,
-                       (const _Float16*)skip_hi, (const unsigned char*)skip_c8, (_Float16*)y_hi, (unsigned char*)y_c8,
-                       y_f32, n_boards, relu);
+    if (channels == 128) {
+        constexpr int P = 2;
+        hipLaunchKernelGGL((k_conv3x3_c8<128, P>), dim3((unsigned)((n_boards + P - 1) / P)), dim3(128 / 32 * 64), 0,
+                           (hipStream_t)stream, (const _Float16*)x_hi, (const unsigned char*)x_c8, (const uint4*)w_packed, bias,
+                           (const _Float16*)skip_hi, (const unsigned char*)skip_c8, (_Float16*)y_hi, (unsigned char*)y_c8,
+                           y_f32, n_boards, relu);
+    } else {
+        hipLaunchKernelGGL((k_conv3x3_c8<192, 1>), dim3((unsigned)n_boards), dim3(192 / 32 * 64), 0,
+                           (hipStream_t)stream, (const _Float16*)x_hi, (const unsigned char*)x_c8, (const uint4*)w_packed, bias,
+                           (const _Float16*)skip_hi, (const unsigned char*)skip_c8, (_Float16*)y_hi, (unsigned char*)y_c8,
+                           y_f32, n_boards, relu);
+    }
     if (hipGetLastError() != hipSuccess) {
         czi_set_error("cz_conv3x3_c8: launch failed");
         return CZ_ERR_HIP;
@@ -2546,6 +2745,13 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
     else if (dtype == CZ_F16C8 && channels == 128 && parts == 2)
         rc = launch_resblock_c8<false, false>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo, y_f32, n_boards,
                                               n_cu, st, HeadArgs{}, g_q.n_dev, FirstArgs{});
+    else if (dtype == CZ_F16C8 && channels == 192 && parts == 2) {
+        const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
+        hipLaunchKernelGGL((k_resblock_ip_c8<192>), dim3(blocks), dim3(192 / 32 * 64 + ip::COPY_THREADS), 0, st,
+                           (const _Float16*)x_hi, (const unsigned char*)x_lo, w1_packed, bias1, w2_packed, bias2,
+                           (_Float16*)y_hi, (unsigned char*)y_lo, y_f32, n_boards, g_q.n_dev);
+        rc = hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
+    }
     if (rc == CZ_ERR_ARG)
         czi_set_error("cz_resblock: supported: 128 / 192 filters (split or plain operands), 256 filters (plain), bf16 / f16; "
                       "use cz_conv3x3 otherwise");

@@ -109,7 +109,7 @@ def main():
             bench = json.loads(open(os.path.join(a.src, "stats.json")).read().strip().splitlines()[-1])
         except Exception:
             pass
-        lines = [f"# rocprofv3 --kernel-trace --stats of `bench.py` (normal config, split-bf16 network), round {a.round}",
+        lines = [f"# rocprofv3 --kernel-trace --stats of `bench.py` (normal config, default tower arithmetic), round {a.round}",
                  "",
                  "Command (GPU box): `cd /tmp && export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv "
                  "-d gpurun_out/prof/stats -o s -- python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-micro "
@@ -205,7 +205,8 @@ def main():
             d["hbm_bytes_per_launch"] = (2 * fk[k]["FETCH_SIZE"] + wk[k]["WRITE_SIZE"]) * 1024.0
         nn[k] = d
     if nn:
-        out = {"workload": "bench.py normal config: 32768 boards per launch, 7x128 network, split-bf16 operands",
+        out = {"workload": "bench.py normal config: 32768 boards per launch, 7x128 network, default tower arithmetic (c8: "
+                           "k_resblock covers the k_resblock_c8 launches -- plain, fused input layer, fused heads)",
                "method": "rocprofv3 --pmc passes of tools/collect_profiles.sh (SQ set, GRBM_GUI_ACTIVE, FETCH_SIZE, "
                          "WRITE_SIZE: one run each); means per launch, first 2 launches of each kernel excluded",
                "mfma_util_definition": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs)",
