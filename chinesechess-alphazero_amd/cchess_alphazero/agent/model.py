@@ -111,8 +111,9 @@ class InferenceNet(nn.Module):
       "f16x3"   the same three MFMAs on (hi, lo) fp16 pairs: 22 bits per operand, ~8x more accurate on networks whose
                 activations and folded filters sit in fp16's range (round 4; tools/f16x3_probe.py: the matrix unit honours
                 fp16 subnormals, which the filters' lo parts are), less accurate than bf16x3 when they are tiny;
-      "c8"      (128 filters) an fp16 main term plus two block-scaled fp8 correction terms (csrc/xq_conv.hip,
-                k_resblock<C8>): one fp16 and two fp8 matrix instructions per 64 input channels, 2^-16 per product;
+      "c8"      (128 / 192 filters) an fp16 main term plus two block-scaled fp8 correction terms (csrc/xq_conv.hip,
+                k_resblock_c8 / k_resblock_ip_c8): one fp16 and two fp8 matrix instructions per 64 input channels, 2^-16
+                per product;
       "c8>N"    the first N residual blocks on c8, the rest on f16x3 (error ~ sqrt(N): the guard's middle ground).
     None of the reduced forms is trusted blindly: guarded_inference_net() below measures the candidate against float64 on
     calibration positions when weights are loaded and falls back along c8 -> c8>N -> f16x3 -> bf16x3."""
@@ -135,8 +136,8 @@ class InferenceNet(nn.Module):
         if arith.startswith("c8"):
             c8_blocks = int(arith[3:]) if arith.startswith("c8>") else nblk
             assert 0 <= c8_blocks <= nblk, arith
-            if not (trunk == "mfma" and dtype == torch.float32 and net.cfg["cnn_filter_num"] == 128):
-                c8_blocks = 0               # the c8 arithmetic exists for the 128-filter split tower only
+            if not (trunk == "mfma" and dtype == torch.float32 and net.cfg["cnn_filter_num"] in (128, 192)):
+                c8_blocks = 0               # the c8 arithmetic exists for the 128- and 192-filter split towers
             arith = "c8" if c8_blocks else "f16x3"
         assert arith in ("bf16x3", "f16x3", "c8"), arith
         if arith == "f16x3" and not (trunk == "mfma" and dtype == torch.float32):

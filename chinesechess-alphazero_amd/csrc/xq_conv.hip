@@ -2592,16 +2592,22 @@ extern "C" int cz_input_conv(const void* planes, int planes_dtype, int in_planes
     else if (dtype == CZ_F16)
         rc = dispatch_input_conv_pt<_Float16>(planes_dtype, channels, planes, in_planes, w_packed, bias, y_hi, y_lo,
                                               n_boards, parts, relu, st);
-    else if (dtype == CZ_F16C8 && channels == 128 && parts == 2 && (planes_dtype == CZ_U8 || planes_dtype == CZ_F32)) {
+    else if (dtype == CZ_F16C8 && (channels == 128 || channels == 192) && parts == 2 &&
+             (planes_dtype == CZ_U8 || planes_dtype == CZ_F32)) {
         // f16-split filters (cz_input_conv_pack_weights with CZ_F16), output = the c8 operand pair (y_lo = the c8 image)
         constexpr int P = 2;
         const unsigned blocks = (unsigned)((n_boards + P - 1) / P);
-#define CZ_IC8(PT, IC16)                                                                                             \
-        hipLaunchKernelGGL((k_input_conv<_Float16, PT, 128, IC16, P, 2, true>), dim3(blocks), dim3(128 / 32 * 64), 0, st, \
+#define CZ_IC8(CH, PT, IC16)                                                                                          \
+        hipLaunchKernelGGL((k_input_conv<_Float16, PT, CH, IC16, P, 2, true>), dim3(blocks), dim3(CH / 32 * 64), 0, st,   \
                            (const PT*)planes, (const _Float16*)w_packed, bias, (_Float16*)y_hi, (_Float16*)y_lo, n_boards,    \
                            in_planes, relu, g_q.rows, g_q.n_dev)
-        if (planes_dtype == CZ_U8) { if (in_planes <= 16) CZ_IC8(unsigned char, 1); else CZ_IC8(unsigned char, 2); }
-        else { if (in_planes <= 16) CZ_IC8(float, 1); else CZ_IC8(float, 2); }
+#define CZ_IC8C(CH)                                                                                                   \
+        do {                                                                                                          \
+            if (planes_dtype == CZ_U8) { if (in_planes <= 16) CZ_IC8(CH, unsigned char, 1); else CZ_IC8(CH, unsigned char, 2); } \
+            else { if (in_planes <= 16) CZ_IC8(CH, float, 1); else CZ_IC8(CH, float, 2); }                              \
+        } while (0)
+        if (channels == 128) CZ_IC8C(128); else CZ_IC8C(192);
+#undef CZ_IC8C
 #undef CZ_IC8
         rc = hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
     }

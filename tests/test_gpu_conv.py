@@ -115,8 +115,9 @@ def test_resblock_equals_two_convolutions(c, dt, parts, n):
     assert all(torch.equal(a, b) for a, b in zip(xi, want))
 
 
+@pytest.mark.parametrize("c", [128, 192])
 @pytest.mark.parametrize("n", [1, 2, 5, 301])
-def test_conv3x3_c8_matches_its_operands_and_the_float64_convolution(n):
+def test_conv3x3_c8_matches_its_operands_and_the_float64_convolution(n, c):
     """cz_conv3x3_c8 (the c8 tower arithmetic: one fp16 and two scaled-fp8 matrix instructions per 64 input
     channels).  (1) Against float64 arithmetic on EXACTLY the operand values the kernel is given (decoded fragments and
     images): only the instructions' accumulation differs -- bounded by 1e-5 of the sum of |terms| of an output (the fp8
@@ -127,7 +128,6 @@ def test_conv3x3_c8_matches_its_operands_and_the_float64_convolution(n):
     import torch.nn.functional as F
     from cchess_alphazero import _native
     from test_c8_pack_cpu import decode_c8_pack
-    c = 128
     g = torch.Generator(device="cuda").manual_seed(40 + n)
     x = (torch.randn((n, 90, c), device="cuda", generator=g) * 1.5).relu()
     x[0, 0, :4] = torch.tensor([300.0, 2e-3, 5e-5, 0.0], device="cuda")           # large / tiny activations
@@ -141,7 +141,7 @@ def test_conv3x3_c8_matches_its_operands_and_the_float64_convolution(n):
     d = torch.float64
     img = lambda t: t.to(d).view(n, 10, 9, c).permute(0, 3, 1, 2)
     conv = lambda a, ww: F.conv2d(a, ww, None, padding=1).permute(0, 2, 3, 1).reshape(n, 90, c)
-    w_hi, k0, k1, sh, sl = decode_c8_pack(packed)
+    w_hi, k0, k1, sh, sl = decode_c8_pack(packed, c)
     tw = lambda a: torch.from_numpy(a).to("cuda", d).view(c, c, 3, 3)
     l8 = x_c8[..., :c].contiguous().view(torch.float8_e4m3fn).to(d)
     h8 = x_c8[..., c:].contiguous().view(torch.float8_e4m3fn).to(d)
@@ -166,17 +166,18 @@ def test_conv3x3_c8_matches_its_operands_and_the_float64_convolution(n):
     assert torch.equal(out2, out.relu())
 
 
-@pytest.mark.parametrize("blocks", [7, 2, 1])
-def test_network_with_c8_tower_matches_fp32_module(blocks):
+@pytest.mark.parametrize("filters,blocks", [(128, 7), (128, 2), (128, 1), (192, 10), (192, 2)])
+def test_network_with_c8_tower_matches_fp32_module(filters, blocks):
     """The whole policy / value network with the c8 tower arithmetic (InferenceNet(arith="c8"): fp16 main term +
     two scaled-fp8 correction terms per product; reference architecture agent/model.py:32-83) against the plain PyTorch
     fp32 module on the CPU: the north_star tolerance (policy / value within 1e-4), the logit and relative bounds of the
-    split-bf16 test, and agreement with the split-bf16 network itself."""
+    split-bf16 test, and agreement with the split-bf16 network itself.  (192, 10) is the reference's deployed topology
+    (configs/distribute.py:84-87) on k_resblock_ip_c8."""
     import torch
     from cchess_alphazero.agent.model import CChessNet, InferenceNet
     import oracle.xq_oracle as xo
     torch.manual_seed(11)
-    net = CChessNet(cnn_filter_num=128, res_layer_num=blocks)
+    net = CChessNet(cnn_filter_num=filters, res_layer_num=blocks)
     for m in net.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
             m.running_mean.normal_(0, 0.3)
@@ -262,13 +263,13 @@ def test_conv3x3_c8_operand_pair_output_and_skip(n):
     assert ((back - v).abs() <= torch.maximum(v.abs() * 2.0 ** -15, torch.tensor(2.0 ** -20, device="cuda"))).all()
 
 
+@pytest.mark.parametrize("c", [128, 192])
 @pytest.mark.parametrize("n", [1, 3, 257, 700])
-def test_resblock_c8_equals_two_c8_convolutions(n):
-    """cz_resblock with the c8 arithmetic (dtype CZ_F16C8: k_resblock<..., C8>) is bit-identical to two
-    cz_conv3x3_c8 launches: pair output, fp32 output, in place, device-side count."""
+def test_resblock_c8_equals_two_c8_convolutions(n, c):
+    """cz_resblock with the c8 arithmetic (dtype CZ_F16C8: k_resblock_c8 for 128 filters, k_resblock_ip_c8 for 192) is
+    bit-identical to two cz_conv3x3_c8 launches: pair output, fp32 output, in place, device-side count."""
     import torch
     from cchess_alphazero import _native
-    c = 128
     g = torch.Generator(device="cuda").manual_seed(90 + n)
     x = torch.randn((n, 90, c), device="cuda", generator=g).relu()
     ws = [torch.randn((c, c, 3, 3), device="cuda", generator=g) / (3.0 * c ** 0.5) for _ in range(2)]
@@ -296,6 +297,8 @@ def test_resblock_c8_equals_two_c8_convolutions(n):
         _native.resblock(xs, ps[0], bs[0], ps[1], bs[1], out=y, count=torch.tensor([cnt], dtype=torch.int32, device="cuda"))
         assert torch.equal(y[0][:cnt], want[0][:cnt]) and torch.equal(y[1][:cnt], want[1][:cnt])
         assert (y[0][cnt:] == 7.0).all() and (y[1][cnt:] == 7).all()
+    if c != 128:
+        return
     # the fused head convolutions on this arithmetic: the same block, then the 1x1 convolutions of its fp32 output
     hw = torch.randn((6, c), device="cuda", generator=g) / c ** 0.5
     hb = torch.randn((6,), device="cuda", generator=g)

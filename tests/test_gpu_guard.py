@@ -118,9 +118,11 @@ def test_guard_keeps_the_requested_arithmetic_where_it_is_exact_enough():
     # guard off: exactly what was asked for, nothing measured
     g0 = guarded_inference_net(net, torch.float32, trunk="mfma", arith="c8", guard=False)
     assert g0.arith_effective == "c8" and g0.calibration is None
-    # other filter counts have no c8: the request degrades to the fp16 pairs
-    g1 = guarded_inference_net(CChessNet(cnn_filter_num=192, res_layer_num=2).eval(), torch.float32, trunk="mfma", arith="c8")
+    # 256 filters have no c8: the request degrades to the fp16 pairs (192 filters: c8 since round 4)
+    g1 = guarded_inference_net(CChessNet(cnn_filter_num=256, res_layer_num=2).eval(), torch.float32, trunk="mfma", arith="c8")
     assert g1.arith_effective == "f16x3"
+    g2 = guarded_inference_net(CChessNet(cnn_filter_num=192, res_layer_num=2).eval(), torch.float32, trunk="mfma", arith="c8")
+    assert g2.arith_effective == "c8"
 
 
 def test_guard_moves_out_of_range_activations_into_the_operand_formats():

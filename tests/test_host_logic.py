@@ -221,15 +221,17 @@ def test_tower_arithmetic_selection_on_the_host(monkeypatch):
     assert InferenceNet(net, torch.float32, trunk="mfma").arith == "bf16x3"                 # explicit default of the class
     assert InferenceNet(net, torch.float32, trunk="library", arith="c8").arith == "bf16x3"  # no hand-written trunk
     assert InferenceNet(net, torch.float16, trunk="mfma", arith="c8").arith == "bf16x3"     # plain fp16 operands
-    # (192 filters have no c8 kernels: the request degrades to the fp16 pairs, the next more exact arithmetic)
-    assert InferenceNet(CChessNet(cnn_filter_num=192, res_layer_num=1), torch.float32, trunk="mfma", arith="c8").arith == "f16x3"
+    # (192 filters: c8 since round 4 -- k_resblock_ip_c8; 256 filters have no c8 kernels: the request degrades to the fp16 pairs)
+    assert InferenceNet(CChessNet(cnn_filter_num=192, res_layer_num=1), torch.float32, trunk="mfma", arith="c8").arith == "c8"
+    assert InferenceNet(CChessNet(cnn_filter_num=256, res_layer_num=1), torch.float32, trunk="mfma", arith="c8").arith == "f16x3"
     monkeypatch.setenv("CZ_TOWER_ARITH", "c8")
     assert InferenceNet(net, torch.float32, trunk="mfma").arith == "c8"
     monkeypatch.setenv("CZ_TOWER_ARITH", "bf16x3")
     assert InferenceNet(net, torch.float32, trunk="mfma").arith == "bf16x3"
-    assert _native.lib().cz_conv3x3_c8_packed_bytes(192) == 0
+    assert _native.lib().cz_conv3x3_c8_packed_bytes(192) == ((9 * 12 + 3) * 6 * 64 + (9 * 3 + 1) * 2 * 6 * 2 * 64 + 1) * 16
+    assert _native.lib().cz_conv3x3_c8_packed_bytes(256) == 0
     with pytest.raises(_native.NativeError):
-        _native.pack_conv3x3_c8_weights(torch.randn(192, 192, 3, 3))
+        _native.pack_conv3x3_c8_weights(torch.randn(256, 256, 3, 3))
 
 
 def test_uci_position_parsing_without_a_gpu():
