@@ -182,3 +182,26 @@ def test_hybrid_tower_runs_its_first_blocks_on_c8(n8):
     cnt = torch.tensor([40], dtype=torch.int32, device="cuda")
     pc, vc = h(planes, rows=rows, count=cnt)
     assert torch.equal(pc[:40], p.flip(0)[:40]) and torch.equal(vc[:40], v.flip(0)[:40])
+
+
+def test_hybrid_and_guard_on_the_192_filter_tower():
+    """The reference's deployed topology (10 x 192, configs/distribute.py:84-87) through the same machinery: c8 on
+    k_resblock_ip_c8, the hybrid hand-over (fp32 out of the last c8 block, re-split into fp16 pairs for k_resblock_ip), the
+    guard's choice on a peaked policy."""
+    import torch
+    from cchess_alphazero.agent.model import (InferenceNet, calibration_planes, guarded_inference_net,
+                                              measure_against_reference, reference_forward_f64)
+    net = peaked_net(60.0, blocks=4, filters=192)
+    planes = calibration_planes(64, 14, seed=21)
+    ref = reference_forward_f64(net, planes)
+    errs = {}
+    for arith in ("f16x3", "c8>2", "c8"):
+        inf = InferenceNet(net, torch.float32, trunk="mfma", arith=arith).cuda()
+        assert inf.arith_name == arith
+        errs[arith] = measure_against_reference(inf, ref, planes)["logit_max_abs"]
+    print("192 filters, logit error:", errs)
+    assert errs["f16x3"] < errs["c8>2"] * 1.5 + 1e-9 and errs["c8>2"] < errs["c8"] * 1.5 + 1e-9 and errs["f16x3"] < 0.3 * errs["c8"]
+    g = guarded_inference_net(net, torch.float32, trunk="mfma", arith="c8")
+    m = measure_against_reference(g, ref, planes)
+    print("guard on 192:", g.arith_effective, m)
+    assert m["policy_max_abs"] < 1e-4 and m["value_max_abs"] < 1e-4
