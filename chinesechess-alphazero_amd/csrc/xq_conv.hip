@@ -1035,7 +1035,9 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
                 if (has_next) {                                // first part of the next board's input layer, under K loop 1
                     __builtin_amdgcn_s_setprio(CZ_FIRST_PRIO);
                     first_begin();                             // (board tn: its planes were fetched a window ago)
+                    RB_STAMP(24);
                     if (tn + stride < n_boards) planes_prefetch(tn + stride);
+                    RB_STAMP(25);
                     first_rounds(fa.w1_rounds);
                     __builtin_amdgcn_s_setprio(0);
                 }

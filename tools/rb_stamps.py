@@ -56,6 +56,9 @@ def main():
         cw = {"wait_A": s[17] - s[16], "window_1_loads_or_gather": s[18] - s[17], "wait_B": s[19] - s[18],
               "store_previous_board": s[20] - s[19], "gather_rest": s[21] - s[20] if s[21] > s[20] else 0,
               "first_end_split": s[22] - max(s[21], s[20]), "write_X": s[23] - s[22]}
+        if s[24] > s[17]:                                  # FIRST: the first window in detail
+            cw["window_1_detail"] = {"first_begin_masks_and_tap_sets": s[24] - s[17], "planes_prefetch_issue": s[25] - s[24],
+                                     "term_rounds": s[18] - s[25]}
         us_per_board = ms * 1e3 / (n / 256.0)
         res[name] = {"ms_per_launch": ms, "us_per_board": us_per_board, "matrix_wave_cycles": m, "copy_wave_cycles": cw,
                      "cycles_stamped": sum(m.values()), "effective_GHz": sum(m.values()) / us_per_board / 1e3}
