@@ -878,7 +878,10 @@ def main():
                                 {"tol": eng.net.calibration["tol"], "positions": eng.net.calibration["positions"],
                                  "candidates": eng.net.calibration["candidates"],
                                  "tower_activation_max": max(eng.net.calibration["activation_max"]),
-                                 "c8_saturating_layers": eng.net.calibration["c8_saturating_layers"]}),
+                                 "act_shift": eng.net.calibration["act_shift"],
+                                 "c8_saturating_layers": eng.net.calibration["c8_saturating_layers"],
+                                 "c8_median_in_subnormals": eng.net.calibration["c8_median_in_subnormals"],
+                                 "activation_quantiles_scaled_1pct_50pct": eng.net.calibration["activation_quantiles_scaled"]}),
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{dict(mini=0, normal=1, eval=3, deep=4)[args.config]}] "
                                    f"'{args.config}': {G} concurrent games/GPU, "

@@ -492,7 +492,16 @@ def reference_forward_f64(net: CChessNet, planes, with_activations=False):
     dev = planes.device
     ref = copy.deepcopy(net).eval().double().to(dev)
     x = planes.double()
-    acts = []
+    acts, small = [], []
+
+    def note(t):                                    # range of a tower tensor: max |x|, and the nonzero values' quantiles
+        acts.append(float(t.abs().max()))
+        nz = t[t > 0]
+        if with_activations and nz.numel():
+            q = torch.quantile(nz.flatten()[:1 << 20].float(), torch.tensor([0.01, 0.5], device=t.device))
+            small.append([float(q[0]), float(q[1])])
+        else:
+            small.append([0.0, 0.0])
 
     def bn(m, t):
         scale = m.weight / torch.sqrt(m.running_var + m.eps)
@@ -505,12 +514,13 @@ def reference_forward_f64(net: CChessNet, planes, with_activations=False):
         return (m.weight.view(m.out_channels, -1) @ cols).view(n, m.out_channels, h, w)
 
     x = F.relu(bn(ref.input_bn, conv(ref.input_conv, x)))
-    acts.append(float(x.abs().max()))
+    note(x)
     for blk in ref.res:
         y = F.relu(bn(blk.bn1, conv(blk.conv1, x)))
-        acts.append(float(y.abs().max()))
+        note(y)
         x = F.relu(x + bn(blk.bn2, conv(blk.conv2, y)))
-        acts.append(float(x.abs().max()))
+        note(x)
+    reference_forward_f64.last_quantiles = small    # (1 % / 50 % quantiles of the nonzero activations, per tensor)
     p = F.relu(bn(ref.policy_bn, conv(ref.policy_conv, x)))
     logits = ref.policy_out(p.flatten(1))
     v = F.relu(bn(ref.value_bn, conv(ref.value_conv, x)))
@@ -609,6 +619,13 @@ def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", ari
         scaled = [a * 2.0 ** (smid[(i - 1) // 2] if i % 2 else sx) for i, a in enumerate(acts)]
         report["activation_max_scaled"] = scaled
         report["c8_saturating_layers_after_scaling"] = [i for i, a in enumerate(scaled) if a > 448.0]
+        # the other end of the c8 image's range: e4m3 is normal down to 2^-6, subnormal (fewer bits) to 2^-9, zero below.  Per
+        # tensor, after scaling: the 1 % and 50 % quantiles of the nonzero activations, and whether the MEDIAN sits in the
+        # subnormals (then half of the w_lo x corrections of that layer are coarse: reported, the measurement decides)
+        qs = getattr(reference_forward_f64, "last_quantiles", [])
+        sc = [2.0 ** (smid[(i - 1) // 2] if i % 2 else sx) for i in range(len(acts))]
+        report["activation_quantiles_scaled"] = [[q[0] * f, q[1] * f] for q, f in zip(qs, sc)]
+        report["c8_median_in_subnormals"] = [i for i, (q, f) in enumerate(zip(qs, sc)) if 0.0 < q[1] * f < 2.0 ** -6]
         chain = guard_chain(first.arith, first.c8_blocks, nblk, scaled)
         cand = first if shift is None else None
         for name in chain:
