@@ -374,3 +374,14 @@ def test_self_play_rank_rendezvous(monkeypatch):
             "t = torch.tensor([r + 1]); d.all_reduce(t); print(int(t)); d.destroy_process_group()")
     ps = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, text=True) for r in range(2)]
     assert [p.communicate(timeout=120)[0].strip().splitlines()[-1] for p in ps] == ["3", "3"]
+
+
+def test_bench_arithmetic_labels():
+    """bench.py: the dtype label and the matrix-pipe cost of a tower arithmetic name (what `dtype` / `roofline` in the line say)."""
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    import bench
+    assert bench.arith_label("c8") == "f16+2xfp8corr-split/f32acc" and bench.arith_label("f16x3") == "f16x3-split/f32acc"
+    assert "first 5 blocks" in bench.arith_label("c8>5") and bench.arith_label(None) is None
+    assert bench.arith_mfma_equivalents("c8", 7) == 2.0 and bench.arith_mfma_equivalents("bf16x3", 7) == 3.0
+    assert abs(bench.arith_mfma_equivalents("c8>5", 7) - (2.0 * 5 + 3.0 * 2) / 7) < 1e-12
+    assert bench.arith_mfma_equivalents("fp32-library", 7) == 1.0
