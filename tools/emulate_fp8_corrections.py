@@ -82,6 +82,34 @@ def conv_model(x, w, b, mode, pad):
         xh, wh = h(x), h(w)
         xl, wl = h(x - xh), h(w - wh)
         y = conv(xh, wh) + conv(xh, wl) + conv(xl, wh)
+    elif mode == "c8-ef":
+        # c8-kernel, but the e4m3 rounding of the filters' lo parts is chosen by ERROR DIFFUSION along the input channels,
+        # weighted by each channel's mean activation (what a calibration pass knows): the systematic part of the arithmetic's
+        # error -- sum_c (w_lo - e4m3(w_lo)) mean(x_c), the same for every position -- is driven to zero per output and tap
+        f8 = lambda t: t.clamp(-448.0, 448.0).to(torch.float32).to(torch.float8_e4m3fn).to(torch.float64)
+        xh = x.to(torch.float32).to(torch.float16).to(torch.float64)
+        wh = w.to(torch.float32).to(torch.float16).to(torch.float64)
+        xl8 = f8((x - xh) * 2048.0) / 2048.0
+        xh8 = f8(x)
+        sh = 2.0 ** (7 - torch.floor(torch.log2(w.abs().max())))
+        wl = w - wh
+        sl = 2.0 ** (7 - torch.floor(torch.log2(wl.abs().max().clamp_min(1e-300))))
+        mu = xh8.mean(dim=(0, 2, 3)).clamp_min(1e-12)                     # [c]
+        t = wl * sl                                                        # [o, c, k, k] in e4m3 units
+        near = f8(t)
+        # the neighbour on the other side of t on the e4m3 grid
+        ulp = torch.where(near.abs() >= 2.0 ** -6, torch.exp2(torch.floor(torch.log2(near.abs().clamp_min(2.0 ** -9))) - 3), torch.full_like(t, 2.0 ** -9))
+        other = f8(near + torch.sign(t - near + 1e-300) * ulp)
+        q = torch.empty_like(t)
+        r = torch.zeros_like(t[:, 0])                                      # running error per (o, k, k), weighted
+        order = torch.argsort(mu, descending=True)
+        for c in order.tolist():
+            e_near = r + (t[:, c] - near[:, c]) * mu[c]
+            e_other = r + (t[:, c] - other[:, c]) * mu[c]
+            pick_other = e_other.abs() < e_near.abs()
+            q[:, c] = torch.where(pick_other, other[:, c], near[:, c])
+            r = torch.where(pick_other, e_other, e_near)
+        y = conv(xh, wh) + conv(xl8, f8(w * sh) / sh) + conv(xh8, q / sl)
     elif mode == "c8-kernel":
         # exactly the kernels' operand model (csrc/xq_conv.hip): FIXED activation scales -- x_lo8 = e4m3(sat(x_lo * 2^11)),
         # x_hi8 = e4m3(sat(x)), saturation at +-448 -- and one power-of-two scale per filter tensor (largest magnitude
@@ -124,7 +152,7 @@ def stored(x, mode):
         if mode == "f16x3-ftz":
             lo = torch.where(lo.abs() < 2.0 ** -14, torch.zeros_like(lo), lo)
         return xh + lo
-    if mode == "c8-kernel":
+    if mode in ("c8-kernel", "c8-ef"):
         lo = ((x - xh) * 2048.0).clamp(-448.0, 448.0).to(torch.float32).to(torch.float8_e4m3fn).to(torch.float64)
         return xh + lo / 2048.0
     return xh + block_scaled(x - xh, 1, "e4m3" if mode == "f16+fp8" else "e2m3")
