@@ -232,19 +232,26 @@ int cz_conv3x3(const void* x_hi, const void* x_lo, const void* w_packed, const f
  * Same layouts and `parts` as cz_conv3x3; y_f32 != NULL (parts = 2 only) writes the fp32 result instead of
  * (y_hi, y_lo); y may alias x.  Supported: 128 filters (parts 1 or 2), 192 / 256 filters (parts 1); anything else returns
  * CZ_ERR_ARG (use two cz_conv3x3 calls).  Bit-identical to the two-call form.
- * dtype CZ_F16C8 (128 filters, parts = 2): the c8 arithmetic -- x_lo / y_lo are c8 images, the filters are
- * cz_conv3x3_c8_pack_weights' (see cz_conv3x3_c8 below); bit-identical to two cz_conv3x3_c8 calls.  cz_resblock_heads,
- * cz_input_conv (filters packed with CZ_F16, parts 2; u8 or fp32 planes) and the _q forms take the same code. */
+ * dtype CZ_F16C8 (128 or 192 filters, parts = 2): the c8 arithmetic -- x_lo / y_lo are c8 images, the filters are
+ * cz_conv3x3_c8_pack_weights' (see cz_conv3x3_c8 below); bit-identical to two cz_conv3x3_c8 calls (k_resblock_c8,
+ * k_resblock_ip_c8).  cz_input_conv (filters packed with CZ_F16, parts 2; u8 or fp32 planes) and the _q forms take the
+ * same code at both filter counts, cz_resblock_heads and cz_input_resblock at 128 filters.
+ * dtype CZ_F16 with parts = 2 ("f16x3": (hi, lo) fp16 pairs, 22 bits per operand) is the more exact sibling of the bf16
+ * pairs at the same cost; it needs activations and folded filters inside fp16's range. */
 int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1, const void* w2_packed,
                 const float* bias2, void* y_hi, void* y_lo, float* y_f32, int n_boards, int channels, int dtype,
                 int parts, void* stream);
-/* The c8 tower arithmetic (csrc/xq_conv.hip, k_conv3x3_c8 / k_resblock<C8>; the self-play default
- * since the end of round 3): one 3x3 convolution, 128 filters, computed as  f16(w) f16(x) + e4m3(w) e4m3(x - f16(x)) + e4m3(w - f16(w)) e4m3(x)  (one fp16 and two block-scaled
+/* The c8 tower arithmetic (csrc/xq_conv.hip, k_conv3x3_c8 / k_resblock_c8 / k_resblock_ip_c8, K loop csrc/xq_c8_kloop.h;
+ * DESIGN section 7b; what the self-play engine REQUESTS by default and keeps where its load-time check against float64
+ * allows -- a host binding these entry points directly owns that check): one 3x3 convolution, 128 or 192
+ * filters (the shapes below are for 128), computed as  f16(w) f16(x) + e4m3(w) e4m3(x - f16(x)) + e4m3(w - f16(w)) e4m3(x)  (one fp16 and two block-scaled
  * fp8 matrix instructions per 64 input channels instead of three bf16 ones).  x_hi: f16 [n][90][128]; x_c8: bytes
  * [n][90][256] = e4m3(x_lo * 2^11) for the 128 channels, then e4m3(x) for them; y = conv + bias (+ skip pair) (ReLU if
  * relu), written as fp32 (y_f32) or as the operand pair (y_hi, y_c8).
- * Reference arithmetic: Keras float32 (agent/model.py:32-83); per-product accuracy 2^-16 like the split-bf16 form, two
- * thirds of its matrix-pipe time.  Activations above 448 lose the w_lo x correction (e4m3 saturates). */
+ * The accumulators start at bias (+ the skip pair's value) and the products are added on top (round 4).
+ * Reference arithmetic: Keras float32 (agent/model.py:32-83); per-product accuracy ~2^-16 (the split-bf16 form: 2^-17; the
+ * fp16 pairs: 2^-21), two thirds of their matrix-pipe time.  Activations above 448 lose the w_lo x correction (e4m3
+ * saturates): scale the folded network by a power of two first (agent/model.py choose_act_shift). */
 size_t cz_conv3x3_c8_packed_bytes(int channels);
 int cz_conv3x3_c8_pack_weights(const float* w_oihw, int channels, void* out_host);
 int cz_conv3x3_c8(const void* x_hi, const void* x_c8, const void* w_packed, const float* bias,
@@ -262,7 +269,8 @@ int cz_resblock_heads(const void* x_hi, const void* x_lo, const void* w1_packed,
                       const void* w2_packed, const float* bias2, const float* head_w, const float* head_b,
                       float* policy_feat, float* value_feat, int n_boards, int channels, int dtype, int n_policy,
                       int n_value, void* stream);
-/* The input layer AND the first residual block in one launch (128 filters, split operands): the 5x5 input convolution
+/* The input layer AND the first residual block in one launch (128 filters; split operands, or dtype CZ_F16C8 with the c8
+ * pair as output and cz_conv3x3_c8_pack_weights filters: k_resblock_c8<FIRST>): the 5x5 input convolution
  * (Conv2D(F, 5, "same") -> BatchNorm -> ReLU, agent/model.py:36-39) of the one-hot feature planes is a gather over the
  * occupied squares, computed in exact fp32 by the block's copy waves while its matrix waves run the previous board.
  *   planes_u8   [n_boards][in_planes][90] uint8, 0 / 1 (what the search kernel writes; in_planes 14 or 28)
