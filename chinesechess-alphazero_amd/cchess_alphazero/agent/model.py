@@ -486,8 +486,9 @@ def calibration_planes(n=CALIBRATION_POSITIONS, input_depth=14, device=None, see
 @torch.no_grad()
 def reference_forward_f64(net: CChessNet, planes, with_activations=False):
     """The reference network (agent/model.py:32-83; BatchNorm in inference mode as Keras predict_on_batch runs it) in float64
-    on the device of `planes`: (policy [n, 2086], value [n], logits) and, on request, max |activation| of every tower
-    tensor (input layer, each block's intermediate and output)."""
+    on the device of `planes`: (policy [n, 2086], value [n], logits) and, on request, two more entries: max |activation|
+    of every tower tensor (input layer, each block's intermediate and output) and the [1 %, 50 %] quantiles of its nonzero
+    values."""
     import copy
     dev = planes.device
     ref = copy.deepcopy(net).eval().double().to(dev)
@@ -520,13 +521,13 @@ def reference_forward_f64(net: CChessNet, planes, with_activations=False):
         note(y)
         x = F.relu(x + bn(blk.bn2, conv(blk.conv2, y)))
         note(x)
-    reference_forward_f64.last_quantiles = small    # (1 % / 50 % quantiles of the nonzero activations, per tensor)
+
     p = F.relu(bn(ref.policy_bn, conv(ref.policy_conv, x)))
     logits = ref.policy_out(p.flatten(1))
     v = F.relu(bn(ref.value_bn, conv(ref.value_conv, x)))
     v = torch.tanh(ref.value_out(F.relu(ref.value_dense(v.flatten(1))))).squeeze(1)
     out = (F.softmax(logits, dim=1), v, logits)
-    return out + (acts,) if with_activations else out
+    return out + (acts, small) if with_activations else out
 
 
 def measure_against_reference(inf, ref_out, planes):
@@ -622,7 +623,7 @@ def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", ari
         # the other end of the c8 image's range: e4m3 is normal down to 2^-6, subnormal (fewer bits) to 2^-9, zero below.  Per
         # tensor, after scaling: the 1 % and 50 % quantiles of the nonzero activations, and whether the MEDIAN sits in the
         # subnormals (then half of the w_lo x corrections of that layer are coarse: reported, the measurement decides)
-        qs = getattr(reference_forward_f64, "last_quantiles", [])
+        qs = ref[4]
         sc = [2.0 ** (smid[(i - 1) // 2] if i % 2 else sx) for i in range(len(acts))]
         report["activation_quantiles_scaled"] = [[q[0] * f, q[1] * f] for q, f in zip(qs, sc)]
         report["c8_median_in_subnormals"] = [i for i, (q, f) in enumerate(zip(qs, sc)) if 0.0 < q[1] * f < 2.0 ** -6]

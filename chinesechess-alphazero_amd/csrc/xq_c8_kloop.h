@@ -20,14 +20,11 @@
 //   * the c8 PIXEL pieces of one kind only are live at a time (8 NT registers instead of 16 NT): the 2 NT pieces a half
 //     block's correction MFMAs need are read in the 2 NT fp16 slots right before them, tile 0 first (>= 128 cycles of
 //     lead each); the fp8 slots are left with the MFMA, the filter loads, the next tap's row arithmetic -- and room for a
-//     caller's shadow work (a residual block's second epilogue, k_resblock_pipe<C8>).
+//     caller's shadow work (k_resblock_c8's deferred second epilogue).  (Reading them in the fp8 slots of the other kind,
+//     one half block ahead, measured the same on the plain block and 12 % worse with shadow work in those slots.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-
-#ifndef C8K_JIT_CX
-#define C8K_JIT_CX 1       // 1: c8 pixel pieces read in the fp16 slots before their MFMAs (one kind live); 0: in the fp8 slots of
-#endif                     //    the other kind, one half block ahead (both kinds live, +8 NT registers) -- A/B builds only
 
 namespace c8k {
 
@@ -138,7 +135,7 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
 
     f16x8 wf[4];                                        // fp16 filter fragments, slot = K-step % 4
     f16x8 px[3][NT];                                    // pixel fragments, slot = K-step % 3 (24 K-steps per loop iteration)
-    i32x8 cx[C8K_JIT_CX ? 1 : 2][NT];                   // c8 pixel pieces (of the kind whose MFMAs come next)
+    i32x8 cx[NT];                                       // c8 pixel pieces of the kind whose MFMAs come next
     i32x8 wcr[2];                                       // c8 filter pieces by kind
     int pre[NT], pre_n[NT];
     if (ZERO_INIT) {
@@ -160,10 +157,6 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
     for (int p = 0; p < NT; ++p) {
         px[0][p] = load_px(pre[p], 0);
         px[1][p] = load_px(pre[p], 1);
-        if (!C8K_JIT_CX) {
-            load_c8(cx[0][p], pre[p], 0, 0, 0);
-            load_c8(cx[0][p], pre[p], 0, 0, 1);
-        }
     }
 
 #pragma unroll 1
@@ -190,7 +183,7 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
                                 px[(g + 2) % 3][i] = kn < KK ? load_px(pre[i], kn) : load_px(pre_n[i], kn - KK);
                                 // piece (k2 NT + i) of the 2 NT c8 pixel pieces of this half block's correction MFMAs
                                 const int s6 = k2 * NT + i;
-                                if (C8K_JIT_CX) load_c8(cx[0][s6 >> 1], pre[s6 >> 1], half, b, s6 & 1);
+                                load_c8(cx[s6 >> 1], pre[s6 >> 1], half, b, s6 & 1);
                             }
                             // the c8 filter pieces of the kind whose MFMAs have just issued, for its next block
                             if (i == 0 && !(PROBE & 1)) {
@@ -204,21 +197,9 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
                     // ---- correction term `half` of this block (K = 64)
 #pragma unroll
                     for (int i = 0; i < NT; ++i) {
-                        acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wcr[half], cx[C8K_JIT_CX ? 0 : half][i], acc[i], 0, 0, 0,
+                        acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wcr[half], cx[i], acc[i], 0, 0, 0,
                                                                                   half ? flt.scale_w_lo : flt.scale_w_hi, 0,
                                                                                   half ? scale_x : scale_x_lo);
-                        if (!C8K_JIT_CX && !(PROBE & 2)) {      // the OTHER kind's pieces for its next use
-                            if (half == 0) {
-                                load_c8(cx[1][i], pre[i], 1, b, 0);
-                                load_c8(cx[1][i], pre[i], 1, b, 1);
-                            } else if (b + 1 < NB) {
-                                load_c8(cx[0][i], pre[i], 0, b + 1, 0);
-                                load_c8(cx[0][i], pre[i], 0, b + 1, 1);
-                            } else {
-                                load_c8(cx[0][i], pre_n[i], 0, 0, 0);
-                                load_c8(cx[0][i], pre_n[i], 0, 0, 1);
-                            }
-                        }
                         // the fp16 filter fragments of the two K-steps just retired, one block ahead (their ring slots are free)
                         if (i < 2 && !(PROBE & 1)) {
                             const int kk = b * 4 + half * 2 + i;

@@ -67,7 +67,7 @@ def test_reference_forward_matches_the_module_in_float64():
     from cchess_alphazero.agent.model import calibration_planes, reference_forward_f64
     net = peaked_net(20.0, blocks=2)
     planes = calibration_planes(16, 14)
-    p, v, lg, acts = reference_forward_f64(net, planes, with_activations=True)
+    p, v, lg, acts, quants = reference_forward_f64(net, planes, with_activations=True)
     with torch.no_grad():
         pr, vr = copy.deepcopy(net).double()(planes.double().cpu())
     # (float64 on the device: rocBLAS GEMMs, 1e-9-class agreement with the CPU module on a peaked policy -- four orders below

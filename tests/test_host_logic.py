@@ -335,7 +335,7 @@ def test_reference_forward_f64_is_the_module_in_float64_on_the_cpu():
             m.running_mean.normal_(0, 0.3)
             m.running_var.uniform_(0.5, 2.0)
     planes = (torch.rand((5, 14, 10, 9)) < 0.07).to(torch.uint8)
-    p, v, lg, acts = reference_forward_f64(net, planes, with_activations=True)
+    p, v, lg, acts, quants = reference_forward_f64(net, planes, with_activations=True)
     with torch.no_grad():
         pr, vr = copy.deepcopy(net).double()(planes.double())
     assert (p - pr).abs().max().item() < 1e-13 and (v - vr).abs().max().item() < 1e-13 and len(acts) == 5
