@@ -385,3 +385,31 @@ def test_bench_arithmetic_labels():
     assert bench.arith_mfma_equivalents("c8", 7) == 2.0 and bench.arith_mfma_equivalents("bf16x3", 7) == 3.0
     assert abs(bench.arith_mfma_equivalents("c8>5", 7) - (2.0 * 5 + 3.0 * 2) / 7) < 1e-12
     assert bench.arith_mfma_equivalents("fp32-library", 7) == 1.0
+
+
+def test_activation_shift_is_an_exact_reparametrisation():
+    """InferenceNet(act_shift=(s_x, [s_mid ...])): power-of-two scales of the residual stream and of every block's
+    intermediate tensor folded into filters and biases (agent/model.py; ReLU commutes with a positive scale) -- the
+    network function is unchanged.  Checked on the CPU through the library trunk, whose folded convolutions are the ones the
+    hand-written kernels pack."""
+    import torch
+    from cchess_alphazero.agent.model import CChessNet, InferenceNet
+    torch.manual_seed(8)
+    net = CChessNet(cnn_filter_num=32, res_layer_num=3).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.normal_(1, 0.2)
+            m.bias.data.normal_(0, 0.2)
+    x = (torch.rand((6, 14, 10, 9)) < 0.08).float()
+    p0, v0 = InferenceNet(net, torch.float32, trunk="library")(x)
+    for shift in ((-5, [3, -2, 0]), (7, [7, 7, 7]), (0, [0, 0, 0])):
+        inf = InferenceNet(net, torch.float32, trunk="library", act_shift=shift)
+        assert (inf.act_shift is None) == (shift == (0, [0, 0, 0]))
+        p, v = inf(x)
+        assert (p - p0).abs().max().item() < 1e-6 and (v - v0).abs().max().item() < 1e-6, shift
+        # the tower really runs at the shifted scale: its first tensor is 2^s_x times the unshifted one
+        a0 = torch.relu(InferenceNet(net, torch.float32, trunk="library").input_conv(x))
+        a1 = torch.relu(inf.input_conv(x))
+        assert torch.allclose(a1, a0 * 2.0 ** shift[0], rtol=1e-6, atol=1e-9)
