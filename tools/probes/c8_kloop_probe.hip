@@ -189,6 +189,42 @@ __global__ __launch_bounds__(256, WGS) void k_probe_r4(const uint4* __restrict__
     if (blockIdx.x == 7 && tid == 0) cycles[0] = clock64() - t0;
 }
 
+// ---- what two boards per filter fragment would buy: the same loop over SIX pixel tiles (two boards in one image; one
+// workgroup of four waves per CU, 512 registers: the shape k_conv3x3_c8 runs) ----
+constexpr int ZROW2 = 192, PART2 = (ZROW2 + 16) * RB, REGION2 = 2 * PART2;
+__global__ __launch_bounds__(256, 1) void k_probe_r4_nt6(const uint4* __restrict__ packed, const uint4* __restrict__ image,
+                                                          float* __restrict__ out, int convs, long long* __restrict__ cycles)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[REGION2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // two copies of the one-board image (rows 0..89 and 90..179 of each part), zero rows at 192
+    for (int i = tid; i < REGION2 / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    for (int part = 0; part < 2; ++part)
+        for (int i = tid; i < 90 * 16; i += 256) {
+            const uint4 v = image[part * (PART_BYTES / 16) + i];
+            reinterpret_cast<uint4*>(lds + part * PART2)[i] = v;
+            reinterpret_cast<uint4*>(lds + part * PART2)[90 * 16 + i] = v;
+        }
+    __syncthreads();
+    const c8k::Filter flt = c8k::make_filter(packed, wave, lane);
+    const c8k::Image img{0, ZROW2, PART2};
+    c8k::f32x16 acc[6];
+    float s = 0.0f;
+    const long long t0 = clock64();
+    for (int conv = 0; conv < convs; ++conv) {
+        c8k::kloop<6>(lds, img, flt, lane, acc, 127 - 11, 127);
+        if (conv + 1 == convs) {
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[p][r];
+        }
+    }
+    out[blockIdx.x * 256 + tid] = s;
+    if (blockIdx.x == 7 && tid == 0) cycles[0] = clock64() - t0;
+}
+
 static uint32_t rnd_state = 7;
 static uint32_t rnd() { rnd_state = rnd_state * 1664525u + 1013904223u; return rnd_state >> 8; }
 
@@ -239,7 +275,7 @@ int main(int argc, char** argv)
         CK(hipMemcpy(dpk, pk.data(), pk.size(), hipMemcpyHostToDevice));
         long long* dcyc;
         CK(hipMalloc(&dcyc, 8));
-        for (int var = 0; var < 5; ++var) {
+        for (int var = 0; var < 6; ++var) {
             const int wgs = var == 1 ? 2 : 1;      // variants: 1 WG, 2 WGs, no filter loads, no LDS reads, neither
             auto go = [&](int convs) {
                 hipEvent_t e0, e1;
@@ -249,7 +285,8 @@ int main(int argc, char** argv)
                 else if (var == 1) hipLaunchKernelGGL((k_probe_r4<2, 0>), dim3(2 * blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
                 else if (var == 2) hipLaunchKernelGGL((k_probe_r4<1, 1>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
                 else if (var == 3) hipLaunchKernelGGL((k_probe_r4<1, 2>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
-                else hipLaunchKernelGGL((k_probe_r4<1, 3>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
+                else if (var == 4) hipLaunchKernelGGL((k_probe_r4<1, 3>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
+                else hipLaunchKernelGGL(k_probe_r4_nt6, dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
                 float ms = 0.0f;
@@ -263,8 +300,9 @@ int main(int argc, char** argv)
             for (int i = 0; i < (int)(seconds / 0.5) + 1; ++i) last = go(chunk);
             long long cyc = 0;
             CK(hipMemcpy(&cyc, dcyc, 8, hipMemcpyDeviceToHost));
-            const char* what[5] = {"as in the product", "2 workgroups per CU", "no filter loads in the loop", "no LDS reads in the loop",
-                                   "no loads at all in the loop"};
+            const char* what[6] = {"as in the product", "2 workgroups per CU", "no filter loads in the loop", "no LDS reads in the loop",
+                                   "no loads at all in the loop",
+                                   "six pixel tiles = TWO boards per filter fragment (halve the figures for one board)"};
             printf("RESULT r4 loop (%s): %.2f us per K loop of a wave, %.2f us per K loop and CU; %.0f shader cycles per K loop "
                    "(MFMA floor 13824) -> %.2f GHz\n", what[var], last * 1e3 / chunk, last * 1e3 / chunk / wgs,
                    (double)cyc / chunk, (double)cyc / chunk / (last * 1e3 / chunk) / 1e3);
