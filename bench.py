@@ -620,6 +620,7 @@ def short_selfplay_leg(label, config, seconds, log, games=None, K=None, dtype=No
                "net_arith_effective": eng.net_arith_effective if split else None,
                "value": d["expansions"] / dt, "unit": "expansions/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
                "sims_per_s": d["sims"] / dt, "queue_slots": slots, "compact_queue": bool(eng.compact),
+               "policy_rows": "logits" if eng.policy_logits else "softmax",
                "queue_utilisation": d["expansions"] / max(1, steps * slots),
                "tree_resets": d["tree_resets"], "overflow_sims": d["overflow_sims"], "depth_overflow": d["depth_overflow"],
                "tree_gib": eng.search.device_bytes() / 2 ** 30}
@@ -891,6 +892,7 @@ def main():
                                    f"INIT_STATE",
                        "games_per_gpu": G, "sims_per_round": K, "queue_slots_per_gpu": slots,
                        "compact_queue": bool(eng.compact),
+                       "policy_rows": "logits" if eng.policy_logits else "softmax",
                        "parallelism": f"games sharded over {world} rank(s), no data-path collective"},
             "sims_per_s": d["sims"] / dt, "plies_per_s": d["plies"] / dt,
             "games_per_hour_est": games_per_hour_estimate(d["expansions"] / dt, args.config),

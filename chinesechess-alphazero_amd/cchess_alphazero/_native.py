@@ -93,7 +93,7 @@ def _declare(L):
         L.cz_input_resblock.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
         L.cz_input_resblock.restype = i32
     if hasattr(L, "cz_heads_tail"):
-        L.cz_heads_tail.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, i32, vp, C.c_float, vp, vp, vp, i32, i32, vp, vp]
+        L.cz_heads_tail.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, i32, vp, C.c_float, vp, vp, vp, i32, i32, i32, vp, vp]
         L.cz_heads_tail.restype = i32
         L.cz_fc_packed_elems.argtypes = [i32, i32]
         L.cz_fc_packed_elems.restype = C.c_size_t
@@ -394,15 +394,16 @@ def pack_fc_weights(w, dtype=None):
     return out
 
 
-def heads_tail(policy_feat, value_feat, wp, bias_p, w1, bias1, w2, b2, policy, value, stats, count=None):
+def heads_tail(policy_feat, value_feat, wp, bias_p, w1, bias1, w2, b2, policy, value, stats, count=None, normalize=True):
     """softmax(policy_feat @ Wp^T + bp) -> policy [N, n_labels]; tanh(relu(value_feat @ W1^T + b1) @ w2 + b2) -> value [N]
     (cz_heads_tail; wp / w1 from pack_fc_weights -- both of the same pair dtype --, everything else fp32 on the device).  count: optional int32 device
-    tensor, only the first min(count, N) rows are computed (compact evaluation queue)."""
+    tensor, only the first min(count, N) rows are computed (compact evaluation queue).  normalize=False: `policy` keeps the
+    raw logits (for a search in cz_search_policy_logits mode)."""
     require_gpu()
     n = policy_feat.shape[0]
     check(lib().cz_heads_tail(_ptr(policy_feat), policy_feat.shape[1], _ptr(wp), _ptr(bias_p), policy.shape[1],
                               _ptr(value_feat), value_feat.shape[1], _ptr(w1), _ptr(bias1), bias1.shape[0], _ptr(w2),
-                              float(b2), _ptr(policy), _ptr(value), _ptr(stats), n, _dt_code(wp.dtype),
+                              float(b2), _ptr(policy), _ptr(value), _ptr(stats), n, _dt_code(wp.dtype), int(bool(normalize)),
                               _ptr(count) if count is not None else None, _stream()), "cz_heads_tail")
     return policy, value
 

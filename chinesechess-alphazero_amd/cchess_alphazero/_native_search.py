@@ -41,6 +41,8 @@ def declare(L):
     L.cz_search_round_q.restype = i32
     L.cz_search_reset_trees.argtypes = [vp, vp]
     L.cz_search_set_sims.argtypes = [vp, i32]
+    L.cz_search_policy_logits.argtypes = [vp, i32]
+    L.cz_search_policy_logits.restype = i32
     L.cz_search_pending.argtypes = [vp, C.POINTER(C.c_int), vp]
     L.cz_search_root_stats.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.cz_search_leaf_rows.argtypes = [vp, vp, vp, C.POINTER(C.c_int), vp]
@@ -60,7 +62,7 @@ def declare(L):
     for n in ("cz_search_create", "cz_search_destroy", "cz_search_info", "cz_search_start_selfplay",
               "cz_search_set_roots", "cz_search_round", "cz_search_reset_trees", "cz_search_pending",
               "cz_search_root_stats", "cz_search_choose", "cz_search_counters", "cz_search_drain_records",
-              "cz_debug_sqrt", "cz_search_set_sims"):
+              "cz_debug_sqrt", "cz_search_set_sims", "cz_search_policy_logits"):
         getattr(L, n).restype = i32
 
 
@@ -176,6 +178,11 @@ class Search:
     def set_sims(self, sims):
         _native.check(self.L.cz_search_set_sims(self.h, int(sims)), "cz_search_set_sims")
         self.sims = int(sims)
+
+    def policy_logits(self, on=True):
+        """The policy rows given to round() are raw logits (agent/model.py forward(logits=True)): the priors are formed from
+        the legal moves' logits alone -- the softmax denominator cancels in the reference's renormalisation."""
+        _native.check(self.L.cz_search_policy_logits(self.h, int(bool(on))), "cz_search_policy_logits")
 
     def reset_trees(self):
         _native.check(self.L.cz_search_reset_trees(self.h, self._stream()), "cz_search_reset_trees")

@@ -374,12 +374,20 @@ class InferenceNet(nn.Module):
         return (self.trunk == "mfma" and self.fused_blocks and self.filters in (128, 192) and
                 getattr(self, "head_w32", torch.empty(0)).shape[0] == 6)
 
+    def supports_logits(self):
+        """True when forward(logits=True) is available: the hand-written dense tail on 6 head filters."""
+        return (self.trunk == "mfma" and self.fused_tail and getattr(self, "head_w32", torch.empty(0)).shape[0] == 6 and
+                self.policy_out.in_features in (180, 360) and self.value_dense.in_features in (180, 360))
+
     @torch.no_grad()
-    def forward(self, planes, rows=None, count=None, out=None):
+    def forward(self, planes, rows=None, count=None, out=None, logits=False):
         """planes: the evaluation queue.  rows / count (int32 cuda tensors, cz_search_round_q): evaluate only the
         boards planes[rows[i]], i < count -- the result rows are indexed by i; rows beyond count are undefined.
         out = (policy [n, 2086] fp32, value [n] fp32): write the results there (the engine's queue tensors) instead of
-        into fresh tensors."""
+        into fresh tensors.  logits=True (hand-written tail only; see supports_logits): the policy rows are left as raw
+        logits -- for a search object in policy_logits mode, which needs the legal moves' entries only."""
+        if logits and not self.supports_logits():
+            raise RuntimeError("logits=True needs the hand-written dense tail")
         if rows is not None and not self.supports_compact_queue():
             raise RuntimeError("compact queue: needs the hand-written trunk (128 filters, fused blocks)")
         if self.trunk == "mfma":
@@ -407,7 +415,7 @@ class InferenceNet(nn.Module):
                         self._bufs[key] = torch.empty((n, 2), dtype=torch.float32, device=planes.device)
                     _native.heads_tail(pf, vf, self.tail_wp.view(self._tail_dtype), self.tail_bp,
                                        self.tail_w1.view(self._tail_dtype), self.tail_b1, self.tail_w2,
-                                       self._tail_b2, out[0], out[1], self._bufs[key], count=count)
+                                       self._tail_b2, out[0], out[1], self._bufs[key], count=count, normalize=not logits)
                     return out
                 p = self.policy_out(pf.to(self.dtype))
                 v = F.relu(self.value_dense(vf.to(self.dtype)))

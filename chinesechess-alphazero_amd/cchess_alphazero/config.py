@@ -81,6 +81,8 @@ class EngineConfig(_Section):
                          max_depth=0,
                          reload_seconds=600,      # self-play re-checks the best-model digest this often (api.py:37-44)
                          compact_queue=True,      # evaluate only the queue slots that hold a new leaf (cz_search_round_q)
+                         policy_logits=True,      # the engine's queue carries raw logits: no softmax pass over all 2086
+                                                  # columns, the priors come from the legal moves' logits (cz_search_policy_logits)
                          use_hip_graph=False, base_seed=0, report_every_rounds=200,
                          max_rounds=None, max_games=None)   # None = run forever, like the reference
 

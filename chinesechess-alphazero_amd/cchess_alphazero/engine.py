@@ -69,6 +69,7 @@ class SelfPlayEngine:
                              max_nodes_per_game=max_nodes_per_game, pool_chunks=pool_chunks, max_depth=max_depth,
                              sims_per_round=sims_per_round, device=self.device, use_history=use_history,
                              pool_fraction=getattr(getattr(config, "engine", None), "pool_fraction", None))
+        self.policy_logits = False             # (an evaluator callable hands over probabilities, like the reference's pipe)
         if evaluator is None:
             self._install(net)
         # compact evaluation queue: the network runs only on the slots that hold a new leaf (2-7 % of the slots of a
@@ -88,6 +89,11 @@ class SelfPlayEngine:
                                          guard=None if guard else False)
         self.net_arith_effective = self.net.arith_effective
         self.net_calibration = self.net.calibration
+        # the engine's own queue: raw logits instead of a softmax over all 2086 columns (the search spreads the priors over
+        # the legal moves anyway, reference player.py:272-283: the denominator cancels) -- engine.policy_logits = False opts out
+        want = getattr(getattr(self.config, "engine", None), "policy_logits", True)
+        self.policy_logits = bool(want and self.net.supports_logits())
+        self.search.policy_logits(self.policy_logits)
 
     # ---- control ----
     def set_network(self, net):
@@ -139,9 +145,9 @@ class SelfPlayEngine:
         else:
             out = (s.policy, s.value)
             if self.compact:
-                p, v = self.net(s.planes, rows=s.q_rows, count=s.q_count, out=out)
+                p, v = self.net(s.planes, rows=s.q_rows, count=s.q_count, out=out, logits=self.policy_logits)
             else:
-                p, v = self.net(s.planes, out=out)
+                p, v = self.net(s.planes, out=out, logits=self.policy_logits)
             if p is s.policy:                                  # written in place (the hand-written network path)
                 return
         s.policy.copy_(p)

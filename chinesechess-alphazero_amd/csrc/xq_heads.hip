@@ -377,7 +377,7 @@ extern "C" int cz_fc_pack_weights(const float* w, int n_out, int n_in, int dtype
 extern "C" int cz_heads_tail(const float* policy_feat, int n_policy_feat, const void* wp_packed, const float* bias_p,
                              int n_labels, const float* value_feat, int n_value_feat, const void* w1_packed,
                              const float* bias1, int n_hidden, const float* w2, float b2, float* policy, float* value,
-                             float* stats_scratch, int n_boards, int dtype, const int32_t* n_dev, void* stream)
+                             float* stats_scratch, int n_boards, int dtype, int normalize, const int32_t* n_dev, void* stream)
 {
     if (!policy_feat || !wp_packed || !bias_p || !value_feat || !w1_packed || !bias1 || !w2 || !policy || !value ||
         !stats_scratch || n_boards < 0 || (dtype != CZ_BF16 && dtype != CZ_F16) || n_labels < 2 || (n_labels & 1) || n_hidden < 1 || n_policy_feat < 1 ||
@@ -407,10 +407,12 @@ extern "C" int cz_heads_tail(const float* policy_feat, int n_policy_feat, const 
         } while (0)
         if (n_policy_feat == 360) CZ_FC(FC_POLICY, 360);
         else CZ_FC(FC_POLICY, 180);
-        size_t nb = ((size_t)n_boards + 3) / 4;
-        if (nb > (size_t)n_cu * 16) nb = (size_t)n_cu * 16;
-        hipLaunchKernelGGL(k_policy_normalize, dim3((unsigned)nb), dim3(256), 0, st, policy,
-                           reinterpret_cast<const float2*>(stats_scratch), n_boards, n_labels, n_dev);
+        if (normalize) {              // (0: `policy` keeps the raw logits -- cz_search_policy_logits takes them as they are)
+            size_t nb = ((size_t)n_boards + 3) / 4;
+            if (nb > (size_t)n_cu * 16) nb = (size_t)n_cu * 16;
+            hipLaunchKernelGGL(k_policy_normalize, dim3((unsigned)nb), dim3(256), 0, st, policy,
+                               reinterpret_cast<const float2*>(stats_scratch), n_boards, n_labels, n_dev);
+        }
     }
     {
         FcArgs a{};

@@ -89,6 +89,8 @@ struct SearchParams {
     uint32_t game_id_stride;
     int ring_cap;
     int record_stride;      // bytes per finished-game record
+    int policy_logits;      // the network rows hold raw LOGITS (cz_search_policy_logits): priors = exp(l - max over the
+                            // node's moves), then the usual renormalisation over them
 };
 
 struct SearchBuffers {

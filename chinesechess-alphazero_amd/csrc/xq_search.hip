@@ -292,7 +292,26 @@ XQ_D void store_meta(char* base, uint32_t v) { *reinterpret_cast<uint32_t*>(base
 XQ_D void store_stat(char* base, uint32_t v) { *reinterpret_cast<uint32_t*>(base + NODE_OFF_HDR + 8) = v; }
 
 // ---- prior spreading: select_action_q_and_u, player.py:272-284 ----------------------------------
-XQ_D void attach_policy(const GameView& gv, SearchLDS& L, int node, const float* __restrict__ prow)
+// Network rows as raw logits (cz_search_policy_logits): the reference spreads the softmax output over the legal moves,
+// p_j / sum_legal p (player.py:272-283), in which the softmax's own denominator cancels -- so only the legal moves' logits
+// matter: p_j := exp(l_j - max over the node's moves).  (The engine's own queue then skips the normalising pass over all
+// 2086 columns: 546 MB of traffic per round for the 4 % of the entries that are read.)
+XQ_D void logits_to_weights(float& q0, float& q1, int nm)
+{
+    const int lane = lane_id();
+    const bool h0 = lane < nm, h1 = lane + 64 < nm;
+    float m = h0 ? q0 : -3.0e38f;
+    if (h1 && q1 > m) m = q1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_xor(m, d, 64);
+        m = o > m ? o : m;
+    }
+    q0 = h0 ? __expf(q0 - m) : 0.0f;
+    q1 = h1 ? __expf(q1 - m) : 0.0f;
+}
+
+XQ_D void attach_policy(const GameView& gv, SearchLDS& L, int node, const float* __restrict__ prow, bool logits)
 {
     const int lane = lane_id();
     char* base = rec_ptr(gv, (uint32_t)node);
@@ -301,8 +320,12 @@ XQ_D void attach_policy(const GameView& gv, SearchLDS& L, int node, const float*
     const int nm = (int)(meta & 0xFF);
     float* pp = node_p(base);
     const uint16_t* pm = node_mv(base, nm);
-    if (lane < nm) L.pr[lane] = prow[pm[lane]];
-    if (lane + 64 < nm) L.pr[lane + 64] = prow[pm[lane + 64]];
+    float q0 = 0.0f, q1 = 0.0f;
+    if (lane < nm) q0 = prow[pm[lane]];
+    if (lane + 64 < nm) q1 = prow[pm[lane + 64]];
+    if (logits) logits_to_weights(q0, q1, nm);
+    if (lane < nm) L.pr[lane] = q0;
+    if (lane + 64 < nm) L.pr[lane + 64] = q1;
     wave_sync();
     float all_p = 0.0f;
     if (nm > 0) {
@@ -322,7 +345,7 @@ XQ_D void attach_policy(const GameView& gv, SearchLDS& L, int node, const float*
 // round trips per leaf instead of five (the BACKUP launch is nothing but such chains, eight leaves one after the other).
 // Same arithmetic, same lanes writing the same words as the three functions it replaces.  depth <= 64.
 XQ_D void attach_and_backup(const SearchParams& P, const GameView& gv, SearchLDS& L, int node, uint32_t meta, int depth,
-                            const float* __restrict__ prow, double v, const int32_t* __restrict__ hp_edge)
+                            const float* __restrict__ prow, double v, const int32_t* __restrict__ hp_edge, bool logits = false)
 {
     const int lane = lane_id();
     char* base = rec_ptr(gv, (uint32_t)node);
@@ -340,6 +363,7 @@ XQ_D void attach_and_backup(const SearchParams& P, const GameView& gv, SearchLDS
     if (lane < nm) p0 = prow[m0];
     if (lane + 64 < nm) p1 = prow[m1];
     if (lane < depth) { ep = edge_ptr(gv, (uint32_t)e); cur = *ep; }
+    if (logits) logits_to_weights(p0, p1, nm);             // (raw logits: weights relative to the largest legal one)
     // prior spreading (select_action_q_and_u, player.py:272-284): float32 accumulation in move order, the terms read
     // straight from the lanes' registers (a loop over an LDS copy paid an LDS round trip per term)
     float all_p = 0.0f;
@@ -1299,9 +1323,9 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             const double v = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), i));   // float(v) of a float32
             if (depth <= 64) {
                 attach_and_backup(P, gv, L, node, (uint32_t)__builtin_amdgcn_readlane((int)my_meta, i), depth,
-                                  policy + slot * NLABELS, v, gv.path_edge + (size_t)i * P.max_depth);
+                                  policy + slot * NLABELS, v, gv.path_edge + (size_t)i * P.max_depth, P.policy_logits != 0);
             } else {
-                attach_policy(gv, L, node, policy + slot * NLABELS);
+                attach_policy(gv, L, node, policy + slot * NLABELS, P.policy_logits != 0);
                 load_path(P, gv, L, i, depth);
                 backup(P, gv, L, depth, v);
             }
@@ -1319,7 +1343,7 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
                 const int row = uni(B.s_qrow[slot]);
                 if (row >= 0) slot = (size_t)row;
             }
-            attach_policy(gv, L, node, policy + slot * NLABELS);
+            attach_policy(gv, L, node, policy + slot * NLABELS, P.policy_logits != 0);
             load_path(P, gv, L, i, depth);
             backup(P, gv, L, depth, (double)value[slot]);             // float(v) of a float32
             sim_finish(gv, i, &active);
@@ -2066,6 +2090,13 @@ int cz_search_set_sims(cz_search* s, int simulation_num_per_move)
     if (keep > s->P.max_chunks) keep = s->P.max_chunks;
     if (keep > s->keep_chunks_created) s->P.keep_chunks = keep;
     else s->P.keep_chunks = s->keep_chunks_created;
+    return CZ_OK;
+}
+
+int cz_search_policy_logits(cz_search* s, int on)
+{
+    if (!s) return serr(CZ_ERR_ARG, "cz_search_policy_logits: null handle");
+    s->P.policy_logits = on ? 1 : 0;
     return CZ_OK;
 }
 

@@ -170,6 +170,11 @@ int cz_search_round_q(cz_search* s, const float* policy, const float* value, voi
 
 /* simulations per search for the following cz_search_set_roots calls (CChessPlayer.action(depth=...), player.py:160) */
 int cz_search_set_sims(cz_search* s, int simulation_num_per_move);
+/* on = 1: the policy rows handed to cz_search_round(_q) are raw LOGITS, not probabilities.  The reference spreads the
+ * softmax output over the legal moves, p_j / sum_legal p (agent/player.py:272-283); the softmax's own denominator cancels
+ * there, so the priors are formed as exp(l_j - max over the node's moves) / their sum -- identical up to float32 rounding,
+ * and the network's tail can skip normalising all 2086 columns (cz_heads_tail normalize = 0).  Default 0. */
+int cz_search_policy_logits(cz_search* s, int on);
 int cz_search_reset_trees(cz_search* s, void* stream);
 /* synchronises the stream; *host_out = number of games whose current search is unfinished */
 int cz_search_pending(cz_search* s, int* host_out, void* stream);
@@ -339,13 +344,16 @@ int cz_head_convs(const void* x, int dtype, const float* w, const float* bias, f
  *   n_dev                    NULL, or the DEVICE int32 count of the compact evaluation queue: only the first
  *                            min(*n_dev, n_boards) rows are computed and written
  *   dtype                    the element type of the packed pairs (the one given to cz_fc_pack_weights): CZ_BF16 or CZ_F16
+ *   normalize                1: policy = softmax (the reference's output).  0: policy keeps the raw LOGITS and the pass over
+ *                            all n_labels columns is skipped -- for a queue consumed by a search with
+ *                            cz_search_policy_logits(h, 1), which needs the legal moves' entries only
  * Precision: operands as (hi, lo) pairs, three MFMAs per product, fp32 accumulation -- the tower's arithmetic: 2^-17 per
  * product with bf16 pairs, 2^-21 class with fp16 pairs (22 bits per operand; the head features are O(1), well inside
  * fp16's range, and the matrix unit honours fp16 subnormals -- tools/f16x3_probe.py). */
 int cz_heads_tail(const float* policy_feat, int n_policy_feat, const void* wp_packed, const float* bias_p,
                   int n_labels, const float* value_feat, int n_value_feat, const void* w1_packed, const float* bias1,
                   int n_hidden, const float* w2, float b2, float* policy, float* value, float* stats_scratch,
-                  int n_boards, int dtype, const int32_t* n_dev, void* stream);
+                  int n_boards, int dtype, int normalize, const int32_t* n_dev, void* stream);
 /* number of 2-byte elements of a packed dense layer (0 = bad argument); HOST: w[n_out][n_in] fp32 -> (hi, lo) pairs of
  * `dtype` (CZ_BF16 / CZ_F16) in fragment order */
 size_t cz_fc_packed_elems(int n_out, int n_in);

@@ -724,6 +724,14 @@ def test_heads_tail_matches_float64(fp, fv, pair):
         # and against what the library path computes in fp32 (the path it replaces): well inside 1e-5
         p32 = torch.softmax(pf[:m].cuda() @ wp.cuda().T + bp.cuda(), dim=1)
         assert (pol[:m] - p32).abs().max().item() < 1e-5
+        # normalize=False (the engine's queue; cz_search_policy_logits): the same rows as raw logits, whose float32
+        # softmax is the normalised output to rounding
+        raw = torch.full((n, n_lab), 7.0, device="cuda")
+        _native.heads_tail(pf.cuda(), vf.cuda(), pk_p, bp.cuda(), pk_1, b1.cuda(), w2.cuda(), b2, raw, val, stats, count=count,
+                           normalize=False)
+        assert torch.all(raw[m:] == 7.0)
+        assert (raw[:m].cpu().double() - lg).abs().max().item() <= bound
+        assert (torch.softmax(raw[:m], dim=1) - pol[:m]).abs().max().item() < 1e-6
 
 
 def test_network_tail_switch_gives_the_same_outputs():

@@ -195,6 +195,49 @@ def test_compact_queue_round_matches_the_slot_queue(gpu):
     s.close()
 
 
+def test_logit_rows_give_the_priors_of_probability_rows(gpu):
+    """cz_search_policy_logits: the queue's policy rows as raw logits.  The reference spreads p_j / sum over the legal
+    moves (player.py:272-283); any per-row factor of p -- the softmax denominator -- cancels there, so a search fed
+    l = log p + (an arbitrary per-row offset) must form the same priors as one fed p, up to float32 rounding of exp / log
+    (a few 2^-24 relative), and, those being that close, spend its visits the same way."""
+    t = gpu.torch
+    pc = play_config(simulation_num_per_move=200, search_threads=8)
+    spec = dict(kind="hash", salt=21)
+    states = [xo.INIT_STATE, MID, END, xo.step(xo.INIT_STATE, '7242'), xo.step(xo.INIT_STATE, '1242')]
+    ev = stub_eval(gpu, spec)
+
+    def run(logits):
+        s = gpu.S.Search(pc, len(states), seed=7)
+        s.policy_logits(logits)
+        s.set_roots(boards_tensor(gpu, states))
+        for _ in range(10000):
+            s.round()
+            if s.pending() == 0:
+                break
+            p, v = ev(s.planes)
+            if logits:
+                off = ((t.arange(p.shape[0], device=p.device) % 13).float() - 6.0) * 3.5        # -21 .. +21 per row
+                p = t.log(p.double()).float() + off[:, None]
+            s.policy.copy_(p)
+            s.value.copy_(v)
+        st = s.root_stats()
+        s.close()
+        return st
+
+    a, b = run(False), run(True)
+    same = 0
+    for g in range(len(states)):
+        c = int(a["counts"][g])
+        assert c == int(b["counts"][g]) and (a["moves"][g, :c] == b["moves"][g, :c]).all()
+        pa, pb = a["p"][g, :c].astype(np.float64), b["p"][g, :c].astype(np.float64)
+        assert np.abs(pb - pa).max() <= 4e-6 * pa.max() and np.all(np.abs(pb - pa) <= 2e-5 * pa + 1e-12), (g, pa, pb)
+        assert int(a["sum_n"][g]) == int(b["sum_n"][g])
+        dn = np.abs(a["n"][g, :c].astype(np.int64) - b["n"][g, :c].astype(np.int64)).sum()
+        assert dn <= 0.05 * int(a["sum_n"][g]), (g, dn)       # (a near-tie in the selection may fall the other way)
+        same += int(dn == 0)
+    assert same >= len(states) - 2, same
+
+
 def test_no_act_and_choose(gpu):
     pc = play_config(simulation_num_per_move=150, search_threads=1, tau_decay_rate=0.98)
     spec = dict(kind="hash", salt=6)
@@ -609,3 +652,37 @@ def test_hip_search_lies_inside_the_reference_spread(gpu):
         cnt = int(st["counts"][0])
         return st["n"][0, :cnt], int(st["sum_n"][0]), st["moves"][0, :cnt]
     assert check_against_spread(data["cases"], search) >= 23
+
+
+def test_engine_queue_of_logits_gives_the_priors_of_the_softmax_queue(gpu):
+    """SelfPlayEngine on its own queue (engine.policy_logits, the default): the network's tail leaves raw logits
+    (cz_heads_tail normalize = 0) and the tree kernel forms the priors from the legal moves' logits -- the same root
+    priors as with the softmax over all 2086 columns in between, to float32 rounding, and the same first visits."""
+    from cchess_alphazero.config import Config
+    from cchess_alphazero.engine import SelfPlayEngine
+    t = gpu.torch
+
+    def run(logits):
+        cfg = Config("normal")
+        cfg.model.cnn_filter_num, cfg.model.res_layer_num = 128, 7         # (BASELINE.json configs[1])
+        cfg.play.noise_eps = 0.0
+        cfg.engine.policy_logits = logits
+        eng = SelfPlayEngine(cfg, 96, dtype=t.float32, seed=5)
+        assert eng.policy_logits == logits and eng.compact
+        eng.start()
+        for _ in range(6):
+            eng.step()
+        st = eng.search.root_stats()
+        x = eng.search.planes[:64].clone()
+        p, _ = eng.net(x)                                       # (outside the engine the rows stay probabilities)
+        assert (p.sum(1) - 1).abs().max().item() < 1e-5
+        return st
+
+    a, b = run(False), run(True)
+    for g in range(96):
+        c = int(a["counts"][g])
+        assert c == int(b["counts"][g]) and c > 0 and (a["moves"][g, :c] == b["moves"][g, :c]).all()
+        pa, pb = a["p"][g, :c].astype(np.float64), b["p"][g, :c].astype(np.float64)
+        assert abs(pa.sum() - 1) < 1e-5 and np.abs(pb - pa).max() <= 4e-6 * pa.max(), (g, np.abs(pb - pa).max())
+    assert (a["sum_n"] == b["sum_n"]).all()
+    assert np.abs(a["n"].astype(np.int64) - b["n"].astype(np.int64)).sum() <= 0.02 * a["sum_n"].sum()
