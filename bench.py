@@ -393,15 +393,18 @@ def arith_label(name):
         return None
     if name.startswith("c8>"):
         return f"f16+2xfp8corr-split(first {name[3:]} blocks)/f16x3-split/f32acc"
-    return {"c8": "f16+2xfp8corr-split/f32acc", "f16x3": "f16x3-split/f32acc", "bf16x3": "bf16x3-split/f32acc",
-            "fp32-library": "f32"}[name]
+    return {"c6": "f16+2xbf6corr-split/f32acc", "c8": "f16+2xfp8corr-split/f32acc", "f16x3": "f16x3-split/f32acc",
+            "bf16x3": "bf16x3-split/f32acc", "fp32-library": "f32"}[name]
 
 
 def arith_mfma_equivalents(name, n_blocks):
     """matrix-pipe time per product in bf16-MFMA units: c8 = one fp16 MFMA + two fp8 MFMAs at twice the rate = 2.0, the
-    three-MFMA pairs 3.0, a hybrid tower the mean over its blocks."""
+    three-MFMA pairs 3.0, a hybrid tower the mean over its blocks; c6 = one fp16 MFMA + two bf6 MFMAs at four times the rate
+    = 1.5 (its first convolution reads the fused input layer's c8 image: 2.0)."""
     if name is None or name == "fp32-library":
         return 1.0
+    if name == "c6":
+        return (2.0 + 1.5 * (2 * n_blocks - 1)) / (2 * n_blocks)
     if name.startswith("c8>"):
         n8 = int(name[3:])
         return (2.0 * n8 + 3.0 * (n_blocks - n8)) / n_blocks
@@ -475,7 +478,8 @@ def sharpened_numerics(eng, ref_net, planes):
         if float(ref[0].max()) >= 0.85:
             break
     requested = eng.net.arith_requested
-    raw = measure_against_reference(InferenceNet(sharp, torch.float32, trunk="mfma", arith=requested).cuda(), ref, planes)
+    raw = measure_against_reference(guarded_inference_net(sharp, torch.float32, trunk="mfma", arith=requested, guard=False,
+                                                          device=planes.device), ref, planes)
     g = guarded_inference_net(sharp, torch.float32, trunk="mfma", arith=requested, device=planes.device)
     m = measure_against_reference(g, ref, planes)
     return {"policy_layer_scale": scale, "max_policy_probability": float(ref[0].max()), "positions": int(planes.shape[0]),

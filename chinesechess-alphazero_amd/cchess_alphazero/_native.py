@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CZ_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libczero.so")   # CZ_LIB: A/B builds (tools/ab_search.sh)
 
 NSQ, NLABELS, MAXMOVES, NOMOVE = 90, 2086, 128, 0xFFFF
-F32, F16, BF16, U8, F16C8 = 0, 1, 2, 3, 4
+F32, F16, BF16, U8, F16C8, F16C6 = 0, 1, 2, 3, 4, 5
 
 _lib = None
 
@@ -87,6 +87,8 @@ def _declare(L):
         L.cz_conv3x3_c8_packed_bytes.restype = C.c_size_t
         L.cz_conv3x3_c8_pack_weights.argtypes = [vp, i32, vp]
         L.cz_conv3x3_c8_pack_weights.restype = i32
+        L.cz_conv3x3_c6_pack_weights.argtypes = [vp, i32, i32, i32, vp]
+        L.cz_conv3x3_c6_pack_weights.restype = i32
         L.cz_conv3x3_c8.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
         L.cz_conv3x3_c8.restype = i32
     if hasattr(L, "cz_input_resblock"):
@@ -245,11 +247,12 @@ def bias_act_(x, bias, residual=None, relu=True):
 
 
 def _pair_code(x):
-    """dtype code of an operand tuple: (f16, uint8 c8 image) is the c8 arithmetic's pair (CZ_F16C8)."""
+    """dtype code of an operand tuple: (f16, uint8 c8 image) is the c8 arithmetic's pair (CZ_F16C8), (f16, int8 image of
+    the same size) the c6 arithmetic's (CZ_F16C6: bf6 pieces in the image; the element type is the tag)."""
     import torch
-    if len(x) == 2 and x[1].dtype == torch.uint8:
+    if len(x) == 2 and x[1].dtype in (torch.uint8, torch.int8):
         assert x[0].dtype == torch.float16 and x[1].shape[-1] == 2 * x[0].shape[-1]
-        return F16C8
+        return F16C8 if x[1].dtype == torch.uint8 else F16C6
     return _dt_code(x[0].dtype)
 
 
@@ -294,6 +297,20 @@ def pack_conv3x3_c8_weights(w_oihw):
         raise NativeError(f"cz_conv3x3_c8: unsupported channels={c}")
     out = torch.empty((n,), dtype=torch.uint8)
     check(lib().cz_conv3x3_c8_pack_weights(_ptr(w), c, _ptr(out)), "cz_conv3x3_c8_pack_weights")
+    return out
+
+
+def pack_conv3x3_c6_weights(w_oihw, x_exp, y_exp):
+    """fp32 [128, 128, 3, 3] filter -> packed bytes for the c6 arithmetic (f16 fragments, bf6 correction pieces, the two
+    filter shifts, and the exponents of the activation images the convolution reads / writes: x_hi6 = bf6(x 2^-exp))."""
+    import torch
+    w = w_oihw.detach().to("cpu", torch.float32).contiguous()
+    c = w.shape[0]
+    n = lib().cz_conv3x3_c8_packed_bytes(c)
+    if n == 0 or c != 128:
+        raise NativeError(f"cz_conv3x3_c6: unsupported channels={c}")
+    out = torch.empty((n,), dtype=torch.uint8)
+    check(lib().cz_conv3x3_c6_pack_weights(_ptr(w), c, int(x_exp), int(y_exp), _ptr(out)), "cz_conv3x3_c6_pack_weights")
     return out
 
 

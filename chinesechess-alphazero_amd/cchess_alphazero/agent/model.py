@@ -118,13 +118,15 @@ class InferenceNet(nn.Module):
     None of the reduced forms is trusted blindly: guarded_inference_net() below measures the candidate against float64 on
     calibration positions when weights are loaded and falls back along c8 -> c8>N -> f16x3 -> bf16x3."""
 
-    def __init__(self, net: CChessNet, dtype=torch.float32, trunk="library", arith=None, act_shift=None):
+    def __init__(self, net: CChessNet, dtype=torch.float32, trunk="library", arith=None, act_shift=None, act_exps=None):
         """act_shift = (s_x, [s_mid per block]): power-of-two activation scales of the residual stream and of every block's
         intermediate tensor, applied as an EXACT reparametrisation of the folded network (ReLU commutes with a positive
         scale): the input layer is multiplied by 2^s_x, block i's first convolution by 2^(s_mid_i - s_x) (bias 2^s_mid_i), its
         second by 2^(s_x - s_mid_i) (bias 2^s_x), the head convolutions by 2^-s_x.  Outputs are unchanged; the tower's tensors
         move into the range the reduced operand formats resolve (e4m3 saturates at 448, fp16 at 65504).  Chosen by
-        guarded_inference_net from the measured activation ranges; None = no scaling."""
+        guarded_inference_net from the measured activation ranges; None = no scaling.
+        act_exps (arith "c6" only) = ([k_mid per block], [k_out per block]): the exponents of the bf6 activation images,
+        2^k * 28 >= the tensor's largest value (c6_exponents of the calibration's activation maxima)."""
         super().__init__()
         net = net.eval()
         assert trunk in ("library", "mfma")
@@ -133,6 +135,15 @@ class InferenceNet(nn.Module):
         arith = arith or os.environ.get("CZ_TOWER_ARITH") or "bf16x3"
         nblk = net.cfg["res_layer_num"]
         c8_blocks = 0
+        self.c6 = False
+        if arith == "c6":
+            # c8 with bf6 correction operands (half the matrix time of the e4m3 ones): 128 filters, >= 2 blocks, whole tower
+            self.c6 = (trunk == "mfma" and dtype == torch.float32 and net.cfg["cnn_filter_num"] == 128 and nblk >= 2)
+            if self.c6 and act_exps is None:
+                raise ValueError("arith='c6' needs the activation images' exponents: build the network through "
+                                 "guarded_inference_net (it measures them on the calibration positions)")
+            arith = "c8"
+        self.act_exps = ([int(v) for v in act_exps[0]], [int(v) for v in act_exps[1]]) if self.c6 else None
         if arith.startswith("c8"):
             c8_blocks = int(arith[3:]) if arith.startswith("c8>") else nblk
             assert 0 <= c8_blocks <= nblk, arith
@@ -220,7 +231,9 @@ class InferenceNet(nn.Module):
 
     @property
     def arith_name(self):
-        """"bf16x3" / "f16x3" / "c8" / "c8>N" (the first N residual blocks on c8, the rest on f16x3)."""
+        """"bf16x3" / "f16x3" / "c8" / "c8>N" (the first N residual blocks on c8, the rest on f16x3) / "c6"."""
+        if self.c6:
+            return "c6"
         if self.arith == "c8" and self.c8_blocks < len(self.res):
             return f"c8>{self.c8_blocks}"
         return self.arith
@@ -246,6 +259,16 @@ class InferenceNet(nn.Module):
         pack_c8 = lambda w: _native.pack_conv3x3_c8_weights(w).view(torch.float16)    # raw bytes, like the others
         pack = lambda w: _native.pack_conv3x3_weights(w, self.operand_dtype, self.parts)
         for i, (c1, c2) in enumerate(self.res):
+            if self.c6:
+                # block i reads the stream image of exponent k_out[i - 1] (block 0: the fused input layer's c8 image, e4m3
+                # filters), writes its intermediate image with k_mid[i] and the stream image with k_out[i]
+                kmid, kout = self.act_exps
+                assert len(kmid) == len(kout) == len(self.res)
+                pk6 = lambda w, kx, ky: _native.pack_conv3x3_c6_weights(w, kx, ky).view(torch.float16)
+                out.append((pack_c8(c1.weight) if i == 0 else pk6(c1.weight, kout[i - 1], kmid[i]),
+                            c1.bias.detach().float().clone(),
+                            pk6(c2.weight, kmid[i], kout[i]), c2.bias.detach().float().clone()))
+                continue
             pk = pack_c8 if i < self.c8_blocks else pack
             out.append((pk(c1.weight), c1.bias.detach().float().clone(),
                         pk(c2.weight), c2.bias.detach().float().clone()))
@@ -260,8 +283,10 @@ class InferenceNet(nn.Module):
         if n > cap:
             od, c = self.operand_dtype, self.filters
             if self.arith == "c8":          # (f16 operand, c8 correction image: e4m3 lo, e4m3 value)
+                # (c6: the same bytes hold bf6 pieces; int8 tags the pair for the entry points)
                 bufs = [(torch.empty((n, 90, c), dtype=od, device=device),
-                         torch.empty((n, 90, 2 * c), dtype=torch.uint8, device=device)) for _ in range(3)]
+                         torch.empty((n, 90, 2 * c), dtype=torch.int8 if self.c6 else torch.uint8, device=device))
+                        for _ in range(3)]
             else:
                 bufs = [tuple(torch.empty((n, 90, c), dtype=od, device=device) for _ in range(self.parts))
                         for _ in range(3)]
@@ -294,6 +319,8 @@ class InferenceNet(nn.Module):
         # (a hybrid tower whose only c8 block is the first hands fp32 over after it: that block stays on cz_resblock)
         first_fused = (fused and self.fused_input and c == 128 and self.parts == 2 and nblk >= 2 and
                        planes.dtype == torch.uint8 and n8 != 1)
+        if self.c6 and not (first_fused and fused):
+            raise RuntimeError("arith='c6' runs on the fused kernels only (uint8 planes, fused input layer and blocks)")
         if not first_fused:
             if self.arith == "c8" and n8 == 0:                  # (cannot happen through the constructor; kept total)
                 cur, tmp, nxt = (self._as_f16_pair(t) for t in (cur, tmp, nxt))
@@ -574,12 +601,23 @@ def choose_act_shift(activation_max, n_blocks, target=128.0, max_dev=3):
     return base + dev(stream), [base + dev(activation_max[2 * i + 1]) for i in range(n_blocks)]
 
 
+def c6_exponents(activation_max):
+    """([k_mid per block], [k_out per block]) for InferenceNet(arith="c6") from the (scaled) activation maxima
+    [input layer, block 0 mid, block 0 out, ...]: the smallest k with 2^k * 28 >= max (bf6's largest value is 28)."""
+    import math
+    k = [int(math.ceil(math.log2(a / 28.0))) if a > 0.0 else 0 for a in activation_max]
+    return k[1::2], k[2::2]
+
+
 def guard_chain(arith, c8_blocks, n_blocks, activation_max):
     """The candidates guarded_inference_net tries, most reduced first, for a requested arithmetic family and the tower's
     measured activation ranges: a c8 image saturates above 448 (such a tower is not even tried), fp16 pairs overflow at
     65504 (kept a factor of two away), bf16 pairs have fp32's range."""
     chain = []
     top = max(activation_max) if activation_max else 0.0
+    if arith == "c6":                                # (the bf6 images carry their own exponents; the fused input layer's is c8)
+        chain.append("c6")
+        arith, c8_blocks = "c8", n_blocks
     if arith == "c8" and top <= 448.0:
         chain += [f"c8>{k}" if k < n_blocks else "c8" for k in (c8_blocks, c8_blocks - 2, c8_blocks - 4) if k >= 1]
     if arith in ("c8", "f16x3") and top < 3.0e4:
@@ -601,13 +639,19 @@ def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", ari
     requested = arith or os.environ.get("CZ_TOWER_ARITH") or "bf16x3"
     if guard is None:
         guard = os.environ.get("CZ_ARITH_GUARD", "1") != "0"
-    first = InferenceNet(net, dtype, trunk=trunk, arith=requested).to(dev)
-    first.arith_requested = requested
-    first.arith_effective = first.arith_name
-    first.calibration = None
     reduced = trunk == "mfma" and dtype == torch.float32        # (a caller asking for bf16 / fp16 operands asked for them)
-    if not guard or not reduced or dev.type != "cuda":
-        return first
+    nblk = len(net.res)
+    c6 = requested == "c6" and reduced and net.cfg["cnn_filter_num"] == 128 and nblk >= 2 and dev.type == "cuda"
+    if requested == "c6" and not c6:
+        requested = "c8"                                         # (c6 exists for the 128-filter tower on the fused kernels)
+    first = None if c6 else InferenceNet(net, dtype, trunk=trunk, arith=requested).to(dev)
+    if first is not None:
+        first.arith_requested = requested
+        first.arith_effective = first.arith_name
+        first.calibration = None
+        if not guard or not reduced or dev.type != "cuda":
+            return first
+    family = "c8" if c6 else first.arith
     with torch.cuda.device(dev):
         if planes is None:
             planes = calibration_planes(CALIBRATION_POSITIONS, net.cfg["input_depth"], dev)
@@ -620,8 +664,7 @@ def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", ari
         # saturating tower is not even tried
         report["c8_saturating_layers"] = [i for i, a in enumerate(acts) if a > 448.0]
         # tensors outside the range the operand formats resolve are moved into it by an exact power-of-two reparametrisation
-        nblk = len(net.res)
-        sx, smid = choose_act_shift(acts, nblk) if first.arith in ("c8", "f16x3") else (0, [0] * nblk)
+        sx, smid = choose_act_shift(acts, nblk) if family in ("c8", "f16x3") else (0, [0] * nblk)
         shift = (sx, smid) if (sx or any(smid)) else None
         report["act_shift"] = {"stream": sx, "mid": smid}
         # (acts: [input layer, block 0 mid, block 0 out, block 1 mid, ...] -- odd entries are intermediate tensors)
@@ -635,11 +678,21 @@ def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", ari
         sc = [2.0 ** (smid[(i - 1) // 2] if i % 2 else sx) for i in range(len(acts))]
         report["activation_quantiles_scaled"] = [[q[0] * f, q[1] * f] for q, f in zip(qs, sc)]
         report["c8_median_in_subnormals"] = [i for i, (q, f) in enumerate(zip(qs, sc)) if 0.0 < q[1] * f < 2.0 ** -6]
-        chain = guard_chain(first.arith, first.c8_blocks, nblk, scaled)
-        cand = first if shift is None else None
+        exps = c6_exponents(scaled)
+        if c6:
+            report["c6_exponents"] = {"mid": exps[0], "out": exps[1]}
+            first = InferenceNet(net, dtype, trunk=trunk, arith="c6", act_shift=shift, act_exps=exps).to(dev)
+            first.arith_requested = requested
+            first.arith_effective = first.arith_name
+            first.calibration = report
+            if not guard:
+                return first
+        chain = guard_chain("c6" if c6 else first.arith, first.c8_blocks, nblk, scaled)
+        cand = first if (shift is None or c6) else None
         for name in chain:
             if cand is None or cand.arith_name != name:
-                cand = InferenceNet(net, dtype, trunk=trunk, arith=name, act_shift=shift).to(dev)
+                cand = InferenceNet(net, dtype, trunk=trunk, arith=name, act_shift=shift,
+                                    act_exps=exps if name == "c6" else None).to(dev)
             m = measure_against_reference(cand, ref, planes)
             m["arith"] = name
             report["candidates"].append(m)

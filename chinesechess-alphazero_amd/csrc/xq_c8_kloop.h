@@ -32,6 +32,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 constexpr int W_PAD_STEPS = 3;
 constexpr int X_LO_SHIFT = 11;
@@ -61,6 +62,7 @@ struct Filter {
     __amdgpu_buffer_rsrc_t rsrc;
     int lane_main;      // byte offset of this lane inside a K-step of fp16 fragments
     int lane_c8;        // byte offset of this lane inside a (block, kind) group of c8 pieces, counted from the c8 base
+    int lane_c6t;       // c6 pieces (24 bytes): the 8-byte tails sit densely behind the 16-byte heads of the group
     int scale_w_hi, scale_w_lo;      // E8M0 scale bytes of the two correction MFMAs (127 - shift)
 };
 
@@ -72,6 +74,7 @@ __device__ __forceinline__ Filter make_filter(const void* packed, int wave, int 
     f.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(packed), 0, (MAIN_U4 + C8_U4 + 1) * 16, 0x00020000);
     f.lane_main = wave * 1024 + lane * 16;
     f.lane_c8 = MAIN_U4 * 16 + wave * 2048 + lane * 16;
+    f.lane_c6t = MAIN_U4 * 16 + wave * 2048 + 1024 + lane * 8;
     const int* sc = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(packed) + MAIN_U4 + C8_U4);
     f.scale_w_hi = 127 - __builtin_amdgcn_readfirstlane(sc[0]);
     f.scale_w_lo = 127 - __builtin_amdgcn_readfirstlane(sc[1]);
@@ -89,7 +92,11 @@ struct NoShadow {
 // bit 1 = no LDS reads inside the loop -- timing experiments with wrong results.
 // ZERO_INIT = false: the caller has put the accumulators' start values into acc (bias, bias + skip connection): the
 // products are added on top, so the epilogue that follows has no additions left to do.
-template <int NT, typename Shadow = NoShadow, int PROBE = 0, bool ZERO_INIT = true, int CH = 128>
+// FMT = 1: the c6 arithmetic -- correction operands in bf6 (e3m2), 24-byte pieces (a 16-byte head where the e4m3 piece's
+// first half sits, an 8-byte tail at the start of its second half), correction MFMAs of 32 cycles instead of 64: the loop's
+// matrix work is 3/4 of c8's, and the room the long fp8 slots offered is gone -- the next tap's row arithmetic is cut
+// into three stages of 3-4 instructions, one per correction slot of the tap's first three half blocks.
+template <int NT, typename Shadow = NoShadow, int PROBE = 0, bool ZERO_INIT = true, int CH = 128, int FMT = 0>
 __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img, const Filter& flt, int lane, f32x16* acc,
                                       int scale_x_lo, int scale_x, Shadow&& shadow = NoShadow())
 {
@@ -121,16 +128,40 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
     auto load_c8 = [&](i32x8& d, int pre_p, int q, int b, int h) {
         const int c0 = q * (CPR / 2) + 4 * b + h;
         const int off = G::POW2 ? pre_p ^ lane_c ^ (c0 << 4) : (pre_p ^ lane_c ^ ((c0 & 7) << 4)) + ((c0 >> 3) << 7);
-        const uint4 t = *reinterpret_cast<const uint4*>(lds + img.part_bytes + off);
-        d[4 * h + 0] = t.x; d[4 * h + 1] = t.y; d[4 * h + 2] = t.z; d[4 * h + 3] = t.w;
+        if (FMT == 0 || h == 0) {
+            const uint4 t = *reinterpret_cast<const uint4*>(lds + img.part_bytes + off);
+            d[4 * h + 0] = t.x; d[4 * h + 1] = t.y; d[4 * h + 2] = t.z; d[4 * h + 3] = t.w;
+        } else {
+            const uint2 t = *reinterpret_cast<const uint2*>(lds + img.part_bytes + off);
+            d[4] = t.x; d[5] = t.y;
+        }
     };
     constexpr int STEP_B = CT * 1024, BLK_B = 2 * CT * 2048;     // bytes of a K-step of fp16 fragments / of a block's c8 pieces
     auto load_w = [&](int step_soff) {                 // fp16 fragment of K-step `step` (soffset = step * STEP_B, wave-uniform)
         return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(flt.rsrc, flt.lane_main, step_soff, 0));
     };
     auto load_wc = [&](i32x8& d, int blk_soff, int q, int h) {      // blk_soff = blk * BLK_B (one block = 2 kinds x CT waves x 2 KB)
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(flt.rsrc, flt.lane_c8 + h * 1024, blk_soff + q * (BLK_B / 2), 0);
-        d[4 * h + 0] = (int)t.x; d[4 * h + 1] = (int)t.y; d[4 * h + 2] = (int)t.z; d[4 * h + 3] = (int)t.w;
+        if (FMT == 0 || h == 0) {
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(flt.rsrc, flt.lane_c8 + h * 1024, blk_soff + q * (BLK_B / 2), 0);
+            d[4 * h + 0] = (int)t.x; d[4 * h + 1] = (int)t.y; d[4 * h + 2] = (int)t.z; d[4 * h + 3] = (int)t.w;
+        } else {
+            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(flt.rsrc, flt.lane_c6t, blk_soff + q * (BLK_B / 2), 0);
+            d[4] = (int)t.x; d[5] = (int)t.y;
+        }
+    };
+    // the next tap's rows in three stages (FMT = 1): A nominal pixel + on-board test, B row, C byte offset
+    int st_nom[NT], st_row[NT];
+    bool st_ok[NT];
+    auto tap_stage = [&](int stage, int dy, int dx, int p, int* out) {
+        const int t = p % 3;
+        if (stage == 0) {
+            st_ok[p] = (unsigned)(qy[t] + dy) < 10u && (unsigned)(qx[t] + dx) < 9u;
+            st_nom[p] = (p / 3) * 90 + t * 32 + ln + dy * 9 + dx;
+        } else if (stage == 1) {
+            st_row[p] = st_ok[p] ? img.row_base + st_nom[p] : img.zrow + (st_nom[p] & 15);
+        } else {
+            out[p] = st_row[p] * RB + (((kb ^ st_nom[p]) & SWZ) << 4);
+        }
     };
 
     f16x8 wf[4];                                        // fp16 filter fragments, slot = K-step % 4
@@ -138,6 +169,11 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
     i32x8 cx[NT];                                       // c8 pixel pieces of the kind whose MFMAs come next
     i32x8 wcr[2];                                       // c8 filter pieces by kind
     int pre[NT], pre_n[NT];
+    if (FMT == 1) {                                     // (registers 6, 7 of a bf6 operand are not read)
+#pragma unroll
+        for (int p = 0; p < NT; ++p) { cx[p][6] = 0; cx[p][7] = 0; }
+        wcr[0][6] = wcr[0][7] = wcr[1][6] = wcr[1][7] = 0;
+    }
     if (ZERO_INIT) {
 #pragma unroll
         for (int p = 0; p < NT; ++p)
@@ -197,7 +233,7 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
                     // ---- correction term `half` of this block (K = 64)
 #pragma unroll
                     for (int i = 0; i < NT; ++i) {
-                        acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wcr[half], cx[i], acc[i], 0, 0, 0,
+                        acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wcr[half], cx[i], acc[i], FMT ? 3 : 0, FMT ? 3 : 0, 0,
                                                                                   half ? flt.scale_w_lo : flt.scale_w_hi, 0,
                                                                                   half ? scale_x : scale_x_lo);
                         // the fp16 filter fragments of the two K-steps just retired, one block ahead (their ring slots are free)
@@ -206,7 +242,11 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
                             wf[kk & 3] = load_w(soff_j + (tap3 * KK + kk + 4) * STEP_B);
                         }
                         // the next tap's rows: one per fp8 slot of the tap's first block (needed from K-step 6 on)
-                        if (b == 0 && half == 0) pre_n[i] = tap_row(ndy, ndx, i);
+                        if (FMT == 0) {
+                            if (b == 0 && half == 0) pre_n[i] = tap_row(ndy, ndx, i);
+                        } else if (b * 2 + half < 3) {
+                            tap_stage(b * 2 + half, ndy, ndx, i, pre_n);
+                        }
                         shadow.fp8(j, ((tt * NB + b) * 2 + half) * NT + i);
                         __builtin_amdgcn_sched_barrier(0);
                     }

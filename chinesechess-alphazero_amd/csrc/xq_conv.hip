@@ -710,8 +710,11 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
 // timing build (tools/rb_stamps.py; never the default library): shader-cycle stamps of one matrix wave's and one copy
 // wave's sections of one steady-state board of k_resblock_c8
 __device__ long long g_rb_stamps[32];
+__device__ int g_rb_knob;              // timing experiments (wrong results): bits switch parts of the c6 store path off
 #define RB_STAMP(i) do { if (stamp_on) g_rb_stamps[i] = clock64(); } while (0)
+#define RB_KNOB() g_rb_knob
 #else
+#define RB_KNOB() 0
 #define RB_STAMP(i) do { } while (0)
 #endif
 
@@ -757,6 +760,26 @@ static_assert(LDS_BYTES <= 160 * 1024, "X + Y + staging + bias + mask boards mus
 // staging offset of channels ch .. ch + 3 of pixel q (fp32, 32 chunks of 16 bytes per row, swizzled by the row)
 __device__ __forceinline__ int stage_off(int q, int ch) { return q * SROW + ((((ch >> 2) & ~7) | (((ch >> 2) ^ q) & 7)) << 4); }
 
+// ---- the c6 arithmetic (round 4): correction operands in bf6 (e3m2), 32 channels of a pixel = one 24-byte piece --------
+// A piece holds the channels of one 32-block in the order v_cvt_scalef32_2xpk16_bf6_f32 packs two 16-vectors (element
+// 2 i = src0[i], 2 i + 1 = src1[i], element e at bits 6 e; tools/probes/bf6_probe.hip) with src0 = the block's even
+// channel quads, src1 = its odd ones -- which is what a matrix wave holds after one v_permlane32_swap per register:
+//     channel of element e = 8 (e >> 3) + ((e >> 1) & 3) + 4 (e & 1)          (cz_conv3x3_c6_pack_weights: the same)
+// and the inverse conversion (sequential) hands accumulator register r of lane half kb its channel at element 2 r + kb.
+// In a 256-byte image row (HBM and LDS alike) piece (kind, block b, half kb) has its 16-byte head in logical chunk
+// 8 kind + 4 b + 2 kb -- where the e4m3 piece's first half sits -- and its 8-byte tail at the start of the next chunk.
+// x_hi6 = bf6(x 2^-k), x_lo6 = bf6((x - f16(x)) 2^(11 - k)) with the image's exponent k from the calibration
+// (2^k * 28 >= the tensor's largest value; the conversion saturates), carried by the packed filters that read / write it.
+typedef __attribute__((ext_vector_type(6))) unsigned int u32x6;
+typedef __attribute__((ext_vector_type(32))) float f32x32;
+__device__ __forceinline__ const int* pack_ints(const void* packed)
+{
+    return reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(packed) + c8k::MAIN_U4 + c8k::C8_U4);
+}
+__device__ __forceinline__ int c6_chunk(int kind, int blk32) { return 8 * kind + 4 * (blk32 >> 1) + 2 * (blk32 & 1); }
+// byte offsets of a piece's head inside a part's pixel row `row` (LDS: chunks swizzled by the row)
+__device__ __forceinline__ int c6_lds_off(int row, int chunk) { return row * RB + ((chunk ^ (row & 15)) << 4); }
+
 struct Shadow {                         // relu(acc2 of the previous board) -> staging, one (tile, channel group) unit per 9 fp8 slots
     unsigned char* lds;
     f32x16* prev;                       // the body always reads prev[0]; rotated at the end of an iteration
@@ -783,7 +806,7 @@ struct Shadow {                         // relu(acc2 of the previous board) -> s
 };
 }  // namespace rb8
 
-template <bool FIRST, bool HEADS>
+template <bool FIRST, bool HEADS, bool C6 = false>
 __global__ __launch_bounds__(512, 2) void k_resblock_c8(
     const _Float16* __restrict__ xh, const unsigned char* __restrict__ xc, const void* __restrict__ w1p,
     const float* __restrict__ b1, const void* __restrict__ w2p, const float* __restrict__ b2, _Float16* __restrict__ yh,
@@ -820,7 +843,7 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
                 for (int k = 0; k < 8; ++k) hw[o][k] = hd.w[o * C + (ctid % (C / 8)) * 8 + k];
         }
         // board `to` from the staging image (fp32, already ReLU'd) to HBM
-        auto store_tile = [&](int to, int ct2) {
+        auto store_tile = [&](int to, int ct2) __attribute__((always_inline)) {
             const size_t ebase = (size_t)to * 90 * C;
 #pragma unroll
             for (int it = 0; it < EITER; ++it) {
@@ -866,6 +889,65 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+        // the same for a c6 output image.  Pass A: the f16 halves in store_tile's mapping (a thread = 8 channels of a pixel:
+        // 16 bytes, consecutive over the lanes -- whole cache lines per instruction).  Pass B: one thread takes the 32 channels
+        // of a (pixel, block) -- a whole piece of each kind (24 bytes, 4 neighbouring lanes fill 96 of a line's 128).
+        // (The K loops' filter stream keeps the CU's vector-memory path ~80 % busy -- 576 KB per board and convolution at
+        //  64 B/clk --, so every extra memory instruction of the copy waves shows: an earlier form that wrote the f16 halves
+        //  from pass B's mapping, 16 bytes at a 64-byte lane stride, cost 0.1 ms per launch more; streaming (nt) stores 0.13.)
+        const int k_out = C6 ? __builtin_amdgcn_readfirstlane(pack_ints(w2p)[3]) : 0;
+        auto store_tile_c6 = [&](int to, int ct2) __attribute__((always_inline)) {
+            const int knob = RB_KNOB();
+            if (knob & 4) return;
+            const size_t ebase = (size_t)to * 90 * C;
+            const float s_hi = __builtin_ldexpf(1.0f, k_out), s_lo = __builtin_ldexpf(1.0f, k_out - cf8::X_LO_SHIFT);
+            struct alignas(16) H8 { Quad<_Float16> a, b; };
+#pragma unroll
+            for (int it = 0; it < EITER; ++it) {               // ---- pass A
+                const int i = it * CTHR + ct2;
+                if (!((it + 1) * CTHR <= PIECES || i < PIECES)) continue;
+                const int qq = i / (C / 8), c8 = i % (C / 8);
+                const float4 f0 = *reinterpret_cast<const float4*>(S + stage_off(qq, c8 * 8));
+                const float4 f1 = *reinterpret_cast<const float4*>(S + stage_off(qq, c8 * 8 + 4));
+                H8 h;
+                h.a.e[0] = (_Float16)f0.x; h.a.e[1] = (_Float16)f0.y; h.a.e[2] = (_Float16)f0.z; h.a.e[3] = (_Float16)f0.w;
+                h.b.e[0] = (_Float16)f1.x; h.b.e[1] = (_Float16)f1.y; h.b.e[2] = (_Float16)f1.z; h.b.e[3] = (_Float16)f1.w;
+                if (!(knob & 1)) reinterpret_cast<uint4*>(yh + ebase)[i] = __builtin_bit_cast(uint4, h);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {                   // ---- pass B
+                const int i = it * CTHR + ct2;
+                if (i >= 90 * 4) continue;
+                const int qq = i >> 2, blk = i & 3;
+                f32x16 av, bv, al, bl;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 f0 = *reinterpret_cast<const float4*>(S + stage_off(qq, blk * 32 + 8 * k));
+                    const float4 f1 = *reinterpret_cast<const float4*>(S + stage_off(qq, blk * 32 + 8 * k + 4));
+                    const float r[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        av[4 * k + j] = r[j];
+                        bv[4 * k + j] = r[4 + j];
+                        al[4 * k + j] = r[j] - (float)(_Float16)r[j];
+                        bl[4 * k + j] = r[4 + j] - (float)(_Float16)r[4 + j];
+                    }
+                }
+                const u32x6 pl = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(al, bl, s_lo);
+                const u32x6 pv = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(av, bv, s_hi);
+                unsigned char* row = yc + ebase * 2 + (size_t)qq * 2 * C;
+                if (knob & 2) continue;
+                *reinterpret_cast<uint4*>(row + 16 * c6_chunk(0, blk)) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+                *reinterpret_cast<uint2*>(row + 16 * c6_chunk(0, blk) + 16) = make_uint2(pl[4], pl[5]);
+                *reinterpret_cast<uint4*>(row + 16 * c6_chunk(1, blk)) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
+                *reinterpret_cast<uint2*>(row + 16 * c6_chunk(1, blk) + 16) = make_uint2(pv[4], pv[5]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // (two call sites each; a wrapper lambda around them was NOT inlined by the compiler: a call inside the kernel, 2.5x
+        //  the scratch and 17 % of the launch time)
+#define CZ_STORE_BOARD(to, ct2) do { if (C6 && !HEADS && !yf && !(RB_KNOB() & 8)) store_tile_c6(to, ct2); else store_tile(to, ct2); } while (0)
         // registers -> X image.  Loaded boards: 16-byte chunks of both parts; FIRST: the thread's 8 channels of a pixel are
         // one 16-byte chunk of the f16 row and two 8-byte pieces of the c8 row [lo8 x 128 | e4m3(x) x 128]
         auto write_x = [&](int ct2) {
@@ -1046,7 +1128,7 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
             RB_STAMP(18);
             __syncthreads();                                   // B_k: staging holds board t_prev; X is free
             RB_STAMP(19);
-            if (t_prev >= 0) store_tile(t_prev, ct2);
+            if (t_prev >= 0) CZ_STORE_BOARD(t_prev, ct2);
             RB_STAMP(20);
             if (has_next) {
                 if (FIRST) {
@@ -1066,7 +1148,8 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
         }
         __syncthreads();                                       // E0: the staging image is free (the store above is done)
         __syncthreads();                                       // E1: the last board is staged
-        store_tile(t_prev, ctid);
+        CZ_STORE_BOARD(t_prev, ctid);
+#undef CZ_STORE_BOARD
         return;
     }
 
@@ -1076,6 +1159,9 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
     const float* bias1 = reinterpret_cast<const float*>(lds + BIAS_OFF);
     const float* bias2 = bias1 + C;
     f32x16 acc[NT], prev[NT];
+    // c6: the exponents of the images the two convolutions read (X: not for the fused input layer's c8 image)
+    const int k_x = C6 && !FIRST ? __builtin_amdgcn_readfirstlane(pack_ints(w1p)[2]) : 0;
+    const int k_y = C6 ? __builtin_amdgcn_readfirstlane(pack_ints(w2p)[2]) : 0;
     rb8::Shadow shd{lds, prev, wave, kb, ln};
     bool have_prev = false;
 #ifdef CZ_RB_STAMPS
@@ -1099,13 +1185,106 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
             }
         }
         __builtin_amdgcn_s_setprio(3);
-        if (have_prev) c8k::kloop<NT, rb8::Shadow&, 0, false>(X, c8k::Image{0, ZROW, PART}, flt1, lane, acc, 127 - cf8::X_LO_SHIFT, 127, shd);
-        else c8k::kloop<NT, c8k::NoShadow, 0, false>(X, c8k::Image{0, ZROW, PART}, flt1, lane, acc, 127 - cf8::X_LO_SHIFT, 127);
+        constexpr int F1 = C6 && !FIRST ? 1 : 0;              // (the fused input layer hands over a c8 image)
+        if (have_prev) c8k::kloop<NT, rb8::Shadow&, 0, false, 128, F1>(X, c8k::Image{0, ZROW, PART}, flt1, lane, acc, 127 + k_x - cf8::X_LO_SHIFT, 127 + k_x, shd);
+        else c8k::kloop<NT, c8k::NoShadow, 0, false, 128, F1>(X, c8k::Image{0, ZROW, PART}, flt1, lane, acc, 127 + k_x - cf8::X_LO_SHIFT, 127 + k_x);
         __builtin_amdgcn_s_setprio(0);
         RB_STAMP(2);
         int ln2 = ln, kb2 = kb;
         asm volatile("" : "+v"(ln2), "+v"(kb2));
         // epilogue 1: relu(acc) -> c8 triple -> Y; the freed accumulators restart at b2 + skip (this lane's own elements of X)
+        if (C6) {
+            // c6: the f16 quads go out per lane as before; the two bf6 pieces of a pixel's 32 channels need the other
+            // lane half's 16 values: tiles 0 and 1 trade halves (one v_permlane32_swap per register -- the lower lanes end
+            // up with tile 0's pixels, the upper ones with tile 1's), tile 2 trades with itself (lower lanes store)
+            const float s_hi = __builtin_ldexpf(1.0f, k_y), s_lo = __builtin_ldexpf(1.0f, k_y - cf8::X_LO_SHIFT);
+            const float s_skip = __builtin_ldexpf(1.0f, k_x - cf8::X_LO_SHIFT);
+            f32x16 lo[NT];
+#pragma unroll
+            for (int p = 0; p < NT; ++p) {
+                const int q = p * 32 + ln2;
+                const int row = q < 90 ? q : 89;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = wave * 32 + g * 8 + kb2 * 4;
+                    const int off = row * RB + (((ch >> 3) ^ (row & 15)) << 4) + (ch & 7) * 2;
+                    Quad<_Float16> hq;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float r = acc[p][g * 4 + i] > 0.0f ? acc[p][g * 4 + i] : 0.0f;
+                        hq.e[i] = (_Float16)r;
+                        acc[p][g * 4 + i] = r;
+                        lo[p][g * 4 + i] = r - (float)hq.e[i];
+                    }
+                    if (q < 90) *reinterpret_cast<Quad<_Float16>*>(Y + off) = hq;
+                }
+            }
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {                   // pair (0, 1), then tile 2 with itself
+                const int pa = pp == 0 ? 0 : 2, pb = pp == 0 ? 1 : 2;
+                f32x16 av, bv, al, bl;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[pa][r]), __float_as_uint(acc[pb][r]), false, false);
+                    const auto sl = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo[pa][r]), __float_as_uint(lo[pb][r]), false, false);
+                    av[r] = __uint_as_float(sv[0]); bv[r] = __uint_as_float(sv[1]);
+                    al[r] = __uint_as_float(sl[0]); bl[r] = __uint_as_float(sl[1]);
+                }
+                const u32x6 pl = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(al, bl, s_lo);
+                const u32x6 pv = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(av, bv, s_hi);
+                const int q = pp == 0 ? kb2 * 32 + ln2 : 64 + ln2;
+                if (pp == 0 || (kb2 == 0 && q < 90)) {
+                    unsigned char* d0 = Y + PART + c6_lds_off(q, c6_chunk(0, wave));
+                    unsigned char* t0 = Y + PART + c6_lds_off(q, c6_chunk(0, wave) + 1);
+                    unsigned char* d1 = Y + PART + c6_lds_off(q, c6_chunk(1, wave));
+                    unsigned char* t1 = Y + PART + c6_lds_off(q, c6_chunk(1, wave) + 1);
+                    *reinterpret_cast<uint4*>(d0) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+                    *reinterpret_cast<uint2*>(t0) = make_uint2(pl[4], pl[5]);
+                    *reinterpret_cast<uint4*>(d1) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
+                    *reinterpret_cast<uint2*>(t1) = make_uint2(pv[4], pv[5]);
+                }
+            }
+            // the accumulators restart at b2 + skip: this lane's channels of X (f16 quads + its elements of the lo piece)
+#pragma unroll
+            for (int p = 0; p < NT; ++p) {
+                const int q = p * 32 + ln2;
+                const int row = q < 90 ? q : 89;
+                f32x32 xl;
+                if (!FIRST) {
+                    const uint4 hd4 = *reinterpret_cast<const uint4*>(X + PART + c6_lds_off(row, c6_chunk(0, wave)));
+                    const uint2 tl2 = *reinterpret_cast<const uint2*>(X + PART + c6_lds_off(row, c6_chunk(0, wave) + 1));
+                    // the upper lane half wants the odd elements: it shifts the piece down by one element (6 bits), so that
+                    // every lane reads element 2 r for its register r  (a select between xl[2 r] and xl[2 r + 1] is
+                    // turned into a variable vector index by the compiler: 31 v_cndmask per element)
+                    const uint32_t wv[7] = {hd4.x, hd4.y, hd4.z, hd4.w, tl2.x, tl2.y, 0u};
+                    const uint32_t sh6 = (uint32_t)kb2 * 6u;
+                    u32x6 pc;
+#pragma unroll
+                    for (int w = 0; w < 6; ++w) pc[w] = __builtin_amdgcn_alignbit(wv[w + 1], wv[w], sh6);
+                    xl = __builtin_amdgcn_cvt_scalef32_pk32_f32_bf6(pc, s_skip);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = wave * 32 + g * 8 + kb2 * 4;
+                    const int off = row * RB + (((ch >> 3) ^ (row & 15)) << 4) + (ch & 7) * 2;
+                    const float4 bv4 = *reinterpret_cast<const float4*>(bias2 + ch);
+                    float vv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
+                    const Quad<_Float16> xq = *reinterpret_cast<const Quad<_Float16>*>(X + off);
+                    if (FIRST) {
+                        const int off_lo = PART + row * RB + (ch & 15) + (((ch >> 4) ^ (row & 15)) << 4);
+                        cf8::add_pair4(vv, xq, *reinterpret_cast<const uint32_t*>(X + off_lo));
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int r = g * 4 + i;
+                            vv[i] += (float)xq.e[i] + xl[2 * r];
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[p][g * 4 + i] = vv[i];
+                }
+            }
+        } else {
 #pragma unroll
         for (int p = 0; p < NT; ++p) {
             const int q = p * 32 + ln2;
@@ -1132,11 +1311,12 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
                 for (int i = 0; i < 4; ++i) acc[p][g * 4 + i] = vv[i];
             }
         }
+        }
         RB_STAMP(3);
         __syncthreads();                                       // B_k: Y complete, X and the previous staging contents free
         RB_STAMP(4);
         __builtin_amdgcn_s_setprio(3);
-        c8k::kloop<NT, c8k::NoShadow, 0, false>(Y, c8k::Image{0, ZROW, PART}, flt2, lane, acc, 127 - cf8::X_LO_SHIFT, 127);
+        c8k::kloop<NT, c8k::NoShadow, 0, false, 128, C6 ? 1 : 0>(Y, c8k::Image{0, ZROW, PART}, flt2, lane, acc, 127 + k_y - cf8::X_LO_SHIFT, 127 + k_y);
         __builtin_amdgcn_s_setprio(0);
         RB_STAMP(5);
 #pragma unroll
@@ -2305,6 +2485,10 @@ inline float f16_bits_to_f32(uint16_t b)
 }  // namespace
 
 #ifdef CZ_RB_STAMPS
+extern "C" int cz_debug_rb_knob(int v)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_rb_knob), &v, sizeof(int)) == hipSuccess ? CZ_OK : CZ_ERR_HIP;
+}
 extern "C" int cz_debug_rb_stamps(long long* out32_host)
 {
     return hipMemcpyFromSymbol(out32_host, HIP_SYMBOL(g_rb_stamps), sizeof(long long) * 32) == hipSuccess ? CZ_OK : CZ_ERR_HIP;
@@ -2374,6 +2558,25 @@ inline uint8_t f32_to_e4m3_bits(float f)
     if (e > 8 || (e == 8 && m > 6)) return sign | 0x7e;
     return sign | (uint8_t)(((e + 7) << 3) | m);
 }
+// fp32 -> bf6 (e3m2, bias 3, no inf / nan): round to nearest even, saturating at 28 -- v_cvt_scalef32_2xpk16_bf6_f32's rule
+inline uint8_t f32_to_bf6_bits(float f)
+{
+    const uint8_t sgn = std::signbit(f) ? 0x20 : 0;
+    float a = fabsf(f);
+    if (!(a == a)) return sgn;                                      // (NaN: no encoding; filters never hold one)
+    if (a >= 28.0f) return sgn | 0x1F;
+    int e;
+    frexpf(a, &e);                                                  // a = m 2^e, m in [0.5, 1)
+    int ex = e - 1;                                                 // a in [2^ex, 2^(ex + 1))
+    if (ex < -2) ex = -2;                                           // subnormals share the smallest normal's step 2^-4
+    const float step = ldexpf(1.0f, ex - 2);
+    const float qf = nearbyintf(a / step);                          // (default rounding mode: to nearest even)
+    const int qi = (int)qf;                                         // 0 .. 8 (8: carries into the next binade)
+    if (a < 0.25f) return sgn | (uint8_t)qi;                        // subnormal: code = multiple of 2^-4 (4 -> the first normal)
+    int ee = ex + 3, m = qi - 4;
+    if (m == 4) { m = 0; ++ee; }
+    return sgn | (uint8_t)((ee << 2) | m);
+}
 inline int pow2_shift_for(float amax, int top)                     // s with amax * 2^s in [2^top, 2^(top + 1))
 {
     if (!(amax > 0.0f)) return 0;
@@ -2431,6 +2634,65 @@ extern "C" int cz_conv3x3_c8_pack_weights(const float* w_oihw, int channels, voi
                             const size_t u4 = ((((size_t)(tap * NB + b) * 2 + q) * CT + ct) * 2 + j / 16) * 64 + lane;
                             c8p[u4 * 16 + j % 16] = f32_to_e4m3_bits(v);
                         }
+            }
+    return CZ_OK;
+}
+
+// The same filter for the c6 arithmetic (k_resblock_c8<.., C6>): fp16 fragments as above; the correction pieces in bf6,
+// 24 bytes per lane -- a 16-byte head where the e4m3 piece's first half sits, the 8-byte tails densely behind the heads of
+// a (block, kind, wave) group -- with element e of lane (row, half) = input channel 64 b + 32 half + 8 (e >> 3) +
+// ((e >> 1) & 3) + 4 (e & 1) (the order the kernels' conversion instruction gives the activations).  Trailing ints:
+// the two filter shifts (largest magnitude in [8, 16): bf6 saturates at 28), then x_exp / y_exp: the exponents k of the
+// activation image this convolution reads and of the one it writes (x_hi6 = bf6(x 2^-k); 2^k 28 >= max |x|).
+extern "C" int cz_conv3x3_c6_pack_weights(const float* w_oihw, int channels, int x_exp, int y_exp, void* out_host)
+{
+    if (!w_oihw || !out_host || channels != 128 || x_exp < -100 || x_exp > 100 || y_exp < -100 || y_exp > 100) {
+        czi_set_error("cz_conv3x3_c6_pack_weights: bad argument (128 filters; image exponents within +-100)");
+        return CZ_ERR_ARG;
+    }
+    const int C = channels, KK = C / 16, CT = C / 32, NB = C / 64;
+    const size_t main_u4 = (size_t)(9 * KK + W_PAD_STEPS) * CT * 64, c8_u4 = (size_t)(9 * NB + 1) * 2 * CT * 2 * 64;
+    memset(out_host, 0, (main_u4 + c8_u4 + 1) * 16);
+    uint16_t* hi = (uint16_t*)out_host;
+    uint8_t* c6p = (uint8_t*)out_host + main_u4 * 16;
+    int32_t* sc = (int32_t*)((uint8_t*)out_host + (main_u4 + c8_u4) * 16);
+    float wmax = 0.0f, lmax = 0.0f;
+    for (size_t i = 0; i < (size_t)C * C * 9; ++i) {
+        const float w = w_oihw[i], l = w - f16_bits_to_f32(f32_to_f16_bits(w));
+        wmax = fabsf(w) > wmax ? fabsf(w) : wmax;
+        lmax = fabsf(l) > lmax ? fabsf(l) : lmax;
+    }
+    const int sh = pow2_shift_for(wmax, 3), sl = pow2_shift_for(lmax, 3);
+    sc[0] = sh;
+    sc[1] = sl;
+    sc[2] = x_exp;
+    sc[3] = y_exp;
+    for (int tap = 0; tap < 9; ++tap)
+        for (int ct = 0; ct < CT; ++ct)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int o = ct * 32 + (lane & 31);
+                for (int kk = 0; kk < KK; ++kk)
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = kk * 16 + (lane >> 5) * 8 + j;
+                        const float w = w_oihw[((size_t)o * C + c) * 9 + tap];
+                        hi[((((size_t)tap * KK + kk) * CT + ct) * 64 + lane) * 8 + j] = f32_to_f16_bits(w);
+                    }
+                for (int b = 0; b < NB; ++b)
+                    for (int q = 0; q < 2; ++q) {
+                        uint8_t piece[24] = {0};
+                        for (int e = 0; e < 32; ++e) {
+                            const int c = b * 64 + (lane >> 5) * 32 + 8 * (e >> 3) + ((e >> 1) & 3) + 4 * (e & 1);
+                            const float w = w_oihw[((size_t)o * C + c) * 9 + tap];
+                            const float v = q == 0 ? ldexpf(w, sh) : ldexpf(w - f16_bits_to_f32(f32_to_f16_bits(w)), sl);
+                            const uint32_t code = f32_to_bf6_bits(v);
+                            const int bit = 6 * e;
+                            piece[bit >> 3] |= (uint8_t)(code << (bit & 7));
+                            if ((bit & 7) > 2) piece[(bit >> 3) + 1] |= (uint8_t)(code >> (8 - (bit & 7)));
+                        }
+                        uint8_t* grp = c6p + ((((size_t)(tap * NB + b) * 2 + q) * CT + ct) * 2) * 64 * 16;    // 2 KB per (block, kind, wave)
+                        memcpy(grp + (size_t)lane * 16, piece, 16);
+                        memcpy(grp + 1024 + (size_t)lane * 8, piece + 16, 8);
+                    }
             }
     return CZ_OK;
 }
@@ -2630,13 +2892,13 @@ int launch_resblock(const void* xh, const void* xl, const void* w1, const float*
     return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
 }
 
-template <bool FIRST, bool HEADS>
+template <bool FIRST, bool HEADS, bool C6 = false>
 int launch_resblock_c8(const void* xh, const void* xc, const void* w1, const float* b1, const void* w2, const float* b2,
                        void* yh, void* yc, float* yf, int n, int n_cu, hipStream_t st, HeadArgs hd, const int32_t* n_dev,
                        FirstArgs fa)
 {
     const unsigned blocks = (unsigned)(n < n_cu ? n : n_cu);
-    hipLaunchKernelGGL((k_resblock_c8<FIRST, HEADS>), dim3(blocks), dim3(512), 0, st, (const _Float16*)xh,
+    hipLaunchKernelGGL((k_resblock_c8<FIRST, HEADS, C6>), dim3(blocks), dim3(512), 0, st, (const _Float16*)xh,
                        (const unsigned char*)xc, w1, b1, w2, b2, (_Float16*)yh, (unsigned char*)yc, yf, n, hd, n_dev, fa);
     return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
 }
@@ -2701,7 +2963,7 @@ extern "C" int cz_resblock_heads(const void* x_hi, const void* x_lo, const void*
         return CZ_ERR_ARG;
     }
     if (n_boards == 0) return CZ_OK;
-    if (channels != 128 || (dtype != CZ_BF16 && dtype != CZ_F16 && dtype != CZ_F16C8)) {
+    if (channels != 128 || (dtype != CZ_BF16 && dtype != CZ_F16 && dtype != CZ_F16C8 && dtype != CZ_F16C6)) {
         czi_set_error("cz_resblock_heads: 128 filters, bf16 / f16 split operands only (use cz_resblock + cz_head_convs)");
         return CZ_ERR_ARG;
     }
@@ -2719,6 +2981,9 @@ extern "C" int cz_resblock_heads(const void* x_hi, const void* x_lo, const void*
     else if (dtype == CZ_F16C8)
         rc = launch_resblock_c8<false, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, nullptr, nullptr, nullptr,
                                              n_boards, n_cu, st, hd, g_q.n_dev, FirstArgs{});
+    else if (dtype == CZ_F16C6)
+        rc = launch_resblock_c8<false, true, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, nullptr, nullptr, nullptr,
+                                                   n_boards, n_cu, st, hd, g_q.n_dev, FirstArgs{});
     else
         rc = launch_resblock<_Float16, 128, 2, 1, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, nullptr,
                                                          nullptr, nullptr, n_boards, n_cu, st, hd);
@@ -2752,6 +3017,9 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
     else if (dtype == CZ_F16C8 && channels == 128 && parts == 2)
         rc = launch_resblock_c8<false, false>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo, y_f32, n_boards,
                                               n_cu, st, HeadArgs{}, g_q.n_dev, FirstArgs{});
+    else if (dtype == CZ_F16C6 && channels == 128 && parts == 2)
+        rc = launch_resblock_c8<false, false, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo, y_f32, n_boards,
+                                                    n_cu, st, HeadArgs{}, g_q.n_dev, FirstArgs{});
     else if (dtype == CZ_F16C8 && channels == 192 && parts == 2) {
         const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
         hipLaunchKernelGGL((k_resblock_ip_c8<192>), dim3(blocks), dim3(192 / 32 * 64 + ip::COPY_THREADS), 0, st,
@@ -2779,8 +3047,8 @@ extern "C" int cz_input_resblock(const void* planes_u8, int in_planes, const flo
         czi_set_error("cz_input_resblock: bad argument (u8 planes, in_planes even and <= 32)");
         return CZ_ERR_ARG;
     }
-    if (channels != 128 || (dtype != CZ_BF16 && dtype != CZ_F16 && dtype != CZ_F16C8)) {
-        czi_set_error("cz_input_resblock: 128 filters; bf16 / f16 split operands or the c8 pair (use cz_input_conv + cz_resblock)");
+    if (channels != 128 || (dtype != CZ_BF16 && dtype != CZ_F16 && dtype != CZ_F16C8 && dtype != CZ_F16C6)) {
+        czi_set_error("cz_input_resblock: 128 filters; bf16 / f16 split operands or the c8 / c6 pair (use cz_input_conv + cz_resblock)");
         return CZ_ERR_ARG;
     }
     if (n_boards == 0) return CZ_OK;
@@ -2794,6 +3062,14 @@ extern "C" int cz_input_resblock(const void* planes_u8, int in_planes, const flo
     // 6 of the ~12-16 term rounds of a board under K loop 1, the rest under K loop 2: measured on one box, extra time of
     // the launch against an inner block's: 0 rounds +0.43 ms, 3: +0.26, 6: +0.14, 9: +0.22 (window 2 also drains the result)
     const FirstArgs fa{(const unsigned char*)planes_u8, in_table, in_bias, rows, in_planes, g_first_w1_rounds};
+    if (dtype == CZ_F16C6) {          // y_lo = a c6 image; w1: cz_conv3x3_c8_pack_weights' (the gather's image is c8), w2: ..._c6_...
+        if (launch_resblock_c8<true, false, true>(nullptr, nullptr, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo, nullptr,
+                                                  n_boards, n_cu, st, HeadArgs{}, n_dev, fa) != CZ_OK) {
+            czi_set_error("cz_input_resblock: launch failed");
+            return CZ_ERR_HIP;
+        }
+        return CZ_OK;
+    }
     if (dtype == CZ_F16C8) {          // y_lo = the c8 image, the filters are cz_conv3x3_c8_pack_weights' (k_resblock_c8<FIRST>)
         if (launch_resblock_c8<true, false>(nullptr, nullptr, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo, nullptr, n_boards,
                                             n_cu, st, HeadArgs{}, n_dev, fa) != CZ_OK) {

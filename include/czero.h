@@ -47,6 +47,8 @@ extern "C" {
 #define CZ_BF16 2
 #define CZ_U8 3
 #define CZ_F16C8 4   /* fp16 operand + c8 correction image (cz_conv3x3_c8): the residual-block entry points only */
+#define CZ_F16C6 5   /* fp16 operand + c6 correction image (bf6 pieces; cz_conv3x3_c6_pack_weights): cz_resblock(_heads),
+                        cz_input_resblock with 128 filters only */
 
 int cz_version(void);
 const char* cz_last_error(void);
@@ -262,6 +264,19 @@ int cz_conv3x3_c8_pack_weights(const float* w_oihw, int channels, void* out_host
 int cz_conv3x3_c8(const void* x_hi, const void* x_c8, const void* w_packed, const float* bias,
                   const void* skip_hi, const void* skip_c8, void* y_hi, void* y_c8, float* y_f32,
                   int n_boards, int channels, int relu, void* stream);
+
+/* The c6 tower arithmetic (round 4; k_resblock_c8<.., C6>, 128 filters, whole residual blocks only): the c8 sum with the
+ * two correction operands in bf6 (e3m2) -- v_mfma_scale_f32_32x32x64_f8f6f4 retires bf6 operands in 32 cycles, e4m3 ones in
+ * 64 (tools/probes/bf6_probe.hip), so a product costs 1.5 instead of 2.0 MFMA-equivalents; per-product accuracy ~2^-15.
+ * Activation images keep the c8 pair's shape (x_hi f16 [n][90][128], image bytes [n][90][256]); the image holds, per pixel
+ * and 32-channel block, a 24-byte piece bf6((x - f16(x)) 2^(11 - k)) and a piece bf6(x 2^-k) (layout: csrc/xq_conv.hip,
+ * namespace rb8), k = the image's exponent, 2^k * 28 >= max |x| (from calibration activations; the conversion saturates).
+ * Filters: cz_conv3x3_c6_pack_weights(w, 128, x_exp, y_exp, out) -- same size as cz_conv3x3_c8_packed_bytes(128) -- with
+ * the exponents of the image the convolution READS and of the one it WRITES; a block's w1 / w2 must agree on the
+ * intermediate image's exponent, consecutive blocks on the stream image's.  Entry points (dtype CZ_F16C6): cz_resblock,
+ * cz_resblock_heads, cz_input_resblock (whose gathered input image is c8: ITS w1 is cz_conv3x3_c8_pack_weights') and the
+ * _q forms.  A host owns the accuracy check exactly as for c8 (agent/model.py guarded_inference_net: c6 -> c8 -> ...). */
+int cz_conv3x3_c6_pack_weights(const float* w_oihw, int channels, int x_exp, int y_exp, void* out_host);
 
 /* test / tuning hook: the 128-filter split residual block with operand-pair output has two schedules that give
  * bit-identical results -- k_resblock_pipe (default, 1): epilogue 2 of a board runs under the next board's first K

@@ -60,6 +60,59 @@ def block_scaled(x, dim, fmt):
     return (q * scale).reshape(shp).movedim(-1, dim)
 
 
+FP6 = {"e2m3": (2, 3, 1), "e3m2": (3, 2, 3)}          # exponent bits, mantissa bits, bias (OCP MX: no inf / nan, saturating)
+
+
+def fp6(y, fmt):
+    """Round float64 y to the fp6 grid of `fmt` (round to nearest even, saturating)."""
+    eb, mb, bias = FP6[fmt]
+    emax = (1 << eb) - 1 - bias
+    top = (2.0 - 2.0 ** -mb) * 2.0 ** emax
+    a = y.abs().clamp_max(top)
+    e = torch.floor(torch.log2(a.clamp_min(1e-300))).clamp(min=1.0 - bias, max=float(emax))
+    step = torch.exp2(e - mb)
+    return torch.sign(y) * (torch.round(a / step) * step).clamp_max(top)
+
+
+def c6_operands(x, w, fmt, xscale):
+    """The operand model of a c6 kernel: fp16 main operands; 6-bit correction operands with the instruction's E8M0 scale
+    per 32 input channels.  Filters: exact per-(output, tap, block) scales for w and for w - f16(w) (host side, free).
+    Activations: xscale = "block": per (pixel, block) the binade of the block's largest |x| (the lo image's scale is that
+    times 2^-11, no second reduction); "fixed": one scale for the tensor from its maximum (a calibration constant)."""
+    eb, mb, bias = FP6[fmt]
+    emax = (1 << eb) - 1 - bias
+
+    def blocks(t, dim):
+        t = t.movedim(dim, -1)
+        return t.reshape(*t.shape[:-1], t.shape[-1] // 32, 32), t.shape
+
+    def back(tb, shp, dim):
+        return tb.reshape(shp).movedim(-1, dim)
+
+    xh = x.to(torch.float32).to(torch.float16).to(torch.float64)
+    xb, shp = blocks(x, 1)
+    xlb, _ = blocks(x - xh, 1)
+    if xscale.startswith("block"):
+        amax = xb.abs().amax(dim=-1, keepdim=True).clamp_min(2.0 ** -24)
+    else:
+        amax = xb.abs().max().clamp_min(2.0 ** -24)
+    sc = torch.exp2(torch.floor(torch.log2(amax)) - emax)
+    xh6 = back(fp6(xb / sc, fmt) * sc, shp, 1)
+    scl = sc * 2.0 ** -11
+    xl6 = back(fp6(xlb / scl, fmt) * scl, shp, 1)
+    wh = w.to(torch.float32).to(torch.float16).to(torch.float64)
+
+    def wq(t):
+        tb, ws = blocks(t, 1)
+        if xscale.endswith("W"):                              # one scale for the whole filter tensor, like c8
+            am = tb.abs().max().clamp_min(1e-300)
+        else:
+            am = tb.abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)
+        s = torch.exp2(torch.floor(torch.log2(am)) - emax)
+        return back(fp6(tb / s, fmt) * s, ws, 1)
+    return xh, xl6, xh6, wh, wq(w - wh), wq(w)
+
+
 def conv_model(x, w, b, mode, pad):
     """x [n, c, 10, 9] float64 (exact activations of the previous layer as the kernel would hold them), w [o, c, k, k]."""
     conv = lambda a, ww: F.conv2d(a, ww, None, padding=pad)
@@ -110,6 +163,23 @@ def conv_model(x, w, b, mode, pad):
             q[:, c] = torch.where(pick_other, other[:, c], near[:, c])
             r = torch.where(pick_other, e_other, e_near)
         y = conv(xh, wh) + conv(xl8, f8(w * sh) / sh) + conv(xh8, q / sl)
+    elif mode.startswith("c6k:"):
+        # exactly the c6 kernels' operand model (csrc/xq_conv.hip, k_resblock_c8<.., C6>): bf6 (e3m2) correction operands with
+        # FIXED scales -- the image's exponent k (2^k * 28 >= the tensor's calibration maximum; saturating), one power of
+        # two per filter tensor (largest magnitude in [8, 16))
+        k = int(mode[4:])
+        xh = x.to(torch.float32).to(torch.float16).to(torch.float64)
+        wh = w.to(torch.float32).to(torch.float16).to(torch.float64)
+        xl6 = fp6((x - xh) * 2.0 ** (11 - k), "e3m2") * 2.0 ** (k - 11)
+        xh6 = fp6(x * 2.0 ** -k, "e3m2") * 2.0 ** k
+        sh = 2.0 ** (3 - torch.floor(torch.log2(w.abs().max())))
+        wl = w - wh
+        sl = 2.0 ** (3 - torch.floor(torch.log2(wl.abs().max().clamp_min(1e-300))))
+        y = conv(xh, wh) + conv(xl6, fp6(w * sh, "e3m2") / sh) + conv(xh6, fp6(wl * sl, "e3m2") / sl)
+    elif mode.startswith("c6-"):                             # c6-<e2m3|e3m2>-<block|fixed>
+        _, fmt, xs = mode.split("-")
+        xh, xl6, xh6, wh, wl6, wh6 = c6_operands(x, w, fmt, xs)
+        y = conv(xh, wh) + conv(xl6, wh6) + conv(xh6, wl6)
     elif mode == "c8-kernel":
         # exactly the kernels' operand model (csrc/xq_conv.hip): FIXED activation scales -- x_lo8 = e4m3(sat(x_lo * 2^11)),
         # x_hi8 = e4m3(sat(x)), saturation at +-448 -- and one power-of-two scale per filter tensor (largest magnitude
@@ -152,23 +222,55 @@ def stored(x, mode):
         if mode == "f16x3-ftz":
             lo = torch.where(lo.abs() < 2.0 ** -14, torch.zeros_like(lo), lo)
         return xh + lo
+    if mode.startswith("c6k:"):
+        k = int(mode[4:])
+        return xh + fp6((x - xh) * 2.0 ** (11 - k), "e3m2") * 2.0 ** (k - 11)
+    if mode.startswith("c6-"):                               # the lo image doubles as the skip connection's low part
+        _, fmt, xs = mode.split("-")
+        xh_, xl6, _, _, _, _ = c6_operands(x, torch.zeros(1, x.shape[1], 1, 1, dtype=x.dtype), fmt, xs)
+        return xh_ + xl6
     if mode in ("c8-kernel", "c8-ef"):
         lo = ((x - xh) * 2048.0).clamp(-448.0, 448.0).to(torch.float32).to(torch.float8_e4m3fn).to(torch.float64)
         return xh + lo / 2048.0
     return xh + block_scaled(x - xh, 1, "e4m3" if mode == "f16+fp8" else "e2m3")
 
 
-def run(net, planes, mode):
+def run(net, planes, mode, exps=None):
+    """exps (mode "c6-kernel"): ([k_mid per block], [k_out per block]), the activation images' exponents (default:
+    agent/model.py c6_exponents of this batch's own float64 activation maxima)."""
     from cchess_alphazero.agent.model import _fold
     d = torch.float64
     with torch.no_grad():
         ic = _fold(net.input_conv, net.input_bn)
         x = F.relu(F.conv2d(planes.to(d), ic.weight.to(d), ic.bias.to(d), padding=ic.padding))     # input layer: exact fp32 gather in the engine
+        if mode == "c6-kernel":
+            # the engine's c6 tower: the fused input layer hands block 0 a c8 image (its first convolution is c8), every
+            # other convolution reads a bf6 image with the exponent its producer was given
+            if exps is None:
+                from cchess_alphazero.agent.model import c6_exponents
+                amax, t = [float(x.max())], x
+                for blk in net.res:
+                    c1, c2 = _fold(blk.conv1, blk.bn1), _fold(blk.conv2, blk.bn2)
+                    u = F.relu(F.conv2d(t, c1.weight.to(d), c1.bias.to(d), padding=1))
+                    t = F.relu(F.conv2d(u, c2.weight.to(d), c2.bias.to(d), padding=1) + t)
+                    amax += [float(u.max()), float(t.max())]
+                exps = c6_exponents(amax)
+            kmid, kout = exps
+            x = stored(x.to(torch.float32).to(d), "c8-kernel")
+            for bi, blk in enumerate(net.res):
+                c1, c2 = _fold(blk.conv1, blk.bn1), _fold(blk.conv2, blk.bn2)
+                m1 = "c8-kernel" if bi == 0 else f"c6k:{kout[bi - 1]}"
+                y = F.relu(conv_model(x, c1.weight.to(d), c1.bias.to(d), m1, 1)).to(torch.float32).to(d)
+                y = stored(y, f"c6k:{kmid[bi]}")
+                z = conv_model(y, c2.weight.to(d), c2.bias.to(d), f"c6k:{kmid[bi]}", 1).to(torch.float32).to(d)
+                x = stored(F.relu(z + x).to(torch.float32).to(d), f"c6k:{kout[bi]}")
+            mode = "done"
         hybrid = None
         if ">" in mode:                      # "c8-kernel>5": blocks 0..4 on the c8 arithmetic, the rest on (hi, lo) fp16 pairs
             mode, hybrid = mode.split(">")[0], int(mode.split(">")[1])
-        x = stored(x.to(torch.float32).to(d), mode)
-        for bi, blk in enumerate(net.res):
+        if mode != "done":
+            x = stored(x.to(torch.float32).to(d), mode)
+        for bi, blk in enumerate(net.res if mode != "done" else []):
             if hybrid is not None and bi == hybrid:
                 mode = "f16x3"
             c1, c2 = _fold(blk.conv1, blk.bn1), _fold(blk.conv2, blk.bn2)
@@ -198,6 +300,7 @@ def main():
                     help="multiplies the input layer's filters and bias: activations of the whole tower grow by about this factor")
     ap.add_argument("--modes", default="bf16x3,f16x3,c8-kernel,f16+fp8,f16+fp6,f16",
                     help="comma-separated; also f16x3-ftz, c8-kernel>N (first N blocks c8, the rest f16x3)")
+    ap.add_argument("--outliers", default="", help="N,G: N channels of the input layer G times larger (heavy-tailed activations)")
     a = ap.parse_args()
     global UNIFORM
     UNIFORM = a.uniform_scales
@@ -215,6 +318,10 @@ def main():
     if a.act_scale != 1.0:                                   # (BatchNorm folded: scale its affine output)
         net.input_bn.weight.data.mul_(a.act_scale)
         net.input_bn.bias.data.mul_(a.act_scale)
+    if a.outliers:
+        n_out, gain = a.outliers.split(",")
+        net.input_bn.weight.data[:int(n_out)].mul_(float(gain))
+        net.input_bn.bias.data[:int(n_out)].mul_(float(gain))
     net.eval()
     rng = np.random.default_rng(a.seed)
     boards, state = [], xo.INIT_STATE

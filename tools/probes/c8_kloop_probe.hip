@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 1) void k_probe(const uint4* __restrict__ wmai
 }
 
 // ---- round 4: the product's K loop (csrc/xq_c8_kloop.h), WGS workgroups of four waves per CU ----------------------------
-template <int WGS, int PROBE>
+template <int WGS, int PROBE, int FMT = 0>
 __global__ __launch_bounds__(256, WGS) void k_probe_r4(const uint4* __restrict__ packed, const uint4* __restrict__ image,
                                                         float* __restrict__ out, int convs, long long* __restrict__ cycles)
 {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, WGS) void k_probe_r4(const uint4* __restrict__
         for (int r = 0; r < 16; ++r) sum[p][r] = 0.0f;
     const long long t0 = clock64();                    // s_memtime: shader cycles
     for (int conv = 0; conv < convs; ++conv) {
-        c8k::kloop<NT, c8k::NoShadow, PROBE>(lds, img, flt, lane, acc, 127 - 11, 127);
+        c8k::kloop<NT, c8k::NoShadow, PROBE, true, 128, FMT>(lds, img, flt, lane, acc, 127 - 11, 127);
         if (conv + 1 == convs) {
 #pragma unroll
             for (int p = 0; p < NT; ++p) sum[p] += acc[p];
@@ -275,8 +275,8 @@ int main(int argc, char** argv)
         CK(hipMemcpy(dpk, pk.data(), pk.size(), hipMemcpyHostToDevice));
         long long* dcyc;
         CK(hipMalloc(&dcyc, 8));
-        for (int var = 0; var < 6; ++var) {
-            const int wgs = var == 1 ? 2 : 1;      // variants: 1 WG, 2 WGs, no filter loads, no LDS reads, neither
+        for (int var = 0; var < 9; ++var) {
+            const int wgs = var == 1 || var == 7 ? 2 : 1;      // variants: 1 WG, 2 WGs, no filter loads, no LDS reads, neither
             auto go = [&](int convs) {
                 hipEvent_t e0, e1;
                 CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -286,7 +286,10 @@ int main(int argc, char** argv)
                 else if (var == 2) hipLaunchKernelGGL((k_probe_r4<1, 1>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
                 else if (var == 3) hipLaunchKernelGGL((k_probe_r4<1, 2>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
                 else if (var == 4) hipLaunchKernelGGL((k_probe_r4<1, 3>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
-                else hipLaunchKernelGGL(k_probe_r4_nt6, dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
+                else if (var == 5) hipLaunchKernelGGL(k_probe_r4_nt6, dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
+                else if (var == 6) hipLaunchKernelGGL((k_probe_r4<1, 0, 1>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
+                else if (var == 7) hipLaunchKernelGGL((k_probe_r4<2, 0, 1>), dim3(2 * blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
+                else hipLaunchKernelGGL((k_probe_r4<1, 3, 1>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
                 float ms = 0.0f;
@@ -300,9 +303,10 @@ int main(int argc, char** argv)
             for (int i = 0; i < (int)(seconds / 0.5) + 1; ++i) last = go(chunk);
             long long cyc = 0;
             CK(hipMemcpy(&cyc, dcyc, 8, hipMemcpyDeviceToHost));
-            const char* what[6] = {"as in the product", "2 workgroups per CU", "no filter loads in the loop", "no LDS reads in the loop",
+            const char* what[9] = {"as in the product", "2 workgroups per CU", "no filter loads in the loop", "no LDS reads in the loop",
                                    "no loads at all in the loop",
-                                   "six pixel tiles = TWO boards per filter fragment (halve the figures for one board)"};
+                                   "six pixel tiles = TWO boards per filter fragment (halve the figures for one board)",
+                                   "c6: bf6 correction operands, MFMA floor 10368", "c6, 2 workgroups per CU", "c6, no loads at all in the loop"};
             printf("RESULT r4 loop (%s): %.2f us per K loop of a wave, %.2f us per K loop and CU; %.0f shader cycles per K loop "
                    "(MFMA floor 13824) -> %.2f GHz\n", what[var], last * 1e3 / chunk, last * 1e3 / chunk / wgs,
                    (double)cyc / chunk, (double)cyc / chunk / (last * 1e3 / chunk) / 1e3);

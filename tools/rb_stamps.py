@@ -34,11 +34,31 @@ def main():
     planes = planes.cuda()
     xin = _native.split_c8(x)
     out = (torch.empty_like(xin[0]), torch.empty_like(xin[1]))
+    # the c6 arithmetic (bf6 correction operands): its input image comes out of the fused first block
+    q1, q2 = _native.pack_conv3x3_c6_weights(w1, 0, 0).cuda(), _native.pack_conv3x3_c6_weights(w2, 0, 0).cuda()
+    x6 = (torch.empty_like(xin[0]), torch.empty_like(xin[1]).view(torch.int8))
+    out6 = (torch.empty_like(x6[0]), torch.empty_like(x6[1]))
+    _native.input_resblock(planes, table, b, p1, b, q2, b, out=x6)
     L = _native.lib()
     L.cz_debug_rb_stamps.argtypes = [C.c_void_p]
     res = {}
+    last = torch.empty((n, 90, c), dtype=torch.float32, device="cuda")
+
+    def knob(v, fn):
+        def run():
+            L.cz_debug_rb_knob(v)
+            fn()
+            L.cz_debug_rb_knob(0)
+        return run
+    c6b = lambda: _native.resblock(x6, q1, b, q2, b, out=out6)
     for name, fn in (("block", lambda: _native.resblock(xin, p1, b, p2, b, out=out)),
-                     ("first_block_with_fused_input_layer", lambda: _native.input_resblock(planes, table, b, p1, b, p2, b, out=out))):
+                     ("first_block_with_fused_input_layer", lambda: _native.input_resblock(planes, table, b, p1, b, p2, b, out=out)),
+                     ("c6_block", lambda: _native.resblock(x6, q1, b, q2, b, out=out6)),
+                     ("c6_first_block", lambda: _native.input_resblock(planes, table, b, p1, b, q2, b, out=out6)),
+                     ("c6_block_f32_out", lambda: _native.resblock(x6, q1, b, q2, b, out_f32=last)),
+                     ("c6_block_knob1_no_f16_stores", knob(1, c6b)), ("c6_block_knob2_no_piece_stores", knob(2, c6b)),
+                     ("c6_block_knob3_no_stores", knob(3, c6b)), ("c6_block_knob4_no_store_pass", knob(4, c6b)),
+                     ("c6_block_knob8_c8_store_pass", knob(8, c6b))):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         for _ in range(30):                               # warm: the clock settles under the sustained load
             fn()

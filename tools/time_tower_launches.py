@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Per-launch times of the 7 x 128 tower (benchmark weights, calibration positions) for a list of arithmetics: HIP events
+around every residual-block launch of InferenceNet (block_events), 32768 positions, mean of the timed repetitions."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "chinesechess-alphazero_amd"))
+
+
+def main():
+    from cchess_alphazero.agent.model import CChessNet, calibration_planes, guarded_inference_net
+    ariths = sys.argv[1].split(",") if len(sys.argv) > 1 else ["c8", "c6"]
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
+    torch.manual_seed(0)
+    net = CChessNet(cnn_filter_num=128, res_layer_num=7).eval()
+    base = calibration_planes(4096, 14, seed=1)
+    planes = base.repeat((n + 4095) // 4096, 1, 1, 1)[:n].contiguous()
+    out = {}
+    for arith in ariths:
+        g = guarded_inference_net(net, torch.float32, trunk="mfma", arith=arith, guard=False)
+        for _ in range(6):
+            g(planes)
+        g.block_events = []
+        reps = 8
+        for _ in range(reps):
+            g(planes)
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in g.block_events]
+        g.block_events = None
+        per = [sum(ms[i::7]) / reps for i in range(7)]
+        out[arith] = {"per_launch_ms": per, "tower_ms": sum(per)}
+        print(arith, " ".join(f"{x:.3f}" for x in per), f"sum {sum(per):.3f}", flush=True)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
