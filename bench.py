@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", default="normal", choices=["mini", "normal", "deep", "eval"])
     ap.add_argument("--arith", default=None,
-                    help="REQUESTED products of the float32 tower (default: the config's engine.net_arith = c8): c8 = fp16 "
+                    help="REQUESTED products of the float32 tower (default: the config's engine.net_arith = c6: fp16 + two bf6 correction MFMAs): c8 = fp16 "
                          "main term + two scaled-fp8 correction MFMAs, c8>N = the first N blocks on c8, f16x3 / bf16x3 = three "
                          "MFMAs on (hi, lo) fp16 / bf16 pairs.  The engine measures the request against float64 when it loads "
                          "the weights and may fall back (net_arith_effective in the line)")
@@ -640,7 +640,10 @@ def short_selfplay_leg(label, config, seconds, log, games=None, K=None, dtype=No
                                "avg_launch_ms": b_ms, "launches_timed": len(blk), "boards_per_launch": rows_launch,
                                "mfmas_per_product": arith_mfma_equivalents(eng.net_arith_effective, nb) if split else 1,
                                "share_of_step": b_ms * len(blk) / steps / (dt / steps * 1e3)}
-            if getattr(eng.net, "arith", "") == "c8":
+            if getattr(eng.net, "c6", False):
+                rec["roofline"]["arithmetic"] = ("one fp16 MFMA (K = 16) per 16 input channels + two block-scaled bf6 MFMAs "
+                                                 "(K = 64, 32 cycles) per 64: 1.5 bf16-MFMA-equivalents per product")
+            elif getattr(eng.net, "arith", "") == "c8":
                 rec["roofline"]["arithmetic"] = ("one fp16 MFMA (K = 16) per 16 input channels + two block-scaled fp8 MFMAs "
                                                  "(K = 64) per 64: 2.0 bf16-MFMA-equivalents of matrix-pipe time per product")
         else:
@@ -867,7 +870,14 @@ def main():
             "ms_per_step": step_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": net_label + "+f64/i32 tree",
-            "dtype_note": ({"c8": "tower products = f16(w) f16(x) + e4m3(w) e4m3(x - f16(x)) + e4m3(w - f16(w)) e4m3(x), fp32 "
+            "dtype_note": ({"c6": "tower products = f16(w) f16(x) + bf6(w) bf6(x - f16(x)) + bf6(w - f16(w)) bf6(x) (bf6 = e3m2 with a "
+                                  "power-of-two scale per tensor from the load-time calibration), fp32 accumulate: ~2^-15 per "
+                                  "product (c8, the same sum with e4m3 corrections: 2^-16; bf16x3: 2^-17), fp32-class results -- "
+                                  "numerics_check in this line compares the network that just ran with the plain fp32 PyTorch "
+                                  "module (north_star tolerance 1e-4 on policy / value); the request is kept only where the "
+                                  "load-time check against float64 allows (net_arith_guard); strict fp32: "
+                                  "other_configs.normal_strict_fp32_library_trunk",
+                            "c8": "tower products = f16(w) f16(x) + e4m3(w) e4m3(x - f16(x)) + e4m3(w - f16(w)) e4m3(x), fp32 "
                                   "accumulate: 2^-16 per product like the split-bf16 form (three bf16 MFMAs per product, "
                                   "other_configs.normal_bf16x3_tower), fp32-class results -- numerics_check in this line "
                                   "compares the network that just ran with the plain fp32 PyTorch module (north_star "
@@ -952,6 +962,12 @@ def main():
                      "correction terms, fp32 accumulate; the first launch also computes the 5x5 input layer (fp32 gather by its "
                      "copy waves), the last one the fused head convolutions; mean over all launches of the tower"
                      if arith == "c8" else
+                     "k_resblock_c8<.., C6> (csrc/xq_conv.hip, K loop csrc/xq_c8_kloop.h FMT = 1): one residual block (2 x conv3x3 + "
+                     "bias + skip + ReLU) of the tower per launch; every product = one fp16 MFMA term + two block-scaled bf6 (e3m2, "
+                     "K = 64, 32 cycles) correction terms, fp32 accumulate; the first launch also computes the 5x5 input layer (fp32 "
+                     "gather by its copy waves; its first convolution reads that c8 image), the last one the fused head "
+                     "convolutions; mean over all launches of the tower"
+                     if arith == "c6" else
                      "k_resblock_pipe / k_resblock (csrc/xq_conv.hip): one residual block (2 x conv3x3 + "
                      "bias + skip + ReLU) of the tower per launch, split-bf16 operands; the first "
                      "launch also computes the 5x5 input layer (fp32 gather by its copy waves), the "

@@ -317,6 +317,10 @@ class InferenceNet(nn.Module):
         fused = self.fused_blocks and ((c in (128, 192)) or (c == 256 and self.parts == 1))
         # input layer + first block in one launch: 128 filters, split operands, byte planes, a tower of >= 2 blocks
         # (a hybrid tower whose only c8 block is the first hands fp32 over after it: that block stays on cz_resblock)
+        if self.c6 and planes.dtype != torch.uint8:
+            # c6 exists on the fused kernels only, whose input layer is a gather over the OCCUPIED squares of byte planes:
+            # the feature planes are 0 / 1 by construction (environment/static_env.py state_to_planes), in any dtype
+            planes = (planes != 0).to(torch.uint8)
         first_fused = (fused and self.fused_input and c == 128 and self.parts == 2 and nblk >= 2 and
                        planes.dtype == torch.uint8 and n8 != 1)
         if self.c6 and not (first_fused and fused):

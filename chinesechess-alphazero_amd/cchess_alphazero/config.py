@@ -68,11 +68,12 @@ class EngineConfig(_Section):
                          sims_per_round=None,     # lock-step batch per game; None = play.search_threads
                          net_dtype="float32",     # float32 (reference precision) | bfloat16 | float16
                          net_trunk="mfma",        # mfma (hand-written convolution kernel) | library (MIOpen)
-                         net_arith="c8",          # REQUESTED products of the float32 tower: c8 (fp16 + two scaled-fp8
-                                                  # correction MFMAs; 128 filters) | c8>N (first N blocks) | f16x3 | bf16x3
-                                                  # (three MFMAs on fp16 / bf16 pairs); CZ_TOWER_ARITH overrides
+                         net_arith="c6",          # REQUESTED products of the float32 tower: c6 (fp16 + two scaled-bf6
+                                                  # correction MFMAs; 128 filters, >= 2 blocks; elsewhere it means c8) |
+                                                  # c8 (e4m3 corrections; 128 / 192 filters) | c8>N (first N blocks) |
+                                                  # f16x3 | bf16x3 (three MFMAs on fp16 / bf16 pairs); CZ_TOWER_ARITH overrides
                          arith_guard=True,        # measure the request against float64 on calibration positions when
-                                                  # weights are loaded and fall back c8 -> c8>N -> f16x3 -> bf16x3 -> fp32
+                                                  # weights are loaded and fall back c6 -> c8 -> c8>N -> f16x3 -> bf16x3 -> fp32
                                                   # library trunk beyond 5e-5 (agent/model.py guarded_inference_net)
                          max_nodes_per_game=0,    # sizes a game's hash / chunk table; 0 = the longest game's whole tree
                          pool_chunks=0,           # tree memory for all games in MiB; 0 = auto (<= 80 % of free HBM)

@@ -202,7 +202,7 @@ def test_weight_packers_on_the_host():
 
 
 def test_tower_arithmetic_selection_on_the_host(monkeypatch):
-    """engine.net_arith = "c8" is the self-play default; InferenceNet takes the c8 arithmetic only where its kernels exist
+    """engine.net_arith = "c6" is the self-play default (c8 where no c6 kernel exists); InferenceNet takes the c8 arithmetic only where its kernels exist
     (hand-written trunk, float32, 128 filters) and otherwise stays on the bf16 pairs; CZ_TOWER_ARITH overrides the
     configuration; the c8 network packs its block filters with cz_conv3x3_c8_pack_weights (byte count of the C-ABI) and
     its input-layer filters as fp16 pairs.  No GPU: construction and packing only."""
@@ -211,7 +211,7 @@ def test_tower_arithmetic_selection_on_the_host(monkeypatch):
     from cchess_alphazero.agent.model import CChessNet, InferenceNet
     from cchess_alphazero.config import Config
     monkeypatch.delenv("CZ_TOWER_ARITH", raising=False)
-    assert Config("normal").engine.net_arith == "c8"
+    assert Config("normal").engine.net_arith == "c6"          # (bf6 corrections; c8 where no c6 kernel exists)
     net = CChessNet(cnn_filter_num=128, res_layer_num=2)
     inf = InferenceNet(net, torch.float32, trunk="mfma", arith="c8")
     assert inf.arith == "c8" and inf.operand_dtype == torch.float16 and inf.parts == 2
@@ -224,6 +224,21 @@ def test_tower_arithmetic_selection_on_the_host(monkeypatch):
     # (192 filters: c8 since round 4 -- k_resblock_ip_c8; 256 filters have no c8 kernels: the request degrades to the fp16 pairs)
     assert InferenceNet(CChessNet(cnn_filter_num=192, res_layer_num=1), torch.float32, trunk="mfma", arith="c8").arith == "c8"
     assert InferenceNet(CChessNet(cnn_filter_num=256, res_layer_num=1), torch.float32, trunk="mfma", arith="c8").arith == "f16x3"
+    # c6: needs the activation images' exponents (the guard measures them); block 0's first convolution stays a c8 pack
+    # (the fused input layer hands it a c8 image), every other filter carries the exponents of the images it reads / writes
+    import numpy as np
+    import pytest
+    from cchess_alphazero.agent.model import c6_exponents
+    with pytest.raises(ValueError):
+        InferenceNet(net, torch.float32, trunk="mfma", arith="c6")
+    assert c6_exponents([3.0, 28.0, 28.1, 0.2, 500.0]) == ([0, -7], [1, 5])
+    i6 = InferenceNet(net, torch.float32, trunk="mfma", arith="c6", act_exps=([-4, -3], [-2, 1]))
+    assert i6.c6 and i6.arith == "c8" and i6.arith_name == "c6" and i6.c8_blocks == 2
+    tail = lambda t: t.numpy().view(np.uint8)[-16:].view(np.int32).tolist()
+    assert tail(i6.tw0a)[2:] == [0, 0] and (i6.tw0a == inf.tw0a).all()            # c8 pack
+    assert tail(i6.tw0b)[2:] == [-4, -2] and tail(i6.tw1a)[2:] == [-2, -3] and tail(i6.tw1b)[2:] == [-3, 1]
+    assert InferenceNet(CChessNet(cnn_filter_num=192, res_layer_num=2), torch.float32, trunk="mfma", arith="c6").arith_name == "c8"
+    assert InferenceNet(CChessNet(cnn_filter_num=128, res_layer_num=1), torch.float32, trunk="mfma", arith="c6").arith_name == "c8"
     monkeypatch.setenv("CZ_TOWER_ARITH", "c8")
     assert InferenceNet(net, torch.float32, trunk="mfma").arith == "c8"
     monkeypatch.setenv("CZ_TOWER_ARITH", "bf16x3")
@@ -307,6 +322,8 @@ def test_guard_chain_orders_the_candidates_by_exactness():
     activation ranges (c8 image saturates at 448, fp16 pairs overflow at 65504)."""
     from cchess_alphazero.agent.model import guard_chain
     assert guard_chain("c8", 7, 7, [3.0, 9.5]) == ["c8", "c8>5", "c8>3", "f16x3", "bf16x3"]
+    assert guard_chain("c6", 7, 7, [3.0, 9.5]) == ["c6", "c8", "c8>5", "c8>3", "f16x3", "bf16x3"]
+    assert guard_chain("c6", 7, 7, [3.0, 500.0]) == ["c6", "f16x3", "bf16x3"]     # (bf6 images carry their own exponents)
     assert guard_chain("c8", 5, 7, [3.0]) == ["c8>5", "c8>3", "c8>1", "f16x3", "bf16x3"]
     assert guard_chain("c8", 2, 2, [1.0]) == ["c8", "f16x3", "bf16x3"]
     assert guard_chain("c8", 7, 7, [3.0, 500.0]) == ["f16x3", "bf16x3"]
@@ -383,6 +400,7 @@ def test_bench_arithmetic_labels():
     assert bench.arith_label("c8") == "f16+2xfp8corr-split/f32acc" and bench.arith_label("f16x3") == "f16x3-split/f32acc"
     assert "first 5 blocks" in bench.arith_label("c8>5") and bench.arith_label(None) is None
     assert bench.arith_mfma_equivalents("c8", 7) == 2.0 and bench.arith_mfma_equivalents("bf16x3", 7) == 3.0
+    assert bench.arith_label("c6") == "f16+2xbf6corr-split/f32acc" and abs(bench.arith_mfma_equivalents("c6", 7) - 21.5 / 14) < 1e-12
     assert abs(bench.arith_mfma_equivalents("c8>5", 7) - (2.0 * 5 + 3.0 * 2) / 7) < 1e-12
     assert bench.arith_mfma_equivalents("fp32-library", 7) == 1.0
 
