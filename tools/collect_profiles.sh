@@ -16,6 +16,8 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_A
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_grbm" -o p -- $BENCH > /dev/null 2> "$OUT/pmc_grbm.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o p -- $BENCH > /dev/null 2> "$OUT/pmc_fetch.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o p -- $BENCH > /dev/null 2> "$OUT/pmc_write.err"
-# keep the merged-back payload small: the per-dispatch trace is not needed, the counter tables are
+# summarise on the box (the counter tables of one pass exceed what gpurun carries back) and keep the payload small
+python $ROOT/tools/summarize_profiles.py --round ${ROUND:-4} --src "$OUT" --out $ROOT/gpurun_out/profiles_summary
 find "$OUT" -name '*kernel_trace.csv' -size +20M -delete
+find "$OUT" -name '*counter_collection.csv' -size +8M -delete
 ls -la "$OUT" "$OUT"/*/ 2>/dev/null | head -40

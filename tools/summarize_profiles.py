@@ -101,9 +101,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--round", type=int, default=1)
     ap.add_argument("--src", default=os.path.join(ROOT, "gpurun_out", "prof"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles"),
+                    help="where to write (on the GPU box: a directory under gpurun_out/, so that the raw counter tables need not travel)")
     a = ap.parse_args()
     tag = f"r{a.round:02d}"
-    prof = os.path.join(ROOT, "profiles")
+    prof = a.out
+    os.makedirs(prof, exist_ok=True)
 
     # ---- 1. kernel stats ----
     sf = glob.glob(os.path.join(a.src, "stats", "**", "*kernel_stats.csv"), recursive=True)
@@ -210,8 +213,9 @@ def main():
             d["hbm_bytes_per_launch"] = (2 * fk[k]["FETCH_SIZE"] + wk[k]["WRITE_SIZE"]) * 1024.0
         nn[k] = d
     if nn:
-        out = {"workload": "bench.py normal config: 32768 boards per launch, 7x128 network, default tower arithmetic (c8: "
-                           "k_resblock covers the k_resblock_c8 launches -- plain, fused input layer, fused heads)",
+        out = {"workload": "bench.py normal config: 32768 boards per launch, 7x128 network, default tower arithmetic (c6 since the end "
+                           "of round 4, c8 in profiles/r04_c8_*: k_resblock covers the k_resblock_c8<FIRST, HEADS, C6> launches -- "
+                           "plain, fused input layer, fused heads -- including the load-time guard's 256-board calibration launches)",
                "method": "rocprofv3 --pmc passes of tools/collect_profiles.sh (SQ set, GRBM_GUI_ACTIVE, FETCH_SIZE, "
                          "WRITE_SIZE: one run each); means per launch, first 2 launches of each kernel excluded",
                "mfma_util_definition": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs)",
