@@ -1,5 +1,6 @@
-// xq_c8_kloop.h -- the K loop of the c8 tower arithmetic (round 4), shared by csrc/xq_conv.hip (k_conv3x3_c8, the c8
-// residual-block kernels) and tools/probes/c8_kloop_probe.hip (which times exactly this instruction stream).
+// xq_c8_kloop.h -- the K loop of the c8 tower arithmetic (round 4) and of c6, its sibling with bf6 correction operands
+// (FMT = 1, at the kloop template below), shared by csrc/xq_conv.hip (k_conv3x3_c8, the c8 / c6 residual-block kernels)
+// and tools/probes/c8_kloop_probe.hip (which times exactly this instruction stream).
 //
 // One call = 9 taps x 128 input channels for the 32 output channels of this wave and NT pixel tiles of 32 of an LDS
 // image; per 64-channel block  two fp16 K-steps -> the block's e4m3(w) x_lo8 MFMAs (K = 64) -> two fp16 K-steps -> its

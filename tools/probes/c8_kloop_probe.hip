@@ -8,6 +8,8 @@
 // addressing (swizzled rows, zero rows, tap shifts), filter fragments streamed from L2 -- for CTW = 1 and CTW = 2 channel
 // tiles per wave, back to back K loops without epilogues, 4 waves per CU on all CUs for a few seconds, and prints the
 // time per unit of matrix work (one channel tile x three pixel tiles x 9 taps x 128 input channels = 324 MFMA slots).
+// Round 4 added: the product's loop (csrc/xq_c8_kloop.h) with s_memtime around it, its variants without filter loads / LDS
+// reads, six pixel tiles per filter fragment, and the c6 form (bf6 correction operands: FMT = 1).
 //     hipcc --offload-arch=gfx950 -O3 tools/probes/c8_kloop_probe.hip -o tools/probes/c8_kloop_probe
 //     tools/probes/c8_kloop_probe [seconds]
 #include <hip/hip_runtime.h>
