@@ -249,7 +249,8 @@ int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_packed, const
                 const float* bias2, void* y_hi, void* y_lo, float* y_f32, int n_boards, int channels, int dtype,
                 int parts, void* stream);
 /* The c8 tower arithmetic (csrc/xq_conv.hip, k_conv3x3_c8 / k_resblock_c8 / k_resblock_ip_c8, K loop csrc/xq_c8_kloop.h;
- * DESIGN section 7b; what the self-play engine REQUESTS by default and keeps where its load-time check against float64
+ * DESIGN section 7b; what the self-play engine requested by default until the end of round 4 -- now its bf6 sibling c6, below, with c8
+ * next in the guard's chain -- and keeps where its load-time check against float64
  * allows -- a host binding these entry points directly owns that check): one 3x3 convolution, 128 or 192
  * filters (the shapes below are for 128), computed as  f16(w) f16(x) + e4m3(w) e4m3(x - f16(x)) + e4m3(w - f16(w)) e4m3(x)  (one fp16 and two block-scaled
  * fp8 matrix instructions per 64 input channels instead of three bf16 ones).  x_hi: f16 [n][90][128]; x_c8: bytes
