@@ -64,7 +64,7 @@ struct Filter {
     int lane_main;      // byte offset of this lane inside a K-step of fp16 fragments
     int lane_c8;        // byte offset of this lane inside a (block, kind) group of c8 pieces, counted from the c8 base
     int lane_c6t;       // c6 pieces (24 bytes): the 8-byte tails sit densely behind the 16-byte heads of the group
-    int scale_w_hi, scale_w_lo;      // E8M0 scale bytes of the two correction MFMAs (127 - shift)
+    int scale_w_hi, scale_w_lo;      // E8M0 scale bytes of the two correction MFMAs (127 - shift), per lane: this row's
 };
 
 template <int CH = 128>
@@ -76,9 +76,12 @@ __device__ __forceinline__ Filter make_filter(const void* packed, int wave, int 
     f.lane_main = wave * 1024 + lane * 16;
     f.lane_c8 = MAIN_U4 * 16 + wave * 2048 + lane * 16;
     f.lane_c6t = MAIN_U4 * 16 + wave * 2048 + 1024 + lane * 8;
-    const int* sc = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(packed) + MAIN_U4 + C8_U4);
-    f.scale_w_hi = 127 - __builtin_amdgcn_readfirstlane(sc[0]);
-    f.scale_w_lo = 127 - __builtin_amdgcn_readfirstlane(sc[1]);
+    // the correction operands' shifts, one pair per OUTPUT CHANNEL (the matrix instruction reads the A operand's E8M0 scale
+    // per lane = per row): 2 x CH signed bytes behind the 16-byte block of ints, this lane's row = wave * 32 + (lane & 31)
+    const signed char* rs = reinterpret_cast<const signed char*>(reinterpret_cast<const uint4*>(packed) + MAIN_U4 + C8_U4 + 1);
+    const int row = wave * 32 + (lane & 31);
+    f.scale_w_hi = 127 - (int)rs[row];
+    f.scale_w_lo = 127 - (int)rs[CH + row];
     return f;
 }
 

@@ -2584,6 +2584,30 @@ inline int pow2_shift_for(float amax, int top)                     // s with ama
     frexpf(amax, &e);
     return top - (e - 1);
 }
+// Per-OUTPUT-CHANNEL shifts of the two correction operands of a filter [C][C][3][3]: out[o] for w, out[C + o] for
+// w - f16(w), each the power of two that brings the row's largest magnitude into [2^top, 2^(top + 1)) (clamped to a signed
+// byte; an all-zero row: 0).  ints[0], ints[1]: the smallest of each kind (the shift a single scale per tensor would be).
+inline void row_shifts(const float* w_oihw, int C, int top, int8_t* out, int32_t* ints)
+{
+    int min_h = 127, min_l = 127;
+    for (int o = 0; o < C; ++o) {
+        float wmax = 0.0f, lmax = 0.0f;
+        for (size_t i = 0; i < (size_t)C * 9; ++i) {
+            const float w = w_oihw[(size_t)o * C * 9 + i], l = w - f16_bits_to_f32(f32_to_f16_bits(w));
+            wmax = fabsf(w) > wmax ? fabsf(w) : wmax;
+            lmax = fabsf(l) > lmax ? fabsf(l) : lmax;
+        }
+        int sh = pow2_shift_for(wmax, top), sl = pow2_shift_for(lmax, top);
+        sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+        sl = sl > 100 ? 100 : (sl < -100 ? -100 : sl);
+        out[o] = (int8_t)sh;
+        out[C + o] = (int8_t)sl;
+        if (wmax > 0.0f && sh < min_h) min_h = sh;
+        if (lmax > 0.0f && sl < min_l) min_l = sl;
+    }
+    ints[0] = min_h == 127 ? 0 : min_h;
+    ints[1] = min_l == 127 ? 0 : min_l;
+}
 }  // namespace
 
 extern "C" size_t cz_conv3x3_c8_packed_bytes(int channels)
@@ -2591,7 +2615,7 @@ extern "C" size_t cz_conv3x3_c8_packed_bytes(int channels)
     if (channels != 128 && channels != 192) return 0;
     const size_t C = channels, KK = C / 16, CT = C / 32, NB = C / 64;
     const size_t main_u4 = (9 * KK + W_PAD_STEPS) * CT * 64, c8_u4 = (9 * NB + 1) * 2 * CT * 2 * 64;
-    return (main_u4 + c8_u4 + 1) * 16;
+    return (main_u4 + c8_u4 + 1) * 16 + 2 * C;          // fragments, 4 ints, 2 x C per-output-channel shifts (signed bytes)
 }
 
 extern "C" int cz_conv3x3_c8_pack_weights(const float* w_oihw, int channels, void* out_host)
@@ -2602,19 +2626,12 @@ extern "C" int cz_conv3x3_c8_pack_weights(const float* w_oihw, int channels, voi
     }
     const int C = channels, KK = C / 16, CT = C / 32, NB = C / 64;
     const size_t main_u4 = (size_t)(9 * KK + W_PAD_STEPS) * CT * 64, c8_u4 = (size_t)(9 * NB + 1) * 2 * CT * 2 * 64;
-    memset(out_host, 0, (main_u4 + c8_u4 + 1) * 16);
+    memset(out_host, 0, (main_u4 + c8_u4 + 1) * 16 + 2 * (size_t)C);
     uint16_t* hi = (uint16_t*)out_host;
     uint8_t* c8p = (uint8_t*)out_host + main_u4 * 16;
     int32_t* sc = (int32_t*)((uint8_t*)out_host + (main_u4 + c8_u4) * 16);
-    float wmax = 0.0f, lmax = 0.0f;
-    for (size_t i = 0; i < (size_t)C * C * 9; ++i) {
-        const float w = w_oihw[i], l = w - f16_bits_to_f32(f32_to_f16_bits(w));
-        wmax = fabsf(w) > wmax ? fabsf(w) : wmax;
-        lmax = fabsf(l) > lmax ? fabsf(l) : lmax;
-    }
-    const int sh = pow2_shift_for(wmax, 7), sl = pow2_shift_for(lmax, 7);      // largest magnitude in [128, 256): below 448
-    sc[0] = sh;
-    sc[1] = sl;
+    int8_t* row_sh = (int8_t*)(sc + 4);                  // per output channel: shift of e4m3(w), then (row_sh + C) of e4m3(w - f16(w))
+    row_shifts(w_oihw, C, 7, row_sh, sc);                // largest magnitude of a row in [128, 256): below 448
     for (int tap = 0; tap < 9; ++tap)
         for (int ct = 0; ct < CT; ++ct)
             for (int lane = 0; lane < 64; ++lane) {
@@ -2630,7 +2647,7 @@ extern "C" int cz_conv3x3_c8_pack_weights(const float* w_oihw, int channels, voi
                         for (int j = 0; j < 32; ++j) {
                             const int c = b * 64 + (lane >> 5) * 32 + j;
                             const float w = w_oihw[((size_t)o * C + c) * 9 + tap];
-                            const float v = q == 0 ? ldexpf(w, sh) : ldexpf(w - f16_bits_to_f32(f32_to_f16_bits(w)), sl);
+                            const float v = q == 0 ? ldexpf(w, row_sh[o]) : ldexpf(w - f16_bits_to_f32(f32_to_f16_bits(w)), row_sh[C + o]);
                             const size_t u4 = ((((size_t)(tap * NB + b) * 2 + q) * CT + ct) * 2 + j / 16) * 64 + lane;
                             c8p[u4 * 16 + j % 16] = f32_to_e4m3_bits(v);
                         }
@@ -2652,19 +2669,12 @@ extern "C" int cz_conv3x3_c6_pack_weights(const float* w_oihw, int channels, int
     }
     const int C = channels, KK = C / 16, CT = C / 32, NB = C / 64;
     const size_t main_u4 = (size_t)(9 * KK + W_PAD_STEPS) * CT * 64, c8_u4 = (size_t)(9 * NB + 1) * 2 * CT * 2 * 64;
-    memset(out_host, 0, (main_u4 + c8_u4 + 1) * 16);
+    memset(out_host, 0, (main_u4 + c8_u4 + 1) * 16 + 2 * (size_t)C);
     uint16_t* hi = (uint16_t*)out_host;
     uint8_t* c6p = (uint8_t*)out_host + main_u4 * 16;
     int32_t* sc = (int32_t*)((uint8_t*)out_host + (main_u4 + c8_u4) * 16);
-    float wmax = 0.0f, lmax = 0.0f;
-    for (size_t i = 0; i < (size_t)C * C * 9; ++i) {
-        const float w = w_oihw[i], l = w - f16_bits_to_f32(f32_to_f16_bits(w));
-        wmax = fabsf(w) > wmax ? fabsf(w) : wmax;
-        lmax = fabsf(l) > lmax ? fabsf(l) : lmax;
-    }
-    const int sh = pow2_shift_for(wmax, 3), sl = pow2_shift_for(lmax, 3);
-    sc[0] = sh;
-    sc[1] = sl;
+    int8_t* row_sh = (int8_t*)(sc + 4);
+    row_shifts(w_oihw, C, 3, row_sh, sc);                // largest magnitude of a row in [8, 16): bf6 saturates at 28
     sc[2] = x_exp;
     sc[3] = y_exp;
     for (int tap = 0; tap < 9; ++tap)
@@ -2683,7 +2693,7 @@ extern "C" int cz_conv3x3_c6_pack_weights(const float* w_oihw, int channels, int
                         for (int e = 0; e < 32; ++e) {
                             const int c = b * 64 + (lane >> 5) * 32 + 8 * (e >> 3) + ((e >> 1) & 3) + 4 * (e & 1);
                             const float w = w_oihw[((size_t)o * C + c) * 9 + tap];
-                            const float v = q == 0 ? ldexpf(w, sh) : ldexpf(w - f16_bits_to_f32(f32_to_f16_bits(w)), sl);
+                            const float v = q == 0 ? ldexpf(w, row_sh[o]) : ldexpf(w - f16_bits_to_f32(f32_to_f16_bits(w)), row_sh[C + o]);
                             const uint32_t code = f32_to_bf6_bits(v);
                             const int bit = 6 * e;
                             piece[bit >> 3] |= (uint8_t)(code << (bit & 7));

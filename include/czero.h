@@ -260,6 +260,10 @@ int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_packed, const
  * Reference arithmetic: Keras float32 (agent/model.py:32-83); per-product accuracy ~2^-16 (the split-bf16 form: 2^-17; the
  * fp16 pairs: 2^-21), two thirds of their matrix-pipe time.  Activations above 448 lose the w_lo x correction (e4m3
  * saturates): scale the folded network by a power of two first (agent/model.py choose_act_shift). */
+/* Packed filter = fp16 fragments, correction fragments, 4 ints, then 2 x channels signed bytes: the correction operands'
+ * power-of-two shifts PER OUTPUT CHANNEL (e4m3(w 2^s) with the row's largest magnitude in [128, 256), the same for
+ * w - f16(w); c6: bf6, [8, 16)) -- the matrix instruction takes the filter operand's scale per row, so channels of very
+ * different magnitude (folded BatchNorm scales) all keep their correction precision. */
 size_t cz_conv3x3_c8_packed_bytes(int channels);
 int cz_conv3x3_c8_pack_weights(const float* w_oihw, int channels, void* out_host);
 int cz_conv3x3_c8(const void* x_hi, const void* x_c8, const void* w_packed, const float* bias,

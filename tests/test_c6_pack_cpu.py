@@ -47,13 +47,17 @@ def test_c6_weight_pack_layout_and_bf6_rounding():
     pk = _native.pack_conv3x3_c6_weights(w, -2, 3).numpy()
     main_u4 = (9 * KK + W_PAD_STEPS) * CT * 64
     c8_u4 = (9 * NB + 1) * 2 * CT * 2 * 64
-    assert pk.size == (main_u4 + c8_u4 + 1) * 16
-    tail = pk[(main_u4 + c8_u4) * 16:].view(np.int32)
-    sh, sl, x_exp, y_exp = (int(v) for v in tail)
+    assert pk.size == (main_u4 + c8_u4 + 1) * 16 + 2 * C
+    tail = pk[(main_u4 + c8_u4) * 16:(main_u4 + c8_u4 + 1) * 16].view(np.int32)
+    _, _, x_exp, y_exp = (int(v) for v in tail)
     assert (x_exp, y_exp) == (-2, 3)
+    rows = pk[(main_u4 + c8_u4 + 1) * 16:].view(np.int8).astype(np.int64)
+    sh, sl = rows[:C], rows[C:]                                  # one shift per OUTPUT CHANNEL and kind
     wn = w.numpy().astype(np.float64)
     wh = w.half().float().numpy().astype(np.float64)
-    assert 8.0 <= np.abs(wn).max() * 2.0 ** sh < 16.0 and 8.0 <= np.abs(wn - wh).max() * 2.0 ** sl < 16.0
+    rmax, lmax = np.abs(wn).reshape(C, -1).max(1), np.abs(wn - wh).reshape(C, -1).max(1)
+    assert ((rmax * 2.0 ** sh >= 8) & (rmax * 2.0 ** sh < 16) & (lmax * 2.0 ** sl >= 8) & (lmax * 2.0 ** sl < 16)).all()
+    assert len(set(sh.tolist())) > 1                             # (row 3 holds the 0.9: its shift differs from the others')
     # the fp16 fragments are the c8 pack's
     ref8 = _native.pack_conv3x3_c8_weights(w).numpy()
     assert (pk[:main_u4 * 16] == ref8[:main_u4 * 16]).all()
@@ -68,7 +72,7 @@ def test_c6_weight_pack_layout_and_bf6_rounding():
         for e in range(32):
             code = (bits >> (6 * e)) & 63
             c = b * 64 + (lane >> 5) * 32 + channel_of(e)
-            src = wn[o, c, ky, kx] * 2.0 ** sh if q == 0 else (wn[o, c, ky, kx] - wh[o, c, ky, kx]) * 2.0 ** sl
+            src = wn[o, c, ky, kx] * 2.0 ** sh[o] if q == 0 else (wn[o, c, ky, kx] - wh[o, c, ky, kx]) * 2.0 ** sl[o]
             want = float(bf6_round(np.array([src]))[0])
             assert bf6_value(code) == want, (tap, ct, lane, b, q, e, src, bf6_value(code), want)
     # the tails of a group sit densely behind its heads: bytes [1024 + 512, 2048) of a group stay zero
@@ -86,10 +90,10 @@ def test_bf6_conversion_on_a_sweep():
     vals = vals[:96]                                             # (three 32-blocks of channels 0 .. 127 are enough)
     w = torch.zeros(128, 128, 3, 3)
     w[0, :len(vals), 0, 0] = torch.tensor(vals) / 2.0            # largest 14 -> shift 0 would put 27.9 / 2 < 16: sh = 0
-    w[0, 127, 0, 0] = -15.0                                      # fixes sh = 0 ([8, 16))
+    w[0, 127, 0, 0] = -15.0                                      # fixes row 0's shift at 0 ([8, 16))
     pk = _native.pack_conv3x3_c6_weights(w, 0, 0).numpy()
     main_u4 = (9 * 8 + W_PAD_STEPS) * 4 * 64
-    sh = int(pk[(main_u4 + (9 * 2 + 1) * 2 * 4 * 2 * 64) * 16:].view(np.int32)[0])
+    sh = int(pk[(main_u4 + (9 * 2 + 1) * 2 * 4 * 2 * 64 + 1) * 16:].view(np.int8)[0])
     assert sh == 0
     c6 = pk[main_u4 * 16:]
     got = {}

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "chinesechess-alphazero_amd"))
 
 def decode_c8_pack(packed, c=128):
     """-> (w_hi [o, c, 9] float32 from the f16 fragments, w_k0 / w_k1 [o, c, 9] float32 from the e4m3 fragments (still
-    scaled), sh, sl): the inverse of the layout cz_conv3x3_c8_pack_weights documents."""
+    scaled), sh [o], sl [o]: the per-output-channel shifts): the inverse of the layout cz_conv3x3_c8_pack_weights documents."""
     import torch
     kk_n, ct_n, nb = c // 16, c // 32, c // 64
     main_u4 = (9 * kk_n + 3) * ct_n * 64
@@ -21,7 +21,11 @@ def decode_c8_pack(packed, c=128):
     hi = torch.from_numpy(raw[:main_u4 * 16].copy()).view(torch.float16).float().numpy().reshape(-1, ct_n, 64, 8)
     f8 = torch.from_numpy(raw[main_u4 * 16:(main_u4 + c8_u4) * 16].copy()).view(torch.float8_e4m3fn).float().numpy()
     f8 = f8.reshape(9 * nb + 1, 2, ct_n, 2, 64, 16)
-    sc = raw[(main_u4 + c8_u4) * 16:].view(np.int32)
+    sc = raw[(main_u4 + c8_u4) * 16:(main_u4 + c8_u4 + 1) * 16].view(np.int32)
+    rows = raw[(main_u4 + c8_u4 + 1) * 16:].view(np.int8).astype(np.int64)
+    assert rows.size == 2 * c
+    sh, sl = rows[:c], rows[c:]
+    assert int(sc[0]) <= int(sh.max()) and int(sc[1]) <= int(sl.max())        # (ints 0 / 1: the smallest row shifts, informational)
     w_hi = np.zeros((c, c, 9), np.float32)
     w_k = np.zeros((2, c, c, 9), np.float32)
     for tap in range(9):
@@ -35,7 +39,7 @@ def decode_c8_pack(packed, c=128):
                         c0 = b * 64 + (lane >> 5) * 32
                         w_k[q, o, c0:c0 + 32, tap] = f8[tap * nb + b, q, ct, :, lane, :].reshape(32)
     assert not f8[9 * nb].any() and not hi[9 * kk_n:].any()            # the prefetch padding is zero
-    return w_hi, w_k[0], w_k[1], int(sc[0]), int(sc[1])
+    return w_hi, w_k[0], w_k[1], sh, sl
 
 
 def test_c8_weight_pack_layout_and_e4m3_rounding():
@@ -50,16 +54,19 @@ def test_c8_weight_pack_layout_and_e4m3_rounding():
     w_hi, k0, k1, sh, sl = decode_c8_pack(packed)
     w3 = w.reshape(128, 128, 9)
     assert np.array_equal(w_hi, w3.half().float().numpy())
-    assert 128 <= float(w.abs().max()) * 2.0 ** sh < 256
     lo = w3 - w3.half().float()
-    assert 128 <= float(lo.abs().max()) * 2.0 ** sl < 256
-    want0 = (w3 * 2.0 ** sh).to(torch.float8_e4m3fn).float().numpy()
-    want1 = (lo * 2.0 ** sl).to(torch.float8_e4m3fn).float().numpy()
+    # one shift per OUTPUT CHANNEL and kind: the row's largest magnitude lands in [128, 256)
+    f = lambda a: torch.from_numpy(2.0 ** a.astype(np.float64)).float().view(128, 1, 1)
+    rmax, lmax = w3.abs().amax((1, 2)), lo.abs().amax((1, 2))
+    assert ((rmax * f(sh).view(-1) >= 128) & (rmax * f(sh).view(-1) < 256)).all()
+    assert ((lmax * f(sl).view(-1) >= 128) & (lmax * f(sl).view(-1) < 256)).all()
+    want0 = (w3 * f(sh)).to(torch.float8_e4m3fn).float().numpy()
+    want1 = (lo * f(sl)).to(torch.float8_e4m3fn).float().numpy()
     assert np.array_equal(k0, want0)
     assert np.array_equal(k1, want1)
-    # what the three terms reconstruct: w to 2^-16-ish of the largest weight
-    rec = w_hi + k1 * 2.0 ** -sl
-    assert np.abs(rec - w3.numpy()).max() <= 2.0 ** -4 * np.abs(lo.numpy()).max() + 1e-12
+    # what the three terms reconstruct: w to 2^-16-ish of the ROW's largest weight
+    rec = w_hi + k1 / f(sl).numpy()
+    assert (np.abs(rec - w3.numpy()).reshape(128, -1).max(1) <= 2.0 ** -4 * lmax.numpy() + 1e-12).all()
 
 
 def test_e4m3_conversion_matches_torch_on_a_sweep():
@@ -77,5 +84,6 @@ def test_e4m3_conversion_matches_torch_on_a_sweep():
     w = w.reshape(128, 128, 3, 3)
     packed = _native.pack_conv3x3_c8_weights(w)
     _, k0, _, sh, _ = decode_c8_pack(packed)
-    scaled = (w.reshape(128, 128, 9) * 2.0 ** sh).clamp(-448, 448)
+    # (per-row shifts since the end of round 4: every row's own largest magnitude lands in [128, 256))
+    scaled = (w.reshape(128, 128, 9) * torch.from_numpy(2.0 ** sh.astype(np.float64)).float().view(128, 1, 1)).clamp(-448, 448)
     assert np.array_equal(k0, scaled.to(torch.float8_e4m3fn).float().numpy())

@@ -132,8 +132,15 @@ def test_conv3x3_c8_matches_its_operands_and_the_float64_convolution(n, c):
     x = (torch.randn((n, 90, c), device="cuda", generator=g) * 1.5).relu()
     x[0, 0, :4] = torch.tensor([300.0, 2e-3, 5e-5, 0.0], device="cuda")           # large / tiny activations
     w = torch.randn((c, c, 3, 3), device="cuda", generator=g) / (3.0 * c ** 0.5)
+    # output channels of very different magnitude (folded BatchNorm scales): every row has its own correction shifts, which
+    # the matrix instruction must take per lane
+    w[::3] *= 0.004
+    w[1::7] *= 50.0
     bias = torch.randn((c,), device="cuda", generator=g)
+    bias[::3] *= 0.004                                     # (the accumulators start at the bias: a bias far above a row's
+    bias[1::7] *= 50.0                                     #  products would set the fp32 rounding floor of that row)
     packed = _native.pack_conv3x3_c8_weights(w)
+    assert len(set(decode_c8_pack(packed, c)[3].tolist())) >= 3
     x_hi, x_c8 = _native.split_c8(x)
     out = torch.full((n, 90, c), 7.0, device="cuda")
     _native.conv3x3_c8((x_hi, x_c8), packed.cuda(), bias, out_f32=out, relu=False)
@@ -146,7 +153,8 @@ def test_conv3x3_c8_matches_its_operands_and_the_float64_convolution(n, c):
     l8 = x_c8[..., :c].contiguous().view(torch.float8_e4m3fn).to(d)
     h8 = x_c8[..., c:].contiguous().view(torch.float8_e4m3fn).to(d)
     main = conv(img(x_hi), tw(w_hi))
-    corr = conv(img(l8), tw(k0)) * 2.0 ** (-sh - _native.C8_X_LO_SHIFT) + conv(img(h8), tw(k1)) * 2.0 ** (-sl)
+    row = lambda a: torch.from_numpy(2.0 ** (-a.astype(np.float64))).to("cuda", d).view(1, 1, c)       # per output channel
+    corr = conv(img(l8), tw(k0)) * row(sh) * 2.0 ** -_native.C8_X_LO_SHIFT + conv(img(h8), tw(k1)) * row(sl)
     want_ops = main + corr + bias.to(d)
     mag = conv(img(x_hi).abs(), tw(w_hi).abs()) + 1e-30
     err_ops = ((out.to(d) - want_ops).abs() / mag).max().item()

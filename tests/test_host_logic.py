@@ -234,7 +234,7 @@ def test_tower_arithmetic_selection_on_the_host(monkeypatch):
     assert c6_exponents([3.0, 28.0, 28.1, 0.2, 500.0]) == ([0, -7], [1, 5])
     i6 = InferenceNet(net, torch.float32, trunk="mfma", arith="c6", act_exps=([-4, -3], [-2, 1]))
     assert i6.c6 and i6.arith == "c8" and i6.arith_name == "c6" and i6.c8_blocks == 2
-    tail = lambda t: t.numpy().view(np.uint8)[-16:].view(np.int32).tolist()
+    tail = lambda t: t.numpy().view(np.uint8)[-16 - 2 * 128:-2 * 128].view(np.int32).tolist()    # (4 ints, then 2 x 128 row shifts)
     assert tail(i6.tw0a)[2:] == [0, 0] and (i6.tw0a == inf.tw0a).all()            # c8 pack
     assert tail(i6.tw0b)[2:] == [-4, -2] and tail(i6.tw1a)[2:] == [-2, -3] and tail(i6.tw1b)[2:] == [-3, 1]
     assert InferenceNet(CChessNet(cnn_filter_num=192, res_layer_num=2), torch.float32, trunk="mfma", arith="c6").arith_name == "c8"
@@ -243,7 +243,7 @@ def test_tower_arithmetic_selection_on_the_host(monkeypatch):
     assert InferenceNet(net, torch.float32, trunk="mfma").arith == "c8"
     monkeypatch.setenv("CZ_TOWER_ARITH", "bf16x3")
     assert InferenceNet(net, torch.float32, trunk="mfma").arith == "bf16x3"
-    assert _native.lib().cz_conv3x3_c8_packed_bytes(192) == ((9 * 12 + 3) * 6 * 64 + (9 * 3 + 1) * 2 * 6 * 2 * 64 + 1) * 16
+    assert _native.lib().cz_conv3x3_c8_packed_bytes(192) == ((9 * 12 + 3) * 6 * 64 + (9 * 3 + 1) * 2 * 6 * 2 * 64 + 1) * 16 + 2 * 192
     assert _native.lib().cz_conv3x3_c8_packed_bytes(256) == 0
     with pytest.raises(_native.NativeError):
         _native.pack_conv3x3_c8_weights(torch.randn(256, 256, 3, 3))

@@ -269,7 +269,7 @@ int main(int argc, char** argv)
     CK(hipMemcpy(dimg, img.data(), REGION, hipMemcpyHostToDevice));
     {
         // the product's loop: packed filter = fp16 fragments, c8 pieces, the two scale exponents
-        std::vector<uint8_t> pk((size_t)(c8k::MAIN_U4 + c8k::C8_U4 + 1) * 16, 0);
+        std::vector<uint8_t> pk((size_t)(c8k::MAIN_U4 + c8k::C8_U4 + 1) * 16 + 2 * 128, 0);     // (+ the per-row shifts)
         for (size_t i = 0; i < (size_t)c8k::MAIN_U4 * 8; ++i) memcpy(&pk[2 * i], &wm[i % wm.size()], 2);
         for (size_t i = 0; i < (size_t)c8k::C8_U4 * 16; ++i) pk[(size_t)c8k::MAIN_U4 * 16 + i] = wc[i % wc.size()];
         uint4* dpk;
