@@ -985,14 +985,18 @@ def main():
                                "library_gemm_bf16_tflops": library_gemm_peak(),
                                "share_of_round": b_ms * len(blk) / args.steps / step_ms,
                                "note": "achieved = fp32-class convolution FLOPs (2 per MAC) / launch time; every product "
-                                       "occupies the matrix pipes for mfma_equivalents_per_product bf16-MFMA units (c8: one "
-                                       "fp16 MFMA + two fp8 MFMAs at twice the rate = 2.0; bf16x3: 3.0) over 96 pixel slots "
+                                       "occupies the matrix pipes for mfma_equivalents_per_product bf16-MFMA units (c6: one "
+                                       "fp16 MFMA + two bf6 MFMAs at four times the rate = 1.5, 1.54 over the tower with the first "
+                                       "convolution on c8; c8: one fp16 + two e4m3 MFMAs at twice the rate = 2.0; bf16x3: 3.0) over 96 pixel slots "
                                        "per 90-pixel board, hence issued_bf16_tflops = that x 96/90 x achieved; against the "
                                        "fp32 matrix peak (157.3 TFLOP/s) the same number is > 1; the chip runs this kernel at "
                                        "its 1.4 kW power cap (profiles/r03_clock_power*.json), not the 2.4 GHz the nominal peak "
                                        "assumes: in shader cycles the c8 K loop runs at 88 % of its MFMA floor (15.7 k cycles per "
                                        "13.8 k of matrix work, profiles/r04_c8_kloop_probe.log), the clock it is granted is "
-                                       "1.5-1.8 GHz (in-kernel cycle stamps: profiles/r04_rb_stamps.json)"}
+                                       "1.5-1.8 GHz (in-kernel cycle stamps: profiles/r04_rb_stamps.json); c6: 13.0 k cycles per 10.4 k "
+                                       "of matrix work, and the filter stream (576 KB per board and convolution through the CU's "
+                                       "64 B/clk vector-memory path) as the second limit (profiles/r04_c6_kloop_probe.log, "
+                                       "r04_c6_rb_stamps.json, r04_clock_power_c6_vs_c8.json)"}
         else:
             out["roofline"] = out.get("roofline_search")
         if sus is not None:
