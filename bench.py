@@ -61,6 +61,97 @@ class _stdout_to_stderr:
         return False
 
 
+FULL_RECORD = "bench_full.json"
+COMPACT_LIMIT = 4096
+
+
+def _r(x, digits=6):
+    """floats of the compact line: 6 significant digits"""
+    return float(f"{x:.{digits}g}") if isinstance(x, float) else x
+
+
+def compact_line(out):
+    """The ONE stdout line (the driver parses the last stdout line and its reader is bounded -- round 4's
+    30 KB line came back `parsed: null`): the contract's keys, `roofline` and `cpu_baseline` with short strings only, and the
+    handful of scalars a reader needs beside them.  Everything else (other_configs, guard report, tree shape, sustained
+    detail, micro-suite, the long kernel descriptions) goes to bench_full.json next to this script (+ gpurun_out/) and to
+    stderr.  Kept below COMPACT_LIMIT bytes (tests/test_host_logic.py::test_bench_line_is_compact)."""
+    def pick(d, keys):
+        return {k: _r(d[k]) for k in keys if d is not None and k in d and d[k] is not None}
+    c = {k: _r(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    if out.get("per_rank_value") is not None:
+        c["per_rank_value"] = [_r(float(v)) for v in out["per_rank_value"]]
+    cfg = out.get("config") or {}
+    c["config"] = pick(cfg, ("workload", "games_per_gpu", "games", "sims_per_round", "queue_slots_per_gpu", "parallelism"))
+    if "workload" in c["config"]:
+        c["config"]["workload"] = c["config"]["workload"][:200]
+    rf = out.get("roofline")
+    c["roofline"] = None
+    if rf:
+        c["roofline"] = pick(rf, ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches_timed",
+                                  "traffic", "traffic_source", "boards_per_launch", "mfma_util_pmc"))
+        c["roofline"]["kernel"] = str(rf.get("kernel_short") or rf.get("kernel", ""))[:80]
+        c["roofline"].setdefault("traffic", None)
+    rs = out.get("roofline_search")
+    if rs and rs is not rf:
+        c["roofline_search"] = pick(rs, ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "traffic"))
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind", "cpu_model"))
+        c["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+        wn = (cb.get("with_network_estimate") or {}).get("value")
+        if wn is not None:
+            c["cpu_baseline"]["with_network_estimate"] = _r(float(wn))
+    else:
+        c["cpu_baseline"] = None
+    for k in ("value_sustained", "roofline_frac_sustained", "games_per_hour_steady_state", "net_arith_requested",
+              "net_arith_effective", "numerics_logit_max_abs", "numerics_within_tolerance", "numerics_peaked_arith",
+              "numerics_peaked_policy_max_abs", "value_peaked_policy", "roofline_frac_peaked_policy"):
+        if out.get(k) is not None:
+            c[k] = _r(out[k])
+    sus = out.get("sustained") or {}
+    if sus:
+        c["sustained"] = pick(sus, ("rounds", "seconds", "ms_per_step", "games_finished", "queue_utilisation",
+                                    "search_round_ms", "search_round_ms_max", "tree_resets"))
+    oc = out.get("other_configs") or {}
+    if oc:                                                   # one number per leg: expansions/s (None = the leg failed)
+        c["other_configs_exp_per_s"] = {k: (_r(float(v["value"])) if isinstance(v, dict) and "value" in v else None)
+                                        for k, v in oc.items()}
+    ms = out.get("micro_suite") or {}
+    if ms:
+        c["micro_suite"] = pick(ms, ("achieved", "unit", "frac", "ms", "boards"))
+    col = out.get("collective") or {}
+    if col:
+        c["collective"] = pick(col, ("backend", "world", "all_reduce_int64x8_us", "probe_ok"))
+    c["full_record"] = FULL_RECORD
+    return c
+
+
+def emit(out):
+    """rank 0: the full record to bench_full.json (next to the script, and into gpurun_out/ when that exists) and to
+    stderr; the compact line -- and nothing else -- to stdout, last."""
+    text = json.dumps(out)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, FULL_RECORD), "w") as f:
+                    f.write(text + "\n")
+            except OSError as e:
+                print(f"bench.py: could not write {d}/{FULL_RECORD}: {e}", file=sys.stderr)
+    print("[bench full record] " + text, file=sys.stderr, flush=True)
+    c = compact_line(out)
+    line = json.dumps(c, separators=(",", ":"))
+    # a line the driver cannot parse is an unmeasured round: drop optional groups before ever exceeding the limit
+    for k in ("collective", "micro_suite", "sustained", "other_configs_exp_per_s", "roofline_search"):
+        if len(line) <= COMPACT_LIMIT:
+            break
+        c.pop(k, None)
+        line = json.dumps(c, separators=(",", ":"))
+    sys.stderr.flush()
+    print(line, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,10 +263,20 @@ def dry_run(args, world, rank):
         dist.barrier()
         dist.all_reduce(delta, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    mine = torch.zeros(world, dtype=torch.float64)
+    mine[rank] = 1000.0 * (rank + 1) / (0.5 + 0.1 * rank)
+    if world > 1:
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
     if rank == 0:
-        print(json.dumps({"metric": "mcts_node_expansions_per_sec", "value": delta[0].item() / tmax.item(),
-                          "unit": "expansions/s", "n_gpus": int(delta[1].item()), "steps": args.steps,
-                          "warmup": args.warmup, "data": "dry-run (no GPU work: launch plumbing only)"}), flush=True)
+        secs = tmax.item()
+        emit({"metric": "mcts_node_expansions_per_sec", "value": delta[0].item() / secs,
+              "unit": "expansions/s", "n_gpus": int(delta[1].item()), "per_rank_value": mine.tolist(), "steps": args.steps,
+              "warmup": args.warmup, "ms_per_step": secs / max(1, args.steps) * 1e3, "higher_is_better": True,
+              "scaling": "weak", "vs_baseline": None, "dtype": "none (dry run)",
+              "data": "dry-run (no GPU work: launch plumbing only)",
+              "config": {"workload": "dry run: synthetic counters through the rank launch / barrier / all-reduce plumbing",
+                         "games_per_gpu": 0, "sims_per_round": 0, "parallelism": f"{world} rank(s), gloo"},
+              "roofline": None, "cpu_baseline": None})
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -462,21 +563,29 @@ def numerics_check(eng, ref_net, cfg, nq=64):
     return out
 
 
+def sharpened_copy(ref_net, planes, target=0.85):
+    """The benchmark's random-init weights with the policy layer scaled until the largest probability on `planes` is
+    >= target: the stand-in for a trained (peaked-policy) network -- real cczero weights are not obtainable here
+    (.MISSING_LARGE_BLOBS).  Returns (network, scale, float64 outputs on planes)."""
+    import copy
+    from cchess_alphazero.agent.model import reference_forward_f64
+    sharp = copy.deepcopy(ref_net).eval()
+    scale, ref = 1.0, None
+    for scale in (30.0, 60.0, 120.0, 240.0, 480.0, 960.0):
+        sharp.policy_out.weight.data.copy_(ref_net.policy_out.weight.data * scale)
+        ref = reference_forward_f64(sharp, planes)
+        if float(ref[0].max()) >= target:
+            break
+    return sharp, scale, ref
+
+
 def sharpened_numerics(eng, ref_net, planes):
     """north_star's 1e-4 on a PEAKED policy: the benchmark's weights with the policy layer scaled until
     the largest probability on these positions is >= 0.85, evaluated (a) by the arithmetic the engine REQUESTED, unguarded,
     and (b) by what the load-time guard selects for those weights (agent/model.py guarded_inference_net), both against the
     float64 network on the same live-queue positions."""
-    import copy
-    from cchess_alphazero.agent.model import (InferenceNet, guarded_inference_net, measure_against_reference,
-                                              reference_forward_f64)
-    sharp = copy.deepcopy(ref_net).eval()
-    scale = 1.0
-    for scale in (30.0, 60.0, 120.0, 240.0, 480.0, 960.0):
-        sharp.policy_out.weight.data.copy_(ref_net.policy_out.weight.data * scale)
-        ref = reference_forward_f64(sharp, planes)
-        if float(ref[0].max()) >= 0.85:
-            break
+    from cchess_alphazero.agent.model import guarded_inference_net, measure_against_reference
+    sharp, scale, ref = sharpened_copy(ref_net, planes)
     requested = eng.net.arith_requested
     raw = measure_against_reference(guarded_inference_net(sharp, torch.float32, trunk="mfma", arith=requested, guard=False,
                                                           device=planes.device), ref, planes)
@@ -561,9 +670,11 @@ def run_arena(args, cfg, max_plies=None):
 
 
 def short_selfplay_leg(label, config, seconds, log, games=None, K=None, dtype=None, trunk=None, model=None, play=None,
-                       workload=None, arith=None):
+                       workload=None, arith=None, sharpen=False):
     """One short self-play leg of another configuration (a few seconds of lock-step rounds from the opening, timed with
-    synchronize on both sides; HIP events around the residual-block launches of every round)."""
+    synchronize on both sides; HIP events around the residual-block launches of every round).  sharpen: play with the
+    peaked-policy copy of the weights (sharpened_copy) -- the engine's load-time guard then selects the arithmetic such a
+    network is allowed, and the leg times THAT."""
     import gc
     from cchess_alphazero.agent.model import CChessNet, flops_per_position
     from cchess_alphazero.engine import SelfPlayEngine
@@ -576,6 +687,12 @@ def short_selfplay_leg(label, config, seconds, log, games=None, K=None, dtype=No
     t_leg = time.perf_counter()
     torch.manual_seed(0)
     ref_net = CChessNet.from_model_config(cfg.model)
+    sharp_rec = None
+    if sharpen:
+        from cchess_alphazero.agent.model import calibration_planes
+        ref_net, scale, ref = sharpened_copy(ref_net, calibration_planes(64, cfg.model.input_depth))
+        sharp_rec = {"policy_layer_scale": scale, "max_policy_probability": float(ref[0].max())}
+        del ref
     G = cfg.engine.games_per_gpu
     prev_arith = os.environ.get("CZ_TOWER_ARITH")
     if arith:
@@ -628,6 +745,10 @@ def short_selfplay_leg(label, config, seconds, log, games=None, K=None, dtype=No
                "queue_utilisation": d["expansions"] / max(1, steps * slots),
                "tree_resets": d["tree_resets"], "overflow_sims": d["overflow_sims"], "depth_overflow": d["depth_overflow"],
                "tree_gib": eng.search.device_bytes() / 2 ** 30}
+        if sharp_rec is not None:
+            cal = eng.net.calibration or {}
+            rec["peaked_policy"] = dict(sharp_rec, guard_candidates=cal.get("candidates"),
+                                        guard_max_policy_probability=cal.get("max_policy_probability"))
         fl = flops_per_position(eng.model_cfg)
         if blk:
             b_ms = sum(blk) / len(blk)
@@ -708,6 +829,11 @@ def other_configs(args, log):
         workload="BASELINE configs[1] 'normal' (4096 games, 800 sims/move, K=8, 7x128 net) on the arithmetic the load-time "
                  "guard falls back to for peaked policies: three fp16 MFMAs per product on (hi, lo) fp16 operand pairs "
                  "(22 bits per operand; k_resblock_pipe, fused input layer), random-init weights, from INIT_STATE"))
+    guarded("normal_peaked_policy", lambda: short_selfplay_leg(
+        "peaked", "normal", sec, log, sharpen=True,
+        workload="BASELINE configs[1] 'normal' (4096 games, 800 sims/move, K=8, 7x128 net) on a PEAKED-policy network: the "
+                 "benchmark's weights with the policy layer scaled until max p >= 0.85 (the stand-in for trained weights), "
+                 "tower arithmetic = what the load-time guard selects for those weights; from INIT_STATE"))
     guarded("mini_1game_50sims_2x32", lambda: short_selfplay_leg(
         "mini", "mini", min(sec, 3.0), log,
         workload="BASELINE configs[0] 'mini' (the reference's own CPU-runnable case): 1 game, 50 sims/move, random-init "
@@ -749,7 +875,7 @@ def main():
     if args.config == "eval":
         if world > 1:
             raise SystemExit("bench.py --config eval runs on one GPU (BASELINE configs[3])")
-        print(json.dumps(run_arena(args, cfg)), flush=True)
+        emit(run_arena(args, cfg))
         return
     dtype = getattr(torch, cfg.engine.net_dtype)
     G = cfg.engine.games_per_gpu
@@ -973,7 +1099,11 @@ def main():
                      "launch also computes the 5x5 input layer (fp32 gather by its copy waves), the "
                      "inner blocks run the software-pipelined schedule, the last one (fused head "
                      "convolutions) the plain one; mean over all launches of the tower")
-            out["roofline"] = {"kernel": kdesc,
+            kshort = {"c8": "k_resblock_c8 (one residual block per launch)", "c6": "k_resblock_c8<C6> (one residual block per launch)"}.get(
+                arith, "k_resblock_pipe (one residual block per launch)")
+            if arith and (arith.startswith("c8>") or arith.startswith("c6>")):
+                kshort = f"k_resblock_c8 / k_resblock_pipe ({arith}, one residual block per launch)"
+            out["roofline"] = {"kernel": kdesc, "kernel_short": kshort,
                                "bound": "mfma", "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s", "frac": tfl / 2500.0,
                                "traffic": pmc.get("hbm_bytes_per_launch"), "traffic_source": pmc.get("source"),
                                "avg_launch_ms": b_ms, "launches_timed": len(blk), "boards_per_launch": rows_launch,
@@ -1042,7 +1172,7 @@ def main():
                             "value_sustained = the 3000-round leg of the same invocation, games in every phase: the figure "
                             "to quote for self-play throughput")
         out["numerics_check"] = numerics_check(eng, ref_net, cfg)
-        # (top-level scalars: the driver's parsed copy of the line drops nested objects)
+        out["numerics_within_tolerance"] = out["numerics_check"]["within_tolerance"]
         out["numerics_logit_max_abs"] = out["numerics_check"]["policy_logit_max_abs_diff"]
         sh = out["numerics_check"].get("sharpened") or {}
         if "guard_selected_measured" in sh:
@@ -1066,7 +1196,13 @@ def main():
             out["cpu_tree_only_expansions_per_s"] = out["cpu_baseline"]["value"]
             out["cpu_with_network_estimate"] = out["cpu_baseline"]["with_network_estimate"]["value"]
             log("cpu baseline done")
-        print(json.dumps(out), flush=True)
+        pk = (out.get("other_configs") or {}).get("normal_peaked_policy") or {}
+        if "value" in pk:
+            # the trained-network stand-in: same kernels and shapes, the arithmetic the guard allows a peaked policy
+            out["value_peaked_policy"] = pk["value"]
+            out["numerics_peaked_arith"] = pk.get("net_arith_effective")
+            out["roofline_frac_peaked_policy"] = (pk.get("roofline") or {}).get("frac")
+        emit(out)
     if dist_on:
         sys.stdout.flush()
         os.dup2(2, 1)                   # (RCCL's tear-down banner must not follow the JSON line on stdout)

@@ -317,6 +317,83 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     assert bad.returncode != 0 and "--gpus 2" in (bad.stderr + bad.stdout)
 
 
+REQUIRED_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "per_rank_value", "steps", "warmup", "ms_per_step",
+                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "cpu_baseline")
+
+
+def test_bench_line_is_compact():
+    """the LAST stdout line of bench.py is a compact JSON object the driver can parse (round 4's 30 KB
+    line came back `parsed: null`): below 4 KB (hard limit 8 KB), json.loads succeeds, the contract's keys are there --
+    for `--dry-run` and `--gpus 2 --dry-run` (eight per_rank_value slots at --gpus 8 follow the same code)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for extra, n in (([], 1), (["--gpus", "2"], 2)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run"] + extra, env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        last = r.stdout.rstrip("\n").splitlines()[-1]
+        assert len(last) < 4096
+        line = json.loads(last)
+        for k in REQUIRED_LINE_KEYS:
+            assert k in line, k
+        assert line["n_gpus"] == n and len(line["per_rank_value"]) == n
+        assert os.path.exists(os.path.join(root, line["full_record"]))
+
+
+def test_compact_line_of_a_fat_record():
+    """bench.compact_line on a record shaped like a real N = 1 run with everything in it (600-character kernel
+    descriptions, guard report, eight other_configs legs): the line stays below 4 KB, carries roofline and cpu_baseline with
+    the keys SURVEY 8(d) / the contract name, the peaked-policy figure beside the headline, and no long strings."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    fat = {"metric": "mcts_node_expansions_per_sec", "value": 1548910.123456789, "unit": "expansions/s", "n_gpus": 8,
+           "per_rank_value": [193613.765432] * 8, "steps": 20, "warmup": 5, "ms_per_step": 21.0543219, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f16+2xbf6corr-split/f32acc+f64/i32 tree", "dtype_note": "x" * 900,
+           "data": "synthetic", "config": {"workload": "w" * 400, "games_per_gpu": 4096, "sims_per_round": 8,
+                                           "queue_slots_per_gpu": 32768, "parallelism": "games sharded over 8 rank(s)"},
+           "net_arith_guard": {"candidates": [{"x": 1.0}] * 40, "note": "y" * 3000},
+           "roofline": {"kernel": "k" * 700, "kernel_short": "k_resblock_c8<C6>", "bound": "mfma", "achieved": 591.3,
+                        "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.2365, "traffic": 3.38e9, "traffic_source": "profiles/x.json",
+                        "avg_launch_ms": 2.93, "launches_timed": 140, "note": "n" * 2000},
+           "roofline_search": {"kernel": "s" * 200, "bound": "hbm", "achieved": 2066.0, "peak": 8000.0, "unit": "GB/s",
+                               "frac": 0.258, "avg_launch_ms": 0.245, "traffic": 2.37e8, "note": "n" * 900},
+           "cpu_baseline": {"value": 1.6e6, "unit": "expansions/s", "cores": 16, "kind": "port", "sample": "s" * 500,
+                            "cpu_model": "AMD EPYC 9575F 64-Core Processor", "with_network_estimate": {"value": 7425.0, "note": "n" * 400},
+                            "reference_python_timing": {"summary": "z" * 2000}},
+           "value_sustained": 1534550.0, "net_arith_requested": "c6", "net_arith_effective": "c6",
+           "numerics_logit_max_abs": 2.4e-6, "numerics_peaked_arith": "c8>5", "value_peaked_policy": 1.3e6,
+           "sustained": {"rounds": 3000, "seconds": 60.7, "note": "n" * 700, "tree_memory": {"a": list(range(200))}},
+           "other_configs": {f"leg_{i}": {"value": 1e5 * i, "workload": "w" * 300, "numerics_check": {"t": "u" * 900}}
+                             for i in range(9)},
+           "numerics_check": {"sharpened": {"guard_candidates_on_calibration_positions": [{"a": 1}] * 30}},
+           "micro_suite": {"achieved": 3678.6, "unit": "GB/s", "frac": 0.4598, "ms": 1.537, "boards": 1 << 20, "kernel": "k" * 90}}
+    c = bench.compact_line(fat)
+    text = json.dumps(c, separators=(",", ":"))
+    assert len(text) < 4096, len(text)
+    for k in REQUIRED_LINE_KEYS + ("roofline", "value_sustained", "value_peaked_policy", "numerics_peaked_arith",
+                                   "net_arith_effective", "numerics_logit_max_abs"):
+        assert k in c, k
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches_timed", "traffic", "traffic_source"):
+        assert k in c["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "cpu_model", "with_network_estimate", "sample"):
+        assert k in c["cpu_baseline"], k
+    assert len(c["per_rank_value"]) == 8 and c["n_gpus"] == 8
+    assert "net_arith_guard" not in c and "dtype_note" not in c and "other_configs" not in c
+
+    def longest(o):
+        if isinstance(o, str):
+            return len(o)
+        if isinstance(o, dict):
+            return max([longest(v) for v in o.values()] + [0])
+        if isinstance(o, list):
+            return max([longest(v) for v in o] + [0])
+        return 0
+    assert longest(c) <= 200
+
+
 def test_guard_chain_orders_the_candidates_by_exactness():
     """agent/model.py guard_chain: which tower arithmetics the load-time guard tries for a request and a tower's measured
     activation ranges (c8 image saturates at 448, fp16 pairs overflow at 65504)."""
