@@ -483,13 +483,31 @@ class InferenceNet(nn.Module):
 # candidate arithmetic is measured against a float64 evaluation of the same network on calibration positions and the
 # first one of  c8 -> c8>N -> f16x3 -> bf16x3 -> fp32 library trunk  that stays inside GUARD_TOL is used.
 GUARD_TOL = 5e-5            # half of north_star's 1e-4: the calibration set is a sample
+# The search never sees the 2086-way softmax: it renormalises the priors over the LEGAL moves (reference player.py:272-283;
+# the engine's logit queue does exactly that), so mass on illegal labels -- which can hide a large logit error behind a tiny
+# absolute softmax error -- drops out.  With d the logit deviation up to the softmax's free constant
+# (logit_max_abs: centred on its mean, so the spread max d - min d is at most 2 * logit_max_abs), a prior renormalised over
+# ANY subset of the labels moves by at most  spread * p (1 - p) <= spread / 4 <= logit_max_abs / 2.  The gate below therefore
+# bounds every renormalised prior's error by north_star's 1e-4 whatever the position's legal set and however peaked its
+# policy is -- a property of the trunk's error and the policy layer's gain, not of the sampled positions' softmax.
+LOGIT_TOL = 2e-4
 CALIBRATION_POSITIONS = 256
 
 
-def calibration_planes(n=CALIBRATION_POSITIONS, input_depth=14, device=None, seed=20260924):
+def within_guard(m, tol=GUARD_TOL, logit_tol=LOGIT_TOL):
+    """The guard's acceptance test on measure_against_reference's figures: finite, policy (full softmax) and value within
+    `tol` on the calibration positions, the logit deviation within `logit_tol` (=> renormalised priors within 1e-4), and --
+    where the legal moves of the positions are known -- the legal-renormalised priors themselves within `tol`."""
+    return bool(m["finite"] and m["policy_max_abs"] <= tol and m["value_max_abs"] <= tol and
+                m["logit_max_abs"] <= logit_tol and m.get("legal_prior_max_abs", 0.0) <= tol)
+
+
+def calibration_planes(n=CALIBRATION_POSITIONS, input_depth=14, device=None, seed=20260924, with_legal=False):
     """uint8 [n, input_depth, 10, 9]: positions of random playouts from the opening, generated with the engine's own rule
     kernels (cz_movegen / cz_step / cz_done / cz_encode) -- openings, middlegames and thinned-out endgames.  For 28-plane
-    (history) networks the second half is the previous position's planes (zero at the start of a game)."""
+    (history) networks the second half is the previous position's planes (zero at the start of a game).
+    with_legal: also the positions' legal moves as a bool mask [n, 2086] over the policy labels (the side to move is always
+    red in the engine's board convention, and cz_movegen's moves are indices into the red label table)."""
     import numpy as np
     from cchess_alphazero import _native
     from cchess_alphazero.environment.static_env import INIT_STATE, state_to_array
@@ -500,13 +518,20 @@ def calibration_planes(n=CALIBRATION_POSITIONS, input_depth=14, device=None, see
     init = torch.from_numpy(state_to_array(INIT_STATE)).to(dev)
     boards = init.repeat(games, 1).contiguous()
     prev = torch.zeros((games, 14, 10, 9), dtype=torch.uint8, device=dev)
-    out, plies = [], 0
+    out, legal, plies = [], [], 0
     stride = 3                                     # keep every third ply of every game
     while sum(t.shape[0] for t in out) < n:
         planes = _native.encode(boards, _native.U8)
+        moves, counts = _native.movegen(boards)
         if plies % stride == 0:
             out.append(planes if input_depth <= 14 else torch.cat([planes, prev], dim=1))
-        moves, counts = _native.movegen(boards)
+            if with_legal:
+                # (a move IS its index into ActionLabelsRed, include/czero.h; the padding 0xFFFF goes to a spare column)
+                live = torch.arange(moves.shape[1], device=dev)[None, :] < counts.to(torch.int64)[:, None]
+                lab = torch.where(live, moves.to(torch.int64), torch.full((), _native.NLABELS, dtype=torch.int64, device=dev))
+                mask = torch.zeros((games, _native.NLABELS + 1), dtype=torch.bool, device=dev)
+                mask.scatter_(1, lab, True)
+                legal.append(mask[:, :_native.NLABELS])
         over = _native.done(boards)[0].cpu().numpy() != 0
         cnt = counts.cpu().numpy().astype(np.int64)
         pick = (rng.random(games) * np.maximum(cnt, 1)).astype(np.int64)
@@ -519,6 +544,8 @@ def calibration_planes(n=CALIBRATION_POSITIONS, input_depth=14, device=None, see
     planes = torch.cat(out)[:n].contiguous()
     if input_depth < planes.shape[1]:
         planes = planes[:, :input_depth].contiguous()
+    if with_legal:
+        return planes, torch.cat(legal)[:n].contiguous()
     return planes
 
 
@@ -569,8 +596,16 @@ def reference_forward_f64(net: CChessNet, planes, with_activations=False):
     return out + (acts, small) if with_activations else out
 
 
-def measure_against_reference(inf, ref_out, planes):
-    """Max deviations of an InferenceNet from reference_forward_f64's outputs on the same planes."""
+def legal_priors(p, legal):
+    """The priors the search consumes (reference player.py:272-283): p restricted to the legal labels and renormalised over
+    them; rows without a legal move (mated positions) come back as zeros."""
+    q = torch.where(legal, p, torch.zeros_like(p))
+    return q / q.sum(1, keepdim=True).clamp_min(1e-300)
+
+
+def measure_against_reference(inf, ref_out, planes, legal=None):
+    """Max deviations of an InferenceNet from reference_forward_f64's outputs on the same planes.  legal (bool [n, 2086]):
+    also legal_prior_max_abs, the deviation of the priors renormalised over each position's legal moves."""
     p, v = inf(planes)
     p, v = p.double(), v.double()
     pr, vr, lr = ref_out[:3]
@@ -578,9 +613,12 @@ def measure_against_reference(inf, ref_out, planes):
     ok = (pr > 1e-30) & (p > 1e-30)
     dl = torch.where(ok, torch.log(p.clamp_min(1e-300)) - torch.log(pr.clamp_min(1e-300)), torch.zeros_like(p))
     dl = dl - dl.sum(1, keepdim=True) / ok.sum(1, keepdim=True).clamp_min(1)
-    return dict(policy_max_abs=float((p - pr).abs().max()), value_max_abs=float((v - vr).abs().max()),
-                logit_max_abs=float(torch.where(ok, dl, torch.zeros_like(dl)).abs().max()),
-                finite=bool(torch.isfinite(p).all() and torch.isfinite(v).all()))
+    out = dict(policy_max_abs=float((p - pr).abs().max()), value_max_abs=float((v - vr).abs().max()),
+               logit_max_abs=float(torch.where(ok, dl, torch.zeros_like(dl)).abs().max()),
+               finite=bool(torch.isfinite(p).all() and torch.isfinite(v).all()))
+    if legal is not None:
+        out["legal_prior_max_abs"] = float((legal_priors(p, legal) - legal_priors(pr, legal)).abs().max())
+    return out
 
 
 def choose_act_shift(activation_max, n_blocks, target=128.0, max_dev=3):
@@ -657,11 +695,14 @@ def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", ari
             return first
     family = "c8" if c6 else first.arith
     with torch.cuda.device(dev):
+        legal = None
         if planes is None:
-            planes = calibration_planes(CALIBRATION_POSITIONS, net.cfg["input_depth"], dev)
+            planes, legal = calibration_planes(CALIBRATION_POSITIONS, net.cfg["input_depth"], dev, with_legal=True)
         ref = reference_forward_f64(net, planes, with_activations=True)
         acts = ref[3]
-        report = dict(tol=tol, positions=int(planes.shape[0]), max_policy_probability=float(ref[0].max()),
+        report = dict(tol=tol, logit_tol=LOGIT_TOL, positions=int(planes.shape[0]),
+                      max_policy_probability=float(ref[0].max()),
+                      max_legal_prior=(float(legal_priors(ref[0], legal).max()) if legal is not None else None),
                       activation_max=acts, candidates=[])
         # what the c8 image would do to these activations (value byte saturates above 448; below 2^-9 it is 0; its
         # lo byte e4m3(x_lo * 2^11) saturates when |x| > ~2^9 * 448 / 2^-... i.e. with the value byte): reported, and a
@@ -697,10 +738,10 @@ def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", ari
             if cand is None or cand.arith_name != name:
                 cand = InferenceNet(net, dtype, trunk=trunk, arith=name, act_shift=shift,
                                     act_exps=exps if name == "c6" else None).to(dev)
-            m = measure_against_reference(cand, ref, planes)
+            m = measure_against_reference(cand, ref, planes, legal)
             m["arith"] = name
             report["candidates"].append(m)
-            if m["finite"] and m["policy_max_abs"] <= tol and m["value_max_abs"] <= tol:
+            if within_guard(m, tol):
                 break
             cand = None
         else:
@@ -710,8 +751,9 @@ def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", ari
             name = "fp32-library"
             chain = chain + [name]
         if name != first.arith_name:
-            logger.warning("tower arithmetic %s deviates from the float64 network by more than %g on the calibration "
-                           "positions (%s): using %s", requested, tol, report["candidates"][0], name)
+            logger.warning("tower arithmetic %s deviates from the float64 network by more than %g (policy / value / legal "
+                           "priors) or %g (logits) on the calibration positions (%s): using %s", requested, tol, LOGIT_TOL,
+                           report["candidates"][0], name)
         cand.arith_requested = requested
         cand.arith_effective = name
         cand.calibration = report

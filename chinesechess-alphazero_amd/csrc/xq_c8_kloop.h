@@ -55,6 +55,8 @@ struct Image {
     int row_base;       // first row of the image (rows are RB bytes)
     int zrow;           // first of the 16 zero rows (a multiple of 16)
     int part_bytes;     // c8 part = fp16 part + part_bytes
+    int row_base2 = 0;  // SLOTS: first row of the SECOND board's image (pixel tiles 3 .. 5); the swizzle key is then the
+                        // board-relative pixel, so an image may start at any row
 };
 
 // A packed filter as the loop reads it: a buffer resource over the whole packed tensor and this lane's byte offset
@@ -100,7 +102,13 @@ struct NoShadow {
 // first half sits, an 8-byte tail at the start of its second half), correction MFMAs of 32 cycles instead of 64: the loop's
 // matrix work is 3/4 of c8's, and the room the long fp8 slots offered is gone -- the next tap's row arithmetic is cut
 // into three stages of 3-4 instructions, one per correction slot of the tap's first three half blocks.
-template <int NT, typename Shadow = NoShadow, int PROBE = 0, bool ZERO_INIT = true, int CH = 128, int FMT = 0>
+// LOOK / RING: pixel fragments are requested LOOK K-steps ahead into a ring of RING slots.  (2, 3) for three pixel tiles (a
+// K-step = 96 cycles); (1, 1) for six -- two boards per filter fragment (round 5 experiment, tools/probes/x2/): a K-step is 192 cycles, the
+// request for tile i of the next K-step is issued right after this K-step's MFMA on tile i has read the same registers, and the
+// ring shrinks from 12 NT to 4 NT registers (six tiles have to live in 256 registers beside the 96 accumulators).
+// SLOTS: the two boards' images start at img.row_base and img.row_base2 (any rows) instead of 90 rows apart.
+template <int NT, typename Shadow = NoShadow, int PROBE = 0, bool ZERO_INIT = true, int CH = 128, int FMT = 0, int LOOK = 2,
+          int RING = 3, bool SLOTS = false>
 __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img, const Filter& flt, int lane, f32x16* acc,
                                       int scale_x_lo, int scale_x, Shadow&& shadow = NoShadow())
 {
@@ -118,8 +126,8 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
     auto tap_row = [&](int dy, int dx, int p) {
         const int t = p % 3;
         const bool ok = (unsigned)(qy[t] + dy) < 10u && (unsigned)(qx[t] + dx) < 9u;
-        const int nominal = (p / 3) * 90 + t * 32 + ln + dy * 9 + dx;
-        const int row = ok ? img.row_base + nominal : img.zrow + (nominal & 15);
+        const int nominal = (SLOTS ? 0 : (p / 3) * 90) + t * 32 + ln + dy * 9 + dx;
+        const int row = ok ? (SLOTS && p >= 3 ? img.row_base2 : img.row_base) + nominal : img.zrow + (nominal & 15);
         return row * RB + (((kb ^ nominal) & SWZ) << 4);
     };
     const int lane_c = (kb * 3) << 4;
@@ -160,16 +168,17 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
         const int t = p % 3;
         if (stage == 0) {
             st_ok[p] = (unsigned)(qy[t] + dy) < 10u && (unsigned)(qx[t] + dx) < 9u;
-            st_nom[p] = (p / 3) * 90 + t * 32 + ln + dy * 9 + dx;
+            st_nom[p] = (SLOTS ? 0 : (p / 3) * 90) + t * 32 + ln + dy * 9 + dx;
         } else if (stage == 1) {
-            st_row[p] = st_ok[p] ? img.row_base + st_nom[p] : img.zrow + (st_nom[p] & 15);
+            st_row[p] = st_ok[p] ? (SLOTS && p >= 3 ? img.row_base2 : img.row_base) + st_nom[p] : img.zrow + (st_nom[p] & 15);
         } else {
             out[p] = st_row[p] * RB + (((kb ^ st_nom[p]) & SWZ) << 4);
         }
     };
 
     f16x8 wf[4];                                        // fp16 filter fragments, slot = K-step % 4
-    f16x8 px[3][NT];                                    // pixel fragments, slot = K-step % 3 (24 K-steps per loop iteration)
+    static_assert(24 % RING == 0 && LOOK >= 1 && LOOK <= RING + (RING == 1) && LOOK <= 2, "ring indices are static per iteration");
+    f16x8 px[RING][NT];                                 // pixel fragments, slot = K-step % RING (24 K-steps per loop iteration)
     i32x8 cx[NT];                                       // c8 pixel pieces of the kind whose MFMAs come next
     i32x8 wcr[2];                                       // c8 filter pieces by kind
     int pre[NT], pre_n[NT];
@@ -196,7 +205,7 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
 #pragma unroll
     for (int p = 0; p < NT; ++p) {
         px[0][p] = load_px(pre[p], 0);
-        px[1][p] = load_px(pre[p], 1);
+        if (LOOK == 2) px[1 % RING][p] = load_px(pre[p], 1);
     }
 
 #pragma unroll 1
@@ -217,10 +226,10 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
                         const int g = tap3 * KK + kk;                         // K-step inside the iteration (ring indices)
 #pragma unroll
                         for (int i = 0; i < NT; ++i) {
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk & 3], px[g % 3][i], acc[i], 0, 0, 0);
-                            const int kn = kk + 2;                             // fragments of the K-step after next
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk & 3], px[g % RING][i], acc[i], 0, 0, 0);
+                            const int kn = kk + LOOK;                          // fragments of the K-step after next (LOOK = 2)
                             if (!(PROBE & 2)) {
-                                px[(g + 2) % 3][i] = kn < KK ? load_px(pre[i], kn) : load_px(pre_n[i], kn - KK);
+                                px[(g + LOOK) % RING][i] = kn < KK ? load_px(pre[i], kn) : load_px(pre_n[i], kn - KK);
                                 // piece (k2 NT + i) of the 2 NT c8 pixel pieces of this half block's correction MFMAs
                                 const int s6 = k2 * NT + i;
                                 load_c8(cx[s6 >> 1], pre[s6 >> 1], half, b, s6 & 1);
@@ -248,6 +257,10 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
                         // the next tap's rows: one per fp8 slot of the tap's first block (needed from K-step 6 on)
                         if (FMT == 0) {
                             if (b == 0 && half == 0) pre_n[i] = tap_row(ndy, ndx, i);
+                        } else if (NT == 6) {
+                            // six tiles: a tile's three stages in three consecutive slots of one group, two tiles per group -- the
+                            // stage registers are live for three slots of one tile instead of two groups of all six
+                            if (b * 2 + half < 3) tap_stage(i % 3, ndy, ndx, (b * 2 + half) * 2 + i / 3, pre_n);
                         } else if (b * 2 + half < 3) {
                             tap_stage(b * 2 + half, ndy, ndx, i, pre_n);
                         }

@@ -194,11 +194,15 @@ __global__ __launch_bounds__(256, WGS) void k_probe_r4(const uint4* __restrict__
 // ---- what two boards per filter fragment would buy: the same loop over SIX pixel tiles (two boards in one image; one
 // workgroup of four waves per CU, 512 registers: the shape k_conv3x3_c8 runs) ----
 constexpr int ZROW2 = 192, PART2 = (ZROW2 + 16) * RB, REGION2 = 2 * PART2;
-__global__ __launch_bounds__(256, 1) void k_probe_r4_nt6(const uint4* __restrict__ packed, const uint4* __restrict__ image,
-                                                          float* __restrict__ out, int convs, long long* __restrict__ cycles)
+// (round 5: MINW = 2 = the 256-register budget of a kernel that also carries four copy waves; LOOK / RING = 1 / 1: the
+//  pixel-fragment ring that fits there; FMT = 1: c6)
+template <int FMT, int LOOK, int RING, int MINW>
+__global__ __launch_bounds__(256 * MINW, MINW) void k_probe_r4_nt6(const uint4* __restrict__ packed, const uint4* __restrict__ image,
+                                                             float* __restrict__ out, int convs, long long* __restrict__ cycles)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[REGION2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid >= 256) return;                            // (MINW = 2: four idle waves, as many registers as k_resblock_c8x2 has)
     // two copies of the one-board image (rows 0..89 and 90..179 of each part), zero rows at 192
     for (int i = tid; i < REGION2 / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void k_probe_r4_nt6(const uint4* __restrict
     float s = 0.0f;
     const long long t0 = clock64();
     for (int conv = 0; conv < convs; ++conv) {
-        c8k::kloop<6>(lds, img, flt, lane, acc, 127 - 11, 127);
+        c8k::kloop<6, c8k::NoShadow, 0, true, 128, FMT, LOOK, RING>(lds, img, flt, lane, acc, 127 - 11, 127);
         if (conv + 1 == convs) {
 #pragma unroll
             for (int p = 0; p < 6; ++p)
@@ -277,7 +281,7 @@ int main(int argc, char** argv)
         CK(hipMemcpy(dpk, pk.data(), pk.size(), hipMemcpyHostToDevice));
         long long* dcyc;
         CK(hipMalloc(&dcyc, 8));
-        for (int var = 0; var < 9; ++var) {
+        for (int var = 0; var < 13; ++var) {
             const int wgs = var == 1 || var == 7 ? 2 : 1;      // variants: 1 WG, 2 WGs, no filter loads, no LDS reads, neither
             auto go = [&](int convs) {
                 hipEvent_t e0, e1;
@@ -288,7 +292,11 @@ int main(int argc, char** argv)
                 else if (var == 2) hipLaunchKernelGGL((k_probe_r4<1, 1>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
                 else if (var == 3) hipLaunchKernelGGL((k_probe_r4<1, 2>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
                 else if (var == 4) hipLaunchKernelGGL((k_probe_r4<1, 3>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
-                else if (var == 5) hipLaunchKernelGGL(k_probe_r4_nt6, dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
+                else if (var == 5) hipLaunchKernelGGL((k_probe_r4_nt6<0, 2, 3, 1>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
+                else if (var == 9) hipLaunchKernelGGL((k_probe_r4_nt6<0, 1, 1, 2>), dim3(blocks), dim3(512), 0, 0, dpk, dimg, out, convs, dcyc);
+                else if (var == 10) hipLaunchKernelGGL((k_probe_r4_nt6<1, 2, 3, 1>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
+                else if (var == 11) hipLaunchKernelGGL((k_probe_r4_nt6<1, 1, 1, 2>), dim3(blocks), dim3(512), 0, 0, dpk, dimg, out, convs, dcyc);
+                else if (var == 12) hipLaunchKernelGGL((k_probe_r4_nt6<1, 1, 1, 1>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
                 else if (var == 6) hipLaunchKernelGGL((k_probe_r4<1, 0, 1>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
                 else if (var == 7) hipLaunchKernelGGL((k_probe_r4<2, 0, 1>), dim3(2 * blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
                 else hipLaunchKernelGGL((k_probe_r4<1, 3, 1>), dim3(blocks), dim3(256), 0, 0, dpk, dimg, out, convs, dcyc);
@@ -305,10 +313,14 @@ int main(int argc, char** argv)
             for (int i = 0; i < (int)(seconds / 0.5) + 1; ++i) last = go(chunk);
             long long cyc = 0;
             CK(hipMemcpy(&cyc, dcyc, 8, hipMemcpyDeviceToHost));
-            const char* what[9] = {"as in the product", "2 workgroups per CU", "no filter loads in the loop", "no LDS reads in the loop",
+            const char* what[13] = {"as in the product", "2 workgroups per CU", "no filter loads in the loop", "no LDS reads in the loop",
                                    "no loads at all in the loop",
                                    "six pixel tiles = TWO boards per filter fragment (halve the figures for one board)",
-                                   "c6: bf6 correction operands, MFMA floor 10368", "c6, 2 workgroups per CU", "c6, no loads at all in the loop"};
+                                   "c6: bf6 correction operands, MFMA floor 10368", "c6, 2 workgroups per CU", "c6, no loads at all in the loop",
+                                   "c8 six tiles, ring 1/1, 256-register budget (halve for one board)",
+                                   "c6 six tiles, ring 2/3, 512 registers (halve for one board)",
+                                   "c6 six tiles, ring 1/1, 256-register budget (halve for one board)",
+                                   "c6 six tiles, ring 1/1, 512 registers (halve for one board)"};
             printf("RESULT r4 loop (%s): %.2f us per K loop of a wave, %.2f us per K loop and CU; %.0f shader cycles per K loop "
                    "(MFMA floor 13824) -> %.2f GHz\n", what[var], last * 1e3 / chunk, last * 1e3 / chunk / wgs,
                    (double)cyc / chunk, (double)cyc / chunk / (last * 1e3 / chunk) / 1e3);
