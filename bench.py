@@ -494,6 +494,8 @@ def arith_label(name):
         return None
     if name.startswith("c8>"):
         return f"f16+2xfp8corr-split(first {name[3:]} blocks)/f16x3-split/f32acc"
+    if name.startswith("c6>"):
+        return f"f16+2xbf6corr-split(first {name[3:]} blocks)/f16+2xfp8corr-split/f32acc"
     return {"c6": "f16+2xbf6corr-split/f32acc", "c8": "f16+2xfp8corr-split/f32acc", "f16x3": "f16x3-split/f32acc",
             "bf16x3": "bf16x3-split/f32acc", "fp32-library": "f32"}[name]
 
@@ -504,8 +506,9 @@ def arith_mfma_equivalents(name, n_blocks):
     = 1.5 (its first convolution reads the fused input layer's c8 image: 2.0)."""
     if name is None or name == "fp32-library":
         return 1.0
-    if name == "c6":
-        return (2.0 + 1.5 * (2 * n_blocks - 1)) / (2 * n_blocks)
+    if name == "c6" or name.startswith("c6>"):      # n6 blocks on c6 (their first convolution of block 0 on c8), the rest on c8
+        n6 = int(name[3:]) if name.startswith("c6>") else n_blocks
+        return (2.0 + 1.5 * (2 * n6 - 1) + 2.0 * 2 * (n_blocks - n6)) / (2 * n_blocks)
     if name.startswith("c8>"):
         n8 = int(name[3:])
         return (2.0 * n8 + 3.0 * (n_blocks - n8)) / n_blocks

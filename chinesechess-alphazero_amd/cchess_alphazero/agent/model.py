@@ -114,9 +114,13 @@ class InferenceNet(nn.Module):
       "c8"      (128 / 192 filters) an fp16 main term plus two block-scaled fp8 correction terms (csrc/xq_conv.hip,
                 k_resblock_c8 / k_resblock_ip_c8): one fp16 and two fp8 matrix instructions per 64 input channels, 2^-16
                 per product;
-      "c8>N"    the first N residual blocks on c8, the rest on f16x3 (error ~ sqrt(N): the guard's middle ground).
+      "c8>N"    the first N residual blocks on c8, the rest on f16x3 (error ~ sqrt(N): the guard's middle ground);
+      "c6"      (128 filters, >= 2 blocks, fused kernels) c8 with bf6 (e3m2) correction operands: half the matrix time of the
+                e4m3 ones, 2^-15 per product; needs act_exps (the images' exponents, from the calibration);
+      "c6>N"    the first N residual blocks on c6, the rest on c8 (round 5: the step down from c6 is not all-or-nothing; block
+                N - 1 writes a c8 image, cz_conv3x3_c6_pack_weights y_exp = 127).
     None of the reduced forms is trusted blindly: guarded_inference_net() below measures the candidate against float64 on
-    calibration positions when weights are loaded and falls back along c8 -> c8>N -> f16x3 -> bf16x3."""
+    calibration positions when weights are loaded and falls back along c6 -> c6>N -> c8 -> c8>N -> f16x3 -> bf16x3."""
 
     def __init__(self, net: CChessNet, dtype=torch.float32, trunk="library", arith=None, act_shift=None, act_exps=None):
         """act_shift = (s_x, [s_mid per block]): power-of-two activation scales of the residual stream and of every block's
@@ -136,12 +140,23 @@ class InferenceNet(nn.Module):
         nblk = net.cfg["res_layer_num"]
         c8_blocks = 0
         self.c6 = False
-        if arith == "c6":
-            # c8 with bf6 correction operands (half the matrix time of the e4m3 ones): 128 filters, >= 2 blocks, whole tower
+        self.c6_blocks = 0
+        from_env = arith == os.environ.get("CZ_TOWER_ARITH")
+        if arith == "c6" or arith.startswith("c6>"):
+            # c8 with bf6 correction operands (half the matrix time of the e4m3 ones): 128 filters, >= 2 blocks; "c6>N": the
+            # first N blocks only, the rest c8
+            n6 = int(arith[3:]) if arith.startswith("c6>") else nblk
+            assert 1 <= n6 <= nblk, arith
             self.c6 = (trunk == "mfma" and dtype == torch.float32 and net.cfg["cnn_filter_num"] == 128 and nblk >= 2)
             if self.c6 and act_exps is None:
-                raise ValueError("arith='c6' needs the activation images' exponents: build the network through "
-                                 "guarded_inference_net (it measures them on the calibration positions)")
+                if not from_env:
+                    raise ValueError("arith='c6' needs the activation images' exponents: build the network through "
+                                     "guarded_inference_net (it measures them on the calibration positions)")
+                # (CZ_TOWER_ARITH=c6 reaching a direct construction -- tests, tools: c8 is the nearest arithmetic that needs
+                #  no calibration)
+                logger.warning("CZ_TOWER_ARITH=%s without calibrated exponents: using c8 (guarded_inference_net measures them)", arith)
+                self.c6 = False
+            self.c6_blocks = n6 if self.c6 else 0
             arith = "c8"
         self.act_exps = ([int(v) for v in act_exps[0]], [int(v) for v in act_exps[1]]) if self.c6 else None
         if arith.startswith("c8"):
@@ -231,9 +246,10 @@ class InferenceNet(nn.Module):
 
     @property
     def arith_name(self):
-        """"bf16x3" / "f16x3" / "c8" / "c8>N" (the first N residual blocks on c8, the rest on f16x3) / "c6"."""
+        """"bf16x3" / "f16x3" / "c8" / "c8>N" (the first N residual blocks on c8, the rest on f16x3) / "c6" / "c6>N" (the
+        first N on c6, the rest on c8)."""
         if self.c6:
-            return "c6"
+            return "c6" if self.c6_blocks == len(self.res) else f"c6>{self.c6_blocks}"
         if self.arith == "c8" and self.c8_blocks < len(self.res):
             return f"c8>{self.c8_blocks}"
         return self.arith
@@ -259,15 +275,17 @@ class InferenceNet(nn.Module):
         pack_c8 = lambda w: _native.pack_conv3x3_c8_weights(w).view(torch.float16)    # raw bytes, like the others
         pack = lambda w: _native.pack_conv3x3_weights(w, self.operand_dtype, self.parts)
         for i, (c1, c2) in enumerate(self.res):
-            if self.c6:
+            if self.c6 and i < self.c6_blocks:
                 # block i reads the stream image of exponent k_out[i - 1] (block 0: the fused input layer's c8 image, e4m3
-                # filters), writes its intermediate image with k_mid[i] and the stream image with k_out[i]
+                # filters), writes its intermediate image with k_mid[i] and the stream image with k_out[i]; the last c6 block of
+                # a hybrid tower writes a c8 image instead (y_exp = 127) for the c8 blocks behind it
                 kmid, kout = self.act_exps
                 assert len(kmid) == len(kout) == len(self.res)
                 pk6 = lambda w, kx, ky: _native.pack_conv3x3_c6_weights(w, kx, ky).view(torch.float16)
+                hand_over = i + 1 == self.c6_blocks and self.c6_blocks < len(self.res)
                 out.append((pack_c8(c1.weight) if i == 0 else pk6(c1.weight, kout[i - 1], kmid[i]),
                             c1.bias.detach().float().clone(),
-                            pk6(c2.weight, kmid[i], kout[i]), c2.bias.detach().float().clone()))
+                            pk6(c2.weight, kmid[i], 127 if hand_over else kout[i]), c2.bias.detach().float().clone()))
                 continue
             pk = pack_c8 if i < self.c8_blocks else pack
             out.append((pk(c1.weight), c1.bias.detach().float().clone(),
@@ -333,6 +351,11 @@ class InferenceNet(nn.Module):
         for i in range(nblk):
             w1 = getattr(self, f"tw{i}a").view(self.operand_dtype)
             w2 = getattr(self, f"tw{i}b").view(self.operand_dtype)
+            if self.c6:
+                # the image tensors' element type is the tag that selects the kernel: int8 = a c6 block (its input AND output
+                # pair, also where the last c6 block of a hybrid tower writes a c8 image), uint8 = a c8 block
+                tag = torch.int8 if i < self.c6_blocks else torch.uint8
+                cur, tmp, nxt = ((t[0], t[1].view(tag)) for t in (cur, tmp, nxt))
             if fused:
                 b1, b2 = getattr(self, f"tb{i}a"), getattr(self, f"tb{i}b")
                 ev = None
@@ -616,8 +639,25 @@ def measure_against_reference(inf, ref_out, planes, legal=None):
     out = dict(policy_max_abs=float((p - pr).abs().max()), value_max_abs=float((v - vr).abs().max()),
                logit_max_abs=float(torch.where(ok, dl, torch.zeros_like(dl)).abs().max()),
                finite=bool(torch.isfinite(p).all() and torch.isfinite(v).all()))
+    lg = None
+    if getattr(inf, "supports_logits", lambda: False)():
+        # the raw logit rows the engine's queue carries: the deviation over ALL labels, centred on its mean
+        lg = inf(planes, logits=True)[0].double()
+        d = lg - lr.double()
+        out["logit_max_abs"] = float((d - d.mean(1, keepdim=True)).abs().max())
     if legal is not None:
-        out["legal_prior_max_abs"] = float((legal_priors(p, legal) - legal_priors(pr, legal)).abs().max())
+        # the engine's queue carries raw logits and the search kernel normalises them over the legal moves: measure exactly
+        # that where the network has the logit path (a softmax over all 2086 labels in fp32 would flush the legal moves'
+        # probabilities to zero when an illegal label holds the peak)
+        if lg is not None:
+            neg = torch.full_like(lg, -float("inf"))
+            q = torch.softmax(torch.where(legal, lg, neg), dim=1)
+            qr = torch.softmax(torch.where(legal, lr.double(), neg), dim=1)
+            has = legal.any(1, keepdim=True)
+            q, qr = torch.where(has, q, torch.zeros_like(q)), torch.where(has, qr, torch.zeros_like(qr))
+        else:
+            q, qr = legal_priors(p, legal), legal_priors(pr, legal)
+        out["legal_prior_max_abs"] = float((q - qr).abs().max())
     return out
 
 
@@ -643,11 +683,22 @@ def choose_act_shift(activation_max, n_blocks, target=128.0, max_dev=3):
     return base + dev(stream), [base + dev(activation_max[2 * i + 1]) for i in range(n_blocks)]
 
 
-def c6_exponents(activation_max):
+C6_HEADROOM_BITS = 1        # see c6_exponents
+
+
+def c6_exponents(activation_max, headroom=None):
     """([k_mid per block], [k_out per block]) for InferenceNet(arith="c6") from the (scaled) activation maxima
-    [input layer, block 0 mid, block 0 out, ...]: the smallest k with 2^k * 28 >= max (bf6's largest value is 28)."""
+    [input layer, block 0 mid, block 0 out, ...]: the smallest k with 2^k * 28 >= 2^headroom * max (bf6's largest value is 28).
+    headroom (bits kept over the calibration sample's maximum; default C6_HEADROOM_BITS): a live activation above the image's
+    range saturates its bf6 value piece and the product falls back to fp16 precision for that element (graceful:
+    tests/test_gpu_c6.py::test_c6_saturation_is_graceful), while every bit of headroom moves ALL small activations one binade
+    towards bf6's subnormals (e3m2: two mantissa bits).  Measured (tools/c6_headroom_ab.py, profiles/r05_c6_headroom_ab.json):
+    fresh positions exceed the calibration sample's maximum in 14 of 15 tower tensors, by up to 8 %; one bit of headroom moves
+    the logit error of the benchmark network from 1.9e-6 / 2.2e-6 (calibration / 1024 fresh positions) to 2.2e-6 / 2.1e-6,
+    two bits to 2.3e-6 / 2.4e-6 -- inside the noise: one bit is kept."""
     import math
-    k = [int(math.ceil(math.log2(a / 28.0))) if a > 0.0 else 0 for a in activation_max]
+    h = C6_HEADROOM_BITS if headroom is None else int(headroom)
+    k = [int(math.ceil(math.log2(a / 28.0))) + h if a > 0.0 else 0 for a in activation_max]
     return k[1::2], k[2::2]
 
 
@@ -657,8 +708,11 @@ def guard_chain(arith, c8_blocks, n_blocks, activation_max):
     65504 (kept a factor of two away), bf16 pairs have fp32's range."""
     chain = []
     top = max(activation_max) if activation_max else 0.0
-    if arith == "c6":                                # (the bf6 images carry their own exponents; the fused input layer's is c8)
-        chain.append("c6")
+    if arith == "c6" or arith.startswith("c6>"):     # (the bf6 images carry their own exponents; the fused input layer's is c8)
+        n6 = int(arith[3:]) if arith.startswith("c6>") else n_blocks
+        # hybrids hand a c8 image over to c8 blocks: only where that image holds the activations
+        steps = (n6, n6 - 2, n6 - 4) if top <= 448.0 else ((n6,) if n6 == n_blocks else ())
+        chain += [f"c6>{k}" if k < n_blocks else "c6" for k in steps if k >= 1]
         arith, c8_blocks = "c8", n_blocks
     if arith == "c8" and top <= 448.0:
         chain += [f"c8>{k}" if k < n_blocks else "c8" for k in (c8_blocks, c8_blocks - 2, c8_blocks - 4) if k >= 1]
@@ -675,7 +729,8 @@ def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", ari
     more than `tol` (c8 -> c8>N with fewer and fewer c8 blocks -> f16x3 -> bf16x3 -> the fp32 library trunk).  The result
     carries  .arith_requested, .arith_effective, .calibration (every candidate's measurements, the tower's activation
     ranges, the c8 image's predicted saturation / underflow counts).  guard=False (or CZ_ARITH_GUARD=0) skips the
-    measurement -- tests of a specific kernel path want exactly what they ask for."""
+    candidate comparison -- tests of a specific kernel path want exactly what they ask for.  (A c6 request still runs the
+    float64 calibration pass then: its images' exponents come from the measured activation ranges.)"""
     from cchess_alphazero import _native
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     requested = arith or os.environ.get("CZ_TOWER_ARITH") or "bf16x3"
@@ -683,8 +738,9 @@ def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", ari
         guard = os.environ.get("CZ_ARITH_GUARD", "1") != "0"
     reduced = trunk == "mfma" and dtype == torch.float32        # (a caller asking for bf16 / fp16 operands asked for them)
     nblk = len(net.res)
-    c6 = requested == "c6" and reduced and net.cfg["cnn_filter_num"] == 128 and nblk >= 2 and dev.type == "cuda"
-    if requested == "c6" and not c6:
+    wants_c6 = requested == "c6" or requested.startswith("c6>")
+    c6 = wants_c6 and reduced and net.cfg["cnn_filter_num"] == 128 and nblk >= 2 and dev.type == "cuda"
+    if wants_c6 and not c6:
         requested = "c8"                                         # (c6 exists for the 128-filter tower on the fused kernels)
     first = None if c6 else InferenceNet(net, dtype, trunk=trunk, arith=requested).to(dev)
     if first is not None:
@@ -726,18 +782,18 @@ def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", ari
         exps = c6_exponents(scaled)
         if c6:
             report["c6_exponents"] = {"mid": exps[0], "out": exps[1]}
-            first = InferenceNet(net, dtype, trunk=trunk, arith="c6", act_shift=shift, act_exps=exps).to(dev)
+            first = InferenceNet(net, dtype, trunk=trunk, arith=requested, act_shift=shift, act_exps=exps).to(dev)
             first.arith_requested = requested
             first.arith_effective = first.arith_name
             first.calibration = report
             if not guard:
                 return first
-        chain = guard_chain("c6" if c6 else first.arith, first.c8_blocks, nblk, scaled)
+        chain = guard_chain(requested if c6 else first.arith, first.c8_blocks, nblk, scaled)
         cand = first if (shift is None or c6) else None
         for name in chain:
             if cand is None or cand.arith_name != name:
                 cand = InferenceNet(net, dtype, trunk=trunk, arith=name, act_shift=shift,
-                                    act_exps=exps if name == "c6" else None).to(dev)
+                                    act_exps=exps if name.startswith("c6") else None).to(dev)
             m = measure_against_reference(cand, ref, planes, legal)
             m["arith"] = name
             report["candidates"].append(m)

@@ -73,8 +73,13 @@ class EngineConfig(_Section):
                                                   # c8 (e4m3 corrections; 128 / 192 filters) | c8>N (first N blocks) |
                                                   # f16x3 | bf16x3 (three MFMAs on fp16 / bf16 pairs); CZ_TOWER_ARITH overrides
                          arith_guard=True,        # measure the request against float64 on calibration positions when
-                                                  # weights are loaded and fall back c6 -> c8 -> c8>N -> f16x3 -> bf16x3 -> fp32
-                                                  # library trunk beyond 5e-5 (agent/model.py guarded_inference_net)
+                                                  # weights are loaded and fall back c6 -> c6>N -> c8 -> c8>N -> f16x3 ->
+                                                  # bf16x3 -> fp32 library trunk beyond 5e-5 on policy / value / legal priors
+                                                  # or 2e-4 on the logits (agent/model.py guarded_inference_net); False skips
+                                                  # the candidate comparison only -- c6 still measures its images' exponents
+                         audit_every_rounds=50000,  # self-play re-measures the running arithmetic on LIVE queue positions
+                         audit_first_round=400,     # this often (and once early); outside the guard -> next more exact
+                                                  # arithmetic (engine.audit_network; None: off)
                          max_nodes_per_game=0,    # sizes a game's hash / chunk table; 0 = the longest game's whole tree
                          pool_chunks=0,           # tree memory for all games in MiB; 0 = auto (<= 80 % of free HBM)
                          pool_fraction=None,      # with pool_chunks = 0: that fraction of the free HBM instead of 80 %

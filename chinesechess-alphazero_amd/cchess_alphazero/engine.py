@@ -70,6 +70,7 @@ class SelfPlayEngine:
                              sims_per_round=sims_per_round, device=self.device, use_history=use_history,
                              pool_fraction=getattr(getattr(config, "engine", None), "pool_fraction", None))
         self.policy_logits = False             # (an evaluator callable hands over probabilities, like the reference's pipe)
+        self._ref_net = net if evaluator is None else None     # (CPU copy of the weights: audit_network's float64 reference)
         if evaluator is None:
             self._install(net)
         # compact evaluation queue: the network runs only on the slots that hold a new leaf (2-7 % of the slots of a
@@ -81,12 +82,16 @@ class SelfPlayEngine:
         self.seed = seed
         self._graph = None
 
-    def _install(self, net):
-        """Build the inference network for these weights with the tower arithmetic checked against float64 (agent/model.py
-        guarded_inference_net): engine.net_arith is the REQUEST, net_arith_effective what the weights allow."""
+    def _build_net(self, net):
+        """The inference network for these weights with the tower arithmetic checked against float64 (agent/model.py
+        guarded_inference_net): engine.net_arith is the REQUEST, .arith_effective what the weights allow.  Nothing of the
+        engine changes here: a guard that raises (out of memory, a damaged weight file) leaves the games on the old network."""
         guard = getattr(getattr(self.config, "engine", None), "arith_guard", True)
-        self.net = guarded_inference_net(net, self.dtype, trunk=self.trunk, arith=self.arith, device=self.device,
-                                         guard=None if guard else False)
+        return guarded_inference_net(net, self.dtype, trunk=self.trunk, arith=self.arith, device=self.device,
+                                     guard=None if guard else False)
+
+    def _install(self, net, built=None):
+        self.net = built if built is not None else self._build_net(net)
         self.net_arith_effective = self.net.arith_effective
         self.net_calibration = self.net.calibration
         # the engine's own queue: raw logits instead of a softmax over all 2086 columns (the search spreads the priors over
@@ -98,18 +103,56 @@ class SelfPlayEngine:
     # ---- control ----
     def set_network(self, net):
         """Swap the weights the games are played with (hot reload of the best model, reference agent/api.py:76-87):
-        rebuilds the inference network; a captured HIP graph holds the old weights' buffers and is captured again."""
+        rebuilds the inference network; a captured HIP graph holds the old weights' buffers and is captured again.
+        The new network is built and measured FIRST (the float64 calibration allocates a few hundred MB beside a
+        search pool that owns most of HBM): if that raises, the engine keeps playing on the old weights -- and its graph --
+        and the exception goes to the caller."""
         if self.evaluator is not None:
             raise RuntimeError("the engine was built on an evaluator callable, not on a network")
         if net.cfg != self.model_cfg:
             raise ValueError(f"hot reload: topology changed ({self.model_cfg} -> {net.cfg})")
+        torch.cuda.synchronize(self.device)
+        built = self._build_net(net)                           # may raise: nothing has been touched yet
         had_graph = self._graph is not None
         self._graph = None
         torch.cuda.synchronize(self.device)
-        self._install(net)
+        self._install(net, built)
+        self._ref_net = net
         self.compact = bool(self._want_compact and self.net.supports_compact_queue())
         if had_graph:
             self.capture_graph()
+
+    def audit_network(self, n=64):
+        """Re-measure the running arithmetic on LIVE queue positions (the load-time calibration set is random
+        playouts; the positions a search actually asks about are more tactical).  Takes the first n planes of the evaluation
+        queue as the last round wrote them, evaluates the float64 reference and the running network on them and returns
+        measure_against_reference's figures + `ok` (within_guard: policy / value within GUARD_TOL, logits within LOGIT_TOL).
+        A failing audit is logged; the caller decides (worker/self_play.py reloads through the guard with these positions
+        added to the calibration set)."""
+        from cchess_alphazero.agent.model import measure_against_reference, reference_forward_f64, within_guard
+        if self.net is None or getattr(self, "_ref_net", None) is None:
+            return None
+        n = min(int(n), self.search.planes.shape[0])
+        planes = self.search.planes[:n].clone()
+        if planes.dtype != torch.uint8:
+            planes = (planes != 0).to(torch.uint8)
+        m = measure_against_reference(self.net, reference_forward_f64(self._ref_net, planes), planes)
+        m["ok"] = within_guard(m)
+        m["arith"] = self.net_arith_effective
+        if not m["ok"]:
+            logger.warning("live-queue audit: arithmetic %s is outside the guard on %d live positions: %s",
+                           self.net_arith_effective, n, m)
+        return m
+
+    def demote_arith(self):
+        """Lower the REQUESTED tower arithmetic one step towards exactness (c6 -> c8 -> f16x3 -> bf16x3) below what is
+        running now; the next _build_net / set_network starts its guard chain there.  False when there is nothing below."""
+        order = ["c6", "c8", "f16x3", "bf16x3"]
+        cur = (self.net_arith_effective or "bf16x3").split(">")[0]
+        if cur not in order or order.index(cur) + 1 >= len(order):
+            return False
+        self.arith = order[order.index(cur) + 1]
+        return True
 
     def start(self, first_game_id=0, game_id_stride=0):
         self.search.start_selfplay(self.seed, first_game_id, game_id_stride)

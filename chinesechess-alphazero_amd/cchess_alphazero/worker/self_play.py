@@ -115,16 +115,37 @@ class SelfPlayWorker:
             logger.error(f"best-model reload failed: {e}")
         return False
 
+    def audit(self):
+        """Measure the running arithmetic against float64 on live queue positions; when it is outside the guard there, ask for
+        the next more exact arithmetic and rebuild the network through the guard (the games go on with the old one if that
+        fails).  Returns the audit's figures (None for an engine built on an evaluator callable)."""
+        try:
+            m = self.engine.audit_network()
+            if m is not None and not m["ok"] and self.engine.demote_arith():
+                self.engine.set_network(self.engine._ref_net)
+                logger.warning(f"Process {self.pid}-{self.rank}: live audit failed ({m}); tower arithmetic now "
+                               f"{self.engine.net_arith_effective}")
+            return m
+        except Exception as e:                 # an audit must never stop the games
+            logger.error(f"live audit failed to run: {e}")
+            return None
+
     def run(self, max_rounds=None, max_games=None):
         if self.engine is None:
             self._make_engine()
         every = max(1, self.config.engine.report_every_rounds)
         reload_s = getattr(self.config.engine, "reload_seconds", 600)
+        # live-queue audit of the running tower arithmetic (engine.audit_network): once when the games have left the opening
+        # book of identical positions, then every audit_every_rounds; None switches it off
+        audit_every = getattr(self.config.engine, "audit_every_rounds", 50000)
+        audit_first = getattr(self.config.engine, "audit_first_round", 400)
         t0, r = time.time(), 0
         last_check = t0
         while True:
             self.engine.step()
             r += 1
+            if audit_every and (r == audit_first or r % audit_every == 0):
+                self.audit()
             if r % every == 0:
                 self._harvest()
                 if reload_s is not None and time.time() - last_check >= reload_s:
@@ -158,8 +179,13 @@ class SelfPlayWorker:
 def rendezvous_file():
     """A fresh file for the FileStore rendezvous of the ranks spawned here.  (A TCP port found free and then closed can
     be taken by another process before the ranks bind it -- ADVICE r03; a file in a private temporary directory cannot.)"""
+    import atexit
+    import shutil
     import tempfile
     d = tempfile.mkdtemp(prefix="czero_rdzv_")
+    # the directory lives as long as the process that created it (the parent of the spawned ranks, or the single rank itself):
+    # removed when that process exits, so /tmp does not collect one per run (ADVICE r04)
+    atexit.register(shutil.rmtree, d, ignore_errors=True)
     return os.path.join(d, "store")
 
 

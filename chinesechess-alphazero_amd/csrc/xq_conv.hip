@@ -750,6 +750,7 @@ struct FirstArgs {
 
 constexpr int CZ_FIRST_PRIO = 3;   // issue priority of the copy waves while they compute the fused input layer (the matrix waves
                                    // run their K loops at 3; at 0 the gather starves: first block 3.53 -> 3.48 ms)
+constexpr int CZ_C6_OUT_C8 = 127;  // y_exp of a c6-packed filter: "the image this convolution's block writes is a c8 image"
 namespace rb8 {
 constexpr int C = 128, RB = 256, ZROW = 96, PART = (ZROW + 16) * RB, REGION = 2 * PART;
 constexpr int SROW = 512, S_BYTES = 90 * SROW;
@@ -947,7 +948,8 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
         };
         // (two call sites each; a wrapper lambda around them was NOT inlined by the compiler: a call inside the kernel, 2.5x
         //  the scratch and 17 % of the launch time)
-#define CZ_STORE_BOARD(to, ct2) do { if (C6 && !HEADS && !yf && !(RB_KNOB() & 8)) store_tile_c6(to, ct2); else store_tile(to, ct2); } while (0)
+        // (k_out == CZ_C6_OUT_C8: the last c6 block of a hybrid c6>N tower hands a c8 image to the c8 blocks behind it)
+#define CZ_STORE_BOARD(to, ct2) do { if (C6 && !HEADS && !yf && k_out != CZ_C6_OUT_C8 && !(RB_KNOB() & 8)) store_tile_c6(to, ct2); else store_tile(to, ct2); } while (0)
         // registers -> X image.  Loaded boards: 16-byte chunks of both parts; FIRST: the thread's 8 channels of a pixel are
         // one 16-byte chunk of the f16 row and two 8-byte pieces of the c8 row [lo8 x 128 | e4m3(x) x 128]
         auto write_x = [&](int ct2) {
@@ -2663,8 +2665,9 @@ extern "C" int cz_conv3x3_c8_pack_weights(const float* w_oihw, int channels, voi
 // activation image this convolution reads and of the one it writes (x_hi6 = bf6(x 2^-k); 2^k 28 >= max |x|).
 extern "C" int cz_conv3x3_c6_pack_weights(const float* w_oihw, int channels, int x_exp, int y_exp, void* out_host)
 {
-    if (!w_oihw || !out_host || channels != 128 || x_exp < -100 || x_exp > 100 || y_exp < -100 || y_exp > 100) {
-        czi_set_error("cz_conv3x3_c6_pack_weights: bad argument (128 filters; image exponents within +-100)");
+    if (!w_oihw || !out_host || channels != 128 || x_exp < -100 || x_exp > 100 ||
+        ((y_exp < -100 || y_exp > 100) && y_exp != CZ_C6_OUT_C8)) {
+        czi_set_error("cz_conv3x3_c6_pack_weights: bad argument (128 filters; image exponents within +-100, or y_exp 127 = c8 output)");
         return CZ_ERR_ARG;
     }
     const int C = channels, KK = C / 16, CT = C / 32, NB = C / 64;

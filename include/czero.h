@@ -280,7 +280,9 @@ int cz_conv3x3_c8(const void* x_hi, const void* x_c8, const void* w_packed, cons
  * the exponents of the image the convolution READS and of the one it WRITES; a block's w1 / w2 must agree on the
  * intermediate image's exponent, consecutive blocks on the stream image's.  Entry points (dtype CZ_F16C6): cz_resblock,
  * cz_resblock_heads, cz_input_resblock (whose gathered input image is c8: ITS w1 is cz_conv3x3_c8_pack_weights') and the
- * _q forms.  A host owns the accuracy check exactly as for c8 (agent/model.py guarded_inference_net: c6 -> c8 -> ...). */
+ * _q forms.  A host owns the accuracy check exactly as for c8 (agent/model.py guarded_inference_net: c6 -> c8 -> ...).
+ * y_exp = 127 on a block's SECOND filter: the block writes a c8 image (y_lo of cz_resblock / cz_input_resblock is then read by
+ * c8 blocks) -- the hand-over of a hybrid "c6>N" tower, whose first N blocks run c6 and the rest c8. */
 int cz_conv3x3_c6_pack_weights(const float* w_oihw, int channels, int x_exp, int y_exp, void* out_host);
 
 /* test / tuning hook: the 128-filter split residual block with operand-pair output has two schedules that give

@@ -119,7 +119,7 @@ def test_c6_saturation_is_graceful():
     planes = calibration_planes(64, 14, seed=3)
     ref = reference_forward_f64(net, planes, with_activations=True)
     from cchess_alphazero.agent.model import c6_exponents
-    kmid, kout = c6_exponents(ref[3])
+    kmid, kout = c6_exponents(ref[3], headroom=0)
     tight = InferenceNet(net, torch.float32, trunk="mfma", arith="c6", act_exps=(kmid, kout)).cuda()
     low = InferenceNet(net, torch.float32, trunk="mfma", arith="c6", act_exps=([k - 3 for k in kmid], [k - 3 for k in kout])).cuda()
     m_t = measure_against_reference(tight, ref, planes)

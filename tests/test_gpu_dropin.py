@@ -388,6 +388,55 @@ def test_selfplay_worker_reloads_a_new_best_model(tmp_path, monkeypatch):
     w.close()
 
 
+def test_engine_keeps_its_network_when_a_reload_fails_and_audits_live_positions(tmp_path, monkeypatch):
+    """(a) a hot reload whose guard raises (out of memory in the float64 calibration, a damaged file) must leave the
+    games on the OLD network and its arithmetic -- set_network builds and measures the new network before it touches the
+    engine; (b) the running arithmetic is re-measured on LIVE queue positions (engine.audit_network; SelfPlayWorker.audit
+    runs it early and every audit_every_rounds) and a failing audit steps the request down one arithmetic."""
+    import torch
+    from cchess_alphazero import engine as engine_mod
+    from cchess_alphazero.agent.model import CChessModel
+    from cchess_alphazero.worker.self_play import SelfPlayWorker
+    cfg = _cfg(tmp_path, monkeypatch, simulation_num_per_move=16, search_threads=4, max_game_length=12, noise_eps=0.0)
+    cfg.model.cnn_filter_num, cfg.model.res_layer_num = 128, 2
+    cfg.engine.games_per_gpu, cfg.engine.report_every_rounds, cfg.engine.reload_seconds = 16, 4, None
+    cfg.engine.audit_first_round, cfg.engine.audit_every_rounds = 6, 1000
+    m = CChessModel(cfg)
+    m.build(seed=1)
+    w = SelfPlayWorker(cfg, model=m)
+    audits = []
+    real_audit = SelfPlayWorker.audit
+    monkeypatch.setattr(SelfPlayWorker, "audit", lambda self: audits.append(real_audit(self)) or audits[-1])
+    w.run(max_rounds=8)
+    assert len(audits) == 1 and audits[0]["ok"] and audits[0]["arith"] == w.engine.net_arith_effective == "c6"
+    assert audits[0]["logit_max_abs"] < 2e-4 and audits[0]["policy_max_abs"] < 5e-5
+    # (a) a guard that raises: nothing changes
+    old_net, x = w.engine.net, w.engine.search.planes[:8].clone()
+    p0, _ = old_net(x)
+    other = CChessModel(cfg)
+    other.build(seed=2)
+
+    def boom(*a, **k):
+        raise RuntimeError("HIP out of memory (simulated)")
+    monkeypatch.setattr(engine_mod, "guarded_inference_net", boom)
+    with pytest.raises(RuntimeError):
+        w.engine.set_network(other.model)
+    assert w.engine.net is old_net and w.engine.net_arith_effective == "c6"
+    assert torch.equal(w.engine.net(x)[0], p0)
+    c = w.run(max_rounds=4)                                  # the games go on
+    assert c["expansions"] > 0
+    monkeypatch.undo()
+    # (b) a failing audit: the request steps down and the network is rebuilt through the guard
+    monkeypatch.setattr(type(w.engine), "audit_network", lambda self, n=64: {"ok": False, "arith": self.net_arith_effective})
+    w.audit()
+    assert w.engine.arith == "c8" and w.engine.net_arith_effective == "c8"
+    with torch.no_grad():
+        pr, vr = m.model.eval()(x.float().cpu())
+    p1, v1 = w.engine.net(x)
+    assert (p1.cpu() - pr).abs().max() < 1e-4 and (v1.cpu() - vr).abs().max() < 1e-4
+    w.close()
+
+
 def test_uci_searches_match_reference_player(tmp_path, monkeypatch):
     """action(depth=...), the principal variation behind `info depth .. pv ..` and the ponder move against the
     REFERENCE's own player run with uci=True (tests/golden/uci_k1.json, make_golden_uci.py)."""

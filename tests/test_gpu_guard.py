@@ -205,3 +205,69 @@ def test_hybrid_and_guard_on_the_192_filter_tower():
     m = measure_against_reference(g, ref, planes)
     print("guard on 192:", g.arith_effective, m)
     assert m["policy_max_abs"] < 1e-4 and m["value_max_abs"] < 1e-4
+
+
+@pytest.mark.parametrize("n6", [1, 3, 5, 7])
+def test_hybrid_tower_runs_its_first_blocks_on_c6(n6):
+    """arith "c6>N" (round 5): the first N blocks on c6, the rest on c8; block N - 1 writes a c8 image (cz_conv3x3_c6_pack_weights
+    y_exp = 127).  N = all blocks is the c6 network bit for bit; in between the error against float64 lies between c8's and
+    c6's; the compact queue goes through the hand-over too."""
+    import torch
+    from cchess_alphazero.agent.model import (calibration_planes, guarded_inference_net, measure_against_reference,
+                                              reference_forward_f64)
+    net = peaked_net(60.0)
+    planes = calibration_planes(96, 14, seed=9)
+    ref = reference_forward_f64(net, planes)
+    build = lambda a: guarded_inference_net(net, torch.float32, trunk="mfma", arith=a, guard=False, planes=planes)
+    h = build(f"c6>{n6}")
+    assert h.arith_name == ("c6" if n6 == 7 else f"c6>{n6}") and h.c6 and h.c6_blocks == n6
+    p, v = h(planes)
+    if n6 == 7:
+        q, w = build("c6")(planes)
+        assert torch.equal(p, q) and torch.equal(v, w)
+    e = {a: measure_against_reference(build(a), ref, planes)["logit_max_abs"] for a in ("c8", "c6")}
+    mine = measure_against_reference(h, ref, planes)["logit_max_abs"]
+    print(f"c6>{n6}: logit error {mine:.2e} (c8 {e['c8']:.2e}, c6 {e['c6']:.2e})")
+    assert mine <= 1.5 * e["c6"] + 1e-9 and mine >= 0.5 * e["c8"]
+    rows = torch.arange(planes.shape[0] - 1, -1, -1, dtype=torch.int32, device="cuda")
+    cnt = torch.tensor([40], dtype=torch.int32, device="cuda")
+    pc, vc = h(planes, rows=rows, count=cnt)
+    assert torch.equal(pc[:40], p.flip(0)[:40]) and torch.equal(vc[:40], v.flip(0)[:40])
+
+
+def test_guard_sees_an_error_that_hides_behind_an_illegal_peak():
+    """the search consumes priors renormalised over the LEGAL moves (reference player.py:272-283), so a
+    label that is never legal can hold almost all of the 2086-way softmax's mass and shrink every absolute softmax error below
+    any tolerance while the priors the search sees are off.  Such a network: a peaked policy plus a large bias on a label that
+    no calibration position can play.  The full-softmax criterion of round 4 accepts c6 there; the guard (logit deviation
+    <= 2e-4, legal-renormalised priors <= 5e-5) does not, and what it selects keeps the legal priors within north_star's 1e-4
+    on fresh positions."""
+    import torch
+    from cchess_alphazero.agent.model import (GUARD_TOL, LOGIT_TOL, calibration_planes, guarded_inference_net,
+                                              measure_against_reference, reference_forward_f64, within_guard)
+    from cchess_alphazero.agent.model import CChessNet
+    torch.manual_seed(0)
+    net = CChessNet(cnn_filter_num=128, res_layer_num=7).eval()    # the benchmark's weights, policy layer x 480 (value head: exact)
+    net.policy_out.weight.data.mul_(480.0)
+    planes, legal = calibration_planes(256, 14, with_legal=True)
+    never = (~legal.any(0)).nonzero().flatten()
+    assert never.numel() > 0                                       # labels no calibration position can play
+    with torch.no_grad():
+        top = float(reference_forward_f64(net, planes)[2].max())
+        net.policy_out.bias.data[int(never[0])] = top + 25.0       # e^-25 of the mass is left for every other label
+    ref = reference_forward_f64(net, planes)
+    assert float(ref[0][:, int(never[0])].min()) > 1.0 - 1e-9      # the illegal label holds the softmax
+    raw = guarded_inference_net(net, torch.float32, trunk="mfma", arith="c6", guard=False, planes=planes)
+    m = measure_against_reference(raw, ref, planes, legal)
+    print("c6, unguarded:", m)
+    assert m["policy_max_abs"] <= GUARD_TOL and m["value_max_abs"] <= GUARD_TOL          # round 4's test: passes
+    assert m["logit_max_abs"] > LOGIT_TOL and m["legal_prior_max_abs"] > GUARD_TOL       # the search's priors: off
+    assert not within_guard(m)
+    g = guarded_inference_net(net, torch.float32, trunk="mfma", arith="c6")
+    assert g.arith_effective != "c6" and g.calibration["candidates"][0]["arith"] == "c6"
+    last = g.calibration["candidates"][-1]
+    assert g.arith_effective == "fp32-library" or within_guard(last)
+    fresh, fresh_legal = calibration_planes(192, 14, seed=4242, with_legal=True)
+    mf = measure_against_reference(g, reference_forward_f64(net, fresh), fresh, fresh_legal)
+    print(f"guard: c6 -> {g.arith_effective}; fresh positions: {mf}")
+    assert mf["legal_prior_max_abs"] <= 1e-4 and mf["value_max_abs"] <= 1e-4

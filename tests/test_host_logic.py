@@ -231,7 +231,8 @@ def test_tower_arithmetic_selection_on_the_host(monkeypatch):
     from cchess_alphazero.agent.model import c6_exponents
     with pytest.raises(ValueError):
         InferenceNet(net, torch.float32, trunk="mfma", arith="c6")
-    assert c6_exponents([3.0, 28.0, 28.1, 0.2, 500.0]) == ([0, -7], [1, 5])
+    assert c6_exponents([3.0, 28.0, 28.1, 0.2, 500.0], headroom=0) == ([0, -7], [1, 5])
+    assert c6_exponents([3.0, 28.0, 28.1, 0.2, 500.0]) == ([1, -6], [2, 6])        # one bit kept over the sample's maximum
     i6 = InferenceNet(net, torch.float32, trunk="mfma", arith="c6", act_exps=([-4, -3], [-2, 1]))
     assert i6.c6 and i6.arith == "c8" and i6.arith_name == "c6" and i6.c8_blocks == 2
     tail = lambda t: t.numpy().view(np.uint8)[-16 - 2 * 128:-2 * 128].view(np.int32).tolist()    # (4 ints, then 2 x 128 row shifts)
@@ -399,8 +400,12 @@ def test_guard_chain_orders_the_candidates_by_exactness():
     activation ranges (c8 image saturates at 448, fp16 pairs overflow at 65504)."""
     from cchess_alphazero.agent.model import guard_chain
     assert guard_chain("c8", 7, 7, [3.0, 9.5]) == ["c8", "c8>5", "c8>3", "f16x3", "bf16x3"]
-    assert guard_chain("c6", 7, 7, [3.0, 9.5]) == ["c6", "c8", "c8>5", "c8>3", "f16x3", "bf16x3"]
-    assert guard_chain("c6", 7, 7, [3.0, 500.0]) == ["c6", "f16x3", "bf16x3"]     # (bf6 images carry their own exponents)
+    assert guard_chain("c6", 7, 7, [3.0, 9.5]) == ["c6", "c6>5", "c6>3", "c8", "c8>5", "c8>3", "f16x3", "bf16x3"]
+    assert guard_chain("c6>5", 7, 7, [3.0, 9.5]) == ["c6>5", "c6>3", "c6>1", "c8", "c8>5", "c8>3", "f16x3", "bf16x3"]
+    assert guard_chain("c6", 2, 2, [1.0]) == ["c6", "c8", "f16x3", "bf16x3"]
+    # (bf6 images carry their own exponents: plain c6 is tried beyond 448, the hybrids -- a c8 hand-over image -- are not)
+    assert guard_chain("c6", 7, 7, [3.0, 500.0]) == ["c6", "f16x3", "bf16x3"]
+    assert guard_chain("c6>5", 7, 7, [3.0, 500.0]) == ["f16x3", "bf16x3"]
     assert guard_chain("c8", 5, 7, [3.0]) == ["c8>5", "c8>3", "c8>1", "f16x3", "bf16x3"]
     assert guard_chain("c8", 2, 2, [1.0]) == ["c8", "f16x3", "bf16x3"]
     assert guard_chain("c8", 7, 7, [3.0, 500.0]) == ["f16x3", "bf16x3"]
@@ -479,6 +484,8 @@ def test_bench_arithmetic_labels():
     assert bench.arith_mfma_equivalents("c8", 7) == 2.0 and bench.arith_mfma_equivalents("bf16x3", 7) == 3.0
     assert bench.arith_label("c6") == "f16+2xbf6corr-split/f32acc" and abs(bench.arith_mfma_equivalents("c6", 7) - 21.5 / 14) < 1e-12
     assert abs(bench.arith_mfma_equivalents("c8>5", 7) - (2.0 * 5 + 3.0 * 2) / 7) < 1e-12
+    assert abs(bench.arith_mfma_equivalents("c6>3", 7) - (2.0 + 1.5 * 5 + 2.0 * 8) / 14) < 1e-12
+    assert "first 3 blocks" in bench.arith_label("c6>3") and "bf6" in bench.arith_label("c6>3")
     assert bench.arith_mfma_equivalents("fp32-library", 7) == 1.0
 
 
