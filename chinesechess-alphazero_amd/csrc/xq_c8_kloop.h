@@ -27,6 +27,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// CZ_C6_TAIL_SWZ (round 5 experiment, default OFF): a c6 piece's 8-byte tail in the UPPER half of its 16-byte chunk when bit 4 of
+// the pixel row is set.  ds_read_b64 serves 32 lanes per pass; pixel rows r and r + 16 carry the same chunk swizzle, so with
+// every tail in the lower half lanes ln and ln + 16 of a pass hit the same two banks (a two-way conflict on every tail read:
+// LDS bank-conflict fraction 0.14 against c8's 0.068, profiles/r04_pmc_nn.json); with the half chosen by row bit 4 the 32 lanes
+// cover all 64 banks.  Bit-identical results (tests/test_gpu_c6.py on both builds) -- and 0.7 % SLOWER in the bench, three
+// alternating pairs on one box (profiles/r05_ab_c6_tail_swizzle.log: 2.960 -> 2.983 ms per block launch): the two VALU
+// instructions per tail read cost more issue slots of a 32-cycle bf6 slot than the conflicts cost LDS passes that sit in the
+// MFMAs' shadow anyway.  Kept as a build switch; one convention for LDS and HBM (images are copied in 16-byte chunks).
+#ifndef CZ_C6_TAIL_SWZ
+#define CZ_C6_TAIL_SWZ 0
+#endif
+
 namespace c8k {
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -144,7 +156,10 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
             const uint4 t = *reinterpret_cast<const uint4*>(lds + img.part_bytes + off);
             d[4 * h + 0] = t.x; d[4 * h + 1] = t.y; d[4 * h + 2] = t.z; d[4 * h + 3] = t.w;
         } else {
-            const uint2 t = *reinterpret_cast<const uint2*>(lds + img.part_bytes + off);
+            // (rows of an image start at a multiple of 32 for every c6 caller, so bit 4 of the pixel row is address bit 12 of
+            //  pre_p; the zero rows hold zeros in both halves)
+            const int half = CZ_C6_TAIL_SWZ ? (pre_p >> 9) & 8 : 0;
+            const uint2 t = *reinterpret_cast<const uint2*>(lds + img.part_bytes + off + half);
             d[4] = t.x; d[5] = t.y;
         }
     };

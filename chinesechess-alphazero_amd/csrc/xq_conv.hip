@@ -768,7 +768,8 @@ __device__ __forceinline__ int stage_off(int q, int ch) { return q * SROW + ((((
 //     channel of element e = 8 (e >> 3) + ((e >> 1) & 3) + 4 (e & 1)          (cz_conv3x3_c6_pack_weights: the same)
 // and the inverse conversion (sequential) hands accumulator register r of lane half kb its channel at element 2 r + kb.
 // In a 256-byte image row (HBM and LDS alike) piece (kind, block b, half kb) has its 16-byte head in logical chunk
-// 8 kind + 4 b + 2 kb -- where the e4m3 piece's first half sits -- and its 8-byte tail at the start of the next chunk.
+// 8 kind + 4 b + 2 kb -- where the e4m3 piece's first half sits -- and its 8-byte tail at the start of the next chunk
+// (c6_tail_half: with the CZ_C6_TAIL_SWZ build switch, its upper half for rows with bit 4 set -- measured and left off).
 // x_hi6 = bf6(x 2^-k), x_lo6 = bf6((x - f16(x)) 2^(11 - k)) with the image's exponent k from the calibration
 // (2^k * 28 >= the tensor's largest value; the conversion saturates), carried by the packed filters that read / write it.
 typedef __attribute__((ext_vector_type(6))) unsigned int u32x6;
@@ -780,6 +781,8 @@ __device__ __forceinline__ const int* pack_ints(const void* packed)
 __device__ __forceinline__ int c6_chunk(int kind, int blk32) { return 8 * kind + 4 * (blk32 >> 1) + 2 * (blk32 & 1); }
 // byte offsets of a piece's head inside a part's pixel row `row` (LDS: chunks swizzled by the row)
 __device__ __forceinline__ int c6_lds_off(int row, int chunk) { return row * RB + ((chunk ^ (row & 15)) << 4); }
+// byte offset of a piece's 8-byte tail inside its chunk (xq_c8_kloop.h CZ_C6_TAIL_SWZ): the upper half for rows with bit 4 set
+__device__ __forceinline__ int c6_tail_half(int row) { return CZ_C6_TAIL_SWZ ? (row >> 1) & 8 : 0; }
 
 struct Shadow {                         // relu(acc2 of the previous board) -> staging, one (tile, channel group) unit per 9 fp8 slots
     unsigned char* lds;
@@ -940,9 +943,9 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
                 unsigned char* row = yc + ebase * 2 + (size_t)qq * 2 * C;
                 if (knob & 2) continue;
                 *reinterpret_cast<uint4*>(row + 16 * c6_chunk(0, blk)) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-                *reinterpret_cast<uint2*>(row + 16 * c6_chunk(0, blk) + 16) = make_uint2(pl[4], pl[5]);
+                *reinterpret_cast<uint2*>(row + 16 * c6_chunk(0, blk) + 16 + c6_tail_half(qq)) = make_uint2(pl[4], pl[5]);
                 *reinterpret_cast<uint4*>(row + 16 * c6_chunk(1, blk)) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
-                *reinterpret_cast<uint2*>(row + 16 * c6_chunk(1, blk) + 16) = make_uint2(pv[4], pv[5]);
+                *reinterpret_cast<uint2*>(row + 16 * c6_chunk(1, blk) + 16 + c6_tail_half(qq)) = make_uint2(pv[4], pv[5]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -1237,9 +1240,9 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
                 const int q = pp == 0 ? kb2 * 32 + ln2 : 64 + ln2;
                 if (pp == 0 || (kb2 == 0 && q < 90)) {
                     unsigned char* d0 = Y + PART + c6_lds_off(q, c6_chunk(0, wave));
-                    unsigned char* t0 = Y + PART + c6_lds_off(q, c6_chunk(0, wave) + 1);
+                    unsigned char* t0 = Y + PART + c6_lds_off(q, c6_chunk(0, wave) + 1) + c6_tail_half(q);
                     unsigned char* d1 = Y + PART + c6_lds_off(q, c6_chunk(1, wave));
-                    unsigned char* t1 = Y + PART + c6_lds_off(q, c6_chunk(1, wave) + 1);
+                    unsigned char* t1 = Y + PART + c6_lds_off(q, c6_chunk(1, wave) + 1) + c6_tail_half(q);
                     *reinterpret_cast<uint4*>(d0) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
                     *reinterpret_cast<uint2*>(t0) = make_uint2(pl[4], pl[5]);
                     *reinterpret_cast<uint4*>(d1) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
@@ -1254,7 +1257,7 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
                 f32x32 xl;
                 if (!FIRST) {
                     const uint4 hd4 = *reinterpret_cast<const uint4*>(X + PART + c6_lds_off(row, c6_chunk(0, wave)));
-                    const uint2 tl2 = *reinterpret_cast<const uint2*>(X + PART + c6_lds_off(row, c6_chunk(0, wave) + 1));
+                    const uint2 tl2 = *reinterpret_cast<const uint2*>(X + PART + c6_lds_off(row, c6_chunk(0, wave) + 1) + c6_tail_half(row));
                     // the upper lane half wants the odd elements: it shifts the piece down by one element (6 bits), so that
                     // every lane reads element 2 r for its register r  (a select between xl[2 r] and xl[2 r + 1] is
                     // turned into a variable vector index by the compiler: 31 v_cndmask per element)
