@@ -139,6 +139,11 @@ def emit(out):
                     f.write(text + "\n")
             except OSError as e:
                 print(f"bench.py: could not write {d}/{FULL_RECORD}: {e}", file=sys.stderr)
+    if os.environ.get("CZ_BENCH_FULL_LINE") == "1":
+        # the repository's own profiling scripts (tools/*.sh, tools/summarize_profiles.py) read every key from the stdout
+        # line; the driver never sets this
+        print(text, flush=True)
+        return
     print("[bench full record] " + text, file=sys.stderr, flush=True)
     c = compact_line(out)
     line = json.dumps(c, separators=(",", ":"))

@@ -2,6 +2,7 @@
 # A/B of library builds x residual-block schedules inside the normal bench, same box, back to back.
 # usage: [CONFIG=deep] bash tools/ab_lib.sh "head:1 new:1 head:0 new:0"   (head -> variants/libczero_head.so, new -> the default build;
 #        the number is CZ_RESBLOCK_MODE: 0 = the plain schedules, 1 = the default ones)
+export CZ_BENCH_FULL_LINE=1   # bench.py prints its full record on stdout for these scripts (round 5: the default is the compact line)
 export TMPDIR=/tmp
 for item in $1; do
   lib=${item%%:*}; mode=${item##*:}

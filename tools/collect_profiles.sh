@@ -4,6 +4,7 @@
 #   2. PMC passes (one per counter set, never combined with trace domains other than kernel-trace):
 #        SQ set (MFMA busy, wave cycles, waits, LDS)   FETCH_SIZE   WRITE_SIZE
 # tools/summarize_profiles.py turns gpurun_out/prof into profiles/rNN_*.{json,md}.
+export CZ_BENCH_FULL_LINE=1   # bench.py prints its full record on stdout for these scripts (round 5: the default is the compact line)
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof

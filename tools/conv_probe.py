@@ -4,7 +4,7 @@
     python tools/conv_probe.py [--n 32768] [--channels 128] [--out gpurun_out/conv_probe.json]
 
 (The ablation / in-kernel time-stamp variants this script once drove were tuning aids that computed wrong results; they
-were removed from csrc/xq_conv.hip in round 3 -- what they measured is recorded in DESIGN.md section 7b.)
+were removed from csrc/xq_conv.hip in round 3 -- what they measured is recorded in EXPERIMENTS.md (Part II, section 7b).)
 """
 import argparse
 import json

@@ -5,6 +5,7 @@
 #   kernel trace of the sustained search probe, complete games (games/hour conversion), clock / power under the bench,
 #   the A/B of the tower arithmetics, a long sustained run.
 #   tools/summarize_profiles.py --round N turns gpurun_out/prof into profiles/rNN_*.
+export CZ_BENCH_FULL_LINE=1   # bench.py prints its full record on stdout for these scripts (round 5: the default is the compact line)
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp

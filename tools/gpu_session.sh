@@ -1,5 +1,6 @@
 #!/bin/bash
 # One gpurun call = GPU tests + a short bench (+ optional extras given as arguments); everything lands in gpurun_out/.
+export CZ_BENCH_FULL_LINE=1   # bench.py prints its full record on stdout for these scripts (round 5: the default is the compact line)
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp

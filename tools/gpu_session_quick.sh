@@ -1,5 +1,6 @@
 #!/bin/bash
 # quick GPU check: the network test files + a kernel trace of a short bench (per-kernel averages)
+export CZ_BENCH_FULL_LINE=1   # bench.py prints its full record on stdout for these scripts (round 5: the default is the compact line)
 set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp
 ROOT=$(pwd)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU: SQ counters (matrix-pipe busy cycles, waits, LDS activity / conflicts) of the 20 x 256 fp16 network's residual block
 # in both schedules: CZ_RESBLOCK_MODE=1 (two channel tiles per matrix wave) and 0 (one).  Output: gpurun_out/pmc_deep_<mode>/
+export CZ_BENCH_FULL_LINE=1   # bench.py prints its full record on stdout for these scripts (round 5: the default is the compact line)
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 for mode in 1 0; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU: instruction mix of the search kernels (bench.py, opening-phase rounds): SQ_INSTS_* per launch
+export CZ_BENCH_FULL_LINE=1   # bench.py prints its full record on stdout for these scripts (round 5: the default is the compact line)
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/pmc_valu

@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel trace of a LONG bench run (games in every phase): where a sustained search round's time goes.
 #   bash tools/profile_sustained.sh [rounds]     -> gpurun_out/prof_sus/  (summarised by tools/summarize_sustained.py)
+export CZ_BENCH_FULL_LINE=1   # bench.py prints its full record on stdout for these scripts (round 5: the default is the compact line)
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_sus

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4: the c6 arithmetic -- tests, then the bench with the arithmetic requested
+export CZ_BENCH_FULL_LINE=1   # bench.py prints its full record on stdout for these scripts (round 5: the default is the compact line)
 mkdir -p gpurun_out
 timeout 600 python -m pytest tests/test_gpu_c6.py -x -q -s > gpurun_out/c6_tests.log 2>&1
 echo "c6 tests rc=$?"; grep -v "amdgpu.ids" gpurun_out/c6_tests.log | tail -25

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, final regression: the whole -m gpu suite, smoke(), the default bench line
+export CZ_BENCH_FULL_LINE=1   # bench.py prints its full record on stdout for these scripts (round 5: the default is the compact line)
 mkdir -p gpurun_out
 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu_final.log 2>&1
 echo "suite rc=$?"; tail -4 gpurun_out/pytest_gpu_final.log

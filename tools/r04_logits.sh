@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4: the engine queue as raw logits (cz_search_policy_logits) -- tests, then bench with and without
+export CZ_BENCH_FULL_LINE=1   # bench.py prints its full record on stdout for these scripts (round 5: the default is the compact line)
 mkdir -p gpurun_out
 python -m pytest tests/test_gpu_search.py tests/test_gpu_conv.py -x -q -m gpu -k "logit or heads_tail or compact" > gpurun_out/logits_tests.log 2>&1
 echo "new tests rc=$?"; tail -3 gpurun_out/logits_tests.log

@@ -4,6 +4,7 @@
 #   bench line, the A/B of the tower arithmetics, the c8 K-loop probe (shader cycles, clock), the in-kernel section stamps
 #   of k_resblock_c8 (variants/libczero_stamps.so, built beforehand), launch times of the block kernels, clock / power
 #   under the bench, complete games, the 11 000-round sustained run.   tools/summarize_profiles.py --round 4 afterwards.
+export CZ_BENCH_FULL_LINE=1   # bench.py prints its full record on stdout for these scripts (round 5: the default is the compact line)
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Quick sanity of the non-default bench configurations (each a few rounds): prints value / ms per step / numerics.
+export CZ_BENCH_FULL_LINE=1   # bench.py prints its full record on stdout for these scripts (round 5: the default is the compact line)
 export TMPDIR=/tmp
 run() {
   timeout 300 python bench.py "$@" --steps 6 --warmup 2 --sustained-rounds 0 --no-micro --no-cpu-baseline 2>/tmp/err.log > /tmp/out.json || { echo "FAILED: $*"; tail -5 /tmp/err.log; return; }
