@@ -1115,6 +1115,10 @@ def main():
                                "bound": "mfma", "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s", "frac": tfl / 2500.0,
                                "traffic": pmc.get("hbm_bytes_per_launch"), "traffic_source": pmc.get("source"),
                                "avg_launch_ms": b_ms, "launches_timed": len(blk), "boards_per_launch": rows_launch,
+                               # mean per position in the tower (block 0 hosts the fused input layer, the last one the heads)
+                               "launch_ms_by_block": [sum(blk[i::cfg.model.res_layer_num]) / max(1, len(blk[i::cfg.model.res_layer_num]))
+                                                      for i in range(cfg.model.res_layer_num)],
+                               "first_launch_ms": sum(blk[0::cfg.model.res_layer_num]) / max(1, len(blk[0::cfg.model.res_layer_num])),
                                "algorithmic_flops_per_launch": flops_launch,
                                "tower_arithmetic": arith, "mfma_equivalents_per_product": mfma_equiv,
                                "issued_bf16_tflops": mfma_equiv * tfl * 96.0 / 90.0,

@@ -381,19 +381,25 @@ def input_table(w_oihw):
     return w.permute(1, 2, 3, 0).reshape(w.shape[1], 25, w.shape[0]).contiguous()
 
 
-def input_resblock(planes, table, in_bias, w1, b1, w2, b2, out, rows=None, count=None):
-    """cz_input_resblock: planes [N, in_planes, 10, 9] uint8 -> input layer + first residual block -> out = (hi, lo)
+def input_resblock(planes, table, in_bias, w1, b1, w2, b2, out, rows=None, count=None, masks=None):
+    """cz_input_resblock(_m): planes [N, in_planes, 10, 9] uint8 -> input layer + first residual block -> out = (hi, lo)
     [N, 90, 128] operand pair, or the c8 pair (f16 [N, 90, 128], uint8 [N, 90, 256]) with cz_conv3x3_c8_pack_weights
-    filters.  rows / count: the compact evaluation queue (int32 device tensors)."""
+    filters.  rows / count: the compact evaluation queue (int32 device tensors).  masks [N, 96] int32: the positions'
+    occupancy boards (Search.leaf_masks): the kernel then skips deriving them from the planes."""
     require_gpu()
     import torch
     if planes.dtype != torch.uint8:
         raise NativeError("cz_input_resblock reads uint8 planes")
     n = planes.shape[0]
-    check(lib().cz_input_resblock(_ptr(planes), planes.shape[1], _ptr(table), _ptr(in_bias), _ptr(w1), _ptr(b1), _ptr(w2),
-                                  _ptr(b2), _ptr(out[0]), _ptr(out[1]), n, out[0].shape[-1], _pair_code(out),
-                                  _ptr(rows) if rows is not None else None, _ptr(count) if count is not None else None,
-                                  _stream()), "cz_input_resblock")
+    if masks is not None:
+        assert masks.dtype == torch.int32 and masks.is_cuda and masks.is_contiguous() and tuple(masks.shape) == (n, 96)
+    L = lib()
+    L.cz_input_resblock_m.restype = C.c_int
+    L.cz_input_resblock_m.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int] * 3 + [C.c_void_p] * 3
+    check(L.cz_input_resblock_m(_ptr(planes), _ptr(masks), planes.shape[1], _ptr(table), _ptr(in_bias), _ptr(w1), _ptr(b1),
+                                _ptr(w2), _ptr(b2), _ptr(out[0]), _ptr(out[1]), n, out[0].shape[-1], _pair_code(out),
+                                _ptr(rows) if rows is not None else None, _ptr(count) if count is not None else None,
+                                _stream()), "cz_input_resblock")
     return out
 
 

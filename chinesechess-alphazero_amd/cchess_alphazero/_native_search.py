@@ -120,6 +120,7 @@ class Search:
         self.planes = torch.zeros((self.slots, self.in_planes, 10, 9), dtype=_native.torch_dtype(planes_dtype), device=self.device)
         self.policy = torch.zeros((self.slots, _native.NLABELS), dtype=torch.float32, device=self.device)
         self.value = torch.zeros((self.slots,), dtype=torch.float32, device=self.device)
+        self.masks = None                      # leaf_masks(): [slots, 96] int32 occupancy boards beside the planes
         self._cursor = C.c_uint(0)
 
     # -- lifetime --
@@ -183,6 +184,20 @@ class Search:
         """The policy rows given to round() are raw logits (agent/model.py forward(logits=True)): the priors are formed from
         the legal moves' logits alone -- the softmax denominator cancels in the reference's renormalisation."""
         _native.check(self.L.cz_search_policy_logits(self.h, int(bool(on))), "cz_search_policy_logits")
+
+    def leaf_masks(self, on=True):
+        """Every new leaf's position is also written as an occupancy board (self.masks [slots, 96] int32: word = plane
+        position, bit c = plane c shows a piece there; cz_search_leaf_masks) -- 384 bytes instead of 1260 (2520), which the
+        first residual block's fused input layer takes directly (InferenceNet.forward(masks=...), cz_input_resblock_m)."""
+        import torch
+        if on and self.masks is None:
+            self.masks = torch.zeros((self.slots, 96), dtype=torch.int32, device=self.device)
+        if not on:
+            self.masks = None
+        ptr = C.c_void_p(self.masks.data_ptr()) if self.masks is not None else None
+        self.L.cz_search_leaf_masks.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.cz_search_leaf_masks.restype = C.c_int
+        _native.check(self.L.cz_search_leaf_masks(self.h, ptr), "cz_search_leaf_masks")
 
     def reset_trees(self):
         _native.check(self.L.cz_search_reset_trees(self.h, self._stream()), "cz_search_reset_trees")

@@ -320,7 +320,7 @@ class InferenceNet(nn.Module):
         """A c8 operand pair's storage seen as an (hi, lo) fp16 pair (same bytes: [n, 90, 2C] u8 = [n, 90, C] f16)."""
         return pair[0], pair[1].view(torch.float16)
 
-    def _trunk_mfma(self, planes, heads=None, rows=None, count=None):
+    def _trunk_mfma(self, planes, heads=None, rows=None, count=None, masks=None):
         """planes: the evaluation queue as the search kernel wrote it ([n, in_planes, 10, 9], any supported dtype).
         heads = (n_policy, policy_feat, value_feat): fold the 1x1 head convolutions into the last block where the
         kernel exists for the shape (returns None then), else returns the [n, 90, c] trunk output."""
@@ -364,7 +364,7 @@ class InferenceNet(nn.Module):
                     ev[0].record()
                 if i == 0 and first_fused:
                     _native.input_resblock(planes.contiguous(), self.in_table32, self.in_bias32, w1, b1, w2, b2, out=nxt,
-                                           rows=rows, count=count)
+                                           rows=rows, count=count, masks=masks)
                     cur, nxt = nxt, cur
                 elif i + 1 == n8 and n8 < nblk:
                     # the last c8 block of a hybrid tower: fp32 out, re-split into (hi, lo) fp16 pairs for the f16x3 blocks
@@ -434,12 +434,14 @@ class InferenceNet(nn.Module):
                 self.policy_out.in_features in (180, 360) and self.value_dense.in_features in (180, 360))
 
     @torch.no_grad()
-    def forward(self, planes, rows=None, count=None, out=None, logits=False):
+    def forward(self, planes, rows=None, count=None, out=None, logits=False, masks=None):
         """planes: the evaluation queue.  rows / count (int32 cuda tensors, cz_search_round_q): evaluate only the
         boards planes[rows[i]], i < count -- the result rows are indexed by i; rows beyond count are undefined.
         out = (policy [n, 2086] fp32, value [n] fp32): write the results there (the engine's queue tensors) instead of
         into fresh tensors.  logits=True (hand-written tail only; see supports_logits): the policy rows are left as raw
-        logits -- for a search object in policy_logits mode, which needs the legal moves' entries only."""
+        logits -- for a search object in policy_logits mode, which needs the legal moves' entries only.
+        masks (int32 [n, 96], Search.leaf_masks): the same positions as occupancy boards; the fused input layer of the first
+        residual block takes them instead of scanning the planes (ignored on every other path)."""
         if logits and not self.supports_logits():
             raise RuntimeError("logits=True needs the hand-written dense tail")
         if rows is not None and not self.supports_compact_queue():
@@ -456,7 +458,7 @@ class InferenceNet(nn.Module):
                     pf = torch.empty((n, npol * 90), dtype=torch.float32, device=planes.device)
                     vf = torch.empty((n, (6 - npol) * 90), dtype=torch.float32, device=planes.device)
                 last = self._trunk_mfma(planes, heads=(npol, pf, vf) if self.fused_heads else None,
-                                        rows=rows, count=count)
+                                        rows=rows, count=count, masks=masks)
                 if last is not None:
                     _native.head_convs(last, self.head_w32, self.head_b32, npol, pf, vf)
                 if self.fused_tail and pf.shape[1] in (180, 360) and vf.shape[1] in (180, 360):

@@ -89,6 +89,8 @@ class EngineConfig(_Section):
                          compact_queue=True,      # evaluate only the queue slots that hold a new leaf (cz_search_round_q)
                          policy_logits=True,      # the engine's queue carries raw logits: no softmax pass over all 2086
                                                   # columns, the priors come from the legal moves' logits (cz_search_policy_logits)
+                         leaf_masks=True,         # the search kernel also writes every leaf as a 96-word occupancy board, which the
+                                                  # first block's fused input layer takes instead of scanning the planes
                          use_hip_graph=False, base_seed=0, report_every_rounds=200,
                          max_rounds=None, max_games=None)   # None = run forever, like the reference
 

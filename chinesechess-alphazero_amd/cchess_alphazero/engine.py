@@ -99,6 +99,10 @@ class SelfPlayEngine:
         want = getattr(getattr(self.config, "engine", None), "policy_logits", True)
         self.policy_logits = bool(want and self.net.supports_logits())
         self.search.policy_logits(self.policy_logits)
+        # the leaves' occupancy boards beside their planes: the fused input layer takes them directly (engine.leaf_masks = False
+        # opts out; only the hand-written trunk on byte planes reads them)
+        want_m = getattr(getattr(self.config, "engine", None), "leaf_masks", True) and os.environ.get("CZ_LEAF_MASKS", "1") != "0"
+        self.search.leaf_masks(bool(want_m and self.trunk == "mfma" and self.search.planes.dtype == torch.uint8))
 
     # ---- control ----
     def set_network(self, net):
@@ -188,9 +192,9 @@ class SelfPlayEngine:
         else:
             out = (s.policy, s.value)
             if self.compact:
-                p, v = self.net(s.planes, rows=s.q_rows, count=s.q_count, out=out, logits=self.policy_logits)
+                p, v = self.net(s.planes, rows=s.q_rows, count=s.q_count, out=out, logits=self.policy_logits, masks=s.masks)
             else:
-                p, v = self.net(s.planes, out=out, logits=self.policy_logits)
+                p, v = self.net(s.planes, out=out, logits=self.policy_logits, masks=s.masks)
             if p is s.policy:                                  # written in place (the hand-written network path)
                 return
         s.policy.copy_(p)

@@ -744,6 +744,8 @@ struct FirstArgs {
     const float* table;            // [in_planes][25][128]
     const float* in_bias;          // [128]
     const int32_t* rows;           // compact queue: board i of the batch is planes[rows[i]] (NULL: identity)
+    const uint32_t* masks;         // [n][96] occupancy boards of the same positions (cz_search_leaf_masks), or NULL: then the copy
+                                   // waves derive them from the planes
     int in_planes;
     int w1_rounds;                 // term rounds done in the first window (under K loop 1), the rest under K loop 2
 };
@@ -981,8 +983,13 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
         uint32_t pw[FIRST ? PW : 1];
         auto planes_prefetch = [&](int board) {
             const int per_board = fa.in_planes * 90;
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(
-                fa.planes + (size_t)(fa.rows ? fa.rows[board] : board) * per_board);
+            const size_t slot = (size_t)(fa.rows ? fa.rows[board] : board);
+            if (fa.masks) {                                    // the board's occupancy board, as the search kernel wrote it
+                pw[0] = fa.masks[slot * 96 + lane];
+                pw[1] = lane < 32 ? fa.masks[slot * 96 + 64 + lane] : 0u;
+                return;
+            }
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(fa.planes + slot * per_board);
 #pragma unroll
             for (int j = 0; j < PW; ++j) {
                 const int w = lane + 64 * j;
@@ -990,20 +997,25 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
             }
         };
         auto first_begin = [&]() {
-            mk[lane] = 0u;
-            if (lane < 32) mk[64 + lane] = 0u;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
+            if (fa.masks) {                                    // (round 5) the mask board arrives ready-made
+                mk[lane] = pw[0];
+                if (lane < 32) mk[64 + lane] = pw[1];
+            } else {
+                mk[lane] = 0u;
+                if (lane < 32) mk[64 + lane] = 0u;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < PW; ++j) {
-                const int w = lane + 64 * j;
-                const uint32_t word = pw[j];
-                if (word == 0u) continue;
-                int c = (w * 4) / 90, pix = w * 4 - c * 90;
+                for (int j = 0; j < PW; ++j) {
+                    const int w = lane + 64 * j;
+                    const uint32_t word = pw[j];
+                    if (word == 0u) continue;
+                    int c = (w * 4) / 90, pix = w * 4 - c * 90;
 #pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    if ((word >> (8 * k4)) & 0xFFu) atomicOr(&mk[pix], 1u << c);
-                    if (++pix == 90) { pix = 0; ++c; }
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        if ((word >> (8 * k4)) & 0xFFu) atomicOr(&mk[pix], 1u << c);
+                        if (++pix == 90) { pix = 0; ++c; }
+                    }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1582,8 +1594,13 @@ __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
         uint32_t pw[FIRST ? PW : 1];
         auto planes_prefetch = [&](int board) {                // HBM -> registers, consumed by the next first_begin
             const int per_board = fa.in_planes * 90;
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(
-                fa.planes + (size_t)(fa.rows ? fa.rows[board] : board) * per_board);
+            const size_t slot = (size_t)(fa.rows ? fa.rows[board] : board);
+            if (fa.masks) {                                    // the board's occupancy board, as the search kernel wrote it
+                pw[0] = fa.masks[slot * 96 + lane];
+                pw[1] = lane < 32 ? fa.masks[slot * 96 + 64 + lane] : 0u;
+                return;
+            }
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(fa.planes + slot * per_board);
 #pragma unroll
             for (int j = 0; j < PW; ++j) {
                 const int w = lane + 64 * j;
@@ -1591,23 +1608,28 @@ __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
             }
         };
         auto first_begin = [&]() {
-            // the occupied planes of every square as a bit mask, built by each copy wave for itself (no barrier with
-            // the other copy waves: they share nothing)
-            mk[lane] = 0u;
-            if (lane < 32) mk[64 + lane] = 0u;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            // (the board's plane words are already in registers: planes_prefetch ran a window earlier)
+            // the occupied planes of every square as a bit mask: handed in ready-made (fa.masks, cz_search_leaf_masks), or
+            // built by each copy wave for itself (no barrier with the other copy waves: they share nothing)
+            if (fa.masks) {
+                mk[lane] = pw[0];
+                if (lane < 32) mk[64 + lane] = pw[1];
+            } else {
+                mk[lane] = 0u;
+                if (lane < 32) mk[64 + lane] = 0u;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                // (the board's plane words are already in registers: planes_prefetch ran a window earlier)
 #pragma unroll
-            for (int j = 0; j < PW; ++j) {
-                const int w = lane + 64 * j;
-                const uint32_t word = pw[j];
-                if (word == 0u) continue;
-                int c = (w * 4) / 90, pix = w * 4 - c * 90;
+                for (int j = 0; j < PW; ++j) {
+                    const int w = lane + 64 * j;
+                    const uint32_t word = pw[j];
+                    if (word == 0u) continue;
+                    int c = (w * 4) / 90, pix = w * 4 - c * 90;
 #pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    if ((word >> (8 * k4)) & 0xFFu) atomicOr(&mk[pix], 1u << c);
-                    if (++pix == 90) { pix = 0; ++c; }
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        if ((word >> (8 * k4)) & 0xFFu) atomicOr(&mk[pix], 1u << c);
+                        if (++pix == 90) { pix = 0; ++c; }
+                    }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -3053,12 +3075,29 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
 
 // The input layer and the first residual block in one launch (k_resblock_pipe<FIRST>): the 5 x 5 input convolution of
 // the one-hot feature planes is a gather over the occupied squares, done by the block's copy waves.
+extern "C" int cz_input_resblock_m(const void* planes_u8, const uint32_t* masks, int in_planes, const float* in_table,
+                                   const float* in_bias, const void* w1_packed, const float* bias1, const void* w2_packed,
+                                   const float* bias2, void* y_hi, void* y_lo, int n_boards, int channels, int dtype,
+                                   const int32_t* rows, const int32_t* n_dev, void* stream);
+
 extern "C" int cz_input_resblock(const void* planes_u8, int in_planes, const float* in_table, const float* in_bias,
                                  const void* w1_packed, const float* bias1, const void* w2_packed, const float* bias2,
                                  void* y_hi, void* y_lo, int n_boards, int channels, int dtype, const int32_t* rows,
                                  const int32_t* n_dev, void* stream)
 {
-    if (n_boards < 0 || !planes_u8 || !in_table || !in_bias || !w1_packed || !w2_packed || !bias1 || !bias2 || !y_hi ||
+    return cz_input_resblock_m(planes_u8, nullptr, in_planes, in_table, in_bias, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo,
+                               n_boards, channels, dtype, rows, n_dev, stream);
+}
+
+// ... with the positions' occupancy boards handed in (masks [n][96] uint32 DEVICE, word = plane position, bit c = plane c shows
+// a piece there: what cz_search_leaf_masks makes the search kernel write beside the planes): the copy waves skip deriving them
+// from the 1260 plane bytes.  masks = NULL: exactly cz_input_resblock.  With masks the planes are not read at all.
+extern "C" int cz_input_resblock_m(const void* planes_u8, const uint32_t* masks, int in_planes, const float* in_table,
+                                   const float* in_bias, const void* w1_packed, const float* bias1, const void* w2_packed,
+                                   const float* bias2, void* y_hi, void* y_lo, int n_boards, int channels, int dtype,
+                                   const int32_t* rows, const int32_t* n_dev, void* stream)
+{
+    if (n_boards < 0 || (!planes_u8 && !masks) || !in_table || !in_bias || !w1_packed || !w2_packed || !bias1 || !bias2 || !y_hi ||
         !y_lo || in_planes < 1 || in_planes > 32 || (in_planes * 90) % 4 != 0) {
         czi_set_error("cz_input_resblock: bad argument (u8 planes, in_planes even and <= 32)");
         return CZ_ERR_ARG;
@@ -3077,7 +3116,7 @@ extern "C" int cz_input_resblock(const void* planes_u8, int in_planes, const flo
     const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
     // 6 of the ~12-16 term rounds of a board under K loop 1, the rest under K loop 2: measured on one box, extra time of
     // the launch against an inner block's: 0 rounds +0.43 ms, 3: +0.26, 6: +0.14, 9: +0.22 (window 2 also drains the result)
-    const FirstArgs fa{(const unsigned char*)planes_u8, in_table, in_bias, rows, in_planes, g_first_w1_rounds};
+    const FirstArgs fa{(const unsigned char*)planes_u8, in_table, in_bias, rows, masks, in_planes, g_first_w1_rounds};
     if (dtype == CZ_F16C6) {          // y_lo = a c6 image; w1: cz_conv3x3_c8_pack_weights' (the gather's image is c8), w2: ..._c6_...
         if (launch_resblock_c8<true, false, true>(nullptr, nullptr, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo, nullptr,
                                                   n_boards, n_cu, st, HeadArgs{}, n_dev, fa) != CZ_OK) {

@@ -94,6 +94,8 @@ struct SearchParams {
 };
 
 struct SearchBuffers {
+    // ---- optional caller-owned output (cz_search_leaf_masks): one 96-word occupancy board per queue slot ----
+    uint32_t* leaf_masks;   // [G*K][96] or NULL
     // ---- trees ----
     char* pool;             // [n_chunks] x 1 MiB
     uint32_t* pool_ring;    // [n_chunks] free chunk numbers; entries [head, tail) are free

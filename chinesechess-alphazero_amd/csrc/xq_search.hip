@@ -527,6 +527,7 @@ struct RoundIO {
     void* planes;
     int planes_dtype;
     int in_planes;
+    uint32_t* masks;       // cz_search_leaf_masks: [slots][96] occupancy boards, or NULL
 };
 
 XQ_D void encode_block(int dtype, const int8_t* b, uint8_t* codes, char* out)
@@ -547,10 +548,32 @@ XQ_D void write_planes(const RoundIO& io, const int8_t* b, uint8_t* codes, size_
     const size_t esz = io.planes_dtype == CZ_F32 ? 4 : (io.planes_dtype == CZ_U8 ? 1 : 2);
     char* out = (char*)io.planes + slot * (size_t)io.in_planes * 90 * esz;
     encode_block(io.planes_dtype, b, codes, out);
+    // the same position as an occupancy board (cz_search_leaf_masks): word pos = plane position i * 9 + j, bit c = plane c shows
+    // a piece there -- `codes` holds exactly that channel per position after the encoder's pass
+    const int lane = lane_id();
+    uint32_t m0 = 0u, m1 = 0u;
+    if (io.masks) {
+        const uint32_t c0 = codes[lane], c1 = lane < 26 ? codes[64 + lane] : 0xFFu;
+        m0 = c0 == 0xFFu ? 0u : 1u << c0;
+        m1 = c1 == 0xFFu ? 0u : 1u << c1;
+    }
     if (HIST) {
         char* out2 = out + 1260 * esz;
-        if (prev) encode_block(io.planes_dtype, prev, codes, out2);
-        else for (int q = lane_id(); q < 315 * (int)esz; q += 64) reinterpret_cast<uint32_t*>(out2)[q] = 0u;
+        if (prev) {
+            encode_block(io.planes_dtype, prev, codes, out2);
+            if (io.masks) {
+                const uint32_t c0 = codes[lane], c1 = lane < 26 ? codes[64 + lane] : 0xFFu;
+                m0 |= c0 == 0xFFu ? 0u : 1u << (14 + c0);
+                m1 |= c1 == 0xFFu ? 0u : 1u << (14 + c1);
+            }
+        } else {
+            for (int q = lane_id(); q < 315 * (int)esz; q += 64) reinterpret_cast<uint32_t*>(out2)[q] = 0u;
+        }
+    }
+    if (io.masks) {
+        uint32_t* mo = io.masks + slot * 96;
+        mo[lane] = m0;
+        if (lane < 32) mo[64 + lane] = m1;
     }
 }
 
@@ -1285,7 +1308,7 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
 #ifdef CZ_SIM_PROFILE
     const long long prof_k0 = clock64();
 #endif
-    const RoundIO io{planes, P.planes_dtype, P.in_planes};
+    const RoundIO io{planes, P.planes_dtype, P.in_planes, B.leaf_masks};
     int active = uni(B.g_active[g]);
     Arena ar{uniu(B.g_heap_top[g]), uni(B.g_nchunks[g]), uni(B.g_node_count[g])};
     const RootCtx rc{false, uni((int)B.g_n_no_act[g]), B.g_no_act + (size_t)g * MAX_NO_ACT,
@@ -2090,6 +2113,13 @@ int cz_search_set_sims(cz_search* s, int simulation_num_per_move)
     if (keep > s->P.max_chunks) keep = s->P.max_chunks;
     if (keep > s->keep_chunks_created) s->P.keep_chunks = keep;
     else s->P.keep_chunks = s->keep_chunks_created;
+    return CZ_OK;
+}
+
+int cz_search_leaf_masks(cz_search* s, uint32_t* masks)
+{
+    if (!s) return serr(CZ_ERR_ARG, "cz_search_leaf_masks: null handle");
+    s->B.leaf_masks = masks;
     return CZ_OK;
 }
 

@@ -177,6 +177,11 @@ int cz_search_set_sims(cz_search* s, int simulation_num_per_move);
  * there, so the priors are formed as exp(l_j - max over the node's moves) / their sum -- identical up to float32 rounding,
  * and the network's tail can skip normalising all 2086 columns (cz_heads_tail normalize = 0).  Default 0. */
 int cz_search_policy_logits(cz_search* s, int on);
+/* (round 5) masks [n_games * sims_per_round][96] uint32 DEVICE, caller-owned (NULL switches it off, the default): every new
+ * leaf's position is ALSO written as an occupancy board into row `slot` -- word pos = plane position, bit c = plane c (0..13 the
+ * position, 14..27 the history block of 28-plane searches) shows a piece there; state_to_planes / state_history_to_planes,
+ * environment/static_env.py:137-194, in 384 bytes -- for cz_input_resblock_m.  The planes are written as before. */
+int cz_search_leaf_masks(cz_search* s, uint32_t* masks);
 int cz_search_reset_trees(cz_search* s, void* stream);
 /* synchronises the stream; *host_out = number of games whose current search is unfinished */
 int cz_search_pending(cz_search* s, int* host_out, void* stream);
@@ -310,6 +315,15 @@ int cz_input_resblock(const void* planes_u8, int in_planes, const float* in_tabl
                       const void* w1_packed, const float* bias1, const void* w2_packed, const float* bias2, void* y_hi,
                       void* y_lo, int n_boards, int channels, int dtype, const int32_t* rows, const int32_t* n_dev,
                       void* stream);
+/* (round 5) The same with the positions' OCCUPANCY BOARDS handed in: masks [n_boards or slots][96] uint32 DEVICE, word pos =
+ * plane position i * 9 + j (words 90 .. 95 zero), bit c = plane c shows a piece there -- the planes' content in 384 bytes, which
+ * is what the block's copy waves otherwise derive from the 1260 (2520) plane bytes before they can start the gather.
+ * cz_search_leaf_masks() makes the search kernel write them beside the planes of every new leaf.  masks = NULL: exactly
+ * cz_input_resblock; with masks, planes_u8 is not read (and may be NULL).  rows index both arrays alike. */
+int cz_input_resblock_m(const void* planes_u8, const uint32_t* masks, int in_planes, const float* in_table,
+                        const float* in_bias, const void* w1_packed, const float* bias1, const void* w2_packed,
+                        const float* bias2, void* y_hi, void* y_lo, int n_boards, int channels, int dtype,
+                        const int32_t* rows, const int32_t* n_dev, void* stream);
 /* number of 2-byte elements of the packed filter (all parts, including the prefetch padding); 0 = bad argument */
 size_t cz_conv3x3_packed_elems(int channels, int parts);
 /* HOST: w_oihw[channels][channels][3][3] fp32 -> MFMA fragment order, split into parts; out_host holds
