@@ -34,18 +34,29 @@ def _line(out):
     assert out.returncode == 0 and lines, out.stderr[-3000:]
     # ONE JSON line on stdout and nothing else (RCCL's version banner, which it prints on stdout, is kept off it)
     assert len(lines) == 1 and lines[0].startswith("{"), lines[:8]
+    assert len(lines[0]) < 4096                  # the compact line the driver parses (bench.py::compact_line)
     return json.loads(lines[0])
+
+
+def _full(out):
+    """the full record of the same run: bench.py prints it on stderr behind a tag (and writes bench_full.json)"""
+    tag = "[bench full record] "
+    rec = [l for l in out.stderr.splitlines() if l.startswith(tag)]
+    assert len(rec) == 1, out.stderr[-2000:]
+    return json.loads(rec[0][len(tag):])
 
 
 def test_bench_under_the_launcher_with_one_rank_all_reduces_over_rccl():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + BENCH_ARGS
-    d = _line(subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600, cwd=ROOT))
+    out = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    d, full = _line(out), _full(out)
     c = d["collective"]
     assert c["backend"] == "nccl" and c["world"] == 1 and c["probe_ok"] is True, c
-    assert c["launched_by"] == "torch.distributed.run"
-    assert d["n_gpus"] == 1                      # the `ranks` entry of the all-reduced counter vector
-    assert d["value"] > 0 and d["tree_shape"]["tree_resets"] == 0
+    assert full["collective"]["launched_by"] == "torch.distributed.run"
+    assert d["n_gpus"] == 1 and d["per_rank_value"] == [d["value"]]   # the `ranks` entry of the all-reduced counter vector
+    assert d["value"] > 0 and full["tree_shape"]["tree_resets"] == 0
+    assert abs(full["value"] - d["value"]) <= 1e-5 * d["value"]      # the compact line rounds to 6 significant digits
 
 
 def test_bench_without_a_launcher_still_brings_rccl_up():
