@@ -538,8 +538,8 @@ def fp16_tolerance(blocks, filters):
 
 def numerics_check(eng, ref_net, cfg, nq=64):
     """The network the engine ran vs the plain fp32 PyTorch module (CPU) on positions of the last round's queue."""
-    nq = min(nq, eng.search.planes.shape[0])
-    qp = eng.search.planes[:nq].clone()
+    qp = eng.queue_planes(nq)           # (rebuilt from the leaves' occupancy boards when the kernel writes only those)
+    nq = qp.shape[0]
     with torch.no_grad():
         pg, vg = eng.net(qp)
         pc_, vc_ = ref_net.eval()(qp.float().cpu())

@@ -121,6 +121,7 @@ class Search:
         self.policy = torch.zeros((self.slots, _native.NLABELS), dtype=torch.float32, device=self.device)
         self.value = torch.zeros((self.slots,), dtype=torch.float32, device=self.device)
         self.masks = None                      # leaf_masks(): [slots, 96] int32 occupancy boards beside the planes
+        self.planes_off = False                # leaf_planes(False): new leaves are written as occupancy boards only
         self._cursor = C.c_uint(0)
 
     # -- lifetime --
@@ -194,10 +195,32 @@ class Search:
             self.masks = torch.zeros((self.slots, 96), dtype=torch.int32, device=self.device)
         if not on:
             self.masks = None
+            self.planes_off = False            # (the library switches the planes back on with the boards gone)
         ptr = C.c_void_p(self.masks.data_ptr()) if self.masks is not None else None
         self.L.cz_search_leaf_masks.argtypes = [C.c_void_p, C.c_void_p]
         self.L.cz_search_leaf_masks.restype = C.c_int
         _native.check(self.L.cz_search_leaf_masks(self.h, ptr), "cz_search_leaf_masks")
+
+    def leaf_planes(self, on=True):
+        """on=False (needs leaf_masks): a new leaf is written as its occupancy board ONLY -- for a network whose input layer
+        reads the boards (InferenceNet.takes_masks); self.planes is then not updated, queue_planes() rebuilds rows on request
+        (cz_search_leaf_planes)."""
+        self.L.cz_search_leaf_planes.argtypes = [C.c_void_p, C.c_int]
+        self.L.cz_search_leaf_planes.restype = C.c_int
+        _native.check(self.L.cz_search_leaf_planes(self.h, int(bool(on))), "cz_search_leaf_planes")
+        self.planes_off = not on
+
+    def queue_planes(self, n=None):
+        """The first n rows of the evaluation queue as a planes tensor (a copy), whatever the kernel writes: with the planes
+        switched off they are rebuilt from the occupancy boards (plane c at position pos = bit c of word pos;
+        state_to_planes, environment/static_env.py:137-156)."""
+        import torch
+        n = self.slots if n is None else min(int(n), self.slots)
+        if not self.planes_off:
+            return self.planes[:n].clone()
+        c = torch.arange(self.in_planes, device=self.device, dtype=torch.int32)
+        bits = (self.masks[:n, None, :90] >> c[None, :, None]) & 1
+        return bits.to(self.planes.dtype).view(n, self.in_planes, 10, 9)
 
     def reset_trees(self):
         _native.check(self.L.cz_search_reset_trees(self.h, self._stream()), "cz_search_reset_trees")

@@ -428,6 +428,17 @@ class InferenceNet(nn.Module):
         return (self.trunk == "mfma" and self.fused_blocks and self.filters in (128, 192) and
                 getattr(self, "head_w32", torch.empty(0)).shape[0] == 6)
 
+    def takes_masks(self, planes_dtype=torch.uint8):
+        """True when forward(masks=...) reads the occupancy boards INSTEAD of the planes: the input layer fused into the
+        first residual block (_trunk_mfma's `first_fused`) -- the engine then lets the search kernel skip the planes
+        (Search.leaf_planes(False))."""
+        if self.trunk != "mfma" or planes_dtype != torch.uint8:
+            return False
+        c, nblk = self.filters, len(self.res)
+        n8 = self.c8_blocks if self.arith == "c8" else 0
+        fused = self.fused_blocks and ((c in (128, 192)) or (c == 256 and self.parts == 1))
+        return bool(fused and self.fused_input and c == 128 and self.parts == 2 and nblk >= 2 and n8 != 1)
+
     def supports_logits(self):
         """True when forward(logits=True) is available: the hand-written dense tail on 6 head filters."""
         return (self.trunk == "mfma" and self.fused_tail and getattr(self, "head_w32", torch.empty(0)).shape[0] == 6 and

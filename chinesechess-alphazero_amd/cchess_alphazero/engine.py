@@ -102,7 +102,14 @@ class SelfPlayEngine:
         # the leaves' occupancy boards beside their planes: the fused input layer takes them directly (engine.leaf_masks = False
         # opts out; only the hand-written trunk on byte planes reads them)
         want_m = getattr(getattr(self.config, "engine", None), "leaf_masks", True) and os.environ.get("CZ_LEAF_MASKS", "1") != "0"
-        self.search.leaf_masks(bool(want_m and self.trunk == "mfma" and self.search.planes.dtype == torch.uint8))
+        use_m = bool(want_m and self.trunk == "mfma" and self.search.planes.dtype == torch.uint8)
+        self.search.leaf_masks(use_m)
+        # ... and where the network reads NOTHING but the boards (input layer fused into the first block) the kernel stops
+        # writing the planes: a leaf costs a code row + two word stores instead of the 1260-element encoder pass
+        # (engine.leaf_planes = True or CZ_LEAF_PLANES=1 keeps them; queue_planes() rebuilds rows for the audits either way)
+        keep_p = getattr(getattr(self.config, "engine", None), "leaf_planes", False) or os.environ.get("CZ_LEAF_PLANES", "0") == "1"
+        if use_m:
+            self.search.leaf_planes(bool(keep_p or not self.net.takes_masks(self.search.planes.dtype)))
 
     # ---- control ----
     def set_network(self, net):
@@ -126,6 +133,11 @@ class SelfPlayEngine:
         if had_graph:
             self.capture_graph()
 
+    def queue_planes(self, n=64):
+        """The first n positions of the evaluation queue as planes (a copy) -- rebuilt from the occupancy boards when the
+        search kernel writes only those (Search.queue_planes)."""
+        return self.search.queue_planes(n)
+
     def audit_network(self, n=64):
         """Re-measure the running arithmetic on LIVE queue positions (the load-time calibration set is random
         playouts; the positions a search actually asks about are more tactical).  Takes the first n planes of the evaluation
@@ -136,8 +148,7 @@ class SelfPlayEngine:
         from cchess_alphazero.agent.model import measure_against_reference, reference_forward_f64, within_guard
         if self.net is None or getattr(self, "_ref_net", None) is None:
             return None
-        n = min(int(n), self.search.planes.shape[0])
-        planes = self.search.planes[:n].clone()
+        planes = self.queue_planes(n)
         if planes.dtype != torch.uint8:
             planes = (planes != 0).to(torch.uint8)
         m = measure_against_reference(self.net, reference_forward_f64(self._ref_net, planes), planes)

@@ -750,6 +750,9 @@ struct FirstArgs {
     int w1_rounds;                 // term rounds done in the first window (under K loop 1), the rest under K loop 2
 };
 
+#ifndef CZ_FIRST_TERMS
+#define CZ_FIRST_TERMS 1
+#endif
 constexpr int CZ_FIRST_PRIO = 3;   // issue priority of the copy waves while they compute the fused input layer (the matrix waves
                                    // run their K loops at 3; at 0 the gather starves: first block 3.53 -> 3.48 ms)
 constexpr int CZ_C6_OUT_C8 = 127;  // y_exp of a c6-packed filter: "the image this convolution's block writes is a c8 image"
@@ -1048,6 +1051,10 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
                 cur_tap[it] = 0;
             }
         };
+        // CZ_FIRST_TERMS (build switch, 1 or 2): table rows fetched per chunk and ROUND.  A round is one L2 round trip; with 2 the
+        // walk of a board takes half as many of them (two rows in flight per chunk) at 48 more registers; the rows are added
+        // in the same order either way (bit-identical results).  max_rounds counts TERMS.
+#if CZ_FIRST_TERMS == 1
         auto first_rounds = [&](int max_rounds) {
 #pragma unroll 1
             for (int round = 0; round < max_rounds; ++round) {
@@ -1086,6 +1093,60 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
                 }
             }
         };
+#else
+        auto first_rounds = [&](int max_rounds) {
+            constexpr int FT = CZ_FIRST_TERMS;
+#pragma unroll 1
+            for (int round = 0; round < max_rounds; round += FT) {
+                uint32_t any = 0u;
+                bool act[FT][LITER];
+                const float4* tp[FT][LITER];
+#pragma unroll
+                for (int k = 0; k < FT; ++k) {
+#pragma unroll
+                    for (int it = 0; it < LITER; ++it) {
+                        if (cur_m[it] == 0u && occ[it] != 0u) {
+                            const int tap = __builtin_ctz(occ[it]);
+                            occ[it] &= occ[it] - 1u;
+                            const int p = prow + 16 * it;
+                            cur_tap[it] = tap;
+                            cur_m[it] = mk[p + (tap / 5 - 2) * 9 + (tap % 5 - 2)];
+                        }
+                        any |= cur_m[it];
+                        act[k][it] = cur_m[it] != 0u;
+                        tp[k][it] = nullptr;
+                        if (act[k][it]) {
+                            const int c = __builtin_ctz(cur_m[it]);
+                            tp[k][it] = reinterpret_cast<const float4*>(fa.table + ((size_t)(c * 25 + cur_tap[it]) * 128 + c8 * 8));
+                            cur_m[it] &= cur_m[it] - 1u;
+                        }
+                    }
+                }
+                if (!__ballot(any != 0u)) break;
+                float4 wa[FT][LITER], wb[FT][LITER];
+#pragma unroll
+                for (int k = 0; k < FT; ++k)
+#pragma unroll
+                    for (int it = 0; it < LITER; ++it) {
+                        wa[k][it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        wb[k][it] = wa[k][it];
+                        if (act[k][it]) {
+                            wa[k][it] = tp[k][it][0];
+                            wb[k][it] = tp[k][it][1];
+                        }
+                    }
+#pragma unroll
+                for (int k = 0; k < FT; ++k)
+#pragma unroll
+                    for (int it = 0; it < LITER; ++it) {
+                        if (act[k][it]) {
+                            acc[it][0] += wa[k][it].x; acc[it][1] += wa[k][it].y; acc[it][2] += wa[k][it].z; acc[it][3] += wa[k][it].w;
+                            acc[it][4] += wb[k][it].x; acc[it][5] += wb[k][it].y; acc[it][6] += wb[k][it].z; acc[it][7] += wb[k][it].w;
+                        }
+                    }
+            }
+        };
+#endif
         auto first_end = [&]() {                              // ReLU, c8 split, pack (see write_x)
 #pragma unroll
             for (int it = 0; it < LITER; ++it) {

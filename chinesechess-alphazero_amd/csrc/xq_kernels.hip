@@ -266,6 +266,73 @@ XQ_D void tpb_write_planes(const int8_t* codes, void* __restrict__ out, const Ch
     }
 }
 
+// ---- (round 5) planes as zero-fill + scatter -----------------------------------------------------------------------------
+// A board's 14 x 90 planes hold at most 32 ones.  The encoder above spends ~100 instructions per board on comparing every
+// element's code (phase 3 was half of the kernel's issue slots); instead the block's planes -- one contiguous run of
+// nb x 1260 elements -- are ZEROED with wide stores before the boards are even loaded (nothing to compute), and after the
+// rules each lane sets the ones of ITS board: one store per piece.  The zero stores are acknowledged by the L2 (vmcnt = 0)
+// before the first one is issued, so a one always lands on its zero.  MEASURED (profiles/r05_ab_tpb_scatter.log): with the
+// zeros written at the start of the iteration the 1 M-board suite went from 1.55 to 2.51 ms -- by the time the ones arrive
+// their lines have left the L2 and each becomes a partial write to HBM.  Build switch, default 0 (the encoder path).
+#ifndef CZ_TPB_SCATTER
+#define CZ_TPB_SCATTER 0
+#endif
+#ifndef CZ_TPB_ZERO_LATE
+#define CZ_TPB_ZERO_LATE 1
+#endif
+template <int DT>
+XQ_D void tpb_zero_planes(void* __restrict__ planes, int base, int nb)
+{
+    constexpr size_t esz = DT == 0 ? 4 : (DT == 3 ? 1 : 2);
+    const int lane = lane_id();
+    char* p = (char*)planes + (size_t)base * 1260 * esz;
+    size_t bytes = (size_t)nb * 1260 * esz;                                  // a multiple of 4
+    const int head = (int)((16u - (unsigned)((uintptr_t)p & 15u)) & 15u);    // bytes up to the first 16-byte boundary
+    if (head) {
+        if (lane * 4 < head) reinterpret_cast<uint32_t*>(p)[lane] = 0u;
+        p += head;
+        bytes -= (size_t)head;
+    }
+    uint4* p4 = reinterpret_cast<uint4*>(p);
+    const int n16 = (int)(bytes >> 4);
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    int i = lane;
+    for (; i + 192 < n16; i += 256) {                                        // four 1 KB rows per pass
+        p4[i] = z; p4[i + 64] = z; p4[i + 128] = z; p4[i + 192] = z;
+    }
+    for (; i < n16; i += 64) p4[i] = z;
+    const int tail = (int)(bytes & 15u) >> 2;
+    if (lane < tail) reinterpret_cast<uint32_t*>(p4 + n16)[lane] = 0u;
+}
+// the ones of this lane's board (b: int8[90] in LDS, 4-byte aligned, y = 0 first): piece p on square (x, y) -> plane
+// (p > 0 ? p - 1 : 6 - p), row 9 - y, column x (state_to_planes, static_env.py:137-156).  `ub` = the planes of the block's
+// first board (wave-uniform), `lane_off` = this lane's board inside the block, in bytes.  The board is read once (23 words),
+// the 90 squares are then walked in registers: no LDS wait per square.
+template <int DT>
+XQ_D void tpb_scatter_ones(const int8_t* b, char* __restrict__ ub, uint32_t lane_off)
+{
+    constexpr uint32_t esz = DT == 0 ? 4 : (DT == 3 ? 1 : 2);
+    uint32_t w[23];
+#pragma unroll
+    for (int k = 0; k < 23; ++k) w[k] = reinterpret_cast<const uint32_t*>(b)[k];
+#pragma unroll
+    for (int s = 0; s < 90; ++s) {
+        const int p = (int)(int8_t)(w[s >> 2] >> (8 * (s & 3)));
+        if (p == 0) continue;
+        const int y = s / 9, x = s - y * 9;
+        // address = uniform base + (lane's board + plane) in a register + the square's position as the instruction's
+        // immediate offset (lo is laundered so that the compiler does not keep 90 pre-added offsets in registers)
+        uint32_t lo = lane_off;
+        asm volatile("" : "+v"(lo));
+        const uint32_t off = lo + (uint32_t)(p > 0 ? p - 1 : 6 - p) * (90u * esz);
+        char* q = ub + (size_t)(((9 - y) * 9 + x) * (int)esz) + off;
+        if (DT == 0) *reinterpret_cast<float*>(q) = 1.0f;
+        else if (DT == 1) *reinterpret_cast<uint16_t*>(q) = (uint16_t)0x3C00u;
+        else if (DT == 2) *reinterpret_cast<uint16_t*>(q) = (uint16_t)0x3F80u;
+        else *reinterpret_cast<uint8_t*>(q) = (uint8_t)1;
+    }
+}
+
 // outputs that are NULL are skipped (cz_movegen: moves + counts; cz_done: flags; cz_rules_fused: everything)
 template <int DT>
 __global__ __launch_bounds__(64) void k_rules_tpb(const int8_t* __restrict__ boards, int n, int need_check,
@@ -282,6 +349,8 @@ __global__ __launch_bounds__(64) void k_rules_tpb(const int8_t* __restrict__ boa
     for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int base = blk * 64;
         const int nb = n - base < 64 ? n - base : 64;
+        // 0. the block's planes, zeroed (see tpb_zero_planes)
+        if (CZ_TPB_SCATTER && !CZ_TPB_ZERO_LATE && planes) tpb_zero_planes<DT>(planes, base, nb);
         // 1. the boards of this block: one contiguous run of nb * 90 bytes, 2 bytes per lane per step
         const uint16_t* src = reinterpret_cast<const uint16_t*>(boards + (size_t)base * NSQ);
         for (int u = lane; u < nb * 45; u += 64) {
@@ -301,7 +370,16 @@ __global__ __launch_bounds__(64) void k_rules_tpb(const int8_t* __restrict__ boa
             if (counts) counts[i] = (uint8_t)(r.n < 255 ? r.n : 255);
             if (over) { over[i] = (int8_t)r.over; v[i] = (int8_t)r.v; final_move[i] = (uint16_t)r.final_move; }
             if (check) check[i] = (uint8_t)r.check;
-            if (planes) board_to_plane_codes(b);
+            if (planes && !CZ_TPB_SCATTER) board_to_plane_codes(b);
+        }
+        if (CZ_TPB_SCATTER && planes) {
+            // (ZERO_LATE: the zeros go out right before the ones, so that the ones still find their lines in the L2 -- zeroed
+            //  at the start of the iteration they had been evicted by then and every one became a partial write to HBM)
+            if (CZ_TPB_ZERO_LATE) tpb_zero_planes<DT>(planes, base, nb);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the zeros have reached the L2
+            if (lane < nb)
+                tpb_scatter_ones<DT>(L.bd + lane * TPB_BOARD_STRIDE, (char*)planes + (size_t)base * 1260 * esz,
+                                     (uint32_t)lane * (uint32_t)(1260 * esz));
         }
         __syncthreads();
         // 3. move lists and planes leave one board at a time, the whole wave storing contiguously
@@ -314,7 +392,7 @@ __global__ __launch_bounds__(64) void k_rules_tpb(const int8_t* __restrict__ boa
                 const uint32_t hi = (2 * lane + 1 < c) ? (pair >> 16) : (uint32_t)NOMOVE;
                 reinterpret_cast<uint32_t*>(moves + (size_t)(base + k) * MAXMOVES)[lane] = lo | (hi << 16);
             }
-            if (planes)
+            if (!CZ_TPB_SCATTER && planes)
                 tpb_write_planes<DT>(L.bd + k * TPB_BOARD_STRIDE, (char*)planes + (size_t)(base + k) * 1260 * esz, cm);
         }
         __syncthreads();

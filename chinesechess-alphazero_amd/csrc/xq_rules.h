@@ -59,6 +59,58 @@ XQ_D int wave_incl_scan(int v)
     return v;
 }
 
+// Wave-wide reductions on the same DPP ladder (round 5): the running value of lane 63 after the six steps is the
+// reduction over all 64 lanes; one v_readlane hands it to everybody as a scalar.  A lane without a source keeps its own
+// value (old = the value itself, bound_ctrl off), which is neutral for max / min.  These replace the six-stage
+// __shfl_xor butterflies (two ds_bpermute round trips per stage for a double) on the PUCT arg-max of every tree level.
+#define XQ_DPP_STEP_MAX_F64(v, ctrl, rmask)                                                                          \
+    do {                                                                                                             \
+        const long long b_ = __double_as_longlong(v);                                                               \
+        const int lo_ = __builtin_amdgcn_update_dpp((int)b_, (int)b_, ctrl, rmask, 0xF, false);                     \
+        const int hi_ = __builtin_amdgcn_update_dpp((int)(b_ >> 32), (int)(b_ >> 32), ctrl, rmask, 0xF, false);     \
+        const double o_ = __longlong_as_double((long long)(((unsigned long long)(unsigned int)hi_ << 32) | (unsigned int)lo_)); \
+        v = o_ > v ? o_ : v;                                                                                         \
+    } while (0)
+XQ_D double wave_max_f64(double v)          // v is never NaN
+{
+    XQ_DPP_STEP_MAX_F64(v, 0x111, 0xF);
+    XQ_DPP_STEP_MAX_F64(v, 0x112, 0xF);
+    XQ_DPP_STEP_MAX_F64(v, 0x114, 0xF);
+    XQ_DPP_STEP_MAX_F64(v, 0x118, 0xF);
+    XQ_DPP_STEP_MAX_F64(v, 0x142, 0xA);
+    XQ_DPP_STEP_MAX_F64(v, 0x143, 0xC);
+    const long long b = __double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)b, 63);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+#undef XQ_DPP_STEP_MAX_F64
+#define XQ_DPP_STEP_MAX_F32(v, ctrl, rmask)                                                                          \
+    do {                                                                                                             \
+        const float o_ = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rmask, 0xF, false)); \
+        v = o_ > v ? o_ : v;                                                                                         \
+    } while (0)
+XQ_D float wave_max_f32(float v)            // v is never NaN
+{
+    XQ_DPP_STEP_MAX_F32(v, 0x111, 0xF);
+    XQ_DPP_STEP_MAX_F32(v, 0x112, 0xF);
+    XQ_DPP_STEP_MAX_F32(v, 0x114, 0xF);
+    XQ_DPP_STEP_MAX_F32(v, 0x118, 0xF);
+    XQ_DPP_STEP_MAX_F32(v, 0x142, 0xA);
+    XQ_DPP_STEP_MAX_F32(v, 0x143, 0xC);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+#undef XQ_DPP_STEP_MAX_F32
+// xor over lanes 0 .. 15 (the first DPP row), returned as a scalar: lane 15 of the row's inclusive xor scan
+XQ_D uint32_t row0_xor_u32(uint32_t v)
+{
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+}
+
 XQ_D int highest_bit(uint64_t lo, uint64_t hi)   // index over the 128-bit (lo: 0..63, hi: 64..127), -1 if none
 {
     if (hi) return 64 + 63 - __clzll((long long)hi);

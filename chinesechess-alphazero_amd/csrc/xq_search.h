@@ -96,6 +96,7 @@ struct SearchParams {
 struct SearchBuffers {
     // ---- optional caller-owned output (cz_search_leaf_masks): one 96-word occupancy board per queue slot ----
     uint32_t* leaf_masks;   // [G*K][96] or NULL
+    int leaf_planes_off;    // cz_search_leaf_planes(0): with leaf_masks set, the planes of a new leaf are NOT written
     // ---- trees ----
     char* pool;             // [n_chunks] x 1 MiB
     uint32_t* pool_ring;    // [n_chunks] free chunk numbers; entries [head, tail) are free

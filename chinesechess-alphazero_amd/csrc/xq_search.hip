@@ -188,14 +188,10 @@ XQ_D uint64_t pack_key(const int8_t* b, uint32_t* key)
         key[lane] = w;
         h = mix64((uint64_t)w + 0x9E3779B97F4A7C15ULL * (uint64_t)(lane + 1));
     }
-    uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-        lo ^= (uint32_t)__shfl_xor((int)lo, d, 64);
-        hi ^= (uint32_t)__shfl_xor((int)hi, d, 64);
-    }
+    // xor of the twelve word hashes (lanes 12 .. 15 hold 0): a DPP scan of the first row, no LDS permute
+    const uint32_t lo = row0_xor_u32((uint32_t)h), hi = row0_xor_u32((uint32_t)(h >> 32));
     wave_sync();
-    h = ((uint64_t)uniu(hi) << 32) | uniu(lo);
+    h = ((uint64_t)hi << 32) | lo;
     return mix64(h);
 }
 
@@ -205,13 +201,8 @@ XQ_D uint64_t hash_of_key(const uint32_t* key)
     const int lane = lane_id();
     uint64_t h = 0;
     if (lane < KEY_WORDS) h = mix64((uint64_t)key[lane] + 0x9E3779B97F4A7C15ULL * (uint64_t)(lane + 1));
-    uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-        lo ^= (uint32_t)__shfl_xor((int)lo, d, 64);
-        hi ^= (uint32_t)__shfl_xor((int)hi, d, 64);
-    }
-    h = ((uint64_t)uniu(hi) << 32) | uniu(lo);
+    const uint32_t lo = row0_xor_u32((uint32_t)h), hi = row0_xor_u32((uint32_t)(h >> 32));
+    h = ((uint64_t)hi << 32) | lo;
     return mix64(h);
 }
 
@@ -302,11 +293,7 @@ XQ_D void logits_to_weights(float& q0, float& q1, int nm)
     const bool h0 = lane < nm, h1 = lane + 64 < nm;
     float m = h0 ? q0 : -3.0e38f;
     if (h1 && q1 > m) m = q1;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const float o = __shfl_xor(m, d, 64);
-        m = o > m ? o : m;
-    }
+    m = wave_max_f32(m);
     q0 = h0 ? __expf(q0 - m) : 0.0f;
     q1 = h1 ? __expf(q1 - m) : 0.0f;
 }
@@ -463,9 +450,7 @@ XQ_D Picked select_edge(const SearchParams& P, char* base, const EdgeStat* sb, i
         // arg max of (score, index): `>=` keeps the LAST maximal move (player.py:312-314).  The maximum itself by a
         // butterfly on the score alone (never NaN: see `valid`), then the lanes that hold it vote: the largest index wins,
         // and an index of the second half (lane + 64) beats any of the first.
-        double m = best_s;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) m = fmax(m, __shfl_xor(m, d, 64));
+        const double m = wave_max_f64(best_s);                       // DPP ladder (xq_rules.h), no LDS permutes
         const bool top = best_j >= 0 && best_s == m;
         const uint64_t t1 = __ballot(top && best_j >= 64), t0 = __ballot(top);
         pick = t1 ? 64 + (63 - __clzll((long long)t1)) : (t0 ? 63 - __clzll((long long)t0) : -1);
@@ -528,7 +513,21 @@ struct RoundIO {
     int planes_dtype;
     int in_planes;
     uint32_t* masks;       // cz_search_leaf_masks: [slots][96] occupancy boards, or NULL
+    bool planes_off;       // cz_search_leaf_planes(0): only the occupancy boards are written
 };
+
+// codes[pos] = plane (0..13) of the piece that plane position pos shows, 0xFF = empty: the first pass of wave_encode_codes
+XQ_D void board_codes(const int8_t* b, uint8_t* codes)
+{
+    const int lane = lane_id();
+    wave_sync();
+    for (int s = lane; s < NSQ; s += 64) {
+        const int p = b[s];
+        const int y = s / 9, x = s - y * 9;
+        codes[(9 - y) * 9 + x] = (uint8_t)(p == 0 ? 0xFF : (p > 0 ? p - 1 : 6 - p));
+    }
+    wave_sync();
+}
 
 XQ_D void encode_block(int dtype, const int8_t* b, uint8_t* codes, char* out)
 {
@@ -547,7 +546,11 @@ XQ_D void write_planes(const RoundIO& io, const int8_t* b, uint8_t* codes, size_
 {
     const size_t esz = io.planes_dtype == CZ_F32 ? 4 : (io.planes_dtype == CZ_U8 ? 1 : 2);
     char* out = (char*)io.planes + slot * (size_t)io.in_planes * 90 * esz;
-    encode_block(io.planes_dtype, b, codes, out);
+    // (round 5) a caller whose network reads the occupancy boards alone (cz_input_resblock_m) switches the planes off
+    // (cz_search_leaf_planes): the leaf then costs the code row + two word stores instead of the 1260-element encoder pass
+    const bool only_masks = io.masks && io.planes_off;
+    if (only_masks) board_codes(b, codes);
+    else encode_block(io.planes_dtype, b, codes, out);
     // the same position as an occupancy board (cz_search_leaf_masks): word pos = plane position i * 9 + j, bit c = plane c shows
     // a piece there -- `codes` holds exactly that channel per position after the encoder's pass
     const int lane = lane_id();
@@ -560,13 +563,14 @@ XQ_D void write_planes(const RoundIO& io, const int8_t* b, uint8_t* codes, size_
     if (HIST) {
         char* out2 = out + 1260 * esz;
         if (prev) {
-            encode_block(io.planes_dtype, prev, codes, out2);
+            if (only_masks) board_codes(prev, codes);
+            else encode_block(io.planes_dtype, prev, codes, out2);
             if (io.masks) {
                 const uint32_t c0 = codes[lane], c1 = lane < 26 ? codes[64 + lane] : 0xFFu;
                 m0 |= c0 == 0xFFu ? 0u : 1u << (14 + c0);
                 m1 |= c1 == 0xFFu ? 0u : 1u << (14 + c1);
             }
-        } else {
+        } else if (!only_masks) {
             for (int q = lane_id(); q < 315 * (int)esz; q += 64) reinterpret_cast<uint32_t*>(out2)[q] = 0u;
         }
     }
@@ -1308,7 +1312,7 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
 #ifdef CZ_SIM_PROFILE
     const long long prof_k0 = clock64();
 #endif
-    const RoundIO io{planes, P.planes_dtype, P.in_planes, B.leaf_masks};
+    const RoundIO io{planes, P.planes_dtype, P.in_planes, B.leaf_masks, B.leaf_planes_off != 0};
     int active = uni(B.g_active[g]);
     Arena ar{uniu(B.g_heap_top[g]), uni(B.g_nchunks[g]), uni(B.g_node_count[g])};
     const RootCtx rc{false, uni((int)B.g_n_no_act[g]), B.g_no_act + (size_t)g * MAX_NO_ACT,
@@ -2120,6 +2124,15 @@ int cz_search_leaf_masks(cz_search* s, uint32_t* masks)
 {
     if (!s) return serr(CZ_ERR_ARG, "cz_search_leaf_masks: null handle");
     s->B.leaf_masks = masks;
+    if (!masks) s->B.leaf_planes_off = 0;
+    return CZ_OK;
+}
+
+int cz_search_leaf_planes(cz_search* s, int on)
+{
+    if (!s) return serr(CZ_ERR_ARG, "cz_search_leaf_planes: null handle");
+    if (!on && !s->B.leaf_masks) return serr(CZ_ERR_ARG, "cz_search_leaf_planes: the planes can only be switched off while cz_search_leaf_masks is set");
+    s->B.leaf_planes_off = on ? 0 : 1;
     return CZ_OK;
 }
 

@@ -182,6 +182,11 @@ int cz_search_policy_logits(cz_search* s, int on);
  * position, 14..27 the history block of 28-plane searches) shows a piece there; state_to_planes / state_history_to_planes,
  * environment/static_env.py:137-194, in 384 bytes -- for cz_input_resblock_m.  The planes are written as before. */
 int cz_search_leaf_masks(cz_search* s, uint32_t* masks);
+/* (round 5) on = 0: while cz_search_leaf_masks is set, a new leaf is written as its occupancy board ONLY -- for a caller whose
+ * network takes the boards (cz_input_resblock_m reads nothing else); the `planes` rows of cz_search_round(_q) are then left
+ * untouched.  on = 1 (default) writes both.  CZ_ERR_ARG when switched off without masks; clearing the masks switches the
+ * planes back on.  (state_to_planes, environment/static_env.py:137-156: the same information in 384 bytes.) */
+int cz_search_leaf_planes(cz_search* s, int on);
 int cz_search_reset_trees(cz_search* s, void* stream);
 /* synchronises the stream; *host_out = number of games whose current search is unfinished */
 int cz_search_pending(cz_search* s, int* host_out, void* stream);

@@ -371,7 +371,7 @@ def test_selfplay_worker_reloads_a_new_best_model(tmp_path, monkeypatch):
     w = SelfPlayWorker(cfg, model=m)
     w.run(max_rounds=8)
     assert not w.reload_best_model()                         # same digest: nothing to do
-    x = w.engine.search.planes[:8].clone()
+    x = w.engine.queue_planes(8)
     p0, _ = w.engine.net(x)
     other = CChessModel(cfg)
     other.build(seed=2)
@@ -411,7 +411,7 @@ def test_engine_keeps_its_network_when_a_reload_fails_and_audits_live_positions(
     assert len(audits) == 1 and audits[0]["ok"] and audits[0]["arith"] == w.engine.net_arith_effective == "c6"
     assert audits[0]["logit_max_abs"] < 2e-4 and audits[0]["policy_max_abs"] < 5e-5
     # (a) a guard that raises: nothing changes
-    old_net, x = w.engine.net, w.engine.search.planes[:8].clone()
+    old_net, x = w.engine.net, w.engine.queue_planes(8)
     p0, _ = old_net(x)
     other = CChessModel(cfg)
     other.build(seed=2)

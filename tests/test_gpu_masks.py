@@ -78,3 +78,89 @@ def test_network_with_handed_in_masks_is_identical(arith):
         pc, vc = g(planes, rows=rows, count=count, masks=masks)
         sel = rows[:211].long()
         assert torch.equal(pc[:211], p0[sel]) and torch.equal(vc[:211], v0[sel]), (arith, depth)
+
+
+@pytest.mark.parametrize("use_history", [False, True])
+def test_leaves_as_occupancy_boards_only(use_history):
+    """cz_search_leaf_planes(0): the kernel writes the boards and leaves the planes alone; queue_planes() rebuilds the same
+    planes; the search itself (driven by the same network outputs) is unchanged edge for edge."""
+    import types
+    import torch
+    import stub_net
+    from cchess_alphazero import _native, _native_search
+    pc = types.SimpleNamespace(simulation_num_per_move=48, search_threads=6, c_puct=1.5, noise_eps=0.0, dirichlet_alpha=0.2,
+                               tau_decay_rate=0.0, virtual_loss=3, resign_threshold=-0.92, min_resign_turn=20,
+                               max_game_length=40, enable_resign_rate=1.0)
+
+    def run(planes_on):
+        s = _native_search.Search(pc, 32, seed=9, planes_dtype=_native.U8, use_history=use_history)
+        with pytest.raises(_native.NativeError):
+            s.leaf_planes(False)                               # not without the boards
+        s.leaf_masks(True)
+        s.leaf_planes(planes_on)
+        s.planes.fill_(77)                                     # a sentinel no encoder writes
+        s.start_selfplay(seed=9)
+        seen = []
+        for r in range(30):
+            s.round(compact=True)
+            cnt = int(s.q_count.item())
+            rows = s.q_rows[:cnt].long()
+            qp = s.queue_planes()
+            if planes_on:
+                assert torch.equal(qp[rows], s.planes[rows])
+            else:
+                assert int((s.planes != 77).sum()) == 0, r     # untouched
+                assert torch.equal(_masks_from_planes(qp[rows]), s.masks[rows])
+            seen.append((rows.clone(), s.masks[rows].clone()))
+            p, v = stub_net.hash_stub_torch(qp, 3)
+            s.policy[:cnt].copy_(p[rows])
+            s.value[:cnt].copy_(v[rows])
+        st = s.root_stats()
+        c = s.counters()
+        s.leaf_masks(False)
+        assert s.planes_off is False
+        s.close()
+        return seen, st, c
+
+    a, sa, ca = run(True)
+    b, sb, cb = run(False)
+    assert len(a) == len(b)
+    for (ra, ma), (rb, mb) in zip(a, b):
+        # (the compact queue's row order is arbitrary between launches: compare by slot)
+        ia, ib = ra.argsort(), rb.argsort()
+        assert torch.equal(ra[ia], rb[ib]) and torch.equal(ma[ia], mb[ib])
+    for k in ("n", "w", "counts"):
+        assert (sa[k] == sb[k]).all(), k
+    assert ca["expansions"] == cb["expansions"] and ca["sims"] == cb["sims"] and ca["plies"] == cb["plies"]
+
+
+def test_engine_switches_the_planes_off_and_plays_the_same_games(monkeypatch):
+    """SelfPlayEngine: with the input layer fused into the first block the engine asks for boards only (Search.planes_off);
+    CZ_LEAF_PLANES=1 keeps the planes.  Same seeds, same network -> the same visit counts either way; the audit positions
+    (queue_planes) are real positions in both."""
+    import torch as t
+    from cchess_alphazero.config import Config
+    from cchess_alphazero.engine import SelfPlayEngine
+
+    def run(keep):
+        monkeypatch.setenv("CZ_LEAF_PLANES", "1" if keep else "0")
+        cfg = Config("mini")
+        cfg.model.cnn_filter_num, cfg.model.res_layer_num = 128, 2
+        cfg.play.simulation_num_per_move, cfg.play.search_threads, cfg.play.noise_eps = 40, 4, 0.0
+        eng = SelfPlayEngine(cfg, 64, dtype=t.float32, seed=11)
+        assert eng.search.masks is not None and eng.net.takes_masks()
+        assert eng.search.planes_off == (not keep)
+        eng.start()
+        for _ in range(12):
+            eng.step()
+        st = eng.search.root_stats()
+        qp = eng.queue_planes(64)
+        assert qp.shape == (64, 14, 10, 9) and int(qp.sum()) > 64 * 10      # positions, not an empty queue
+        au = eng.audit_network(32)
+        assert au is None or au["ok"]
+        return st, qp
+
+    (a, qa), (b, qb) = run(True), run(False)
+    for k in ("n", "w", "counts"):
+        assert (a[k] == b[k]).all(), k
+    assert t.equal(qa, qb)

@@ -673,7 +673,7 @@ def test_engine_queue_of_logits_gives_the_priors_of_the_softmax_queue(gpu):
         for _ in range(6):
             eng.step()
         st = eng.search.root_stats()
-        x = eng.search.planes[:64].clone()
+        x = eng.queue_planes(64)
         p, _ = eng.net(x)                                       # (outside the engine the rows stay probabilities)
         assert (p.sum(1) - 1).abs().max().item() < 1e-5
         return st

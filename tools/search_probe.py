@@ -4,7 +4,7 @@ the hash-stub network (tests/stub_net.py: microseconds per round instead of 30 m
 games in every phase, trees tens of thousands of nodes deep -- take seconds; then the search round is timed with HIP
 events over the next rounds (per-launch: mean / median / p99).  A/B tool for changes to csrc/xq_search.hip.
 
-    python tools/search_probe.py [--rounds 3000] [--timed 200] [--compact 1]
+    python tools/search_probe.py [--rounds 3000] [--timed 200] [--compact 1] [--masks-only 1]
 """
 import argparse
 import json
@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--timed", type=int, default=200)
     ap.add_argument("--compact", type=int, default=1)
     ap.add_argument("--games", type=int, default=4096)
+    ap.add_argument("--masks-only", type=int, default=0, help="1: leaves written as occupancy boards only (cz_search_leaf_planes(0))")
     a = ap.parse_args()
     import types
     import stub_net
@@ -31,12 +32,16 @@ def main():
                                dirichlet_alpha=0.2, tau_decay_rate=0.9, virtual_loss=3, resign_threshold=-0.98,
                                min_resign_turn=40, max_game_length=100, enable_resign_rate=0.5)
     s = Search(pc, a.games, planes_dtype=_native.U8, seed=20260923)
+    if a.masks_only:
+        s.leaf_masks(True)
+        s.leaf_planes(False)
     s.start_selfplay(seed=20260923)
+    planes_of = (lambda: s.queue_planes()) if a.masks_only else (lambda: s.planes)   # (the same planes either way: same trees)
 
     def step():
         s.round(compact=bool(a.compact))
         # a near-uniform, position-dependent network: cheap, and the trees grow like the random-init net's
-        p, v = stub_net.hash_stub_torch(s.planes, 1)
+        p, v = stub_net.hash_stub_torch(planes_of(), 1)
         p = p * 0 + 1.0 / 2086 + p * 1e-3
         if a.compact:
             n = s.slots
@@ -57,7 +62,7 @@ def main():
         s.round(compact=bool(a.compact))
         e[1].record()
         ev.append(e)
-        p, v = stub_net.hash_stub_torch(s.planes, 1)
+        p, v = stub_net.hash_stub_torch(planes_of(), 1)
         p = p * 0 + 1.0 / 2086 + p * 1e-3
         if a.compact:
             rows = s.q_rows.long().clamp_(0, s.slots - 1)
@@ -69,7 +74,7 @@ def main():
     torch.cuda.synchronize()
     t = sorted(x.elapsed_time(y) for x, y in ev)
     c, m = s.counters(), s.memory_info()
-    out = {"rounds_before": a.rounds, "timed": a.timed, "compact": a.compact,
+    out = {"rounds_before": a.rounds, "timed": a.timed, "compact": a.compact, "masks_only": a.masks_only,
            "search_round_ms": {"mean": sum(t) / len(t), "median": t[len(t) // 2], "p99": t[int(len(t) * 0.99)], "max": t[-1]},
            "mean_depth": c["sum_depth"] / max(1, c["sims"]), "plies": c["plies"], "games": c["games"],
            "tree_resets": c["tree_resets"], "nodes": m["nodes"], "tree_gb": m["tree_bytes"] / 1e9}
