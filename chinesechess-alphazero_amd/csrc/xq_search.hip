@@ -331,25 +331,50 @@ XQ_D void attach_policy(const GameView& gv, SearchLDS& L, int node, const float*
 // with the path's edge ids, then the priors of those labels with the statistics of those edges -- two dependent memory
 // round trips per leaf instead of five (the BACKUP launch is nothing but such chains, eight leaves one after the other).
 // Same arithmetic, same lanes writing the same words as the three functions it replaces.  depth <= 64.
+// (round 5) The part of a leaf's chain that does not depend on the tree -- its move labels, its path's edge ids, the network
+// row's entries for those labels -- is fetched one leaf AHEAD (LeafPre: leaf_pre_a, then leaf_pre_b once the labels are
+// back), under the previous leaf's edge update and fence; what stays in a leaf's serial chain is the edge statistics' load,
+// the arithmetic and the store fence: two memory round trips per leaf instead of three.
+struct LeafPre {
+    uint16_t m0, m1;
+    int e;
+    float p0, p1;
+};
+XQ_D void leaf_pre_a(const GameView& gv, LeafPre& lp, int node, uint32_t meta, int depth, const int32_t* __restrict__ hp_edge)
+{
+    const int lane = lane_id();
+    char* base = rec_ptr(gv, (uint32_t)node);
+    const int nm = (int)(meta & 0xFF);
+    const uint16_t* pm = node_mv(base, nm);
+    lp.m0 = 0; lp.m1 = 0; lp.e = 0;
+    if (lane < nm) lp.m0 = pm[lane];
+    if (lane + 64 < nm) lp.m1 = pm[lane + 64];
+    if (lane < depth) lp.e = hp_edge[lane];
+}
+XQ_D void leaf_pre_b(LeafPre& lp, uint32_t meta, const float* __restrict__ prow)
+{
+    const int lane = lane_id();
+    const int nm = (int)(meta & 0xFF);
+    lp.p0 = 0.0f; lp.p1 = 0.0f;
+    if (lane < nm) lp.p0 = prow[lp.m0];
+    if (lane + 64 < nm) lp.p1 = prow[lp.m1];
+}
+
+// `lp`: this leaf's prefetched labels / edge ids / row entries.  `next`: issued between this leaf's edge-statistics load and
+// its arithmetic -- the caller's prefetch of the following leaf.
+template <typename Next>
 XQ_D void attach_and_backup(const SearchParams& P, const GameView& gv, SearchLDS& L, int node, uint32_t meta, int depth,
-                            const float* __restrict__ prow, double v, const int32_t* __restrict__ hp_edge, bool logits = false)
+                            const LeafPre& lp, double v, bool logits, Next&& next)
 {
     const int lane = lane_id();
     char* base = rec_ptr(gv, (uint32_t)node);
     const int nm = (int)(meta & 0xFF);
     float* pp = node_p(base);
-    const uint16_t* pm = node_mv(base, nm);
-    uint16_t m0 = 0, m1 = 0;
-    int e = 0;
-    if (lane < nm) m0 = pm[lane];
-    if (lane + 64 < nm) m1 = pm[lane + 64];
-    if (lane < depth) e = hp_edge[lane];
-    float p0 = 0.0f, p1 = 0.0f;
+    float p0 = lp.p0, p1 = lp.p1;
     EdgeStat cur{0.0, 0, 0};
     EdgeStat* ep = nullptr;
-    if (lane < nm) p0 = prow[m0];
-    if (lane + 64 < nm) p1 = prow[m1];
-    if (lane < depth) { ep = edge_ptr(gv, (uint32_t)e); cur = *ep; }
+    if (lane < depth) { ep = edge_ptr(gv, (uint32_t)lp.e); cur = *ep; }
+    next();
     if (logits) logits_to_weights(p0, p1, nm);             // (raw logits: weights relative to the largest legal one)
     // prior spreading (select_action_q_and_u, player.py:272-284): float32 accumulation in move order, the terms read
     // straight from the lanes' registers (a loop over an LDS copy paid an LDS round trip per term)
@@ -516,17 +541,14 @@ struct RoundIO {
     bool planes_off;       // cz_search_leaf_planes(0): only the occupancy boards are written
 };
 
-// codes[pos] = plane (0..13) of the piece that plane position pos shows, 0xFF = empty: the first pass of wave_encode_codes
-XQ_D void board_codes(const int8_t* b, uint8_t* codes)
+// occupancy-board word of plane position pos (row i = pos / 9 of the planes shows rank y = 9 - i): bit `shift` + plane of the
+// piece on that square, 0 for an empty square or pos >= 90 (state_to_planes, static_env.py:137-156)
+XQ_D uint32_t mask_word(const int8_t* b, int pos, int shift)
 {
-    const int lane = lane_id();
-    wave_sync();
-    for (int s = lane; s < NSQ; s += 64) {
-        const int p = b[s];
-        const int y = s / 9, x = s - y * 9;
-        codes[(9 - y) * 9 + x] = (uint8_t)(p == 0 ? 0xFF : (p > 0 ? p - 1 : 6 - p));
-    }
-    wave_sync();
+    if (pos >= NSQ) return 0u;
+    const int i = pos / 9, j = pos - i * 9;
+    const int p = b[(9 - i) * 9 + j];
+    return p == 0 ? 0u : 1u << (shift + (p > 0 ? p - 1 : 6 - p));
 }
 
 XQ_D void encode_block(int dtype, const int8_t* b, uint8_t* codes, char* out)
@@ -549,8 +571,17 @@ XQ_D void write_planes(const RoundIO& io, const int8_t* b, uint8_t* codes, size_
     // (round 5) a caller whose network reads the occupancy boards alone (cz_input_resblock_m) switches the planes off
     // (cz_search_leaf_planes): the leaf then costs the code row + two word stores instead of the 1260-element encoder pass
     const bool only_masks = io.masks && io.planes_off;
-    if (only_masks) board_codes(b, codes);
-    else encode_block(io.planes_dtype, b, codes, out);
+    if (only_masks) {
+        // boards only: one LDS read and a shift per word, straight from the position(s) -- no code row, no encoder pass
+        const int lane = lane_id();
+        uint32_t m0 = mask_word(b, lane, 0), m1 = mask_word(b, 64 + lane, 0);
+        if (HIST && prev) { m0 |= mask_word(prev, lane, 14); m1 |= mask_word(prev, 64 + lane, 14); }
+        uint32_t* mo = io.masks + slot * 96;
+        mo[lane] = m0;
+        if (lane < 32) mo[64 + lane] = m1;
+        return;
+    }
+    encode_block(io.planes_dtype, b, codes, out);
     // the same position as an occupancy board (cz_search_leaf_masks): word pos = plane position i * 9 + j, bit c = plane c shows
     // a piece there -- `codes` holds exactly that channel per position after the encoder's pass
     const int lane = lane_id();
@@ -563,14 +594,13 @@ XQ_D void write_planes(const RoundIO& io, const int8_t* b, uint8_t* codes, size_
     if (HIST) {
         char* out2 = out + 1260 * esz;
         if (prev) {
-            if (only_masks) board_codes(prev, codes);
-            else encode_block(io.planes_dtype, prev, codes, out2);
+            encode_block(io.planes_dtype, prev, codes, out2);
             if (io.masks) {
                 const uint32_t c0 = codes[lane], c1 = lane < 26 ? codes[64 + lane] : 0xFFu;
                 m0 |= c0 == 0xFFu ? 0u : 1u << (14 + c0);
                 m1 |= c1 == 0xFFu ? 0u : 1u << (14 + c1);
             }
-        } else if (!only_masks) {
+        } else {
             for (int q = lane_id(); q < 315 * (int)esz; q += 64) reinterpret_cast<uint32_t*>(out2)[q] = 0u;
         }
     }
@@ -1342,20 +1372,47 @@ __global__ __launch_bounds__(64, 4) void k_sim(SearchParams P, SearchBuffers B, 
             my_v = value[my_row];
         }
         PROF_BEGIN();
-        for (int i = 0; i < P.K; ++i) {
-            if (__builtin_amdgcn_readlane(sn_state, i) != SIM_LEAF) continue;
+        // the evaluated leaves of this game, in simulation order, as a bit set; leaf_at(i) = its wave-uniform fields
+        const uint64_t leaves = __ballot(sn_state == SIM_LEAF) & (P.K < 64 ? (1ull << P.K) - 1ull : ~0ull);
+        auto pre_a = [&](LeafPre& lp, int i) {
+            const int depth = __builtin_amdgcn_readlane(sn_depth, i);
+            if (depth <= 64)
+                leaf_pre_a(gv, lp, __builtin_amdgcn_readlane(sn_node, i), (uint32_t)__builtin_amdgcn_readlane((int)my_meta, i),
+                           depth, gv.path_edge + (size_t)i * P.max_depth);
+        };
+        auto pre_b = [&](LeafPre& lp, int i) {
+            if (__builtin_amdgcn_readlane(sn_depth, i) <= 64)
+                leaf_pre_b(lp, (uint32_t)__builtin_amdgcn_readlane((int)my_meta, i),
+                           policy + (size_t)__builtin_amdgcn_readlane(my_row, i) * NLABELS);
+        };
+        LeafPre lp{0, 0, 0, 0.0f, 0.0f};
+        uint64_t rest = leaves;
+        if (rest) {
+            const int i0 = __ffsll((long long)rest) - 1;
+            pre_a(lp, i0);
+            pre_b(lp, i0);
+        }
+        while (rest) {
+            const int i = __ffsll((long long)rest) - 1;
+            rest &= rest - 1;
+            const int i_next = rest ? __ffsll((long long)rest) - 1 : -1;
             const int node = __builtin_amdgcn_readlane(sn_node, i);
             const int depth = __builtin_amdgcn_readlane(sn_depth, i);
             const size_t slot = (size_t)__builtin_amdgcn_readlane(my_row, i);
             const double v = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), i));   // float(v) of a float32
+            LeafPre nx{0, 0, 0, 0.0f, 0.0f};
             if (depth <= 64) {
-                attach_and_backup(P, gv, L, node, (uint32_t)__builtin_amdgcn_readlane((int)my_meta, i), depth,
-                                  policy + slot * NLABELS, v, gv.path_edge + (size_t)i * P.max_depth, P.policy_logits != 0);
+                attach_and_backup(P, gv, L, node, (uint32_t)__builtin_amdgcn_readlane((int)my_meta, i), depth, lp, v,
+                                  P.policy_logits != 0, [&]() {
+                                      if (i_next >= 0) { pre_a(nx, i_next); pre_b(nx, i_next); }
+                                  });
             } else {
                 attach_policy(gv, L, node, policy + slot * NLABELS, P.policy_logits != 0);
                 load_path(P, gv, L, i, depth);
                 backup(P, gv, L, depth, v);
+                if (i_next >= 0) { pre_a(nx, i_next); pre_b(nx, i_next); }
             }
+            lp = nx;
             sim_finish(gv, i, &active);
         }
         PROF(CT_CYC_ATTACH);

@@ -65,11 +65,17 @@ def test_one_small_search_threads_8_search_matches_the_unmodified_reference():
     simulations, the reference's own thread timing, two runs -- under a hard timeout (100 s): the reference's threaded search
     needs 2 s or minutes for the same position (its sender thread holds the queue lock, SURVEY C-12), so a timeout is an
     expected failure, a mismatch is a real one."""
-    try:
-        n = run_check("kgt1", 909, 1, 8, 120, 2, timeout=100)
-    except subprocess.TimeoutExpired:
-        pytest.xfail("the unmodified reference's threaded search did not finish within 100 s (erratic by construction)")
-    assert n == 1
+    # (VERDICT r04: one 100 s attempt ended in the xfail on most boxes.  The slow case is a property of a RUN, not of the
+    #  position -- the same command finishes in 2 s the next time -- so several short attempts find a fast run far more often
+    #  than one long one waits a slow run out.  Any attempt that finishes decides the test.)
+    for attempt_timeout in (20, 20, 25, 30):
+        try:
+            n = run_check("kgt1", 909, 1, 8, 120, 2, timeout=attempt_timeout)
+        except subprocess.TimeoutExpired:
+            continue
+        assert n == 1
+        return
+    pytest.xfail("the unmodified reference's threaded search did not finish in four attempts (20-30 s each; erratic by construction)")
 
 
 @pytest.mark.skipif(os.environ.get("CZ_LIVE_KGT1") != "1",
