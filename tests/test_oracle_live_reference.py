@@ -65,17 +65,21 @@ def test_one_small_search_threads_8_search_matches_the_unmodified_reference():
     simulations, the reference's own thread timing, two runs -- under a hard timeout (100 s): the reference's threaded search
     needs 2 s or minutes for the same position (its sender thread holds the queue lock, SURVEY C-12), so a timeout is an
     expected failure, a mismatch is a real one."""
-    # (VERDICT r04: one 100 s attempt ended in the xfail on most boxes.  The slow case is a property of a RUN, not of the
-    #  position -- the same command finishes in 2 s the next time -- so several short attempts find a fast run far more often
-    #  than one long one waits a slow run out.  Any attempt that finishes decides the test.)
-    for attempt_timeout in (20, 20, 25, 30):
+    # (VERDICT r04: one 100 s attempt ended in the xfail on most boxes.  Measured in round 5: the slow mode is a property of the
+    #  HOST's state, not of the position -- right after a CPU-heavy test (the arena check before this one) the same command
+    #  times out three times in a row, after 25 idle seconds it finishes in 2 s, every time.  So: cool down first, and again
+    #  before each retry (a timed-out attempt is itself 8 busy threads).  Any attempt that finishes decides the test.)
+    import time
+    for attempt_timeout in (25, 25, 30):
+        time.sleep(22)
         try:
             n = run_check("kgt1", 909, 1, 8, 120, 2, timeout=attempt_timeout)
         except subprocess.TimeoutExpired:
             continue
         assert n == 1
         return
-    pytest.xfail("the unmodified reference's threaded search did not finish in four attempts (20-30 s each; erratic by construction)")
+    pytest.xfail("the unmodified reference's threaded search did not finish in three attempts (25-30 s each, 22 s of idle "
+                 "before each; erratic by construction)")
 
 
 @pytest.mark.skipif(os.environ.get("CZ_LIVE_KGT1") != "1",
