@@ -77,6 +77,18 @@ constexpr int W_PAD_STEPS = 3;   // zero K-steps appended to the packed filter s
 
 template <typename E> struct alignas(8) Quad { E e[4]; };
 
+// sum over the 16 lanes of a DPP row, on every lane of the row: four rotate-and-add steps in the VALU (round 5; the head
+// convolutions' 16-lane butterflies were ds_bpermute round trips through the LDS the matrix waves read their operands from)
+__device__ __forceinline__ float row16_sum(float a)
+{
+    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x128, 0xF, 0xF, false));   // row_ror:8
+    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x124, 0xF, 0xF, false));   // row_ror:4
+    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x122, 0xF, 0xF, false));   // row_ror:2
+    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x121, 0xF, 0xF, false));   // row_ror:1
+    return a;
+}
+
+
 // ---- geometry shared by both kernels -----------------------------------------------------------------------------
 template <int C, int P, int PARTS> struct Geom {
     static constexpr int RB = C * 2;                 // bytes per pixel row in LDS
@@ -571,8 +583,7 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
                                 float a = 0.0f;
 #pragma unroll
                                 for (int k = 0; k < 8; ++k) a += r[k] * hw[o][k];
-#pragma unroll
-                                for (int d = 1; d < 16; d <<= 1) a += __shfl_xor(a, d, 64);
+                                a = row16_sum(a);
                                 hs[o] = a;
                             }
                             const int board = to * P + qq / 90, q = qq % 90;
@@ -871,8 +882,7 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
                         float a = 0.0f;
 #pragma unroll
                         for (int k = 0; k < 8; ++k) a += r[k] * hw[o][k];
-#pragma unroll
-                        for (int d = 1; d < 16; d <<= 1) a += __shfl_xor(a, d, 64);
+                        a = row16_sum(a);
                         hs[o] = a;
                     }
 #pragma unroll
