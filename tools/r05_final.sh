@@ -25,6 +25,7 @@ print("other:", d.get("other_configs_exp_per_s")); print("micro:", d.get("micro_
 PY
 ROUND=5 bash tools/collect_profiles.sh > gpurun_out/collect.log 2>&1
 cd $ROOT; grep "^wrote" gpurun_out/collect.log
+if [ "${EXTRAS:-1}" != "1" ]; then exit 0; fi       # EXTRAS=0: regression + bench + profiles only
 bash tools/pmc_valu.sh > gpurun_out/pmc_valu.log 2>&1
 cd $ROOT
 bash tools/profile_search_probe.sh 3000 > gpurun_out/probe_trace.log 2>&1
