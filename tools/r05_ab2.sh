@@ -1,4 +1,7 @@
 #!/bin/bash
+# Variants (git-ignored, built beforehand with `python chinesechess-alphazero_amd/build.py --out variants/libczero_<name>.so [-D...]`;
+# base / r5a from `git archive <commit>` trees): base = f3d8f07, r5a = 620264f, first2 = -DCZ_FIRST_TERMS=2, tpbscat =
+# -DCZ_TPB_SCATTER=1, prof = -DCZ_SIM_PROFILE.
 # GPU (round 5, second A/B call): suite on the new default library; search probe base / r5a / new; section profile;
 # fused input layer with two table rows per round (variants/libczero_first2.so); k_rules_tpb zero-late scatter variant.
 set -u

@@ -1,5 +1,6 @@
 #!/bin/bash
-# GPU (round 5): the balanced 192-filter c8 residual block (k_resblock_ip_c8b, CZ_IP_C8_BALANCED=1) against k_resblock_ip_c8:
+# GPU (round 5): the balanced 192-filter c8 residual block (k_resblock_ip_c8b, CZ_IP_C8_BALANCED=1) against k_resblock_ip_c8.
+# The kernel is NOT in the library (measured 14 % slower): `git apply tools/patches/r05_ip_c8_balanced.patch` and rebuild first.
 # the 192-filter tests on the new kernel (bit-identical to two cz_conv3x3_c8 launches), then the 10 x 192 leg, alternating.
 set -u
 mkdir -p gpurun_out
