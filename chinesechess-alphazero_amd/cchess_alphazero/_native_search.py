@@ -66,6 +66,28 @@ def declare(L):
         getattr(L, n).restype = i32
 
 
+def masks_to_planes(masks, in_planes, dtype=None):
+    """Occupancy boards (int32 [n, 96]: word = plane position i * 9 + j, bit c = plane c shows a piece there; what
+    cz_search_leaf_masks makes the search kernel write) -> the planes tensor [n, in_planes, 10, 9] they stand for
+    (state_to_planes / state_history_to_planes, environment/static_env.py:137-194).  Pure torch: runs on any device."""
+    import torch
+    n = masks.shape[0]
+    c = torch.arange(in_planes, device=masks.device, dtype=torch.int32)
+    bits = (masks[:, None, :90].to(torch.int32) >> c[None, :, None]) & 1
+    return bits.to(dtype or torch.uint8).view(n, in_planes, 10, 9)
+
+
+def planes_to_masks(planes):
+    """The inverse: planes [n, in_planes, 10, 9] (0 / non-zero) -> occupancy boards int32 [n, 96] (words 90 .. 95 zero)."""
+    import torch
+    n, c = planes.shape[0], planes.shape[1]
+    bits = (planes.reshape(n, c, 90) != 0).to(torch.int64)
+    w = (1 << torch.arange(c, device=planes.device, dtype=torch.int64)).view(1, c, 1)
+    out = torch.zeros((n, 96), dtype=torch.int64, device=planes.device)
+    out[:, :90] = (bits * w).sum(1)
+    return out.to(torch.int32)
+
+
 class Search:
     """Owns one cz_search (device memory for G game trees) plus the evaluation-queue tensors.
 
@@ -214,13 +236,10 @@ class Search:
         """The first n rows of the evaluation queue as a planes tensor (a copy), whatever the kernel writes: with the planes
         switched off they are rebuilt from the occupancy boards (plane c at position pos = bit c of word pos;
         state_to_planes, environment/static_env.py:137-156)."""
-        import torch
         n = self.slots if n is None else min(int(n), self.slots)
         if not self.planes_off:
             return self.planes[:n].clone()
-        c = torch.arange(self.in_planes, device=self.device, dtype=torch.int32)
-        bits = (self.masks[:n, None, :90] >> c[None, :, None]) & 1
-        return bits.to(self.planes.dtype).view(n, self.in_planes, 10, 9)
+        return masks_to_planes(self.masks[:n], self.in_planes, self.planes.dtype)
 
     def reset_trees(self):
         _native.check(self.L.cz_search_reset_trees(self.h, self._stream()), "cz_search_reset_trees")

@@ -515,3 +515,43 @@ def test_activation_shift_is_an_exact_reparametrisation():
         a0 = torch.relu(InferenceNet(net, torch.float32, trunk="library").input_conv(x))
         a1 = torch.relu(inf.input_conv(x))
         assert torch.allclose(a1, a0 * 2.0 ** shift[0], rtol=1e-6, atol=1e-9)
+
+
+def test_occupancy_boards_stand_for_the_planes():
+    """cz_search_leaf_masks' convention, pinned on the CPU against the oracle's state_to_planes (static_env.py:137-156): word
+    pos = plane position i * 9 + j, bit c = plane c shows a piece there; words 90 .. 95 zero; masks_to_planes (what
+    Search.queue_planes rebuilds the audit positions with when the kernel writes boards only) is the exact inverse."""
+    import random
+    import torch
+    from cchess_alphazero._native_search import masks_to_planes, planes_to_masks
+    rng = random.Random(7)
+    states = [xo.INIT_STATE, '3s5/4m4/9/9/4p4/2R6/9/4C4/4M4/3MS4', '3s5/9/9/9/9/9/9/9/9/3S5']
+    s = xo.INIT_STATE
+    for _ in range(60):                                  # a random playout: positions with captures and flipped sides
+        mv = xo.get_legal_moves(s)
+        if not mv:
+            break
+        s = xo.step(s, rng.choice(mv))
+        states.append(s)
+    boards = np.stack([xo.state_to_board(x) for x in states])
+    planes = torch.from_numpy(xo.batch_rules(boards)["planes"])              # [n, 14, 10, 9] float32, 0 / 1
+    masks = planes_to_masks(planes)
+    assert masks.dtype == torch.int32 and masks.shape == (len(states), 96) and int(masks[:, 90:].abs().sum()) == 0
+    # every square shows at most one piece: a word has at most one bit; the bits of a board = its pieces
+    pop = torch.tensor([[bin(int(w)).count("1") for w in row] for row in masks.tolist()])
+    assert int(pop.max()) == 1 and (pop.sum(1) == torch.from_numpy((boards != 0).sum(1))).all()
+    # the convention itself, from the board: piece p (> 0 mover, < 0 opponent) on square y * 9 + x -> plane (p > 0 ? p - 1 : 6 - p),
+    # plane position (9 - y) * 9 + x
+    for b, row in zip(boards, masks.tolist()):
+        for sq in range(90):
+            p = int(b[sq])
+            y, x = divmod(sq, 9)
+            want = 0 if p == 0 else 1 << (p - 1 if p > 0 else 6 - p)
+            assert row[(9 - y) * 9 + x] == want
+    back = masks_to_planes(masks, 14, torch.float32)
+    assert torch.equal(back, planes)
+    # 28 planes: the history block in bits 14 .. 27
+    both = torch.cat([planes, planes.flip(0)], 1)
+    m28 = planes_to_masks(both)
+    assert torch.equal(masks_to_planes(m28, 28, torch.uint8), both.to(torch.uint8))
+    assert torch.equal(m28 & 0x3FFF, masks) and torch.equal(m28 >> 14, masks.flip(0))
