@@ -61,7 +61,8 @@ XQ_D int wave_incl_scan(int v)
 
 // Wave-wide reductions on the same DPP ladder (round 5): the running value of lane 63 after the six steps is the
 // reduction over all 64 lanes; one v_readlane hands it to everybody as a scalar.  A lane without a source keeps its own
-// value (old = the value itself, bound_ctrl off), which is neutral for max / min.  These replace the six-stage
+// value (old = the value itself, bound_ctrl off), which is neutral for max / min.  Call them in wave-uniform control flow (all
+// 64 lanes active: the result is read from lane 63 / lane 15).  These replace the six-stage
 // __shfl_xor butterflies (two ds_bpermute round trips per stage for a double) on the PUCT arg-max of every tree level.
 #define XQ_DPP_STEP_MAX_F64(v, ctrl, rmask)                                                                          \
     do {                                                                                                             \
