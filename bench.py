@@ -684,7 +684,7 @@ def short_selfplay_leg(label, config, seconds, log, games=None, K=None, dtype=No
     peaked-policy copy of the weights (sharpened_copy) -- the engine's load-time guard then selects the arithmetic such a
     network is allowed, and the leg times THAT."""
     import gc
-    from cchess_alphazero.agent.model import CChessNet, flops_per_position
+    from cchess_alphazero.agent.model import CChessNet, events_ms, flops_per_position
     from cchess_alphazero.engine import SelfPlayEngine
     ns = argparse.Namespace(config=config, games=games, sims_per_round=K, dtype=dtype, trunk=trunk)
     cfg = build_config(ns)
@@ -734,7 +734,7 @@ def short_selfplay_leg(label, config, seconds, log, games=None, K=None, dtype=No
         dt = time.perf_counter() - t0
         c1 = eng.counters()
         d = {k: c1[k] - c0[k] for k in keys}
-        blk = [x.elapsed_time(y) for x, y in eng.net.block_events]
+        blk = events_ms(eng.net.block_events)
         eng.net.block_events = None
         Kq = eng.search.K
         slots = G * Kq
@@ -872,7 +872,7 @@ def main():
     torch.cuda.set_device(local_rank)
     collective = init_collective(world, rank, args)
     dist_on = dist.is_initialized()
-    from cchess_alphazero.agent.model import flops_per_position
+    from cchess_alphazero.agent.model import events_ms, flops_per_position
     from cchess_alphazero.engine import SelfPlayEngine, bytes_per_expansion
 
     t_start = time.perf_counter()
@@ -973,7 +973,7 @@ def main():
         k_ms_ = sum(k_all) / len(k_all) if ev else None
         dd["search_round_ms_median"] = k_all[len(k_all) // 2] if ev else None
         dd["search_round_ms_max"] = k_all[-1] if ev else None
-        b_ms_ = [x.elapsed_time(y) for x, y in blk_all]
+        b_ms_ = events_ms(blk_all)
         return float(tmax.item()), dd, k_ms_, b_ms_
 
     dt, d, k_ms, blk_ms = run_leg(args.steps, 1)

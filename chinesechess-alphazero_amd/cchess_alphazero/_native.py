@@ -479,6 +479,22 @@ def resblock(x, w1_packed, bias1, w2_packed, bias2, out=None, out_f32=None, coun
     return out_f32 if out_f32 is not None else out
 
 
+def tower_c6(x, blocks, out, count=None):
+    """cz_tower_c6: the consecutive c6 residual blocks `blocks` = [(w1_packed, bias1, w2_packed, bias2), ...] (2 .. 8) in ONE
+    launch, activations in LDS between them; x / out: c6 operand pairs (f16 [N, 90, 128], int8 [N, 90, 256]).  Bit-identical to
+    len(blocks) resblock() calls."""
+    require_gpu()
+    L = lib()
+    nb = len(blocks)
+    arr = lambda k: (C.c_void_p * nb)(*[_ptr(b[k]) for b in blocks])
+    L.cz_tower_c6.restype = C.c_int
+    L.cz_tower_c6.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    check(L.cz_tower_c6(_ptr(x[0]), _ptr(x[1]), nb, arr(0), arr(1), arr(2), arr(3), _ptr(out[0]), _ptr(out[1]), x[0].shape[0],
+                        _ptr(count), _stream()), "cz_tower_c6")
+    return out
+
+
 def resblock_pipelined(enable=None):
     """Which schedule the 128-filter split residual block runs on (both bit-identical): True = k_resblock_pipe (default),
     False = k_resblock.  None only queries.  Returns the previous setting."""

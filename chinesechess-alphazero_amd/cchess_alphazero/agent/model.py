@@ -97,6 +97,18 @@ def _fold(conv, bn):
     return out
 
 
+def events_ms(events):
+    """Per-BLOCK times (ms) of the tower launches recorded in InferenceNet.block_events: a (start, end) pair is one residual
+    block; (start, end, m) is a launch of m chained blocks (cz_tower_c6), counted as m blocks of elapsed / m each, so that the
+    list keeps one entry per block of the tower in tower order."""
+    out = []
+    for e in events:
+        ms = e[0].elapsed_time(e[1])
+        m = e[2] if len(e) > 2 else 1
+        out += [ms / m] * m
+    return out
+
+
 class InferenceNet(nn.Module):
     """Eval-mode network for self-play: BN folded, channels_last, optional reduced precision.
     Outputs are always fp32: softmax policy [B, 2086] and value [B].
@@ -178,7 +190,9 @@ class InferenceNet(nn.Module):
         # dense layers + softmax / tanh on the hand-written kernels (csrc/xq_heads.hip); CZ_FUSED_TAIL=0: the hipBLASLt /
         # PyTorch tail they replace (A/B runs)
         self.fused_tail = os.environ.get("CZ_FUSED_TAIL", "1") != "0"
-        self.block_events = None            # bench.py: list collecting (start, end) HIP events around tower launches
+        self.block_events = None            # bench.py: list collecting (start, end[, blocks]) HIP events around tower launches
+        # consecutive c6 inner blocks as one launch (cz_tower_c6; CZ_TOWER_CHAIN=0 / 1 overrides the default)
+        self.chain_blocks = os.environ.get("CZ_TOWER_CHAIN", "0") != "0"
         self.input_depth = net.cfg["input_depth"]
         self.filters = net.cfg["cnn_filter_num"]
         with torch.no_grad():
@@ -348,7 +362,17 @@ class InferenceNet(nn.Module):
                 cur, tmp, nxt = (self._as_f16_pair(t) for t in (cur, tmp, nxt))
             _native.input_conv(planes.contiguous(), self.in_w.view(self.operand_dtype), self.in_bias32, cur,
                                rows=rows, count=count)
+        # (round 5) consecutive c6 -> c6 inner blocks run as ONE launch with the activations staying in LDS (cz_tower_c6): the
+        # blocks behind the fused input layer up to, not including, the last c6 block of the tower (fused heads, or the
+        # hand-over to c8 in a hybrid) -- blocks 1 .. 5 of the 7 x 128 benchmark tower
+        chain = range(0)
+        if self.c6 and fused and first_fused and self.chain_blocks:
+            end = min(self.c6_blocks - 1, nblk - 1)
+            if end - 1 >= 2:
+                chain = range(1, min(end, 1 + 8))
         for i in range(nblk):
+            if i in chain and i != chain.start:
+                continue                                        # (part of the chain launched at chain.start)
             w1 = getattr(self, f"tw{i}a").view(self.operand_dtype)
             w2 = getattr(self, f"tw{i}b").view(self.operand_dtype)
             if self.c6:
@@ -366,6 +390,13 @@ class InferenceNet(nn.Module):
                     _native.input_resblock(planes.contiguous(), self.in_table32, self.in_bias32, w1, b1, w2, b2, out=nxt,
                                            rows=rows, count=count, masks=masks)
                     cur, nxt = nxt, cur
+                elif i in chain:
+                    blocks = [(getattr(self, f"tw{k}a").view(self.operand_dtype), getattr(self, f"tb{k}a"),
+                               getattr(self, f"tw{k}b").view(self.operand_dtype), getattr(self, f"tb{k}b")) for k in chain]
+                    _native.tower_c6(cur, blocks, out=nxt, count=count)
+                    cur, nxt = nxt, cur
+                    if ev is not None:
+                        ev = ev + (len(chain),)                  # (events_ms spreads the launch over its blocks)
                 elif i + 1 == n8 and n8 < nblk:
                     # the last c8 block of a hybrid tower: fp32 out, re-split into (hi, lo) fp16 pairs for the f16x3 blocks
                     _native.resblock(cur, w1, b1, w2, b2, out_f32=last, count=count)

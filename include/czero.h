@@ -354,6 +354,17 @@ int cz_input_conv_q(const void* planes, int planes_dtype, int in_planes, const v
 int cz_resblock_q(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1, const void* w2_packed,
                   const float* bias2, void* y_hi, void* y_lo, float* y_f32, int n_boards, int channels, int dtype,
                   int parts, const int32_t* n_dev, void* stream);
+/* (round 5) n_blocks (2 .. 8) CONSECUTIVE c6 residual blocks of a 128-filter tower in ONE launch (k_tower_c6): the same
+ * arithmetic as n_blocks calls of cz_resblock(dtype CZ_F16C6) -- bit-identical results -- with the activations staying in the
+ * CU's LDS between the blocks (a workgroup takes a pair of boards through the whole chain; HBM sees a board at the chain's
+ * entry and exit only).  Replaces the inner part of the residual tower, agent/model.py:41-43 (`for _ in range(res_layer_num):
+ * x = self._build_residual_block(x)`).  w1_packed / bias1 / w2_packed / bias2: HOST arrays of n_blocks DEVICE pointers
+ * (cz_conv3x3_c6_pack_weights filters; every block's second filter carries a c6 output exponent, block b + 1 reads the image
+ * block b writes).  x / y: c6 operand pairs [n_boards][90][128] f16 + [n_boards][90][256] bytes.  n_dev: compact queue (DEVICE
+ * int32, may be NULL): min(n_boards, *n_dev) boards. */
+int cz_tower_c6(const void* x_hi, const void* x_c6, int n_blocks, const void* const* w1_packed, const float* const* bias1,
+                const void* const* w2_packed, const float* const* bias2, void* y_hi, void* y_c6, int n_boards,
+                const int32_t* n_dev, void* stream);
 int cz_resblock_heads_q(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1,
                         const void* w2_packed, const float* bias2, const float* head_w, const float* head_b,
                         float* policy_feat, float* value_feat, int n_boards, int channels, int dtype, int n_policy,

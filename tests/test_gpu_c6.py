@@ -127,3 +127,38 @@ def test_c6_saturation_is_graceful():
     print("exponents", kmid, kout, "fitted:", m_t, " 3 too small:", m_l)
     assert m_t["finite"] and m_l["finite"]
     assert m_t["logit_max_abs"] < 1e-4 and m_l["logit_max_abs"] < 5e-3
+
+
+@pytest.mark.parametrize("blocks", [4, 7])
+def test_chained_c6_tower_is_bit_identical_to_block_by_block(blocks):
+    """cz_tower_c6 (k_tower_c6, round 5): the consecutive c6 inner blocks in ONE launch, activations staying in LDS (a workgroup
+    takes a pair of boards through the chain; results staged inside the dead image of the other slot and converted in place).
+    Same arithmetic, accumulation order and conversions as one k_resblock_c8<.., C6> launch per block: the network's outputs are
+    IDENTICAL -- for batch sizes that give the workgroups one board (the odd-count path: the board runs in both slots), two,
+    three, and many; through the compact queue as well."""
+    import torch
+    from cchess_alphazero.agent.model import calibration_planes, guarded_inference_net
+    net = peaked_net(20.0, blocks=blocks)
+    planes_all = calibration_planes(1100, 14, seed=23)
+    g = guarded_inference_net(net, torch.float32, trunk="mfma", arith="c6", guard=False, planes=planes_all[:256])
+    assert g.c6 and g.c6_blocks == blocks
+    for n in (1, 37, 256, 300, 700, 1100):
+        planes = planes_all[:n].contiguous()
+        g.chain_blocks = False
+        p0, v0 = (t.clone() for t in g(planes))
+        g.chain_blocks = True
+        g.block_events = []
+        p1, v1 = g(planes)
+        launches = [len(e) > 2 and e[2] or 1 for e in g.block_events]
+        g.block_events = None
+        assert launches == [1, blocks - 2, 1], launches               # FIRST | the chain | HEADS
+        assert torch.equal(p0, p1) and torch.equal(v0, v1), (blocks, n, (p0 - p1).abs().max().item())
+    # compact queue: rows / count on the device
+    planes = planes_all[:900].contiguous()
+    rows = torch.randperm(900, device="cuda")[:640].int()
+    count = torch.tensor([517], dtype=torch.int32, device="cuda")
+    g.chain_blocks = False
+    p0, v0 = (t.clone() for t in g(planes, rows=rows, count=count))
+    g.chain_blocks = True
+    p1, v1 = g(planes, rows=rows, count=count)
+    assert torch.equal(p0[:517], p1[:517]) and torch.equal(v0[:517], v1[:517])

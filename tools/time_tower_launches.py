@@ -39,7 +39,8 @@ def main():
         for _ in range(reps):
             g(planes, masks=masks)
         torch.cuda.synchronize()
-        ms = [a.elapsed_time(b) for a, b in g.block_events]
+        from cchess_alphazero.agent.model import events_ms
+        ms = events_ms(g.block_events)
         g.block_events = None
         per = [sum(ms[i::7]) / reps for i in range(7)]
         out[arith] = {"per_launch_ms": per, "tower_ms": sum(per)}
