@@ -192,7 +192,7 @@ class InferenceNet(nn.Module):
         self.fused_tail = os.environ.get("CZ_FUSED_TAIL", "1") != "0"
         self.block_events = None            # bench.py: list collecting (start, end[, blocks]) HIP events around tower launches
         # consecutive c6 inner blocks as one launch (cz_tower_c6; CZ_TOWER_CHAIN=0 / 1 overrides the default)
-        self.chain_blocks = os.environ.get("CZ_TOWER_CHAIN", "0") != "0"
+        self.chain_blocks = os.environ.get("CZ_TOWER_CHAIN", "1") != "0"
         self.input_depth = net.cfg["input_depth"]
         self.filters = net.cfg["cnn_filter_num"]
         with torch.no_grad():

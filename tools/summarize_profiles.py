@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEARCH = ("k_noise", "k_sim", "k_advance")
 ROUND_LAUNCHES = 4            # k_sim(BACKUP), k_advance, k_noise, k_sim(SELECT)   (round 2: five, k_noise twice)
 ROUND_NAMES = ["k_sim", "k_advance", "k_noise", "k_sim"]
-NN = ("k_resblock_ip", "k_resblock", "k_input_conv", "k_conv3x3", "k_split_bias_act", "k_bias_act", "k_fc_tile<0", "k_fc_tile<1",
+NN = ("k_tower_c6", "k_resblock_ip", "k_resblock", "k_input_conv", "k_conv3x3", "k_split_bias_act", "k_bias_act", "k_fc_tile<0", "k_fc_tile<1",
       "k_policy_normalize", "k_head_convs")
 
 
