@@ -1092,13 +1092,15 @@ def main():
             tfl = flops_launch / (b_ms * 1e-3) / 1e12
             pmc = pmc_nn("k_resblock")
             chained = bool(arith == "c6" and getattr(eng.net, "chain_blocks", False) and cfg.model.res_layer_num >= 4)
+            n_chain = 0
             if chained:
                 # the inner blocks run as ONE k_tower_c6 launch (activations in LDS): its counters, per block of the tower
-                # (the committed PMC pass has one entry per kernel: the tower launch covers res_layer_num - 2 blocks)
+                # (the committed PMC pass has one entry per kernel: the tower launch covers n_chain blocks)
                 pt = pmc_nn("k_tower_c6")
                 nb_ = cfg.model.res_layer_num
+                n_chain = nb_ - 1 if getattr(eng.net, "chain_heads", False) else nb_ - 2
                 if pt.get("hbm_bytes_per_launch") and pmc.get("hbm_bytes_per_launch"):
-                    pmc = {"hbm_bytes_per_launch": (pt["hbm_bytes_per_launch"] + 2 * pmc["hbm_bytes_per_launch"]) / nb_,
+                    pmc = {"hbm_bytes_per_launch": (pt["hbm_bytes_per_launch"] + (nb_ - n_chain) * pmc["hbm_bytes_per_launch"]) / nb_,
                            "mfma_util": pt.get("mfma_util"), "source": pt.get("source")}
             kdesc = ("k_resblock_c8 (csrc/xq_conv.hip, K loop csrc/xq_c8_kloop.h): one residual block (2 x conv3x3 + bias + skip + "
                      "ReLU) of the tower per launch; every product = one fp16 MFMA term + two block-scaled fp8 (e4m3, K = 64) "
@@ -1121,13 +1123,15 @@ def main():
             if arith and (arith.startswith("c8>") or arith.startswith("c6>")):
                 kshort = f"k_resblock_c8 / k_resblock_pipe ({arith}, one residual block per launch)"
             if chained:
-                kshort = f"k_tower_c6 ({cfg.model.res_layer_num - 2} chained blocks) + k_resblock_c8<C6> x2; per block"
+                kshort = (f"k_tower_c6 ({n_chain} chained blocks) + k_resblock_c8<C6> x{cfg.model.res_layer_num - n_chain}; "
+                          "per block")
                 kdesc = ("k_tower_c6 (csrc/xq_conv.hip, K loop csrc/xq_c8_kloop.h FMT = 1): the tower's inner residual blocks (2 x conv3x3 "
                          "+ bias + skip + ReLU each) in ONE launch, activations staying in LDS between them (a workgroup takes a pair "
                          "of boards through the chain); every product = one fp16 MFMA term + two block-scaled bf6 correction terms, "
-                         "fp32 accumulate; the first block (fused 5x5 input layer) and the last (fused head convolutions) are "
-                         "k_resblock_c8<.., C6> launches; all times per BLOCK of the tower (the chained launch spread over its "
-                         "blocks), mean over the tower")
+                         "fp32 accumulate; the first block (fused 5x5 input layer) is a k_resblock_c8<FIRST, C6> launch, the last "
+                         "block is the chain's last with the head convolutions as its exit pass (CZ_TOWER_HEADS=0: a "
+                         "k_resblock_c8<HEADS, C6> launch); all times per BLOCK of the tower (the chained launch spread over "
+                         "its blocks), mean over the tower")
             out["roofline"] = {"kernel": kdesc, "kernel_short": kshort,
                                "bound": "mfma", "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s", "frac": tfl / 2500.0,
                                "traffic": pmc.get("hbm_bytes_per_launch"), "traffic_source": pmc.get("source"),

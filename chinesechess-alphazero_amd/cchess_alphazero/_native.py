@@ -495,6 +495,21 @@ def tower_c6(x, blocks, out, count=None):
     return out
 
 
+def tower_c6_heads(x, blocks, head_w, head_b, n_policy, policy_feat, value_feat, count=None):
+    """cz_tower_c6_heads: tower_c6 ending on the tower's last block, the 1x1 head convolutions as the chain's exit."""
+    require_gpu()
+    L = lib()
+    nb = len(blocks)
+    arr = lambda k: (C.c_void_p * nb)(*[_ptr(b[k]) for b in blocks])
+    L.cz_tower_c6_heads.restype = C.c_int
+    L.cz_tower_c6_heads.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    check(L.cz_tower_c6_heads(_ptr(x[0]), _ptr(x[1]), nb, arr(0), arr(1), arr(2), arr(3), _ptr(head_w), _ptr(head_b),
+                              _ptr(policy_feat), _ptr(value_feat), x[0].shape[0], n_policy, head_w.shape[0] - n_policy,
+                              _ptr(count), _stream()), "cz_tower_c6_heads")
+    return policy_feat, value_feat
+
+
 def resblock_pipelined(enable=None):
     """Which schedule the 128-filter split residual block runs on (both bit-identical): True = k_resblock_pipe (default),
     False = k_resblock.  None only queries.  Returns the previous setting."""

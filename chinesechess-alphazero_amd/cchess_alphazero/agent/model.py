@@ -193,6 +193,7 @@ class InferenceNet(nn.Module):
         self.block_events = None            # bench.py: list collecting (start, end[, blocks]) HIP events around tower launches
         # consecutive c6 inner blocks as one launch (cz_tower_c6; CZ_TOWER_CHAIN=0 / 1 overrides the default)
         self.chain_blocks = os.environ.get("CZ_TOWER_CHAIN", "1") != "0"
+        self.chain_heads = os.environ.get("CZ_TOWER_HEADS", "1") != "0"
         self.input_depth = net.cfg["input_depth"]
         self.filters = net.cfg["cnn_filter_num"]
         with torch.no_grad():
@@ -365,11 +366,15 @@ class InferenceNet(nn.Module):
         # (round 5) consecutive c6 -> c6 inner blocks run as ONE launch with the activations staying in LDS (cz_tower_c6): the
         # blocks behind the fused input layer up to, not including, the last c6 block of the tower (fused heads, or the
         # hand-over to c8 in a hybrid) -- blocks 1 .. 5 of the 7 x 128 benchmark tower
-        chain = range(0)
+        chain, chain_heads = range(0), False
         if self.c6 and fused and first_fused and self.chain_blocks:
             end = min(self.c6_blocks - 1, nblk - 1)
             if end - 1 >= 2:
                 chain = range(1, min(end, 1 + 8))
+            # ... and through the tower's last block with the head convolutions as the chain's exit (CZ_TOWER_HEADS=0: off)
+            if (self.chain_heads and self.c6_blocks == nblk and heads is not None and self.parts == 2 and c == 128 and
+                    3 <= nblk <= 9):
+                chain, chain_heads = range(1, nblk), True
         for i in range(nblk):
             if i in chain and i != chain.start:
                 continue                                        # (part of the chain launched at chain.start)
@@ -393,8 +398,11 @@ class InferenceNet(nn.Module):
                 elif i in chain:
                     blocks = [(getattr(self, f"tw{k}a").view(self.operand_dtype), getattr(self, f"tb{k}a"),
                                getattr(self, f"tw{k}b").view(self.operand_dtype), getattr(self, f"tb{k}b")) for k in chain]
-                    _native.tower_c6(cur, blocks, out=nxt, count=count)
-                    cur, nxt = nxt, cur
+                    if chain_heads:
+                        _native.tower_c6_heads(cur, blocks, self.head_w32, self.head_b32, heads[0], heads[1], heads[2], count=count)
+                    else:
+                        _native.tower_c6(cur, blocks, out=nxt, count=count)
+                        cur, nxt = nxt, cur
                     if ev is not None:
                         ev = ev + (len(chain),)                  # (events_ms spreads the launch over its blocks)
                 elif i + 1 == n8 and n8 < nblk:

@@ -1439,9 +1439,10 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
 namespace tw {
 constexpr int C = 128, RB = 256, ROW_XA = 0, ROW_XB = 90, ROW_Y = 180, ROW_DUMP = 270, ROW_Z = 272, PSTR = (ROW_Z + 16) * RB;
 constexpr int BIAS_OFF = 2 * PSTR;                 // float bias[2 buffers][2 convolutions][128]
-constexpr int LDS_BYTES = BIAS_OFF + 2 * 2 * C * 4;
+constexpr int HW_OFF = BIAS_OFF + 2 * 2 * C * 4;   // HEADS: float head_w[6][128]
+constexpr int LDS_BYTES = HW_OFF, LDS_BYTES_HEADS = HW_OFF + 6 * C * 4;
 constexpr int MAX_BLOCKS = 8;
-static_assert(LDS_BYTES <= 160 * 1024, "XA + XB + Y + zero rows + bias buffers must fit the CU's LDS");
+static_assert(LDS_BYTES_HEADS <= 160 * 1024, "XA + XB + Y + zero rows + bias buffers (+ head filters) must fit the CU's LDS");
 struct Chain {
     const void* w1[MAX_BLOCKS];
     const void* w2[MAX_BLOCKS];
@@ -1478,9 +1479,13 @@ struct Shadow {                         // relu(acc2 of the previous step) -> st
 };
 }  // namespace tw
 
+// HEADS: the chain's last block is the tower's last block -- at the exit the copy waves apply the two 1 x 1 head convolutions to
+// the staged fp32 activation (the thread of a (pixel, 32-channel block) item forms six partial dot products, the four lanes of
+// the pixel add them with two DPP quad permutes) instead of converting and storing the operand triple.
+template <bool HEADS>
 __global__ __launch_bounds__(512, 2) void k_tower_c6(
     const _Float16* __restrict__ xh, const unsigned char* __restrict__ xc, tw::Chain ch, _Float16* __restrict__ yh,
-    unsigned char* __restrict__ yc, int n_boards, const int32_t* __restrict__ n_dev)
+    unsigned char* __restrict__ yc, int n_boards, const int32_t* __restrict__ n_dev, HeadArgs hd)
 {
     using namespace tw;
     using rb8::c6_chunk;
@@ -1490,7 +1495,7 @@ __global__ __launch_bounds__(512, 2) void k_tower_c6(
     using rb8::f32x32;
     static_assert(CZ_C6_TAIL_SWZ == 0, "the chained tower keeps one tail convention");
     constexpr int NT = 3, CTHR = 256;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[HEADS ? LDS_BYTES_HEADS : LDS_BYTES];
     if (n_dev) {
         const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
         n_boards = nd < n_boards ? nd : n_boards;
@@ -1605,6 +1610,41 @@ __global__ __launch_bounds__(512, 2) void k_tower_c6(
                 __builtin_amdgcn_wave_barrier();
             }
         };
+        // HEADS exit: staging of slot s -> the six head features of every pixel of `board` (nothing is written to LDS)
+        auto heads_exit = [&](int s, int board) {
+            const unsigned char* X = lds + row_of(s) * RB;
+            const float* hwl = reinterpret_cast<const float*>(lds + HW_OFF);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int i = it * CTHR + ctid;
+                if (i >= 90 * 4) continue;
+                const int qq = i >> 2, blk = i & 3;
+                float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float4 f = *reinterpret_cast<const float4*>(X + stage_off(qq, blk * 32 + 4 * k));
+#pragma unroll
+                    for (int o = 0; o < 6; ++o) {
+                        const float4 w = *reinterpret_cast<const float4*>(hwl + o * C + blk * 32 + 4 * k);
+                        a[o] += f.x * w.x; a[o] += f.y * w.y; a[o] += f.z * w.z; a[o] += f.w * w.w;
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < 6; ++o) {                  // the four lanes of the pixel: (a0 + a1) + (a2 + a3) on every lane
+                    a[o] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a[o]), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+                    a[o] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a[o]), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+                }
+                if (board < 0) continue;
+#pragma unroll
+                for (int o = 0; o < 6; ++o)
+                    if ((o & 3) == blk) {                       // lane blk writes outputs blk and blk + 4
+                        float hv = a[o] + hd.b[o];
+                        hv = hv > 0.0f ? hv : 0.0f;
+                        if (o < hd.n_pol) hd.pol[(size_t)board * (hd.n_pol * 90) + o * 90 + qq] = hv;
+                        else hd.val[(size_t)board * ((6 - hd.n_pol) * 90) + (o - hd.n_pol) * 90 + qq] = hv;
+                    }
+            }
+        };
         auto write_bias = [&](int b) {
             if (ctid < C) {
                 float* dst = reinterpret_cast<float*>(lds + BIAS_OFF) + (b & 1) * 2 * C;
@@ -1621,6 +1661,8 @@ __global__ __launch_bounds__(512, 2) void k_tower_c6(
             *reinterpret_cast<uint4*>(lds + PSTR + ROW_Z * RB + i * 16) = make_uint4(0, 0, 0, 0);
         }
         write_bias(0);
+        if (HEADS)
+            for (int i = ctid; i < 6 * C; i += CTHR) reinterpret_cast<float*>(lds + HW_OFF)[i] = hd.w[i];
         int pp = -1, pb = 0, ps = 0;                    // the previous step (pair, block, slot); pp < 0: none
         for (int p = 0; p < pairs; ++p)
             for (int b = 0; b < NB; ++b)
@@ -1644,7 +1686,8 @@ __global__ __launch_bounds__(512, 2) void k_tower_c6(
                             board = board_of(pp, so, was_real);
                             if (!was_real) board = -1;
                         }
-                        convert(so, k_out, board);
+                        if (HEADS && pb == NB - 1) heads_exit(so, board);
+                        else convert(so, k_out, board);
                     }
                     if (fill) write_x(so);
                     if (s == 1) write_bias(b + 1 < NB ? b + 1 : 0);     // the next block's bias (its buffer is read no more)
@@ -1656,7 +1699,8 @@ __global__ __launch_bounds__(512, 2) void k_tower_c6(
             const int k_out = __builtin_amdgcn_readfirstlane(pack_ints(ch.w2[NB - 1])[3]);
             bool was_real;
             const int board = board_of(pairs - 1, 1, was_real);
-            convert(1, k_out, was_real ? board : -1);
+            if (HEADS) heads_exit(1, was_real ? board : -1);
+            else convert(1, k_out, was_real ? board : -1);
         }
         return;
     }
@@ -3610,10 +3654,48 @@ extern "C" int cz_tower_c6(const void* x_hi, const void* x_c6, int n_blocks, con
         return CZ_ERR_HIP;
     }
     const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
-    hipLaunchKernelGGL(k_tower_c6, dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const _Float16*)x_hi,
-                       (const unsigned char*)x_c6, ch, (_Float16*)y_hi, (unsigned char*)y_c6, n_boards, n_dev);
+    hipLaunchKernelGGL(k_tower_c6<false>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const _Float16*)x_hi,
+                       (const unsigned char*)x_c6, ch, (_Float16*)y_hi, (unsigned char*)y_c6, n_boards, n_dev, HeadArgs{});
     if (hipGetLastError() != hipSuccess) {
         czi_set_error("cz_tower_c6: launch failed");
+        return CZ_ERR_HIP;
+    }
+    return CZ_OK;
+}
+
+// ... with the tower's LAST block as the chain's last block: the fused head convolutions as the exit (cz_resblock_heads' outputs)
+extern "C" int cz_tower_c6_heads(const void* x_hi, const void* x_c6, int n_blocks, const void* const* w1_packed,
+                                 const float* const* bias1, const void* const* w2_packed, const float* const* bias2,
+                                 const float* head_w, const float* head_b, float* policy_feat, float* value_feat, int n_boards,
+                                 int n_policy, int n_value, const int32_t* n_dev, void* stream)
+{
+    if (n_boards < 0 || !x_hi || !x_c6 || !w1_packed || !w2_packed || !bias1 || !bias2 || n_blocks < 2 ||
+        n_blocks > tw::MAX_BLOCKS || !head_w || !head_b || !policy_feat || !value_feat || n_policy < 1 || n_value < 1 ||
+        n_policy + n_value != 6) {
+        czi_set_error("cz_tower_c6_heads: bad argument (2 .. 8 blocks, c6 operand pair in, n_policy + n_value == 6)");
+        return CZ_ERR_ARG;
+    }
+    tw::Chain ch{};
+    ch.n = n_blocks;
+    for (int b = 0; b < n_blocks; ++b) {
+        if (!w1_packed[b] || !w2_packed[b] || !bias1[b] || !bias2[b]) {
+            czi_set_error("cz_tower_c6_heads: null block parameter");
+            return CZ_ERR_ARG;
+        }
+        ch.w1[b] = w1_packed[b]; ch.w2[b] = w2_packed[b]; ch.b1[b] = bias1[b]; ch.b2[b] = bias2[b];
+    }
+    if (n_boards == 0) return CZ_OK;
+    const int n_cu = device_cu_count();
+    if (n_cu < 0) {
+        czi_set_error("cz_tower_c6_heads: cannot query the device");
+        return CZ_ERR_HIP;
+    }
+    const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
+    hipLaunchKernelGGL(k_tower_c6<true>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const _Float16*)x_hi,
+                       (const unsigned char*)x_c6, ch, (_Float16*)nullptr, (unsigned char*)nullptr, n_boards, n_dev,
+                       HeadArgs{head_w, head_b, policy_feat, value_feat, n_policy});
+    if (hipGetLastError() != hipSuccess) {
+        czi_set_error("cz_tower_c6_heads: launch failed");
         return CZ_ERR_HIP;
     }
     return CZ_OK;

@@ -365,6 +365,14 @@ int cz_resblock_q(const void* x_hi, const void* x_lo, const void* w1_packed, con
 int cz_tower_c6(const void* x_hi, const void* x_c6, int n_blocks, const void* const* w1_packed, const float* const* bias1,
                 const void* const* w2_packed, const float* const* bias2, void* y_hi, void* y_c6, int n_boards,
                 const int32_t* n_dev, void* stream);
+/* The same chain ending on the tower's LAST block with the 1 x 1 head convolutions as its exit (cz_resblock_heads' outputs:
+ * policy_feat [n][n_policy * 90], value_feat [n][n_value * 90] fp32, ReLU'd; agent/model.py:46-60, the heads' first layers).  The
+ * head dot products are summed over a pixel's four 32-channel partial sums: equal to cz_resblock_heads up to the rounding of
+ * that summation order (2e-6 relative). */
+int cz_tower_c6_heads(const void* x_hi, const void* x_c6, int n_blocks, const void* const* w1_packed, const float* const* bias1,
+                      const void* const* w2_packed, const float* const* bias2, const float* head_w, const float* head_b,
+                      float* policy_feat, float* value_feat, int n_boards, int n_policy, int n_value, const int32_t* n_dev,
+                      void* stream);
 int cz_resblock_heads_q(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1,
                         const void* w2_packed, const float* bias2, const float* head_w, const float* head_b,
                         float* policy_feat, float* value_feat, int n_boards, int channels, int dtype, int n_policy,

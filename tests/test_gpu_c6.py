@@ -142,6 +142,7 @@ def test_chained_c6_tower_is_bit_identical_to_block_by_block(blocks):
     planes_all = calibration_planes(1100, 14, seed=23)
     g = guarded_inference_net(net, torch.float32, trunk="mfma", arith="c6", guard=False, planes=planes_all[:256])
     assert g.c6 and g.c6_blocks == blocks
+    g.chain_heads = False                     # (the chain proper: the heads-as-exit variant reorders the head sums, tested below)
     for n in (1, 37, 256, 300, 700, 1100):
         planes = planes_all[:n].contiguous()
         g.chain_blocks = False
@@ -162,3 +163,30 @@ def test_chained_c6_tower_is_bit_identical_to_block_by_block(blocks):
     g.chain_blocks = True
     p1, v1 = g(planes, rows=rows, count=count)
     assert torch.equal(p0[:517], p1[:517]) and torch.equal(v0[:517], v1[:517])
+
+
+@pytest.mark.parametrize("blocks", [3, 7])
+def test_chain_through_the_last_block_with_the_heads_as_its_exit(blocks):
+    """cz_tower_c6_heads (the default where the whole tower is c6; CZ_TOWER_HEADS=0 switches it off): the chain ends on the tower's last block and the 1 x 1 head convolutions are
+    its exit pass.  The head dot products are summed in a different order than the unchained launch's (four 32-channel partial
+    sums per pixel instead of sixteen 8-channel ones), everything else is identical: policy / value agree to float32 rounding."""
+    import torch
+    from cchess_alphazero.agent.model import calibration_planes, guarded_inference_net
+    net = peaked_net(20.0, blocks=blocks)
+    planes_all = calibration_planes(700, 14, seed=29)
+    g = guarded_inference_net(net, torch.float32, trunk="mfma", arith="c6", guard=False, planes=planes_all[:256])
+    for n in (1, 37, 300, 700):
+        planes = planes_all[:n].contiguous()
+        g.chain_heads = False
+        p0, v0 = (t.clone() for t in g(planes))
+        g.chain_heads = True
+        g.block_events = []
+        p1, v1 = g(planes)
+        launches = [len(e) > 2 and e[2] or 1 for e in g.block_events]
+        g.block_events = None
+        assert launches == [1, blocks - 1], launches                  # FIRST | the chain through the last block
+        # (128-term fp32 sums in two association orders, through the dense heads of a hostile test network: policy a few
+        #  1e-7, value up to 1e-5 -- the float32 noise either order has against float64; north_star's tolerance is 1e-4)
+        assert torch.isfinite(p1).all() and (p0 - p1).abs().max().item() < 5e-6 and (v0 - v1).abs().max().item() < 3e-5, \
+            (blocks, n, (p0 - p1).abs().max().item(), (v0 - v1).abs().max().item())
+    g.chain_heads = False
