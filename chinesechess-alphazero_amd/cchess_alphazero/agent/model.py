@@ -97,6 +97,22 @@ def _fold(conv, bn):
     return out
 
 
+def chain_plan(nblk, c6_blocks, chain_blocks=True, heads_exit=True):
+    """Which residual blocks of a c6 tower (fused input layer in block 0) run as ONE cz_tower_c6 launch: (range of block indices,
+    whether the chain ends on the tower's last block with the head convolutions as its exit).  Chainable are the c6 blocks
+    behind the first one whose OUTPUT is a c6 image: up to, not including, the last c6 block (which feeds the heads, or hands a
+    c8 image over in a hybrid c6>N tower) -- and that last block too when the whole tower is c6 and the heads are fused
+    (cz_tower_c6_heads).  A chain has 2 .. 8 blocks; an empty range = one launch per block."""
+    if not chain_blocks:
+        return range(0), False
+    if heads_exit and c6_blocks == nblk and 3 <= nblk <= 9:
+        return range(1, nblk), True
+    end = min(c6_blocks - 1, nblk - 1)
+    if end - 1 >= 2:
+        return range(1, min(end, 1 + 8)), False
+    return range(0), False
+
+
 def events_ms(events):
     """Per-BLOCK times (ms) of the tower launches recorded in InferenceNet.block_events: a (start, end) pair is one residual
     block; (start, end, m) is a launch of m chained blocks (cz_tower_c6), counted as m blocks of elapsed / m each, so that the
@@ -367,14 +383,9 @@ class InferenceNet(nn.Module):
         # blocks behind the fused input layer up to, not including, the last c6 block of the tower (fused heads, or the
         # hand-over to c8 in a hybrid) -- blocks 1 .. 5 of the 7 x 128 benchmark tower
         chain, chain_heads = range(0), False
-        if self.c6 and fused and first_fused and self.chain_blocks:
-            end = min(self.c6_blocks - 1, nblk - 1)
-            if end - 1 >= 2:
-                chain = range(1, min(end, 1 + 8))
-            # ... and through the tower's last block with the head convolutions as the chain's exit (CZ_TOWER_HEADS=0: off)
-            if (self.chain_heads and self.c6_blocks == nblk and heads is not None and self.parts == 2 and c == 128 and
-                    3 <= nblk <= 9):
-                chain, chain_heads = range(1, nblk), True
+        if self.c6 and fused and first_fused:
+            chain, chain_heads = chain_plan(nblk, self.c6_blocks, self.chain_blocks,
+                                            self.chain_heads and heads is not None and self.parts == 2 and c == 128)
         for i in range(nblk):
             if i in chain and i != chain.start:
                 continue                                        # (part of the chain launched at chain.start)

@@ -555,3 +555,28 @@ def test_occupancy_boards_stand_for_the_planes():
     m28 = planes_to_masks(both)
     assert torch.equal(masks_to_planes(m28, 28, torch.uint8), both.to(torch.uint8))
     assert torch.equal(m28 & 0x3FFF, masks) and torch.equal(m28 >> 14, masks.flip(0))
+
+
+def test_chain_plan_and_block_events():
+    """agent/model.py: which blocks of a c6 tower run as one cz_tower_c6 launch, and how bench.py spreads a chained launch's time
+    over its blocks (host logic only)."""
+    from cchess_alphazero.agent.model import chain_plan, events_ms
+    assert chain_plan(7, 7) == (range(1, 7), True)                  # the benchmark tower: FIRST | blocks 1 .. 6 with the heads as exit
+    assert chain_plan(7, 7, heads_exit=False) == (range(1, 6), False)      # ... FIRST | 1 .. 5 | HEADS
+    assert chain_plan(7, 5) == (range(1, 4), False)                 # c6>5: block 4 hands a c8 image over, 5 and 6 are c8 blocks
+    assert chain_plan(7, 3)[0] == range(0) and chain_plan(7, 4) == (range(1, 3), False)
+    assert chain_plan(3, 3) == (range(1, 3), True) and chain_plan(3, 3, heads_exit=False)[0] == range(0)
+    assert chain_plan(2, 2)[0] == range(0)                          # FIRST | HEADS: nothing to chain
+    assert chain_plan(4, 4, heads_exit=False) == (range(1, 3), False)
+    assert chain_plan(12, 12) == (range(1, 9), False)               # at most 8 blocks per launch; the rest one per launch
+    assert chain_plan(7, 7, chain_blocks=False) == (range(0), False)
+    for nblk in range(2, 13):
+        for c6 in range(1, nblk + 1):
+            r, h = chain_plan(nblk, c6)
+            assert len(r) == 0 or (r.start == 1 and 2 <= len(r) <= 8 and r.stop <= c6 and (r.stop == nblk) == h)
+
+    class Ev:
+        def __init__(self, t): self.t = t
+        def elapsed_time(self, other): return other.t - self.t
+    ms = events_ms([(Ev(0.0), Ev(3.3)), (Ev(3.3), Ev(19.3), 6)])
+    assert len(ms) == 7 and abs(ms[0] - 3.3) < 1e-12 and all(abs(x - 16.0 / 6) < 1e-12 for x in ms[1:])
