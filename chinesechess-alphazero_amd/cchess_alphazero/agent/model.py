@@ -379,9 +379,9 @@ class InferenceNet(nn.Module):
                 cur, tmp, nxt = (self._as_f16_pair(t) for t in (cur, tmp, nxt))
             _native.input_conv(planes.contiguous(), self.in_w.view(self.operand_dtype), self.in_bias32, cur,
                                rows=rows, count=count)
-        # (round 5) consecutive c6 -> c6 inner blocks run as ONE launch with the activations staying in LDS (cz_tower_c6): the
-        # blocks behind the fused input layer up to, not including, the last c6 block of the tower (fused heads, or the
-        # hand-over to c8 in a hybrid) -- blocks 1 .. 5 of the 7 x 128 benchmark tower
+        # (round 5) the c6 blocks behind the fused input layer run as ONE launch with the activations staying in LDS
+        # (cz_tower_c6 / cz_tower_c6_heads; chain_plan): blocks 1 .. 6 of the 7 x 128 benchmark tower, the head convolutions
+        # as the chain's exit
         chain, chain_heads = range(0), False
         if self.c6 and fused and first_fused:
             chain, chain_heads = chain_plan(nblk, self.c6_blocks, self.chain_blocks,
