@@ -580,3 +580,38 @@ def test_chain_plan_and_block_events():
         def elapsed_time(self, other): return other.t - self.t
     ms = events_ms([(Ev(0.0), Ev(3.3)), (Ev(3.3), Ev(19.3), 6)])
     assert len(ms) == 7 and abs(ms[0] - 3.3) < 1e-12 and all(abs(x - 16.0 / 6) < 1e-12 for x in ms[1:])
+
+
+def test_chained_tower_staging_layout_model():
+    """The address arithmetic behind k_tower_c6's in-place conversion (csrc/xq_conv.hip, namespace tw), restated: a board's fp32
+    result is staged INSIDE its slot's image -- channels 0 .. 63 of pixel q in row q of the f16 part, 64 .. 127 in row q of the
+    c6 part -- and the four lanes (32-channel blocks) of a pixel turn the row into the operand triple in place.  What makes
+    that safe without any synchronisation among the copy waves: per pixel row, the four lanes' reads cover exactly the row's
+    512 bytes, their writes stay inside the same 512 bytes (f16: the whole part-0 row; c6: eight 24-byte pieces of the part-1
+    row), and no two rows share a byte."""
+    RB, PSTR = 256, (272 + 16) * 256
+    stage_off = lambda q, ch: (ch >> 6) * PSTR + q * RB + ((((ch >> 2) & 15) ^ (q & 15)) << 4)
+    c6_chunk = lambda kind, blk: 8 * kind + 4 * (blk >> 1) + 2 * (blk & 1)
+    c6_lds_off = lambda row, chunk: row * RB + ((chunk ^ (row & 15)) << 4)
+    seen = set()
+    for q in range(90):
+        row_bytes = set(range(q * RB, q * RB + RB)) | set(range(PSTR + q * RB, PSTR + q * RB + RB))
+        reads, writes = set(), []
+        for blk in range(4):
+            for k in range(8):                                   # eight float4 of the lane's 32 channels
+                o = stage_off(q, blk * 32 + 4 * k)
+                reads |= set(range(o, o + 16))
+            for k in range(4):                                   # f16: chunk 4 blk + k of the part-0 row
+                o = q * RB + (((blk * 4 + k) ^ (q & 15)) << 4)
+                writes.append(set(range(o, o + 16)))
+            for kind in range(2):                                # a piece = 16-byte head in its chunk + 8-byte tail in the next
+                c = c6_chunk(kind, blk)
+                writes.append(set(range(PSTR + c6_lds_off(q, c), PSTR + c6_lds_off(q, c) + 16)))
+                writes.append(set(range(PSTR + c6_lds_off(q, c + 1), PSTR + c6_lds_off(q, c + 1) + 8)))
+        assert reads == row_bytes, q                             # the staging of a pixel IS its two image rows
+        allw = set().union(*writes)
+        assert sum(len(w) for w in writes) == len(allw) == 256 + 8 * 24 and allw <= row_bytes, q    # disjoint, inside the row
+        assert not (row_bytes & seen), q
+        seen |= row_bytes
+    # the channel -> (row, chunk) map is one to one: 32 float4 per pixel on 32 distinct chunks
+    assert len({stage_off(7, 4 * i) for i in range(32)}) == 32
