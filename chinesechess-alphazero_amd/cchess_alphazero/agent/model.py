@@ -164,12 +164,12 @@ class InferenceNet(nn.Module):
         assert trunk in ("library", "mfma")
         self.dtype = dtype
         self.trunk = trunk
+        from_env = arith is None and bool(os.environ.get("CZ_TOWER_ARITH"))    # (an explicit argument is never "from the environment")
         arith = arith or os.environ.get("CZ_TOWER_ARITH") or "bf16x3"
         nblk = net.cfg["res_layer_num"]
         c8_blocks = 0
         self.c6 = False
         self.c6_blocks = 0
-        from_env = arith == os.environ.get("CZ_TOWER_ARITH")
         if arith == "c6" or arith.startswith("c6>"):
             # c8 with bf6 correction operands (half the matrix time of the e4m3 ones): 128 filters, >= 2 blocks; "c6>N": the
             # first N blocks only, the rest c8
@@ -542,7 +542,9 @@ class InferenceNet(nn.Module):
                     return out
                 v = torch.tanh(self.value_out(v).float())
                 return F.softmax(p.float(), dim=1), v.squeeze(1)
-            last = self._trunk_mfma(planes)
+            # (other head widths -- CChessNet(policy_filters=..., value_filters=...), keras_io: the fused input layer still
+            #  reads the occupancy boards where the engine has switched the planes off: takes_masks)
+            last = self._trunk_mfma(planes, rows=rows, count=count, masks=masks)
             x = last.view(n, 10, 9, self.filters).permute(0, 3, 1, 2)    # logical NCHW over channels-last memory
         else:
             x = planes.to(self.dtype).contiguous(memory_format=torch.channels_last)
