@@ -17,7 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libczero.so")
-SOURCES = ["xq_kernels.hip", "xq_search.hip", "xq_nn_epilogue.hip", "xq_conv.hip", "xq_heads.hip"]
+SOURCES = ["xq_kernels.hip", "xq_search.hip", "xq_nn_epilogue.hip", "xq_conv.hip", "xq_tower.hip", "xq_heads.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-ffp-contract=off",          # PUCT / backup arithmetic must not be fused (bit-parity with the reference)
          "-fno-fast-math"]
@@ -60,7 +60,7 @@ def build(force=False, verbose=True, defines=(), out=None):
         subprocess.check_call(cmd)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, _sources()))
     cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib]
     if verbose:

@@ -94,6 +94,17 @@ def _declare(L):
     if hasattr(L, "cz_input_resblock"):
         L.cz_input_resblock.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
         L.cz_input_resblock.restype = i32
+    if hasattr(L, "cz_tower"):
+        L.cz_input_resblock_m.restype = i32
+        L.cz_input_resblock_m.argtypes = [vp, vp, i32] + [vp] * 8 + [i32] * 3 + [vp] * 3
+        L.cz_tower.restype = i32
+        L.cz_tower.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+        L.cz_tower_pairs.restype = i32
+        L.cz_tower_pairs.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+        L.cz_tower_c6.restype = i32
+        L.cz_tower_c6.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+        L.cz_tower_c6_heads.restype = i32
+        L.cz_tower_c6_heads.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
     if hasattr(L, "cz_heads_tail"):
         L.cz_heads_tail.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, i32, vp, C.c_float, vp, vp, vp, i32, i32, i32, vp, vp]
         L.cz_heads_tail.restype = i32
@@ -394,8 +405,6 @@ def input_resblock(planes, table, in_bias, w1, b1, w2, b2, out, rows=None, count
     if masks is not None:
         assert masks.dtype == torch.int32 and masks.is_cuda and masks.is_contiguous() and tuple(masks.shape) == (n, 96)
     L = lib()
-    L.cz_input_resblock_m.restype = C.c_int
-    L.cz_input_resblock_m.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int] * 3 + [C.c_void_p] * 3
     check(L.cz_input_resblock_m(_ptr(planes), _ptr(masks), planes.shape[1], _ptr(table), _ptr(in_bias), _ptr(w1), _ptr(b1),
                                 _ptr(w2), _ptr(b2), _ptr(out[0]), _ptr(out[1]), n, out[0].shape[-1], _pair_code(out),
                                 _ptr(rows) if rows is not None else None, _ptr(count) if count is not None else None,
@@ -479,34 +488,86 @@ def resblock(x, w1_packed, bias1, w2_packed, bias2, out=None, out_f32=None, coun
     return out_f32 if out_f32 is not None else out
 
 
+IMG_C8, IMG_C6, IMG_PAIR, EXIT_HEADS = 0, 1, 2, 3      # include/czero.h CZ_IMG_* / CZ_EXIT_HEADS
+
+
+class BlockList:
+    """The per-block parameter arrays a chain launch takes (HOST arrays of device pointers + the blocks' image formats), built
+    once for a list of blocks [(w1_packed, bias1, w2_packed, bias2), ...] and reused every round (the default path
+    runs without a HIP graph, the arrays were rebuilt per call).  Keeps the tensors alive."""
+
+    def __init__(self, blocks, fmt_x=None, fmt_y=None):
+        self.blocks = list(blocks)
+        nb = self.n = len(self.blocks)
+        self.arrays = tuple((C.c_void_p * nb)(*[_ptr(b[k]) for b in self.blocks]) for k in range(4))
+        self.fmt_x = (C.c_int * nb)(*[int(v) for v in fmt_x]) if fmt_x is not None else None
+        self.fmt_y = (C.c_int * nb)(*[int(v) for v in fmt_y]) if fmt_y is not None else None
+
+
+def _block_list(blocks, fmt_x=None, fmt_y=None):
+    return blocks if isinstance(blocks, BlockList) else BlockList(blocks, fmt_x, fmt_y)
+
+
+def tower(x, blocks, exit_fmt, out=None, heads=None, count=None, fmt_x=None, fmt_y=None):
+    """cz_tower: the consecutive residual blocks `blocks` (a BlockList, or [(w1_packed, bias1, w2_packed, bias2), ...] with fmt_x /
+    fmt_y = per-block IMG_C8 / IMG_C6 lists; None = all c6) on the c8 / c6 arithmetics in ONE launch, activations in LDS between
+    them.  x: the operand pair the first block reads.  exit_fmt IMG_C8 / IMG_C6: out = that operand pair; IMG_PAIR: out = (hi, lo)
+    fp16 tensors [N, 90, 128] (the hand-over of a c8>N tower); EXIT_HEADS: heads = (head_w, head_b, n_policy, policy_feat,
+    value_feat).  Bit-identical to len(blocks) resblock() calls."""
+    require_gpu()
+    L = lib()
+    bl = _block_list(blocks, fmt_x, fmt_y)
+    a = bl.arrays
+    hw = hb = pf = vf = None
+    npol = nval = 0
+    if exit_fmt == EXIT_HEADS:
+        hw, hb, npol, pf, vf = heads
+        nval = hw.shape[0] - npol
+    check(L.cz_tower(_ptr(x[0]), _ptr(x[1]), bl.n, a[0], a[1], a[2], a[3], bl.fmt_x, bl.fmt_y, int(exit_fmt),
+                     _ptr(out[0]) if out is not None else None, _ptr(out[1]) if out is not None else None,
+                     _ptr(hw), _ptr(hb), _ptr(pf), _ptr(vf), npol, nval, x[0].shape[0], _ptr(count), _stream()), "cz_tower")
+    return out if exit_fmt != EXIT_HEADS else (pf, vf)
+
+
+def tower_pairs(x, blocks, out=None, heads=None, count=None):
+    """cz_tower_pairs: consecutive (hi, lo) pair blocks (f16x3 / bf16x3) in one launch; x = (hi, lo) [N, 90, 128] fp16 / bf16.
+    out = (hi, lo), or heads = (head_w, head_b, n_policy, policy_feat, value_feat) when the chain ends the tower."""
+    require_gpu()
+    L = lib()
+    bl = _block_list(blocks)
+    a = bl.arrays
+    hw = hb = pf = vf = None
+    npol = nval = 0
+    if heads is not None:
+        hw, hb, npol, pf, vf = heads
+        nval = hw.shape[0] - npol
+    check(L.cz_tower_pairs(_ptr(x[0]), _ptr(x[1]), bl.n, a[0], a[1], a[2], a[3],
+                           _ptr(out[0]) if out is not None else None, _ptr(out[1]) if out is not None else None,
+                           _ptr(hw), _ptr(hb), _ptr(pf), _ptr(vf), npol, nval, x[0].shape[0], _dt_code(x[0].dtype),
+                           _ptr(count), _stream()), "cz_tower_pairs")
+    return out if heads is None else (pf, vf)
+
+
 def tower_c6(x, blocks, out, count=None):
     """cz_tower_c6: the consecutive c6 residual blocks `blocks` = [(w1_packed, bias1, w2_packed, bias2), ...] (2 .. 8) in ONE
     launch, activations in LDS between them; x / out: c6 operand pairs (f16 [N, 90, 128], int8 [N, 90, 256]).  Bit-identical to
     len(blocks) resblock() calls."""
     require_gpu()
-    L = lib()
-    nb = len(blocks)
-    arr = lambda k: (C.c_void_p * nb)(*[_ptr(b[k]) for b in blocks])
-    L.cz_tower_c6.restype = C.c_int
-    L.cz_tower_c6.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                              C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-    check(L.cz_tower_c6(_ptr(x[0]), _ptr(x[1]), nb, arr(0), arr(1), arr(2), arr(3), _ptr(out[0]), _ptr(out[1]), x[0].shape[0],
-                        _ptr(count), _stream()), "cz_tower_c6")
+    bl = _block_list(blocks)
+    a = bl.arrays
+    check(lib().cz_tower_c6(_ptr(x[0]), _ptr(x[1]), bl.n, a[0], a[1], a[2], a[3], _ptr(out[0]), _ptr(out[1]), x[0].shape[0],
+                            _ptr(count), _stream()), "cz_tower_c6")
     return out
 
 
 def tower_c6_heads(x, blocks, head_w, head_b, n_policy, policy_feat, value_feat, count=None):
     """cz_tower_c6_heads: tower_c6 ending on the tower's last block, the 1x1 head convolutions as the chain's exit."""
     require_gpu()
-    L = lib()
-    nb = len(blocks)
-    arr = lambda k: (C.c_void_p * nb)(*[_ptr(b[k]) for b in blocks])
-    L.cz_tower_c6_heads.restype = C.c_int
-    L.cz_tower_c6_heads.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    check(L.cz_tower_c6_heads(_ptr(x[0]), _ptr(x[1]), nb, arr(0), arr(1), arr(2), arr(3), _ptr(head_w), _ptr(head_b),
-                              _ptr(policy_feat), _ptr(value_feat), x[0].shape[0], n_policy, head_w.shape[0] - n_policy,
-                              _ptr(count), _stream()), "cz_tower_c6_heads")
+    bl = _block_list(blocks)
+    a = bl.arrays
+    check(lib().cz_tower_c6_heads(_ptr(x[0]), _ptr(x[1]), bl.n, a[0], a[1], a[2], a[3], _ptr(head_w), _ptr(head_b),
+                                  _ptr(policy_feat), _ptr(value_feat), x[0].shape[0], n_policy, head_w.shape[0] - n_policy,
+                                  _ptr(count), _stream()), "cz_tower_c6_heads")
     return policy_feat, value_feat
 
 

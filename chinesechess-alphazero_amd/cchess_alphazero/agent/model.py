@@ -97,25 +97,52 @@ def _fold(conv, bn):
     return out
 
 
-def chain_plan(nblk, c6_blocks, chain_blocks=True, heads_exit=True):
-    """Which residual blocks of a c6 tower (fused input layer in block 0) run as ONE cz_tower_c6 launch: (range of block indices,
-    whether the chain ends on the tower's last block with the head convolutions as its exit).  Chainable are the c6 blocks
-    behind the first one whose OUTPUT is a c6 image: up to, not including, the last c6 block (which feeds the heads, or hands a
-    c8 image over in a hybrid c6>N tower) -- and that last block too when the whole tower is c6 and the heads are fused
-    (cz_tower_c6_heads).  A chain has 2 .. 8 blocks; an empty range = one launch per block."""
-    if not chain_blocks:
-        return range(0), False
-    if heads_exit and c6_blocks == nblk and 3 <= nblk <= 9:
-        return range(1, nblk), True
-    end = min(c6_blocks - 1, nblk - 1)
-    if end - 1 >= 2:
-        return range(1, min(end, 1 + 8)), False
-    return range(0), False
+def tower_plan(kinds, heads_exit=True, chain_heads=True, max_chain=8):
+    """The launches of a 128-filter tower behind the fused input layer (round 6: every arithmetic chains).  kinds[i] = the
+    arithmetic of residual block i: "c6" / "c8" (blocks whose result is staged and converted: cz_tower) or "pair" ((hi, lo)
+    operands, f16x3 / bf16x3: cz_tower_pairs), in guard_chain's order: c6 blocks, then c8 blocks, then pair blocks.  A launch
+    runs ONE arithmetic; its exit hands over to the next.
+    Returns a list of steps:
+      ("first", 0)                       cz_input_resblock: input layer + block 0
+      ("tower", [blocks], exit)          one cz_tower launch (blocks of one kind); exit = "c6" / "c8" (the image the next launch
+                                         reads), "pair" (the hand-over of a c8>N tower to its pair blocks) or "heads"
+      ("pairs", [blocks], heads: bool)   one cz_tower_pairs launch
+      ("block", i)                       the tower's last block on its own launch (fp32 output / heads not chained)
+    heads_exit: the head convolutions can be the last launch's exit (6 head filters); chain_heads=False keeps them on the last
+    block's own launch (CZ_TOWER_HEADS=0; the bit-identity tests).  A launch takes at most max_chain blocks."""
+    nblk = len(kinds)
+    assert nblk >= 2 and all(k in ("c6", "c8", "pair") for k in kinds)
+    m = next((i for i, k in enumerate(kinds) if k == "pair"), nblk)          # staged blocks [0, m), pair blocks [m, nblk)
+    assert all(k == "pair" for k in kinds[m:]), kinds
+    assert m != 1, "a tower whose only staged block is the first hands fp32 over after it (cz_resblock): not a fused-input tower"
+    steps = [("first", 0)]
+    in_chain_last = heads_exit and chain_heads           # the tower's last block inside a chain (heads as the exit)
+    end = nblk if in_chain_last else nblk - 1            # blocks [1, end) are chained, block nblk - 1 maybe on its own
+
+    def chunks(lo, hi):
+        out = []
+        while lo < hi:
+            out.append(list(range(lo, min(hi, lo + max_chain))))
+            lo += max_chain
+        return out
+    # staged chains: one per arithmetic (the last c6 block writes the c8 image the c8 chain reads), at most max_chain blocks each
+    m6 = next((i for i, k in enumerate(kinds) if k != "c6"), nblk)
+    staged = chunks(1, min(m6, m, end)) + chunks(max(m6, 1), min(m, end))
+    for blk in staged:
+        nxt = blk[-1] + 1
+        steps.append(("tower", blk, "heads" if nxt == nblk else kinds[nxt]))
+    if m < nblk:
+        pr = chunks(max(m, 1), end)
+        for j, blk in enumerate(pr):
+            steps.append(("pairs", blk, blk[-1] + 1 == nblk))
+    if not in_chain_last:
+        steps.append(("block", nblk - 1))
+    return steps
 
 
 def events_ms(events):
     """Per-BLOCK times (ms) of the tower launches recorded in InferenceNet.block_events: a (start, end) pair is one residual
-    block; (start, end, m) is a launch of m chained blocks (cz_tower_c6), counted as m blocks of elapsed / m each, so that the
+    block; (start, end, m) is a launch of m chained blocks (cz_tower / cz_tower_pairs), counted as m blocks of elapsed / m each, so that the
     list keeps one entry per block of the tower in tower order."""
     out = []
     for e in events:
@@ -207,7 +234,7 @@ class InferenceNet(nn.Module):
         # PyTorch tail they replace (A/B runs)
         self.fused_tail = os.environ.get("CZ_FUSED_TAIL", "1") != "0"
         self.block_events = None            # bench.py: list collecting (start, end[, blocks]) HIP events around tower launches
-        # consecutive c6 inner blocks as one launch (cz_tower_c6; CZ_TOWER_CHAIN=0 / 1 overrides the default)
+        # consecutive blocks as one launch (cz_tower / cz_tower_pairs, tower_plan; CZ_TOWER_CHAIN=0: one launch per block)
         self.chain_blocks = os.environ.get("CZ_TOWER_CHAIN", "1") != "0"
         self.chain_heads = os.environ.get("CZ_TOWER_HEADS", "1") != "0"
         self.input_depth = net.cfg["input_depth"]
@@ -379,16 +406,13 @@ class InferenceNet(nn.Module):
                 cur, tmp, nxt = (self._as_f16_pair(t) for t in (cur, tmp, nxt))
             _native.input_conv(planes.contiguous(), self.in_w.view(self.operand_dtype), self.in_bias32, cur,
                                rows=rows, count=count)
-        # (round 5) the c6 blocks behind the fused input layer run as ONE launch with the activations staying in LDS
-        # (cz_tower_c6 / cz_tower_c6_heads; chain_plan): blocks 1 .. 6 of the 7 x 128 benchmark tower, the head convolutions
-        # as the chain's exit
-        chain, chain_heads = range(0), False
-        if self.c6 and fused and first_fused:
-            chain, chain_heads = chain_plan(nblk, self.c6_blocks, self.chain_blocks,
-                                            self.chain_heads and heads is not None and self.parts == 2 and c == 128)
+        # (round 5 / 6) the blocks behind the fused input layer run as CHAINS -- one launch for consecutive blocks with the
+        # activations staying in LDS (cz_tower for c6 / c8 blocks, cz_tower_pairs for f16x3 / bf16x3 ones; tower_plan): the 7 x 128
+        # benchmark tower is FIRST | blocks 1 .. 6 with the head convolutions as the chain's exit, a c8>3 tower FIRST | 1 .. 2 (exit:
+        # fp16 pairs) | 3 .. 6 (heads)
+        if fused and first_fused and self.chain_blocks:
+            return self._tower_chained(planes, cur, nxt, last, heads, rows, count, masks)
         for i in range(nblk):
-            if i in chain and i != chain.start:
-                continue                                        # (part of the chain launched at chain.start)
             w1 = getattr(self, f"tw{i}a").view(self.operand_dtype)
             w2 = getattr(self, f"tw{i}b").view(self.operand_dtype)
             if self.c6:
@@ -406,16 +430,6 @@ class InferenceNet(nn.Module):
                     _native.input_resblock(planes.contiguous(), self.in_table32, self.in_bias32, w1, b1, w2, b2, out=nxt,
                                            rows=rows, count=count, masks=masks)
                     cur, nxt = nxt, cur
-                elif i in chain:
-                    blocks = [(getattr(self, f"tw{k}a").view(self.operand_dtype), getattr(self, f"tb{k}a"),
-                               getattr(self, f"tw{k}b").view(self.operand_dtype), getattr(self, f"tb{k}b")) for k in chain]
-                    if chain_heads:
-                        _native.tower_c6_heads(cur, blocks, self.head_w32, self.head_b32, heads[0], heads[1], heads[2], count=count)
-                    else:
-                        _native.tower_c6(cur, blocks, out=nxt, count=count)
-                        cur, nxt = nxt, cur
-                    if ev is not None:
-                        ev = ev + (len(chain),)                  # (events_ms spreads the launch over its blocks)
                 elif i + 1 == n8 and n8 < nblk:
                     # the last c8 block of a hybrid tower: fp32 out, re-split into (hi, lo) fp16 pairs for the f16x3 blocks
                     _native.resblock(cur, w1, b1, w2, b2, out_f32=last, count=count)
@@ -450,6 +464,97 @@ class InferenceNet(nn.Module):
         if heads is not None and fused and self.parts == 2 and c == 128:
             return None                                                  # the head features are already written
         return last                                                      # [n, 90, c] channels-last trunk output
+
+    def block_kinds(self):
+        """Per residual block, the arithmetic its launch runs (tower_plan's kinds): "c6" / "c8" / "pair"."""
+        nblk = len(self.res)
+        if self.c6:
+            return ["c6"] * self.c6_blocks + ["c8"] * (nblk - self.c6_blocks)
+        if self.arith == "c8":
+            return ["c8"] * self.c8_blocks + ["pair"] * (nblk - self.c8_blocks)
+        return ["pair"] * nblk
+
+    def _block_params(self, i):
+        od = self.operand_dtype
+        return (getattr(self, f"tw{i}a").view(od), getattr(self, f"tb{i}a"), getattr(self, f"tw{i}b").view(od), getattr(self, f"tb{i}b"))
+
+    def _tower_chained(self, planes, cur, nxt, last, heads, rows, count, masks):
+        """The fused 128-filter tower as tower_plan's launches.  cur / nxt: two operand buffers of _operands (storage: (f16, image
+        bytes) for the c8 / c6 family, (hi, lo) otherwise); returns like _trunk_mfma."""
+        from cchess_alphazero import _native
+        kinds = self.block_kinds()
+        nblk = len(kinds)
+        heads_ok = heads is not None and self.parts == 2 and self.filters == 128
+        # the head convolutions as a pair chain's exit read the block's value as hi + lo: fp16 pairs stand for it to 2^-22, bf16
+        # pairs only to 2^-17 -- bf16x3 (the guard's last resort before the fp32 library trunk) keeps its HEADS launch, which
+        # works on the fp32 value
+        chain_heads = self.chain_heads and not (kinds[-1] == "pair" and self.operand_dtype == torch.bfloat16)
+        key = ("plan", heads_ok, chain_heads, self.tb0a.data_ptr())     # (device pointers inside: rebuilt if the module moved)
+        if key not in self._bufs:
+            # launch steps + the per-launch pointer arrays, built once (invalidated with the buffers on a weight repack)
+            plan = []
+            for step in tower_plan(kinds, heads_exit=heads_ok, chain_heads=chain_heads):
+                if step[0] in ("tower", "pairs"):
+                    blk = step[1]
+                    fmt = [_native.IMG_C6 if kinds[blk[0]] == "c6" else _native.IMG_C8] * len(blk)     # (one arithmetic per launch)
+                    bl = _native.BlockList([self._block_params(i) for i in blk], *((fmt, fmt) if step[0] == "tower" else ()))
+                    plan.append(step + (bl,))
+                else:
+                    plan.append(step)
+            self._bufs[key] = plan
+        img_tag = {"c6": torch.int8, "c8": torch.uint8}
+
+        def view(t, kind):                      # an operand buffer seen as the pair of `kind`
+            if kind == "pair":
+                return (t[0], t[1].view(t[0].dtype)) if t[1].dtype in (torch.uint8, torch.int8) else t
+            return (t[0], t[1].view(img_tag[kind]))
+        fmt_code = {"c6": _native.IMG_C6, "c8": _native.IMG_C8, "pair": _native.IMG_PAIR}
+        hd = (self.head_w32, self.head_b32, heads[0], heads[1], heads[2]) if heads_ok else None
+        done_heads = False
+        for step in self._bufs[key]:
+            ev = None
+            if self.block_events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            if step[0] == "first":
+                w1, b1, w2, b2 = self._block_params(0)
+                _native.input_resblock(planes.contiguous(), self.in_table32, self.in_bias32, w1, b1, w2, b2,
+                                       out=view(nxt, kinds[0]), rows=rows, count=count, masks=masks)
+                cur, nxt = nxt, cur
+                nb = 1
+            elif step[0] == "tower":
+                _, blk, ex, bl = step
+                nb = len(blk)
+                if ex == "heads":
+                    _native.tower(view(cur, kinds[blk[0]]), bl, _native.EXIT_HEADS, heads=hd, count=count)
+                    done_heads = True
+                else:
+                    _native.tower(view(cur, kinds[blk[0]]), bl, fmt_code[ex], out=view(nxt, ex), count=count)
+                    cur, nxt = nxt, cur
+            elif step[0] == "pairs":
+                _, blk, with_heads, bl = step
+                nb = len(blk)
+                if with_heads:
+                    _native.tower_pairs(view(cur, "pair"), bl, heads=hd, count=count)
+                    done_heads = True
+                else:
+                    _native.tower_pairs(view(cur, "pair"), bl, out=view(nxt, "pair"), count=count)
+                    cur, nxt = nxt, cur
+            else:                               # the last block on its own launch
+                i = step[1]
+                nb = 1
+                w1, b1, w2, b2 = self._block_params(i)
+                x = view(cur, kinds[i])
+                if heads_ok:
+                    _native.resblock_heads(x, w1, b1, w2, b2, self.head_w32, self.head_b32, heads[0], heads[1], heads[2],
+                                           count=count)
+                    done_heads = True
+                else:
+                    _native.resblock(x, w1, b1, w2, b2, out_f32=last, count=count)
+            if ev is not None:
+                ev[1].record()
+                self.block_events.append(ev + (nb,) if nb > 1 else ev)
+        return None if done_heads else last
 
     def _head_feats(self, n, npol, device):
         key = ("hf", n, str(device))

@@ -1297,414 +1297,7 @@ __global__ __launch_bounds__(512, 2) void k_resblock_c8(
     __syncthreads();                                           // E1
 }
 
-// ---- kernel 2d: a CHAIN of c6 residual blocks in one launch (round 5) --------------------------------------------------------
-// k_resblock_c8<.., C6> runs ONE block per launch: every block reads its input image from HBM and writes its output image
-// back, and the copy waves' loads and stores share the CU's vector-memory path with the K loops' filter stream (with the
-// stores switched off a block is 6.7 % faster, profiles/r04_c6_rb_stamps.json).  Here a workgroup takes a PAIR of boards through
-// all blocks of the chain with the activations staying in LDS: three images -- XA, XB, Y -- share 16 zero rows (the layout of
-// k_resblock_pipe: 147.5 KB); the steps of a pair are (block 0, A), (block 0, B), (block 1, A), ... and a step is exactly a
-// board of k_resblock_c8: K loop 1 on X[s] with the PREVIOUS step's second epilogue in its shadow, epilogue 1 -> Y, K loop 2.
-// The previous step belongs to the other slot s', whose X image is dead by then, so its fp32 result is staged INSIDE that
-// image's rows (row-local: channels 0 .. 63 of a pixel in the row of the f16 part, 64 .. 127 in the row of the c6 part), and
-// during this step's K loop 2 the copy waves turn it into the operand triple IN PLACE -- the same conversion they apply on the
-// way to HBM today (f16, bf6(x_lo), bf6(x) with the block's output exponent), four adjacent lanes per pixel, all LDS reads of a
-// wave before its writes -- which is the next block's input of slot s'.  HBM sees a board at the chain's entry and exit only.
-// Arithmetic, accumulation order and conversions are those of k_resblock_c8<false, false, true>: bit-identical to the
-// block-by-block launches (tests/test_gpu_c6.py).  A workgroup with an odd number of boards runs its last board in both slots.
-namespace tw {
-constexpr int C = 128, RB = 256, ROW_XA = 0, ROW_XB = 90, ROW_Y = 180, ROW_DUMP = 270, ROW_Z = 272, PSTR = (ROW_Z + 16) * RB;
-constexpr int BIAS_OFF = 2 * PSTR;                 // float bias[2 buffers][2 convolutions][128]
-constexpr int HW_OFF = BIAS_OFF + 2 * 2 * C * 4;   // HEADS: float head_w[6][128]
-constexpr int LDS_BYTES = HW_OFF, LDS_BYTES_HEADS = HW_OFF + 6 * C * 4;
-constexpr int MAX_BLOCKS = 8;
-static_assert(LDS_BYTES_HEADS <= 160 * 1024, "XA + XB + Y + zero rows + bias buffers (+ head filters) must fit the CU's LDS");
-struct Chain {
-    const void* w1[MAX_BLOCKS];
-    const void* w2[MAX_BLOCKS];
-    const float* b1[MAX_BLOCKS];
-    const float* b2[MAX_BLOCKS];
-    int n;
-};
-// fp32 staging inside an image: byte offset (from the image's first row in the f16 part) of channels ch .. ch + 3 of pixel q
-__device__ __forceinline__ int stage_off(int q, int ch) { return (ch >> 6) * PSTR + q * RB + ((((ch >> 2) & 15) ^ (q & 15)) << 4); }
-
-struct Shadow {                         // relu(acc2 of the previous step) -> staging inside the previous step's own X image
-    unsigned char* lds;
-    f32x16* prev;
-    int wave, kb, ln, base;             // base: byte offset of that image's first row
-    __device__ __forceinline__ void unit(const f32x16& a, int q, int g)
-    {
-        const int ch = wave * 32 + g * 8 + kb * 4;
-        const int addr = q < 90 ? base + stage_off(q, ch) : ROW_DUMP * RB + (kb * 6 + (ln - 26)) * 16;
-        float4 v;
-        v.x = a[g * 4 + 0] > 0.0f ? a[g * 4 + 0] : 0.0f;
-        v.y = a[g * 4 + 1] > 0.0f ? a[g * 4 + 1] : 0.0f;
-        v.z = a[g * 4 + 2] > 0.0f ? a[g * 4 + 2] : 0.0f;
-        v.w = a[g * 4 + 3] > 0.0f ? a[g * 4 + 3] : 0.0f;
-        *reinterpret_cast<float4*>(lds + addr) = v;
-    }
-    __device__ __forceinline__ void fp8(int j, int slot)
-    {
-        if (slot % 9 == 4) unit(prev[0], j * 32 + ln, slot / 9);
-        if (slot == 35) {
-            prev[0] = prev[1];
-            prev[1] = prev[2];
-        }
-    }
-};
-}  // namespace tw
-
-// HEADS: the chain's last block is the tower's last block -- at the exit the copy waves apply the two 1 x 1 head convolutions to
-// the staged fp32 activation (the thread of a (pixel, 32-channel block) item forms six partial dot products, the four lanes of
-// the pixel add them with two DPP quad permutes) instead of converting and storing the operand triple.
-template <bool HEADS>
-__global__ __launch_bounds__(512, 2) void k_tower_c6(
-    const _Float16* __restrict__ xh, const unsigned char* __restrict__ xc, tw::Chain ch, _Float16* __restrict__ yh,
-    unsigned char* __restrict__ yc, int n_boards, const int32_t* __restrict__ n_dev, HeadArgs hd)
-{
-    using namespace tw;
-    using rb8::c6_chunk;
-    using rb8::c6_lds_off;
-    using rb8::pack_ints;
-    using rb8::u32x6;
-    using rb8::f32x32;
-    static_assert(CZ_C6_TAIL_SWZ == 0, "the chained tower keeps one tail convention");
-    constexpr int NT = 3, CTHR = 256;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[HEADS ? LDS_BYTES_HEADS : LDS_BYTES];
-    if (n_dev) {
-        const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
-        n_boards = nd < n_boards ? nd : n_boards;
-    }
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int stride = gridDim.x, t0 = blockIdx.x;
-    if (t0 >= n_boards) return;
-    const int NB = ch.n;
-    const int mine = (n_boards - t0 + stride - 1) / stride;          // boards of this workgroup
-    const int pairs = (mine + 1) / 2;
-    // board of (pair p, slot s); the last board twice when the count is odd (`real` false for the copy: not stored)
-    auto board_of = [&](int p, int s, bool& real) {
-        const int k = 2 * p + s;
-        real = k < mine;
-        return t0 + (real ? k : mine - 1) * stride;
-    };
-    auto row_of = [](int s) { return s ? ROW_XB : ROW_XA; };
-
-    if (wave >= 4) {                                    // ---- copy waves ----
-        const int ctid = tid - 256;
-        // Every pass of the copy waves uses ONE mapping: item i = it * 256 + ctid < 360 is (pixel row i >> 2, 32-channel block
-        // i & 3) -- the row's f16 chunks 4 blk .. 4 blk + 3 and the four c6 chunks of the block's two pieces.  A thread only ever
-        // touches the bytes of its own row quarter, and the four quarters of a row sit in adjacent lanes of one wave, so load ->
-        // write, convert (in place) and drain need no synchronisation among the copy waves.
-        uint4 v[2][8];                                  // [it][f16 chunk k = 0..3 | c6 chunks: kind 0 head, tail, kind 1 head, tail]
-        auto load = [&](int board) {
-            const uint4* sh = reinterpret_cast<const uint4*>(xh + (size_t)board * 90 * C);
-            const uint4* sc = reinterpret_cast<const uint4*>(xc + (size_t)board * 90 * 2 * C);
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int i = it * CTHR + ctid;
-                if (i >= 90 * 4) continue;
-                const int qq = i >> 2, blk = i & 3, c0 = c6_chunk(0, blk);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[it][k] = sh[qq * 16 + blk * 4 + k];
-                v[it][4] = sc[qq * 16 + c0];
-                v[it][5] = sc[qq * 16 + c0 + 1];
-                v[it][6] = sc[qq * 16 + 8 + c0];
-                v[it][7] = sc[qq * 16 + 8 + c0 + 1];
-            }
-        };
-        auto write_x = [&](int s) {
-            unsigned char* X = lds + row_of(s) * RB;
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int i = it * CTHR + ctid;
-                if (i >= 90 * 4) continue;
-                const int qq = i >> 2, blk = i & 3, c0 = c6_chunk(0, blk);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    *reinterpret_cast<uint4*>(X + qq * RB + (((blk * 4 + k) ^ (qq & 15)) << 4)) = v[it][k];
-                *reinterpret_cast<uint4*>(X + PSTR + c6_lds_off(qq, c0)) = v[it][4];
-                *reinterpret_cast<uint4*>(X + PSTR + c6_lds_off(qq, c0 + 1)) = v[it][5];
-                *reinterpret_cast<uint4*>(X + PSTR + c6_lds_off(qq, 8 + c0)) = v[it][6];
-                *reinterpret_cast<uint4*>(X + PSTR + c6_lds_off(qq, 8 + c0 + 1)) = v[it][7];
-            }
-        };
-        // fp32 staging of slot s -> its operand triple, in place (k_out: the exponent of the image, from the block that made it);
-        // board >= 0: the chain's exit -- the triple also goes to HBM, straight from the registers (store_tile_c6's pass B stores)
-        auto convert = [&](int s, int k_out, int board) {
-            unsigned char* X = lds + row_of(s) * RB;
-            const float s_hi = __builtin_ldexpf(1.0f, k_out), s_lo = __builtin_ldexpf(1.0f, k_out - cf8::X_LO_SHIFT);
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int i = it * CTHR + ctid;
-                if (i >= 90 * 4) continue;
-                const int qq = i >> 2, blk = i & 3;
-                f32x16 av, bv, al, bl;
-                struct alignas(16) H8 { Quad<_Float16> a, b; };
-                H8 h[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float4 f0 = *reinterpret_cast<const float4*>(X + stage_off(qq, blk * 32 + 8 * k));
-                    const float4 f1 = *reinterpret_cast<const float4*>(X + stage_off(qq, blk * 32 + 8 * k + 4));
-                    const float r[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        h[k].a.e[j] = (_Float16)r[j];
-                        h[k].b.e[j] = (_Float16)r[4 + j];
-                        av[4 * k + j] = r[j];
-                        bv[4 * k + j] = r[4 + j];
-                        al[4 * k + j] = r[j] - (float)h[k].a.e[j];
-                        bl[4 * k + j] = r[4 + j] - (float)h[k].b.e[j];
-                    }
-                }
-                const u32x6 pl = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(al, bl, s_lo);
-                const u32x6 pv = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(av, bv, s_hi);
-                // (every lane of the wave has read its part of the row by now: the writes below may land on bytes another
-                //  lane of the SAME row -- one of the three neighbours in this wave -- has just read)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    *reinterpret_cast<uint4*>(X + qq * RB + (((blk * 4 + k) ^ (qq & 15)) << 4)) = __builtin_bit_cast(uint4, h[k]);
-                unsigned char* P1 = X + PSTR;
-                *reinterpret_cast<uint4*>(P1 + c6_lds_off(qq, c6_chunk(0, blk))) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-                *reinterpret_cast<uint2*>(P1 + c6_lds_off(qq, c6_chunk(0, blk) + 1)) = make_uint2(pl[4], pl[5]);
-                *reinterpret_cast<uint4*>(P1 + c6_lds_off(qq, c6_chunk(1, blk))) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
-                *reinterpret_cast<uint2*>(P1 + c6_lds_off(qq, c6_chunk(1, blk) + 1)) = make_uint2(pv[4], pv[5]);
-                if (board >= 0) {
-                    const size_t ebase = (size_t)board * 90 * C;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        reinterpret_cast<uint4*>(yh + ebase)[qq * 16 + blk * 4 + k] = __builtin_bit_cast(uint4, h[k]);
-                    unsigned char* row = yc + ebase * 2 + (size_t)qq * 2 * C;
-                    *reinterpret_cast<uint4*>(row + 16 * c6_chunk(0, blk)) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-                    *reinterpret_cast<uint2*>(row + 16 * c6_chunk(0, blk) + 16) = make_uint2(pl[4], pl[5]);
-                    *reinterpret_cast<uint4*>(row + 16 * c6_chunk(1, blk)) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
-                    *reinterpret_cast<uint2*>(row + 16 * c6_chunk(1, blk) + 16) = make_uint2(pv[4], pv[5]);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-            }
-        };
-        // HEADS exit: staging of slot s -> the six head features of every pixel of `board` (nothing is written to LDS)
-        auto heads_exit = [&](int s, int board) {
-            const unsigned char* X = lds + row_of(s) * RB;
-            const float* hwl = reinterpret_cast<const float*>(lds + HW_OFF);
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int i = it * CTHR + ctid;
-                if (i >= 90 * 4) continue;
-                const int qq = i >> 2, blk = i & 3;
-                float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float4 f = *reinterpret_cast<const float4*>(X + stage_off(qq, blk * 32 + 4 * k));
-#pragma unroll
-                    for (int o = 0; o < 6; ++o) {
-                        const float4 w = *reinterpret_cast<const float4*>(hwl + o * C + blk * 32 + 4 * k);
-                        a[o] += f.x * w.x; a[o] += f.y * w.y; a[o] += f.z * w.z; a[o] += f.w * w.w;
-                    }
-                }
-#pragma unroll
-                for (int o = 0; o < 6; ++o) {                  // the four lanes of the pixel: (a0 + a1) + (a2 + a3) on every lane
-                    a[o] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a[o]), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-                    a[o] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a[o]), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-                }
-                if (board < 0) continue;
-#pragma unroll
-                for (int o = 0; o < 6; ++o)
-                    if ((o & 3) == blk) {                       // lane blk writes outputs blk and blk + 4
-                        float hv = a[o] + hd.b[o];
-                        hv = hv > 0.0f ? hv : 0.0f;
-                        if (o < hd.n_pol) hd.pol[(size_t)board * (hd.n_pol * 90) + o * 90 + qq] = hv;
-                        else hd.val[(size_t)board * ((6 - hd.n_pol) * 90) + (o - hd.n_pol) * 90 + qq] = hv;
-                    }
-            }
-        };
-        auto write_bias = [&](int b) {
-            if (ctid < C) {
-                float* dst = reinterpret_cast<float*>(lds + BIAS_OFF) + (b & 1) * 2 * C;
-                dst[ctid] = ch.b1[b][ctid];
-                dst[C + ctid] = ch.b2[b][ctid];
-            }
-        };
-        // ---- prologue: slot A's first board, the zero rows, block 0's bias
-        bool real;
-        load(board_of(0, 0, real));
-        write_x(0);
-        for (int i = ctid; i < 16 * 16; i += CTHR) {
-            *reinterpret_cast<uint4*>(lds + ROW_Z * RB + i * 16) = make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(lds + PSTR + ROW_Z * RB + i * 16) = make_uint4(0, 0, 0, 0);
-        }
-        write_bias(0);
-        if (HEADS)
-            for (int i = ctid; i < 6 * C; i += CTHR) reinterpret_cast<float*>(lds + HW_OFF)[i] = hd.w[i];
-        int pp = -1, pb = 0, ps = 0;                    // the previous step (pair, block, slot); pp < 0: none
-        for (int p = 0; p < pairs; ++p)
-            for (int b = 0; b < NB; ++b)
-                for (int s = 0; s < 2; ++s) {
-                    __syncthreads();                                    // A: X[s] holds this step's input
-                    // what X[1 - s] needs next: the first board of slot B (very first step), or the next pair's board once the
-                    // previous step was the chain's last block for it -- HBM -> registers now (lands under K loop 1)
-                    const int so = 1 - s;
-                    bool fill = false;
-                    if (pp < 0) { fill = true; load(board_of(0, 1, real)); }
-                    else if (pb == NB - 1) {
-                        const int pn = pp + 1;                           // slot `so` (= ps) gets the next pair's board
-                        if (pn < pairs) { fill = true; load(board_of(pn, so, real)); }
-                    }
-                    __syncthreads();                                    // B: the previous step's result is staged in X[so]
-                    if (pp >= 0) {
-                        const int k_out = __builtin_amdgcn_readfirstlane(pack_ints(ch.w2[pb])[3]);
-                        int board = -1;
-                        if (pb == NB - 1) {                              // the chain's exit: to HBM as well
-                            bool was_real;
-                            board = board_of(pp, so, was_real);
-                            if (!was_real) board = -1;
-                        }
-                        if (HEADS && pb == NB - 1) heads_exit(so, board);
-                        else convert(so, k_out, board);
-                    }
-                    if (fill) write_x(so);
-                    if (s == 1) write_bias(b + 1 < NB ? b + 1 : 0);     // the next block's bias (its buffer is read no more)
-                    pp = p; pb = b; ps = s;
-                }
-        (void)ps;
-        __syncthreads();                                                // E1: the last step's result is staged in X[B]
-        {
-            const int k_out = __builtin_amdgcn_readfirstlane(pack_ints(ch.w2[NB - 1])[3]);
-            bool was_real;
-            const int board = board_of(pairs - 1, 1, was_real);
-            if (HEADS) heads_exit(1, was_real ? board : -1);
-            else convert(1, k_out, was_real ? board : -1);
-        }
-        return;
-    }
-
-    // ---- matrix waves ----
-    const int kb = lane >> 5, ln = lane & 31;
-    f32x16 acc[NT], prev[NT];
-    tw::Shadow shd{lds, prev, wave, kb, ln, 0};
-    bool have_prev = false;
-    int prev_slot = 0;
-    unsigned char* Y = lds + ROW_Y * RB;
-    for (int p = 0; p < pairs; ++p)
-        for (int b = 0; b < NB; ++b) {
-            const c8k::Filter flt1 = c8k::make_filter(ch.w1[b], wave, lane), flt2 = c8k::make_filter(ch.w2[b], wave, lane);
-            const int k_x = __builtin_amdgcn_readfirstlane(pack_ints(ch.w1[b])[2]);
-            const int k_y = __builtin_amdgcn_readfirstlane(pack_ints(ch.w2[b])[2]);
-            const float* bias1 = reinterpret_cast<const float*>(lds + BIAS_OFF) + (b & 1) * 2 * C;
-            const float* bias2 = bias1 + C;
-            for (int s = 0; s < 2; ++s) {
-                unsigned char* X = lds + row_of(s) * RB;
-                __syncthreads();                                       // A
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 bv = *reinterpret_cast<const float4*>(bias1 + wave * 32 + g * 8 + kb * 4);
-#pragma unroll
-                    for (int q = 0; q < NT; ++q) {
-                        acc[q][g * 4 + 0] = bv.x; acc[q][g * 4 + 1] = bv.y; acc[q][g * 4 + 2] = bv.z; acc[q][g * 4 + 3] = bv.w;
-                    }
-                }
-                shd.base = row_of(prev_slot) * RB;
-                __builtin_amdgcn_s_setprio(3);
-                if (have_prev) c8k::kloop<NT, tw::Shadow&, 0, false, 128, 1>(lds, c8k::Image{row_of(s), ROW_Z, PSTR}, flt1, lane, acc, 127 + k_x - cf8::X_LO_SHIFT, 127 + k_x, shd);
-                else c8k::kloop<NT, c8k::NoShadow, 0, false, 128, 1>(lds, c8k::Image{row_of(s), ROW_Z, PSTR}, flt1, lane, acc, 127 + k_x - cf8::X_LO_SHIFT, 127 + k_x);
-                __builtin_amdgcn_s_setprio(0);
-                int ln2 = ln, kb2 = kb;
-                asm volatile("" : "+v"(ln2), "+v"(kb2));
-                // epilogue 1 (k_resblock_c8's c6 path): relu(acc) -> the operand triple -> Y; accumulators restart at b2 + skip
-                {
-                    const float s_hi = __builtin_ldexpf(1.0f, k_y), s_lo = __builtin_ldexpf(1.0f, k_y - cf8::X_LO_SHIFT);
-                    const float s_skip = __builtin_ldexpf(1.0f, k_x - cf8::X_LO_SHIFT);
-                    f32x16 lo[NT];
-#pragma unroll
-                    for (int q3 = 0; q3 < NT; ++q3) {
-                        const int q = q3 * 32 + ln2;
-                        const int row = q < 90 ? q : 89;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int c = wave * 32 + g * 8 + kb2 * 4;
-                            const int off = row * RB + (((c >> 3) ^ (row & 15)) << 4) + (c & 7) * 2;
-                            Quad<_Float16> hq;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float r = acc[q3][g * 4 + i] > 0.0f ? acc[q3][g * 4 + i] : 0.0f;
-                                hq.e[i] = (_Float16)r;
-                                acc[q3][g * 4 + i] = r;
-                                lo[q3][g * 4 + i] = r - (float)hq.e[i];
-                            }
-                            if (q < 90) *reinterpret_cast<Quad<_Float16>*>(Y + off) = hq;
-                        }
-                    }
-#pragma unroll
-                    for (int pq = 0; pq < 2; ++pq) {               // pair (0, 1), then tile 2 with itself
-                        const int pa = pq == 0 ? 0 : 2, pb2 = pq == 0 ? 1 : 2;
-                        f32x16 av, bv, al, bl;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[pa][r]), __float_as_uint(acc[pb2][r]), false, false);
-                            const auto sl = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo[pa][r]), __float_as_uint(lo[pb2][r]), false, false);
-                            av[r] = __uint_as_float(sv[0]); bv[r] = __uint_as_float(sv[1]);
-                            al[r] = __uint_as_float(sl[0]); bl[r] = __uint_as_float(sl[1]);
-                        }
-                        const u32x6 pl = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(al, bl, s_lo);
-                        const u32x6 pv = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(av, bv, s_hi);
-                        const int q = pq == 0 ? kb2 * 32 + ln2 : 64 + ln2;
-                        if (pq == 0 || (kb2 == 0 && q < 90)) {
-                            unsigned char* P1 = Y + PSTR;
-                            *reinterpret_cast<uint4*>(P1 + c6_lds_off(q, c6_chunk(0, wave))) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-                            *reinterpret_cast<uint2*>(P1 + c6_lds_off(q, c6_chunk(0, wave) + 1)) = make_uint2(pl[4], pl[5]);
-                            *reinterpret_cast<uint4*>(P1 + c6_lds_off(q, c6_chunk(1, wave))) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
-                            *reinterpret_cast<uint2*>(P1 + c6_lds_off(q, c6_chunk(1, wave) + 1)) = make_uint2(pv[4], pv[5]);
-                        }
-                    }
-#pragma unroll
-                    for (int q3 = 0; q3 < NT; ++q3) {
-                        const int q = q3 * 32 + ln2;
-                        const int row = q < 90 ? q : 89;
-                        const uint4 hd4 = *reinterpret_cast<const uint4*>(X + PSTR + c6_lds_off(row, c6_chunk(0, wave)));
-                        const uint2 tl2 = *reinterpret_cast<const uint2*>(X + PSTR + c6_lds_off(row, c6_chunk(0, wave) + 1));
-                        const uint32_t wv[7] = {hd4.x, hd4.y, hd4.z, hd4.w, tl2.x, tl2.y, 0u};
-                        const uint32_t sh6 = (uint32_t)kb2 * 6u;
-                        u32x6 pc;
-#pragma unroll
-                        for (int w = 0; w < 6; ++w) pc[w] = __builtin_amdgcn_alignbit(wv[w + 1], wv[w], sh6);
-                        const f32x32 xl = __builtin_amdgcn_cvt_scalef32_pk32_f32_bf6(pc, s_skip);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int c = wave * 32 + g * 8 + kb2 * 4;
-                            const int off = row * RB + (((c >> 3) ^ (row & 15)) << 4) + (c & 7) * 2;
-                            const float4 bv4 = *reinterpret_cast<const float4*>(bias2 + c);
-                            float vv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
-                            const Quad<_Float16> xq = *reinterpret_cast<const Quad<_Float16>*>(X + off);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int r = g * 4 + i;
-                                vv[i] += (float)xq.e[i] + xl[2 * r];
-                            }
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) acc[q3][g * 4 + i] = vv[i];
-                        }
-                    }
-                }
-                __syncthreads();                                       // B: Y complete; the previous step's staging complete
-                __builtin_amdgcn_s_setprio(3);
-                c8k::kloop<NT, c8k::NoShadow, 0, false, 128, 1>(lds, c8k::Image{ROW_Y, ROW_Z, PSTR}, flt2, lane, acc, 127 + k_y - cf8::X_LO_SHIFT, 127 + k_y);
-                __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-                for (int q = 0; q < NT; ++q) prev[q] = acc[q];
-                have_prev = true;
-                prev_slot = s;
-            }
-        }
-    // the last step's second epilogue, not overlapped: into its own image (slot B), dead since that step's barrier B
-    shd.base = row_of(1) * RB;
-#pragma unroll
-    for (int q = 0; q < NT; ++q)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) shd.unit(prev[q], q * 32 + ln, g);
-    __syncthreads();                                                    // E1
-}
+// (kernel 2d, the chains of residual blocks in one launch -- k_tower, k_tower_pairs -- live in csrc/xq_tower.hip)
 
 // ---- kernel 2b: the residual block, software-pipelined over boards (128 filters, split operands) ------------------
 // Same arithmetic as k_resblock (bit-identical results), different schedule: the second epilogue of board t-1
@@ -3352,79 +2945,6 @@ extern "C" int cz_input_resblock_m(const void* planes_u8, const uint32_t* masks,
                            (_Float16*)y_hi, (_Float16*)y_lo, n_boards, n_dev, fa);
     if (hipGetLastError() != hipSuccess) {
         czi_set_error("cz_input_resblock: launch failed");
-        return CZ_ERR_HIP;
-    }
-    return CZ_OK;
-}
-
-// A chain of consecutive c6 residual blocks (128 filters) in one launch: k_tower_c6.  Host arrays of n_blocks DEVICE pointers.
-extern "C" int cz_tower_c6(const void* x_hi, const void* x_c6, int n_blocks, const void* const* w1_packed,
-                           const float* const* bias1, const void* const* w2_packed, const float* const* bias2, void* y_hi,
-                           void* y_c6, int n_boards, const int32_t* n_dev, void* stream)
-{
-    if (n_boards < 0 || !x_hi || !x_c6 || !y_hi || !y_c6 || !w1_packed || !w2_packed || !bias1 || !bias2 || n_blocks < 2 ||
-        n_blocks > tw::MAX_BLOCKS) {
-        czi_set_error("cz_tower_c6: bad argument (2 .. 8 blocks, c6 operand pairs in and out)");
-        return CZ_ERR_ARG;
-    }
-    tw::Chain ch{};
-    ch.n = n_blocks;
-    for (int b = 0; b < n_blocks; ++b) {
-        if (!w1_packed[b] || !w2_packed[b] || !bias1[b] || !bias2[b]) {
-            czi_set_error("cz_tower_c6: null block parameter");
-            return CZ_ERR_ARG;
-        }
-        ch.w1[b] = w1_packed[b]; ch.w2[b] = w2_packed[b]; ch.b1[b] = bias1[b]; ch.b2[b] = bias2[b];
-    }
-    if (n_boards == 0) return CZ_OK;
-    const int n_cu = device_cu_count();
-    if (n_cu < 0) {
-        czi_set_error("cz_tower_c6: cannot query the device");
-        return CZ_ERR_HIP;
-    }
-    const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
-    hipLaunchKernelGGL(k_tower_c6<false>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const _Float16*)x_hi,
-                       (const unsigned char*)x_c6, ch, (_Float16*)y_hi, (unsigned char*)y_c6, n_boards, n_dev, HeadArgs{});
-    if (hipGetLastError() != hipSuccess) {
-        czi_set_error("cz_tower_c6: launch failed");
-        return CZ_ERR_HIP;
-    }
-    return CZ_OK;
-}
-
-// ... with the tower's LAST block as the chain's last block: the fused head convolutions as the exit (cz_resblock_heads' outputs)
-extern "C" int cz_tower_c6_heads(const void* x_hi, const void* x_c6, int n_blocks, const void* const* w1_packed,
-                                 const float* const* bias1, const void* const* w2_packed, const float* const* bias2,
-                                 const float* head_w, const float* head_b, float* policy_feat, float* value_feat, int n_boards,
-                                 int n_policy, int n_value, const int32_t* n_dev, void* stream)
-{
-    if (n_boards < 0 || !x_hi || !x_c6 || !w1_packed || !w2_packed || !bias1 || !bias2 || n_blocks < 2 ||
-        n_blocks > tw::MAX_BLOCKS || !head_w || !head_b || !policy_feat || !value_feat || n_policy < 1 || n_value < 1 ||
-        n_policy + n_value != 6) {
-        czi_set_error("cz_tower_c6_heads: bad argument (2 .. 8 blocks, c6 operand pair in, n_policy + n_value == 6)");
-        return CZ_ERR_ARG;
-    }
-    tw::Chain ch{};
-    ch.n = n_blocks;
-    for (int b = 0; b < n_blocks; ++b) {
-        if (!w1_packed[b] || !w2_packed[b] || !bias1[b] || !bias2[b]) {
-            czi_set_error("cz_tower_c6_heads: null block parameter");
-            return CZ_ERR_ARG;
-        }
-        ch.w1[b] = w1_packed[b]; ch.w2[b] = w2_packed[b]; ch.b1[b] = bias1[b]; ch.b2[b] = bias2[b];
-    }
-    if (n_boards == 0) return CZ_OK;
-    const int n_cu = device_cu_count();
-    if (n_cu < 0) {
-        czi_set_error("cz_tower_c6_heads: cannot query the device");
-        return CZ_ERR_HIP;
-    }
-    const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
-    hipLaunchKernelGGL(k_tower_c6<true>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const _Float16*)x_hi,
-                       (const unsigned char*)x_c6, ch, (_Float16*)nullptr, (unsigned char*)nullptr, n_boards, n_dev,
-                       HeadArgs{head_w, head_b, policy_feat, value_feat, n_policy});
-    if (hipGetLastError() != hipSuccess) {
-        czi_set_error("cz_tower_c6_heads: launch failed");
         return CZ_ERR_HIP;
     }
     return CZ_OK;

@@ -151,6 +151,7 @@ template <typename E>
 struct PipeShadow {                 // epilogue 2 of the previous board, one (tile, channel group) unit at a time
     unsigned char* lds;
     int prev_row_base;              // first absolute row of the previous board's X image
+    int bias2_off = pipe::BIAS_OFF + 128 * 4;      // byte offset of the second convolution's bias vector (float[128])
     int wave, kb, ln;
     Quad<E> sh, sl;
     float4 bv;
@@ -164,7 +165,7 @@ struct PipeShadow {                 // epilogue 2 of the previous board, one (ti
         // being predicated: no exec-mask branches inside the MFMA loop
         off = q < 90 ? (prev_row_base + q) * pipe::RB + (((ch >> 3) ^ (q & 15)) << 4) + (ch & 7) * 2
                      : 270 * pipe::RB + (kb * 32 + ln) * 8;
-        bv = *reinterpret_cast<const float4*>(lds + pipe::BIAS_OFF + (128 + ch) * 4);
+        bv = *reinterpret_cast<const float4*>(lds + bias2_off + ch * 4);
         sh = *reinterpret_cast<const Quad<E>*>(lds + off);
         sl = *reinterpret_cast<const Quad<E>*>(lds + pipe::PSTR + off);
     }

@@ -373,6 +373,31 @@ int cz_tower_c6_heads(const void* x_hi, const void* x_c6, int n_blocks, const vo
                       const void* const* w2_packed, const float* const* bias2, const float* head_w, const float* head_b,
                       float* policy_feat, float* value_feat, int n_boards, int n_policy, int n_value, const int32_t* n_dev,
                       void* stream);
+/* (round 6) The chain for EVERY tower arithmetic.  A chain block's two images (the one its first convolution reads = the one the
+ * block before wrote, and its intermediate image) each have a format: */
+#define CZ_IMG_C8 0      /* f16 + e4m3 corrections (cz_conv3x3_c8_pack_weights filters read it) */
+#define CZ_IMG_C6 1      /* f16 + bf6 pieces with an exponent (cz_conv3x3_c6_pack_weights) */
+#define CZ_IMG_PAIR 2    /* (hi, lo) fp16 / bf16 pair (cz_conv3x3_pack_weights, parts = 2) */
+#define CZ_EXIT_HEADS 3  /* exit only: the 1 x 1 head convolutions instead of an image */
+/* cz_tower: n_blocks (1 .. 8) consecutive residual blocks on the c8 OR the c6 arithmetic in ONE launch (k_tower) -- bit-identical
+ * to n_blocks calls of cz_resblock with the matching dtype.  fmt_x[b] / fmt_y[b] (HOST int arrays; NULL = all CZ_IMG_C6): the
+ * format of the image block b's first / second filter reads -- one format per chain (all CZ_IMG_C8 or all CZ_IMG_C6; a hybrid
+ * tower is one chain per arithmetic).  exit_fmt: what the last block's result becomes -- CZ_IMG_C6 / CZ_IMG_C8: that operand
+ * pair in (y_hi, y_img) (a c6 chain whose last block carries y_exp = 127 ends on CZ_IMG_C8: the hand-over of a "c6>N" tower);
+ * CZ_IMG_PAIR (c8 chains): (hi, lo) fp16 pairs, y_img = the lo array [n][90][128] f16: the hand-over of a "c8>N" tower to its
+ * f16x3 blocks (cz_resblock's y_f32 + cz_split_bias_act in one); CZ_EXIT_HEADS: the head features (cz_resblock_heads'
+ * outputs; y_hi / y_img unused).  Replaces agent/model.py:41-43 for those blocks. */
+int cz_tower(const void* x_hi, const void* x_img, int n_blocks, const void* const* w1_packed, const float* const* bias1,
+             const void* const* w2_packed, const float* const* bias2, const int* fmt_x, const int* fmt_y, int exit_fmt,
+             void* y_hi, void* y_img, const float* head_w, const float* head_b, float* policy_feat, float* value_feat,
+             int n_policy, int n_value, int n_boards, const int32_t* n_dev, void* stream);
+/* cz_tower_pairs: the same for (hi, lo) pair blocks (f16x3 / bf16x3 arithmetic, dtype CZ_F16 / CZ_BF16; k_tower_pairs):
+ * bit-identical to n_blocks calls of cz_resblock(parts = 2).  head_w != NULL: the chain ends on the tower's last block and
+ * writes the head features (from hi + lo of the block's result) instead of (y_hi, y_lo). */
+int cz_tower_pairs(const void* x_hi, const void* x_lo, int n_blocks, const void* const* w1_packed, const float* const* bias1,
+                   const void* const* w2_packed, const float* const* bias2, void* y_hi, void* y_lo, const float* head_w,
+                   const float* head_b, float* policy_feat, float* value_feat, int n_policy, int n_value, int n_boards,
+                   int dtype, const int32_t* n_dev, void* stream);
 int cz_resblock_heads_q(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1,
                         const void* w2_packed, const float* bias2, const float* head_w, const float* head_b,
                         float* policy_feat, float* value_feat, int n_boards, int channels, int dtype, int n_policy,

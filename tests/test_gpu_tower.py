@@ -1,0 +1,158 @@
+"""-m gpu: the residual tower as CHAINS of blocks for every arithmetic (round 6: cz_tower, cz_tower_pairs; csrc/xq_tower.hip).
+
+Reference: CChessModel.build's loop `for _ in range(res_layer_num): x = self._build_residual_block(x)` (agent/model.py:41-43,
+blocks :68-83).  One launch per block makes every block read its input from HBM and write its output back; a chain keeps a pair
+of boards in LDS through all its blocks.  What a chain must be: the SAME arithmetic in the same order as the one-block kernels
+-- so the network's outputs are compared for EQUALITY with the block-by-block launches (CZ_TOWER_CHAIN=0 / chain_blocks False),
+for every arithmetic the load-time guard can choose: c6, c6>N (c6 blocks, a hand-over, c8 blocks -- one launch), c8, c8>N (c8
+blocks whose exit writes fp16 pairs, then the f16x3 blocks), f16x3, bf16x3; batch sizes that give the workgroups one board (the
+odd-count path: the board runs in both slots), two, three and many; the compact queue.  Where the head convolutions are the last
+chain's exit the head sums associate differently (four 32-channel partial sums per pixel): float32 rounding, bounded here."""
+import pytest
+
+from test_gpu_guard import peaked_net
+
+pytestmark = pytest.mark.gpu
+
+ARITHS = ["c6", "c6>5", "c6>2", "c6>1", "c8", "c8>3", "c8>2", "c8>5", "f16x3", "bf16x3"]
+
+
+def _net(arith, blocks):
+    import torch
+    from cchess_alphazero.agent.model import calibration_planes, guarded_inference_net
+    net = peaked_net(20.0, blocks=blocks)
+    planes_all = calibration_planes(1100, 14, seed=23)
+    g = guarded_inference_net(net, torch.float32, trunk="mfma", arith=arith, guard=False, planes=planes_all[:256])
+    assert g.arith_name == arith, (g.arith_name, arith)
+    return g, planes_all
+
+
+def _launches(g, planes, **kw):
+    g.block_events = []
+    out = tuple(t.clone() for t in g(planes, **kw))
+    launches = [e[2] if len(e) > 2 else 1 for e in g.block_events]
+    g.block_events = None
+    return out, launches
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+def test_chained_tower_is_bit_identical_to_block_by_block(arith):
+    import torch
+    from cchess_alphazero.agent.model import tower_plan
+    blocks = 7
+    g, planes_all = _net(arith, blocks)
+    g.chain_heads = False                     # (the chains proper: the heads-as-exit variants reorder the head sums, tested below)
+    want = [len(st[1]) if st[0] in ("tower", "pairs") else 1 for st in tower_plan(g.block_kinds(), chain_heads=False)]
+    for n in (1, 37, 256, 300, 700, 1100):
+        planes = planes_all[:n].contiguous()
+        g.chain_blocks = False
+        (p0, v0), l0 = _launches(g, planes)
+        assert l0 == [1] * blocks, l0
+        g.chain_blocks = True
+        (p1, v1), l1 = _launches(g, planes)
+        assert l1 == want, (l1, want)
+        assert torch.isfinite(p1).all() and torch.isfinite(v1).all()
+        assert torch.equal(p0, p1) and torch.equal(v0, v1), (arith, n, (p0 - p1).abs().max().item(), (v0 - v1).abs().max().item())
+    # compact queue: rows / count on the device
+    planes = planes_all[:900].contiguous()
+    rows = torch.randperm(900, device="cuda")[:640].int()
+    count = torch.tensor([517], dtype=torch.int32, device="cuda")
+    g.chain_blocks = False
+    p0, v0 = (t.clone() for t in g(planes, rows=rows, count=count))
+    g.chain_blocks = True
+    p1, v1 = g(planes, rows=rows, count=count)
+    assert torch.equal(p0[:517], p1[:517]) and torch.equal(v0[:517], v1[:517])
+
+
+@pytest.mark.parametrize("arith,blocks", [("c8", 4), ("c8>2", 4), ("c6>2", 4), ("f16x3", 3), ("c8>2", 3), ("c6", 2), ("f16x3", 2)])
+def test_short_towers_chain_too(arith, blocks):
+    """Chains of one and two blocks, hand-overs right behind the first block, a chain that is only the last block."""
+    import torch
+    g, planes_all = _net(arith, blocks)
+    for heads_in_chain in (False, True):
+        g.chain_heads = heads_in_chain
+        for n in (1, 3, 300, 513):
+            planes = planes_all[:n].contiguous()
+            g.chain_blocks = False
+            p0, v0 = (t.clone() for t in g(planes))
+            g.chain_blocks = True
+            p1, v1 = g(planes)
+            if heads_in_chain:
+                assert (p0 - p1).abs().max().item() < 5e-6 and (v0 - v1).abs().max().item() < 3e-5, (arith, blocks, n)
+            else:
+                assert torch.equal(p0, p1) and torch.equal(v0, v1), (arith, blocks, n)
+
+
+@pytest.mark.parametrize("arith", ["c6>5", "c8", "c8>3", "f16x3"])
+def test_heads_as_the_last_chains_exit(arith):
+    """The default: the tower's last block is inside the last chain and the 1 x 1 head convolutions are its exit pass.  The head
+    dot products are summed over four 32-channel partial sums per pixel (the one-block HEADS kernels: sixteen 8-channel ones);
+    the pair chains take the block's value as hi + lo of its operand pair (k_resblock<HEADS> keeps the fp32 value: an fp16 pair
+    stands for it to 2^-22; bf16 pairs, 2^-17, keep their HEADS launch -- last test).  Everything else is identical: policy /
+    value agree to float32 rounding."""
+    import torch
+    from cchess_alphazero.agent.model import tower_plan
+    g, planes_all = _net(arith, 7)
+    want = [len(st[1]) if st[0] in ("tower", "pairs") else 1 for st in tower_plan(g.block_kinds())]
+    for n in (1, 37, 300, 700):
+        planes = planes_all[:n].contiguous()
+        g.chain_heads = False
+        p0, v0 = (t.clone() for t in g(planes))
+        g.chain_heads = True
+        (p1, v1), l1 = _launches(g, planes)
+        assert l1 == want and sum(l1) == 7, (l1, want)
+        assert torch.isfinite(p1).all() and (p0 - p1).abs().max().item() < 5e-6 and (v0 - v1).abs().max().item() < 3e-5, \
+            (arith, n, (p0 - p1).abs().max().item(), (v0 - v1).abs().max().item())
+
+
+def test_the_guards_choice_for_a_peaked_policy_runs_as_three_launches():
+    """What VERDICT r05 item 1 asks for: the arithmetic the load-time guard gives a peaked-policy network (c8>N: c8 blocks, then
+    f16x3 blocks) as FIRST | the c8 blocks, exit = fp16 pairs | the f16x3 blocks with the heads -- with the guard untouched and
+    the outputs within north_star's tolerance of the float64 network."""
+    import torch
+    from cchess_alphazero.agent.model import (GUARD_TOL, LOGIT_TOL, calibration_planes, guarded_inference_net,
+                                              measure_against_reference, reference_forward_f64, within_guard)
+    assert GUARD_TOL == 5e-5 and LOGIT_TOL == 2e-4
+    from cchess_alphazero.agent.model import CChessNet
+    torch.manual_seed(0)                                         # bench.py's stand-in for a trained network (sharpened_copy): the
+    net = CChessNet(cnn_filter_num=128, res_layer_num=7).eval()  # benchmark's random-init weights, policy layer x 240 (max p 0.86)
+    net.policy_out.weight.data.mul_(240.0)
+    g = guarded_inference_net(net, torch.float32, trunk="mfma", arith="c6")
+    name = g.arith_effective
+    assert name.startswith("c8>"), (name, g.calibration["candidates"])
+    planes = calibration_planes(512, 14, seed=77)
+    (p, v), launches = _launches(g, planes)
+    n8 = int(name[3:])
+    assert launches == [1, n8 - 1, 7 - n8], (name, launches)
+    m = measure_against_reference(g, reference_forward_f64(net, planes), planes)
+    assert within_guard(m, tol=1e-4, logit_tol=LOGIT_TOL * 1.5), m           # (fresh positions, not the calibration set)
+
+
+def test_bf16_pairs_keep_their_heads_launch():
+    import torch
+    g, planes_all = _net("bf16x3", 7)
+    (p, v), launches = _launches(g, planes_all[:300].contiguous())
+    assert launches == [1, 5, 1], launches                        # FIRST | the pair chain | HEADS (fp32 value)
+    g.chain_blocks = False
+    p0, v0 = g(planes_all[:300].contiguous())
+    assert torch.equal(p0, p) and torch.equal(v0, v)
+
+
+def test_tower_entry_points_reject_what_they_cannot_run():
+    import torch
+    from cchess_alphazero import _native
+    g, planes_all = _net("c8", 3)
+    x = (torch.zeros((4, 90, 128), dtype=torch.float16, device="cuda"), torch.zeros((4, 90, 256), dtype=torch.uint8, device="cuda"))
+    blk = [g._block_params(1)]
+    with pytest.raises(_native.NativeError):
+        _native.tower(x, blk * 9, _native.IMG_C8, out=x, fmt_x=[0] * 9, fmt_y=[0] * 9)      # more than 8 blocks
+    with pytest.raises(_native.NativeError):
+        _native.tower(x, blk, _native.IMG_C8, out=x, fmt_x=[2], fmt_y=[0])                   # pair blocks belong to cz_tower_pairs
+    with pytest.raises(_native.NativeError):
+        _native.tower(x, blk * 2, _native.IMG_C8, out=x, fmt_x=[1, 0], fmt_y=[1, 0])         # one arithmetic per launch
+    with pytest.raises(_native.NativeError):
+        _native.tower(x, blk, _native.IMG_C6, out=x, fmt_x=[0], fmt_y=[0])                   # a c8 chain cannot write a c6 image
+    with pytest.raises(_native.NativeError):
+        _native.tower(x, blk, 7, out=x, fmt_x=[0], fmt_y=[0])                                # no such exit
+    with pytest.raises(_native.NativeError):
+        _native.tower(x, blk, _native.EXIT_HEADS, heads=(g.head_w32[:5], g.head_b32, 4, x[0], x[0]), fmt_x=[0], fmt_y=[0])

@@ -557,23 +557,50 @@ def test_occupancy_boards_stand_for_the_planes():
     assert torch.equal(m28 & 0x3FFF, masks) and torch.equal(m28 >> 14, masks.flip(0))
 
 
-def test_chain_plan_and_block_events():
-    """agent/model.py: which blocks of a c6 tower run as one cz_tower_c6 launch, and how bench.py spreads a chained launch's time
-    over its blocks (host logic only)."""
-    from cchess_alphazero.agent.model import chain_plan, events_ms
-    assert chain_plan(7, 7) == (range(1, 7), True)                  # the benchmark tower: FIRST | blocks 1 .. 6 with the heads as exit
-    assert chain_plan(7, 7, heads_exit=False) == (range(1, 6), False)      # ... FIRST | 1 .. 5 | HEADS
-    assert chain_plan(7, 5) == (range(1, 4), False)                 # c6>5: block 4 hands a c8 image over, 5 and 6 are c8 blocks
-    assert chain_plan(7, 3)[0] == range(0) and chain_plan(7, 4) == (range(1, 3), False)
-    assert chain_plan(3, 3) == (range(1, 3), True) and chain_plan(3, 3, heads_exit=False)[0] == range(0)
-    assert chain_plan(2, 2)[0] == range(0)                          # FIRST | HEADS: nothing to chain
-    assert chain_plan(4, 4, heads_exit=False) == (range(1, 3), False)
-    assert chain_plan(12, 12) == (range(1, 9), False)               # at most 8 blocks per launch; the rest one per launch
-    assert chain_plan(7, 7, chain_blocks=False) == (range(0), False)
+def test_tower_plan_and_block_events():
+    """agent/model.py: which launches a fused 128-filter tower runs as (round 6: every arithmetic chains), and how bench.py
+    spreads a chained launch's time over its blocks (host logic only)."""
+    from cchess_alphazero.agent.model import events_ms, tower_plan
+    c6, c8, pr = "c6", "c8", "pair"
+    # the benchmark tower: FIRST | blocks 1 .. 6 with the heads as the chain's exit
+    assert tower_plan([c6] * 7) == [("first", 0), ("tower", [1, 2, 3, 4, 5, 6], "heads")]
+    assert tower_plan([c6] * 7, chain_heads=False) == [("first", 0), ("tower", [1, 2, 3, 4, 5], "c6"), ("block", 6)]
+    assert tower_plan([c6] * 7, heads_exit=False) == tower_plan([c6] * 7, chain_heads=False)
+    # c6>5: one chain per arithmetic -- the c6 chain's exit writes the c8 image (the last c6 block hands over)
+    assert tower_plan([c6] * 5 + [c8] * 2) == [("first", 0), ("tower", [1, 2, 3, 4], "c8"), ("tower", [5, 6], "heads")]
+    assert tower_plan([c6] * 5 + [c8] * 2, chain_heads=False)[1:] == [("tower", [1, 2, 3, 4], "c8"), ("tower", [5], "c8"), ("block", 6)]
+    assert tower_plan([c6] + [c8] * 6) == [("first", 0), ("tower", [1, 2, 3, 4, 5, 6], "heads")]
+    # c8>3 (what the guard gives a peaked policy): FIRST | c8 blocks, exit = fp16 pairs | the f16x3 blocks with the heads
+    assert tower_plan([c8] * 3 + [pr] * 4) == [("first", 0), ("tower", [1, 2], "pair"), ("pairs", [3, 4, 5, 6], True)]
+    assert tower_plan([c8] * 3 + [pr] * 4, chain_heads=False) == [("first", 0), ("tower", [1, 2], "pair"),
+                                                                   ("pairs", [3, 4, 5], False), ("block", 6)]
+    assert tower_plan([pr] * 7) == [("first", 0), ("pairs", [1, 2, 3, 4, 5, 6], True)]
+    assert tower_plan([c8] * 6 + [pr]) == [("first", 0), ("tower", [1, 2, 3, 4, 5], "pair"), ("pairs", [6], True)]
+    assert tower_plan([c6] * 2) == [("first", 0), ("tower", [1], "heads")]
+    assert tower_plan([c6] * 2, chain_heads=False) == [("first", 0), ("block", 1)]
+    # at most 8 blocks per launch
+    assert tower_plan([c6] * 12) == [("first", 0), ("tower", list(range(1, 9)), "c6"), ("tower", [9, 10, 11], "heads")]
+    with pytest.raises(AssertionError):
+        tower_plan([c8] + [pr] * 3)                                 # (that tower is not a fused-input tower: model.py n8 != 1)
     for nblk in range(2, 13):
-        for c6 in range(1, nblk + 1):
-            r, h = chain_plan(nblk, c6)
-            assert len(r) == 0 or (r.start == 1 and 2 <= len(r) <= 8 and r.stop <= c6 and (r.stop == nblk) == h)
+        for a in range(0, nblk + 1):
+            for b in range(a, nblk + 1):
+                kinds = [c6] * a + [c8] * (b - a) + [pr] * (nblk - b)
+                if b == 1 and nblk > 1:
+                    continue
+                for hx in (True, False):
+                    steps = tower_plan(kinds, heads_exit=hx)
+                    covered = [0]
+                    for st in steps[1:]:
+                        covered += st[1] if st[0] != "block" else [st[1]]
+                        if st[0] == "tower":
+                            assert kinds[st[1][0]] != pr and len({kinds[i] for i in st[1]}) == 1 and len(st[1]) <= 8
+                            nxt = st[1][-1] + 1
+                            assert st[2] == ("heads" if nxt == nblk else kinds[nxt])
+                        if st[0] == "pairs":
+                            assert all(kinds[i] == pr for i in st[1]) and st[2] == (st[1][-1] + 1 == nblk)
+                    assert covered == list(range(nblk)), (kinds, steps)             # every block exactly once, in order
+                    assert (steps[-1][0] == "block") == (not hx)
 
     class Ev:
         def __init__(self, t): self.t = t
