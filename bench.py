@@ -103,6 +103,9 @@ def compact_line(out):
         wn = (cb.get("with_network_estimate") or {}).get("value")
         if wn is not None:
             c["cpu_baseline"]["with_network_estimate"] = _r(float(wn))
+        rp = cb.get("reference_python")
+        if rp:                                              # the UNMODIFIED reference (Python), timed where it exists (build container)
+            c["cpu_baseline"]["reference_python"] = rp
     else:
         c["cpu_baseline"] = None
     for k in ("value_sustained", "roofline_frac_sustained", "games_per_hour_steady_state", "net_arith_requested",
@@ -359,7 +362,7 @@ def cpu_baseline(cfg, seconds):
                       f"{seconds:.0f} s of self-play from INIT_STATE, {pc.simulation_num_per_move} sims/move, "
                       f"K={pc.search_threads}, hash-stub net (tree + rules only, no ResNet), one seed per process, "
                       f"new tree per game; value = sum over processes",
-            "reference_python_timing": reference_cpu_timing()}
+            "reference_python_timing": reference_cpu_timing(), "reference_python": reference_python_compact()}
 
 
 def cpu_network_rate(cfg, threads, seconds=3.0):
@@ -403,6 +406,25 @@ def reference_cpu_timing():
         if k in d:
             out[k] = d[k]
     return out
+
+
+def reference_python_compact():
+    """cpu_baseline.reference_python of the compact line: the unmodified reference's own figure -- value,
+    host, cores, K -- from the committed timing (profiles/r*_reference_cpu.json: SURVEY 8(d)'s protocol, stub network, the
+    reference's default search_threads), next to the C port's."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reference_cpu.json")))
+    d = _load_profile(files[-1]) if files else None
+    if not d:
+        return None
+    runs = [r for r in d.get("runs", []) if r.get("network") == "stub"]
+    if not runs:
+        return None
+    r = max(runs, key=lambda x: x.get("aggregate_expansions_per_s_median", 0.0))
+    return {"value": _r(float(r["aggregate_expansions_per_s_median"])), "unit": "expansions/s", "network": "stub",
+            "search_threads": r.get("search_threads"), "processes": r.get("processes"),
+            "cores": (d.get("host") or {}).get("cpus"), "host": str((d.get("host") or {}).get("model", ""))[:48],
+            "source": os.path.relpath(files[-1], ROOT)}
 
 
 def micro_suite(n=1 << 20, iters=10):
@@ -491,6 +513,49 @@ def pmc_nn(kernel):
     d = (_load_profile(files[-1]) or {}).get("kernels", {}).get(kernel, {})
     return {"hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "mfma_util": d.get("mfma_util"),
             "source": os.path.relpath(files[-1], ROOT)}
+
+
+def tower_launch_plan(net):
+    """What one forward of `net` launches for its residual tower (agent/model.py tower_plan, as executed): a list of
+    {step, kernel, blocks, kind, exit}; `kernel` is the key tools/summarize_profiles.py gives that launch's counters.  None when
+    the tower does not run as chains."""
+    plan = getattr(net, "last_plan", None)
+    if not plan or not getattr(net, "chain_blocks", False):
+        return None
+    kinds = net.block_kinds()
+    od = "bf16" if net.operand_dtype == torch.bfloat16 else "f16"
+    out = []
+    for st in plan:
+        if st[0] == "first":
+            k = kinds[0]
+            kern = {"c6": "k_resblock_c8<FIRST, C6>", "c8": "k_resblock_c8<FIRST>"}.get(k, f"k_resblock_pipe<{od}, FIRST>")
+            out.append({"step": "first", "kernel": kern, "blocks": 1, "kind": k, "exit": kinds[1] if len(kinds) > 1 else None})
+        elif st[0] == "tower":
+            k = kinds[st[1][0]]
+            out.append({"step": "tower", "kernel": f"k_tower<{'HEADS' if st[2] == 'heads' else 'image'}, {k}>",
+                        "blocks": len(st[1]), "kind": k, "exit": st[2]})
+        elif st[0] == "pairs":
+            out.append({"step": "pairs", "kernel": f"k_tower_pairs<{od}, {'HEADS' if st[2] else 'pairs'}>", "blocks": len(st[1]),
+                        "kind": "pair", "exit": "heads" if st[2] else "pair"})
+        else:
+            k = kinds[st[1]]
+            kern = {"c6": "k_resblock_c8<HEADS, C6>", "c8": "k_resblock_c8<HEADS>"}.get(k, "k_resblock")
+            out.append({"step": "block", "kernel": kern, "blocks": 1, "kind": k, "exit": "heads"})
+    return out
+
+
+def pmc_tower(arith):
+    """HBM bytes per forward of the tower's launches from the committed PMC passes (profiles/rNN_pmc_nn.json, tower_traffic),
+    only when that pass profiled the same tower arithmetic."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_nn.json")))
+    if not files:
+        return {}
+    t = ((_load_profile(files[-1]) or {}).get("tower_traffic") or {}).get("per_forward") or {}
+    if not t.get("measured_bytes") or t.get("tower_arithmetic") != arith:
+        return {}
+    return {"hbm_bytes_per_forward": t["measured_bytes"], "algorithmic_activation_bytes_per_forward": t["algorithmic_activation_bytes"],
+            "blocks": t["blocks"], "source": os.path.relpath(files[-1], ROOT)}
 
 
 def arith_label(name):
@@ -1090,48 +1155,36 @@ def main():
             rows_launch = exp_per_launch if eng.compact else slots
             flops_launch = 2 * 2.0 * 90 * f * f * 9 * rows_launch
             tfl = flops_launch / (b_ms * 1e-3) / 1e12
-            pmc = pmc_nn("k_resblock")
-            chained = bool(arith == "c6" and getattr(eng.net, "chain_blocks", False) and cfg.model.res_layer_num >= 4)
-            n_chain = 0
-            if chained:
-                # the inner blocks run as ONE k_tower_c6 launch (activations in LDS): its counters, per block of the tower
-                # (the committed PMC pass has one entry per kernel: the tower launch covers n_chain blocks)
-                pt = pmc_nn("k_tower_c6")
-                nb_ = cfg.model.res_layer_num
-                n_chain = nb_ - 1 if getattr(eng.net, "chain_heads", False) else nb_ - 2
-                if pt.get("hbm_bytes_per_launch") and pmc.get("hbm_bytes_per_launch"):
-                    pmc = {"hbm_bytes_per_launch": (pt["hbm_bytes_per_launch"] + (nb_ - n_chain) * pmc["hbm_bytes_per_launch"]) / nb_,
-                           "mfma_util": pt.get("mfma_util"), "source": pt.get("source")}
-            kdesc = ("k_resblock_c8 (csrc/xq_conv.hip, K loop csrc/xq_c8_kloop.h): one residual block (2 x conv3x3 + bias + skip + "
-                     "ReLU) of the tower per launch; every product = one fp16 MFMA term + two block-scaled fp8 (e4m3, K = 64) "
-                     "correction terms, fp32 accumulate; the first launch also computes the 5x5 input layer (fp32 gather by its "
-                     "copy waves), the last one the fused head convolutions; mean over all launches of the tower"
-                     if arith == "c8" else
-                     "k_resblock_c8<.., C6> (csrc/xq_conv.hip, K loop csrc/xq_c8_kloop.h FMT = 1): one residual block (2 x conv3x3 + "
-                     "bias + skip + ReLU) of the tower per launch; every product = one fp16 MFMA term + two block-scaled bf6 (e3m2, "
-                     "K = 64, 32 cycles) correction terms, fp32 accumulate; the first launch also computes the 5x5 input layer (fp32 "
-                     "gather by its copy waves; its first convolution reads that c8 image), the last one the fused head "
-                     "convolutions; mean over all launches of the tower"
-                     if arith == "c6" else
-                     "k_resblock_pipe / k_resblock (csrc/xq_conv.hip): one residual block (2 x conv3x3 + "
-                     "bias + skip + ReLU) of the tower per launch, split-bf16 operands; the first "
-                     "launch also computes the 5x5 input layer (fp32 gather by its copy waves), the "
-                     "inner blocks run the software-pipelined schedule, the last one (fused head "
-                     "convolutions) the plain one; mean over all launches of the tower")
-            kshort = {"c8": "k_resblock_c8 (one residual block per launch)", "c6": "k_resblock_c8<C6> (one residual block per launch)"}.get(
-                arith, "k_resblock_pipe (one residual block per launch)")
-            if arith and (arith.startswith("c8>") or arith.startswith("c6>")):
-                kshort = f"k_resblock_c8 / k_resblock_pipe ({arith}, one residual block per launch)"
-            if chained:
-                kshort = (f"k_tower_c6 ({n_chain} chained blocks) + k_resblock_c8<C6> x{cfg.model.res_layer_num - n_chain}; "
-                          "per block")
-                kdesc = ("k_tower_c6 (csrc/xq_conv.hip, K loop csrc/xq_c8_kloop.h FMT = 1): the tower's inner residual blocks (2 x conv3x3 "
-                         "+ bias + skip + ReLU each) in ONE launch, activations staying in LDS between them (a workgroup takes a pair "
-                         "of boards through the chain); every product = one fp16 MFMA term + two block-scaled bf6 correction terms, "
-                         "fp32 accumulate; the first block (fused 5x5 input layer) is a k_resblock_c8<FIRST, C6> launch, the last "
-                         "block is the chain's last with the head convolutions as its exit pass (CZ_TOWER_HEADS=0: a "
-                         "k_resblock_c8<HEADS, C6> launch); all times per BLOCK of the tower (the chained launch spread over "
-                         "its blocks), mean over the tower")
+            lplan = tower_launch_plan(eng.net)
+            nb_ = cfg.model.res_layer_num
+            pmc, pt = {}, pmc_tower(arith)
+            if pt:
+                # the committed PMC pass of this arithmetic: HBM bytes of a forward's tower launches, per block of the tower
+                pmc = {"hbm_bytes_per_launch": pt["hbm_bytes_per_forward"] / pt["blocks"], "source": pt["source"],
+                       "algorithmic_activation_bytes_per_block": pt["algorithmic_activation_bytes_per_forward"] / pt["blocks"]}
+                mu = [pmc_nn(st["kernel"]).get("mfma_util") for st in (lplan or []) if st["step"] in ("tower", "pairs")]
+                pmc["mfma_util"] = next((m for m in mu if m), None)
+            arith_text = {"c6": "one fp16 MFMA term + two block-scaled bf6 (e3m2, K = 64, 32 cycles) correction terms",
+                          "c8": "one fp16 MFMA term + two block-scaled fp8 (e4m3, K = 64) correction terms",
+                          "pair": "three fp16 / bf16 MFMAs on (hi, lo) operand pairs"}
+            if lplan:
+                kshort = " + ".join(f"{st['kernel']}" + (f" x{st['blocks']} blocks" if st["blocks"] > 1 else "") for st in lplan) + "; per block"
+                kinds_used = []
+                for st in lplan:
+                    if st["kind"] not in kinds_used:
+                        kinds_used.append(st["kind"])
+                kdesc = ("the residual tower (2 x conv3x3 + bias + skip + ReLU per block) as CHAINS of blocks (csrc/xq_tower.hip; K loops "
+                         "csrc/xq_c8_kloop.h / pipe_kloop): a workgroup takes a pair of boards through all blocks of a launch with the "
+                         "activations staying in LDS; launches of a forward: " + kshort + ".  The first launch (csrc/xq_conv.hip) also "
+                         "computes the 5x5 input layer (fp32 gather by its copy waves); 'HEADS' launches apply the 1x1 head convolutions "
+                         "as their exit.  Products: " + "; ".join(f"{k}: {arith_text[k]}" for k in kinds_used) + ", fp32 accumulate.  All "
+                         "times per BLOCK of the tower (a chained launch spread over its blocks), mean over the tower")
+            else:
+                kshort = {"c8": "k_resblock_c8 (one residual block per launch)", "c6": "k_resblock_c8<C6> (one residual block per launch)"}.get(
+                    arith, "k_resblock_pipe / k_resblock_ip (one residual block per launch)")
+                kdesc = ("one residual block (2 x conv3x3 + bias + skip + ReLU) of the tower per launch (csrc/xq_conv.hip); the first "
+                         "launch also computes the 5x5 input layer where the kernel exists for the shape, the last one the fused head "
+                         "convolutions; mean over all launches of the tower")
             out["roofline"] = {"kernel": kdesc, "kernel_short": kshort,
                                "bound": "mfma", "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s", "frac": tfl / 2500.0,
                                "traffic": pmc.get("hbm_bytes_per_launch"), "traffic_source": pmc.get("source"),
@@ -1140,7 +1193,8 @@ def main():
                                "launch_ms_by_block": [sum(blk[i::cfg.model.res_layer_num]) / max(1, len(blk[i::cfg.model.res_layer_num]))
                                                       for i in range(cfg.model.res_layer_num)],
                                "first_launch_ms": sum(blk[0::cfg.model.res_layer_num]) / max(1, len(blk[0::cfg.model.res_layer_num])),
-                               "algorithmic_flops_per_launch": flops_launch,
+                               "algorithmic_flops_per_launch": flops_launch, "launch_plan": lplan,
+                               "algorithmic_activation_bytes_per_block": pmc.get("algorithmic_activation_bytes_per_block"),
                                "tower_arithmetic": arith, "mfma_equivalents_per_product": mfma_equiv,
                                "issued_bf16_tflops": mfma_equiv * tfl * 96.0 / 90.0,
                                "issued_frac_of_peak": mfma_equiv * tfl * 96.0 / 90.0 / 2500.0,

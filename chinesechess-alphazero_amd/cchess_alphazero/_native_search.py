@@ -232,10 +232,15 @@ class Search:
         _native.check(self.L.cz_search_leaf_planes(self.h, int(bool(on))), "cz_search_leaf_planes")
         self.planes_off = not on
 
-    def queue_planes(self, n=None):
-        """The first n rows of the evaluation queue as a planes tensor (a copy), whatever the kernel writes: with the planes
-        switched off they are rebuilt from the occupancy boards (plane c at position pos = bit c of word pos;
-        state_to_planes, environment/static_env.py:137-156)."""
+    def queue_planes(self, n=None, rows=None):
+        """The first n rows of the evaluation queue -- or the queue slots `rows` (int64 device tensor, e.g. q_rows[:q_count]: the
+        slots that hold a leaf of the last round) -- as a planes tensor (a copy), whatever the kernel writes: with the planes
+        switched off they are rebuilt from the occupancy boards (plane c at position pos = bit c of word pos; state_to_planes,
+        environment/static_env.py:137-156)."""
+        if rows is not None:
+            if not self.planes_off:
+                return self.planes[rows].clone()
+            return masks_to_planes(self.masks[rows], self.in_planes, self.planes.dtype)
         n = self.slots if n is None else min(int(n), self.slots)
         if not self.planes_off:
             return self.planes[:n].clone()

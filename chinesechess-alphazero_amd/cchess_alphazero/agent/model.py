@@ -234,6 +234,7 @@ class InferenceNet(nn.Module):
         # PyTorch tail they replace (A/B runs)
         self.fused_tail = os.environ.get("CZ_FUSED_TAIL", "1") != "0"
         self.block_events = None            # bench.py: list collecting (start, end[, blocks]) HIP events around tower launches
+        self.last_plan = None               # tower_plan's steps of the last chained forward
         # consecutive blocks as one launch (cz_tower / cz_tower_pairs, tower_plan; CZ_TOWER_CHAIN=0: one launch per block)
         self.chain_blocks = os.environ.get("CZ_TOWER_CHAIN", "1") != "0"
         self.chain_heads = os.environ.get("CZ_TOWER_HEADS", "1") != "0"
@@ -502,6 +503,7 @@ class InferenceNet(nn.Module):
                 else:
                     plan.append(step)
             self._bufs[key] = plan
+        self.last_plan = [st[:3] if st[0] != "first" else st for st in self._bufs[key]]      # (bench.py: what a forward launches)
         img_tag = {"c6": torch.int8, "c8": torch.uint8}
 
         def view(t, kind):                      # an operand buffer seen as the pair of `kind`

@@ -140,23 +140,33 @@ class SelfPlayEngine:
 
     def audit_network(self, n=64):
         """Re-measure the running arithmetic on LIVE queue positions (the load-time calibration set is random
-        playouts; the positions a search actually asks about are more tactical).  Takes the first n planes of the evaluation
-        queue as the last round wrote them, evaluates the float64 reference and the running network on them and returns
-        measure_against_reference's figures + `ok` (within_guard: policy / value within GUARD_TOL, logits within LOGIT_TOL).
-        A failing audit is logged; the caller decides (worker/self_play.py reloads through the guard with these positions
-        added to the calibration set)."""
+        playouts; the positions a search actually asks about are more tactical).  Takes up to n of the positions the last round
+        asked about -- the compact queue's rows q_rows[:q_count]; slots that were never written (empty boards) are dropped --,
+        evaluates the float64 reference and the running network on them and returns measure_against_reference's figures + `ok`
+        (within_guard: policy / value within GUARD_TOL, logits within LOGIT_TOL) + `positions`.  A failing audit is logged; the
+        caller decides (worker/self_play.py asks for the next more exact arithmetic and rebuilds the network through the
+        load-time guard on its standard calibration set)."""
         from cchess_alphazero.agent.model import measure_against_reference, reference_forward_f64, within_guard
         if self.net is None or getattr(self, "_ref_net", None) is None:
             return None
-        planes = self.queue_planes(n)
+        rows = None
+        if getattr(self.search, "q_rows", None) is not None:
+            cnt = min(int(self.search.q_count.item()), int(n))
+            if cnt > 0:
+                rows = self.search.q_rows[:cnt].long()
+        planes = self.search.queue_planes(rows=rows) if rows is not None else self.queue_planes(n)
         if planes.dtype != torch.uint8:
             planes = (planes != 0).to(torch.uint8)
+        planes = planes[planes.flatten(1).any(1)].contiguous()          # (a slot no leaf was ever written to is an empty board)
+        if planes.shape[0] == 0:
+            return None
         m = measure_against_reference(self.net, reference_forward_f64(self._ref_net, planes), planes)
         m["ok"] = within_guard(m)
         m["arith"] = self.net_arith_effective
+        m["positions"] = int(planes.shape[0])
         if not m["ok"]:
             logger.warning("live-queue audit: arithmetic %s is outside the guard on %d live positions: %s",
-                           self.net_arith_effective, n, m)
+                           self.net_arith_effective, planes.shape[0], m)
         return m
 
     def demote_arith(self):

@@ -36,8 +36,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_LIB_PATH)
+        # XQ_ORACLE_LIB: another build of the same sources (oracle/Makefile `asan`: the sanitizer build the CPU tests run under)
+        path = os.environ.get("XQ_ORACLE_LIB")
+        if not path:
+            build()
+            path = _LIB_PATH
+        _lib = C.CDLL(path)
         _lib.xqo_init()
         _sig(_lib)
     return _lib

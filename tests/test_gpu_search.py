@@ -620,6 +620,35 @@ def test_golden_visit_counts_on_the_1k_suite(gpu, positions_1k):
     s.close()
 
 
+def test_special_positions_of_the_1k_suite_against_the_oracle(gpu, positions_1k):
+    """The hand-made positions of the suite (the entries behind its `n_random` real-play positions: bare kings, flying-king
+    captures, stalemated movers, ...) have NO reference visit-count record: the reference's search thread dies on a node whose
+    mover has no move at all and action() never returns (tests/golden/make_golden_mcts.py gen_mcts_1k).  They are searched here
+    anyway -- K = 1, 800 simulations, the 1k suite's stub network -- against the ORACLE (oracle/xq_mcts.c, pinned to the reference
+    by the 943 recorded searches of the real-play positions): visit counts, W bits, prior bits, edge for edge (VERDICT r05
+    weak 9)."""
+    data = _golden("mcts_1k.json")
+    with open(os.path.join(os.path.dirname(__file__), "golden", "positions_1k.json")) as f:
+        n_random = json.load(f)["n_random"]
+    idx = [i for i in range(n_random, len(positions_1k)) if not positions_1k[i]["done"][0] and positions_1k[i]["moves"]]
+    assert len(idx) >= 20 and all(data["results"][i] is None for i in idx if i < len(data["results"]))
+    states = [positions_1k[i]["state"] for i in idx]
+    pc = play_config(simulation_num_per_move=data["sims"], search_threads=1)
+    s = gpu.S.Search(pc, len(states), seed=0)
+    s.set_roots(boards_tensor(gpu, states))
+    s.run_until_idle(stub_eval(gpu, data["stub"]))
+    st = s.root_stats()
+    ctr = s.counters()
+    s.close()
+    assert ctr["overflow_sims"] == 0 and ctr["tree_resets"] == 0
+    for g, state in enumerate(states):
+        pl = xo.Player(oracle_cfg(pc), data["stub"])
+        pl.search(state)
+        assert_root_equal(st, g, pl.node_stats(state), state)
+        pl.close()
+    assert int(st["sum_n"].sum()) > 0
+
+
 def test_hip_search_lies_inside_the_reference_spread(gpu):
     """K > 1 on the GPU against the reference itself (not only against the oracle's canonical order): the reference's
     search_threads race, recorded from the unmodified reference's own CChessPlayer with its own thread timing

@@ -20,14 +20,51 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEARCH = ("k_noise", "k_sim", "k_advance")
 ROUND_LAUNCHES = 4            # k_sim(BACKUP), k_advance, k_noise, k_sim(SELECT)   (round 2: five, k_noise twice)
 ROUND_NAMES = ["k_sim", "k_advance", "k_noise", "k_sim"]
-NN = ("k_tower_c6", "k_resblock_ip", "k_resblock", "k_input_conv", "k_conv3x3", "k_split_bias_act", "k_bias_act", "k_fc_tile<0", "k_fc_tile<1",
-      "k_policy_normalize", "k_head_convs")
+NN = ("k_tower_pairs", "k_tower", "k_resblock_ip", "k_resblock_c8", "k_resblock_pipe", "k_resblock", "k_input_conv", "k_conv3x3",
+      "k_split_bias_act", "k_bias_act", "k_fc_tile", "k_policy_normalize", "k_head_convs")
+TOWER = ("k_tower_pairs", "k_tower", "k_resblock_c8", "k_resblock_pipe", "k_resblock")       # the residual tower's launches
+
+
+def _targs(name, base):
+    """the template arguments of kernel `base` in a demangled name: 'k_tower<true, 1>(...)' -> ['true', '1']"""
+    i = name.find(base + "<")
+    if i < 0:
+        return []
+    j, depth, out, cur = i + len(base) + 1, 1, [], ""
+    while j < len(name) and depth:
+        ch = name[j]
+        depth += ch == "<"
+        depth -= ch == ">"
+        if depth == 1 and ch == ",":
+            out.append(cur.strip()); cur = ""
+        elif depth:
+            cur += ch
+        j += 1
+    return out + [cur.strip()]
 
 
 def short(name):
-    for k in SEARCH + NN + ("k_rules_tpb", "k_movegen_fix", "k_start_selfplay"):
+    """Key of a kernel in the summaries.  Network kernels are keyed on their TEMPLATE ARGUMENTS (the FIRST and
+    HEADS variants of one kernel were averaged under one name): k_tower<HEADS, c6>, k_resblock_c8<FIRST, C6>, ..."""
+    for k in SEARCH + ("k_rules_tpb", "k_movegen_fix", "k_start_selfplay"):
         if k in name:
             return k
+    for k in NN:
+        if k + "<" in name or k + "(" in name:
+            a = _targs(name, k)
+            t = lambda v: v in ("true", "1")
+            if k == "k_tower" and len(a) == 2:
+                return f"k_tower<{'HEADS' if t(a[0]) else 'image'}, {'c6' if a[1] == '1' else 'c8'}>"
+            if k == "k_tower_pairs" and len(a) == 2:
+                return f"k_tower_pairs<{'bf16' if 'bf16' in a[0] or 'DF16b' in a[0] else 'f16'}, {'HEADS' if t(a[1]) else 'pairs'}>"
+            if k == "k_resblock_c8" and len(a) >= 2:
+                tags = [n for n, v in zip(("FIRST", "HEADS", "C6"), a + ["false"] * 3) if t(v)]
+                return "k_resblock_c8<" + ", ".join(tags or ["inner"]) + ">"
+            if k == "k_resblock_pipe" and a:
+                return "k_resblock_pipe<" + ("bf16" if "bf16" in a[0] else "f16") + (", FIRST" if len(a) > 1 and t(a[1]) else "") + ">"
+            if k == "k_fc_tile" and a:
+                return f"k_fc_tile<{a[0]}>"
+            return k if not a else k + "<" + ", ".join(a)[:40] + ">"
     return name[:70]
 
 
@@ -190,8 +227,8 @@ def main():
     grbm = per_kernel(read_counters(a.src, "pmc_grbm"))
     fk, wk = per_kernel(fetch), per_kernel(write)
     nn = {}
-    for k in NN:
-        if k not in sq:
+    for k in sorted(sq):
+        if not any(k == b or k.startswith(b + "<") for b in NN):
             continue
         d = dict(sq[k])
         gui = grbm.get(k, {}).get("GRBM_GUI_ACTIVE")
@@ -210,16 +247,57 @@ def main():
         if k in fk and k in wk:
             d["FETCH_SIZE_KB"] = fk[k]["FETCH_SIZE"]
             d["WRITE_SIZE_KB"] = wk[k]["WRITE_SIZE"]
-            d["hbm_bytes_per_launch"] = (2 * fk[k]["FETCH_SIZE"] + wk[k]["WRITE_SIZE"]) * 1024.0
+            # FETCH_SIZE reports half of a wide read, WRITE_SIZE is exact for dense stores and counts 32-byte granules for the
+            # 24-byte bf6 pieces (profiles/r06_hbm_counter_calibration.json)
+            d["hbm_read_bytes"] = 2 * fk[k]["FETCH_SIZE"] * 1024.0
+            d["hbm_write_bytes"] = wk[k]["WRITE_SIZE"] * 1024.0
+            d["hbm_bytes_per_launch"] = d["hbm_read_bytes"] + d["hbm_write_bytes"]
         nn[k] = d
+    # what a forward's tower launches are expected to move (an operand pair is 46 080 B per board) next to what the
+    # counters saw; the launch plan and the boards per launch come from the bench line of the stats run
+    bench = {}
+    try:
+        bench = json.loads(open(os.path.join(a.src, "stats.json")).read().strip().splitlines()[-1])
+    except Exception:
+        pass
+    boards = (bench.get("roofline") or {}).get("boards_per_launch")
+    plan = (bench.get("roofline") or {}).get("launch_plan")
+    tower = {}
+    if boards and plan:
+        PAIR, HEADF, MASK = 46080.0, 6 * 90 * 4.0, 384.0
+        filt = {"c6": 2 * 0.52e6, "c8": 2 * 0.59e6, "pair": 2 * 0.59e6}        # one block's two packed filters (bytes)
+        tot_alg = tot_meas = 0.0
+        for st in plan:
+            key, rd, wr, nb = st.get("kernel"), 0.0, 0.0, st.get("blocks", 1)
+            rd = MASK if st["step"] == "first" else PAIR
+            wr = HEADF if st.get("exit") == "heads" else PAIR
+            alg = boards * (rd + wr)
+            e = {"blocks": nb, "algorithmic_activation_bytes": alg}
+            m = nn.get(key)
+            if m and m.get("hbm_bytes_per_launch"):
+                e["measured_bytes"] = m["hbm_bytes_per_launch"]
+                e["measured_read_bytes"], e["measured_write_bytes"] = m["hbm_read_bytes"], m["hbm_write_bytes"]
+                # the rest: every workgroup streams its blocks' filters through its XCD's L2 (8 L2s: at least 8 first reads of
+                # each filter; refetches when a chain's filters exceed 4 MB) + the input-layer table
+                e["excess_over_activations"] = m["hbm_bytes_per_launch"] - alg
+                e["write_ratio"] = m["hbm_write_bytes"] / (boards * wr)
+                e["read_ratio"] = m["hbm_read_bytes"] / (boards * rd)
+                e["filter_bytes_one_read_per_xcd"] = 8 * nb * filt.get(st.get("kind"), 1.1e6)
+                tot_meas += m["hbm_bytes_per_launch"]
+            tot_alg += alg
+            tower[f"{st['step']}:{key}"] = e
+        tower["per_forward"] = {"algorithmic_activation_bytes": tot_alg, "measured_bytes": tot_meas or None,
+                                "blocks": sum(st.get("blocks", 1) for st in plan), "boards_per_launch": boards,
+                                "tower_arithmetic": (bench.get("roofline") or {}).get("tower_arithmetic")}
     if nn:
-        out = {"workload": "bench.py normal config: 32768 boards per launch, 7x128 network, default tower arithmetic (c6 since the end "
-                           "of round 4, c8 in profiles/r04_c8_*: k_resblock covers the k_resblock_c8<FIRST, HEADS, C6> launches -- "
-                           "plain, fused input layer, fused heads -- including the load-time guard's 256-board calibration launches)",
+        out = {"workload": "bench.py normal config: the compact queue's boards per launch (tower_traffic.per_forward), 7x128 network, "
+                           "default tower arithmetic; kernels keyed on their template arguments; means over the full-size launches "
+                           "(the load-time guard's 256-board calibration launches are dropped)",
                "method": "rocprofv3 --pmc passes of tools/collect_profiles.sh (SQ set, GRBM_GUI_ACTIVE, FETCH_SIZE, "
                          "WRITE_SIZE: one run each); means per launch, first 2 launches of each kernel excluded",
                "mfma_util_definition": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs)",
-               "kernels": nn}
+               "counter_calibration": "profiles/r06_hbm_counter_calibration.json (hbm_read_bytes = 2 x FETCH_SIZE, hbm_write_bytes = WRITE_SIZE)",
+               "tower_traffic": tower, "kernels": nn}
         with open(os.path.join(prof, f"{tag}_pmc_nn.json"), "w") as f:
             json.dump(out, f, indent=1)
         print("wrote", f"{tag}_pmc_nn.json", {k: round(v.get("mfma_util", 0), 3) for k, v in nn.items()})
