@@ -530,9 +530,10 @@ def tower_launch_plan(net):
             k = kinds[0]
             kern = {"c6": "k_resblock_c8<FIRST, C6>", "c8": "k_resblock_c8<FIRST>"}.get(k, f"k_resblock_pipe<{od}, FIRST>")
             out.append({"step": "first", "kernel": kern, "blocks": 1, "kind": k, "exit": kinds[1] if len(kinds) > 1 else None})
-        elif st[0] == "tower":
+        elif st[0] in ("tower", "tower_first"):
             k = kinds[st[1][0]]
-            out.append({"step": "tower", "kernel": f"k_tower<{'HEADS' if st[2] == 'heads' else 'image'}, {k}>",
+            first = ", FIRST" if st[0] == "tower_first" else ""
+            out.append({"step": st[0], "kernel": f"k_tower<{'HEADS' if st[2] == 'heads' else 'image'}, {k}{first}>",
                         "blocks": len(st[1]), "kind": k, "exit": st[2]})
         elif st[0] == "pairs":
             out.append({"step": "pairs", "kernel": f"k_tower_pairs<{od}, {'HEADS' if st[2] else 'pairs'}>", "blocks": len(st[1]),
@@ -1162,7 +1163,7 @@ def main():
                 # the committed PMC pass of this arithmetic: HBM bytes of a forward's tower launches, per block of the tower
                 pmc = {"hbm_bytes_per_launch": pt["hbm_bytes_per_forward"] / pt["blocks"], "source": pt["source"],
                        "algorithmic_activation_bytes_per_block": pt["algorithmic_activation_bytes_per_forward"] / pt["blocks"]}
-                mu = [pmc_nn(st["kernel"]).get("mfma_util") for st in (lplan or []) if st["step"] in ("tower", "pairs")]
+                mu = [pmc_nn(st["kernel"]).get("mfma_util") for st in (lplan or []) if st["step"] in ("tower", "tower_first", "pairs")]
                 pmc["mfma_util"] = next((m for m in mu if m), None)
             arith_text = {"c6": "one fp16 MFMA term + two block-scaled bf6 (e3m2, K = 64, 32 cycles) correction terms",
                           "c8": "one fp16 MFMA term + two block-scaled fp8 (e4m3, K = 64) correction terms",
@@ -1175,9 +1176,9 @@ def main():
                         kinds_used.append(st["kind"])
                 kdesc = ("the residual tower (2 x conv3x3 + bias + skip + ReLU per block) as CHAINS of blocks (csrc/xq_tower.hip; K loops "
                          "csrc/xq_c8_kloop.h / pipe_kloop): a workgroup takes a pair of boards through all blocks of a launch with the "
-                         "activations staying in LDS; launches of a forward: " + kshort + ".  The first launch (csrc/xq_conv.hip) also "
-                         "computes the 5x5 input layer (fp32 gather by its copy waves); 'HEADS' launches apply the 1x1 head convolutions "
-                         "as their exit.  Products: " + "; ".join(f"{k}: {arith_text[k]}" for k in kinds_used) + ", fp32 accumulate.  All "
+                         "activations staying in LDS; launches of a forward: " + kshort + ".  The first launch also computes the 5x5 "
+                         "input layer (fp32 gather by its copy waves; 'FIRST': inside the chain, for the next pair of boards); 'HEADS' "
+                         "launches apply the 1x1 head convolutions as their exit.  Products: " + "; ".join(f"{k}: {arith_text[k]}" for k in kinds_used) + ", fp32 accumulate.  All "
                          "times per BLOCK of the tower (a chained launch spread over its blocks), mean over the tower")
             else:
                 kshort = {"c8": "k_resblock_c8 (one residual block per launch)", "c6": "k_resblock_c8<C6> (one residual block per launch)"}.get(

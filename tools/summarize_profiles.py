@@ -26,7 +26,25 @@ TOWER = ("k_tower_pairs", "k_tower", "k_resblock_c8", "k_resblock_pipe", "k_resb
 
 
 def _targs(name, base):
-    """the template arguments of kernel `base` in a demangled name: 'k_tower<true, 1>(...)' -> ['true', '1']"""
+    """the template arguments of kernel `base` in a kernel name: 'k_tower<true, 1>(...)' -> ['true', '1']; rocprofv3 leaves names
+    with _Float16 parameters MANGLED (its demangler does not know DF16_): '7k_towerILb1ELi1EEEv...' -> ['true', '1'] too."""
+    tag = f"{len(base)}{base}I"
+    i = name.find(tag)
+    if name.startswith("_Z") and i >= 0:
+        j, out = i + len(tag), []
+        while j < len(name) and name[j] != "E":
+            if name.startswith("Lb", j):
+                out.append("true" if name[j + 2] == "1" else "false"); j += 4
+            elif name.startswith("Li", j):
+                k = name.index("E", j)
+                out.append(name[j + 2:k].replace("n", "-")); j = k + 1
+            elif name.startswith("DF16_", j):
+                out.append("_Float16"); j += 5
+            elif name.startswith("DF16b", j):
+                out.append("__bf16"); j += 5
+            else:
+                return out                                   # (something this mini-parser does not know: keep what we have)
+        return out
     i = name.find(base + "<")
     if i < 0:
         return []
@@ -50,11 +68,11 @@ def short(name):
         if k in name:
             return k
     for k in NN:
-        if k + "<" in name or k + "(" in name:
+        if k + "<" in name or k + "(" in name or f"{len(k)}{k}I" in name or f"{len(k)}{k}E" in name:
             a = _targs(name, k)
             t = lambda v: v in ("true", "1")
-            if k == "k_tower" and len(a) == 2:
-                return f"k_tower<{'HEADS' if t(a[0]) else 'image'}, {'c6' if a[1] == '1' else 'c8'}>"
+            if k == "k_tower" and len(a) >= 2:
+                return f"k_tower<{'HEADS' if t(a[0]) else 'image'}, {'c6' if a[1] == '1' else 'c8'}{', FIRST' if len(a) > 2 and t(a[2]) else ''}>"
             if k == "k_tower_pairs" and len(a) == 2:
                 return f"k_tower_pairs<{'bf16' if 'bf16' in a[0] or 'DF16b' in a[0] else 'f16'}, {'HEADS' if t(a[1]) else 'pairs'}>"
             if k == "k_resblock_c8" and len(a) >= 2:
@@ -269,7 +287,7 @@ def main():
         tot_alg = tot_meas = 0.0
         for st in plan:
             key, rd, wr, nb = st.get("kernel"), 0.0, 0.0, st.get("blocks", 1)
-            rd = MASK if st["step"] == "first" else PAIR
+            rd = MASK if st["step"] in ("first", "tower_first") else PAIR
             wr = HEADF if st.get("exit") == "heads" else PAIR
             alg = boards * (rd + wr)
             e = {"blocks": nb, "algorithmic_activation_bytes": alg}
