@@ -152,13 +152,56 @@ def search_launch_counters(rows, skip_rounds=3):
     return out
 
 
+FILTER_BYTES = {"c6": 2 * 0.52e6, "c8": 2 * 0.59e6, "pair": 2 * 0.59e6}        # one block's two packed filters
+
+
+def tower_filter_model(e, boards, nb, kind, chained):
+    """Adds the FILTER term to a tower launch's traffic entry: every XCD's L2 (4 MB) streams the launch's filters.  A one-block
+    launch reads its two filters (1.0-1.2 MB) once per XCD.  A chain of nb blocks cycles nb x 1.0-1.2 MB through each L2 once per
+    PAIR of boards of its workgroups (the workgroups of an XCD run nearly in lock-step): 8 XCDs x pairs x nb filters -- more than
+    the L2 holds from three blocks on, so every cycle comes from HBM / the memory-side cache again.  (Same instruction stream with
+    every block reading ONE block's filters: no faster, profiles/r06_chain_same_filters.log -- the refetches cost nothing.)"""
+    fb = nb * FILTER_BYTES.get(kind, 1.1e6)
+    pairs = -(-int(boards) // (256 * 2)) if chained else 1
+    cycles = pairs if fb > 3.5e6 else 1
+    e["filter_bytes_model"] = 8 * cycles * fb
+    e["filter_model"] = f"8 XCDs x {cycles} L2 cycle(s) x {nb} block(s) x {FILTER_BYTES.get(kind, 1.1e6) / 1e6:.2f} MB"
+    if e.get("measured_bytes"):
+        e["modelled_bytes"] = e["algorithmic_activation_bytes"] + e["filter_bytes_model"]
+        e["measured_over_modelled"] = e["measured_bytes"] / e["modelled_bytes"]
+    return e
+
+
+def patch_json(path):
+    """Recompute the filter-model fields of an existing rNN_pmc_nn.json (the raw counter tables do not travel back from the box)."""
+    d = json.load(open(path))
+    tt = d.get("tower_traffic") or {}
+    boards = (tt.get("per_forward") or {}).get("boards_per_launch")
+    tot = 0.0
+    for key, e in tt.items():
+        if key == "per_forward" or not boards:
+            continue
+        step, kern = key.split(":", 1)
+        kind = "c6" if "c6" in kern.lower() else ("c8" if "c8" in kern else "pair")
+        tower_filter_model(e, boards, e.get("blocks", 1), kind, step in ("tower", "pairs", "tower_first"))
+        tot += e.get("modelled_bytes", 0.0)
+    if tot and tt.get("per_forward", {}).get("measured_bytes"):
+        tt["per_forward"]["modelled_bytes"] = tot
+        tt["per_forward"]["measured_over_modelled"] = tt["per_forward"]["measured_bytes"] / tot
+    json.dump(d, open(path, "w"), indent=1)
+    print("patched", path, {k: round(v.get("measured_over_modelled", 0), 3) for k, v in tt.items() if isinstance(v, dict)})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--round", type=int, default=1)
     ap.add_argument("--src", default=os.path.join(ROOT, "gpurun_out", "prof"))
+    ap.add_argument("--patch-json", default=None, help="only recompute the filter-model fields of an existing rNN_pmc_nn.json")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles"),
                     help="where to write (on the GPU box: a directory under gpurun_out/, so that the raw counter tables need not travel)")
     a = ap.parse_args()
+    if a.patch_json:
+        return patch_json(a.patch_json)
     tag = f"r{a.round:02d}"
     prof = a.out
     os.makedirs(prof, exist_ok=True)
@@ -283,8 +326,7 @@ def main():
     tower = {}
     if boards and plan:
         PAIR, HEADF, MASK = 46080.0, 6 * 90 * 4.0, 384.0
-        filt = {"c6": 2 * 0.52e6, "c8": 2 * 0.59e6, "pair": 2 * 0.59e6}        # one block's two packed filters (bytes)
-        tot_alg = tot_meas = 0.0
+        tot_alg = tot_meas = tot_model = 0.0
         for st in plan:
             key, rd, wr, nb = st.get("kernel"), 0.0, 0.0, st.get("blocks", 1)
             rd = MASK if st["step"] in ("first", "tower_first") else PAIR
@@ -300,11 +342,14 @@ def main():
                 e["excess_over_activations"] = m["hbm_bytes_per_launch"] - alg
                 e["write_ratio"] = m["hbm_write_bytes"] / (boards * wr)
                 e["read_ratio"] = m["hbm_read_bytes"] / (boards * rd)
-                e["filter_bytes_one_read_per_xcd"] = 8 * nb * filt.get(st.get("kind"), 1.1e6)
                 tot_meas += m["hbm_bytes_per_launch"]
+            tower_filter_model(e, boards, nb, st.get("kind"), st["step"] in ("tower", "pairs", "tower_first"))
+            tot_model += e.get("modelled_bytes", 0.0)
             tot_alg += alg
             tower[f"{st['step']}:{key}"] = e
         tower["per_forward"] = {"algorithmic_activation_bytes": tot_alg, "measured_bytes": tot_meas or None,
+                                "modelled_bytes": tot_model or None,
+                                "measured_over_modelled": (tot_meas / tot_model) if tot_meas and tot_model else None,
                                 "blocks": sum(st.get("blocks", 1) for st in plan), "boards_per_launch": boards,
                                 "tower_arithmetic": (bench.get("roofline") or {}).get("tower_arithmetic")}
     if nn:
