@@ -834,7 +834,10 @@ def short_selfplay_leg(label, config, seconds, log, games=None, K=None, dtype=No
                                "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s", "frac": tfl / 2500.0,
                                "avg_launch_ms": b_ms, "launches_timed": len(blk), "boards_per_launch": rows_launch,
                                "mfmas_per_product": arith_mfma_equivalents(eng.net_arith_effective, nb) if split else 1,
-                               "share_of_step": b_ms * len(blk) / steps / (dt / steps * 1e3)}
+                               "share_of_step": b_ms * len(blk) / steps / (dt / steps * 1e3),
+                               "launch_ms_by_block": [sum(blk[i::nb]) / max(1, len(blk[i::nb])) for i in range(nb)],
+                               "launch_plan": [list(st[:2]) + [str(st[2])] for st in (getattr(eng.net, "last_plan", None) or [])
+                                               if len(st) > 2] or None}
             if getattr(eng.net, "c6", False):
                 rec["roofline"]["arithmetic"] = ("one fp16 MFMA (K = 16) per 16 input channels + two block-scaled bf6 MFMAs "
                                                  "(K = 64, 32 cycles) per 64: 1.5 bf16-MFMA-equivalents per product")

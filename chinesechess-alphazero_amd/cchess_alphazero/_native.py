@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CZ_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libczero.so")   # CZ_LIB: A/B builds (tools/ab_search.sh)
 
 NSQ, NLABELS, MAXMOVES, NOMOVE = 90, 2086, 128, 0xFFFF
-F32, F16, BF16, U8, F16C8, F16C6 = 0, 1, 2, 3, 4, 5
+F32, F16, BF16, U8, F16C8, F16C6, F16C86 = 0, 1, 2, 3, 4, 5, 6
 
 _lib = None
 
@@ -99,6 +99,8 @@ def _declare(L):
         L.cz_input_resblock_m.argtypes = [vp, vp, i32] + [vp] * 8 + [i32] * 3 + [vp] * 3
         L.cz_tower.restype = i32
         L.cz_tower.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+        L.cz_resblock_chain.restype = i32
+        L.cz_resblock_chain.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
         L.cz_tower_pairs.restype = i32
         L.cz_tower_pairs.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
         L.cz_tower_c6.restype = i32
@@ -312,13 +314,13 @@ def pack_conv3x3_c8_weights(w_oihw):
 
 
 def pack_conv3x3_c6_weights(w_oihw, x_exp, y_exp):
-    """fp32 [128, 128, 3, 3] filter -> packed bytes for the c6 arithmetic (f16 fragments, bf6 correction pieces, the two
+    """fp32 [C, C, 3, 3] filter (C = 128 or 192) -> packed bytes for the c6 arithmetic (f16 fragments, bf6 correction pieces, the two
     filter shifts, and the exponents of the activation images the convolution reads / writes: x_hi6 = bf6(x 2^-exp))."""
     import torch
     w = w_oihw.detach().to("cpu", torch.float32).contiguous()
     c = w.shape[0]
     n = lib().cz_conv3x3_c8_packed_bytes(c)
-    if n == 0 or c != 128:
+    if n == 0 or c not in (128, 192):
         raise NativeError(f"cz_conv3x3_c6: unsupported channels={c}")
     out = torch.empty((n,), dtype=torch.uint8)
     check(lib().cz_conv3x3_c6_pack_weights(_ptr(w), c, int(x_exp), int(y_exp), _ptr(out)), "cz_conv3x3_c6_pack_weights")
@@ -472,9 +474,10 @@ def input_conv(planes, w_packed, bias, out, relu=True, rows=None, count=None):
     return out
 
 
-def resblock(x, w1_packed, bias1, w2_packed, bias2, out=None, out_f32=None, count=None):
+def resblock(x, w1_packed, bias1, w2_packed, bias2, out=None, out_f32=None, count=None, dtype_code=None):
     """One residual block relu(conv(relu(conv(x, w1) + b1), w2) + b2 + x) in a single launch.  x and out are (hi,) or
-    (hi, lo) tuples of [N, 90, C] tensors; out_f32 (split operands only) receives fp32 instead of `out`."""
+    (hi, lo) tuples of [N, 90, C] tensors; out_f32 (split operands only) receives fp32 instead of `out`.  dtype_code: overrides
+    the code derived from x (F16C86: 192 filters, a c6 block reading the input layer's c8 image)."""
     require_gpu()
     parts = len(x)
     xh = x[0]
@@ -483,8 +486,8 @@ def resblock(x, w1_packed, bias1, w2_packed, bias2, out=None, out_f32=None, coun
     yh = out[0] if out is not None else None
     yl = out[1] if out is not None and parts == 2 else None
     check(lib().cz_resblock_q(_ptr(xh), _ptr(xl), _ptr(w1_packed), _ptr(bias1), _ptr(w2_packed), _ptr(bias2),
-                              _ptr(yh), _ptr(yl), _ptr(out_f32), n, c, _pair_code(x), parts, _ptr(count),
-                              _stream()), "cz_resblock")
+                              _ptr(yh), _ptr(yl), _ptr(out_f32), n, c, _pair_code(x) if dtype_code is None else int(dtype_code),
+                              parts, _ptr(count), _stream()), "cz_resblock")
     return out_f32 if out_f32 is not None else out
 
 
@@ -527,6 +530,20 @@ def tower(x, blocks, exit_fmt, out=None, heads=None, count=None, fmt_x=None, fmt
                      _ptr(out[0]) if out is not None else None, _ptr(out[1]) if out is not None else None,
                      _ptr(hw), _ptr(hb), _ptr(pf), _ptr(vf), npol, nval, x[0].shape[0], _ptr(count), _stream()), "cz_tower")
     return out if exit_fmt != EXIT_HEADS else (pf, vf)
+
+
+def resblock_chain(x, blocks, out=None, out_f32=None, count=None):
+    """cz_resblock_chain: consecutive 192-filter blocks (a BlockList or [(w1_packed, bias1, w2_packed, bias2), ...], 1 .. 8) of one
+    staged arithmetic in one launch; x: the c8 (uint8 image) or c6 (int8 image) operand pair; out: the same kind of pair, or
+    out_f32 [N, 90, 192] for the last block.  Bit-identical to len(blocks) resblock() calls."""
+    require_gpu()
+    bl = _block_list(blocks)
+    a = bl.arrays
+    check(lib().cz_resblock_chain(_ptr(x[0]), _ptr(x[1]), bl.n, a[0], a[1], a[2], a[3],
+                                  _ptr(out[0]) if out is not None else None, _ptr(out[1]) if out is not None else None,
+                                  _ptr(out_f32), x[0].shape[0], x[0].shape[-1], _pair_code(x), _ptr(count), _stream()),
+          "cz_resblock_chain")
+    return out_f32 if out_f32 is not None else out
 
 
 def tower_pairs(x, blocks, out=None, heads=None, count=None):

@@ -140,6 +140,25 @@ def tower_plan(kinds, heads_exit=True, chain_heads=True, max_chain=8):
     return steps
 
 
+def ip_segments(kinds, max_chain=12):
+    """The launches of a 192-filter tower's blocks (k_resblock_ip_c8 / k_resblock_ip; round 6): ("chain", [blocks]) = one
+    cz_resblock_chain launch of consecutive blocks of one staged arithmetic, ("block", [i]) = a block on its own launch -- a c6
+    tower's block 0 (it reads the input layer's c8 image: its own kernel variant) and the pair blocks."""
+    segs, i, n = [], 0, len(kinds)
+    while i < n:
+        k = kinds[i]
+        if k == "pair" or (k == "c6" and i == 0):
+            segs.append(("block", [i]))
+            i += 1
+            continue
+        j = i
+        while j < n and kinds[j] == k and j - i < max_chain:
+            j += 1
+        segs.append(("chain", list(range(i, j))))
+        i = j
+    return segs
+
+
 def events_ms(events):
     """Per-BLOCK times (ms) of the tower launches recorded in InferenceNet.block_events: a (start, end) pair is one residual
     block; (start, end, m) is a launch of m chained blocks (cz_tower / cz_tower_pairs), counted as m blocks of elapsed / m each, so that the
@@ -170,7 +189,7 @@ class InferenceNet(nn.Module):
                 k_resblock_c8 / k_resblock_ip_c8): one fp16 and two fp8 matrix instructions per 64 input channels, 2^-16
                 per product;
       "c8>N"    the first N residual blocks on c8, the rest on f16x3 (error ~ sqrt(N): the guard's middle ground);
-      "c6"      (128 filters, >= 2 blocks, fused kernels) c8 with bf6 (e3m2) correction operands: half the matrix time of the
+      "c6"      (128 / 192 filters, >= 2 blocks, fused kernels) c8 with bf6 (e3m2) correction operands: half the matrix time of the
                 e4m3 ones, 2^-15 per product; needs act_exps (the images' exponents, from the calibration);
       "c6>N"    the first N residual blocks on c6, the rest on c8 (round 5: the step down from c6 is not all-or-nothing; block
                 N - 1 writes a c8 image, cz_conv3x3_c6_pack_weights y_exp = 127).
@@ -202,7 +221,7 @@ class InferenceNet(nn.Module):
             # first N blocks only, the rest c8
             n6 = int(arith[3:]) if arith.startswith("c6>") else nblk
             assert 1 <= n6 <= nblk, arith
-            self.c6 = (trunk == "mfma" and dtype == torch.float32 and net.cfg["cnn_filter_num"] == 128 and nblk >= 2)
+            self.c6 = (trunk == "mfma" and dtype == torch.float32 and net.cfg["cnn_filter_num"] in (128, 192) and nblk >= 2)
             if self.c6 and act_exps is None:
                 if not from_env:
                     raise ValueError("arith='c6' needs the activation images' exponents: build the network through "
@@ -394,18 +413,20 @@ class InferenceNet(nn.Module):
         fused = self.fused_blocks and ((c in (128, 192)) or (c == 256 and self.parts == 1))
         # input layer + first block in one launch: 128 filters, split operands, byte planes, a tower of >= 2 blocks
         # (a hybrid tower whose only c8 block is the first hands fp32 over after it: that block stays on cz_resblock)
-        if self.c6 and planes.dtype != torch.uint8:
+        if self.c6 and c == 128 and planes.dtype != torch.uint8:
             # c6 exists on the fused kernels only, whose input layer is a gather over the OCCUPIED squares of byte planes:
             # the feature planes are 0 / 1 by construction (environment/static_env.py state_to_planes), in any dtype
             planes = (planes != 0).to(torch.uint8)
         first_fused = (fused and self.fused_input and c == 128 and self.parts == 2 and nblk >= 2 and
                        planes.dtype == torch.uint8 and n8 != 1)
-        if self.c6 and not (first_fused and fused):
-            raise RuntimeError("arith='c6' runs on the fused kernels only (uint8 planes, fused input layer and blocks)")
+        if self.c6 and not (fused and (first_fused or c == 192)):
+            raise RuntimeError("arith='c6' runs on the fused kernels only (128 filters: uint8 planes, fused input layer and blocks)")
         if not first_fused:
             if self.arith == "c8" and n8 == 0:                  # (cannot happen through the constructor; kept total)
                 cur, tmp, nxt = (self._as_f16_pair(t) for t in (cur, tmp, nxt))
-            _native.input_conv(planes.contiguous(), self.in_w.view(self.operand_dtype), self.in_bias32, cur,
+            # (a c6 tower's input layer writes a c8 image: its first block's first filter is a c8 filter)
+            cur_in = (cur[0], cur[1].view(torch.uint8)) if self.c6 else cur
+            _native.input_conv(planes.contiguous(), self.in_w.view(self.operand_dtype), self.in_bias32, cur_in,
                                rows=rows, count=count)
         # (round 5 / 6) the blocks behind the fused input layer run as CHAINS -- one launch for consecutive blocks with the
         # activations staying in LDS (cz_tower for c6 / c8 blocks, cz_tower_pairs for f16x3 / bf16x3 ones; tower_plan): the 7 x 128
@@ -413,6 +434,8 @@ class InferenceNet(nn.Module):
         # fp16 pairs) | 3 .. 6 (heads)
         if fused and first_fused and self.chain_blocks:
             return self._tower_chained(planes, cur, nxt, last, heads, rows, count, masks)
+        if fused and c == 192 and self.parts == 2 and self.arith == "c8" and self.chain_blocks:
+            return self._tower_192(cur, nxt, last, count)
         for i in range(nblk):
             w1 = getattr(self, f"tw{i}a").view(self.operand_dtype)
             w2 = getattr(self, f"tw{i}b").view(self.operand_dtype)
@@ -437,7 +460,9 @@ class InferenceNet(nn.Module):
                     cur, tmp, nxt = (self._as_f16_pair(t) for t in (cur, tmp, nxt))
                     _native.split_bias_act(last, None, cur, relu=False)
                 elif i + 1 < nblk:
-                    _native.resblock(cur, w1, b1, w2, b2, out=nxt, count=count)
+                    # (192 filters, c6: block 0 reads the input layer's c8 image -- its own dtype code)
+                    code = _native.F16C86 if (self.c6 and i == 0 and not first_fused) else None
+                    _native.resblock(cur, w1, b1, w2, b2, out=nxt, count=count, dtype_code=code)
                     cur, nxt = nxt, cur
                 elif heads is not None and self.parts == 2 and c == 128:
                     _native.resblock_heads(cur, w1, b1, w2, b2, self.head_w32, self.head_b32, heads[0], heads[1],
@@ -557,6 +582,51 @@ class InferenceNet(nn.Module):
                 ev[1].record()
                 self.block_events.append(ev + (nb,) if nb > 1 else ev)
         return None if done_heads else last
+
+    def _tower_192(self, cur, nxt, last, count):
+        """The 192-filter tower (c8 / c6 families) behind cz_input_conv as ip_segments' launches; returns the fp32 trunk output."""
+        from cchess_alphazero import _native
+        kinds = self.block_kinds()
+        nblk = len(kinds)
+        key = ("plan192", self.tb0a.data_ptr())
+        if key not in self._bufs:
+            self._bufs[key] = [(kind, blk, _native.BlockList([self._block_params(i) for i in blk])) for kind, blk in ip_segments(kinds)]
+        self.last_plan = [("chain192" if kind == "chain" else "block192", blk, kinds[blk[0]]) for kind, blk, _ in self._bufs[key]]
+        tag = {"c6": torch.int8, "c8": torch.uint8}
+        for kind, blk, bl in self._bufs[key]:
+            ev = None
+            if self.block_events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            k, i1 = kinds[blk[0]], blk[-1]
+            tower_end = i1 + 1 == nblk
+            to_pairs = k == "c8" and not tower_end and kinds[i1 + 1] == "pair"
+            if k == "pair":
+                x = self._as_f16_pair(cur)
+                w1, b1, w2, b2 = bl.blocks[0]
+                if tower_end:
+                    _native.resblock(x, w1, b1, w2, b2, out_f32=last, count=count)
+                else:
+                    _native.resblock(x, w1, b1, w2, b2, out=self._as_f16_pair(nxt), count=count)
+                    cur, nxt = nxt, cur
+            elif kind == "block":                   # a c6 tower's block 0: c8 image in, c6 (or, c6>1, c8) image out
+                w1, b1, w2, b2 = bl.blocks[0]
+                _native.resblock((cur[0], cur[1].view(torch.uint8)), w1, b1, w2, b2, out=(nxt[0], nxt[1].view(torch.int8)),
+                                 count=count, dtype_code=_native.F16C86)
+                cur, nxt = nxt, cur
+            else:
+                x = (cur[0], cur[1].view(tag[k]))
+                if tower_end or to_pairs:
+                    _native.resblock_chain(x, bl, out_f32=last, count=count)
+                    if to_pairs:                    # the hand-over of a c8>N tower: re-split into (hi, lo) fp16 pairs
+                        _native.split_bias_act(last, None, self._as_f16_pair(cur), relu=False)
+                else:
+                    _native.resblock_chain(x, bl, out=(nxt[0], nxt[1].view(tag[k])), count=count)
+                    cur, nxt = nxt, cur
+            if ev is not None:
+                ev[1].record()
+                self.block_events.append(ev + (len(blk),) if len(blk) > 1 else ev)
+        return last
 
     def _head_feats(self, n, npol, device):
         key = ("hf", n, str(device))
@@ -911,9 +981,9 @@ def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", ari
     reduced = trunk == "mfma" and dtype == torch.float32        # (a caller asking for bf16 / fp16 operands asked for them)
     nblk = len(net.res)
     wants_c6 = requested == "c6" or requested.startswith("c6>")
-    c6 = wants_c6 and reduced and net.cfg["cnn_filter_num"] == 128 and nblk >= 2 and dev.type == "cuda"
+    c6 = wants_c6 and reduced and net.cfg["cnn_filter_num"] in (128, 192) and nblk >= 2 and dev.type == "cuda"
     if wants_c6 and not c6:
-        requested = "c8"                                         # (c6 exists for the 128-filter tower on the fused kernels)
+        requested = "c8"                                         # (c6 exists for the 128- and 192-filter towers on the fused kernels)
     first = None if c6 else InferenceNet(net, dtype, trunk=trunk, arith=requested).to(dev)
     if first is not None:
         first.arith_requested = requested

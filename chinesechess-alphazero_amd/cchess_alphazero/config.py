@@ -69,7 +69,7 @@ class EngineConfig(_Section):
                          net_dtype="float32",     # float32 (reference precision) | bfloat16 | float16
                          net_trunk="mfma",        # mfma (hand-written convolution kernel) | library (MIOpen)
                          net_arith="c6",          # REQUESTED products of the float32 tower: c6 (fp16 + two scaled-bf6
-                                                  # correction MFMAs; 128 filters, >= 2 blocks; elsewhere it means c8) |
+                                                  # correction MFMAs; 128 / 192 filters, >= 2 blocks; elsewhere it means c8) |
                                                   # c8 (e4m3 corrections; 128 / 192 filters) | c8>N (first N blocks) |
                                                   # f16x3 | bf16x3 (three MFMAs on fp16 / bf16 pairs); CZ_TOWER_ARITH overrides
                          arith_guard=True,        # measure the request against float64 on calibration positions when

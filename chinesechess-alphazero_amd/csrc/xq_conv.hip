@@ -1658,6 +1658,14 @@ __global__ __launch_bounds__(512, 1) void k_resblock_pipe(
 // cz_conv3x3 launches.  The last block of a tower writes fp32 (y_f32) straight from the accumulators' epilogue instead.
 namespace ip {
 constexpr int ROW_Y = 90, ROW_Z = 192, ROWS = ROW_Z + 16, COPY_THREADS = 128;       // (ROW_Z: a multiple of 16)
+constexpr int MAX_BLOCKS = 12;
+struct Chain {                      // k_resblock_ip_c8: the consecutive blocks a launch takes every board through (1 .. 12)
+    const void* w1[MAX_BLOCKS];
+    const void* w2[MAX_BLOCKS];
+    const float* b1[MAX_BLOCKS];
+    const float* b2[MAX_BLOCKS];
+    int n;
+};
 }
 
 template <typename E, int C>
@@ -1844,18 +1852,30 @@ __global__ __launch_bounds__((C / 32) * 64 + ip::COPY_THREADS, 1) void k_resbloc
 // blocks per tap -- and k_resblock_c8's arithmetic: accumulators start at bias (K loop 1) / bias + skip (K loop 2, read from
 // X by the owning lane), the epilogues only apply ReLU and split.  2.0 instead of 3.0 MFMA-equivalents per product for the
 // reference's deployed 10 x 192 topology (configs/distribute.py:84-87).  Bit-identical to two cz_conv3x3_c8 launches.
-template <int C>
+// XF / YF (round 6): the formats of the image the first convolution reads and of the intermediate image -- 0 = c8 (e4m3
+// corrections), 1 = c6 (bf6 pieces with an exponent: cz_conv3x3_c6_pack_weights filters; 25 % less matrix time per product).
+// <0, 0>: the c8 block; <1, 1>: a c6 block; <0, 1>: the tower's first c6 block, whose input is the input layer's c8 image.
+// A c6 block's result is a c6 image with its second filter's output exponent -- or a c8 image where that filter carries
+// y_exp = 127 (the hand-over of a c6>N tower), or fp32 (y_f32).  The c6 pieces are formed exactly as in k_resblock_c8<.., C6>
+// (tiles trade lane halves with v_permlane32_swap, v_cvt_scalef32_2xpk16_bf6_f32); piece (kind, 32-channel block w) of a pixel
+// row has its 16-byte head in chunk kind * CPR / 2 + 4 (w >> 1) + 2 (w & 1), its 8-byte tail at the start of the next chunk.
+// CHAIN (round 6, cz_resblock_chain): ch.n consecutive blocks of ONE format per launch.  Two images leave no room for a second
+// board, so a workgroup takes ONE board through all blocks: the in-place second epilogue already leaves block b's result in X
+// as block b + 1's input, and the drain to HBM + refill (69 KB through two copy waves, all matrix waves waiting) happens once
+// per chain instead of once per block.  Biases double-buffered in LDS by the running block count; filters and image exponents
+// switch per block; y_f32 applies to the chain's last block.  Same arithmetic as ch.n one-block launches: bit-identical.
+template <int C, int XF = 0, int YF = 0>
 __global__ __launch_bounds__((C / 32) * 64 + ip::COPY_THREADS, 1) void k_resblock_ip_c8(
-    const _Float16* __restrict__ xh, const unsigned char* __restrict__ xc, const void* __restrict__ w1p,
-    const float* __restrict__ b1, const void* __restrict__ w2p, const float* __restrict__ b2, _Float16* __restrict__ yh,
-    unsigned char* __restrict__ yc, float* __restrict__ yf, int n_boards, const int32_t* __restrict__ n_dev)
+    const _Float16* __restrict__ xh, const unsigned char* __restrict__ xc, ip::Chain ch, _Float16* __restrict__ yh,
+    unsigned char* __restrict__ yc, float* __restrict__ yf_last, int n_boards, const int32_t* __restrict__ n_dev)
 {
     typedef Geom<C, 1, 2> G;
     constexpr int RB = G::RB, CPR = G::CPR, CT = G::CT, NT = 3;
     constexpr int PSTR = ip::ROWS * RB;                         // bytes per operand part
     constexpr int BIAS_OFF = 2 * PSTR;
     constexpr int CTHR = ip::COPY_THREADS, CHUNKS = 90 * CPR, LITER = (CHUNKS + CTHR - 1) / CTHR;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[BIAS_OFF + 2 * C * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BIAS_OFF + 2 * 2 * C * 4];       // bias[2 buffers][2 convolutions][C]
+    const int NB = ch.n;
     static_assert(sizeof(lds) <= 160 * 1024, "two images + zero rows must fit the CU's LDS");
     if (n_dev) {
         const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
@@ -1906,7 +1926,7 @@ __global__ __launch_bounds__((C / 32) * 64 + ip::COPY_THREADS, 1) void k_resbloc
                     const int i = it * CTHR + ctid;
                     if (!((it + 1) * CTHR <= CHUNKS || i < CHUNKS)) continue;
                     unsigned char* a = lds + part * PSTR + chunk_off(i);
-                    if (!yf) dst[i] = *reinterpret_cast<const uint4*>(a);
+                    if (!yf_last) dst[i] = *reinterpret_cast<const uint4*>(a);
                     if (refill) *reinterpret_cast<uint4*>(a) = v[part][it];
                 }
             }
@@ -1917,17 +1937,28 @@ __global__ __launch_bounds__((C / 32) * 64 + ip::COPY_THREADS, 1) void k_resbloc
             *reinterpret_cast<uint4*>(lds + ip::ROW_Z * RB + i * 16) = make_uint4(0, 0, 0, 0);
             *reinterpret_cast<uint4*>(lds + PSTR + ip::ROW_Z * RB + i * 16) = make_uint4(0, 0, 0, 0);
         }
-        for (int i = ctid; i < C; i += CTHR) {
-            reinterpret_cast<float*>(lds + BIAS_OFF)[i] = b1[i];
-            reinterpret_cast<float*>(lds + BIAS_OFF)[C + i] = b2[i];
-        }
+        // biases of running block g (block g % NB) into buffer g & 1
+        auto write_bias = [&](int g) {
+            const int blk = g % NB;
+            float* dst = reinterpret_cast<float*>(lds + BIAS_OFF) + (g & 1) * 2 * C;
+            for (int i = ctid; i < C; i += CTHR) {
+                dst[i] = ch.b1[blk][i];
+                dst[C + i] = ch.b2[blk][i];
+            }
+        };
+        write_bias(0);
+        write_bias(1);                                          // (one block per launch: both buffers hold its biases)
+        int g = 0;
         for (;;) {
             __syncthreads();                                    // A: X holds board t
             const int tn = t + stride;
             const bool has_next = tn < n_boards;
             if (has_next) fetch(tn);
-            __syncthreads();                                    // B: Y complete
-            __syncthreads();                                    // C: the result is in X
+            for (int b = 0; b < NB; ++b, ++g) {
+                __syncthreads();                                // B: Y complete; block g's biases are consumed
+                if (NB > 1) write_bias(g + 2);                  // (one block per launch: its biases never change)
+                __syncthreads();                                // C: the block's result is in X
+            }
             drain(t, has_next);
             if (!has_next) break;
             t = tn;
@@ -1937,9 +1968,59 @@ __global__ __launch_bounds__((C / 32) * 64 + ip::COPY_THREADS, 1) void k_resbloc
 
     // ---- matrix waves ----
     const int kb = lane >> 5, ln = lane & 31;
-    const c8k::Filter flt1 = c8k::make_filter<C>(w1p, wave, lane), flt2 = c8k::make_filter<C>(w2p, wave, lane);
-    const float* bias1 = reinterpret_cast<const float*>(lds + BIAS_OFF);
-    const float* bias2 = bias1 + C;
+    // byte offset (inside a part) of 16-byte chunk `chunk` of pixel row `row_abs`, swizzle key = the image-relative row
+    auto choff = [&](int row_abs, int key, int chunk) {
+        return row_abs * RB + ((chunk & ~G::SWZ) << 4) + (((chunk ^ key) & G::SWZ) << 4);
+    };
+    // relu'd fp32 accumulators of the three tiles -> the c6 operand triple of image `row0` (its first absolute row) with
+    // exponent k: f16 quads per lane, the two bf6 pieces of a pixel's 32 channels after the lane halves traded tiles.
+    // acc keeps relu(acc).
+    auto write_c6 = [&](f32x16* acc, int row0, int k, int ln2, int kb2) __attribute__((always_inline)) {
+        using rb8::u32x6;
+        const float s_hi = __builtin_ldexpf(1.0f, k), s_lo = __builtin_ldexpf(1.0f, k - cf8::X_LO_SHIFT);
+        f32x16 lo[NT];
+#pragma unroll
+        for (int p = 0; p < NT; ++p) {
+            const int q = p * 32 + ln2;
+            const int row = q < 90 ? q : 89;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = wave * 32 + g * 8 + kb2 * 4;
+                Quad<_Float16> hq;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float r = acc[p][g * 4 + i] > 0.0f ? acc[p][g * 4 + i] : 0.0f;
+                    hq.e[i] = (_Float16)r;
+                    acc[p][g * 4 + i] = r;
+                    lo[p][g * 4 + i] = r - (float)hq.e[i];
+                }
+                if (q < 90) *reinterpret_cast<Quad<_Float16>*>(lds + choff(row0 + row, row, ch >> 3) + (ch & 7) * 2) = hq;
+            }
+        }
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {                       // pair (0, 1), then tile 2 with itself
+            const int pa = pp == 0 ? 0 : 2, pb = pp == 0 ? 1 : 2;
+            f32x16 av, bv, al, bl;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[pa][r]), __float_as_uint(acc[pb][r]), false, false);
+                const auto sl = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo[pa][r]), __float_as_uint(lo[pb][r]), false, false);
+                av[r] = __uint_as_float(sv[0]); bv[r] = __uint_as_float(sv[1]);
+                al[r] = __uint_as_float(sl[0]); bl[r] = __uint_as_float(sl[1]);
+            }
+            const u32x6 pl = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(al, bl, s_lo);
+            const u32x6 pv = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(av, bv, s_hi);
+            const int q = pp == 0 ? kb2 * 32 + ln2 : 64 + ln2;
+            if (pp == 0 || (kb2 == 0 && q < 90)) {
+                const int c0 = 4 * (wave >> 1) + 2 * (wave & 1), c1 = CPR / 2 + c0;
+                unsigned char* P1 = lds + PSTR;
+                *reinterpret_cast<uint4*>(P1 + choff(row0 + q, q, c0)) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+                *reinterpret_cast<uint2*>(P1 + choff(row0 + q, q, c0 + 1)) = make_uint2(pl[4], pl[5]);
+                *reinterpret_cast<uint4*>(P1 + choff(row0 + q, q, c1)) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
+                *reinterpret_cast<uint2*>(P1 + choff(row0 + q, q, c1 + 1)) = make_uint2(pv[4], pv[5]);
+            }
+        }
+    };
     // offsets of this lane's four channels ch .. ch + 3 of pixel row `row` (image-relative key for the swizzle): the f16 quad,
     // its lo8 word, its e4m3(x) word
     auto offs = [&](int row_abs, int key, int ch, int& off, int& off_lo, int& off_hi) {
@@ -1948,9 +2029,23 @@ __global__ __launch_bounds__((C / 32) * 64 + ip::COPY_THREADS, 1) void k_resbloc
         off_lo = PSTR + row_abs * RB + ((c_lo & ~G::SWZ) << 4) + (((c_lo ^ key) & G::SWZ) << 4) + (ch & 15);
         off_hi = PSTR + row_abs * RB + ((c_hi & ~G::SWZ) << 4) + (((c_hi ^ key) & G::SWZ) << 4) + (ch & 15);
     };
+    int g = 0;                                                  // running block count: its parity picks the bias buffer
     for (;;) {
         __syncthreads();                                        // A
         const bool has_next = t + stride < n_boards;
+      for (int blk = 0; blk < NB; ++blk, ++g) {
+        const void* w1p = ch.w1[blk];
+        const void* w2p = ch.w2[blk];
+        const c8k::Filter flt1 = c8k::make_filter<C>(w1p, wave, lane), flt2 = c8k::make_filter<C>(w2p, wave, lane);
+        const float* bias1 = reinterpret_cast<const float*>(lds + BIAS_OFF) + (g & 1) * 2 * C;
+        const float* bias2 = bias1 + C;
+        // c6: the exponents of the images the two convolutions read and of the one the block writes (127: a c8 image)
+        const int* ints1 = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(w1p) + c8k::Geo<C>::MAIN_U4 + c8k::Geo<C>::C8_U4);
+        const int* ints2 = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(w2p) + c8k::Geo<C>::MAIN_U4 + c8k::Geo<C>::C8_U4);
+        const int k_x = XF ? __builtin_amdgcn_readfirstlane(ints1[2]) : 0;
+        const int k_y = YF ? __builtin_amdgcn_readfirstlane(ints2[2]) : 0;
+        const int k_out = YF ? __builtin_amdgcn_readfirstlane(ints2[3]) : CZ_C6_OUT_C8;
+        float* yf = blk == NB - 1 ? yf_last : nullptr;          // fp32 output: the chain's last block only
         f32x16 acc[NT];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1961,45 +2056,69 @@ __global__ __launch_bounds__((C / 32) * 64 + ip::COPY_THREADS, 1) void k_resbloc
             }
         }
         __builtin_amdgcn_s_setprio(3);
-        c8k::kloop<NT, c8k::NoShadow, 0, false, C>(lds, c8k::Image{0, ip::ROW_Z, PSTR}, flt1, lane, acc, 127 - cf8::X_LO_SHIFT, 127);
+        c8k::kloop<NT, c8k::NoShadow, 0, false, C, XF>(lds, c8k::Image{0, ip::ROW_Z, PSTR}, flt1, lane, acc, 127 + k_x - cf8::X_LO_SHIFT, 127 + k_x);
         __builtin_amdgcn_s_setprio(0);
         int ln2 = ln, kb2 = kb;
         asm volatile("" : "+v"(ln2), "+v"(kb2));
-        // epilogue 1: relu(acc) -> c8 triple -> Y; the freed accumulators restart at b2 + skip (this lane's own elements of X)
+        // epilogue 1: relu(acc) -> the operand triple (format YF) -> Y; the freed accumulators restart at b2 + skip (this lane's
+        // own elements of X, format XF)
+        if (YF) write_c6(acc, ip::ROW_Y, k_y, ln2, kb2);
 #pragma unroll
         for (int p = 0; p < NT; ++p) {
             const int q = p * 32 + ln2;
             const int row = q < 90 ? q : 89;
+            rb8::f32x32 xl;
+            if (XF) {                                           // this lane's elements of the x_lo piece of its 32-channel block
+                const int c0 = 4 * (wave >> 1) + 2 * (wave & 1);
+                const uint4 hd4 = *reinterpret_cast<const uint4*>(lds + PSTR + choff(row, row, c0));
+                const uint2 tl2 = *reinterpret_cast<const uint2*>(lds + PSTR + choff(row, row, c0 + 1));
+                const uint32_t wv[7] = {hd4.x, hd4.y, hd4.z, hd4.w, tl2.x, tl2.y, 0u};
+                const uint32_t sh6 = (uint32_t)kb2 * 6u;       // (the upper lane half wants the odd elements: see k_resblock_c8)
+                rb8::u32x6 pc;
+#pragma unroll
+                for (int w = 0; w < 6; ++w) pc[w] = __builtin_amdgcn_alignbit(wv[w + 1], wv[w], sh6);
+                xl = __builtin_amdgcn_cvt_scalef32_pk32_f32_bf6(pc, __builtin_ldexpf(1.0f, k_x - cf8::X_LO_SHIFT));
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ch = wave * 32 + g * 8 + kb2 * 4;
                 int ox, oxl, oxh, oy, oyl, oyh;
                 offs(row, row, ch, ox, oxl, oxh);
                 offs(ip::ROW_Y + row, row, ch, oy, oyl, oyh);
-                float r[4];
+                if (!YF) {
+                    float r[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) r[i] = acc[p][g * 4 + i] > 0.0f ? acc[p][g * 4 + i] : 0.0f;
-                const cf8::Split4 o = cf8::split4(r);
-                if (q < 90) {
-                    *reinterpret_cast<Quad<_Float16>*>(lds + oy) = o.hi;
-                    *reinterpret_cast<uint32_t*>(lds + oyl) = o.l8;
-                    *reinterpret_cast<uint32_t*>(lds + oyh) = o.h8;
+                    for (int i = 0; i < 4; ++i) r[i] = acc[p][g * 4 + i] > 0.0f ? acc[p][g * 4 + i] : 0.0f;
+                    const cf8::Split4 o = cf8::split4(r);
+                    if (q < 90) {
+                        *reinterpret_cast<Quad<_Float16>*>(lds + oy) = o.hi;
+                        *reinterpret_cast<uint32_t*>(lds + oyl) = o.l8;
+                        *reinterpret_cast<uint32_t*>(lds + oyh) = o.h8;
+                    }
                 }
                 const float4 bv = *reinterpret_cast<const float4*>(bias2 + ch);
                 float vv[4] = {bv.x, bv.y, bv.z, bv.w};
-                cf8::add_pair4(vv, *reinterpret_cast<const Quad<_Float16>*>(lds + ox), *reinterpret_cast<const uint32_t*>(lds + oxl));
+                if (XF) {
+                    const Quad<_Float16> xq = *reinterpret_cast<const Quad<_Float16>*>(lds + ox);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) vv[i] += (float)xq.e[i] + xl[2 * (g * 4 + i)];
+                } else {
+                    cf8::add_pair4(vv, *reinterpret_cast<const Quad<_Float16>*>(lds + ox), *reinterpret_cast<const uint32_t*>(lds + oxl));
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[p][g * 4 + i] = vv[i];
             }
         }
         __syncthreads();                                        // B: Y complete
         __builtin_amdgcn_s_setprio(3);
-        c8k::kloop<NT, c8k::NoShadow, 0, false, C>(lds, c8k::Image{ip::ROW_Y, ip::ROW_Z, PSTR}, flt2, lane, acc,
-                                                   127 - cf8::X_LO_SHIFT, 127);
+        c8k::kloop<NT, c8k::NoShadow, 0, false, C, YF>(lds, c8k::Image{ip::ROW_Y, ip::ROW_Z, PSTR}, flt2, lane, acc,
+                                                       127 + k_y - cf8::X_LO_SHIFT, 127 + k_y);
         __builtin_amdgcn_s_setprio(0);
         asm volatile("" : "+v"(ln2), "+v"(kb2));
-        // epilogue 2: relu(acc) -> the c8 triple in place over the skip operand (each lane writes only its own bytes of X), or
-        // fp32 straight to HBM for the last block of a tower
+        // epilogue 2: relu(acc) -> the operand triple in place over the skip operand (X is dead: every lane consumed its skip
+        // elements before barrier B), or fp32 straight to HBM for the last block of a tower
+        if (YF && !yf && k_out != CZ_C6_OUT_C8) write_c6(acc, 0, k_out, ln2, kb2);
+        else
 #pragma unroll
         for (int p = 0; p < NT; ++p) {
             const int q = p * 32 + ln2;
@@ -2024,6 +2143,7 @@ __global__ __launch_bounds__((C / 32) * 64 + ip::COPY_THREADS, 1) void k_resbloc
             }
         }
         __syncthreads();                                        // C: the result is in X
+      }
         if (!has_next) break;
         t += stride;
     }
@@ -2492,9 +2612,9 @@ extern "C" int cz_conv3x3_c8_pack_weights(const float* w_oihw, int channels, voi
 // activation image this convolution reads and of the one it writes (x_hi6 = bf6(x 2^-k); 2^k 28 >= max |x|).
 extern "C" int cz_conv3x3_c6_pack_weights(const float* w_oihw, int channels, int x_exp, int y_exp, void* out_host)
 {
-    if (!w_oihw || !out_host || channels != 128 || x_exp < -100 || x_exp > 100 ||
+    if (!w_oihw || !out_host || (channels != 128 && channels != 192) || x_exp < -100 || x_exp > 100 ||
         ((y_exp < -100 || y_exp > 100) && y_exp != CZ_C6_OUT_C8)) {
-        czi_set_error("cz_conv3x3_c6_pack_weights: bad argument (128 filters; image exponents within +-100, or y_exp 127 = c8 output)");
+        czi_set_error("cz_conv3x3_c6_pack_weights: bad argument (128 or 192 filters; image exponents within +-100, or y_exp 127 = c8 output)");
         return CZ_ERR_ARG;
     }
     const int C = channels, KK = C / 16, CT = C / 32, NB = C / 64;
@@ -2860,11 +2980,20 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
     else if (dtype == CZ_F16C6 && channels == 128 && parts == 2)
         rc = launch_resblock_c8<false, false, true>(x_hi, x_lo, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo, y_f32, n_boards,
                                                     n_cu, st, HeadArgs{}, g_q.n_dev, FirstArgs{});
-    else if (dtype == CZ_F16C8 && channels == 192 && parts == 2) {
+    else if ((dtype == CZ_F16C8 || dtype == CZ_F16C6 || dtype == CZ_F16C86) && channels == 192 && parts == 2) {
+        // 192 filters: the two-image in-place block on c8, on c6 (round 6), or as the tower's first c6 block behind the input
+        // layer's c8 image (CZ_F16C86: the first filter is cz_conv3x3_c8_pack_weights', the second cz_conv3x3_c6_pack_weights')
         const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
-        hipLaunchKernelGGL((k_resblock_ip_c8<192>), dim3(blocks), dim3(192 / 32 * 64 + ip::COPY_THREADS), 0, st,
-                           (const _Float16*)x_hi, (const unsigned char*)x_lo, w1_packed, bias1, w2_packed, bias2,
-                           (_Float16*)y_hi, (unsigned char*)y_lo, y_f32, n_boards, g_q.n_dev);
+        ip::Chain ch{};
+        ch.n = 1;
+        ch.w1[0] = w1_packed; ch.w2[0] = w2_packed; ch.b1[0] = bias1; ch.b2[0] = bias2;
+#define CZ_IP_LAUNCH(XF, YF) hipLaunchKernelGGL((k_resblock_ip_c8<192, XF, YF>), dim3(blocks), dim3(192 / 32 * 64 + ip::COPY_THREADS), 0, st, \
+                           (const _Float16*)x_hi, (const unsigned char*)x_lo, ch, \
+                           (_Float16*)y_hi, (unsigned char*)y_lo, y_f32, n_boards, g_q.n_dev)
+        if (dtype == CZ_F16C8) CZ_IP_LAUNCH(0, 0);
+        else if (dtype == CZ_F16C6) CZ_IP_LAUNCH(1, 1);
+        else CZ_IP_LAUNCH(0, 1);
+#undef CZ_IP_LAUNCH
         rc = hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
     }
     if (rc == CZ_ERR_ARG)
@@ -2873,6 +3002,49 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
     else if (rc != CZ_OK)
         czi_set_error("cz_resblock: launch failed");
     return rc;
+}
+
+// n_blocks (1 .. 12) consecutive residual blocks of a 192-filter tower on ONE staged arithmetic in one launch (k_resblock_ip_c8's
+// chain): dtype CZ_F16C8 (c8 blocks) or CZ_F16C6 (c6 blocks behind the tower's first one).  y_f32 != NULL: the last block writes
+// fp32 instead of the operand pair.
+extern "C" int cz_resblock_chain(const void* x_hi, const void* x_img, int n_blocks, const void* const* w1_packed,
+                                 const float* const* bias1, const void* const* w2_packed, const float* const* bias2, void* y_hi,
+                                 void* y_img, float* y_f32, int n_boards, int channels, int dtype, const int32_t* n_dev,
+                                 void* stream)
+{
+    if (n_boards < 0 || !x_hi || !x_img || !w1_packed || !w2_packed || !bias1 || !bias2 || n_blocks < 1 ||
+        n_blocks > ip::MAX_BLOCKS || channels != 192 || (dtype != CZ_F16C8 && dtype != CZ_F16C6) || (!y_f32 && (!y_hi || !y_img))) {
+        czi_set_error("cz_resblock_chain: bad argument (192 filters, 1 .. 12 blocks, dtype CZ_F16C8 or CZ_F16C6; y_f32, or y_hi + y_img)");
+        return CZ_ERR_ARG;
+    }
+    ip::Chain ch{};
+    ch.n = n_blocks;
+    for (int b = 0; b < n_blocks; ++b) {
+        if (!w1_packed[b] || !w2_packed[b] || !bias1[b] || !bias2[b]) {
+            czi_set_error("cz_resblock_chain: null block parameter");
+            return CZ_ERR_ARG;
+        }
+        ch.w1[b] = w1_packed[b]; ch.w2[b] = w2_packed[b]; ch.b1[b] = bias1[b]; ch.b2[b] = bias2[b];
+    }
+    if (n_boards == 0) return CZ_OK;
+    const int n_cu = device_cu_count();
+    if (n_cu < 0) {
+        czi_set_error("cz_resblock_chain: cannot query the device");
+        return CZ_ERR_HIP;
+    }
+    const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == CZ_F16C8)
+        hipLaunchKernelGGL((k_resblock_ip_c8<192, 0, 0>), dim3(blocks), dim3(192 / 32 * 64 + ip::COPY_THREADS), 0, st, (const _Float16*)x_hi,
+                           (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev);
+    else
+        hipLaunchKernelGGL((k_resblock_ip_c8<192, 1, 1>), dim3(blocks), dim3(192 / 32 * 64 + ip::COPY_THREADS), 0, st, (const _Float16*)x_hi,
+                           (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev);
+    if (hipGetLastError() != hipSuccess) {
+        czi_set_error("cz_resblock_chain: launch failed");
+        return CZ_ERR_HIP;
+    }
+    return CZ_OK;
 }
 
 // The input layer and the first residual block in one launch (k_resblock_pipe<FIRST>): the 5 x 5 input convolution of

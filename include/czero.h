@@ -49,6 +49,8 @@ extern "C" {
 #define CZ_F16C8 4   /* fp16 operand + c8 correction image (cz_conv3x3_c8): the residual-block entry points only */
 #define CZ_F16C6 5   /* fp16 operand + c6 correction image (bf6 pieces; cz_conv3x3_c6_pack_weights): cz_resblock(_heads),
                         cz_input_resblock with 128 filters only */
+#define CZ_F16C86 6  /* cz_resblock, 192 filters: the first c6 block of a tower whose input layer wrote a c8 image (x = c8 pair; first
+                      * filter cz_conv3x3_c8_pack_weights', second cz_conv3x3_c6_pack_weights'; y = a c6 pair) */
 
 int cz_version(void);
 const char* cz_last_error(void);
@@ -398,6 +400,15 @@ int cz_tower_pairs(const void* x_hi, const void* x_lo, int n_blocks, const void*
                    const void* const* w2_packed, const float* const* bias2, void* y_hi, void* y_lo, const float* head_w,
                    const float* head_b, float* policy_feat, float* value_feat, int n_policy, int n_value, int n_boards,
                    int dtype, const int32_t* n_dev, void* stream);
+/* cz_resblock_chain (round 6): n_blocks (1 .. 12) consecutive residual blocks of a 192-FILTER tower (the reference's deployed
+ * width, configs/distribute.py:84-87) on one staged arithmetic -- dtype CZ_F16C8, or CZ_F16C6 (c6 blocks behind the tower's first
+ * one, which reads the input layer's c8 image: cz_resblock with CZ_F16C86) -- in ONE launch: a workgroup takes a board through
+ * all blocks in its two LDS images (the in-place second epilogue leaves block b's result as block b + 1's input), HBM sees it at
+ * the entry and the exit.  Bit-identical to n_blocks calls of cz_resblock.  y_f32 != NULL: the last block writes fp32 [n][90][192]
+ * instead of the operand pair (the tower's last block / the hand-over of a c8>N tower). */
+int cz_resblock_chain(const void* x_hi, const void* x_img, int n_blocks, const void* const* w1_packed, const float* const* bias1,
+                      const void* const* w2_packed, const float* const* bias2, void* y_hi, void* y_img, float* y_f32, int n_boards,
+                      int channels, int dtype, const int32_t* n_dev, void* stream);
 int cz_resblock_heads_q(const void* x_hi, const void* x_lo, const void* w1_packed, const float* bias1,
                         const void* w2_packed, const float* bias2, const float* head_w, const float* head_b,
                         float* policy_feat, float* value_feat, int n_boards, int channels, int dtype, int n_policy,

@@ -30,13 +30,15 @@ def centred_logits(p):
     return lg - lg.mean(1, keepdim=True)
 
 
-@pytest.mark.parametrize("blocks", [2, 3])
-def test_c6_tower_matches_its_operand_model(blocks):
-    """2 blocks: fused-input block + heads block; 3: + a plain block in between (all three kernel variants)."""
+@pytest.mark.parametrize("blocks,filters", [(2, 128), (3, 128), (2, 192), (3, 192)])
+def test_c6_tower_matches_its_operand_model(blocks, filters):
+    """128 filters, 2 blocks: fused-input block + heads block; 3: + a plain block in between (all three kernel variants).
+    192 filters (round 6; the reference's deployed width, configs/distribute.py:84-87): k_resblock_ip_c8<192, XF, YF> -- block 0
+    reads the input layer's c8 image (<0, 1>), the others are c6 blocks (<1, 1>), the last one writes fp32."""
     import torch
     import emulate_fp8_corrections as emu
     from cchess_alphazero.agent.model import calibration_planes, guarded_inference_net, reference_forward_f64
-    net = peaked_net(20.0, blocks=blocks)
+    net = peaked_net(20.0, blocks=blocks, filters=filters)
     planes = calibration_planes(40, 14, seed=5)
     g = guarded_inference_net(net, torch.float32, trunk="mfma", arith="c6", guard=False, planes=planes)
     assert g.arith_name == "c6" and g.c6 and g.arith_effective == "c6"
@@ -58,10 +60,11 @@ def test_c6_tower_matches_its_operand_model(blocks):
     assert d_f16 > 8.0 * d_total, (d_f16, d_total)
 
 
-def test_c6_results_do_not_depend_on_the_batch():
+@pytest.mark.parametrize("filters", [128, 192])
+def test_c6_results_do_not_depend_on_the_batch(filters):
     import torch
     from cchess_alphazero.agent.model import calibration_planes, guarded_inference_net
-    net = peaked_net(20.0, blocks=3)
+    net = peaked_net(20.0, blocks=3, filters=filters)
     planes = calibration_planes(1500, 14, seed=9)                # > 5 boards per workgroup on 256 CUs
     g = guarded_inference_net(net, torch.float32, trunk="mfma", arith="c6", guard=False, planes=planes[:256])
     p_all, v_all = (t.clone() for t in g(planes))
@@ -103,9 +106,12 @@ def test_guard_keeps_c6_on_the_benchmark_network_and_leaves_it_where_it_must():
         print(f"policy x{scale:g}: c6 -> {gs.arith_effective} via {names}: policy {ms['policy_max_abs']:.2e} value {ms['value_max_abs']:.2e}")
         assert names[0] == "c6" and gs.arith_requested == "c6"
         assert ms["policy_max_abs"] < 1e-4 and ms["value_max_abs"] < 1e-4
-    # shapes without a c6 kernel degrade to the c8 family
+    # 192 filters have c6 since round 6 (the benchmark's random-init weights keep it there too) ...
     g192 = guarded_inference_net(CChessNet(cnn_filter_num=192, res_layer_num=2).eval(), torch.float32, trunk="mfma", arith="c6")
-    assert g192.arith_effective == "c8"
+    assert g192.arith_effective == "c6" and g192.c6, g192.calibration["candidates"]
+    # ... shapes without a c6 kernel degrade to the c8 family
+    g256 = guarded_inference_net(CChessNet(cnn_filter_num=256, res_layer_num=2).eval(), torch.float32, trunk="mfma", arith="c6")
+    assert g256.arith_effective in ("f16x3", "bf16x3"), g256.arith_effective
     g1 = guarded_inference_net(CChessNet(cnn_filter_num=128, res_layer_num=1).eval(), torch.float32, trunk="mfma", arith="c6")
     assert g1.arith_effective == "c8"
 

@@ -199,8 +199,14 @@ def test_hybrid_and_guard_on_the_192_filter_tower():
         inf = InferenceNet(net, torch.float32, trunk="mfma", arith=arith).cuda()
         assert inf.arith_name == arith
         errs[arith] = measure_against_reference(inf, ref, planes)["logit_max_abs"]
+    # (round 6) c6 at 192 filters, and its hybrids: a c6 block writing the c8 image the c8 blocks behind it read
+    for arith in ("c6", "c6>2", "c6>1"):
+        inf = guarded_inference_net(net, torch.float32, trunk="mfma", arith=arith, guard=False, planes=planes)
+        assert inf.arith_name == arith and inf.c6
+        errs[arith] = measure_against_reference(inf, ref, planes)["logit_max_abs"]
     print("192 filters, logit error:", errs)
     assert errs["f16x3"] < errs["c8>2"] * 1.5 + 1e-9 and errs["c8>2"] < errs["c8"] * 1.5 + 1e-9 and errs["f16x3"] < 0.3 * errs["c8"]
+    assert errs["c8"] * 0.5 < errs["c6>2"] < errs["c6"] * 1.5 + 1e-9 and errs["c6"] < 6.0 * errs["c8"], errs
     g = guarded_inference_net(net, torch.float32, trunk="mfma", arith="c8")
     m = measure_against_reference(g, ref, planes)
     print("guard on 192:", g.arith_effective, m)

@@ -238,7 +238,15 @@ def test_tower_arithmetic_selection_on_the_host(monkeypatch):
     tail = lambda t: t.numpy().view(np.uint8)[-16 - 2 * 128:-2 * 128].view(np.int32).tolist()    # (4 ints, then 2 x 128 row shifts)
     assert tail(i6.tw0a)[2:] == [0, 0] and (i6.tw0a == inf.tw0a).all()            # c8 pack
     assert tail(i6.tw0b)[2:] == [-4, -2] and tail(i6.tw1a)[2:] == [-2, -3] and tail(i6.tw1b)[2:] == [-3, 1]
-    assert InferenceNet(CChessNet(cnn_filter_num=192, res_layer_num=2), torch.float32, trunk="mfma", arith="c6").arith_name == "c8"
+    # 192 filters have c6 since round 6 (the same exponents contract) ...
+    with pytest.raises(ValueError):
+        InferenceNet(CChessNet(cnn_filter_num=192, res_layer_num=2), torch.float32, trunk="mfma", arith="c6")
+    i192 = InferenceNet(CChessNet(cnn_filter_num=192, res_layer_num=2), torch.float32, trunk="mfma", arith="c6", act_exps=([-4, -3], [-2, 1]))
+    assert i192.c6 and i192.arith_name == "c6" and i192.block_kinds() == ["c6", "c6"]
+    tail192 = lambda t: t.numpy().view(np.uint8)[-16 - 2 * 192:-2 * 192].view(np.int32).tolist()
+    assert tail192(i192.tw0a)[2:] == [0, 0] and tail192(i192.tw0b)[2:] == [-4, -2] and tail192(i192.tw1a)[2:] == [-2, -3]
+    # ... 256 filters have neither c6 nor c8: the request degrades to the fp16 pairs
+    assert InferenceNet(CChessNet(cnn_filter_num=256, res_layer_num=2), torch.float32, trunk="mfma", arith="c6").arith_name == "f16x3"
     assert InferenceNet(CChessNet(cnn_filter_num=128, res_layer_num=1), torch.float32, trunk="mfma", arith="c6").arith_name == "c8"
     monkeypatch.setenv("CZ_TOWER_ARITH", "c8")
     assert InferenceNet(net, torch.float32, trunk="mfma").arith == "c8"
@@ -601,6 +609,14 @@ def test_tower_plan_and_block_events():
                             assert all(kinds[i] == pr for i in st[1]) and st[2] == (st[1][-1] + 1 == nblk)
                     assert covered == list(range(nblk)), (kinds, steps)             # every block exactly once, in order
                     assert (steps[-1][0] == "block") == (not hx)
+
+    # 192 filters (cz_resblock_chain): one launch per arithmetic; a c6 tower's block 0 reads the input layer's c8 image on its own
+    from cchess_alphazero.agent.model import ip_segments
+    assert ip_segments([c6] * 10) == [("block", [0]), ("chain", list(range(1, 10)))]
+    assert ip_segments([c8] * 10) == [("chain", list(range(10)))]
+    assert ip_segments([c6] * 3 + [c8] * 7) == [("block", [0]), ("chain", [1, 2]), ("chain", list(range(3, 10)))]
+    assert ip_segments([c8] * 2 + [pr] * 2) == [("chain", [0, 1]), ("block", [2]), ("block", [3])]
+    assert ip_segments([c8] * 14)[0] == ("chain", list(range(12)))        # at most 12 blocks per launch
 
     class Ev:
         def __init__(self, t): self.t = t

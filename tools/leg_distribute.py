@@ -23,6 +23,8 @@ def main():
         n = r["numerics_check"]
         print(json.dumps({"arith": a, "effective": r["net_arith_effective"], "value": r["value"], "ms_per_step": r["ms_per_step"],
                           "block_ms": r["roofline"].get("avg_launch_ms"), "frac": r["roofline"]["frac"],
+                          "by_block": [round(x, 2) for x in r["roofline"].get("launch_ms_by_block") or []],
+                          "plan": r["roofline"].get("launch_plan"), "boards": r["roofline"].get("boards_per_launch"),
                           "logit": n["policy_logit_max_abs_diff"], "value_err": n["value_max_abs_diff"],
                           "within": n["within_tolerance"]}), flush=True)
 
