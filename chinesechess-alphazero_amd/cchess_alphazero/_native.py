@@ -101,6 +101,8 @@ def _declare(L):
         L.cz_tower.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
         L.cz_resblock_chain.restype = i32
         L.cz_resblock_chain.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+        L.cz_tower_plain.restype = i32
+        L.cz_tower_plain.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
         L.cz_tower_pairs.restype = i32
         L.cz_tower_pairs.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
         L.cz_tower_c6.restype = i32
@@ -544,6 +546,17 @@ def resblock_chain(x, blocks, out=None, out_f32=None, count=None):
                                   _ptr(out_f32), x[0].shape[0], x[0].shape[-1], _pair_code(x), _ptr(count), _stream()),
           "cz_resblock_chain")
     return out_f32 if out_f32 is not None else out
+
+
+def tower_plain(x, blocks, out, count=None):
+    """cz_tower_plain: consecutive 256-filter blocks on plain fp16 / bf16 operands (a BlockList or list, 1 .. 24) in one launch;
+    x / out: [N, 90, 256] tensors.  Bit-identical to len(blocks) resblock() calls with one-part operands."""
+    require_gpu()
+    bl = _block_list(blocks)
+    a = bl.arrays
+    check(lib().cz_tower_plain(_ptr(x), bl.n, a[0], a[1], a[2], a[3], _ptr(out), x.shape[0], x.shape[-1], _dt_code(x.dtype),
+                               _ptr(count), _stream()), "cz_tower_plain")
+    return out
 
 
 def tower_pairs(x, blocks, out=None, heads=None, count=None):

@@ -436,6 +436,26 @@ class InferenceNet(nn.Module):
             return self._tower_chained(planes, cur, nxt, last, heads, rows, count, masks)
         if fused and c == 192 and self.parts == 2 and self.arith == "c8" and self.chain_blocks:
             return self._tower_192(cur, nxt, last, count)
+        if fused and c == 256 and self.parts == 1 and self.chain_blocks:
+            # the deep tower on plain operands: all blocks in one cz_tower_plain launch (24 at most per launch)
+            key = ("plan256", self.tb0a.data_ptr())
+            if key not in self._bufs:
+                self._bufs[key] = [_native.BlockList([self._block_params(i) for i in range(lo, min(nblk, lo + 24))])
+                                   for lo in range(0, nblk, 24)]
+            self.last_plan = [("chain256", list(range(24 * j, 24 * j + bl.n)), "plain") for j, bl in enumerate(self._bufs[key])]
+            x = cur[0]
+            for j, bl in enumerate(self._bufs[key]):
+                ev = None
+                if self.block_events is not None:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                y = last if j + 1 == len(self._bufs[key]) else nxt[0]
+                _native.tower_plain(x, bl, y, count=count)
+                x = y
+                if ev is not None:
+                    ev[1].record()
+                    self.block_events.append(ev + (bl.n,) if bl.n > 1 else ev)
+            return last
         for i in range(nblk):
             w1 = getattr(self, f"tw{i}a").view(self.operand_dtype)
             w2 = getattr(self, f"tw{i}b").view(self.operand_dtype)

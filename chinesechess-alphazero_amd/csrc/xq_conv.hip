@@ -627,6 +627,157 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
     }
 }
 
+// ---- kernel 2p: a CHAIN of residual blocks on plain 2-byte operands (256 filters: the `deep` 20 x 256 fp16 tower) ---------------
+// k_resblock<E, 256, 1, 1, false, 2> keeps X | Y | a staging image and sends every block's result through the copy waves to HBM and
+// back.  With one board per workgroup and plain operands the second epilogue can write its result IN PLACE over the skip operand
+// (a lane reads and writes only its own 8 bytes), which is block b + 1's input: a workgroup takes a board through ALL blocks of
+// the tower in X | Y, HBM sees it at the entry and the exit, the matrix waves never wait for a refill between blocks.  Same K loop
+// (conv_kloop, two channel tiles per wave) and the same epilogue arithmetic in the same order: bit-identical to ch.n launches of
+// k_resblock (BASELINE configs[4]; reference tower agent/model.py:41-43).
+namespace pl {
+constexpr int MAX_BLOCKS = 24;
+struct Chain {
+    const void* w1[MAX_BLOCKS];
+    const void* w2[MAX_BLOCKS];
+    const float* b1[MAX_BLOCKS];
+    const float* b2[MAX_BLOCKS];
+    int n;
+};
+}  // namespace pl
+
+template <typename E, int C, int CTW>
+__global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4) void k_tower_plain(
+    const E* __restrict__ xh, pl::Chain ch, E* __restrict__ yh, int n_boards, const int32_t* __restrict__ n_dev)
+{
+    if (n_dev) {
+        const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
+        n_boards = nd < n_boards ? nd : n_boards;
+    }
+    typedef Geom<C, 1, 1> G;
+    constexpr int NT = G::NT, CT = G::CT / CTW, CTHR = RB_COPY_THREADS;
+    constexpr int LITER = (G::CHUNKS + CTHR - 1) / CTHR;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::REGION];
+    unsigned char* X = lds;
+    unsigned char* Y = lds + G::REGION;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NB = ch.n;
+    int t = blockIdx.x;
+    if (t >= n_boards) return;
+    const int stride = gridDim.x;
+
+    if (wave >= CT) {                                   // ---- copy waves ----
+        const int ctid = tid - CT * 64;
+        uint4 v[1][LITER];
+        tile_load<E, C, 1, 1, CTHR>(xh, nullptr, t, n_boards, ctid, v);
+        tile_write<C, 1, 1, CTHR>(X, ctid, v);
+        zero_rows_write<C, 1, 1, CTHR>(X, ctid);
+        zero_rows_write<C, 1, 1, CTHR>(Y, ctid);
+        for (;;) {
+            __syncthreads();                                   // A: X holds board t
+            const int tn = t + stride;
+            const bool has_next = tn < n_boards;
+            int ct2 = ctid;
+            asm volatile("" : "+v"(ct2));
+            if (has_next) tile_load<E, C, 1, 1, CTHR>(xh, nullptr, tn, n_boards, ct2, v);
+            for (int b = 0; b < NB; ++b) {
+                __syncthreads();                               // B
+                __syncthreads();                               // C: block b's result is in X
+            }
+            // the chain's result to HBM; the same chunks take the next board
+            uint4* dst = reinterpret_cast<uint4*>(yh + (size_t)t * 90 * C);
+#pragma unroll
+            for (int it = 0; it < LITER; ++it) {
+                const int i = it * CTHR + ct2;
+                if (!((it + 1) * CTHR <= G::CHUNKS || i < G::CHUNKS)) continue;
+                const int row = i / G::CPR, chn = i % G::CPR;
+                unsigned char* a = X + row * G::RB + ((chn ^ (row & G::SWZ)) << 4);
+                const uint4 o = *reinterpret_cast<const uint4*>(a);
+                if (has_next) *reinterpret_cast<uint4*>(a) = v[0][it];
+                dst[i] = o;
+            }
+            if (!has_next) break;
+            t = tn;
+        }
+        return;
+    }
+
+    // ---- matrix waves ----
+    const int wg = wave * CTW;                                 // first channel tile of this wave
+    const int kb = lane >> 5, ln = lane & 31;
+    for (;;) {
+        __syncthreads();                                       // A
+        const bool has_next = t + stride < n_boards;
+        for (int blk = 0; blk < NB; ++blk) {
+            const uint4* wq1 = reinterpret_cast<const uint4*>(ch.w1[blk]) + wg * 64 + lane;
+            const uint4* wq2 = reinterpret_cast<const uint4*>(ch.w2[blk]) + wg * 64 + lane;
+            const float* b1 = ch.b1[blk];
+            const float* b2 = ch.b2[blk];
+            f32x16 acc[CTW * NT];
+            __builtin_amdgcn_s_setprio(3);
+            conv_kloop<E, C, 1, 1, CTW>(X, wq1, lane, acc);
+            __builtin_amdgcn_s_setprio(0);
+            int ln2 = ln, kb2 = kb;
+            asm volatile("" : "+v"(ln2), "+v"(kb2));
+            // epilogue 1: relu(acc + b1) -> Y (k_resblock's)
+#pragma unroll
+            for (int cp = 0; cp < CTW * NT; ++cp) {
+                const int p = cp % NT, c = cp / NT;
+                const int q = p * 32 + ln2;
+                if (q < 90) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int chn = (wg + c) * 32 + g * 8 + kb2 * 4;
+                        const float4 bv = *reinterpret_cast<const float4*>(b1 + chn);
+                        const float vv[4] = {acc[cp][g * 4 + 0] + bv.x, acc[cp][g * 4 + 1] + bv.y, acc[cp][g * 4 + 2] + bv.z,
+                                             acc[cp][g * 4 + 3] + bv.w};
+                        const int off = q * G::RB + (((chn >> 3) ^ (q & G::SWZ)) << 4) + (chn & 7) * 2;
+                        Quad<E> hi;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float r = vv[i] > 0.0f ? vv[i] : 0.0f;
+                            hi.e[i] = (E)r;
+                        }
+                        *reinterpret_cast<Quad<E>*>(Y + off) = hi;
+                    }
+                }
+            }
+            __syncthreads();                                   // B: Y complete
+            __builtin_amdgcn_s_setprio(3);
+            conv_kloop<E, C, 1, 1, CTW>(Y, wq2, lane, acc);
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("" : "+v"(ln2), "+v"(kb2));
+            // epilogue 2: relu(acc + b2 + x) -> X, in place over the skip operand (this lane's own 8 bytes)
+#pragma unroll
+            for (int cp = 0; cp < CTW * NT; ++cp) {
+                const int p = cp % NT, c = cp / NT;
+                const int q = p * 32 + ln2;
+                if (q < 90) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int chn = (wg + c) * 32 + g * 8 + kb2 * 4;
+                        const float4 bv = *reinterpret_cast<const float4*>(b2 + chn);
+                        const int off = q * G::RB + (((chn >> 3) ^ (q & G::SWZ)) << 4) + (chn & 7) * 2;
+                        const Quad<E> sh = *reinterpret_cast<const Quad<E>*>(X + off);
+                        float vv[4] = {acc[cp][g * 4 + 0] + bv.x, acc[cp][g * 4 + 1] + bv.y, acc[cp][g * 4 + 2] + bv.z,
+                                       acc[cp][g * 4 + 3] + bv.w};
+                        Quad<E> o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            vv[i] += (float)sh.e[i];
+                            vv[i] = vv[i] > 0.0f ? vv[i] : 0.0f;
+                            o.e[i] = (E)vv[i];
+                        }
+                        *reinterpret_cast<Quad<E>*>(X + off) = o;
+                    }
+                }
+            }
+            __syncthreads();                                   // C: the block's result is in X
+        }
+        if (!has_next) break;
+        t += stride;
+    }
+}
+
 #ifdef CZ_RB_STAMPS
 // timing build (tools/rb_stamps.py; never the default library): shader-cycle stamps of one matrix wave's and one copy
 // wave's sections of one steady-state board of k_resblock_c8
@@ -3042,6 +3193,47 @@ extern "C" int cz_resblock_chain(const void* x_hi, const void* x_img, int n_bloc
                            (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev);
     if (hipGetLastError() != hipSuccess) {
         czi_set_error("cz_resblock_chain: launch failed");
+        return CZ_ERR_HIP;
+    }
+    return CZ_OK;
+}
+
+// n_blocks (1 .. 24) consecutive residual blocks of a 256-filter tower on plain fp16 / bf16 operands in one launch
+// (k_tower_plain): the `deep` 20 x 256 configuration is ONE launch.  Filters: cz_conv3x3_pack_weights(parts = 1).
+extern "C" int cz_tower_plain(const void* x, int n_blocks, const void* const* w1_packed, const float* const* bias1,
+                              const void* const* w2_packed, const float* const* bias2, void* y, int n_boards, int channels,
+                              int dtype, const int32_t* n_dev, void* stream)
+{
+    if (n_boards < 0 || !x || !y || !w1_packed || !w2_packed || !bias1 || !bias2 || n_blocks < 1 || n_blocks > pl::MAX_BLOCKS ||
+        channels != 256 || (dtype != CZ_F16 && dtype != CZ_BF16)) {
+        czi_set_error("cz_tower_plain: bad argument (256 filters, plain f16 / bf16 operands, 1 .. 24 blocks)");
+        return CZ_ERR_ARG;
+    }
+    pl::Chain ch{};
+    ch.n = n_blocks;
+    for (int b = 0; b < n_blocks; ++b) {
+        if (!w1_packed[b] || !w2_packed[b] || !bias1[b] || !bias2[b]) {
+            czi_set_error("cz_tower_plain: null block parameter");
+            return CZ_ERR_ARG;
+        }
+        ch.w1[b] = w1_packed[b]; ch.w2[b] = w2_packed[b]; ch.b1[b] = bias1[b]; ch.b2[b] = bias2[b];
+    }
+    if (n_boards == 0) return CZ_OK;
+    const int n_cu = device_cu_count();
+    if (n_cu < 0) {
+        czi_set_error("cz_tower_plain: cannot query the device");
+        return CZ_ERR_HIP;
+    }
+    const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == CZ_F16)
+        hipLaunchKernelGGL((k_tower_plain<_Float16, 256, 2>), dim3(blocks), dim3((256 / 32 / 2 + 4) * 64), 0, st, (const _Float16*)x, ch,
+                           (_Float16*)y, n_boards, n_dev);
+    else
+        hipLaunchKernelGGL((k_tower_plain<__bf16, 256, 2>), dim3(blocks), dim3((256 / 32 / 2 + 4) * 64), 0, st, (const __bf16*)x, ch,
+                           (__bf16*)y, n_boards, n_dev);
+    if (hipGetLastError() != hipSuccess) {
+        czi_set_error("cz_tower_plain: launch failed");
         return CZ_ERR_HIP;
     }
     return CZ_OK;

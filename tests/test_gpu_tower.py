@@ -170,6 +170,29 @@ def test_192_filter_tower_chains_are_bit_identical(arith, blocks):
     assert torch.equal(p0[:333], p1[:333]) and torch.equal(v0[:333], v1[:333])
 
 
+@pytest.mark.parametrize("dtype,blocks", [("float16", 20), ("float16", 3), ("bfloat16", 5), ("float16", 26)])
+def test_deep_tower_on_plain_operands_is_one_launch(dtype, blocks):
+    """cz_tower_plain (BASELINE configs[4]: 20 x 256, fp16 MFMA evaluation): all blocks of a 256-filter tower on plain 2-byte
+    operands in one launch (24 at most), a board staying in the workgroup's two LDS images.  Equal to one k_resblock launch per
+    block."""
+    import torch
+    from cchess_alphazero.agent.model import CChessNet, InferenceNet, calibration_planes
+    torch.manual_seed(13)
+    net = CChessNet(cnn_filter_num=256, res_layer_num=blocks).eval()
+    planes_all = calibration_planes(600, 14, seed=41)
+    g = InferenceNet(net, getattr(torch, dtype), trunk="mfma").cuda()
+    assert g.parts == 1 and g.filters == 256
+    for n in (1, 37, 300, 600):
+        planes = planes_all[:n].contiguous()
+        g.chain_blocks = False
+        (p0, v0), l0 = _launches(g, planes)
+        assert l0 == [1] * blocks, l0
+        g.chain_blocks = True
+        (p1, v1), l1 = _launches(g, planes)
+        assert l1 == ([24, blocks - 24] if blocks > 24 else [blocks]), l1
+        assert torch.isfinite(p1).all() and torch.equal(p0, p1) and torch.equal(v0, v1), (dtype, blocks, n, (p0 - p1).abs().max().item())
+
+
 def test_tower_entry_points_reject_what_they_cannot_run():
     import torch
     from cchess_alphazero import _native
