@@ -80,6 +80,27 @@ def test_network_with_handed_in_masks_is_identical(arith):
         assert torch.equal(pc[:211], p0[sel]) and torch.equal(vc[:211], v0[sel]), (arith, depth)
 
 
+def test_masks_reach_the_fused_input_layer_with_other_head_widths():
+    """a network whose heads do not have 4 + 2 filters (CChessNet(policy_filters=..., value_filters=...), reachable
+    through lib/keras_io.py) runs the generic head path -- takes_masks() is still True for it, the engine switches the planes
+    off, so that path must hand the occupancy boards to the fused input layer too: same outputs from the planes, from the
+    boards with the planes poisoned, and within 1e-4 of the fp32 module."""
+    import torch
+    from cchess_alphazero.agent.model import CChessNet, InferenceNet, calibration_planes
+    torch.manual_seed(5)
+    net = CChessNet(cnn_filter_num=128, res_layer_num=3, policy_filters=2, value_filters=1).eval()
+    planes = calibration_planes(300, 14, seed=19)
+    masks = _masks_from_planes(planes).contiguous()
+    g = InferenceNet(net, torch.float32, trunk="mfma", arith="f16x3").cuda()
+    assert g.head_w32.shape[0] == 3 and g.takes_masks()
+    p0, v0 = (t.clone() for t in g(planes))
+    p1, v1 = g(torch.full_like(planes, 255), masks=masks)
+    assert torch.equal(p0, p1) and torch.equal(v0, v1)
+    with torch.no_grad():
+        pr, vr = net(planes.float().cpu())
+    assert (p0.cpu() - pr).abs().max().item() < 1e-4 and (v0.cpu() - vr).abs().max().item() < 1e-4
+
+
 @pytest.mark.parametrize("use_history", [False, True])
 def test_leaves_as_occupancy_boards_only(use_history):
     """cz_search_leaf_planes(0): the kernel writes the boards and leaves the planes alone; queue_planes() rebuilds the same
