@@ -964,24 +964,67 @@ def c6_exponents(activation_max, headroom=None):
     return k[1::2], k[2::2]
 
 
-def guard_chain(arith, c8_blocks, n_blocks, activation_max):
-    """The candidates guarded_inference_net tries, most reduced first, for a requested arithmetic family and the tower's
-    measured activation ranges: a c8 image saturates above 448 (such a tower is not even tried), fp16 pairs overflow at
-    65504 (kept a factor of two away), bf16 pairs have fp32's range."""
-    chain = []
+def guard_search(arith, c8_blocks, n_blocks, activation_max, passes):
+    """The load-time guard's walk over the tower arithmetics, most reduced first, for a requested arithmetic and the
+    tower's measured activation ranges; passes(name) -> bool measures one candidate (called once per name).  Returns
+    (chosen or None, names in the order they were measured).
+
+      c6 family   the request itself; if it fails, plain c8 is measured next -- a c6>k hybrid runs its remaining blocks on
+                  c8 and its c6 blocks are the coarser ones, so where c8 fails the hybrids are not tried; where c8 passes,
+                  c6>k for k = n6-1 .. 1, and c8 itself if none of them does
+      c8 family   c8>k for k = c8_blocks .. 2, one block at a time (round 6: the stand-in for a trained network passes at
+                  c8>4, which the round-5 steps N, N-2, N-4 never tried).  c8>1 only where it is the request: a tower whose
+                  only c8 block is the first has no fused input launch and no chain (_trunk_mfma) -- slower than f16x3
+      pairs       f16x3, then bf16x3
+
+    A c8 image saturates above 448 (such a tower is not even tried; bf6 images carry their own exponents, so plain c6 is,
+    its hybrids -- a c8 hand-over image -- are not), fp16 pairs overflow at 65504 (kept a factor of two away), bf16 pairs
+    have fp32's range."""
+    seen, order = {}, []
+
+    def ok(name):
+        if name not in seen:
+            order.append(name)
+            seen[name] = bool(passes(name))
+        return seen[name]
+
+    def hyb(fam, k):
+        return fam if k >= n_blocks else f"{fam}>{k}"
+
     top = max(activation_max) if activation_max else 0.0
-    if arith == "c6" or arith.startswith("c6>"):     # (the bf6 images carry their own exponents; the fused input layer's is c8)
-        n6 = int(arith[3:]) if arith.startswith("c6>") else n_blocks
-        # hybrids hand a c8 image over to c8 blocks: only where that image holds the activations
-        steps = (n6, n6 - 2, n6 - 4) if top <= 448.0 else ((n6,) if n6 == n_blocks else ())
-        chain += [f"c6>{k}" if k < n_blocks else "c6" for k in steps if k >= 1]
-        arith, c8_blocks = "c8", n_blocks
-    if arith == "c8" and top <= 448.0:
-        chain += [f"c8>{k}" if k < n_blocks else "c8" for k in (c8_blocks, c8_blocks - 2, c8_blocks - 4) if k >= 1]
-    if arith in ("c8", "f16x3") and top < 3.0e4:
-        chain.append("f16x3")
-    chain.append("bf16x3")
-    return chain
+    c8_fits = top <= 448.0
+    fam = arith.split(">")[0]
+    if fam == "c6":
+        n6 = int(arith[3:]) if ">" in arith else n_blocks
+        if (n6 >= n_blocks or c8_fits) and ok(hyb("c6", n6)):
+            return hyb("c6", n6), order
+        if c8_fits and ok("c8"):
+            for k in range(min(n6, n_blocks) - 1, 0, -1):
+                if ok(hyb("c6", k)):
+                    return hyb("c6", k), order
+            return "c8", order
+        fam, c8_blocks = "c8", n_blocks
+    if fam == "c8" and c8_fits:
+        for k in range(c8_blocks, min(c8_blocks, 2) - 1, -1):
+            if ok(hyb("c8", k)):
+                return hyb("c8", k), order
+    if fam in ("c8", "f16x3") and top < 3.0e4 and ok("f16x3"):
+        return "f16x3", order
+    if ok("bf16x3"):
+        return "bf16x3", order
+    return None, order
+
+
+def next_more_exact(name, n_blocks):
+    """The request one step below a running arithmetic (engine.demote_arith after a failed live audit): one reduced block
+    fewer, then the next family; None below bf16x3."""
+    fam, _, k = name.partition(">")
+    k = int(k) if k else n_blocks
+    if fam == "c6":
+        return f"c6>{k - 1}" if k > 1 else "c8"
+    if fam == "c8":
+        return f"c8>{k - 1}" if k > 2 else "f16x3"              # (c8>1: no fused launches, see guard_search)
+    return "bf16x3" if fam == "f16x3" else None
 
 
 def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", arith=None, device=None, tol=GUARD_TOL,
@@ -1050,24 +1093,33 @@ def guarded_inference_net(net: CChessNet, dtype=torch.float32, trunk="mfma", ari
             first.calibration = report
             if not guard:
                 return first
-        chain = guard_chain(requested if c6 else first.arith, first.c8_blocks, nblk, scaled)
-        cand = first if (shift is None or c6) else None
-        for name in chain:
-            if cand is None or cand.arith_name != name:
+        built = {first.arith_name: first} if (shift is None or c6) else {}
+
+        def passes(name):
+            # (one candidate alive at a time besides the requested one: packed filters of seven arithmetics add up)
+            cand = built.pop(name, None)
+            if cand is None:
                 cand = InferenceNet(net, dtype, trunk=trunk, arith=name, act_shift=shift,
                                     act_exps=exps if name.startswith("c6") else None).to(dev)
             m = measure_against_reference(cand, ref, planes, legal)
             m["arith"] = name
             report["candidates"].append(m)
             if within_guard(m, tol):
-                break
-            cand = None
-        else:
+                built[name] = cand
+                return True
+            return False
+
+        name, tried = guard_search(requested if c6 else first.arith, first.c8_blocks, nblk, scaled, passes)
+        if name is None:
             logger.warning("no split arithmetic keeps this network within %g of float64 (%s): using the fp32 library trunk",
                            tol, report["candidates"])
             cand = InferenceNet(net, dtype, trunk="library").to(dev)
             name = "fp32-library"
-            chain = chain + [name]
+        else:
+            cand = built[name]
+        built.clear()
+        report["tried"] = tried + (["fp32-library"] if name == "fp32-library" else [])
+        report["chosen"] = next((m for m in report["candidates"] if m["arith"] == name), None)
         if name != first.arith_name:
             logger.warning("tower arithmetic %s deviates from the float64 network by more than %g (policy / value / legal "
                            "priors) or %g (logits) on the calibration positions (%s): using %s", requested, tol, LOGIT_TOL,

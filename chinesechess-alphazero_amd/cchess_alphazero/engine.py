@@ -157,7 +157,7 @@ class SelfPlayEngine:
         planes = self.search.queue_planes(rows=rows) if rows is not None else self.queue_planes(n)
         if planes.dtype != torch.uint8:
             planes = (planes != 0).to(torch.uint8)
-        planes = planes[planes.flatten(1).any(1)].contiguous()          # (a slot no leaf was ever written to is an empty board)
+        planes = planes[planes.flatten(1).ne(0).any(1)].contiguous()          # (a slot no leaf was ever written to is an empty board)
         if planes.shape[0] == 0:
             return None
         m = measure_against_reference(self.net, reference_forward_f64(self._ref_net, planes), planes)
@@ -170,13 +170,15 @@ class SelfPlayEngine:
         return m
 
     def demote_arith(self):
-        """Lower the REQUESTED tower arithmetic one step towards exactness (c6 -> c8 -> f16x3 -> bf16x3) below what is
-        running now; the next _build_net / set_network starts its guard chain there.  False when there is nothing below."""
-        order = ["c6", "c8", "f16x3", "bf16x3"]
-        cur = (self.net_arith_effective or "bf16x3").split(">")[0]
-        if cur not in order or order.index(cur) + 1 >= len(order):
+        """Lower the REQUESTED tower arithmetic one step towards exactness below what is running now (one reduced block
+        fewer -- c6 -> c6>N-1 -> ... -> c6>1 -> c8 -> c8>N-1 -> ... -> f16x3 -> bf16x3; agent/model.py next_more_exact); the
+        next _build_net / set_network starts its guard there.  False when there is nothing below."""
+        from cchess_alphazero.agent.model import next_more_exact
+        cur = self.net_arith_effective or "bf16x3"
+        nxt = next_more_exact(cur, len(self.net.res)) if cur.split(">")[0] in ("c6", "c8", "f16x3") else None
+        if nxt is None:
             return False
-        self.arith = order[order.index(cur) + 1]
+        self.arith = nxt
         return True
 
     def start(self, first_game_id=0, game_id_stride=0):

@@ -426,8 +426,10 @@ def test_engine_keeps_its_network_when_a_reload_fails_and_audits_live_positions(
     c = w.run(max_rounds=4)                                  # the games go on
     assert c["expansions"] > 0
     monkeypatch.undo()
-    # (b) a failing audit: the request steps down and the network is rebuilt through the guard
+    # (b) a failing audit: the request steps down -- one reduced block fewer -- and the network is rebuilt through the guard
     monkeypatch.setattr(type(w.engine), "audit_network", lambda self, n=64: {"ok": False, "arith": self.net_arith_effective})
+    w.audit()
+    assert w.engine.arith == "c6>1" and w.engine.net_arith_effective == "c6>1"
     w.audit()
     assert w.engine.arith == "c8" and w.engine.net_arith_effective == "c8"
     with torch.no_grad():

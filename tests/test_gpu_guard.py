@@ -99,9 +99,10 @@ def test_peaked_policy_networks_stay_within_tolerance(policy_scale, min_peak):
           f"(margin {1e-4 / max(m['policy_max_abs'], 1e-30):.1f}x), candidates {g.calibration['candidates']}")
     assert g.arith_requested == "c8" and g.calibration["max_policy_probability"] >= min_peak
     assert m["policy_max_abs"] < 5e-5 and m["value_max_abs"] < 5e-5, (g.arith_effective, m)
-    last = g.calibration["candidates"][-1]
-    assert g.arith_effective in (last["arith"], "fp32-library") and \
-        (g.arith_effective == "fp32-library" or last["policy_max_abs"] <= g.calibration["tol"])
+    last = g.calibration["chosen"]
+    assert g.arith_effective == "fp32-library" or \
+        (g.arith_effective == last["arith"] and last["policy_max_abs"] <= g.calibration["tol"])
+    assert [r["arith"] for r in g.calibration["candidates"]] == [n for n in g.calibration["tried"] if n != "fp32-library"]
 
 
 def test_guard_keeps_the_requested_arithmetic_where_it_is_exact_enough():
@@ -271,8 +272,8 @@ def test_guard_sees_an_error_that_hides_behind_an_illegal_peak():
     assert not within_guard(m)
     g = guarded_inference_net(net, torch.float32, trunk="mfma", arith="c6")
     assert g.arith_effective != "c6" and g.calibration["candidates"][0]["arith"] == "c6"
-    last = g.calibration["candidates"][-1]
-    assert g.arith_effective == "fp32-library" or within_guard(last)
+    last = g.calibration["chosen"]
+    assert g.arith_effective == "fp32-library" or (last["arith"] == g.arith_effective and within_guard(last))
     fresh, fresh_legal = calibration_planes(192, 14, seed=4242, with_legal=True)
     mf = measure_against_reference(g, reference_forward_f64(net, fresh), fresh, fresh_legal)
     print(f"guard: c6 -> {g.arith_effective}; fresh positions: {mf}")

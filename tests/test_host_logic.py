@@ -404,22 +404,46 @@ def test_compact_line_of_a_fat_record():
 
 
 def test_guard_chain_orders_the_candidates_by_exactness():
-    """agent/model.py guard_chain: which tower arithmetics the load-time guard tries for a request and a tower's measured
-    activation ranges (c8 image saturates at 448, fp16 pairs overflow at 65504)."""
-    from cchess_alphazero.agent.model import guard_chain
-    assert guard_chain("c8", 7, 7, [3.0, 9.5]) == ["c8", "c8>5", "c8>3", "f16x3", "bf16x3"]
-    assert guard_chain("c6", 7, 7, [3.0, 9.5]) == ["c6", "c6>5", "c6>3", "c8", "c8>5", "c8>3", "f16x3", "bf16x3"]
-    assert guard_chain("c6>5", 7, 7, [3.0, 9.5]) == ["c6>5", "c6>3", "c6>1", "c8", "c8>5", "c8>3", "f16x3", "bf16x3"]
-    assert guard_chain("c6", 2, 2, [1.0]) == ["c6", "c8", "f16x3", "bf16x3"]
+    """agent/model.py guard_search: which tower arithmetics the load-time guard measures, in which order, for a request, a
+    tower's measured activation ranges (c8 image saturates at 448, fp16 pairs overflow at 65504) and the candidates that
+    pass; next_more_exact: the request below a running arithmetic after a failed live audit."""
+    from cchess_alphazero.agent.model import guard_search, next_more_exact
+
+    def walk(arith, c8b, n, amax, good):
+        return guard_search(arith, c8b, n, amax, lambda name: name in good)
+    small = [3.0, 9.5]
+    assert walk("c6", 7, 7, small, {"c6"}) == ("c6", ["c6"])
+    assert walk("c8", 7, 7, small, {"c8", "f16x3"}) == ("c8", ["c8"])
+    # round 6's stand-in for a trained network: passes from c8>4 down -- found one block at a time, the c6 hybrids skipped
+    peaked = {"c8>4", "c8>3", "c8>2", "c8>1", "f16x3", "bf16x3"}
+    assert walk("c6", 7, 7, small, peaked) == ("c8>4", ["c6", "c8", "c8>6", "c8>5", "c8>4"])
+    assert walk("c8", 7, 7, small, peaked) == ("c8>4", ["c8", "c8>6", "c8>5", "c8>4"])
+    assert walk("c8>3", 3, 7, small, peaked) == ("c8>3", ["c8>3"])
+    # c8 passes, c6 does not: the c6 hybrids, most c6 blocks first; c8 itself where none of them does
+    assert walk("c6", 7, 7, small, {"c8", "c6>2", "c6>1"}) == ("c6>2", ["c6", "c8", "c6>6", "c6>5", "c6>4", "c6>3", "c6>2"])
+    assert walk("c6", 3, 3, small, {"c8"}) == ("c8", ["c6", "c8", "c6>2", "c6>1"])
+    assert walk("c6>5", 7, 7, small, {"c8", "c6>4"}) == ("c6>4", ["c6>5", "c8", "c6>4"])
+    assert walk("c6", 2, 2, [1.0], {"f16x3"}) == ("f16x3", ["c6", "c8", "f16x3"])
+    assert walk("c8>1", 1, 7, small, {"c8>1"}) == ("c8>1", ["c8>1"])                # (not a candidate unless it is the request)
+    # nothing passes: every family in turn, then None (the caller's fp32 library trunk)
+    assert walk("c6", 3, 3, small, set()) == (None, ["c6", "c8", "c8>2", "f16x3", "bf16x3"])
+    assert walk("c8", 5, 7, [3.0], set()) == (None, ["c8>5", "c8>4", "c8>3", "c8>2", "f16x3", "bf16x3"])
     # (bf6 images carry their own exponents: plain c6 is tried beyond 448, the hybrids -- a c8 hand-over image -- are not)
-    assert guard_chain("c6", 7, 7, [3.0, 500.0]) == ["c6", "f16x3", "bf16x3"]
-    assert guard_chain("c6>5", 7, 7, [3.0, 500.0]) == ["f16x3", "bf16x3"]
-    assert guard_chain("c8", 5, 7, [3.0]) == ["c8>5", "c8>3", "c8>1", "f16x3", "bf16x3"]
-    assert guard_chain("c8", 2, 2, [1.0]) == ["c8", "f16x3", "bf16x3"]
-    assert guard_chain("c8", 7, 7, [3.0, 500.0]) == ["f16x3", "bf16x3"]
-    assert guard_chain("c8", 7, 7, [4.0e4]) == ["bf16x3"]
-    assert guard_chain("f16x3", 0, 7, [3.0]) == ["f16x3", "bf16x3"]
-    assert guard_chain("bf16x3", 0, 7, [3.0]) == ["bf16x3"]
+    assert walk("c6", 7, 7, [3.0, 500.0], {"bf16x3"}) == ("bf16x3", ["c6", "f16x3", "bf16x3"])
+    assert walk("c6>5", 7, 7, [3.0, 500.0], {"f16x3"}) == ("f16x3", ["f16x3"])
+    assert walk("c8", 7, 7, [3.0, 500.0], set()) == (None, ["f16x3", "bf16x3"])
+    assert walk("c8", 7, 7, [4.0e4], {"bf16x3"}) == ("bf16x3", ["bf16x3"])
+    assert walk("f16x3", 0, 7, [3.0], set()) == (None, ["f16x3", "bf16x3"])
+    assert walk("bf16x3", 0, 7, [3.0], {"bf16x3"}) == ("bf16x3", ["bf16x3"])
+    calls = []
+    guard_search("c6", 7, 7, small, lambda name: calls.append(name) or False)
+    assert len(calls) == len(set(calls))                                            # each candidate is measured once
+    steps, cur = [], "c6"
+    while cur is not None:
+        steps.append(cur)
+        cur = next_more_exact(cur, 3)
+    assert steps == ["c6", "c6>2", "c6>1", "c8", "c8>2", "f16x3", "bf16x3"]
+    assert next_more_exact("c8>4", 7) == "c8>3" and next_more_exact("c6", 1) == "c8"
     # power-of-two activation scales from the measured ranges [input, b0 mid, b0 out, b1 mid, b1 out]: a common shift for a
     # tower outside [2^-3, 224] (filters untouched), bounded per-tensor deviations against overflow only
     from cchess_alphazero.agent.model import choose_act_shift
