@@ -55,6 +55,8 @@ def declare(L):
     L.cz_search_pv.argtypes = [vp, i32, vp, vp, vp]
     L.cz_search_pv.restype = i32
     L.cz_search_counters.argtypes = [vp, vp, vp]
+    L.cz_search_game_counters.argtypes = [vp, vp, vp]
+    L.cz_search_game_counters.restype = i32
     L.cz_search_drain_records.argtypes = [vp, C.POINTER(C.c_uint), vp, i32, C.POINTER(C.c_int), vp]
     L.cz_debug_sqrt.argtypes = [vp, vp, i32, vp]
     L.cz_debug_noise.argtypes = [C.c_uint64, C.c_uint32, C.c_double, i32, vp, i32, vp]
@@ -373,6 +375,14 @@ class Search:
         out = (C.c_uint64 * self.n_counters)()
         _native.check(self.L.cz_search_counters(self.h, out, self._stream()), "cz_search_counters")
         return {k: int(out[i]) for i, k in enumerate(COUNTER_NAMES[:self.n_counters])}
+
+    def game_counters(self):
+        """The counters per game, before the sum: numpy uint64 [G, n_counters] (columns: COUNTER_NAMES)."""
+        import numpy as np
+        out = np.zeros((self.G, self.n_counters), dtype=np.uint64)
+        _native.check(self.L.cz_search_game_counters(self.h, out.ctypes.data_as(C.c_void_p), self._stream()),
+                      "cz_search_game_counters")
+        return out
 
     def drain_records(self, max_records=4096):
         """Finished games since the last call: list of dict(game_id, turns, value, store, resigned, moves[labels])."""

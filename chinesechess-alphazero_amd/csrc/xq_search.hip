@@ -2308,6 +2308,17 @@ int cz_search_counters(cz_search* s, uint64_t* host_out, void* stream)
     return CZ_OK;
 }
 
+int cz_search_game_counters(cz_search* s, uint64_t* host_out, void* stream)
+{
+    if (!s || !host_out) return serr(CZ_ERR_ARG, "cz_search_game_counters: null argument");
+    static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "counters are 64-bit");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(host_out, s->B.counters, (size_t)s->P.G * CT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return serr_hip("cz_search_game_counters", e);
+    return CZ_OK;
+}
+
 int cz_search_drain_records(cz_search* s, unsigned int* cursor, void* host_buf, int max_records, int* n_out, void* stream)
 {
     if (!s || !cursor || !host_buf || !n_out) return serr(CZ_ERR_ARG, "cz_search_drain_records: null argument");

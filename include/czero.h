@@ -220,6 +220,9 @@ int cz_search_stop(cz_search* s, void* stream);
 int cz_search_choose(cz_search* s, const double* u, int32_t* action, void* stream);
 /* HOST out[n_counters] (order: enum Counter in csrc/xq_search.h); synchronises the stream */
 int cz_search_counters(cz_search* s, uint64_t* host_out, void* stream);
+/* the same counters before the sum over games: HOST out[G][n_counters] (tuning: which game's wavefront a launch waits for,
+ * tools/search_tail.py); synchronises the stream */
+int cz_search_game_counters(cz_search* s, uint64_t* host_out, void* stream);
 /* copies finished-game records (record_stride bytes each) written since *cursor into HOST memory */
 int cz_search_drain_records(cz_search* s, unsigned int* cursor, void* host_buf, int max_records, int* n_out,
                             void* stream);
