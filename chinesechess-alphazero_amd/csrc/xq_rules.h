@@ -334,13 +334,14 @@ XQ_D int wave_catch_list(const int8_t* b, const MoveList& moves, int nmoves,
         const int f = ft >> 8, t = ft & 0xFF;
         const int vict = b[t];
         if (vict == 0) continue;                               // no capture
-        step_board(b, f, t, nextb);
-        const int nr = wave_movegen<true>(nextb, reply, plist);
-        if (first_move_to(reply, nr, 89 - t) >= 0) continue;   // could be recaptured
+        // (the three cheap exclusions first: the reference tests them after be_catched, all four only skip the move)
         const int a = b[f];
         if (a == PAWN && f / 9 <= 4) continue;                 // :443-444
         if (vict == -PAWN && t / 9 > 4) continue;              // :447-448
         if (-vict == a) continue;                              // exchange, :450-451
+        step_board(b, f, t, nextb);
+        const int nr = wave_movegen<true>(nextb, reply, plist);
+        if (first_move_to(reply, nr, 89 - t) >= 0) continue;   // could be recaptured
         const uint32_t key = ((uint32_t)a << 24) | ((uint32_t)f << 16) | ((uint32_t)(-vict) << 8) | (uint32_t)t;
         const bool dup0 = lane < cnt && set[lane] == key;
         const bool dup1 = lane + 64 < cnt && set[lane + 64] == key;
