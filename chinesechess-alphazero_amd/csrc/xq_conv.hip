@@ -553,6 +553,20 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
         __builtin_amdgcn_s_setprio(3);
         conv_kloop<E, C, P, PARTS, CTW>(X, wq1, lane, acc);
         __builtin_amdgcn_s_setprio(0);
+        // the biases of this wave's channels: all loads in flight at once, materialised once (round 6: left to the compiler there
+        // was one load and one vmcnt(0) per 8-byte store -- 4 CTW NT L2 round trips in a row per epilogue, 7 % of the deep tower)
+        f32x4 bq[CTW][4];
+        auto bias_fetch = [&](const float* bp) {
+#pragma unroll
+            for (int c = 0; c < CTW; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bq[c][g] = *reinterpret_cast<const f32x4*>(bp + (wg + c) * 32 + g * 8 + kb * 4);
+#pragma unroll
+            for (int c = 0; c < CTW; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bq[c][g]));
+        };
+        bias_fetch(b1);
         int ln2 = ln, kb2 = kb, gt2 = tid;
         asm volatile("" : "+v"(ln2), "+v"(kb2), "+v"(gt2));
         // epilogue 1: relu(acc + b1) -> (hi, lo) -> Y image (operand layout of the second convolution)
@@ -565,9 +579,9 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int ch = (wg + c) * 32 + g * 8 + kb2 * 4;
-                    const float4 bv = *reinterpret_cast<const float4*>(b1 + ch);
-                    const float vv[4] = {acc[cp][g * 4 + 0] + bv.x, acc[cp][g * 4 + 1] + bv.y, acc[cp][g * 4 + 2] + bv.z,
-                                         acc[cp][g * 4 + 3] + bv.w};
+                    const f32x4 bv = bq[c][g];
+                    const float vv[4] = {acc[cp][g * 4 + 0] + bv[0], acc[cp][g * 4 + 1] + bv[1], acc[cp][g * 4 + 2] + bv[2],
+                                         acc[cp][g * 4 + 3] + bv[3]};
                     const int off = row * G::RB + (((ch >> 3) ^ (row & G::SWZ)) << 4) + (ch & 7) * 2;
                     Quad<E> hi, lo;
 #pragma unroll
@@ -585,6 +599,7 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
         __builtin_amdgcn_s_setprio(3);
         conv_kloop<E, C, P, PARTS, CTW>(Y, wq2, lane, acc);
         __builtin_amdgcn_s_setprio(0);
+        bias_fetch(b2);
         asm volatile("" : "+v"(ln2), "+v"(kb2));
         // epilogue 2: relu(acc + b2 + x) -> staging
 #pragma unroll
@@ -596,11 +611,11 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int ch = (wg + c) * 32 + g * 8 + kb2 * 4;
-                    const float4 bv = *reinterpret_cast<const float4*>(b2 + ch);
+                    const f32x4 bv = bq[c][g];
                     const int off = row * G::RB + (((ch >> 3) ^ (row & G::SWZ)) << 4) + (ch & 7) * 2;
                     const Quad<E> sh = *reinterpret_cast<const Quad<E>*>(X + off);
-                    float vv[4] = {acc[cp][g * 4 + 0] + bv.x, acc[cp][g * 4 + 1] + bv.y, acc[cp][g * 4 + 2] + bv.z,
-                                   acc[cp][g * 4 + 3] + bv.w};
+                    float vv[4] = {acc[cp][g * 4 + 0] + bv[0], acc[cp][g * 4 + 1] + bv[1], acc[cp][g * 4 + 2] + bv[2],
+                                   acc[cp][g * 4 + 3] + bv[3]};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) vv[i] += (float)sh.e[i];
                     if (PARTS == 2) {
@@ -716,6 +731,18 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
             __builtin_amdgcn_s_setprio(3);
             conv_kloop<E, C, 1, 1, CTW>(X, wq1, lane, acc);
             __builtin_amdgcn_s_setprio(0);
+            f32x4 bq[CTW][4];                                  // (k_resblock's bias_fetch)
+            auto bias_fetch = [&](const float* bp) {
+#pragma unroll
+                for (int c = 0; c < CTW; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) bq[c][g] = *reinterpret_cast<const f32x4*>(bp + (wg + c) * 32 + g * 8 + kb * 4);
+#pragma unroll
+                for (int c = 0; c < CTW; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bq[c][g]));
+            };
+            bias_fetch(b1);
             int ln2 = ln, kb2 = kb;
             asm volatile("" : "+v"(ln2), "+v"(kb2));
             // epilogue 1: relu(acc + b1) -> Y (k_resblock's)
@@ -727,9 +754,9 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int chn = (wg + c) * 32 + g * 8 + kb2 * 4;
-                        const float4 bv = *reinterpret_cast<const float4*>(b1 + chn);
-                        const float vv[4] = {acc[cp][g * 4 + 0] + bv.x, acc[cp][g * 4 + 1] + bv.y, acc[cp][g * 4 + 2] + bv.z,
-                                             acc[cp][g * 4 + 3] + bv.w};
+                        const f32x4 bv = bq[c][g];
+                        const float vv[4] = {acc[cp][g * 4 + 0] + bv[0], acc[cp][g * 4 + 1] + bv[1], acc[cp][g * 4 + 2] + bv[2],
+                                             acc[cp][g * 4 + 3] + bv[3]};
                         const int off = q * G::RB + (((chn >> 3) ^ (q & G::SWZ)) << 4) + (chn & 7) * 2;
                         Quad<E> hi;
 #pragma unroll
@@ -745,6 +772,7 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
             __builtin_amdgcn_s_setprio(3);
             conv_kloop<E, C, 1, 1, CTW>(Y, wq2, lane, acc);
             __builtin_amdgcn_s_setprio(0);
+            bias_fetch(b2);
             asm volatile("" : "+v"(ln2), "+v"(kb2));
             // epilogue 2: relu(acc + b2 + x) -> X, in place over the skip operand (this lane's own 8 bytes)
 #pragma unroll
@@ -755,11 +783,11 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int chn = (wg + c) * 32 + g * 8 + kb2 * 4;
-                        const float4 bv = *reinterpret_cast<const float4*>(b2 + chn);
+                        const f32x4 bv = bq[c][g];
                         const int off = q * G::RB + (((chn >> 3) ^ (q & G::SWZ)) << 4) + (chn & 7) * 2;
                         const Quad<E> sh = *reinterpret_cast<const Quad<E>*>(X + off);
-                        float vv[4] = {acc[cp][g * 4 + 0] + bv.x, acc[cp][g * 4 + 1] + bv.y, acc[cp][g * 4 + 2] + bv.z,
-                                       acc[cp][g * 4 + 3] + bv.w};
+                        float vv[4] = {acc[cp][g * 4 + 0] + bv[0], acc[cp][g * 4 + 1] + bv[1], acc[cp][g * 4 + 2] + bv[2],
+                                       acc[cp][g * 4 + 3] + bv[3]};
                         Quad<E> o;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
@@ -775,6 +803,184 @@ __global__ __launch_bounds__((C / 32 / CTW + 4) * 64, (C / 32 / CTW + 4 + 3) / 4
         }
         if (!has_next) break;
         t += stride;
+    }
+}
+
+// ---- kernel 2pp: the same chain for a PAIR of boards per workgroup, ONE LDS image per board -------------------------------------
+// What bounds k_tower_plain is energy per board (EXPERIMENTS Part III): per board and convolution 1.18 MB of packed filter come
+// from L2 into the CU.  Here a filter fragment feeds SIX pixel tiles (two boards) instead of three: half the filter stream per
+// board, same LDS reads per MFMA.  Two boards with X | Y each do not fit 160 KB; they do with ONE image per board: after K loop 1
+// (barrier: every wave has read all of X) a lane moves its own skip values from X into registers (96 values per board) and
+// writes relu(conv1 + b1) over them -- X now IS Y --, and epilogue 2 writes relu(conv2 + b2 + skip) to the same 8 bytes again.
+// 192 accumulator + 96 skip registers per wave: four matrix waves, no copy waves, one wave per SIMD (512 registers); the matrix
+// waves fetch and store the pair themselves, once per chain.  K loop (conv_kloop<E, 256, 2, 1, 2>) and epilogue arithmetic are
+// k_resblock's, per accumulator tile in the same order: bit-identical to k_tower_plain and to ch.n launches of k_resblock.
+#ifndef CZ_TP2_BIAS_EARLY
+#define CZ_TP2_BIAS_EARLY 1
+#endif
+#ifndef CZ_TP2_TILE_FENCE
+#define CZ_TP2_TILE_FENCE 0
+#endif
+#ifndef CZ_TP2_SKIP_LDS
+#define CZ_TP2_SKIP_LDS 1
+#endif
+template <typename E, int C, int CTW>
+__global__ __launch_bounds__(C / 32 / CTW * 64, 1) void k_tower_plain2(
+    const E* __restrict__ xh, pl::Chain ch, E* __restrict__ yh, int n_boards, const int32_t* __restrict__ n_dev)
+{
+    if (n_dev) {
+        const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
+        n_boards = nd < n_boards ? nd : n_boards;
+    }
+    typedef Geom<C, 2, 1> G;
+    constexpr int NT = G::NT, NTHR = C / 32 / CTW * 64;
+    constexpr int LITER = (G::CHUNKS + NTHR - 1) / NTHR;
+    // X: the pair's image.  SK: the FIRST board's skip values while its intermediate activation sits in X (the second board's wait
+    // in registers: 48 -- all 96 in registers left no room beside 192 accumulators and the K loop's rings: half of them spilled)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[G::REGION + (CZ_TP2_SKIP_LDS ? 90 * G::RB : 0)];
+    unsigned char* X = lds;
+    unsigned char* SK = lds + G::REGION;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NB = ch.n;
+    const int n_pairs = (n_boards + 1) / 2;
+    const int wg = wave * CTW;                                 // first channel tile of this wave
+    const int kb = lane >> 5, ln = lane & 31;
+    zero_rows_write<C, 2, 1, NTHR>(X, tid);
+    for (int t = blockIdx.x; t < n_pairs; t += gridDim.x) {
+        {
+            // global -> LDS image, 16 bytes per lane per step in flights of eight (a missing second board: zeros)
+            typedef c8k::u32x4 u4;
+            const u4* src = reinterpret_cast<const u4*>(xh + (size_t)2 * t * 90 * C);
+            const int have = (n_boards - 2 * t < 2 ? n_boards - 2 * t : 2) * 90 * G::CPR;
+#pragma unroll
+            for (int it0 = 0; it0 < LITER; it0 += 8) {
+                u4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = (it0 + j) * NTHR + tid;
+                    v[j] = u4{0u, 0u, 0u, 0u};
+                    if (it0 + j < LITER && i < have) v[j] = src[i];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = (it0 + j) * NTHR + tid;
+                    if (it0 + j < LITER && i < G::CHUNKS) {
+                        const int row = i / G::CPR, chn = i % G::CPR;
+                        *reinterpret_cast<u4*>(X + row * G::RB + ((chn ^ (row & G::SWZ)) << 4)) = v[j];
+                    }
+                }
+            }
+        }
+        __syncthreads();                                       // A: X holds the pair
+        for (int blk = 0; blk < NB; ++blk) {
+            const uint4* wq1 = reinterpret_cast<const uint4*>(ch.w1[blk]) + wg * 64 + lane;
+            const uint4* wq2 = reinterpret_cast<const uint4*>(ch.w2[blk]) + wg * 64 + lane;
+            const float* b1 = ch.b1[blk];
+            const float* b2 = ch.b2[blk];
+            f32x16 acc[CTW * NT];
+            c8k::u32x2 skip[CZ_TP2_SKIP_LDS ? CTW * 3 : CTW * NT][4];          // (packed: four 2-byte values in two registers)
+            f32x4 bq[CTW][4];
+            // the biases of this wave's channels: all eight loads in flight across the barrier, materialised once (left to the
+            // compiler there was one load and one vmcnt(0) per 8-byte store: 48 L2 round trips in a row per epilogue)
+            auto bias_request = [&](const float* bp) {
+#pragma unroll
+                for (int c = 0; c < CTW; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) bq[c][g] = *reinterpret_cast<const f32x4*>(bp + (wg + c) * 32 + g * 8 + kb * 4);
+            };
+            auto bias_pin = [&]() {
+#pragma unroll
+                for (int c = 0; c < CTW; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bq[c][g]));
+            };
+            __builtin_amdgcn_s_setprio(3);
+            conv_kloop<E, C, 2, 1, CTW>(X, wq1, lane, acc);
+            __builtin_amdgcn_s_setprio(0);
+            if (CZ_TP2_BIAS_EARLY) bias_request(b1);
+            __syncthreads();                                   // K1: every wave has read X
+            if (CZ_TP2_BIAS_EARLY) bias_pin();
+            int ln2 = ln, kb2 = kb;
+            asm volatile("" : "+v"(ln2), "+v"(kb2));
+            // epilogue 1: skip <- X, X <- relu(acc + b1)   (this lane's own 8 bytes)
+#pragma unroll
+            for (int cp = 0; cp < CTW * NT; ++cp) {
+                const int p = cp % NT, c = cp / NT;
+                const int q = (p % 3) * 32 + ln2;
+                const int row = (p / 3) * 90 + q;
+                if (q < 90) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int chn = (wg + c) * 32 + g * 8 + kb2 * 4;
+                        const f32x4 bv = CZ_TP2_BIAS_EARLY ? bq[c][g] : *reinterpret_cast<const f32x4*>(b1 + chn);
+                        const float vv[4] = {acc[cp][g * 4 + 0] + bv[0], acc[cp][g * 4 + 1] + bv[1], acc[cp][g * 4 + 2] + bv[2],
+                                             acc[cp][g * 4 + 3] + bv[3]};
+                        const int off = row * G::RB + (((chn >> 3) ^ (row & G::SWZ)) << 4) + (chn & 7) * 2;
+                        const c8k::u32x2 sk = *reinterpret_cast<const c8k::u32x2*>(X + off);
+                        if (!CZ_TP2_SKIP_LDS) skip[cp][g] = sk;
+                        else if (p < 3) *reinterpret_cast<c8k::u32x2*>(SK + off) = sk;
+                        else skip[c * 3 + p - 3][g] = sk;
+                        Quad<E> hi;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float r = vv[i] > 0.0f ? vv[i] : 0.0f;
+                            hi.e[i] = (E)r;
+                        }
+                        *reinterpret_cast<Quad<E>*>(X + off) = hi;
+                    }
+                }
+                if (CZ_TP2_TILE_FENCE) __builtin_amdgcn_sched_barrier(0);     // one accumulator tile at a time (they leave the AGPRs 16 by 16)
+            }
+            __syncthreads();                                   // B: X holds the intermediate activation
+            __builtin_amdgcn_s_setprio(3);
+            conv_kloop<E, C, 2, 1, CTW>(X, wq2, lane, acc);
+            __builtin_amdgcn_s_setprio(0);
+            if (CZ_TP2_BIAS_EARLY) bias_request(b2);
+            __syncthreads();                                   // K2: every wave has read it
+            if (CZ_TP2_BIAS_EARLY) bias_pin();
+            asm volatile("" : "+v"(ln2), "+v"(kb2));
+            // epilogue 2: X <- relu(acc + b2 + skip)
+#pragma unroll
+            for (int cp = 0; cp < CTW * NT; ++cp) {
+                const int p = cp % NT, c = cp / NT;
+                const int q = (p % 3) * 32 + ln2;
+                const int row = (p / 3) * 90 + q;
+                if (q < 90) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int chn = (wg + c) * 32 + g * 8 + kb2 * 4;
+                        const f32x4 bv = CZ_TP2_BIAS_EARLY ? bq[c][g] : *reinterpret_cast<const f32x4*>(b2 + chn);
+                        const int off = row * G::RB + (((chn >> 3) ^ (row & G::SWZ)) << 4) + (chn & 7) * 2;
+                        float vv[4] = {acc[cp][g * 4 + 0] + bv[0], acc[cp][g * 4 + 1] + bv[1], acc[cp][g * 4 + 2] + bv[2],
+                                       acc[cp][g * 4 + 3] + bv[3]};
+                        const c8k::u32x2 sk = !CZ_TP2_SKIP_LDS ? skip[cp][g]
+                                              : (p < 3 ? *reinterpret_cast<const c8k::u32x2*>(SK + off) : skip[c * 3 + p - 3][g]);
+                        const Quad<E> sh = __builtin_bit_cast(Quad<E>, sk);
+                        Quad<E> o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            vv[i] += (float)sh.e[i];
+                            vv[i] = vv[i] > 0.0f ? vv[i] : 0.0f;
+                            o.e[i] = (E)vv[i];
+                        }
+                        *reinterpret_cast<Quad<E>*>(X + off) = o;
+                    }
+                }
+                if (CZ_TP2_TILE_FENCE) __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();                                   // C: the block's result is in X
+        }
+        // the chain's result to HBM
+        const int valid = (n_boards - 2 * t < 2 ? n_boards - 2 * t : 2) * 90 * G::CPR;
+        c8k::u32x4* dst = reinterpret_cast<c8k::u32x4*>(yh + (size_t)2 * t * 90 * C);
+#pragma unroll
+        for (int it = 0; it < LITER; ++it) {
+            const int i = it * NTHR + tid;
+            if (!((it + 1) * NTHR <= G::CHUNKS || i < G::CHUNKS) || i >= valid) continue;
+            const int row = i / G::CPR, chn = i % G::CPR;
+            dst[i] = *reinterpret_cast<const c8k::u32x4*>(X + row * G::RB + ((chn ^ (row & G::SWZ)) << 4));
+        }
+        __syncthreads();                                       // X may take the next pair
     }
 }
 
@@ -3199,7 +3405,8 @@ extern "C" int cz_resblock_chain(const void* x_hi, const void* x_img, int n_bloc
 }
 
 // n_blocks (1 .. 24) consecutive residual blocks of a 256-filter tower on plain fp16 / bf16 operands in one launch
-// (k_tower_plain): the `deep` 20 x 256 configuration is ONE launch.  Filters: cz_conv3x3_pack_weights(parts = 1).
+// (k_tower_plain2: a pair of boards per workgroup, one LDS image per board; k_tower_plain with CZ_TOWER_PLAIN_PAIR=0): the `deep`
+// 20 x 256 configuration is ONE launch.  Filters: cz_conv3x3_pack_weights(parts = 1).
 extern "C" int cz_tower_plain(const void* x, int n_blocks, const void* const* w1_packed, const float* const* bias1,
                               const void* const* w2_packed, const float* const* bias2, void* y, int n_boards, int channels,
                               int dtype, const int32_t* n_dev, void* stream)
@@ -3224,14 +3431,28 @@ extern "C" int cz_tower_plain(const void* x, int n_blocks, const void* const* w1
         czi_set_error("cz_tower_plain: cannot query the device");
         return CZ_ERR_HIP;
     }
-    const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == CZ_F16)
-        hipLaunchKernelGGL((k_tower_plain<_Float16, 256, 2>), dim3(blocks), dim3((256 / 32 / 2 + 4) * 64), 0, st, (const _Float16*)x, ch,
-                           (_Float16*)y, n_boards, n_dev);
-    else
-        hipLaunchKernelGGL((k_tower_plain<__bf16, 256, 2>), dim3(blocks), dim3((256 / 32 / 2 + 4) * 64), 0, st, (const __bf16*)x, ch,
-                           (__bf16*)y, n_boards, n_dev);
+    // CZ_TOWER_PLAIN_PAIR=0: one board per workgroup in X | Y (k_tower_plain, round 6's first version; A/B and the tests)
+    const char* pair_env = getenv("CZ_TOWER_PLAIN_PAIR");       // (read per call: the tests run both)
+    const bool pair = !(pair_env && pair_env[0] == '0');
+    if (pair) {
+        const int n_pairs = (n_boards + 1) / 2;
+        const unsigned blocks = (unsigned)(n_pairs < n_cu ? n_pairs : n_cu);
+        if (dtype == CZ_F16)
+            hipLaunchKernelGGL((k_tower_plain2<_Float16, 256, 2>), dim3(blocks), dim3(256 / 32 / 2 * 64), 0, st, (const _Float16*)x, ch,
+                               (_Float16*)y, n_boards, n_dev);
+        else
+            hipLaunchKernelGGL((k_tower_plain2<__bf16, 256, 2>), dim3(blocks), dim3(256 / 32 / 2 * 64), 0, st, (const __bf16*)x, ch,
+                               (__bf16*)y, n_boards, n_dev);
+    } else {
+        const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
+        if (dtype == CZ_F16)
+            hipLaunchKernelGGL((k_tower_plain<_Float16, 256, 2>), dim3(blocks), dim3((256 / 32 / 2 + 4) * 64), 0, st, (const _Float16*)x, ch,
+                               (_Float16*)y, n_boards, n_dev);
+        else
+            hipLaunchKernelGGL((k_tower_plain<__bf16, 256, 2>), dim3(blocks), dim3((256 / 32 / 2 + 4) * 64), 0, st, (const __bf16*)x, ch,
+                               (__bf16*)y, n_boards, n_dev);
+    }
     if (hipGetLastError() != hipSuccess) {
         czi_set_error("cz_tower_plain: launch failed");
         return CZ_ERR_HIP;

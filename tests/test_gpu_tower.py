@@ -172,10 +172,11 @@ def test_192_filter_tower_chains_are_bit_identical(arith, blocks):
 
 
 @pytest.mark.parametrize("dtype,blocks", [("float16", 20), ("float16", 3), ("bfloat16", 5), ("float16", 26)])
-def test_deep_tower_on_plain_operands_is_one_launch(dtype, blocks):
+def test_deep_tower_on_plain_operands_is_one_launch(dtype, blocks, monkeypatch):
     """cz_tower_plain (BASELINE configs[4]: 20 x 256, fp16 MFMA evaluation): all blocks of a 256-filter tower on plain 2-byte
-    operands in one launch (24 at most), a board staying in the workgroup's two LDS images.  Equal to one k_resblock launch per
-    block."""
+    operands in one launch (24 at most) -- a pair of boards per workgroup with ONE LDS image per board (k_tower_plain2: the
+    skip values wait in registers while the intermediate activation overwrites them), or CZ_TOWER_PLAIN_PAIR=0: one board in
+    two images (k_tower_plain).  Both equal to one k_resblock launch per block."""
     import torch
     from cchess_alphazero.agent.model import CChessNet, InferenceNet, calibration_planes
     torch.manual_seed(13)
@@ -189,9 +190,23 @@ def test_deep_tower_on_plain_operands_is_one_launch(dtype, blocks):
         (p0, v0), l0 = _launches(g, planes)
         assert l0 == [1] * blocks, l0
         g.chain_blocks = True
-        (p1, v1), l1 = _launches(g, planes)
-        assert l1 == ([24, blocks - 24] if blocks > 24 else [blocks]), l1
-        assert torch.isfinite(p1).all() and torch.equal(p0, p1) and torch.equal(v0, v1), (dtype, blocks, n, (p0 - p1).abs().max().item())
+        for pair in ("1", "0"):
+            monkeypatch.setenv("CZ_TOWER_PLAIN_PAIR", pair)
+            (p1, v1), l1 = _launches(g, planes)
+            assert l1 == ([24, blocks - 24] if blocks > 24 else [blocks]), l1
+            assert torch.isfinite(p1).all() and torch.equal(p0, p1) and torch.equal(v0, v1), \
+                (dtype, blocks, n, pair, (p0 - p1).abs().max().item())
+    # the board count on the device (cz_tower_plain's n_dev; an odd count: the last pair is half empty, rows beyond it untouched)
+    from cchess_alphazero import _native
+    bl = [g._block_params(i) for i in range(min(blocks, 3))]
+    x = (torch.randn((300, 90, 256), device="cuda") * 0.5).to(getattr(torch, dtype))
+    want = _native.tower_plain(x[:189].contiguous(), bl, torch.empty_like(x[:189]))
+    count = torch.tensor([189], dtype=torch.int32, device="cuda")
+    for pair in ("1", "0"):
+        monkeypatch.setenv("CZ_TOWER_PLAIN_PAIR", pair)
+        y = torch.full_like(x, 7.0)
+        _native.tower_plain(x, bl, y, count=count)
+        assert torch.equal(y[:189], want) and bool((y[189:] == 7.0).all()), (dtype, pair)
 
 
 def test_tower_entry_points_reject_what_they_cannot_run():
