@@ -414,8 +414,10 @@ int cz_resblock_chain(const void* x_hi, const void* x_img, int n_blocks, const v
                       int channels, int dtype, const int32_t* n_dev, void* stream);
 /* cz_tower_plain (round 6): n_blocks (1 .. 24) consecutive residual blocks of a 256-FILTER tower on plain fp16 / bf16 operands
  * (dtype CZ_F16 / CZ_BF16, cz_conv3x3_pack_weights with parts = 1) in ONE launch -- BASELINE configs[4], the 20 x 256 fp16 tower,
- * is a single launch: a workgroup takes a board through all blocks in two LDS images (the second epilogue writes in place over
- * the skip operand).  Bit-identical to n_blocks calls of cz_resblock(parts = 1).  x / y: [n_boards][90][256]. */
+ * is a single launch: a workgroup takes a PAIR of boards through all blocks with ONE LDS image per board (a filter fragment
+ * feeds both boards; the intermediate activation overwrites the block's input, whose values wait as the skip operand in
+ * registers / spare LDS; environment CZ_TOWER_PLAIN_PAIR=0: one board in two images).  Bit-identical to n_blocks calls of
+ * cz_resblock(parts = 1).  x / y: [n_boards][90][256]. */
 int cz_tower_plain(const void* x, int n_blocks, const void* const* w1_packed, const float* const* bias1,
                    const void* const* w2_packed, const float* const* bias2, void* y, int n_boards, int channels, int dtype,
                    const int32_t* n_dev, void* stream);
