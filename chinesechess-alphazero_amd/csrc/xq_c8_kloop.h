@@ -290,4 +290,145 @@ __device__ __forceinline__ void kloop(const unsigned char* lds, const Image img,
     }
 }
 
+
+// ---- the same K loop for CTW channel tiles per wave (round 6; k_resblock_ip4_c8: 192 filters, four matrix waves of three
+// channel tiles each, one wave per SIMD = 512 registers).  Per accumulator tile the products arrive in exactly kloop's order
+// (per 64-channel block: two fp16 K-steps, correction term 0, two fp16 K-steps, correction term 1), so results are bit-identical
+// to it; what changes is the traffic: a pixel fragment read from LDS feeds CTW MFMAs, and six channel tiles spread evenly over
+// four SIMDs (with one tile per wave two SIMDs carry two matrix waves and two carry one).  flt[c]: the wave's c-th channel tile
+// (make_filter with the tile index in place of the wave index); acc[c * NT + i]: channel tile c, pixel tile i.
+template <int CTW, int NT, int CH, int FMT>
+__device__ __forceinline__ void kloop_ctw(const unsigned char* lds, const Image img, const Filter* flt, int lane, f32x16* acc,
+                                          int scale_x_lo, int scale_x)
+{
+    typedef Geo<CH> G;
+    constexpr int RB = G::RB, CPR = G::CPR, SWZ = G::SWZ, KK = G::KK, NB = G::NB, CT = G::CT;
+    const int kb = lane >> 5, ln = lane & 31;
+    int qy[3], qx[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int q = t * 32 + ln;
+        qy[t] = q < 90 ? q / 9 : 100;
+        qx[t] = q - (q / 9) * 9;
+    }
+    auto tap_row = [&](int dy, int dx, int p) {
+        const int t = p % 3;
+        const bool ok = (unsigned)(qy[t] + dy) < 10u && (unsigned)(qx[t] + dx) < 9u;
+        const int nominal = (p / 3) * 90 + t * 32 + ln + dy * 9 + dx;
+        const int row = ok ? img.row_base + nominal : img.zrow + (nominal & 15);
+        return row * RB + (((kb ^ nominal) & SWZ) << 4);
+    };
+    const int lane_c = (kb * 3) << 4;
+    auto load_px = [&](int pre_p, int kk) {
+        const int off = G::POW2 ? pre_p ^ (kk << 5) : (pre_p ^ ((kk & 3) << 5)) + ((kk >> 2) << 7);
+        return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds + off));
+    };
+    auto load_c8 = [&](i32x8& d, int pre_p, int q, int b, int h) {
+        const int c0 = q * (CPR / 2) + 4 * b + h;
+        const int off = G::POW2 ? pre_p ^ lane_c ^ (c0 << 4) : (pre_p ^ lane_c ^ ((c0 & 7) << 4)) + ((c0 >> 3) << 7);
+        if (FMT == 0 || h == 0) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(lds + img.part_bytes + off);
+            d[4 * h + 0] = t.x; d[4 * h + 1] = t.y; d[4 * h + 2] = t.z; d[4 * h + 3] = t.w;
+        } else {
+            const u32x2 t = *reinterpret_cast<const u32x2*>(lds + img.part_bytes + off);
+            d[4] = t.x; d[5] = t.y;
+        }
+    };
+    constexpr int STEP_B = CT * 1024, BLK_B = 2 * CT * 2048;
+    auto load_w = [&](int c, int step_soff) {
+        return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(flt[c].rsrc, flt[c].lane_main, step_soff, 0));
+    };
+    auto load_wc = [&](i32x8& d, int c, int blk_soff, int q, int h) {
+        if (FMT == 0 || h == 0) {
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(flt[c].rsrc, flt[c].lane_c8 + h * 1024, blk_soff + q * (BLK_B / 2), 0);
+            d[4 * h + 0] = (int)t.x; d[4 * h + 1] = (int)t.y; d[4 * h + 2] = (int)t.z; d[4 * h + 3] = (int)t.w;
+        } else {
+            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(flt[c].rsrc, flt[c].lane_c6t, blk_soff + q * (BLK_B / 2), 0);
+            d[4] = (int)t.x; d[5] = (int)t.y;
+        }
+    };
+    f16x8 wf[4][CTW];
+    f16x8 px[3][NT];
+    i32x8 cx[NT];
+    i32x8 wcr[2][CTW];
+    int pre[NT], pre_n[NT];
+    if (FMT == 1) {
+#pragma unroll
+        for (int p = 0; p < NT; ++p) { cx[p][6] = 0; cx[p][7] = 0; }
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) { wcr[0][c][6] = wcr[0][c][7] = wcr[1][c][6] = wcr[1][c][7] = 0; }
+    }
+#pragma unroll
+    for (int p = 0; p < NT; ++p) pre[p] = tap_row(-1, -1, p);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) wf[s][c] = load_w(c, s * STEP_B);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+            load_wc(wcr[q][c], c, 0, q, 0);
+            load_wc(wcr[q][c], c, 0, q, 1);
+        }
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+        px[0][p] = load_px(pre[p], 0);
+        px[1][p] = load_px(pre[p], 1);
+    }
+    static_assert((3 * KK) % 3 == 0, "ring indices are static per iteration");
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {
+        const int soff_j = j * (3 * KK * STEP_B), boff_j = j * (3 * NB * BLK_B);
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+            const int ndy = tt < 2 ? j - 1 : (j < 2 ? j : 1), ndx = tt < 2 ? tt : (j < 2 ? -1 : 1);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        const int kk = b * 4 + half * 2 + k2;
+                        const int g = tt * KK + kk;
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) {
+#pragma unroll
+                            for (int c = 0; c < CTW; ++c)
+                                acc[c * NT + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk & 3][c], px[g % 3][i], acc[c * NT + i], 0, 0, 0);
+                            const int kn = kk + 2;
+                            px[(g + 2) % 3][i] = kn < KK ? load_px(pre[i], kn) : load_px(pre_n[i], kn - KK);
+                            const int s6 = k2 * NT + i;                    // piece s6 of the 2 NT pixel pieces of this half block
+                            load_c8(cx[s6 >> 1], pre[s6 >> 1], half, b, s6 & 1);
+                            if (i < CTW) {                                 // the filter pieces of the kind used one group ago, next block
+                                const int q = 1 - half;
+                                const int blk_next = tt * NB + b + (half == 0 ? 0 : 1);
+                                load_wc(wcr[q][i], i, boff_j + blk_next * BLK_B, q, k2);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) {
+#pragma unroll
+                        for (int c = 0; c < CTW; ++c)
+                            acc[c * NT + i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                                wcr[half][c], cx[i], acc[c * NT + i], FMT ? 3 : 0, FMT ? 3 : 0, 0,
+                                half ? flt[c].scale_w_lo : flt[c].scale_w_hi, 0, half ? scale_x : scale_x_lo);
+                        if (i < 2) {                                       // the fp16 fragments of the two K-steps just retired, one block ahead
+                            const int kk = b * 4 + half * 2 + i;
+#pragma unroll
+                            for (int c = 0; c < CTW; ++c) wf[kk & 3][c] = load_w(c, soff_j + (tt * KK + kk + 4) * STEP_B);
+                        }
+                        if (b == 0 && half == 0) pre_n[i] = tap_row(ndy, ndx, i);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < NT; ++p) pre[p] = pre_n[p];
+        }
+    }
+}
+
 }  // namespace c8k

@@ -2506,6 +2506,322 @@ __global__ __launch_bounds__((C / 32) * 64 + ip::COPY_THREADS, 1) void k_resbloc
     }
 }
 
+// ---- kernel 2c / c8 / four waves: k_resblock_ip_c8's chain on FOUR matrix waves of three channel tiles each, a pair of boards
+// per workgroup (round 6) -------------------------------------------------------------------------------------------------------
+// 192 filters are six channel tiles.  k_resblock_ip_c8 gives each of six matrix waves one tile: two SIMDs carry two matrix waves,
+// two carry one -- the convolution takes as long as the SIMDs with two, the others idle half of it, and every wave reads every
+// pixel fragment from LDS for ONE MFMA.  Here a workgroup holds two boards (A = rows [0, 90), B = rows [90, 180): the X and Y rows
+// of k_resblock_ip_c8 -- its arithmetic restarts the accumulators at b2 + skip inside epilogue 1, so the intermediate activation
+// can be written over a board's input IN PLACE) and has four matrix waves, one per SIMD with 512 registers: wave w takes board
+// w >> 1, channel tiles 3 (w & 1) .. + 2, all three pixel tiles (c8k::kloop_ctw<3, 3>: 144 accumulators, a pixel fragment feeds
+// three MFMAs).  36 (tile, pixel tile, board) units, nine per SIMD.  No copy waves: the four waves write the bias buffers and
+// drain / refill the pair once per chain.  A c6 piece holds the 32 channels of ONE channel tile for a pixel and is written by
+// lanes that traded pixel tiles: per channel tile a wave reads the skip elements of both tiles of a trade before it writes their
+// pieces.  Chains of one arithmetic (FMT 0 = c8, 1 = c6).  Per accumulator tile the same products in the same order and the same
+// epilogue arithmetic as k_resblock_ip_c8: bit-identical.
+template <int C, int FMT>
+__global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
+    const _Float16* __restrict__ xh, const unsigned char* __restrict__ xc, ip::Chain ch, _Float16* __restrict__ yh,
+    unsigned char* __restrict__ yc, float* __restrict__ yf_last, int n_boards, const int32_t* __restrict__ n_dev)
+{
+    typedef Geom<C, 1, 2> G;
+    constexpr int RB = G::RB, CPR = G::CPR, NT = 3, CTW = 3, NTHR = 256;
+    static_assert(G::CT == 2 * CTW, "two waves of three channel tiles per board");
+    constexpr int PSTR = ip::ROWS * RB;                         // bytes per operand part
+    constexpr int BIAS_OFF = 2 * PSTR;
+    constexpr int CHUNKS = 180 * CPR, LITER = (CHUNKS + NTHR - 1) / NTHR;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BIAS_OFF + 2 * 2 * C * 4];       // bias[2 buffers][2 convolutions][C]
+    const int NB = ch.n;
+    if (n_dev) {
+        const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
+        n_boards = nd < n_boards ? nd : n_boards;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_pairs = (n_boards + 1) / 2;
+    int t = blockIdx.x;
+    if (t >= n_pairs) return;
+    const int stride = gridDim.x;
+    typedef c8k::u32x4 u4;
+    // 16-byte chunk `chunk` of pixel row `key` of board `bd` (inside a part): the swizzle key is the board-relative row
+    auto choff = [&](int bd, int key, int chunk) {
+        return (bd * 90 + key) * RB + ((chunk & ~G::SWZ) << 4) + (((chunk ^ key) & G::SWZ) << 4);
+    };
+    auto chunk_off = [&](int i) {                               // chunk i of the pair
+        const int row = i / CPR, c = i - row * CPR;
+        return choff(row >= 90 ? 1 : 0, row >= 90 ? row - 90 : row, c);
+    };
+    auto fill = [&](int pr) __attribute__((always_inline)) {    // HBM -> images (a missing second board: zeros)
+        const int have = (n_boards - 2 * pr < 2 ? n_boards - 2 * pr : 2) * 90 * CPR;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const u4* src = part ? reinterpret_cast<const u4*>(xc + (size_t)2 * pr * 90 * 2 * C)
+                                 : reinterpret_cast<const u4*>(xh + (size_t)2 * pr * 90 * C);
+#pragma unroll
+            for (int it0 = 0; it0 < LITER; it0 += 9) {
+                u4 v[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const int i = (it0 + j) * NTHR + tid;
+                    v[j] = u4{0u, 0u, 0u, 0u};
+                    if (it0 + j < LITER && i < have) v[j] = src[i];
+                }
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const int i = (it0 + j) * NTHR + tid;
+                    if (it0 + j < LITER && i < CHUNKS) *reinterpret_cast<u4*>(lds + part * PSTR + chunk_off(i)) = v[j];
+                }
+            }
+        }
+    };
+    auto drain = [&](int pr) __attribute__((always_inline)) {
+        const int have = (n_boards - 2 * pr < 2 ? n_boards - 2 * pr : 2) * 90 * CPR;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            u4* dst = part ? reinterpret_cast<u4*>(yc + (size_t)2 * pr * 90 * 2 * C) : reinterpret_cast<u4*>(yh + (size_t)2 * pr * 90 * C);
+#pragma unroll
+            for (int it = 0; it < LITER; ++it) {
+                const int i = it * NTHR + tid;
+                if (i < have) dst[i] = *reinterpret_cast<const u4*>(lds + part * PSTR + chunk_off(i));
+            }
+        }
+    };
+    auto write_bias = [&](int g) {                              // biases of running block g (block g % NB) into buffer g & 1
+        const int blk = g % NB;
+        float* dst = reinterpret_cast<float*>(lds + BIAS_OFF) + (g & 1) * 2 * C;
+        for (int i = tid; i < C; i += NTHR) {
+            dst[i] = ch.b1[blk][i];
+            dst[C + i] = ch.b2[blk][i];
+        }
+    };
+    for (int i = tid; i < 16 * CPR; i += NTHR) {                // the shared zero rows, both parts
+        *reinterpret_cast<u4*>(lds + ip::ROW_Z * RB + i * 16) = u4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u4*>(lds + PSTR + ip::ROW_Z * RB + i * 16) = u4{0u, 0u, 0u, 0u};
+    }
+    fill(t);
+    write_bias(0);
+    write_bias(1);
+
+    const int kb = lane >> 5, ln = lane & 31;
+    const int bd = wave >> 1, tile0 = CTW * (wave & 1);         // this wave's board and first channel tile
+    // this lane's four channels chn .. chn + 3 of pixel row `key` of its board: the f16 quad, its lo8 word, its e4m3(x) word
+    auto offs = [&](int key, int chn, int& off, int& off_lo, int& off_hi) {
+        off = choff(bd, key, chn >> 3) + (chn & 7) * 2;
+        off_lo = PSTR + choff(bd, key, chn >> 4) + (chn & 15);
+        off_hi = PSTR + choff(bd, key, CPR / 2 + (chn >> 4)) + (chn & 15);
+    };
+    // one unit of a c6 image: channel tile tc, pixel tiles (0, 1) (pp = 0) or tile 2 with itself (pp = 1) of this wave's board.
+    // relu(a*) -> f16 quads + the two bf6 pieces of a pixel's 32 channels (exponent k); a* keep relu(a*).
+    auto write_c6_unit = [&](f32x16& aa, f32x16& ab, int tc, int pp, int k, int ln2, int kb2) __attribute__((always_inline)) {
+        using rb8::u32x6;
+        const float s_hi = __builtin_ldexpf(1.0f, k), s_lo = __builtin_ldexpf(1.0f, k - cf8::X_LO_SHIFT);
+        f32x16 lo_a, lo_b;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && pp == 1) break;
+            const int tt = pp == 0 ? h : 2;
+            const int q = tt * 32 + ln2;
+            const int key = q < 90 ? q : 89;
+            f32x16& a = h ? ab : aa;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const int chn = tc * 32 + gg * 8 + kb2 * 4;
+                Quad<_Float16> hq;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float r = a[gg * 4 + i] > 0.0f ? a[gg * 4 + i] : 0.0f;
+                    hq.e[i] = (_Float16)r;
+                    a[gg * 4 + i] = r;
+                    (h ? lo_b : lo_a)[gg * 4 + i] = r - (float)hq.e[i];
+                }
+                if (q < 90) *reinterpret_cast<Quad<_Float16>*>(lds + choff(bd, key, chn >> 3) + (chn & 7) * 2) = hq;
+            }
+        }
+        if (pp == 1) lo_b = lo_a;
+        f32x16 av, bv, al, bl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(aa[r]), __float_as_uint(pp == 0 ? ab[r] : aa[r]), false, false);
+            const auto sl = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_a[r]), __float_as_uint(lo_b[r]), false, false);
+            av[r] = __uint_as_float(sv[0]); bv[r] = __uint_as_float(sv[1]);
+            al[r] = __uint_as_float(sl[0]); bl[r] = __uint_as_float(sl[1]);
+        }
+        const u32x6 pl = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(al, bl, s_lo);
+        const u32x6 pv = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(av, bv, s_hi);
+        const int q = pp == 0 ? kb2 * 32 + ln2 : 64 + ln2;
+        if (pp == 0 || (kb2 == 0 && q < 90)) {
+            const int c0 = 4 * (tc >> 1) + 2 * (tc & 1), c1 = CPR / 2 + c0;
+            unsigned char* P1 = lds + PSTR;
+            *reinterpret_cast<u4*>(P1 + choff(bd, q, c0)) = u4{pl[0], pl[1], pl[2], pl[3]};
+            *reinterpret_cast<c8k::u32x2*>(P1 + choff(bd, q, c0 + 1)) = c8k::u32x2{pl[4], pl[5]};
+            *reinterpret_cast<u4*>(P1 + choff(bd, q, c1)) = u4{pv[0], pv[1], pv[2], pv[3]};
+            *reinterpret_cast<c8k::u32x2*>(P1 + choff(bd, q, c1 + 1)) = c8k::u32x2{pv[4], pv[5]};
+        }
+    };
+    int g = 0;                                                  // running block count: its parity picks the bias buffer
+    for (;;) {
+        __syncthreads();                                        // A: the images hold pair t, the bias buffers are written
+        for (int blk = 0; blk < NB; ++blk, ++g) {
+            const void* w1p = ch.w1[blk];
+            const void* w2p = ch.w2[blk];
+            c8k::Filter flt1[CTW], flt2[CTW];
+#pragma unroll
+            for (int c = 0; c < CTW; ++c) {
+                flt1[c] = c8k::make_filter<C>(w1p, tile0 + c, lane);
+                flt2[c] = c8k::make_filter<C>(w2p, tile0 + c, lane);
+            }
+            const float* bias1 = reinterpret_cast<const float*>(lds + BIAS_OFF) + (g & 1) * 2 * C;
+            const float* bias2 = bias1 + C;
+            const int* ints1 = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(w1p) + c8k::Geo<C>::MAIN_U4 + c8k::Geo<C>::C8_U4);
+            const int* ints2 = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(w2p) + c8k::Geo<C>::MAIN_U4 + c8k::Geo<C>::C8_U4);
+            const int k_x = FMT ? __builtin_amdgcn_readfirstlane(ints1[2]) : 0;
+            const int k_y = FMT ? __builtin_amdgcn_readfirstlane(ints2[2]) : 0;
+            const int k_out = FMT ? __builtin_amdgcn_readfirstlane(ints2[3]) : CZ_C6_OUT_C8;
+            float* yf = blk == NB - 1 ? yf_last : nullptr;      // fp32 output: the chain's last block only
+            f32x16 acc[CTW * NT];
+#pragma unroll
+            for (int c = 0; c < CTW; ++c)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bias1 + (tile0 + c) * 32 + gg * 8 + kb * 4);
+#pragma unroll
+                    for (int p = 0; p < NT; ++p) {
+                        acc[c * NT + p][gg * 4 + 0] = bv.x; acc[c * NT + p][gg * 4 + 1] = bv.y;
+                        acc[c * NT + p][gg * 4 + 2] = bv.z; acc[c * NT + p][gg * 4 + 3] = bv.w;
+                    }
+                }
+            const c8k::Image img{bd * 90, ip::ROW_Z, PSTR};
+            __builtin_amdgcn_s_setprio(3);
+            c8k::kloop_ctw<CTW, NT, C, FMT>(lds, img, flt1, lane, acc, 127 + k_x - cf8::X_LO_SHIFT, 127 + k_x);
+            __builtin_amdgcn_s_setprio(0);
+            __syncthreads();                                    // K1: both waves of a board have read its image
+            int ln2 = ln, kb2 = kb;
+            asm volatile("" : "+v"(ln2), "+v"(kb2));
+            // epilogue 1, in place: this lane's skip elements out of the image, relu(acc) in the operand format over them, the
+            // freed accumulators restart at b2 + skip
+#pragma unroll
+            for (int c = 0; c < CTW; ++c) {
+                const int tc = tile0 + c;
+                if (FMT) {
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        f32x16 sk[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            if (h == 1 && pp == 1) break;
+                            const int tt = pp == 0 ? h : 2;
+                            const int q = tt * 32 + ln2;
+                            const int key = q < 90 ? q : 89;
+                            const int c0 = 4 * (tc >> 1) + 2 * (tc & 1);
+                            const u4 hd4 = *reinterpret_cast<const u4*>(lds + PSTR + choff(bd, key, c0));
+                            const c8k::u32x2 tl2 = *reinterpret_cast<const c8k::u32x2*>(lds + PSTR + choff(bd, key, c0 + 1));
+                            const uint32_t wv[7] = {hd4.x, hd4.y, hd4.z, hd4.w, tl2.x, tl2.y, 0u};
+                            const uint32_t sh6 = (uint32_t)kb2 * 6u;
+                            rb8::u32x6 pc;
+#pragma unroll
+                            for (int w = 0; w < 6; ++w) pc[w] = __builtin_amdgcn_alignbit(wv[w + 1], wv[w], sh6);
+                            const rb8::f32x32 xl = __builtin_amdgcn_cvt_scalef32_pk32_f32_bf6(pc, __builtin_ldexpf(1.0f, k_x - cf8::X_LO_SHIFT));
+#pragma unroll
+                            for (int gg = 0; gg < 4; ++gg) {
+                                const int chn = tc * 32 + gg * 8 + kb2 * 4;
+                                const float4 bv = *reinterpret_cast<const float4*>(bias2 + chn);
+                                float vv[4] = {bv.x, bv.y, bv.z, bv.w};
+                                const Quad<_Float16> xq = *reinterpret_cast<const Quad<_Float16>*>(lds + choff(bd, key, chn >> 3) + (chn & 7) * 2);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    vv[i] += (float)xq.e[i] + xl[2 * (gg * 4 + i)];
+                                    sk[h][gg * 4 + i] = vv[i];
+                                }
+                            }
+                        }
+                        if (pp == 0) {
+                            write_c6_unit(acc[c * NT + 0], acc[c * NT + 1], tc, 0, k_y, ln2, kb2);
+                            acc[c * NT + 0] = sk[0];
+                            acc[c * NT + 1] = sk[1];
+                        } else {
+                            write_c6_unit(acc[c * NT + 2], acc[c * NT + 2], tc, 1, k_y, ln2, kb2);
+                            acc[c * NT + 2] = sk[0];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < NT; ++p) {
+                        const int q = p * 32 + ln2;
+                        const int key = q < 90 ? q : 89;
+#pragma unroll
+                        for (int gg = 0; gg < 4; ++gg) {
+                            const int chn = tc * 32 + gg * 8 + kb2 * 4;
+                            int ox, oxl, oxh;
+                            offs(key, chn, ox, oxl, oxh);
+                            const float4 bv = *reinterpret_cast<const float4*>(bias2 + chn);
+                            float vv[4] = {bv.x, bv.y, bv.z, bv.w};
+                            cf8::add_pair4(vv, *reinterpret_cast<const Quad<_Float16>*>(lds + ox), *reinterpret_cast<const uint32_t*>(lds + oxl));
+                            float r[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) r[i] = acc[c * NT + p][gg * 4 + i] > 0.0f ? acc[c * NT + p][gg * 4 + i] : 0.0f;
+                            const cf8::Split4 o = cf8::split4(r);
+                            if (q < 90) {
+                                *reinterpret_cast<Quad<_Float16>*>(lds + ox) = o.hi;
+                                *reinterpret_cast<uint32_t*>(lds + oxl) = o.l8;
+                                *reinterpret_cast<uint32_t*>(lds + oxh) = o.h8;
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[c * NT + p][gg * 4 + i] = vv[i];
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                    // B: the images hold the intermediate activation; block g's biases are consumed
+            if (NB > 1) write_bias(g + 2);
+            __builtin_amdgcn_s_setprio(3);
+            c8k::kloop_ctw<CTW, NT, C, FMT>(lds, img, flt2, lane, acc, 127 + k_y - cf8::X_LO_SHIFT, 127 + k_y);
+            __builtin_amdgcn_s_setprio(0);
+            __syncthreads();                                    // K2: both waves of a board have read it
+            asm volatile("" : "+v"(ln2), "+v"(kb2));
+            // epilogue 2: relu(acc) -> the operand triple over the image, or fp32 straight to HBM for the last block of a tower
+#pragma unroll
+            for (int c = 0; c < CTW; ++c) {
+                const int tc = tile0 + c;
+                if (FMT && !yf && k_out != CZ_C6_OUT_C8) {
+                    write_c6_unit(acc[c * NT + 0], acc[c * NT + 1], tc, 0, k_out, ln2, kb2);
+                    write_c6_unit(acc[c * NT + 2], acc[c * NT + 2], tc, 1, k_out, ln2, kb2);
+                } else {
+#pragma unroll
+                    for (int p = 0; p < NT; ++p) {
+                        const int q = p * 32 + ln2;
+                        const int board = 2 * t + bd;
+                        if (q < 90) {
+#pragma unroll
+                            for (int gg = 0; gg < 4; ++gg) {
+                                const int chn = tc * 32 + gg * 8 + kb2 * 4;
+                                float r[4];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) r[i] = acc[c * NT + p][gg * 4 + i] > 0.0f ? acc[c * NT + p][gg * 4 + i] : 0.0f;
+                                if (yf) {
+                                    if (board < n_boards)
+                                        *reinterpret_cast<float4*>(yf + ((size_t)board * 90 + q) * C + chn) = make_float4(r[0], r[1], r[2], r[3]);
+                                } else {
+                                    int ox, oxl, oxh;
+                                    offs(q, chn, ox, oxl, oxh);
+                                    const cf8::Split4 o = cf8::split4(r);
+                                    *reinterpret_cast<Quad<_Float16>*>(lds + ox) = o.hi;
+                                    *reinterpret_cast<uint32_t*>(lds + oxl) = o.l8;
+                                    *reinterpret_cast<uint32_t*>(lds + oxh) = o.h8;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                    // C: the result is in the images
+        }
+        if (!yf_last) drain(t);
+        t += stride;
+        if (t >= n_pairs) break;
+        __syncthreads();                                        // (drain has read the images)
+        fill(t);
+    }
+}
+
 // ---- kernel 3: the input convolution (5x5, 14 or 28 feature planes -> C channels) ----------------------------------
 // Reference: Conv2D(F, 5, padding="same") -> BatchNorm -> ReLU on the state_to_planes input (agent/model.py:36-39).
 // The planes arrive exactly as the search kernel writes them ([in_planes][10][9] per board, values 0 / 1, any of
@@ -3389,14 +3705,28 @@ extern "C" int cz_resblock_chain(const void* x_hi, const void* x_img, int n_bloc
         czi_set_error("cz_resblock_chain: cannot query the device");
         return CZ_ERR_HIP;
     }
-    const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == CZ_F16C8)
-        hipLaunchKernelGGL((k_resblock_ip_c8<192, 0, 0>), dim3(blocks), dim3(192 / 32 * 64 + ip::COPY_THREADS), 0, st, (const _Float16*)x_hi,
-                           (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev);
-    else
-        hipLaunchKernelGGL((k_resblock_ip_c8<192, 1, 1>), dim3(blocks), dim3(192 / 32 * 64 + ip::COPY_THREADS), 0, st, (const _Float16*)x_hi,
-                           (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev);
+    // chains of two blocks and more: a pair of boards per workgroup on four matrix waves of three channel tiles (k_resblock_ip4_c8);
+    // CZ_IP_PAIR=0: one board on six matrix waves (k_resblock_ip_c8; A/B runs, the tests run both)
+    const char* pair_env = getenv("CZ_IP_PAIR");
+    if (n_blocks >= 2 && !(pair_env && pair_env[0] == '0')) {
+        const int n_pairs = (n_boards + 1) / 2;
+        const unsigned blocks = (unsigned)(n_pairs < n_cu ? n_pairs : n_cu);
+        if (dtype == CZ_F16C8)
+            hipLaunchKernelGGL((k_resblock_ip4_c8<192, 0>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi,
+                               (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev);
+        else
+            hipLaunchKernelGGL((k_resblock_ip4_c8<192, 1>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi,
+                               (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev);
+    } else {
+        const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
+        if (dtype == CZ_F16C8)
+            hipLaunchKernelGGL((k_resblock_ip_c8<192, 0, 0>), dim3(blocks), dim3(192 / 32 * 64 + ip::COPY_THREADS), 0, st, (const _Float16*)x_hi,
+                               (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev);
+        else
+            hipLaunchKernelGGL((k_resblock_ip_c8<192, 1, 1>), dim3(blocks), dim3(192 / 32 * 64 + ip::COPY_THREADS), 0, st, (const _Float16*)x_hi,
+                               (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev);
+    }
     if (hipGetLastError() != hipSuccess) {
         czi_set_error("cz_resblock_chain: launch failed");
         return CZ_ERR_HIP;

@@ -140,11 +140,12 @@ def test_bf16_pairs_keep_their_heads_launch():
 
 
 @pytest.mark.parametrize("arith,blocks", [("c8", 10), ("c6", 10), ("c6>3", 10), ("c8>6", 10), ("c6", 2), ("c8", 2), ("c6>1", 4), ("c8>2", 4)])
-def test_192_filter_tower_chains_are_bit_identical(arith, blocks):
+def test_192_filter_tower_chains_are_bit_identical(arith, blocks, monkeypatch):
     """cz_resblock_chain (the reference's deployed width, configs/distribute.py:84-87): consecutive 192-filter blocks of one
-    arithmetic in one launch -- a board stays in the workgroup's two LDS images through all of them.  Equal to one launch per block
-    for c8, c6 (round 6: k_resblock_ip_c8<192, 1, 1>; block 0 reads the input layer's c8 image on a launch of its own), the c6>N
-    hand-over (a c6 block writing a c8 image) and c8>N (fp32 out of the c8 chain, re-split into fp16 pairs)."""
+    arithmetic in one launch -- a PAIR of boards per workgroup, one LDS image per board, four matrix waves of three channel tiles
+    (k_resblock_ip4_c8), or CZ_IP_PAIR=0: one board in two images on six matrix waves (k_resblock_ip_c8).  Both equal to one
+    launch per block for c8, c6 (block 0 reads the input layer's c8 image on a launch of its own), the c6>N hand-over (a c6 block
+    writing a c8 image) and c8>N (fp32 out of the c8 chain, re-split into fp16 pairs)."""
     import torch
     from cchess_alphazero.agent.model import calibration_planes, guarded_inference_net, ip_segments
     net = peaked_net(20.0, blocks=blocks, filters=192)
@@ -158,17 +159,22 @@ def test_192_filter_tower_chains_are_bit_identical(arith, blocks):
         (p0, v0), l0 = _launches(g, planes)
         assert l0 == [1] * blocks, l0
         g.chain_blocks = True
-        (p1, v1), l1 = _launches(g, planes)
-        assert l1 == want, (l1, want)
-        assert torch.isfinite(p1).all() and torch.equal(p0, p1) and torch.equal(v0, v1), (arith, blocks, n, (p0 - p1).abs().max().item())
+        for pair in ("1", "0"):
+            monkeypatch.setenv("CZ_IP_PAIR", pair)
+            (p1, v1), l1 = _launches(g, planes)
+            assert l1 == want, (l1, want)
+            assert torch.isfinite(p1).all() and torch.equal(p0, p1) and torch.equal(v0, v1), \
+                (arith, blocks, n, pair, (p0 - p1).abs().max().item())
     rows = torch.randperm(700, device="cuda")[:500].int()
     count = torch.tensor([333], dtype=torch.int32, device="cuda")
     planes = planes_all.contiguous()
     g.chain_blocks = False
     p0, v0 = (t.clone() for t in g(planes, rows=rows, count=count))
     g.chain_blocks = True
-    p1, v1 = g(planes, rows=rows, count=count)
-    assert torch.equal(p0[:333], p1[:333]) and torch.equal(v0[:333], v1[:333])
+    for pair in ("1", "0"):
+        monkeypatch.setenv("CZ_IP_PAIR", pair)
+        p1, v1 = g(planes, rows=rows, count=count)
+        assert torch.equal(p0[:333], p1[:333]) and torch.equal(v0[:333], v1[:333]), (arith, blocks, pair)
 
 
 @pytest.mark.parametrize("dtype,blocks", [("float16", 20), ("float16", 3), ("bfloat16", 5), ("float16", 26)])
