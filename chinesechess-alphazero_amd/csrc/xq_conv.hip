@@ -2517,9 +2517,9 @@ __global__ __launch_bounds__((C / 32) * 64 + ip::COPY_THREADS, 1) void k_resbloc
 // three MFMAs).  36 (tile, pixel tile, board) units, nine per SIMD.  No copy waves: the four waves write the bias buffers and
 // drain / refill the pair once per chain.  A c6 piece holds the 32 channels of ONE channel tile for a pixel and is written by
 // lanes that traded pixel tiles: per channel tile a wave reads the skip elements of both tiles of a trade before it writes their
-// pieces.  Chains of one arithmetic (FMT 0 = c8, 1 = c6).  Per accumulator tile the same products in the same order and the same
+// pieces.  XF / YF as in k_resblock_ip_c8 (<0, 0> c8, <1, 1> c6, <0, 1> the tower's first c6 block; a chain runs one of them).  Per accumulator tile the same products in the same order and the same
 // epilogue arithmetic as k_resblock_ip_c8: bit-identical.
-template <int C, int FMT>
+template <int C, int XF, int YF>
 __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
     const _Float16* __restrict__ xh, const unsigned char* __restrict__ xc, ip::Chain ch, _Float16* __restrict__ yh,
     unsigned char* __restrict__ yc, float* __restrict__ yf_last, int n_boards, const int32_t* __restrict__ n_dev)
@@ -2673,9 +2673,9 @@ __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
             const float* bias2 = bias1 + C;
             const int* ints1 = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(w1p) + c8k::Geo<C>::MAIN_U4 + c8k::Geo<C>::C8_U4);
             const int* ints2 = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(w2p) + c8k::Geo<C>::MAIN_U4 + c8k::Geo<C>::C8_U4);
-            const int k_x = FMT ? __builtin_amdgcn_readfirstlane(ints1[2]) : 0;
-            const int k_y = FMT ? __builtin_amdgcn_readfirstlane(ints2[2]) : 0;
-            const int k_out = FMT ? __builtin_amdgcn_readfirstlane(ints2[3]) : CZ_C6_OUT_C8;
+            const int k_x = XF ? __builtin_amdgcn_readfirstlane(ints1[2]) : 0;
+            const int k_y = YF ? __builtin_amdgcn_readfirstlane(ints2[2]) : 0;
+            const int k_out = YF ? __builtin_amdgcn_readfirstlane(ints2[3]) : CZ_C6_OUT_C8;
             float* yf = blk == NB - 1 ? yf_last : nullptr;      // fp32 output: the chain's last block only
             f32x16 acc[CTW * NT];
 #pragma unroll
@@ -2691,7 +2691,7 @@ __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
                 }
             const c8k::Image img{bd * 90, ip::ROW_Z, PSTR};
             __builtin_amdgcn_s_setprio(3);
-            c8k::kloop_ctw<CTW, NT, C, FMT>(lds, img, flt1, lane, acc, 127 + k_x - cf8::X_LO_SHIFT, 127 + k_x);
+            c8k::kloop_ctw<CTW, NT, C, XF>(lds, img, flt1, lane, acc, 127 + k_x - cf8::X_LO_SHIFT, 127 + k_x);
             __builtin_amdgcn_s_setprio(0);
             __syncthreads();                                    // K1: both waves of a board have read its image
             int ln2 = ln, kb2 = kb;
@@ -2701,7 +2701,7 @@ __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
 #pragma unroll
             for (int c = 0; c < CTW; ++c) {
                 const int tc = tile0 + c;
-                if (FMT) {
+                if (YF) {
 #pragma unroll
                     for (int pp = 0; pp < 2; ++pp) {
                         f32x16 sk[2];
@@ -2711,26 +2711,34 @@ __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
                             const int tt = pp == 0 ? h : 2;
                             const int q = tt * 32 + ln2;
                             const int key = q < 90 ? q : 89;
-                            const int c0 = 4 * (tc >> 1) + 2 * (tc & 1);
-                            const u4 hd4 = *reinterpret_cast<const u4*>(lds + PSTR + choff(bd, key, c0));
-                            const c8k::u32x2 tl2 = *reinterpret_cast<const c8k::u32x2*>(lds + PSTR + choff(bd, key, c0 + 1));
-                            const uint32_t wv[7] = {hd4.x, hd4.y, hd4.z, hd4.w, tl2.x, tl2.y, 0u};
-                            const uint32_t sh6 = (uint32_t)kb2 * 6u;
-                            rb8::u32x6 pc;
+                            rb8::f32x32 xl;
+                            if (XF) {                           // this lane's elements of the x_lo piece of the channel tile
+                                const int c0 = 4 * (tc >> 1) + 2 * (tc & 1);
+                                const u4 hd4 = *reinterpret_cast<const u4*>(lds + PSTR + choff(bd, key, c0));
+                                const c8k::u32x2 tl2 = *reinterpret_cast<const c8k::u32x2*>(lds + PSTR + choff(bd, key, c0 + 1));
+                                const uint32_t wv[7] = {hd4.x, hd4.y, hd4.z, hd4.w, tl2.x, tl2.y, 0u};
+                                const uint32_t sh6 = (uint32_t)kb2 * 6u;
+                                rb8::u32x6 pc;
 #pragma unroll
-                            for (int w = 0; w < 6; ++w) pc[w] = __builtin_amdgcn_alignbit(wv[w + 1], wv[w], sh6);
-                            const rb8::f32x32 xl = __builtin_amdgcn_cvt_scalef32_pk32_f32_bf6(pc, __builtin_ldexpf(1.0f, k_x - cf8::X_LO_SHIFT));
+                                for (int w = 0; w < 6; ++w) pc[w] = __builtin_amdgcn_alignbit(wv[w + 1], wv[w], sh6);
+                                xl = __builtin_amdgcn_cvt_scalef32_pk32_f32_bf6(pc, __builtin_ldexpf(1.0f, k_x - cf8::X_LO_SHIFT));
+                            }
 #pragma unroll
                             for (int gg = 0; gg < 4; ++gg) {
                                 const int chn = tc * 32 + gg * 8 + kb2 * 4;
                                 const float4 bv = *reinterpret_cast<const float4*>(bias2 + chn);
                                 float vv[4] = {bv.x, bv.y, bv.z, bv.w};
-                                const Quad<_Float16> xq = *reinterpret_cast<const Quad<_Float16>*>(lds + choff(bd, key, chn >> 3) + (chn & 7) * 2);
+                                if (XF) {
+                                    const Quad<_Float16> xq = *reinterpret_cast<const Quad<_Float16>*>(lds + choff(bd, key, chn >> 3) + (chn & 7) * 2);
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    vv[i] += (float)xq.e[i] + xl[2 * (gg * 4 + i)];
-                                    sk[h][gg * 4 + i] = vv[i];
+                                    for (int i = 0; i < 4; ++i) vv[i] += (float)xq.e[i] + xl[2 * (gg * 4 + i)];
+                                } else {                        // (the tower's first c6 block: the input layer's c8 image)
+                                    int ox, oxl, oxh;
+                                    offs(key, chn, ox, oxl, oxh);
+                                    cf8::add_pair4(vv, *reinterpret_cast<const Quad<_Float16>*>(lds + ox), *reinterpret_cast<const uint32_t*>(lds + oxl));
                                 }
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) sk[h][gg * 4 + i] = vv[i];
                             }
                         }
                         if (pp == 0) {
@@ -2743,6 +2751,7 @@ __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
                         }
                     }
                 } else {
+                    static_assert(YF || !XF, "a c8 intermediate image behind a c6 input does not exist");
 #pragma unroll
                     for (int p = 0; p < NT; ++p) {
                         const int q = p * 32 + ln2;
@@ -2773,7 +2782,7 @@ __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
             __syncthreads();                                    // B: the images hold the intermediate activation; block g's biases are consumed
             if (NB > 1) write_bias(g + 2);
             __builtin_amdgcn_s_setprio(3);
-            c8k::kloop_ctw<CTW, NT, C, FMT>(lds, img, flt2, lane, acc, 127 + k_y - cf8::X_LO_SHIFT, 127 + k_y);
+            c8k::kloop_ctw<CTW, NT, C, YF>(lds, img, flt2, lane, acc, 127 + k_y - cf8::X_LO_SHIFT, 127 + k_y);
             __builtin_amdgcn_s_setprio(0);
             __syncthreads();                                    // K2: both waves of a board have read it
             asm volatile("" : "+v"(ln2), "+v"(kb2));
@@ -2781,7 +2790,7 @@ __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
 #pragma unroll
             for (int c = 0; c < CTW; ++c) {
                 const int tc = tile0 + c;
-                if (FMT && !yf && k_out != CZ_C6_OUT_C8) {
+                if (YF && !yf && k_out != CZ_C6_OUT_C8) {
                     write_c6_unit(acc[c * NT + 0], acc[c * NT + 1], tc, 0, k_out, ln2, kb2);
                     write_c6_unit(acc[c * NT + 2], acc[c * NT + 2], tc, 1, k_out, ln2, kb2);
                 } else {
@@ -3656,13 +3665,20 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
     else if ((dtype == CZ_F16C8 || dtype == CZ_F16C6 || dtype == CZ_F16C86) && channels == 192 && parts == 2) {
         // 192 filters: the two-image in-place block on c8, on c6 (round 6), or as the tower's first c6 block behind the input
         // layer's c8 image (CZ_F16C86: the first filter is cz_conv3x3_c8_pack_weights', the second cz_conv3x3_c6_pack_weights')
-        const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
         ip::Chain ch{};
         ch.n = 1;
         ch.w1[0] = w1_packed; ch.w2[0] = w2_packed; ch.b1[0] = bias1; ch.b2[0] = bias2;
-#define CZ_IP_LAUNCH(XF, YF) hipLaunchKernelGGL((k_resblock_ip_c8<192, XF, YF>), dim3(blocks), dim3(192 / 32 * 64 + ip::COPY_THREADS), 0, st, \
-                           (const _Float16*)x_hi, (const unsigned char*)x_lo, ch, \
-                           (_Float16*)y_hi, (unsigned char*)y_lo, y_f32, n_boards, g_q.n_dev)
+        // CZ_IP_PAIR=0: one board on six matrix waves (k_resblock_ip_c8); default: a pair on four waves of three channel tiles
+        const char* pair_env = getenv("CZ_IP_PAIR");
+        const bool pair = !(pair_env && pair_env[0] == '0');
+        const int units = pair ? (n_boards + 1) / 2 : n_boards;
+        const unsigned blocks = (unsigned)(units < n_cu ? units : n_cu);
+#define CZ_IP_LAUNCH(XF, YF) do { \
+            if (pair) hipLaunchKernelGGL((k_resblock_ip4_c8<192, XF, YF>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi, \
+                                         (const unsigned char*)x_lo, ch, (_Float16*)y_hi, (unsigned char*)y_lo, y_f32, n_boards, g_q.n_dev); \
+            else hipLaunchKernelGGL((k_resblock_ip_c8<192, XF, YF>), dim3(blocks), dim3(192 / 32 * 64 + ip::COPY_THREADS), 0, st, \
+                                    (const _Float16*)x_hi, (const unsigned char*)x_lo, ch, (_Float16*)y_hi, (unsigned char*)y_lo, y_f32, \
+                                    n_boards, g_q.n_dev); } while (0)
         if (dtype == CZ_F16C8) CZ_IP_LAUNCH(0, 0);
         else if (dtype == CZ_F16C6) CZ_IP_LAUNCH(1, 1);
         else CZ_IP_LAUNCH(0, 1);
@@ -3706,17 +3722,17 @@ extern "C" int cz_resblock_chain(const void* x_hi, const void* x_img, int n_bloc
         return CZ_ERR_HIP;
     }
     hipStream_t st = (hipStream_t)stream;
-    // chains of two blocks and more: a pair of boards per workgroup on four matrix waves of three channel tiles (k_resblock_ip4_c8);
+    // a pair of boards per workgroup on four matrix waves of three channel tiles (k_resblock_ip4_c8);
     // CZ_IP_PAIR=0: one board on six matrix waves (k_resblock_ip_c8; A/B runs, the tests run both)
     const char* pair_env = getenv("CZ_IP_PAIR");
-    if (n_blocks >= 2 && !(pair_env && pair_env[0] == '0')) {
+    if (!(pair_env && pair_env[0] == '0')) {
         const int n_pairs = (n_boards + 1) / 2;
         const unsigned blocks = (unsigned)(n_pairs < n_cu ? n_pairs : n_cu);
         if (dtype == CZ_F16C8)
-            hipLaunchKernelGGL((k_resblock_ip4_c8<192, 0>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi,
+            hipLaunchKernelGGL((k_resblock_ip4_c8<192, 0, 0>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi,
                                (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev);
         else
-            hipLaunchKernelGGL((k_resblock_ip4_c8<192, 1>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi,
+            hipLaunchKernelGGL((k_resblock_ip4_c8<192, 1, 1>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi,
                                (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev);
     } else {
         const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);

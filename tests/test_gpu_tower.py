@@ -156,8 +156,12 @@ def test_192_filter_tower_chains_are_bit_identical(arith, blocks, monkeypatch):
     for n in (1, 37, 300, 700):
         planes = planes_all[:n].contiguous()
         g.chain_blocks = False
+        monkeypatch.setenv("CZ_IP_PAIR", "0")                # (the reference: one launch per block of the six-wave kernel)
         (p0, v0), l0 = _launches(g, planes)
         assert l0 == [1] * blocks, l0
+        monkeypatch.setenv("CZ_IP_PAIR", "1")
+        (p2, v2), _ = _launches(g, planes)                   # one launch per block of the four-wave kernel
+        assert torch.equal(p0, p2) and torch.equal(v0, v2), (arith, blocks, n)
         g.chain_blocks = True
         for pair in ("1", "0"):
             monkeypatch.setenv("CZ_IP_PAIR", pair)
@@ -169,12 +173,14 @@ def test_192_filter_tower_chains_are_bit_identical(arith, blocks, monkeypatch):
     count = torch.tensor([333], dtype=torch.int32, device="cuda")
     planes = planes_all.contiguous()
     g.chain_blocks = False
+    monkeypatch.setenv("CZ_IP_PAIR", "0")
     p0, v0 = (t.clone() for t in g(planes, rows=rows, count=count))
-    g.chain_blocks = True
-    for pair in ("1", "0"):
-        monkeypatch.setenv("CZ_IP_PAIR", pair)
-        p1, v1 = g(planes, rows=rows, count=count)
-        assert torch.equal(p0[:333], p1[:333]) and torch.equal(v0[:333], v1[:333]), (arith, blocks, pair)
+    for chain in (False, True):
+        g.chain_blocks = chain
+        for pair in ("1", "0"):
+            monkeypatch.setenv("CZ_IP_PAIR", pair)
+            p1, v1 = g(planes, rows=rows, count=count)
+            assert torch.equal(p0[:333], p1[:333]) and torch.equal(v0[:333], v1[:333]), (arith, blocks, chain, pair)
 
 
 @pytest.mark.parametrize("dtype,blocks", [("float16", 20), ("float16", 3), ("bfloat16", 5), ("float16", 26)])
