@@ -405,9 +405,10 @@ int cz_tower_pairs(const void* x_hi, const void* x_lo, int n_blocks, const void*
                    int dtype, const int32_t* n_dev, void* stream);
 /* cz_resblock_chain (round 6): n_blocks (1 .. 12) consecutive residual blocks of a 192-FILTER tower (the reference's deployed
  * width, configs/distribute.py:84-87) on one staged arithmetic -- dtype CZ_F16C8, or CZ_F16C6 (c6 blocks behind the tower's first
- * one, which reads the input layer's c8 image: cz_resblock with CZ_F16C86) -- in ONE launch: a workgroup takes a board through
- * all blocks in its two LDS images (the in-place second epilogue leaves block b's result as block b + 1's input), HBM sees it at
- * the entry and the exit.  Bit-identical to n_blocks calls of cz_resblock.  y_f32 != NULL: the last block writes fp32 [n][90][192]
+ * one, which reads the input layer's c8 image: cz_resblock with CZ_F16C86) -- in ONE launch: a workgroup takes a PAIR of boards
+ * through all blocks, one LDS image per board (both epilogues in place), on four matrix waves of three channel tiles each -- six
+ * channel tiles spread evenly over the CU's four SIMDs (k_resblock_ip4_c8; environment CZ_IP_PAIR=0: one board in two images on
+ * six matrix waves, k_resblock_ip_c8).  HBM sees a board at the entry and the exit.  Bit-identical to n_blocks calls of cz_resblock.  y_f32 != NULL: the last block writes fp32 [n][90][192]
  * instead of the operand pair (the tower's last block / the hand-over of a c8>N tower). */
 int cz_resblock_chain(const void* x_hi, const void* x_img, int n_blocks, const void* const* w1_packed, const float* const* bias1,
                       const void* const* w2_packed, const float* const* bias2, void* y_hi, void* y_img, float* y_f32, int n_boards,
