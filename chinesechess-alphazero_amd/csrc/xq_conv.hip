@@ -2519,18 +2519,25 @@ __global__ __launch_bounds__((C / 32) * 64 + ip::COPY_THREADS, 1) void k_resbloc
 // lanes that traded pixel tiles: per channel tile a wave reads the skip elements of both tiles of a trade before it writes their
 // pieces.  XF / YF as in k_resblock_ip_c8 (<0, 0> c8, <1, 1> c6, <0, 1> the tower's first c6 block; a chain runs one of them).  Per accumulator tile the same products in the same order and the same
 // epilogue arithmetic as k_resblock_ip_c8: bit-identical.
+constexpr int IP4_EXIT_PAIRS = 2, IP4_EXIT_HEADS = 3;
 template <int C, int XF, int YF>
 __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
     const _Float16* __restrict__ xh, const unsigned char* __restrict__ xc, ip::Chain ch, _Float16* __restrict__ yh,
-    unsigned char* __restrict__ yc, float* __restrict__ yf_last, int n_boards, const int32_t* __restrict__ n_dev)
+    unsigned char* __restrict__ yc, float* __restrict__ yf_last, int n_boards, const int32_t* __restrict__ n_dev,
+    int exit_mode, HeadArgs hd)
 {
     typedef Geom<C, 1, 2> G;
-    constexpr int RB = G::RB, CPR = G::CPR, NT = 3, CTW = 3, NTHR = 256;
-    static_assert(G::CT == 2 * CTW, "two waves of three channel tiles per board");
+    constexpr int RB = G::RB, CPR = G::CPR, NT = 3, CTW = G::CT / 2, NTHR = 256;
+    static_assert(G::CT == 2 * CTW, "two waves of CTW channel tiles per board");
     constexpr int PSTR = ip::ROWS * RB;                         // bytes per operand part
     constexpr int BIAS_OFF = 2 * PSTR;
     constexpr int CHUNKS = 180 * CPR, LITER = (CHUNKS + NTHR - 1) / NTHR;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[BIAS_OFF + 2 * 2 * C * 4];       // bias[2 buffers][2 convolutions][C]
+    // exit_mode (the chain's LAST block, 128 filters: cz_tower's exits): 0 = the operand pair / fp32 (yf_last); IP4_EXIT_PAIRS =
+    // (hi, lo) fp16 pairs [n][90][C] to yh and yc; IP4_EXIT_HEADS = the six 1 x 1 head features (hd).  Both stage relu(acc) as fp32
+    // in the board's dead image ([pixel][64 channels] per part, 16-byte chunks swizzled by the pixel) and apply k_tower's exit
+    // arithmetic, item for item: bit-identical to k_tower's exits.
+    constexpr int HW_OFF = BIAS_OFF + 2 * 2 * C * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[HW_OFF + (C == 128 ? 6 * C * 4 : 0)];   // bias[2 buffers][2 convolutions][C] | head filters
     const int NB = ch.n;
     if (n_dev) {
         const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
@@ -2600,6 +2607,8 @@ __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
     fill(t);
     write_bias(0);
     write_bias(1);
+    if (C == 128 && exit_mode == IP4_EXIT_HEADS)
+        for (int i = tid; i < 6 * C; i += NTHR) reinterpret_cast<float*>(lds + HW_OFF)[i] = hd.w[i];
 
     const int kb = lane >> 5, ln = lane & 31;
     const int bd = wave >> 1, tile0 = CTW * (wave & 1);         // this wave's board and first channel tile
@@ -2787,6 +2796,29 @@ __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
             __syncthreads();                                    // K2: both waves of a board have read it
             asm volatile("" : "+v"(ln2), "+v"(kb2));
             // epilogue 2: relu(acc) -> the operand triple over the image, or fp32 straight to HBM for the last block of a tower
+            const int ex = blk == NB - 1 ? exit_mode : 0;
+            // byte offset of channels chn .. chn + 3 (fp32) of pixel q in the board's staging (128 filters)
+            auto stg = [&](int q, int chn) {
+                return (chn >> 6) * PSTR + (bd * 90 + q) * RB + (((((chn & 63) >> 2)) ^ (q & 15)) << 4);
+            };
+            if (C == 128 && ex != 0) {
+#pragma unroll
+                for (int c = 0; c < CTW; ++c)
+#pragma unroll
+                    for (int p = 0; p < NT; ++p) {
+                        const int q = p * 32 + ln2;
+                        if (q < 90) {
+#pragma unroll
+                            for (int gg = 0; gg < 4; ++gg) {
+                                const int chn = (tile0 + c) * 32 + gg * 8 + kb2 * 4;
+                                float r[4];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) r[i] = acc[c * NT + p][gg * 4 + i] > 0.0f ? acc[c * NT + p][gg * 4 + i] : 0.0f;
+                                *reinterpret_cast<float4*>(lds + stg(q, chn)) = make_float4(r[0], r[1], r[2], r[3]);
+                            }
+                        }
+                    }
+            } else
 #pragma unroll
             for (int c = 0; c < CTW; ++c) {
                 const int tc = tile0 + c;
@@ -2822,8 +2854,66 @@ __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
                 }
             }
             __syncthreads();                                    // C: the result is in the images
+            if (C == 128 && ex != 0) {
+                // the exit of board 2 t + bd by its two waves: item i = (pixel i >> 2, 32-channel block i & 3), as k_tower's copy waves
+                const int board = 2 * t + bd;
+                struct alignas(16) H8 { Quad<_Float16> a, b; };
+                const float* hwl = reinterpret_cast<const float*>(lds + HW_OFF);
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const int i = it * 128 + (wave & 1) * 64 + lane;
+                    if (i >= 90 * 4) continue;
+                    const int qq = i >> 2, b32 = i & 3;
+                    if (ex == IP4_EXIT_PAIRS) {
+                        if (board >= n_boards) continue;
+                        const size_t ebase = (size_t)board * 90 * C;
+                        _Float16* yl = reinterpret_cast<_Float16*>(yc);
+#pragma unroll
+                        for (int k8 = 0; k8 < 4; ++k8) {
+                            const float4 f0 = *reinterpret_cast<const float4*>(lds + stg(qq, b32 * 32 + 8 * k8));
+                            const float4 f1 = *reinterpret_cast<const float4*>(lds + stg(qq, b32 * 32 + 8 * k8 + 4));
+                            const float r[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                            H8 hi, lo;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                hi.a.e[j] = (_Float16)r[j];
+                                hi.b.e[j] = (_Float16)r[4 + j];
+                                lo.a.e[j] = (_Float16)(r[j] - (float)hi.a.e[j]);
+                                lo.b.e[j] = (_Float16)(r[4 + j] - (float)hi.b.e[j]);
+                            }
+                            reinterpret_cast<u4*>(yh + ebase)[qq * 16 + b32 * 4 + k8] = __builtin_bit_cast(u4, hi);
+                            reinterpret_cast<u4*>(yl + ebase)[qq * 16 + b32 * 4 + k8] = __builtin_bit_cast(u4, lo);
+                        }
+                    } else {
+                        float a6[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int k4 = 0; k4 < 8; ++k4) {
+                            const float4 f = *reinterpret_cast<const float4*>(lds + stg(qq, b32 * 32 + 4 * k4));
+#pragma unroll
+                            for (int o = 0; o < 6; ++o) {
+                                const float4 w = *reinterpret_cast<const float4*>(hwl + o * C + b32 * 32 + 4 * k4);
+                                a6[o] += f.x * w.x; a6[o] += f.y * w.y; a6[o] += f.z * w.z; a6[o] += f.w * w.w;
+                            }
+                        }
+#pragma unroll
+                        for (int o = 0; o < 6; ++o) {              // the four lanes of the pixel: (a0 + a1) + (a2 + a3) on every lane
+                            a6[o] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a6[o]), 0xB1, 0xF, 0xF, true));
+                            a6[o] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a6[o]), 0x4E, 0xF, 0xF, true));
+                        }
+                        if (board >= n_boards) continue;
+#pragma unroll
+                        for (int o = 0; o < 6; ++o)
+                            if ((o & 3) == b32) {                   // lane b32 writes outputs b32 and b32 + 4
+                                float hv = a6[o] + hd.b[o];
+                                hv = hv > 0.0f ? hv : 0.0f;
+                                if (o < hd.n_pol) hd.pol[(size_t)board * (hd.n_pol * 90) + o * 90 + qq] = hv;
+                                else hd.val[(size_t)board * ((6 - hd.n_pol) * 90) + (o - hd.n_pol) * 90 + qq] = hv;
+                            }
+                    }
+                }
+            }
         }
-        if (!yf_last) drain(t);
+        if (!yf_last && exit_mode == 0) drain(t);
         t += stride;
         if (t >= n_pairs) break;
         __syncthreads();                                        // (drain has read the images)
@@ -3675,7 +3765,7 @@ extern "C" int cz_resblock(const void* x_hi, const void* x_lo, const void* w1_pa
         const unsigned blocks = (unsigned)(units < n_cu ? units : n_cu);
 #define CZ_IP_LAUNCH(XF, YF) do { \
             if (pair) hipLaunchKernelGGL((k_resblock_ip4_c8<192, XF, YF>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi, \
-                                         (const unsigned char*)x_lo, ch, (_Float16*)y_hi, (unsigned char*)y_lo, y_f32, n_boards, g_q.n_dev); \
+                                         (const unsigned char*)x_lo, ch, (_Float16*)y_hi, (unsigned char*)y_lo, y_f32, n_boards, g_q.n_dev, 0, HeadArgs{}); \
             else hipLaunchKernelGGL((k_resblock_ip_c8<192, XF, YF>), dim3(blocks), dim3(192 / 32 * 64 + ip::COPY_THREADS), 0, st, \
                                     (const _Float16*)x_hi, (const unsigned char*)x_lo, ch, (_Float16*)y_hi, (unsigned char*)y_lo, y_f32, \
                                     n_boards, g_q.n_dev); } while (0)
@@ -3702,7 +3792,8 @@ extern "C" int cz_resblock_chain(const void* x_hi, const void* x_img, int n_bloc
                                  void* stream)
 {
     if (n_boards < 0 || !x_hi || !x_img || !w1_packed || !w2_packed || !bias1 || !bias2 || n_blocks < 1 ||
-        n_blocks > ip::MAX_BLOCKS || channels != 192 || (dtype != CZ_F16C8 && dtype != CZ_F16C6) || (!y_f32 && (!y_hi || !y_img))) {
+        n_blocks > ip::MAX_BLOCKS || (channels != 192 && channels != 128) || (dtype != CZ_F16C8 && dtype != CZ_F16C6) ||
+        (!y_f32 && (!y_hi || !y_img))) {
         czi_set_error("cz_resblock_chain: bad argument (192 filters, 1 .. 12 blocks, dtype CZ_F16C8 or CZ_F16C6; y_f32, or y_hi + y_img)");
         return CZ_ERR_ARG;
     }
@@ -3725,15 +3816,24 @@ extern "C" int cz_resblock_chain(const void* x_hi, const void* x_img, int n_bloc
     // a pair of boards per workgroup on four matrix waves of three channel tiles (k_resblock_ip4_c8);
     // CZ_IP_PAIR=0: one board on six matrix waves (k_resblock_ip_c8; A/B runs, the tests run both)
     const char* pair_env = getenv("CZ_IP_PAIR");
-    if (!(pair_env && pair_env[0] == '0')) {
+    if (channels == 128) {                  // (experiment, round 6: the four-wave kernel on the 128-filter tower's images)
+        const int n_pairs = (n_boards + 1) / 2;
+        const unsigned blocks = (unsigned)(n_pairs < n_cu ? n_pairs : n_cu);
+        if (dtype == CZ_F16C8)
+            hipLaunchKernelGGL((k_resblock_ip4_c8<128, 0, 0>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi,
+                               (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev, 0, HeadArgs{});
+        else
+            hipLaunchKernelGGL((k_resblock_ip4_c8<128, 1, 1>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi,
+                               (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev, 0, HeadArgs{});
+    } else if (!(pair_env && pair_env[0] == '0')) {
         const int n_pairs = (n_boards + 1) / 2;
         const unsigned blocks = (unsigned)(n_pairs < n_cu ? n_pairs : n_cu);
         if (dtype == CZ_F16C8)
             hipLaunchKernelGGL((k_resblock_ip4_c8<192, 0, 0>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi,
-                               (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev);
+                               (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev, 0, HeadArgs{});
         else
             hipLaunchKernelGGL((k_resblock_ip4_c8<192, 1, 1>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi,
-                               (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev);
+                               (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev, 0, HeadArgs{});
     } else {
         const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
         if (dtype == CZ_F16C8)
@@ -3748,6 +3848,30 @@ extern "C" int cz_resblock_chain(const void* x_hi, const void* x_img, int n_bloc
         return CZ_ERR_HIP;
     }
     return CZ_OK;
+}
+
+// cz_tower's launches on the four-wave kernel (csrc/xq_tower.hip): a chain of 128-filter blocks of one staged arithmetic
+// (c6: 1, c8: 0); exit: 0 = the operand pair (c6 image, or the c8 image a c6 chain hands over), IP4_EXIT_PAIRS, IP4_EXIT_HEADS.
+extern "C" int czi_tower4_launch(const void* x_hi, const void* x_img, int n_blocks, const void* const* w1, const float* const* b1,
+                                 const void* const* w2, const float* const* b2, int c6, int exit_mode, void* y_hi, void* y_img,
+                                 const float* head_w, const float* head_b, float* pol, float* val, int n_pol, int n_boards,
+                                 int n_cu, const int32_t* n_dev, void* stream)
+{
+    if (n_blocks > ip::MAX_BLOCKS) return CZ_ERR_ARG;
+    const HeadArgs hd{head_w, head_b, pol, val, n_pol};
+    hipStream_t st = (hipStream_t)stream;
+    ip::Chain ch{};
+    ch.n = n_blocks;
+    for (int b = 0; b < n_blocks; ++b) { ch.w1[b] = w1[b]; ch.w2[b] = w2[b]; ch.b1[b] = b1[b]; ch.b2[b] = b2[b]; }
+    const int n_pairs = (n_boards + 1) / 2;
+    const unsigned blocks = (unsigned)(n_pairs < n_cu ? n_pairs : n_cu);
+    if (c6)
+        hipLaunchKernelGGL((k_resblock_ip4_c8<128, 1, 1>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi, (const unsigned char*)x_img,
+                           ch, (_Float16*)y_hi, (unsigned char*)y_img, (float*)nullptr, n_boards, n_dev, exit_mode, hd);
+    else
+        hipLaunchKernelGGL((k_resblock_ip4_c8<128, 0, 0>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi, (const unsigned char*)x_img,
+                           ch, (_Float16*)y_hi, (unsigned char*)y_img, (float*)nullptr, n_boards, n_dev, exit_mode, hd);
+    return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
 }
 
 // n_blocks (1 .. 24) consecutive residual blocks of a 256-filter tower on plain fp16 / bf16 operands in one launch

@@ -28,6 +28,11 @@
 #include "xq_nn_common.h"
 
 extern "C" void czi_set_error(const char* msg);
+// csrc/xq_conv.hip: cz_tower's launches on the four-wave pair kernel (k_resblock_ip4_c8<128>)
+extern "C" int czi_tower4_launch(const void* x_hi, const void* x_img, int n_blocks, const void* const* w1, const float* const* b1,
+                                 const void* const* w2, const float* const* b2, int c6, int exit_mode, void* y_hi, void* y_img,
+                                 const float* head_w, const float* head_b, float* pol, float* val, int n_pol, int n_boards,
+                                 int n_cu, const int32_t* n_dev, void* stream);
 
 namespace {
 
@@ -914,6 +919,17 @@ extern "C" int cz_tower(const void* x_hi, const void* x_img, int n_blocks, const
     const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
     const HeadArgs hd = heads ? HeadArgs{head_w, head_b, policy_feat, value_feat, n_policy} : HeadArgs{};
     hipStream_t st = (hipStream_t)stream;
+    // round 6: the chain on FOUR matrix waves of two channel tiles, a pair of boards with one image each and both epilogues in
+    // place (k_resblock_ip4_c8<128>, csrc/xq_conv.hip; built for the 192-filter tower and 9 % faster per block than k_tower
+    // here: a pixel fragment feeds two MFMAs, no copy waves).  Same exits, bit-identical.  CZ_TOWER4=0: k_tower.
+    const char* t4 = getenv("CZ_TOWER4");
+    if (!(t4 && t4[0] == '0')) {
+        const int rc = czi_tower4_launch(x_hi, x_img, n_blocks, w1_packed, bias1, w2_packed, bias2, fmt0 == CZ_IMG_C6,
+                                         heads ? 3 : (exit_fmt == CZ_IMG_PAIR ? 2 : 0), y_hi, y_img, head_w, head_b, policy_feat,
+                                         value_feat, n_policy, n_boards, n_cu, n_dev, stream);
+        if (rc != CZ_OK) czi_set_error("cz_tower: launch failed");
+        return rc;
+    }
 #define CZ_TOWER_LAUNCH(H, U) hipLaunchKernelGGL((k_tower<H, U>), dim3(blocks), dim3(512), 0, st, (const _Float16*)x_hi, \
         (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, n_boards, n_dev, hd)
     if (fmt0 == CZ_IMG_C6) {
