@@ -36,8 +36,10 @@ def _launches(g, planes, **kw):
     return out, launches
 
 
+@pytest.mark.parametrize("tower4", ["1", "0"])          # cz_tower on k_resblock_ip4_c8<128> (default) / on k_tower (CZ_TOWER4=0)
 @pytest.mark.parametrize("arith", ARITHS)
-def test_chained_tower_is_bit_identical_to_block_by_block(arith):
+def test_chained_tower_is_bit_identical_to_block_by_block(arith, tower4, monkeypatch):
+    monkeypatch.setenv("CZ_TOWER4", tower4)
     import torch
     from cchess_alphazero.agent.model import tower_plan
     blocks = 7
@@ -84,8 +86,9 @@ def test_short_towers_chain_too(arith, blocks):
                 assert torch.equal(p0, p1) and torch.equal(v0, v1), (arith, blocks, n)
 
 
+@pytest.mark.parametrize("tower4", ["1", "0"])
 @pytest.mark.parametrize("arith", ["c6>5", "c8", "c8>3", "f16x3"])
-def test_heads_as_the_last_chains_exit(arith):
+def test_heads_as_the_last_chains_exit(arith, tower4, monkeypatch):
     """The default: the tower's last block is inside the last chain and the 1 x 1 head convolutions are its exit pass.  The head
     dot products are summed over four 32-channel partial sums per pixel (the one-block HEADS kernels: sixteen 8-channel ones);
     the pair chains take the block's value as hi + lo of its operand pair (k_resblock<HEADS> keeps the fp32 value: an fp16 pair
@@ -93,6 +96,7 @@ def test_heads_as_the_last_chains_exit(arith):
     value agree to float32 rounding."""
     import torch
     from cchess_alphazero.agent.model import tower_plan
+    monkeypatch.setenv("CZ_TOWER4", tower4)
     g, planes_all = _net(arith, 7)
     want = [len(st[1]) if st[0] in ("tower", "pairs") else 1 for st in tower_plan(g.block_kinds())]
     for n in (1, 37, 300, 700):
@@ -127,6 +131,22 @@ def test_the_guards_choice_for_a_peaked_policy_runs_as_three_launches():
     assert launches == [1, n8 - 1, 7 - n8], (name, launches)
     m = measure_against_reference(g, reference_forward_f64(net, planes), planes)
     assert within_guard(m, tol=1e-4, logit_tol=LOGIT_TOL * 1.5), m           # (fresh positions, not the calibration set)
+
+
+@pytest.mark.parametrize("arith", ["c6", "c8", "c6>3", "c8>3"])
+def test_both_chain_kernels_give_the_same_bits(arith, monkeypatch):
+    """cz_tower on k_tower (CZ_TOWER4=0) and on the four-wave pair kernel k_resblock_ip4_c8<128> (round 6, default): same
+    products in the same order per accumulator tile, the exits (operand image, fp16 pairs, head features) computed item for item
+    the same way -- identical network outputs, heads exit included."""
+    import torch
+    g, planes_all = _net(arith, 7)
+    for n in (1, 37, 300, 1100):
+        planes = planes_all[:n].contiguous()
+        monkeypatch.setenv("CZ_TOWER4", "0")
+        p0, v0 = (t.clone() for t in g(planes))
+        monkeypatch.setenv("CZ_TOWER4", "1")
+        p1, v1 = g(planes)
+        assert torch.equal(p0, p1) and torch.equal(v0, v1), (arith, n, (p0 - p1).abs().max().item())
 
 
 def test_bf16_pairs_keep_their_heads_launch():
