@@ -533,8 +533,10 @@ def tower_launch_plan(net):
         elif st[0] in ("tower", "tower_first"):
             k = kinds[st[1][0]]
             first = ", FIRST" if st[0] == "tower_first" else ""
-            out.append({"step": st[0], "kernel": f"k_tower<{'HEADS' if st[2] == 'heads' else 'image'}, {k}{first}>",
-                        "blocks": len(st[1]), "kind": k, "exit": st[2]})
+            # (round 6: cz_tower runs on the four-wave pair kernel unless CZ_TOWER4=0; its exits are run-time arguments)
+            kern = (f"k_tower<{'HEADS' if st[2] == 'heads' else 'image'}, {k}{first}>" if os.environ.get("CZ_TOWER4", "1")[:1] == "0"
+                    else f"k_resblock_ip4_c8<128, {k}>")
+            out.append({"step": st[0], "kernel": kern, "blocks": len(st[1]), "kind": k, "exit": st[2]})
         elif st[0] == "pairs":
             out.append({"step": "pairs", "kernel": f"k_tower_pairs<{od}, {'HEADS' if st[2] else 'pairs'}>", "blocks": len(st[1]),
                         "kind": "pair", "exit": "heads" if st[2] else "pair"})

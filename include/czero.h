@@ -384,8 +384,11 @@ int cz_tower_c6_heads(const void* x_hi, const void* x_c6, int n_blocks, const vo
 #define CZ_IMG_C6 1      /* f16 + bf6 pieces with an exponent (cz_conv3x3_c6_pack_weights) */
 #define CZ_IMG_PAIR 2    /* (hi, lo) fp16 / bf16 pair (cz_conv3x3_pack_weights, parts = 2) */
 #define CZ_EXIT_HEADS 3  /* exit only: the 1 x 1 head convolutions instead of an image */
-/* cz_tower: n_blocks (1 .. 8) consecutive residual blocks on the c8 OR the c6 arithmetic in ONE launch (k_tower) -- bit-identical
- * to n_blocks calls of cz_resblock with the matching dtype.  fmt_x[b] / fmt_y[b] (HOST int arrays; NULL = all CZ_IMG_C6): the
+/* cz_tower: n_blocks (1 .. 8) consecutive residual blocks on the c8 OR the c6 arithmetic in ONE launch -- bit-identical to
+ * n_blocks calls of cz_resblock with the matching dtype.  Kernel (end of round 6): k_resblock_ip4_c8<128> -- a pair of boards
+ * per workgroup with one LDS image each, both epilogues in place, FOUR matrix waves of two channel tiles (a pixel fragment from
+ * LDS feeds two MFMAs, no copy waves); environment CZ_TOWER4=0: k_tower (the pair alternating through X | X | Y with copy waves
+ * converting the staged result) -- same bits, 6 % slower in the engine.  fmt_x[b] / fmt_y[b] (HOST int arrays; NULL = all CZ_IMG_C6): the
  * format of the image block b's first / second filter reads -- one format per chain (all CZ_IMG_C8 or all CZ_IMG_C6; a hybrid
  * tower is one chain per arithmetic).  exit_fmt: what the last block's result becomes -- CZ_IMG_C6 / CZ_IMG_C8: that operand
  * pair in (y_hi, y_img) (a c6 chain whose last block carries y_exp = 127 ends on CZ_IMG_C8: the hand-over of a "c6>N" tower);

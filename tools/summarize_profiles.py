@@ -20,9 +20,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEARCH = ("k_noise", "k_sim", "k_advance")
 ROUND_LAUNCHES = 4            # k_sim(BACKUP), k_advance, k_noise, k_sim(SELECT)   (round 2: five, k_noise twice)
 ROUND_NAMES = ["k_sim", "k_advance", "k_noise", "k_sim"]
-NN = ("k_tower_pairs", "k_tower", "k_resblock_ip", "k_resblock_c8", "k_resblock_pipe", "k_resblock", "k_input_conv", "k_conv3x3",
+NN = ("k_tower_pairs", "k_tower_plain2", "k_tower_plain", "k_tower", "k_resblock_ip4_c8", "k_resblock_ip_c8", "k_resblock_ip", "k_resblock_c8", "k_resblock_pipe", "k_resblock", "k_input_conv", "k_conv3x3",
       "k_split_bias_act", "k_bias_act", "k_fc_tile", "k_policy_normalize", "k_head_convs")
-TOWER = ("k_tower_pairs", "k_tower", "k_resblock_c8", "k_resblock_pipe", "k_resblock")       # the residual tower's launches
+TOWER = ("k_tower_pairs", "k_tower", "k_resblock_ip4_c8", "k_resblock_c8", "k_resblock_pipe", "k_resblock")       # the residual tower's launches
 
 
 def _targs(name, base):
@@ -73,6 +73,8 @@ def short(name):
             t = lambda v: v in ("true", "1")
             if k == "k_tower" and len(a) >= 2:
                 return f"k_tower<{'HEADS' if t(a[0]) else 'image'}, {'c6' if a[1] == '1' else 'c8'}{', FIRST' if len(a) > 2 and t(a[2]) else ''}>"
+            if k == "k_resblock_ip4_c8" and len(a) == 3:     # <C, XF, YF>: the chain on four matrix waves (exits are run-time arguments)
+                return f"k_resblock_ip4_c8<{a[0]}, {'c6' if a[1] == '1' else ('c8' if a[2] == '0' else 'c8 -> c6')}>"
             if k == "k_tower_pairs" and len(a) == 2:
                 return f"k_tower_pairs<{'bf16' if 'bf16' in a[0] or 'DF16b' in a[0] else 'f16'}, {'HEADS' if t(a[1]) else 'pairs'}>"
             if k == "k_resblock_c8" and len(a) >= 2:
