@@ -873,6 +873,305 @@ static int tower_cu_count()
 
 // One chain of staged blocks.  fmt_x / fmt_y: per block, CZ_IMG_C8 or CZ_IMG_C6 (NULL: all CZ_IMG_C6); exit_fmt: CZ_IMG_C8 /
 // CZ_IMG_C6 / CZ_IMG_PAIR, or CZ_EXIT_HEADS.
+// ---- kernel: the chain of PAIR blocks on four matrix waves (round 6) -----------------------------------------------------------
+// k_tower_pairs' arithmetic (three MFMAs per product: w_hi x_hi, w_lo x_hi, w_hi x_lo in that order per K-step; epilogue 1
+// relu(acc + b1) -> (hi, lo); epilogue 2 ((acc + b2) + skip_hi) + skip_lo, relu, (hi, lo)) in k_resblock_ip4_c8's shape: a
+// pair of boards per workgroup with ONE image each (A = rows [0, 90), B = rows [90, 180)), four matrix waves of 512 registers, no
+// copy waves -- wave w takes board w >> 1 and channel tiles 2 (w & 1), + 1, so a pixel fragment read from LDS feeds two MFMAs
+// per pass.  After K loop 1 (barrier: both waves of a board have read its image) a lane moves its skip elements (hi and lo
+// quads of its own channels: 96 registers) out of the image and writes the intermediate activation over them; epilogue 2 writes
+// the block's result to the same bytes.  Exits: the (hi, lo) pair to HBM, or the head features from hi + lo of the result as
+// k_tower_pairs forms them, item for item.  Bit-identical to k_tower_pairs.
+namespace tp4 {
+constexpr int C = 128, RB = 256, CPR = 16, NT = 3, CTW = 2, NTHR = 256, KK = 8, ROW_Z = 192, PSTR = (ROW_Z + 16) * RB;
+constexpr int BIAS_OFF = 2 * PSTR, HW_OFF = BIAS_OFF + 2 * 2 * C * 4, LDS_BYTES = HW_OFF + 6 * C * 4;
+constexpr int W_STEP = 4 * 64, W_PART = (9 * KK + W_PAD_STEPS) * W_STEP, W_RING = 4;
+}  // namespace tp4
+
+template <typename E>
+__device__ __forceinline__ void pairs_kloop_ctw(const unsigned char* lds, int row_base, const uint4* wq, int lane, f32x16* acc)
+{
+    using namespace tp4;
+    typedef typename Mfma<E>::V8 V8;
+    const int kb = lane >> 5, ln = lane & 31;
+    int pre[NT], pre_n[NT];
+    int qy[3], qx[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int q = t * 32 + ln;
+        qy[t] = q < 90 ? q / 9 : 100;
+        qx[t] = q - (q / 9) * 9;
+    }
+    auto tap_row = [&](int dy, int dx, int t) {
+        const bool ok = (unsigned)(qy[t] + dy) < 10u && (unsigned)(qx[t] + dx) < 9u;
+        const int nominal = t * 32 + ln + dy * 9 + dx;
+        const int row = ok ? row_base + nominal : ROW_Z + (nominal & 15);
+        return row * RB + (((kb ^ nominal) & 15) << 4);       // swizzle key = the board-relative row
+    };
+    V8 wf[W_RING][CTW][2];
+    V8 px[2][NT][2];
+#pragma unroll
+    for (int p = 0; p < CTW * NT; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+    auto load_w = [&](int step, int c, int part) {
+        return __builtin_bit_cast(V8, wq[(size_t)part * W_PART + (size_t)step * W_STEP + c * 64]);
+    };
+    auto load_px = [&](int off, int part) {
+        return __builtin_bit_cast(V8, *reinterpret_cast<const c8k::u32x4*>(lds + part * PSTR + off));
+    };
+#pragma unroll
+    for (int p = 0; p < NT; ++p) pre[p] = tap_row(-1, -1, p);
+#pragma unroll
+    for (int s = 0; s < W_RING - 1; ++s)
+#pragma unroll
+        for (int c = 0; c < CTW; ++c)
+#pragma unroll
+            for (int part = 0; part < 2; ++part) wf[s][c][part] = load_w(s, c, part);
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int p = 0; p < NT; ++p) px[0][p][part] = load_px(pre[p], part);
+    constexpr int NM = 3 * NT * CTW, NL = NT * 2, NW = CTW * 2;
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+            const int tap = 3 * j + tt;
+            const int ndy = tt < 2 ? j - 1 : (j < 2 ? j : 1), ndx = tt < 2 ? tt : -1;   // the NEXT tap (last: a valid one, unused)
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const int step = tap * KK + kk;
+                const int* rows = kk + 1 < KK ? pre : pre_n;
+                const int kn = (kk + 1) % KK;
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    const int pass = i / (NT * CTW), p = (i % (NT * CTW)) / CTW, c = i % CTW;
+                    acc[c * NT + p] = Mfma<E>::mma(wf[kk % W_RING][c][pass == 1 ? 1 : 0], px[kk & 1][p][pass == 2 ? 1 : 0], acc[c * NT + p]);
+                    if (i < NL) px[(kk + 1) & 1][i % NT][i / NT] = load_px(rows[i % NT] ^ (kn << 5), i / NT);
+                    if (i == NM - 1 - NW && kk < NT) pre_n[kk] = tap_row(ndy, ndx, kk);
+                    if (i >= NM - NW) {
+                        const int idx = i - (NM - NW);
+                        wf[(kk + W_RING - 1) % W_RING][idx / 2][idx % 2] = load_w(step + W_RING - 1, idx / 2, idx % 2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < NT; ++p) pre[p] = pre_n[p];
+        }
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(256, 1) void k_tower_pairs4(
+    const E* __restrict__ xh, const E* __restrict__ xl, tw::Chain ch, E* __restrict__ yh, E* __restrict__ yl, int n_boards,
+    const int32_t* __restrict__ n_dev, HeadArgs hd, int heads)
+{
+    using namespace tp4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    const int NB = ch.n;
+    if (n_dev) {
+        const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
+        n_boards = nd < n_boards ? nd : n_boards;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_pairs = (n_boards + 1) / 2;
+    int t = blockIdx.x;
+    if (t >= n_pairs) return;
+    const int stride = gridDim.x;
+    typedef c8k::u32x4 u4;
+    constexpr int CHUNKS = 180 * CPR, LITER = (CHUNKS + NTHR - 1) / NTHR;
+    auto choff = [&](int bd, int key, int chunk) { return (bd * 90 + key) * RB + ((chunk ^ (key & 15)) << 4); };
+    auto chunk_off = [&](int i) {
+        const int row = i / CPR, c = i - row * CPR;
+        return choff(row >= 90 ? 1 : 0, row >= 90 ? row - 90 : row, c);
+    };
+    auto fill = [&](int pr) __attribute__((always_inline)) {    // HBM -> images (a missing second board: zeros)
+        const int have = (n_boards - 2 * pr < 2 ? n_boards - 2 * pr : 2) * 90 * CPR;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const u4* src = reinterpret_cast<const u4*>((part ? xl : xh) + (size_t)2 * pr * 90 * C);
+#pragma unroll
+            for (int it0 = 0; it0 < LITER; it0 += 8) {
+                u4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = (it0 + j) * NTHR + tid;
+                    v[j] = u4{0u, 0u, 0u, 0u};
+                    if (it0 + j < LITER && i < have) v[j] = src[i];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = (it0 + j) * NTHR + tid;
+                    if (it0 + j < LITER && i < CHUNKS) *reinterpret_cast<u4*>(lds + part * PSTR + chunk_off(i)) = v[j];
+                }
+            }
+        }
+    };
+    auto drain = [&](int pr) __attribute__((always_inline)) {
+        const int have = (n_boards - 2 * pr < 2 ? n_boards - 2 * pr : 2) * 90 * CPR;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            u4* dst = reinterpret_cast<u4*>((part ? yl : yh) + (size_t)2 * pr * 90 * C);
+#pragma unroll
+            for (int it = 0; it < LITER; ++it) {
+                const int i = it * NTHR + tid;
+                if (i < have) dst[i] = *reinterpret_cast<const u4*>(lds + part * PSTR + chunk_off(i));
+            }
+        }
+    };
+    auto write_bias = [&](int g) {                              // biases of running block g (block g % NB) into buffer g & 1
+        const int blk = g % NB;
+        float* dst = reinterpret_cast<float*>(lds + BIAS_OFF) + (g & 1) * 2 * C;
+        if (tid < C) {
+            dst[tid] = ch.b1[blk][tid];
+            dst[C + tid] = ch.b2[blk][tid];
+        }
+    };
+    for (int i = tid; i < 16 * CPR; i += NTHR) {                // the shared zero rows, both parts
+        *reinterpret_cast<u4*>(lds + ROW_Z * RB + i * 16) = u4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u4*>(lds + PSTR + ROW_Z * RB + i * 16) = u4{0u, 0u, 0u, 0u};
+    }
+    fill(t);
+    write_bias(0);
+    write_bias(1);
+    if (heads)
+        for (int i = tid; i < 6 * C; i += NTHR) reinterpret_cast<float*>(lds + HW_OFF)[i] = hd.w[i];
+
+    const int kb = lane >> 5, ln = lane & 31;
+    const int bd = wave >> 1, tile0 = CTW * (wave & 1);
+    int g = 0;
+    for (;;) {
+        __syncthreads();                                        // A: the images hold pair t, the bias buffers are written
+        for (int blk = 0; blk < NB; ++blk, ++g) {
+            const uint4* wq1 = reinterpret_cast<const uint4*>(ch.w1[blk]) + tile0 * 64 + lane;
+            const uint4* wq2 = reinterpret_cast<const uint4*>(ch.w2[blk]) + tile0 * 64 + lane;
+            const float* bias1 = reinterpret_cast<const float*>(lds + BIAS_OFF) + (g & 1) * 2 * C;
+            const float* bias2 = bias1 + C;
+            f32x16 acc[CTW * NT];
+            c8k::u32x2 skh[CTW * NT][4], skl[CTW * NT][4];      // the skip operand's (hi, lo) quads, packed
+            __builtin_amdgcn_s_setprio(3);
+            pairs_kloop_ctw<E>(lds, bd * 90, wq1, lane, acc);
+            __builtin_amdgcn_s_setprio(0);
+            __syncthreads();                                    // K1: both waves of a board have read its image
+            int ln2 = ln, kb2 = kb;
+            asm volatile("" : "+v"(ln2), "+v"(kb2));
+            // epilogue 1, in place: skip <- image, image <- relu(acc + b1) as (hi, lo)
+#pragma unroll
+            for (int cp = 0; cp < CTW * NT; ++cp) {
+                const int c = cp / NT, p = cp % NT;
+                const int q = p * 32 + ln2;
+                const int key = q < 90 ? q : 89;
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const int chn = (tile0 + c) * 32 + gg * 8 + kb2 * 4;
+                    const int off = choff(bd, key, chn >> 3) + (chn & 7) * 2;
+                    skh[cp][gg] = *reinterpret_cast<const c8k::u32x2*>(lds + off);
+                    skl[cp][gg] = *reinterpret_cast<const c8k::u32x2*>(lds + PSTR + off);
+                    const float4 bv = *reinterpret_cast<const float4*>(bias1 + chn);
+                    const float vv[4] = {acc[cp][gg * 4 + 0] + bv.x, acc[cp][gg * 4 + 1] + bv.y, acc[cp][gg * 4 + 2] + bv.z,
+                                         acc[cp][gg * 4 + 3] + bv.w};
+                    Quad<E> hi, lo;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float r = vv[i] > 0.0f ? vv[i] : 0.0f;
+                        hi.e[i] = (E)r;
+                        lo.e[i] = (E)(r - (float)hi.e[i]);
+                    }
+                    if (q < 90) {
+                        *reinterpret_cast<Quad<E>*>(lds + off) = hi;
+                        *reinterpret_cast<Quad<E>*>(lds + PSTR + off) = lo;
+                    }
+                }
+            }
+            __syncthreads();                                    // B: the images hold the intermediate activation; block g's b1 is consumed
+            __builtin_amdgcn_s_setprio(3);
+            pairs_kloop_ctw<E>(lds, bd * 90, wq2, lane, acc);
+            __builtin_amdgcn_s_setprio(0);
+            __syncthreads();                                    // K2
+            asm volatile("" : "+v"(ln2), "+v"(kb2));
+            // epilogue 2, in place: image <- relu(((acc + b2) + skip_hi) + skip_lo) as (hi, lo)
+#pragma unroll
+            for (int cp = 0; cp < CTW * NT; ++cp) {
+                const int c = cp / NT, p = cp % NT;
+                const int q = p * 32 + ln2;
+                if (q < 90) {
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        const int chn = (tile0 + c) * 32 + gg * 8 + kb2 * 4;
+                        const int off = choff(bd, q, chn >> 3) + (chn & 7) * 2;
+                        const float4 bv = *reinterpret_cast<const float4*>(bias2 + chn);
+                        const Quad<E> sh = __builtin_bit_cast(Quad<E>, skh[cp][gg]), sl = __builtin_bit_cast(Quad<E>, skl[cp][gg]);
+                        float v[4] = {acc[cp][gg * 4 + 0] + bv.x, acc[cp][gg * 4 + 1] + bv.y, acc[cp][gg * 4 + 2] + bv.z,
+                                      acc[cp][gg * 4 + 3] + bv.w};
+                        Quad<E> hi, lo;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            v[i] += (float)sh.e[i];
+                            v[i] += (float)sl.e[i];
+                            v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+                            hi.e[i] = (E)v[i];
+                            lo.e[i] = (E)(v[i] - (float)hi.e[i]);
+                        }
+                        *reinterpret_cast<Quad<E>*>(lds + off) = hi;
+                        *reinterpret_cast<Quad<E>*>(lds + PSTR + off) = lo;
+                    }
+                }
+            }
+            __syncthreads();                                    // C: the block's result is in the images; its b2 is consumed
+            if (NB > 1) write_bias(g + 2);                      // (into the buffer block g has just released)
+        }
+        if (heads) {
+            // the head features of board 2 t + bd by its two waves, from hi + lo of the result (k_tower_pairs' heads_exit)
+            const int board = 2 * t + bd;
+            const float* hwl = reinterpret_cast<const float*>(lds + HW_OFF);
+            struct alignas(16) E8 { E e[8]; };
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int i = it * 128 + (wave & 1) * 64 + lane;
+                if (i >= 90 * 4) continue;
+                const int qq = i >> 2, b32 = i & 3;
+                float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int off = choff(bd, qq, b32 * 4 + k);
+                    const E8 h = __builtin_bit_cast(E8, *reinterpret_cast<const u4*>(lds + off));
+                    const E8 l = __builtin_bit_cast(E8, *reinterpret_cast<const u4*>(lds + PSTR + off));
+#pragma unroll
+                    for (int o = 0; o < 6; ++o) {
+                        const float4 w0 = *reinterpret_cast<const float4*>(hwl + o * C + b32 * 32 + 8 * k);
+                        const float4 w1 = *reinterpret_cast<const float4*>(hwl + o * C + b32 * 32 + 8 * k + 4);
+                        const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) a[o] += ((float)h.e[jj] + (float)l.e[jj]) * w[jj];
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < 6; ++o) {
+                    a[o] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a[o]), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+                    a[o] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a[o]), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+                }
+                if (board >= n_boards) continue;
+#pragma unroll
+                for (int o = 0; o < 6; ++o)
+                    if ((o & 3) == b32) {
+                        float hv = a[o] + hd.b[o];
+                        hv = hv > 0.0f ? hv : 0.0f;
+                        if (o < hd.n_pol) hd.pol[(size_t)board * (hd.n_pol * 90) + o * 90 + qq] = hv;
+                        else hd.val[(size_t)board * ((6 - hd.n_pol) * 90) + (o - hd.n_pol) * 90 + qq] = hv;
+                    }
+            }
+        } else {
+            drain(t);
+        }
+        t += stride;
+        if (t >= n_pairs) break;
+        __syncthreads();                                        // (the exit has read the images)
+        fill(t);
+    }
+}
+
 extern "C" int cz_tower(const void* x_hi, const void* x_img, int n_blocks, const void* const* w1_packed,
                         const float* const* bias1, const void* const* w2_packed, const float* const* bias2,
                         const int* fmt_x, const int* fmt_y, int exit_fmt, void* y_hi, void* y_img, const float* head_w,
@@ -1007,6 +1306,22 @@ extern "C" int cz_tower_pairs(const void* x_hi, const void* x_lo, int n_blocks, 
     const unsigned blocks = (unsigned)(n_boards < n_cu ? n_boards : n_cu);
     const HeadArgs hd = heads ? HeadArgs{head_w, head_b, policy_feat, value_feat, n_policy} : HeadArgs{};
     hipStream_t st = (hipStream_t)stream;
+    const char* t4 = getenv("CZ_TOWER4");                       // (round 6) the chain on four matrix waves; CZ_TOWER4=0: k_tower_pairs
+    if (!(t4 && t4[0] == '0')) {
+        const int n_pairs = (n_boards + 1) / 2;
+        const unsigned blocks4 = (unsigned)(n_pairs < n_cu ? n_pairs : n_cu);
+        if (dtype == CZ_F16)
+            hipLaunchKernelGGL((k_tower_pairs4<_Float16>), dim3(blocks4), dim3(256), 0, st, (const _Float16*)x_hi, (const _Float16*)x_lo, ch,
+                               (_Float16*)y_hi, (_Float16*)y_lo, n_boards, n_dev, hd, heads ? 1 : 0);
+        else
+            hipLaunchKernelGGL((k_tower_pairs4<__bf16>), dim3(blocks4), dim3(256), 0, st, (const __bf16*)x_hi, (const __bf16*)x_lo, ch,
+                               (__bf16*)y_hi, (__bf16*)y_lo, n_boards, n_dev, hd, heads ? 1 : 0);
+        if (hipGetLastError() != hipSuccess) {
+            czi_set_error("cz_tower_pairs: launch failed");
+            return CZ_ERR_HIP;
+        }
+        return CZ_OK;
+    }
 #define CZ_PAIRS_LAUNCH(E, H) hipLaunchKernelGGL((k_tower_pairs<E, H>), dim3(blocks), dim3(512), 0, st, (const E*)x_hi, \
         (const E*)x_lo, ch, (E*)y_hi, (E*)y_lo, n_boards, n_dev, hd)
     if (dtype == CZ_F16) {
