@@ -3792,8 +3792,7 @@ extern "C" int cz_resblock_chain(const void* x_hi, const void* x_img, int n_bloc
                                  void* stream)
 {
     if (n_boards < 0 || !x_hi || !x_img || !w1_packed || !w2_packed || !bias1 || !bias2 || n_blocks < 1 ||
-        n_blocks > ip::MAX_BLOCKS || (channels != 192 && channels != 128) || (dtype != CZ_F16C8 && dtype != CZ_F16C6) ||
-        (!y_f32 && (!y_hi || !y_img))) {
+        n_blocks > ip::MAX_BLOCKS || channels != 192 || (dtype != CZ_F16C8 && dtype != CZ_F16C6) || (!y_f32 && (!y_hi || !y_img))) {
         czi_set_error("cz_resblock_chain: bad argument (192 filters, 1 .. 12 blocks, dtype CZ_F16C8 or CZ_F16C6; y_f32, or y_hi + y_img)");
         return CZ_ERR_ARG;
     }
@@ -3816,16 +3815,7 @@ extern "C" int cz_resblock_chain(const void* x_hi, const void* x_img, int n_bloc
     // a pair of boards per workgroup on four matrix waves of three channel tiles (k_resblock_ip4_c8);
     // CZ_IP_PAIR=0: one board on six matrix waves (k_resblock_ip_c8; A/B runs, the tests run both)
     const char* pair_env = getenv("CZ_IP_PAIR");
-    if (channels == 128) {                  // (experiment, round 6: the four-wave kernel on the 128-filter tower's images)
-        const int n_pairs = (n_boards + 1) / 2;
-        const unsigned blocks = (unsigned)(n_pairs < n_cu ? n_pairs : n_cu);
-        if (dtype == CZ_F16C8)
-            hipLaunchKernelGGL((k_resblock_ip4_c8<128, 0, 0>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi,
-                               (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev, 0, HeadArgs{});
-        else
-            hipLaunchKernelGGL((k_resblock_ip4_c8<128, 1, 1>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi,
-                               (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev, 0, HeadArgs{});
-    } else if (!(pair_env && pair_env[0] == '0')) {
+    if (!(pair_env && pair_env[0] == '0')) {
         const int n_pairs = (n_boards + 1) / 2;
         const unsigned blocks = (unsigned)(n_pairs < n_cu ? n_pairs : n_cu);
         if (dtype == CZ_F16C8)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""GPU experiment (round 6): the four-wave pair kernel (k_resblock_ip4_c8, built for 192 filters) instantiated for the 128-filter
-tower's images, against k_tower on the same chain of blocks: equality of the exit image and time per block.
+"""GPU (round 6): the four-wave pair kernel (k_resblock_ip4_c8, built for 192 filters) on the 128-filter tower's images against
+k_tower on the same chain of blocks (cz_tower under CZ_TOWER4=1 / 0): equality of the exit image and time per block.
 
     python tools/time_ip4_128.py [c6|c8] [boards] [blocks]"""
 import sys
@@ -31,15 +31,16 @@ def main():
     _native.input_resblock(planes, g.in_table32, g.in_bias32, w1, b1, w2, b2, out=x)
     blocks = [g._block_params(i) for i in range(1, 1 + nb)]
     bl_t = _native.BlockList(blocks, [fmt] * nb, [fmt] * nb)
-    bl_c = _native.BlockList(blocks)
     ya = tuple(torch.empty_like(t) for t in x)
     yb = tuple(torch.zeros_like(t) for t in x)
 
-    def run_tower():
+    def run_tower():                       # cz_tower on k_tower (round 6's first chain kernel)
+        os.environ["CZ_TOWER4"] = "0"
         _native.tower(x, bl_t, fmt, out=ya)
 
-    def run_ip4():
-        _native.resblock_chain(x, bl_c, out=yb)
+    def run_ip4():                         # cz_tower on the four-wave pair kernel (the default since the end of round 6)
+        os.environ["CZ_TOWER4"] = "1"
+        _native.tower(x, bl_t, fmt, out=yb)
     run_tower()
     run_ip4()
     torch.cuda.synchronize()
