@@ -2520,6 +2520,9 @@ __global__ __launch_bounds__((C / 32) * 64 + ip::COPY_THREADS, 1) void k_resbloc
 // pieces.  XF / YF as in k_resblock_ip_c8 (<0, 0> c8, <1, 1> c6, <0, 1> the tower's first c6 block; a chain runs one of them).  Per accumulator tile the same products in the same order and the same
 // epilogue arithmetic as k_resblock_ip_c8: bit-identical.
 constexpr int IP4_EXIT_PAIRS = 2, IP4_EXIT_HEADS = 3;
+#ifndef CZ_IP4_PROBE        // timing experiments (wrong results; 0 in the product): bit 0 = no epilogue 1, bit 1 = no epilogue 2
+#define CZ_IP4_PROBE 0
+#endif
 template <int C, int XF, int YF>
 __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
     const _Float16* __restrict__ xh, const unsigned char* __restrict__ xc, ip::Chain ch, _Float16* __restrict__ yh,
@@ -2710,6 +2713,7 @@ __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
 #pragma unroll
             for (int c = 0; c < CTW; ++c) {
                 const int tc = tile0 + c;
+                if (CZ_IP4_PROBE & 1) continue;
                 if (YF) {
 #pragma unroll
                     for (int pp = 0; pp < 2; ++pp) {
@@ -2801,7 +2805,8 @@ __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
             auto stg = [&](int q, int chn) {
                 return (chn >> 6) * PSTR + (bd * 90 + q) * RB + (((((chn & 63) >> 2)) ^ (q & 15)) << 4);
             };
-            if (C == 128 && ex != 0) {
+            if (CZ_IP4_PROBE & 2) {
+            } else if (C == 128 && ex != 0) {
 #pragma unroll
                 for (int c = 0; c < CTW; ++c)
 #pragma unroll
