@@ -922,6 +922,12 @@ def other_configs(args, log):
     guarded("distribute_10x192_K10_cpuct5", lambda: short_selfplay_leg(
         "distribute", "normal", sec, log, K=10, model=dict(cnn_filter_num=192, res_layer_num=10),
         play=dict(c_puct=5, noise_eps=0.2, max_game_length=200)))
+    guarded("distribute_10x192_peaked_policy", lambda: short_selfplay_leg(
+        "distribute_peaked", "normal", sec, log, K=10, sharpen=True, model=dict(cnn_filter_num=192, res_layer_num=10),
+        play=dict(c_puct=5, noise_eps=0.2, max_game_length=200),
+        workload="the reference's deployed topology (configs/distribute.py:33-51,84-87: 10 x 192, K = 10, c_puct 5) with the "
+                 "peaked-policy stand-in of a trained network: tower arithmetic = what the load-time guard selects for those "
+                 "weights (f16x3 at the end of round 6); from INIT_STATE"))
     return out
 
 

@@ -141,13 +141,14 @@ def tower_plan(kinds, heads_exit=True, chain_heads=True, max_chain=8):
 
 
 def ip_segments(kinds, max_chain=12):
-    """The launches of a 192-filter tower's blocks (k_resblock_ip_c8 / k_resblock_ip; round 6): ("chain", [blocks]) = one
-    cz_resblock_chain launch of consecutive blocks of one staged arithmetic, ("block", [i]) = a block on its own launch -- a c6
-    tower's block 0 (it reads the input layer's c8 image: its own kernel variant) and the pair blocks."""
+    """The launches of a 192-filter tower's blocks (round 6): ("chain", [blocks]) = one cz_resblock_chain launch of consecutive
+    blocks of one arithmetic (c8 / c6 images: k_resblock_ip4_c8; (hi, lo) pairs: k_tower_pairs4), ("block", [i]) = a block on its
+    own launch -- a c6 tower's block 0 (it reads the input layer's c8 image: its own kernel variant).  A chain that ends the
+    tower writes fp32 (the head convolutions' input)."""
     segs, i, n = [], 0, len(kinds)
     while i < n:
         k = kinds[i]
-        if k == "pair" or (k == "c6" and i == 0):
+        if k == "c6" and i == 0:
             segs.append(("block", [i]))
             i += 1
             continue
@@ -395,8 +396,9 @@ class InferenceNet(nn.Module):
 
     @staticmethod
     def _as_f16_pair(pair):
-        """A c8 operand pair's storage seen as an (hi, lo) fp16 pair (same bytes: [n, 90, 2C] u8 = [n, 90, C] f16)."""
-        return pair[0], pair[1].view(torch.float16)
+        """A c8 operand pair's storage seen as an (hi, lo) fp16 pair (same bytes: [n, 90, 2C] u8 = [n, 90, C] f16); an (hi, lo)
+        pair of the operand dtype (f16x3 / bf16x3 towers) as it is."""
+        return (pair[0], pair[1].view(torch.float16)) if pair[1].dtype in (torch.uint8, torch.int8) else pair
 
     def _trunk_mfma(self, planes, heads=None, rows=None, count=None, masks=None):
         """planes: the evaluation queue as the search kernel wrote it ([n, in_planes, 10, 9], any supported dtype).
@@ -434,7 +436,7 @@ class InferenceNet(nn.Module):
         # fp16 pairs) | 3 .. 6 (heads)
         if fused and first_fused and self.chain_blocks:
             return self._tower_chained(planes, cur, nxt, last, heads, rows, count, masks)
-        if fused and c == 192 and self.parts == 2 and self.arith == "c8" and self.chain_blocks:
+        if fused and c == 192 and self.parts == 2 and self.chain_blocks:
             return self._tower_192(cur, nxt, last, count)
         if fused and c == 256 and self.parts == 1 and self.chain_blocks:
             # the deep tower on plain operands: all blocks in one cz_tower_plain launch (24 at most per launch)
@@ -604,7 +606,7 @@ class InferenceNet(nn.Module):
         return None if done_heads else last
 
     def _tower_192(self, cur, nxt, last, count):
-        """The 192-filter tower (c8 / c6 families) behind cz_input_conv as ip_segments' launches; returns the fp32 trunk output."""
+        """The 192-filter tower (every split arithmetic) behind cz_input_conv as ip_segments' launches; returns the fp32 trunk output."""
         from cchess_alphazero import _native
         kinds = self.block_kinds()
         nblk = len(kinds)
@@ -624,7 +626,12 @@ class InferenceNet(nn.Module):
             if k == "pair":
                 x = self._as_f16_pair(cur)
                 w1, b1, w2, b2 = bl.blocks[0]
-                if tower_end:
+                if kind == "chain" and tower_end:   # consecutive pair blocks in one launch (k_tower_pairs4<E, 192>)
+                    _native.resblock_chain(x, bl, out_f32=last, count=count)
+                elif kind == "chain":
+                    _native.resblock_chain(x, bl, out=self._as_f16_pair(nxt), count=count)
+                    cur, nxt = nxt, cur
+                elif tower_end:
                     _native.resblock(x, w1, b1, w2, b2, out_f32=last, count=count)
                 else:
                     _native.resblock(x, w1, b1, w2, b2, out=self._as_f16_pair(nxt), count=count)

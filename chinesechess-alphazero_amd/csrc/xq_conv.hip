@@ -41,6 +41,11 @@
 #include "xq_nn_common.h"
 
 extern "C" void czi_set_error(const char* msg);
+// csrc/xq_tower.hip: a chain of (hi, lo) pair blocks on four matrix waves (k_tower_pairs4<E, 128 / 192>)
+extern "C" int czi_pairs4_launch(const void* x_hi, const void* x_lo, int n_blocks, const void* const* w1, const float* const* b1,
+                                 const void* const* w2, const float* const* b2, void* y_hi, void* y_lo, const float* head_w,
+                                 const float* head_b, float* pol, float* val, int n_pol, int n_boards, int channels, int dtype,
+                                 int n_cu, const int32_t* n_dev, void* stream, float* y_f32);
 
 namespace {
 
@@ -3796,10 +3801,30 @@ extern "C" int cz_resblock_chain(const void* x_hi, const void* x_img, int n_bloc
                                  void* y_img, float* y_f32, int n_boards, int channels, int dtype, const int32_t* n_dev,
                                  void* stream)
 {
+    const bool pairs = dtype == CZ_F16 || dtype == CZ_BF16;     // (hi, lo) pair blocks: x_img / y_img are the lo tensors
     if (n_boards < 0 || !x_hi || !x_img || !w1_packed || !w2_packed || !bias1 || !bias2 || n_blocks < 1 ||
-        n_blocks > ip::MAX_BLOCKS || channels != 192 || (dtype != CZ_F16C8 && dtype != CZ_F16C6) || (!y_f32 && (!y_hi || !y_img))) {
-        czi_set_error("cz_resblock_chain: bad argument (192 filters, 1 .. 12 blocks, dtype CZ_F16C8 or CZ_F16C6; y_f32, or y_hi + y_img)");
+        n_blocks > ip::MAX_BLOCKS || channels != 192 || (dtype != CZ_F16C8 && dtype != CZ_F16C6 && !pairs) ||
+        (!y_f32 && (!y_hi || !y_img))) {
+        czi_set_error("cz_resblock_chain: bad argument (192 filters, 1 .. 12 blocks, dtype CZ_F16C8 / CZ_F16C6 with y_f32 or y_hi + y_img, "
+                      "or CZ_F16 / CZ_BF16 pair blocks with y_f32 or y_hi + y_lo)");
         return CZ_ERR_ARG;
+    }
+    if (pairs) {
+        for (int b = 0; b < n_blocks; ++b)
+            if (!w1_packed[b] || !w2_packed[b] || !bias1[b] || !bias2[b]) {
+                czi_set_error("cz_resblock_chain: null block parameter");
+                return CZ_ERR_ARG;
+            }
+        if (n_boards == 0) return CZ_OK;
+        const int n_cu_p = device_cu_count();
+        if (n_cu_p < 0) {
+            czi_set_error("cz_resblock_chain: cannot query the device");
+            return CZ_ERR_HIP;
+        }
+        const int rc = czi_pairs4_launch(x_hi, x_img, n_blocks, w1_packed, bias1, w2_packed, bias2, y_hi, y_img, nullptr, nullptr, nullptr,
+                                         nullptr, 0, n_boards, 192, dtype, n_cu_p, n_dev, stream, y_f32);
+        if (rc != CZ_OK) czi_set_error("cz_resblock_chain: launch failed");
+        return rc;
     }
     ip::Chain ch{};
     ch.n = n_blocks;

@@ -882,16 +882,41 @@ static int tower_cu_count()
 // quads of its own channels: 96 registers) out of the image and writes the intermediate activation over them; epilogue 2 writes
 // the block's result to the same bytes.  Exits: the (hi, lo) pair to HBM, or the head features from hi + lo of the result as
 // k_tower_pairs forms them, item for item.  Bit-identical to k_tower_pairs.
-namespace tp4 {
-constexpr int C = 128, RB = 256, CPR = 16, NT = 3, CTW = 2, NTHR = 256, KK = 8, ROW_Z = 192, PSTR = (ROW_Z + 16) * RB;
-constexpr int BIAS_OFF = 2 * PSTR, HW_OFF = BIAS_OFF + 2 * 2 * C * 4, LDS_BYTES = HW_OFF + 6 * C * 4;
-constexpr int W_STEP = 4 * 64, W_PART = (9 * KK + W_PAD_STEPS) * W_STEP, W_RING = 4;
-}  // namespace tp4
+namespace tw4 {
+constexpr int MAX_BLOCKS = 12;
+struct Chain {
+    const void* w1[MAX_BLOCKS];
+    const void* w2[MAX_BLOCKS];
+    const float* b1[MAX_BLOCKS];
+    const float* b2[MAX_BLOCKS];
+    int n;
+};
+}  // namespace tw4
 
-template <typename E>
+template <int CH> struct Tp4 {                  // geometry for CH filters (128: 256-byte rows; 192: 384-byte rows, chunks swizzled in groups of 8)
+    static constexpr int C = CH, RB = 2 * CH, CPR = CH / 8, NT = 3, CT = CH / 32, CTW = CT / 2, NTHR = 256, KK = CH / 16;
+    static constexpr bool POW2 = (RB & (RB - 1)) == 0;
+    static constexpr int SWZ = POW2 ? 15 : 7;
+    static constexpr int ROW_Z = 192, PSTR = (ROW_Z + 16) * RB;
+    static constexpr int BIAS_OFF = 2 * PSTR, HW_OFF = BIAS_OFF + 2 * 2 * CH * 4;
+    static constexpr int LDS_BYTES = HW_OFF + (CH == 128 ? 6 * CH * 4 : 0);      // (192 filters: no room for the head filters, no heads exit)
+    static constexpr int W_STEP = CT * 64, W_PART = (9 * KK + W_PAD_STEPS) * W_STEP, W_RING = CH == 128 ? 4 : 3;
+    static_assert(CT == 2 * CTW && KK % W_RING == 0 && KK % 2 == 0 && LDS_BYTES <= 160 * 1024, "two waves of CTW channel tiles per board");
+    // byte offset of K-step kk relative to a tap's row offset (the lane's kb ^ row bits folded in)
+    static __device__ __forceinline__ int kstep(int pre, int kk) { return POW2 ? pre ^ (kk << 5) : (pre ^ ((kk & 3) << 5)) + ((kk >> 2) << 7); }
+    // 16-byte chunk `chunk` of pixel row `key` of board `bd` (inside a part): the swizzle key is the board-relative row
+    static __device__ __forceinline__ int choff(int bd, int key, int chunk)
+    {
+        return (bd * 90 + key) * RB + ((chunk & ~SWZ) << 4) + (((chunk ^ key) & SWZ) << 4);
+    }
+};
+
+template <typename E, int CH>
 __device__ __forceinline__ void pairs_kloop_ctw(const unsigned char* lds, int row_base, const uint4* wq, int lane, f32x16* acc)
 {
-    using namespace tp4;
+    typedef Tp4<CH> G;
+    constexpr int RB = G::RB, NT = G::NT, CTW = G::CTW, KK = G::KK, ROW_Z = G::ROW_Z, PSTR = G::PSTR, W_STEP = G::W_STEP,
+                  W_PART = G::W_PART, W_RING = G::W_RING;
     typedef typename Mfma<E>::V8 V8;
     const int kb = lane >> 5, ln = lane & 31;
     int pre[NT], pre_n[NT];
@@ -906,7 +931,7 @@ __device__ __forceinline__ void pairs_kloop_ctw(const unsigned char* lds, int ro
         const bool ok = (unsigned)(qy[t] + dy) < 10u && (unsigned)(qx[t] + dx) < 9u;
         const int nominal = t * 32 + ln + dy * 9 + dx;
         const int row = ok ? row_base + nominal : ROW_Z + (nominal & 15);
-        return row * RB + (((kb ^ nominal) & 15) << 4);       // swizzle key = the board-relative row
+        return row * RB + (((kb ^ nominal) & G::SWZ) << 4);   // swizzle key = the board-relative row
     };
     V8 wf[W_RING][CTW][2];
     V8 px[2][NT][2];
@@ -948,7 +973,7 @@ __device__ __forceinline__ void pairs_kloop_ctw(const unsigned char* lds, int ro
                 for (int i = 0; i < NM; ++i) {
                     const int pass = i / (NT * CTW), p = (i % (NT * CTW)) / CTW, c = i % CTW;
                     acc[c * NT + p] = Mfma<E>::mma(wf[kk % W_RING][c][pass == 1 ? 1 : 0], px[kk & 1][p][pass == 2 ? 1 : 0], acc[c * NT + p]);
-                    if (i < NL) px[(kk + 1) & 1][i % NT][i / NT] = load_px(rows[i % NT] ^ (kn << 5), i / NT);
+                    if (i < NL) px[(kk + 1) & 1][i % NT][i / NT] = load_px(G::kstep(rows[i % NT], kn), i / NT);
                     if (i == NM - 1 - NW && kk < NT) pre_n[kk] = tap_row(ndy, ndx, kk);
                     if (i >= NM - NW) {
                         const int idx = i - (NM - NW);
@@ -963,13 +988,15 @@ __device__ __forceinline__ void pairs_kloop_ctw(const unsigned char* lds, int ro
     }
 }
 
-template <typename E>
+template <typename E, int CH>
 __global__ __launch_bounds__(256, 1) void k_tower_pairs4(
-    const E* __restrict__ xh, const E* __restrict__ xl, tw::Chain ch, E* __restrict__ yh, E* __restrict__ yl, int n_boards,
-    const int32_t* __restrict__ n_dev, HeadArgs hd, int heads)
+    const E* __restrict__ xh, const E* __restrict__ xl, tw4::Chain ch, E* __restrict__ yh, E* __restrict__ yl, int n_boards,
+    const int32_t* __restrict__ n_dev, HeadArgs hd, int heads, float* __restrict__ yf_last)
 {
-    using namespace tp4;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    typedef Tp4<CH> G;
+    constexpr int C = G::C, RB = G::RB, CPR = G::CPR, NT = G::NT, CTW = G::CTW, NTHR = G::NTHR, ROW_Z = G::ROW_Z, PSTR = G::PSTR,
+                  BIAS_OFF = G::BIAS_OFF, HW_OFF = G::HW_OFF;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES];
     const int NB = ch.n;
     if (n_dev) {
         const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
@@ -982,7 +1009,7 @@ __global__ __launch_bounds__(256, 1) void k_tower_pairs4(
     const int stride = gridDim.x;
     typedef c8k::u32x4 u4;
     constexpr int CHUNKS = 180 * CPR, LITER = (CHUNKS + NTHR - 1) / NTHR;
-    auto choff = [&](int bd, int key, int chunk) { return (bd * 90 + key) * RB + ((chunk ^ (key & 15)) << 4); };
+    auto choff = [&](int bd, int key, int chunk) { return G::choff(bd, key, chunk); };
     auto chunk_off = [&](int i) {
         const int row = i / CPR, c = i - row * CPR;
         return choff(row >= 90 ? 1 : 0, row >= 90 ? row - 90 : row, c);
@@ -1028,6 +1055,7 @@ __global__ __launch_bounds__(256, 1) void k_tower_pairs4(
             dst[tid] = ch.b1[blk][tid];
             dst[C + tid] = ch.b2[blk][tid];
         }
+        static_assert(C <= NTHR, "one thread per channel");
     };
     for (int i = tid; i < 16 * CPR; i += NTHR) {                // the shared zero rows, both parts
         *reinterpret_cast<u4*>(lds + ROW_Z * RB + i * 16) = u4{0u, 0u, 0u, 0u};
@@ -1036,7 +1064,7 @@ __global__ __launch_bounds__(256, 1) void k_tower_pairs4(
     fill(t);
     write_bias(0);
     write_bias(1);
-    if (heads)
+    if (C == 128 && heads)
         for (int i = tid; i < 6 * C; i += NTHR) reinterpret_cast<float*>(lds + HW_OFF)[i] = hd.w[i];
 
     const int kb = lane >> 5, ln = lane & 31;
@@ -1052,7 +1080,7 @@ __global__ __launch_bounds__(256, 1) void k_tower_pairs4(
             f32x16 acc[CTW * NT];
             c8k::u32x2 skh[CTW * NT][4], skl[CTW * NT][4];      // the skip operand's (hi, lo) quads, packed
             __builtin_amdgcn_s_setprio(3);
-            pairs_kloop_ctw<E>(lds, bd * 90, wq1, lane, acc);
+            pairs_kloop_ctw<E, CH>(lds, bd * 90, wq1, lane, acc);
             __builtin_amdgcn_s_setprio(0);
             __syncthreads();                                    // K1: both waves of a board have read its image
             int ln2 = ln, kb2 = kb;
@@ -1087,7 +1115,7 @@ __global__ __launch_bounds__(256, 1) void k_tower_pairs4(
             }
             __syncthreads();                                    // B: the images hold the intermediate activation; block g's b1 is consumed
             __builtin_amdgcn_s_setprio(3);
-            pairs_kloop_ctw<E>(lds, bd * 90, wq2, lane, acc);
+            pairs_kloop_ctw<E, CH>(lds, bd * 90, wq2, lane, acc);
             __builtin_amdgcn_s_setprio(0);
             __syncthreads();                                    // K2
             asm volatile("" : "+v"(ln2), "+v"(kb2));
@@ -1114,6 +1142,12 @@ __global__ __launch_bounds__(256, 1) void k_tower_pairs4(
                             hi.e[i] = (E)v[i];
                             lo.e[i] = (E)(v[i] - (float)hi.e[i]);
                         }
+                        if (yf_last && blk == NB - 1) {          // the tower's last block: its fp32 value for the head convolutions
+                            const int board = 2 * t + bd;
+                            if (board < n_boards)
+                                *reinterpret_cast<float4*>(yf_last + ((size_t)board * 90 + q) * C + chn) = make_float4(v[0], v[1], v[2], v[3]);
+                            continue;
+                        }
                         *reinterpret_cast<Quad<E>*>(lds + off) = hi;
                         *reinterpret_cast<Quad<E>*>(lds + PSTR + off) = lo;
                     }
@@ -1122,7 +1156,7 @@ __global__ __launch_bounds__(256, 1) void k_tower_pairs4(
             __syncthreads();                                    // C: the block's result is in the images; its b2 is consumed
             if (NB > 1) write_bias(g + 2);                      // (into the buffer block g has just released)
         }
-        if (heads) {
+        if (C == 128 && heads) {
             // the head features of board 2 t + bd by its two waves, from hi + lo of the result (k_tower_pairs' heads_exit)
             const int board = 2 * t + bd;
             const float* hwl = reinterpret_cast<const float*>(lds + HW_OFF);
@@ -1162,7 +1196,7 @@ __global__ __launch_bounds__(256, 1) void k_tower_pairs4(
                         else hd.val[(size_t)board * ((6 - hd.n_pol) * 90) + (o - hd.n_pol) * 90 + qq] = hv;
                     }
             }
-        } else {
+        } else if (!yf_last) {
             drain(t);
         }
         t += stride;
@@ -1170,6 +1204,28 @@ __global__ __launch_bounds__(256, 1) void k_tower_pairs4(
         __syncthreads();                                        // (the exit has read the images)
         fill(t);
     }
+}
+
+// the pair chains' launches (cz_tower_pairs: 128 filters; cz_resblock_chain in csrc/xq_conv.hip: 192 filters, no heads exit)
+extern "C" int czi_pairs4_launch(const void* x_hi, const void* x_lo, int n_blocks, const void* const* w1, const float* const* b1,
+                                 const void* const* w2, const float* const* b2, void* y_hi, void* y_lo, const float* head_w,
+                                 const float* head_b, float* pol, float* val, int n_pol, int n_boards, int channels, int dtype,
+                                 int n_cu, const int32_t* n_dev, void* stream, float* y_f32)
+{
+    if (n_blocks > tw4::MAX_BLOCKS || (channels != 128 && channels != 192) || (head_w && channels != 128)) return CZ_ERR_ARG;
+    tw4::Chain ch{};
+    ch.n = n_blocks;
+    for (int b = 0; b < n_blocks; ++b) { ch.w1[b] = w1[b]; ch.w2[b] = w2[b]; ch.b1[b] = b1[b]; ch.b2[b] = b2[b]; }
+    const HeadArgs hd = head_w ? HeadArgs{head_w, head_b, pol, val, n_pol} : HeadArgs{};
+    const int n_pairs = (n_boards + 1) / 2;
+    const unsigned blocks = (unsigned)(n_pairs < n_cu ? n_pairs : n_cu);
+    hipStream_t st = (hipStream_t)stream;
+#define CZ_P4(E, CH) hipLaunchKernelGGL((k_tower_pairs4<E, CH>), dim3(blocks), dim3(256), 0, st, (const E*)x_hi, (const E*)x_lo, ch, \
+                                        (E*)y_hi, (E*)y_lo, n_boards, n_dev, hd, head_w ? 1 : 0, y_f32)
+    if (channels == 128) { if (dtype == CZ_F16) CZ_P4(_Float16, 128); else CZ_P4(__bf16, 128); }
+    else { if (dtype == CZ_F16) CZ_P4(_Float16, 192); else CZ_P4(__bf16, 192); }
+#undef CZ_P4
+    return hipGetLastError() == hipSuccess ? CZ_OK : CZ_ERR_HIP;
 }
 
 extern "C" int cz_tower(const void* x_hi, const void* x_img, int n_blocks, const void* const* w1_packed,
@@ -1308,19 +1364,10 @@ extern "C" int cz_tower_pairs(const void* x_hi, const void* x_lo, int n_blocks, 
     hipStream_t st = (hipStream_t)stream;
     const char* t4 = getenv("CZ_TOWER4");                       // (round 6) the chain on four matrix waves; CZ_TOWER4=0: k_tower_pairs
     if (!(t4 && t4[0] == '0')) {
-        const int n_pairs = (n_boards + 1) / 2;
-        const unsigned blocks4 = (unsigned)(n_pairs < n_cu ? n_pairs : n_cu);
-        if (dtype == CZ_F16)
-            hipLaunchKernelGGL((k_tower_pairs4<_Float16>), dim3(blocks4), dim3(256), 0, st, (const _Float16*)x_hi, (const _Float16*)x_lo, ch,
-                               (_Float16*)y_hi, (_Float16*)y_lo, n_boards, n_dev, hd, heads ? 1 : 0);
-        else
-            hipLaunchKernelGGL((k_tower_pairs4<__bf16>), dim3(blocks4), dim3(256), 0, st, (const __bf16*)x_hi, (const __bf16*)x_lo, ch,
-                               (__bf16*)y_hi, (__bf16*)y_lo, n_boards, n_dev, hd, heads ? 1 : 0);
-        if (hipGetLastError() != hipSuccess) {
-            czi_set_error("cz_tower_pairs: launch failed");
-            return CZ_ERR_HIP;
-        }
-        return CZ_OK;
+        const int rc = czi_pairs4_launch(x_hi, x_lo, n_blocks, w1_packed, bias1, w2_packed, bias2, y_hi, y_lo, head_w, head_b,
+                                         policy_feat, value_feat, n_policy, n_boards, 128, dtype, n_cu, n_dev, stream, nullptr);
+        if (rc != CZ_OK) czi_set_error("cz_tower_pairs: launch failed");
+        return rc;
     }
 #define CZ_PAIRS_LAUNCH(E, H) hipLaunchKernelGGL((k_tower_pairs<E, H>), dim3(blocks), dim3(512), 0, st, (const E*)x_hi, \
         (const E*)x_lo, ch, (E*)y_hi, (E*)y_lo, n_boards, n_dev, hd)

@@ -159,7 +159,8 @@ def test_bf16_pairs_keep_their_heads_launch():
     assert torch.equal(p0, p) and torch.equal(v0, v)
 
 
-@pytest.mark.parametrize("arith,blocks", [("c8", 10), ("c6", 10), ("c6>3", 10), ("c8>6", 10), ("c6", 2), ("c8", 2), ("c6>1", 4), ("c8>2", 4)])
+@pytest.mark.parametrize("arith,blocks", [("c8", 10), ("c6", 10), ("c6>3", 10), ("c8>6", 10), ("c6", 2), ("c8", 2), ("c6>1", 4), ("c8>2", 4),
+                                          ("f16x3", 10), ("bf16x3", 4), ("f16x3", 3), ("c8>2", 10)])
 def test_192_filter_tower_chains_are_bit_identical(arith, blocks, monkeypatch):
     """cz_resblock_chain (the reference's deployed width, configs/distribute.py:84-87): consecutive 192-filter blocks of one
     arithmetic in one launch -- a PAIR of boards per workgroup, one LDS image per board, four matrix waves of three channel tiles

@@ -639,8 +639,12 @@ def test_tower_plan_and_block_events():
     assert ip_segments([c6] * 10) == [("block", [0]), ("chain", list(range(1, 10)))]
     assert ip_segments([c8] * 10) == [("chain", list(range(10)))]
     assert ip_segments([c6] * 3 + [c8] * 7) == [("block", [0]), ("chain", [1, 2]), ("chain", list(range(3, 10)))]
-    assert ip_segments([c8] * 2 + [pr] * 2) == [("chain", [0, 1]), ("block", [2]), ("block", [3])]
+    assert ip_segments([c8] * 2 + [pr] * 2) == [("chain", [0, 1]), ("chain", [2, 3])]     # (round 6: pair blocks chain too)
     assert ip_segments([c8] * 14)[0] == ("chain", list(range(12)))        # at most 12 blocks per launch
+    # pair blocks chain too (round 6: k_tower_pairs4<E, 192>; a chain that ends the tower writes fp32)
+    assert ip_segments(["pair"] * 4) == [("chain", [0, 1, 2, 3])]
+    assert ip_segments(["c8"] * 2 + ["pair"] * 3) == [("chain", [0, 1]), ("chain", [2, 3, 4])]
+    assert ip_segments(["c8"] * 9 + ["pair"]) == [("chain", list(range(9))), ("chain", [9])]
 
     class Ev:
         def __init__(self, t): self.t = t
