@@ -236,6 +236,9 @@ XQ_D ChunkMap make_chunk_map()
     return m;
 }
 
+#ifndef CZ_TPB_NT            // build switch: the planes of the one-board-per-lane kernel leave with nontemporal stores
+#define CZ_TPB_NT 0
+#endif
 template <int DT>
 XQ_D void tpb_write_planes(const int8_t* codes, void* __restrict__ out, const ChunkMap& cm)
 {
@@ -252,7 +255,10 @@ XQ_D void tpb_write_planes(const int8_t* codes, void* __restrict__ out, const Ch
             if (++pos == 90) { pos = 0; ++c; }
         }
         if (DT == 0) {
-            reinterpret_cast<float4*>(out)[q] = make_float4((float)bit[0], (float)bit[1], (float)bit[2], (float)bit[3]);
+            typedef __attribute__((ext_vector_type(4))) float f4;
+            const f4 v = {(float)bit[0], (float)bit[1], (float)bit[2], (float)bit[3]};
+            if (CZ_TPB_NT) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out) + q);     // (written once, read by another kernel much later)
+            else reinterpret_cast<f4*>(out)[q] = v;
         } else if (DT == 1 || DT == 2) {
             const uint32_t one = (DT == 1) ? 0x3C00u : 0x3F80u;
             uint2 v;
