@@ -3076,6 +3076,11 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_input_conv(
     // 94 M sixteen-byte write requests per launch are a request-rate limit, not a bandwidth one.
     typedef Geom<C, 1, PARTS> GS;                   // staging geometry: [90 pixels][C] per part, chunks swizzled by row
     constexpr int SROWB = C * 2, SPART = 90 * SROWB;
+    f32x4 bq[4];                                    // this wave's biases, fetched once (not once per 8-byte store: see k_resblock)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(bias + wave * 32 + g * 8 + kb * 4);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bq[g]));
 #pragma unroll
     for (int bb = 0; bb < P; ++bb) {
         if (bb > 0) __syncthreads();                // the previous board has left the staging image
@@ -3087,9 +3092,9 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void k_input_conv(
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ch = wave * 32 + g * 8 + kb * 4;
-                const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
-                float v[4] = {acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
-                              acc[p][g * 4 + 3] + bv.w};
+                const f32x4 bv = bq[g];
+                float v[4] = {acc[p][g * 4 + 0] + bv[0], acc[p][g * 4 + 1] + bv[1], acc[p][g * 4 + 2] + bv[2],
+                              acc[p][g * 4 + 3] + bv[3]};
                 const int off = q * SROWB + (((ch >> 3) ^ (q & GS::SWZ)) << 4) + (ch & 7) * 2;
                 if constexpr (C8) {                 // the operand pair of the c8 arithmetic (k_conv3x3_c8): f16 row, then the c8 row
                     static_assert(!C8 || (PARTS == 2 && sizeof(E) == 2), "c8 output: fp16 operand pairs");
