@@ -277,6 +277,31 @@ __global__ __launch_bounds__(C / 32 * 64, MINW) void k_conv3x3(
 
     // ---- epilogue: lane holds, for pixel (tile p, column ln), channels 32*wave + 8*g + 4*kb + {0..3}, g = 0..3 ----
     const int kb = lane >> 5, ln = lane & 31;
+    // everything the epilogue reads from memory is requested up front (round 6: with a load next to every store the compiler
+    // waited for each -- 4 NT bias + skip round trips in a row; a one-board batch, the `mini` configuration, felt every one)
+    f32x4 bq[4];
+    c8k::u32x2 skh[NT][4], skl[NT][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(bias + wave * 32 + g * 8 + kb * 4);
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+        const int q = (p % 3) * 32 + ln;
+        const int n = n0 + p / 3;
+        const bool live = q < 90 && n < n_boards;
+        const size_t pix = ((size_t)(live ? n : 0) * 90 + (live ? q : 0)) * C;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = wave * 32 + g * 8 + kb * 4;
+            skh[p][g] = c8k::u32x2{0u, 0u};
+            skl[p][g] = c8k::u32x2{0u, 0u};
+            if (sh && live) {
+                skh[p][g] = *reinterpret_cast<const c8k::u32x2*>(sh + pix + ch);
+                if (PARTS == 2) skl[p][g] = *reinterpret_cast<const c8k::u32x2*>(sl + pix + ch);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bq[g]));
 #pragma unroll
     for (int p = 0; p < NT; ++p) {
         const int q = (p % 3) * 32 + ln;
@@ -286,15 +311,15 @@ __global__ __launch_bounds__(C / 32 * 64, MINW) void k_conv3x3(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int ch = wave * 32 + g * 8 + kb * 4;
-            const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
-            float v[4] = {acc[p][g * 4 + 0] + bv.x, acc[p][g * 4 + 1] + bv.y, acc[p][g * 4 + 2] + bv.z,
-                          acc[p][g * 4 + 3] + bv.w};
+            const f32x4 bv = bq[g];
+            float v[4] = {acc[p][g * 4 + 0] + bv[0], acc[p][g * 4 + 1] + bv[1], acc[p][g * 4 + 2] + bv[2],
+                          acc[p][g * 4 + 3] + bv[3]};
             if (sh) {
-                const Quad<E> a = *reinterpret_cast<const Quad<E>*>(sh + pix + ch);
+                const Quad<E> a = __builtin_bit_cast(Quad<E>, skh[p][g]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] += (float)a.e[i];
                 if (PARTS == 2) {
-                    const Quad<E> b2 = *reinterpret_cast<const Quad<E>*>(sl + pix + ch);
+                    const Quad<E> b2 = __builtin_bit_cast(Quad<E>, skl[p][g]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] += (float)b2.e[i];
                 }
