@@ -223,6 +223,8 @@ XQ_D void board_to_plane_codes(int8_t* b)
 // which (channel, position) each of this lane's five 4-element chunks starts at: the same for every board
 struct ChunkMap {
     uint16_t cpos[5];       // channel << 8 | position
+    uint32_t tgt[5];        // the channel each of the chunk's four elements is compared with, one per byte (a chunk that runs past
+                            // square 89 continues on square 0 of the next channel: the codes row repeats squares 0 .. 3 behind 89)
 };
 XQ_D ChunkMap make_chunk_map()
 {
@@ -230,8 +232,12 @@ XQ_D ChunkMap make_chunk_map()
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
         const int o = (lane_id() + 64 * it) * 4;
-        const int c = o / 90;
-        m.cpos[it] = (uint16_t)((c << 8) | (o - c * 90));
+        const int c = o / 90, pos = o - c * 90;
+        m.cpos[it] = (uint16_t)((c << 8) | pos);
+        uint32_t t = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t |= (uint32_t)(pos + e < 90 ? c : c + 1) << (8 * e);
+        m.tgt[it] = t;
     }
     return m;
 }
@@ -247,13 +253,15 @@ XQ_D void tpb_write_planes(const int8_t* codes, void* __restrict__ out, const Ch
     for (int it = 0; it < 5; ++it) {
         const int q = lane + 64 * it;
         if (q >= 315) break;
-        int c = cm.cpos[it] >> 8, pos = cm.cpos[it] & 0xFF;
+        // the chunk's four codes with two aligned dword reads (round 6; four byte reads, a compare and the wrap test per element
+        // before: this loop was half of the kernel's issue slots), compared with their channels bytewise
+        const int pos = cm.cpos[it] & 0xFF;
+        const uint32_t lo = *reinterpret_cast<const uint32_t*>(codes + (pos & ~3));
+        const uint32_t hi = *reinterpret_cast<const uint32_t*>(codes + (pos & ~3) + 4);
+        const uint32_t x = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(pos & 3)) ^ cm.tgt[it];
         int bit[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            bit[e] = codes[pos] == c;
-            if (++pos == 90) { pos = 0; ++c; }
-        }
+        for (int e = 0; e < 4; ++e) bit[e] = ((x >> (8 * e)) & 0xFFu) == 0u;
         if (DT == 0) {
             typedef __attribute__((ext_vector_type(4))) float f4;
             const f4 v = {(float)bit[0], (float)bit[1], (float)bit[2], (float)bit[3]};
@@ -376,7 +384,11 @@ __global__ __launch_bounds__(64) void k_rules_tpb(const int8_t* __restrict__ boa
             if (counts) counts[i] = (uint8_t)(r.n < 255 ? r.n : 255);
             if (over) { over[i] = (int8_t)r.over; v[i] = (int8_t)r.v; final_move[i] = (uint16_t)r.final_move; }
             if (check) check[i] = (uint8_t)r.check;
-            if (planes && !CZ_TPB_SCATTER) board_to_plane_codes(b);
+            if (planes && !CZ_TPB_SCATTER) {
+                board_to_plane_codes(b);
+                *reinterpret_cast<uint32_t*>(b + 92) = 0xFFFFFFFFu;      // (bytes 94, 95 are read, never matched)
+                b[90] = b[0]; b[91] = b[1]; b[92] = b[2]; b[93] = b[3];   // squares 0 .. 3 again behind square 89 (tpb_write_planes)
+            }
         }
         if (CZ_TPB_SCATTER && planes) {
             // (ZERO_LATE: the zeros go out right before the ones, so that the ones still find their lines in the L2 -- zeroed
