@@ -534,16 +534,18 @@ def tower(x, blocks, exit_fmt, out=None, heads=None, count=None, fmt_x=None, fmt
     return out if exit_fmt != EXIT_HEADS else (pf, vf)
 
 
-def resblock_chain(x, blocks, out=None, out_f32=None, count=None):
+def resblock_chain(x, blocks, out=None, out_f32=None, count=None, dtype_code=None):
     """cz_resblock_chain: consecutive 192-filter blocks (a BlockList or [(w1_packed, bias1, w2_packed, bias2), ...], 1 .. 8) of one
     staged arithmetic in one launch; x: the c8 (uint8 image) or c6 (int8 image) operand pair; out: the same kind of pair, or
-    out_f32 [N, 90, 192] for the last block.  Bit-identical to len(blocks) resblock() calls."""
+    out_f32 [N, 90, 192] for the last block.  dtype_code=F16C86: a c6 chain that starts the tower (x = the input layer's c8 image,
+    block 0's first filter c8-packed).  Bit-identical to len(blocks) resblock() calls."""
     require_gpu()
     bl = _block_list(blocks)
     a = bl.arrays
     check(lib().cz_resblock_chain(_ptr(x[0]), _ptr(x[1]), bl.n, a[0], a[1], a[2], a[3],
                                   _ptr(out[0]) if out is not None else None, _ptr(out[1]) if out is not None else None,
-                                  _ptr(out_f32), x[0].shape[0], x[0].shape[-1], _pair_code(x), _ptr(count), _stream()),
+                                  _ptr(out_f32), x[0].shape[0], x[0].shape[-1], _pair_code(x) if dtype_code is None else dtype_code,
+                                  _ptr(count), _stream()),
           "cz_resblock_chain")
     return out_f32 if out_f32 is not None else out
 

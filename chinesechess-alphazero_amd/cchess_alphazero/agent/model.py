@@ -140,15 +140,16 @@ def tower_plan(kinds, heads_exit=True, chain_heads=True, max_chain=8):
     return steps
 
 
-def ip_segments(kinds, max_chain=12):
+def ip_segments(kinds, max_chain=12, first_alone=False):
     """The launches of a 192-filter tower's blocks (round 6): ("chain", [blocks]) = one cz_resblock_chain launch of consecutive
     blocks of one arithmetic (c8 / c6 images: k_resblock_ip4_c8; (hi, lo) pairs: k_tower_pairs4), ("block", [i]) = a block on its
-    own launch -- a c6 tower's block 0 (it reads the input layer's c8 image: its own kernel variant).  A chain that ends the
-    tower writes fp32 (the head convolutions' input)."""
+    own launch -- with first_alone (the six-wave kernels, CZ_IP_PAIR=0) a c6 tower's block 0, which reads the input layer's c8
+    image (the four-wave kernel takes it as the first block of its chain: dtype CZ_F16C86).  A chain that ends the tower writes
+    fp32 (the head convolutions' input)."""
     segs, i, n = [], 0, len(kinds)
     while i < n:
         k = kinds[i]
-        if k == "c6" and i == 0:
+        if k == "c6" and i == 0 and first_alone:
             segs.append(("block", [i]))
             i += 1
             continue
@@ -610,9 +611,11 @@ class InferenceNet(nn.Module):
         from cchess_alphazero import _native
         kinds = self.block_kinds()
         nblk = len(kinds)
-        key = ("plan192", self.tb0a.data_ptr())
+        legacy = os.environ.get("CZ_IP_PAIR", "1")[:1] == "0"          # (the six-wave kernels: block 0 of a c6 tower on its own launch)
+        key = ("plan192", legacy, self.tb0a.data_ptr())
         if key not in self._bufs:
-            self._bufs[key] = [(kind, blk, _native.BlockList([self._block_params(i) for i in blk])) for kind, blk in ip_segments(kinds)]
+            self._bufs[key] = [(kind, blk, _native.BlockList([self._block_params(i) for i in blk]))
+                               for kind, blk in ip_segments(kinds, first_alone=legacy)]
         self.last_plan = [("chain192" if kind == "chain" else "block192", blk, kinds[blk[0]]) for kind, blk, _ in self._bufs[key]]
         tag = {"c6": torch.int8, "c8": torch.uint8}
         for kind, blk, bl in self._bufs[key]:
@@ -642,13 +645,18 @@ class InferenceNet(nn.Module):
                                  count=count, dtype_code=_native.F16C86)
                 cur, nxt = nxt, cur
             else:
-                x = (cur[0], cur[1].view(tag[k]))
+                # (a c6 chain that starts the tower reads the input layer's c8 image: CZ_F16C86)
+                first6 = k == "c6" and blk[0] == 0
+                x = (cur[0], cur[1].view(torch.uint8 if first6 else tag[k]))
+                code = _native.F16C86 if first6 else None
+                # (a c6 chain whose last block hands over to c8 blocks writes a c8 image)
+                out_tag = tag[kinds[i1 + 1]] if (k == "c6" and not tower_end and kinds[i1 + 1] == "c8") else tag[k]
                 if tower_end or to_pairs:
-                    _native.resblock_chain(x, bl, out_f32=last, count=count)
+                    _native.resblock_chain(x, bl, out_f32=last, count=count, dtype_code=code)
                     if to_pairs:                    # the hand-over of a c8>N tower: re-split into (hi, lo) fp16 pairs
                         _native.split_bias_act(last, None, self._as_f16_pair(cur), relu=False)
                 else:
-                    _native.resblock_chain(x, bl, out=(nxt[0], nxt[1].view(tag[k])), count=count)
+                    _native.resblock_chain(x, bl, out=(nxt[0], nxt[1].view(out_tag)), count=count, dtype_code=code)
                     cur, nxt = nxt, cur
             if ev is not None:
                 ev[1].record()

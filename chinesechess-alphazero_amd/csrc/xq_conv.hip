@@ -2553,7 +2553,8 @@ constexpr int IP4_EXIT_PAIRS = 2, IP4_EXIT_HEADS = 3;
 #ifndef CZ_IP4_PROBE        // timing experiments (wrong results; 0 in the product): bit 0 = no epilogue 1, bit 1 = no epilogue 2
 #define CZ_IP4_PROBE 0
 #endif
-template <int C, int XF, int YF>
+// MIX (with <1, 1>): the chain starts the tower -- its block 0 reads the input layer's c8 image (first filter c8-packed: CZ_F16C86)
+template <int C, int XF, int YF, bool MIX = false>
 __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
     const _Float16* __restrict__ xh, const unsigned char* __restrict__ xc, ip::Chain ch, _Float16* __restrict__ yh,
     unsigned char* __restrict__ yc, float* __restrict__ yf_last, int n_boards, const int32_t* __restrict__ n_dev,
@@ -2715,7 +2716,9 @@ __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
             const float* bias2 = bias1 + C;
             const int* ints1 = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(w1p) + c8k::Geo<C>::MAIN_U4 + c8k::Geo<C>::C8_U4);
             const int* ints2 = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(w2p) + c8k::Geo<C>::MAIN_U4 + c8k::Geo<C>::C8_U4);
-            const int k_x = XF ? __builtin_amdgcn_readfirstlane(ints1[2]) : 0;
+            static_assert(!MIX || (XF == 1 && YF == 1), "a c6 chain whose first block reads a c8 image");
+            const bool xf = MIX ? blk != 0 : XF != 0;           // the format of the image this block's first convolution reads
+            const int k_x = xf ? __builtin_amdgcn_readfirstlane(ints1[2]) : 0;
             const int k_y = YF ? __builtin_amdgcn_readfirstlane(ints2[2]) : 0;
             const int k_out = YF ? __builtin_amdgcn_readfirstlane(ints2[3]) : CZ_C6_OUT_C8;
             float* yf = blk == NB - 1 ? yf_last : nullptr;      // fp32 output: the chain's last block only
@@ -2733,7 +2736,8 @@ __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
                 }
             const c8k::Image img{bd * 90, ip::ROW_Z, PSTR};
             __builtin_amdgcn_s_setprio(3);
-            c8k::kloop_ctw<CTW, NT, C, XF>(lds, img, flt1, lane, acc, 127 + k_x - cf8::X_LO_SHIFT, 127 + k_x);
+            if (MIX && !xf) c8k::kloop_ctw<CTW, NT, C, 0>(lds, img, flt1, lane, acc, 127 - cf8::X_LO_SHIFT, 127);
+            else c8k::kloop_ctw<CTW, NT, C, XF>(lds, img, flt1, lane, acc, 127 + k_x - cf8::X_LO_SHIFT, 127 + k_x);
             __builtin_amdgcn_s_setprio(0);
             __syncthreads();                                    // K1: both waves of a board have read its image
             int ln2 = ln, kb2 = kb;
@@ -2755,7 +2759,7 @@ __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
                             const int q = tt * 32 + ln2;
                             const int key = q < 90 ? q : 89;
                             rb8::f32x32 xl;
-                            if (XF) {                           // this lane's elements of the x_lo piece of the channel tile
+                            if (xf) {                           // this lane's elements of the x_lo piece of the channel tile
                                 const int c0 = 4 * (tc >> 1) + 2 * (tc & 1);
                                 const u4 hd4 = *reinterpret_cast<const u4*>(lds + PSTR + choff(bd, key, c0));
                                 const c8k::u32x2 tl2 = *reinterpret_cast<const c8k::u32x2*>(lds + PSTR + choff(bd, key, c0 + 1));
@@ -2771,7 +2775,7 @@ __global__ __launch_bounds__(256, 1) void k_resblock_ip4_c8(
                                 const int chn = tc * 32 + gg * 8 + kb2 * 4;
                                 const float4 bv = *reinterpret_cast<const float4*>(bias2 + chn);
                                 float vv[4] = {bv.x, bv.y, bv.z, bv.w};
-                                if (XF) {
+                                if (xf) {
                                     const Quad<_Float16> xq = *reinterpret_cast<const Quad<_Float16>*>(lds + choff(bd, key, chn >> 3) + (chn & 7) * 2);
 #pragma unroll
                                     for (int i = 0; i < 4; ++i) vv[i] += (float)xq.e[i] + xl[2 * (gg * 4 + i)];
@@ -3833,9 +3837,9 @@ extern "C" int cz_resblock_chain(const void* x_hi, const void* x_img, int n_bloc
 {
     const bool pairs = dtype == CZ_F16 || dtype == CZ_BF16;     // (hi, lo) pair blocks: x_img / y_img are the lo tensors
     if (n_boards < 0 || !x_hi || !x_img || !w1_packed || !w2_packed || !bias1 || !bias2 || n_blocks < 1 ||
-        n_blocks > ip::MAX_BLOCKS || channels != 192 || (dtype != CZ_F16C8 && dtype != CZ_F16C6 && !pairs) ||
+        n_blocks > ip::MAX_BLOCKS || channels != 192 || (dtype != CZ_F16C8 && dtype != CZ_F16C6 && dtype != CZ_F16C86 && !pairs) ||
         (!y_f32 && (!y_hi || !y_img))) {
-        czi_set_error("cz_resblock_chain: bad argument (192 filters, 1 .. 12 blocks, dtype CZ_F16C8 / CZ_F16C6 with y_f32 or y_hi + y_img, "
+        czi_set_error("cz_resblock_chain: bad argument (192 filters, 1 .. 12 blocks, dtype CZ_F16C8 / CZ_F16C6 / CZ_F16C86 with y_f32 or y_hi + y_img, "
                       "or CZ_F16 / CZ_BF16 pair blocks with y_f32 or y_hi + y_lo)");
         return CZ_ERR_ARG;
     }
@@ -3875,10 +3879,16 @@ extern "C" int cz_resblock_chain(const void* x_hi, const void* x_img, int n_bloc
     // a pair of boards per workgroup on four matrix waves of three channel tiles (k_resblock_ip4_c8);
     // CZ_IP_PAIR=0: one board on six matrix waves (k_resblock_ip_c8; A/B runs, the tests run both)
     const char* pair_env = getenv("CZ_IP_PAIR");
-    if (!(pair_env && pair_env[0] == '0')) {
+    if (dtype == CZ_F16C86 && pair_env && pair_env[0] == '0') {
+        czi_set_error("cz_resblock_chain: CZ_F16C86 (a c6 chain that starts the tower) exists on the four-wave kernel only (CZ_IP_PAIR=0 is set)");
+        return CZ_ERR_ARG;
+    } else if (!(pair_env && pair_env[0] == '0')) {
         const int n_pairs = (n_boards + 1) / 2;
         const unsigned blocks = (unsigned)(n_pairs < n_cu ? n_pairs : n_cu);
-        if (dtype == CZ_F16C8)
+        if (dtype == CZ_F16C86)
+            hipLaunchKernelGGL((k_resblock_ip4_c8<192, 1, 1, true>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi,
+                               (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev, 0, HeadArgs{});
+        else if (dtype == CZ_F16C8)
             hipLaunchKernelGGL((k_resblock_ip4_c8<192, 0, 0>), dim3(blocks), dim3(256), 0, st, (const _Float16*)x_hi,
                                (const unsigned char*)x_img, ch, (_Float16*)y_hi, (unsigned char*)y_img, y_f32, n_boards, n_dev, 0, HeadArgs{});
         else

@@ -412,7 +412,9 @@ int cz_tower_pairs(const void* x_hi, const void* x_lo, int n_blocks, const void*
  * through all blocks, one LDS image per board (both epilogues in place), on four matrix waves of three channel tiles each -- six
  * channel tiles spread evenly over the CU's four SIMDs (k_resblock_ip4_c8; environment CZ_IP_PAIR=0: one board in two images on
  * six matrix waves, k_resblock_ip_c8).  HBM sees a board at the entry and the exit.  Bit-identical to n_blocks calls of cz_resblock.  y_f32 != NULL: the last block writes fp32 [n][90][192]
- * instead of the operand pair (the tower's last block / the hand-over of a c8>N tower).  dtype CZ_F16 / CZ_BF16: (hi, lo) PAIR
+ * instead of the operand pair (the tower's last block / the hand-over of a c8>N tower).  dtype CZ_F16C86: a c6 chain that STARTS
+ * the tower -- its block 0 reads the input layer's c8 image (first filter c8-packed, as for cz_resblock with CZ_F16C86), the
+ * blocks behind it are c6 blocks: a 10 x 192 c6 tower is one launch.  dtype CZ_F16 / CZ_BF16: (hi, lo) PAIR
  * blocks (f16x3 / bf16x3 -- what the load-time guard gives a peaked-policy network at this width), x_img / y_img = the lo tensors
  * [n][90][192]; same shape of kernel (k_tower_pairs4<E, 192>). */
 int cz_resblock_chain(const void* x_hi, const void* x_img, int n_blocks, const void* const* w1_packed, const float* const* bias1,

@@ -636,9 +636,11 @@ def test_tower_plan_and_block_events():
 
     # 192 filters (cz_resblock_chain): one launch per arithmetic; a c6 tower's block 0 reads the input layer's c8 image on its own
     from cchess_alphazero.agent.model import ip_segments
-    assert ip_segments([c6] * 10) == [("block", [0]), ("chain", list(range(1, 10)))]
+    assert ip_segments([c6] * 10) == [("chain", list(range(10)))]               # (the four-wave kernel: block 0 inside, CZ_F16C86)
+    assert ip_segments([c6] * 10, first_alone=True) == [("block", [0]), ("chain", list(range(1, 10)))]     # (CZ_IP_PAIR=0)
     assert ip_segments([c8] * 10) == [("chain", list(range(10)))]
-    assert ip_segments([c6] * 3 + [c8] * 7) == [("block", [0]), ("chain", [1, 2]), ("chain", list(range(3, 10)))]
+    assert ip_segments([c6] * 3 + [c8] * 7) == [("chain", [0, 1, 2]), ("chain", list(range(3, 10)))]
+    assert ip_segments([c6] * 3 + [c8] * 7, first_alone=True) == [("block", [0]), ("chain", [1, 2]), ("chain", list(range(3, 10)))]
     assert ip_segments([c8] * 2 + [pr] * 2) == [("chain", [0, 1]), ("chain", [2, 3])]     # (round 6: pair blocks chain too)
     assert ip_segments([c8] * 14)[0] == ("chain", list(range(12)))        # at most 12 blocks per launch
     # pair blocks chain too (round 6: k_tower_pairs4<E, 192>; a chain that ends the tower writes fp32)
